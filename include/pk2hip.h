@@ -1,0 +1,233 @@
+/* pk2hip.h -- C ABI of libpk2hip.so, the MI355X (gfx950) implementation of the
+ * PyKaldi2 sequence-training hot path.
+ *
+ * The reference (jzlianglu/pykaldi2) has no FFI of its own: its hot path is
+ * Python calling torch.nn / PyKaldi / Horovod.  Each entry point below replaces
+ * one of those third-party calls; the reference call site is cited.  The
+ * boundary is plain C: raw device pointers, sizes, a hipStream_t passed as
+ * void*.  No torch types.  All device memory (inputs, outputs, workspaces) is
+ * allocated and owned by the caller; the library never allocates device memory
+ * on the hot path (graph handles own their static arrays, created once).
+ *
+ * Every function returns 0 on success or a negative pk2_status; the message of
+ * the last failure on the calling thread is at pk2_last_error().  Kernels are
+ * enqueued on `stream`; nothing synchronises unless stated.
+ */
+#ifndef PK2HIP_H_
+#define PK2HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  PK2_OK = 0,
+  PK2_ERR_INVALID = -1,   /* bad argument */
+  PK2_ERR_HIP = -2,       /* HIP runtime error (see pk2_last_error) */
+  PK2_ERR_LIMIT = -3,     /* size exceeds a documented kernel limit */
+  PK2_ERR_IO = -4         /* file could not be read / bad format */
+} pk2_status;
+
+const char* pk2_last_error(void);
+int pk2_version(void);               /* ABI version, currently 1 */
+
+/* ------------------------------------------------------------------ *
+ * Denominator graph.  Replaces kaldi.chain.DenominatorGraph(den_fst, P)
+ * (reference bin/train_chain.py:167,202).  Host arrays describe den.fst's
+ * arcs: prob = exp(-weight), pdf = ilabel-1.  The library computes
+ * initial_probs (100-iteration rule), builds its three arc orderings
+ * (by destination / by source / by pdf) and uploads them once.
+ * ------------------------------------------------------------------ */
+typedef struct pk2_den_graph pk2_den_graph;
+
+int pk2_den_graph_create(int32_t num_states, int32_t num_pdfs, int64_t num_arcs,
+                         const int32_t* arc_src, const int32_t* arc_dst,
+                         const int32_t* arc_pdf, const float* arc_prob,
+                         int32_t start_state, pk2_den_graph** out);
+/* Reads an OpenFst binary StdVectorFst (den.fst) -- StdVectorFst.read at
+ * reference bin/train_chain.py:167. */
+int pk2_den_graph_from_openfst(const char* path, int32_t num_pdfs, pk2_den_graph** out);
+int pk2_den_graph_destroy(pk2_den_graph* g);
+int pk2_den_graph_info(const pk2_den_graph* g, int32_t* num_states, int32_t* num_pdfs,
+                       int64_t* num_arcs);
+/* Copies initial_probs (num_states floats) to a host buffer. */
+int pk2_den_graph_initial_probs(const pk2_den_graph* g, float* host_out);
+
+/* ------------------------------------------------------------------ *
+ * LF-MMI objective and derivative for a minibatch of N sequences.
+ * Replaces kaldi.chain.compute_chain_objf_and_deriv (reference ops/ops.py:265)
+ * plus the wrapper's own grad += xent_regularize * grad_xent (ops/ops.py:267),
+ * without the host round trips of ops/ops.py:255,261,269-271.
+ *
+ * logits: device f32; sequence n, frame t, pdf p at
+ *         logits[n*seq_stride + t*frame_stride + p]   (frame_stride >= P).
+ * lengths: host int32[N], frames_per_sequence of each supervision.
+ * grad:   device f32, same addressing as logits (grad_seq_stride/frame_stride);
+ *         receives d objf / d logits for t < lengths[n] and 0 for the padding
+ *         frames lengths[n] <= t < max_frames.
+ * Numerator supervisions (Kaldi chain::Supervision FSTs: acyclic, one frame
+ * per arc, label = pdf) are concatenated over the batch, on the device:
+ *   num_arc_src/dst/pdf int32[total_arcs], num_arc_weight f32 (-log prob),
+ *   arcs of one sequence sorted by the frame of their source state;
+ *   num_frame_off int32[sum(lengths)+N]: for sequence n (base = sum_{m<n}
+ *   (lengths[m]+1)) entry base+t is the first arc (global index) leaving frame
+ *   t, entry base+lengths[n] is one past the last;
+ *   num_state_off int32[N+1] gives each sequence's state-id base (arc src/dst
+ *   are local to the sequence); state 0 is initial;
+ *   num_final_state int32[total_finals], num_final_weight f32,
+ *   num_final_off int32[N+1].
+ * out (device f32[3*N]): objf[n] = weight*(log p_num - log p_den),
+ *   num_logprob[n], den_logprob[n].  Kaldi's guard is mirrored: if a value is
+ *   not finite or the alpha-beta check fails, objf[n] = -10*weight*lengths[n]
+ *   and that sequence's gradient is zero.
+ * workspace: device, at least pk2_chain_workspace_bytes() bytes.
+ * ------------------------------------------------------------------ */
+typedef struct {
+  const int32_t* arc_src;
+  const int32_t* arc_dst;
+  const int32_t* arc_pdf;
+  const float* arc_weight;
+  const int32_t* frame_off;
+  const int32_t* state_off;     /* host pointer, int32[N+1] */
+  const int32_t* final_state;
+  const float* final_weight;
+  const int32_t* final_off;     /* host pointer, int32[N+1] */
+  int64_t total_arcs;
+} pk2_num_batch;
+
+size_t pk2_chain_workspace_bytes(const pk2_den_graph* g, int32_t num_seqs, int32_t max_frames,
+                                 int64_t num_total_states);
+
+int pk2_chain_objf_and_deriv(const pk2_den_graph* g, const float* logits, int64_t seq_stride,
+                             int64_t frame_stride, const int32_t* lengths, int32_t num_seqs,
+                             const pk2_num_batch* num, float leaky_hmm_coefficient,
+                             float xent_regularize, float l2_regularize, float weight,
+                             float* grad, int64_t grad_seq_stride, int64_t grad_frame_stride,
+                             float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Denominator only (log p_den and its occupancies); used by tests/profiling.
+ * den_logprob: device f32[N]; gamma: device, logits addressing, receives
+ * d log p_den / d logits (posteriors, rows sum to 1). */
+int pk2_chain_den_fwd_bwd(const pk2_den_graph* g, const float* logits, int64_t seq_stride,
+                          int64_t frame_stride, const int32_t* lengths, int32_t num_seqs,
+                          float leaky_hmm_coefficient, float* den_logprob, float* gamma,
+                          int64_t gamma_seq_stride, int64_t gamma_frame_stride, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 80-dim log-mel filterbank + CMN + frame subsampling.
+ * Replaces DataGeneratorTrain._logfbank_extractor (reference
+ * data/sr_dataset.py:279-296 over simulation/freq_analysis.py:113-150),
+ * preprocess.cmn(axis=0) (reader/preprocess.py:34-41, called
+ * data/sr_dataset.py:365-366) and the roll+unfold subsampling of
+ * bin/train_chain.py:251-255.
+ * ------------------------------------------------------------------ */
+/* mel: host f32[80*257], the rows of data/mel80_window.txt (un-normalised);
+ * the column normalisation of sr_dataset.py:283-286 is applied inside. */
+typedef struct pk2_fbank pk2_fbank;
+int pk2_fbank_create(const float* mel_80x257, pk2_fbank** out);
+int pk2_fbank_destroy(pk2_fbank* fb);
+/* wav: device f32, utterance n at wav[wav_off[n] .. wav_off[n+1]) (HOST int64
+ * offsets).  feats: device f32 [sum_n frames[n]][80] packed in utterance order;
+ * frames[n] = pk2_fbank_num_frames(samples).  feat_row_off: DEVICE int64
+ * [num_utts+1] prefix sums of frames[] (row of each utterance's first frame).
+ * If apply_cmn, the per-utterance mean over time is subtracted. */
+int32_t pk2_fbank_num_frames(int64_t num_samples);
+int pk2_fbank_compute(const pk2_fbank* fb, const float* wav, const int64_t* wav_off,
+                      int32_t num_utts, float* feats, const int64_t* feat_row_off,
+                      int32_t apply_cmn, void* stream);
+/* Zero-pad to max_t, roll by `shift` (<=0, wraps like torch.roll) and keep
+ * every `subsample`-th frame: x(n, j)[:] = feats_n[(j*subsample - shift) mod
+ * max_t] (zero where that index >= frames[n]).  x is [num_utts][out_t][80], or
+ * [out_t][num_utts][80] when time_major != 0 (the layout the LSTM kernels use). */
+int pk2_pad_roll_subsample(const float* feats, const int64_t* feat_row_off, int32_t num_utts,
+                           int32_t max_t, int32_t shift, int32_t subsample, float* x,
+                           int32_t out_t, int32_t time_major, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Fused log-softmax + NLL + gradient.  Replaces nn.CrossEntropyLoss
+ * (ignore_index=-100; reduction mean: reference bin/train_ce.py:134,189;
+ * reduction sum: bin/train_se.py:214,235).
+ * loss_sum, count: device f32[1] / int32[1] accumulators (zeroed inside);
+ * grad receives d(sum loss)/d logits * grad_scale (rows with ignore_index get
+ * zeros); the caller divides by count for the mean reduction.
+ * ------------------------------------------------------------------ */
+int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_t* targets,
+                           int64_t ignore_index, int64_t rows, int32_t num_classes,
+                           float* loss_sum, int32_t* count, float* grad, int64_t grad_row_stride,
+                           float* logprob_out /* optional [rows][P] or NULL */, void* stream);
+/* grad *= (*scale_num) / max(1, *count_den) on the device (mean reduction). */
+int pk2_scale_by_count(float* data, int64_t n, float numerator, const int32_t* count_den,
+                       void* stream);
+
+/* ------------------------------------------------------------------ *
+ * f32 MFMA GEMM: C[M,N] (+)= alpha * op(A) * op(B) (+ bias[N]).
+ * Replaces the cuBLAS calls under nn.Linear / nn.LSTM (reference
+ * models/lstm.py:45-59).  Row-major; lda/ldb/ldc are row strides.
+ * transa: A is stored [K,M];  transb: B is stored [N,K] (torch Linear weight).
+ * ------------------------------------------------------------------ */
+int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                 const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                 int64_t ldc, const float* bias, void* stream);
+/* out[n] (+)= sum_m A[m][n]  (bias gradients). */
+int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,
+                   void* stream);
+
+/* ------------------------------------------------------------------ *
+ * One (bi)directional LSTM layer, forward and backward through time.
+ * Replaces the cuDNN RNN under nn.LSTM (reference models/lstm.py:49-58): gate
+ * order i,f,g,o; h0 = c0 = 0; runs over all T frames of every sequence
+ * (padding included, as the reference does).
+ *
+ * All activations are TIME-MAJOR (row = t*B + b) so that "previous step" is a
+ * constant row offset and the W_hh gradient is one GEMM over shifted slices.
+ * gx:  device f32 [T][B][D*4H], input projections x W_ih^T + b_ih of
+ *      direction d at column offset d*4H (computed with pk2_gemm_f32).
+ * whh: device f32 [D][4H][H] (weight_hh_l{k}, weight_hh_l{k}_reverse).
+ * bhh: device f32 [D][4H] (bias_hh_l{k}[_reverse]) added inside, or NULL.
+ * y:   device f32 [T][B][D*H] layer output (h_t; direction d at column d*H).
+ * gates: device f32 [D][T][B][4H] post-activation i,f,g,o (saved for backward).
+ * cells: device f32 [D][T][B][H] c_t (saved for backward).
+ * H in {64,128,256,512,1024}.
+ * ------------------------------------------------------------------ */
+int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float* bhh, int32_t B, int32_t T,
+                       int32_t H, int32_t num_dirs, float* y, float* gates, float* cells,
+                       void* stream);
+/* dy: device f32 [T][B][D*H] gradient wrt y.  dgx: device f32 [T][B][D*4H]
+ * receives the gradient wrt the pre-activations (= gradient wrt gx).
+ * scratch: device f32, at least pk2_lstm_bwd_scratch_floats(B,H,D). */
+size_t pk2_lstm_bwd_scratch_floats(int32_t B, int32_t H, int32_t num_dirs);
+int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, const float* cells,
+                       int32_t B, int32_t T, int32_t H, int32_t num_dirs, float* dgx,
+                       float* scratch, void* stream);
+/* The W_hh gradient dwhh[d] = sum_t dgates[d][t]^T h[d][t-1] (t+1 for the reverse direction)
+ * is one pk2_gemm_f32 by the caller over row-shifted slices of dgx and y. */
+
+/* ------------------------------------------------------------------ *
+ * Optimiser: global-norm clip + Adam(amsgrad) / SGD(momentum) over one flat
+ * f32 parameter buffer.  Replaces clip_grad_norm_ + torch.optim.Adam / SGD
+ * (reference bin/train_ce.py:123,195; bin/train_chain.py:138,287-288;
+ * bin/train_se.py:127).
+ * ------------------------------------------------------------------ */
+/* norm_out: device f32[1] receives ||grad||_2. */
+int pk2_grad_norm(const float* grad, int64_t n, float* norm_out, void* workspace,
+                  size_t workspace_bytes, void* stream);
+size_t pk2_grad_norm_workspace_bytes(int64_t n);
+/* clip coefficient = min(1, max_norm / (*norm + 1e-6)) read on the device;
+ * max_norm <= 0 disables clipping.  step is 1-based.  grad_scale multiplies the
+ * gradient first (1/world_size for the averaged all-reduce). */
+int pk2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  float* max_exp_avg_sq /* NULL = no amsgrad */, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float max_norm,
+                  const float* norm, float grad_scale, void* stream);
+int pk2_sgd_step(float* param, const float* grad, float* momentum_buf /* NULL = none */,
+                 int64_t n, float lr, float momentum, float weight_decay, int32_t first_step,
+                 float max_norm, const float* norm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PK2HIP_H_ */

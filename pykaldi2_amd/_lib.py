@@ -1,0 +1,107 @@
+"""ctypes binding of libpk2hip.so (C ABI declared in include/pk2hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+error is raised.  torch is imported first so the library resolves
+libamdhip64.so.7 to the HIP runtime PyTorch already loaded (one runtime, one
+set of streams per process).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: loads the HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpk2hip.so")
+
+
+class Pk2Error(RuntimeError):
+    pass
+
+
+class NumBatch(C.Structure):
+    _fields_ = [("arc_src", C.c_void_p), ("arc_dst", C.c_void_p), ("arc_pdf", C.c_void_p),
+                ("arc_weight", C.c_void_p), ("frame_off", C.c_void_p), ("state_off", C.c_void_p),
+                ("final_state", C.c_void_p), ("final_weight", C.c_void_p), ("final_off", C.c_void_p),
+                ("total_arcs", C.c_int64)]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pk2hip.h one to one
+SIGNATURES = {
+    "pk2_last_error": (C.c_char_p, []),
+    "pk2_version": (C.c_int, []),
+    "pk2_den_graph_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "pk2_den_graph_from_openfst": (C.c_int, [C.c_char_p, _i32, C.POINTER(_vp)]),
+    "pk2_den_graph_destroy": (C.c_int, [_vp]),
+    "pk2_den_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "pk2_den_graph_initial_probs": (C.c_int, [_vp, _vp]),
+    "pk2_den_graph_debug_ordering": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i32), _vp, _vp,
+                                               _vp, _vp, _vp, _vp]),
+    "pk2_chain_workspace_bytes": (_sz, [_vp, _i32, _i32, _i64]),
+    "pk2_chain_objf_and_deriv": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(NumBatch), _f32,
+                                           _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "pk2_chain_den_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _f32, _vp, _vp, _i64, _i64,
+                                        _vp, _sz, _vp]),
+    "pk2_fbank_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "pk2_fbank_destroy": (C.c_int, [_vp]),
+    "pk2_fbank_num_frames": (_i32, [_i64]),
+    "pk2_fbank_compute": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "pk2_pad_roll_subsample": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "pk2_softmax_ce_fwd_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "pk2_scale_by_count": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
+    "pk2_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64,
+                               _vp, _vp]),
+    "pk2_colsum_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
+    "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pk2_grad_norm": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "pk2_grad_norm_workspace_bytes": (_sz, [_i64]),
+    "pk2_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32,
+                                _vp, _f32, _vp]),
+    "pk2_sgd_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libpk2hip.so once; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Pk2Error("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = lib().pk2_last_error()
+        raise Pk2Error("libpk2hip status %d: %s" % (status, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Raw address of a torch tensor / numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise Pk2Error("pykaldi2_amd needs an MI355X (torch.cuda.is_available() is False); "
+                       "there is no CPU fallback")

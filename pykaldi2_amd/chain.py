@@ -1,0 +1,227 @@
+"""Host-side mirror of the ``kaldi.chain`` objects the reference's LF-MMI path uses
+(reference bin/train_chain.py:184-202, ops/ops.py:243-280), backed by libpk2hip.so.
+
+  DenominatorGraph(den_fst, num_pdfs)       bin/train_chain.py:167,202
+  ChainTrainingOptions                       bin/train_chain.py:191-193
+  SupervisionOptions                         bin/train_chain.py:184-188
+  Supervision                                bin/train_chain.py:271-272
+  compute_chain_objf_and_deriv(...)          ops/ops.py:265
+
+``den_fst`` may be a path to an OpenFst binary ``den.fst`` or a dict of arc
+arrays (``num_states, start, src, dst, pdf, prob`` as produced by
+pykaldi2_amd.synth.den_graph_arcs).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class ChainTrainingOptions:
+    """kaldi.chain.ChainTrainingOptions (fields used by the reference)."""
+
+    def __init__(self, leaky_hmm_coefficient=1.0e-05, xent_regularize=0.0, l2_regularize=0.0):
+        self.leaky_hmm_coefficient = leaky_hmm_coefficient
+        self.xent_regularize = xent_regularize
+        self.l2_regularize = l2_regularize
+
+
+class SupervisionOptions:
+    """kaldi.chain.SupervisionOptions (reference bin/train_chain.py:184-188)."""
+
+    def __init__(self):
+        self.convert_to_pdfs = True
+        self.frame_subsampling_factor = 3
+        self.left_tolerance = 5
+        self.right_tolerance = 5
+
+
+class DenominatorGraph:
+    def __init__(self, den_fst, num_pdfs):
+        L = _lib.lib()
+        h = C.c_void_p()
+        if isinstance(den_fst, (str, bytes)):
+            path = den_fst.encode() if isinstance(den_fst, str) else den_fst
+            _lib.check(L.pk2_den_graph_from_openfst(path, int(num_pdfs), C.byref(h)))
+        else:
+            src = np.ascontiguousarray(den_fst["src"], dtype=np.int32)
+            dst = np.ascontiguousarray(den_fst["dst"], dtype=np.int32)
+            pdf = np.ascontiguousarray(den_fst["pdf"], dtype=np.int32)
+            prob = np.ascontiguousarray(den_fst["prob"], dtype=np.float32)
+            _lib.check(L.pk2_den_graph_create(int(den_fst["num_states"]), int(num_pdfs), src.shape[0],
+                                              _lib.ptr(src), _lib.ptr(dst), _lib.ptr(pdf), _lib.ptr(prob),
+                                              int(den_fst.get("start", 0)), C.byref(h)))
+        self._h = h
+        s, p, a = C.c_int32(), C.c_int32(), C.c_int64()
+        _lib.check(L.pk2_den_graph_info(h, C.byref(s), C.byref(p), C.byref(a)))
+        self._num_states, self._num_pdfs, self._num_arcs = s.value, p.value, a.value
+
+    def num_states(self):
+        return self._num_states
+
+    def num_pdfs(self):
+        return self._num_pdfs
+
+    def num_arcs(self):
+        return self._num_arcs
+
+    def initial_probs(self):
+        out = np.empty(self._num_states, dtype=np.float32)
+        _lib.check(_lib.lib().pk2_den_graph_initial_probs(self._h, _lib.ptr(out)))
+        return out
+
+    def debug_ordering(self, which):
+        """Host-side work decomposition (test hook): which = 0 by dst, 1 by src, 2 by pdf."""
+        L = _lib.lib()
+        na, nc = C.c_int64(), C.c_int32()
+        _lib.check(L.pk2_den_graph_debug_ordering(self._h, which, C.byref(na), C.byref(nc), None, None,
+                                                  None, None, None, None))
+        arcs = np.empty((na.value, 4), dtype=np.int32)
+        meta = np.empty(na.value // 8, dtype=np.uint32)
+        wb_off = np.empty(nc.value + 1, dtype=np.int32)
+        row0 = np.empty(nc.value, dtype=np.int32)
+        nrows = np.empty(nc.value, dtype=np.int32)
+        atomic = np.empty(nc.value, dtype=np.int32)
+        _lib.check(L.pk2_den_graph_debug_ordering(self._h, which, None, None, _lib.ptr(arcs), _lib.ptr(meta),
+                                                  _lib.ptr(wb_off), _lib.ptr(row0), _lib.ptr(nrows),
+                                                  _lib.ptr(atomic)))
+        return dict(arcs=arcs, meta=meta, wb_off=wb_off, row0=row0, nrows=nrows, atomic=atomic)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().pk2_den_graph_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Supervision:
+    """kaldi.chain.Supervision for one utterance (num_sequences = 1): an acyclic FST in which
+    every arc consumes one frame and carries a pdf label.  Arrays (numpy, host):
+    src/dst int32 (state 0 initial), pdf int32, weight f32 (-log prob), arcs sorted by the
+    frame of their source state with frame_offsets[t] = first arc of frame t."""
+
+    def __init__(self, fst, weight=1.0, label_dim=None):
+        self.weight = float(weight)
+        self.num_sequences = 1
+        self.frames_per_sequence = int(fst["frames"])
+        self.label_dim = label_dim
+        self.num_states = int(fst["num_states"])
+        self.src = np.ascontiguousarray(fst["src"], dtype=np.int32)
+        self.dst = np.ascontiguousarray(fst["dst"], dtype=np.int32)
+        self.pdf = np.ascontiguousarray(fst["pdf"], dtype=np.int32)
+        self.arc_weight = np.ascontiguousarray(fst["weight"], dtype=np.float32)
+        self.frame_offsets = np.ascontiguousarray(fst["frame_offsets"], dtype=np.int32)
+        self.final_states = np.ascontiguousarray(fst["final_states"], dtype=np.int32)
+        self.final_weights = np.ascontiguousarray(fst["final_weights"], dtype=np.float32)
+        self.state_time = fst.get("state_time")
+        assert self.frame_offsets.shape[0] == self.frames_per_sequence + 1
+
+
+class _SupervisionBatch:
+    """Concatenates per-utterance supervisions and ships them to the device in one
+    pinned H2D copy (a few tens of KB)."""
+
+    def __init__(self, sups, device):
+        n = len(sups)
+        arcs = np.cumsum([0] + [s.src.shape[0] for s in sups])
+        self.total_arcs = int(arcs[-1])
+        self.state_off = np.cumsum([0] + [s.num_states for s in sups]).astype(np.int32)
+        self.final_off = np.cumsum([0] + [s.final_states.shape[0] for s in sups]).astype(np.int32)
+        self.lengths = np.asarray([s.frames_per_sequence for s in sups], dtype=np.int32)
+        frame_off = np.concatenate([s.frame_offsets + arcs[i] for i, s in enumerate(sups)]).astype(np.int32)
+        ints = [np.concatenate([s.src for s in sups]), np.concatenate([s.dst for s in sups]),
+                np.concatenate([s.pdf for s in sups]), frame_off,
+                np.concatenate([s.final_states for s in sups])]
+        flts = [np.concatenate([s.arc_weight for s in sups]), np.concatenate([s.final_weights for s in sups])]
+        sizes = [a.shape[0] for a in ints + flts]
+        offs = np.cumsum([0] + [(-(-s // 64)) * 64 for s in sizes])
+        host = torch.empty(int(offs[-1]), dtype=torch.int32).pin_memory()
+        hv = host.numpy()
+        for a, o in zip(ints, offs[:5]):
+            hv[o:o + a.shape[0]] = a
+        for a, o in zip(flts, offs[5:7]):
+            hv[o:o + a.shape[0]] = a.view(np.int32)
+        self._host = host
+        self.dev = host.to(device, non_blocking=True)
+        base = self.dev.data_ptr()
+        p = [C.c_void_p(base + int(o) * 4) for o in offs[:7]]
+        self.struct = _lib.NumBatch(p[0], p[1], p[2], p[5], p[3], _lib.ptr(self.state_off), p[4], p[6],
+                                    _lib.ptr(self.final_off), self.total_arcs)
+        self.n = n
+
+
+_workspace_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspace_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _workspace_cache[key] = None
+        ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _workspace_cache[key] = ws
+    return ws
+
+
+def compute_chain_objf_and_deriv(opts, den_graph, supervisions, nnet_output, lengths=None):
+    """Batched kaldi.chain.compute_chain_objf_and_deriv (reference ops/ops.py:265-267).
+
+    nnet_output: f32 CUDA tensor [N, T, P] (or [T, P] with a single Supervision); row t of
+    sequence n is frame t.  Returns (out, grad): out is a device tensor [3, N] =
+    (objf, log p_num, log p_den) per sequence, grad is d objf / d nnet_output with
+    xent_regularize * numerator posterior already added (zeros on padding frames).
+    """
+    _lib.require_gpu()
+    if isinstance(supervisions, Supervision):
+        supervisions = [supervisions]
+    x = nnet_output
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1
+    N, T, P = x.shape
+    assert N == len(supervisions) and P == den_graph.num_pdfs()
+    sb = _SupervisionBatch(supervisions, x.device)
+    assert int(sb.lengths.max()) <= T
+    weight = supervisions[0].weight
+    L = _lib.lib()
+    Tmax = int(sb.lengths.max())
+    bound = max(sb.total_arcs, int(sb.lengths.sum()) + N)
+    nbytes = L.pk2_chain_workspace_bytes(den_graph._h, N, Tmax, bound)
+    ws = _workspace(x.device, nbytes)
+    grad = torch.empty_like(x)
+    if Tmax < T:
+        grad[:, Tmax:].zero_()
+    out = torch.empty(3, N, dtype=torch.float32, device=x.device)
+    _lib.check(L.pk2_chain_objf_and_deriv(den_graph._h, _lib.ptr(x), x.stride(0), x.stride(1),
+                                          _lib.ptr(sb.lengths), N, C.byref(sb.struct),
+                                          float(opts.leaky_hmm_coefficient), float(opts.xent_regularize),
+                                          float(opts.l2_regularize), float(weight), _lib.ptr(grad),
+                                          grad.stride(0), grad.stride(1), _lib.ptr(out), _lib.ptr(ws),
+                                          ws.numel(), _lib.stream_ptr(x.device)))
+    # keep the pinned staging buffer alive until the stream has consumed it
+    out._pk2_keepalive = sb
+    return out, grad
+
+
+def den_forward_backward(den_graph, nnet_output, lengths, leaky):
+    """Denominator only: (log p_den [N], occupancies [N,T,P]).  Test / profiling hook."""
+    _lib.require_gpu()
+    x = nnet_output
+    N, T, P = x.shape
+    lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+    L = _lib.lib()
+    Tmax = int(lengths.max())
+    nbytes = L.pk2_chain_workspace_bytes(den_graph._h, N, Tmax, 0)
+    ws = _workspace(x.device, nbytes)
+    gamma = torch.zeros_like(x)
+    lp = torch.empty(N, dtype=torch.float32, device=x.device)
+    _lib.check(L.pk2_chain_den_fwd_bwd(den_graph._h, _lib.ptr(x), x.stride(0), x.stride(1),
+                                       _lib.ptr(lengths), N, float(leaky), _lib.ptr(lp), _lib.ptr(gamma),
+                                       gamma.stride(0), gamma.stride(1), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(x.device)))
+    return lp, gamma

@@ -1,0 +1,111 @@
+// Internal declarations shared by chain_den.hip / chain_num.hip / chain_objf.hip.
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace pk2 {
+
+// Work decomposition of one arc ordering (arcs sorted by a row key).
+//  * a chunk = the arcs of a contiguous range of whole rows, processed by one
+//    workgroup; <= kChunkArcs arcs and <= kMaxRows rows.  A row longer than
+//    kChunkArcs is split over several single-row chunks flagged `atomic`
+//    (their partial results are combined with global atomics).
+//  * inside a chunk, arcs are padded to wave blocks of 64*kK arcs; lane i of a
+//    wave block owns kK consecutive sorted arcs, stored interleaved so that
+//    iteration j of all 64 lanes is one coalesced 1 KiB load:
+//        arcs[(wb*kK + j)*64 + lane]  <->  sorted arc  wb*64*kK + lane*kK + j
+//  * meta[wb*64+lane] = c0 | (mask << 16): c0 = chunk-local row of the lane's
+//    first arc, bit j of mask = "flush the running sum into row c after arc j,
+//    then c++" (set where a row ends and at j = kK-1).
+constexpr int kK = 8;
+constexpr int kChunkArcs = 4096;
+constexpr int kMaxRows = 2048;
+constexpr int kDenThreads = 512;
+constexpr int kDenWaves = kDenThreads / 64;
+
+struct HostOrdering {
+  std::vector<int4> arcs;        // {a, b, prob bits, pi*prob bits}
+  std::vector<uint32_t> meta;    // per lane of each wave block
+  std::vector<int32_t> wb_off;   // [n_chunks+1]
+  std::vector<int32_t> row0;     // [n_chunks]
+  std::vector<int32_t> nrows;    // [n_chunks]
+  std::vector<int32_t> atomic;   // [n_chunks]
+  int n_chunks = 0;
+};
+
+struct DevOrdering {
+  const int4* arcs = nullptr;
+  const uint32_t* meta = nullptr;
+  const int32_t* wb_off = nullptr;
+  const int32_t* row0 = nullptr;
+  const int32_t* nrows = nullptr;
+  const int32_t* atomic = nullptr;
+  int n_chunks = 0;
+};
+
+}  // namespace pk2
+
+struct pk2_den_graph {
+  int32_t S = 0, P = 0, start = 0;
+  int64_t A = 0;
+  std::vector<float> pi;
+  double pi_sum = 0.0;
+  pk2::HostOrdering h_fwd, h_bwd, h_gam;  // keyed by dst / src / pdf
+  // device copies, created lazily on the first compute call
+  bool uploaded = false;
+  int device = -1;
+  pk2::DevOrdering fwd, bwd, gam;
+  float* d_pi = nullptr;
+  std::vector<void*> allocs;
+};
+
+namespace pk2 {
+
+// Per-call geometry of the denominator computation.
+struct DenGeom {
+  int NG;      // sequences interleaved per group (4, 2 or 1)
+  int G;       // number of groups
+  int N;       // sequences
+  int Tmax;
+};
+
+struct DenBuffers {
+  float* alpha;   // [G][Tmax+1][S][NG]  alpha (before the leaky term)
+  float* beta;    // [G][Tmax+1][S][NG]  beta' (before the leaky term)
+  float* xs;      // [G][Tmax][P][NG]    exp(clamp(logits)), sequences interleaved
+  float* gamma;   // [G][Tmax][P][NG]    occupancies
+  float* apart;   // [G][Tmax+1][nc_fwd][NG]
+  float* bpart;   // [G][Tmax+1][nc_bwd][NG]
+  float* asum;    // [G][Tmax+1][NG]
+  float* inv_tot; // [G][NG]
+  float* den_lp;  // [G*NG]
+  float* check;   // [G*NG]
+  int32_t* lengths;  // [G*NG] device copy (0 for the padding sequences)
+};
+
+int den_choose_ng(const pk2_den_graph* g);
+size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, DenBuffers* buf,
+                     void* base);
+int den_upload(pk2_den_graph* g);
+// Runs exp-transpose, T forward steps, finalize, T backward steps.  Leaves
+// gamma / den_lp / check in `buf`.
+int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64_t frame_stride,
+                const int32_t* lengths_host, const DenGeom& geom, const DenBuffers& buf,
+                float leaky, hipStream_t stream);
+
+// Numerator.
+struct NumBuffers {
+  float* score;     // [total_arcs]
+  float* frame_max; // [sum lengths]
+  int32_t* seqinfo; // [N][8]
+  float* num_lp;    // [N]
+};
+size_t num_workspace(int N, int64_t total_arcs, int64_t total_frames, NumBuffers* buf, void* base);
+// Adds scale * posterior into grad (which must already hold zeros) and writes num_lp.
+int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride,
+                int64_t frame_stride, const int32_t* lengths_host, int N, float scale, float* grad,
+                int64_t grad_seq_stride, int64_t grad_frame_stride, const NumBuffers& buf,
+                hipStream_t stream);
+
+}  // namespace pk2

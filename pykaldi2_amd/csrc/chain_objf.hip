@@ -1,0 +1,152 @@
+// pk2_chain_objf_and_deriv: numerator + denominator + Kaldi's ComputeChainObjfAndDeriv glue
+//  and the reference wrapper's grad += xent_regularize * grad_xent
+// (reference ops/ops.py:267), all on the device, no host round trip (reference
+// ops/ops.py:255,261,269-271 copy [T,P] logits to the host and the gradient back per utterance).
+#include <algorithm>
+
+#include "chain_internal.h"
+
+namespace pk2 {
+
+void den_gamma_out_launch(const DenGeom& ge, const DenBuffers& b, int P, float scale, float* out,
+                          int64_t ss, int64_t fs, hipStream_t stream);
+
+__global__ void __launch_bounds__(256) zero_rows(float* out, int64_t seq_stride, int64_t frame_stride,
+                                                 int P, int Tmax) {
+  float* row = out + (int64_t)blockIdx.y * seq_stride + (int64_t)blockIdx.x * frame_stride;
+  for (int p = threadIdx.x; p < P; p += 256) row[p] = 0.f;
+}
+
+// flags[n] = 1 if every quantity of sequence n is usable (Kaldi: objf finite and the
+// alpha-beta check within tolerance); out = {objf, num_lp, den_lp} per sequence.
+__global__ void chain_flags(const float* num_lp, const float* den_lp, const float* check,
+                            const int32_t* lengths, int N, float weight, float* out, int32_t* flags) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float nl = num_lp[n], dl = den_lp[n], ck = check[n];
+  const float objf = weight * (nl - dl);
+  const bool ok = isfinite(objf) && isfinite(ck) && fabsf(ck - 1.0f) <= 0.05f;
+  flags[n] = ok ? 1 : 0;
+  out[n] = ok ? objf : -10.0f * weight * (float)lengths[n];
+  out[N + n] = nl;
+  out[2 * N + n] = dl;
+}
+
+// grad[n][t][p] = ok ? grad - weight*gamma - weight*l2*logit : 0     (grad holds the numerator part)
+template <int NG>
+__global__ void __launch_bounds__(256) chain_combine(const float* __restrict__ gamma,
+                                                     const int32_t* __restrict__ lengths,
+                                                     const int32_t* __restrict__ flags, int N, int P,
+                                                     int Tmax, float weight, float l2,
+                                                     const float* __restrict__ logits, int64_t lss,
+                                                     int64_t lfs, float* grad, int64_t gss, int64_t gfs) {
+  const int t = blockIdx.x, g = blockIdx.y;
+  const float* src = gamma + ((size_t)g * Tmax + t) * (size_t)P * NG;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    float v[NG];
+    {
+      using T = typename std::conditional<NG == 4, float4, typename std::conditional<NG == 2, float2, float>::type>::type;
+      T tv = *reinterpret_cast<const T*>(src + (size_t)p * NG);
+      const float* f = reinterpret_cast<const float*>(&tv);
+#pragma unroll
+      for (int n = 0; n < NG; ++n) v[n] = f[n];
+    }
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+      const int seq = g * NG + n;
+      if (seq < N) {
+        float* o = grad + (int64_t)seq * gss + (int64_t)t * gfs + p;
+        const bool live = t < lengths[seq] && flags[seq] != 0;
+        float r = 0.f;
+        if (live) {
+          r = *o - weight * v[n];
+          if (l2 != 0.f) r -= weight * l2 * logits[(int64_t)seq * lss + (int64_t)t * lfs + p];
+        }
+        *o = r;
+      }
+    }
+  }
+}
+
+}  // namespace pk2
+
+using namespace pk2;
+
+static size_t chain_carve(const pk2_den_graph* g, int N, int Tmax, int64_t total_arcs,
+                          int64_t total_frames, void* base, DenGeom* ge, DenBuffers* db,
+                          NumBuffers* nb, int32_t** flags, int32_t** lengths_dev) {
+  size_t den_bytes = den_workspace(g, N, Tmax, ge, db, base);
+  char* b2 = base ? static_cast<char*>(base) + den_bytes : nullptr;
+  size_t num_bytes = num_workspace(N, total_arcs, total_frames, nb, b2);
+  Carver c(base ? b2 + num_bytes : nullptr);
+  int32_t* f = c.take<int32_t>((size_t)N);
+  int32_t* l = c.take<int32_t>((size_t)N);
+  if (flags) *flags = f;
+  if (lengths_dev) *lengths_dev = l;
+  return den_bytes + num_bytes + c.bytes();
+}
+
+extern "C" size_t pk2_chain_workspace_bytes(const pk2_den_graph* g, int32_t num_seqs,
+                                            int32_t max_frames, int64_t num_total_states) {
+  if (!g || num_seqs <= 0 || max_frames <= 0) return 0;
+  (void)num_total_states;
+  // arcs/frames upper bounds: the caller passes the concatenated supervision sizes through
+  // num_total_states = max(total_arcs, total_frames + num_seqs)
+  int64_t bound = std::max<int64_t>(num_total_states, (int64_t)num_seqs * (max_frames + 1));
+  return chain_carve(g, num_seqs, max_frames, bound, bound, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr);
+}
+
+extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* logits,
+                                        int64_t seq_stride, int64_t frame_stride,
+                                        const int32_t* lengths, int32_t N, const pk2_num_batch* num,
+                                        float leaky, float xent_regularize, float l2_regularize,
+                                        float weight, float* grad, int64_t gss, int64_t gfs,
+                                        float* out, void* workspace, size_t workspace_bytes,
+                                        void* stream_) {
+  PK2_REQUIRE(gc && logits && lengths && N > 0 && num && grad && out && workspace,
+              "chain_objf_and_deriv: bad args");
+  pk2_den_graph* g = const_cast<pk2_den_graph*>(gc);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int Tmax = 0; int64_t total_frames = 0;
+  for (int n = 0; n < N; ++n) {
+    PK2_REQUIRE(lengths[n] > 0, "chain_objf_and_deriv: sequence %d has no frames", n);
+    Tmax = std::max(Tmax, lengths[n]);
+    total_frames += lengths[n];
+  }
+  int64_t bound = std::max<int64_t>(std::max<int64_t>(num->total_arcs, total_frames + N),
+                                    (int64_t)N * (Tmax + 1));
+  DenGeom ge; DenBuffers db; NumBuffers nbuf; int32_t* flags; int32_t* ldev;
+  size_t need = chain_carve(g, N, Tmax, bound, bound, workspace, &ge, &db, &nbuf, &flags, &ldev);
+  PK2_REQUIRE(workspace_bytes >= need, "chain_objf_and_deriv: workspace %zu < %zu", workspace_bytes, need);
+
+  // 1. gradient buffer starts at zero; the numerator adds (1 + xent_regularize) * w * posterior
+  hipLaunchKernelGGL(zero_rows, dim3(Tmax, N), dim3(256), 0, stream, grad, gss, gfs, g->P, Tmax);
+  int rc = num_compute(num, logits, seq_stride, frame_stride, lengths, N,
+                       weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, stream);
+  if (rc) return rc;
+  // 2. denominator
+  rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream);
+  if (rc) return rc;
+  // 3. objective, guards, gradient = numerator - denominator occupancies
+  hipLaunchKernelGGL(chain_flags, dim3((N + 63) / 64), dim3(64), 0, stream, nbuf.num_lp, db.den_lp,
+                     db.check, db.lengths, N, weight, out, flags);
+  switch (ge.NG) {
+    case 4:
+      hipLaunchKernelGGL(chain_combine<4>, dim3(Tmax, ge.G), dim3(256), 0, stream, db.gamma, db.lengths,
+                         flags, N, g->P, Tmax, weight, l2_regularize, logits, seq_stride, frame_stride,
+                         grad, gss, gfs);
+      break;
+    case 2:
+      hipLaunchKernelGGL(chain_combine<2>, dim3(Tmax, ge.G), dim3(256), 0, stream, db.gamma, db.lengths,
+                         flags, N, g->P, Tmax, weight, l2_regularize, logits, seq_stride, frame_stride,
+                         grad, gss, gfs);
+      break;
+    default:
+      hipLaunchKernelGGL(chain_combine<1>, dim3(Tmax, ge.G), dim3(256), 0, stream, db.gamma, db.lengths,
+                         flags, N, g->P, Tmax, weight, l2_regularize, logits, seq_stride, frame_stride,
+                         grad, gss, gfs);
+  }
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}

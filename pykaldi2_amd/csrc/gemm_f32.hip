@@ -1,0 +1,208 @@
+// f32 MFMA GEMM for gfx950:  C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N].
+//
+// Replaces the cuBLAS GEMMs under nn.Linear / nn.LSTM's input projections (reference
+// models/lstm.py:45-59).  FP32 inputs and accumulation on v_mfma_f32_32x32x2_f32: the north
+// star's 1e-4 posterior tolerance rules out bf16 GEMMs, and gfx950 has
+// no TF32-like mode, so the f32 MFMA (157 TFLOP/s peak) is the matrix-core path for this model.
+//
+// 128x128x16 block tile, 256 threads = 4 wavefronts in a 2x2 grid, each wave owns a 64x64
+// sub-tile = 2x2 MFMA tiles (64 accumulator VGPRs).  Operands are staged through LDS in
+// k-major order ([k][m] / [k][n]) whatever their memory layout, so every MFMA operand fetch is a
+// conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  The next k-tile is
+// prefetched into registers while the current one is multiplied.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pk2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_LD = 132;  // padded leading dimension of the [BK][128] LDS tiles
+constexpr int kGemmThreads = 256;
+
+// Loads the 128 x 16 (rows x k) slab of an operand into registers.
+//   KCONTIG: element (r, k) at base[r*ld + k]  -> thread owns float4 along k of 2 rows
+//  !KCONTIG: element (r, k) at base[k*ld + r]  -> thread owns float4 along r of 2 k's
+// Out-of-range elements read as 0.  `vec` = base/ld allow aligned float4 loads.
+template <bool KCONTIG>
+__device__ __forceinline__ void load_slab(const float* __restrict__ base, int64_t ld, int r0, int k0,
+                                          int R, int K, bool vec, float4 (&reg)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int r, k;
+    if (KCONTIG) { r = (tid >> 2) + h * 64; k = (tid & 3) * 4; }
+    else         { k = (tid >> 5) + h * 8;  r = (tid & 31) * 4; }
+    const int gr = r0 + r, gk = k0 + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KCONTIG) {
+      if (gr < R) {
+        const float* p = base + (int64_t)gr * ld + gk;
+        if (vec && gk + 3 < K) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk + 0 < K) v.x = p[0];
+          if (gk + 1 < K) v.y = p[1];
+          if (gk + 2 < K) v.z = p[2];
+          if (gk + 3 < K) v.w = p[3];
+        }
+      }
+    } else {
+      if (gk < K) {
+        const float* p = base + (int64_t)gk * ld + gr;
+        if (vec && gr + 3 < R) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gr + 0 < R) v.x = p[0];
+          if (gr + 1 < R) v.y = p[1];
+          if (gr + 2 < R) v.z = p[2];
+          if (gr + 3 < R) v.w = p[3];
+        }
+      }
+    }
+    reg[h] = v;
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_slab(float* __restrict__ tile, const float4 (&reg)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (KCONTIG) {
+      const int r = (tid >> 2) + h * 64, k = (tid & 3) * 4;
+      tile[(k + 0) * LDS_LD + r] = reg[h].x;
+      tile[(k + 1) * LDS_LD + r] = reg[h].y;
+      tile[(k + 2) * LDS_LD + r] = reg[h].z;
+      tile[(k + 3) * LDS_LD + r] = reg[h].w;
+    } else {
+      const int k = (tid >> 5) + h * 8, r = (tid & 31) * 4;
+      *reinterpret_cast<float4*>(&tile[k * LDS_LD + r]) = reg[h];
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, int K, float alpha,
+                                                                const float* __restrict__ A, int64_t lda,
+                                                                const float* __restrict__ B, int64_t ldb,
+                                                                float beta, float* __restrict__ C, int64_t ldc,
+                                                                const float* __restrict__ bias, bool vecA,
+                                                                bool vecB) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  // A is "k-contiguous" when not transposed ([M,K]); B is k-contiguous when transposed ([N,K]).
+  load_slab<!TA>(A, lda, m0, 0, M, K, vecA, ra);
+  load_slab<TB>(B, ldb, n0, 0, N, K, vecB, rb);
+  const int nk = (K + BK - 1) / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    store_slab<!TA>(As, ra);
+    store_slab<TB>(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_slab<!TA>(A, lda, m0, (kt + 1) * BK, M, K, vecA, ra);
+      load_slab<TB>(B, ldb, n0, (kt + 1) * BK, N, K, vecB, rb);
+    }
+    const int kq = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[(kk + kq) * LDS_LD + wm + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + kq) * LDS_LD + wn + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gc = n0 + wn + j * 32 + col_l;
+      if (gc >= N) continue;
+      const float bv = bias ? bias[gc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (gr < M) {
+          float* o = C + (int64_t)gr * ldc + gc;
+          float v = alpha * acc[i][j][r] + bv;
+          if (beta != 0.f) v += beta * (*o);
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
+// out[n] = beta*out[n] + sum_m A[m][n]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int64_t lda, int M, int N,
+                                                     float beta, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (n < N)
+    for (int m = part; m < M; m += 4) acc += A[(int64_t)m * lda + n];
+  red[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && n < N) {
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[n] = (beta != 0.f ? beta * out[n] : 0.f) + s;
+  }
+}
+
+}  // namespace pk2
+
+using namespace pk2;
+
+extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                            const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                            int64_t ldc, const float* bias, void* stream_) {
+  PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
+  const bool vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(kGemmThreads);
+#define PK2_GEMM(TA, TB)                                                                               \
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, ldb, \
+                     beta, C, ldc, bias, vecA, vecB)
+  if (!transa && !transb) PK2_GEMM(false, false);
+  else if (!transa && transb) PK2_GEMM(false, true);
+  else if (transa && !transb) PK2_GEMM(true, false);
+  else PK2_GEMM(true, true);
+#undef PK2_GEMM
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
+
+extern "C" int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,
+                              void* stream_) {
+  PK2_REQUIRE(A && out && M > 0 && N > 0, "colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream_), A,
+                     lda, M, N, beta, out);
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}

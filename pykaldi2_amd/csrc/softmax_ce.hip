@@ -1,0 +1,135 @@
+// Fused log-softmax + NLL + gradient, one pass over the logits (gfx950).
+//
+// Replaces nn.CrossEntropyLoss(ignore_index=-100) as called by the reference
+// (bin/train_ce.py:134,189 mean reduction; bin/train_se.py:214,235 sum reduction).
+// HBM-bound: reads rows*P floats once, writes rows*P floats once.  One 256-thread workgroup
+// per row keeps the whole row (P <= 8192) in registers between the max / sum-exp reductions
+// and the gradient write.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pk2 {
+
+constexpr int kCeThreads = 256;
+constexpr int kCeVpt = 32;  // values per thread held in registers -> P <= 8192
+
+__device__ __forceinline__ float ce_block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float ce_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <bool IN_REGS>
+__global__ void __launch_bounds__(kCeThreads) softmax_ce_kernel(
+    const float* __restrict__ logits, int64_t row_stride, const int64_t* __restrict__ targets,
+    int64_t ignore_index, int P, float* loss_sum, int32_t* count, float* __restrict__ grad,
+    int64_t grad_row_stride, float* __restrict__ logprob) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* x = logits + row * row_stride;
+  const int64_t tgt = targets[row];
+  const bool ignored = tgt == ignore_index;
+  float* g = grad ? grad + row * grad_row_stride : nullptr;
+  if (ignored && !logprob) {
+    if (g) for (int p = tid; p < P; p += kCeThreads) g[p] = 0.f;
+    return;
+  }
+  float v[kCeVpt];
+  float m = -INFINITY;
+  if (IN_REGS) {
+#pragma unroll
+    for (int k = 0; k < kCeVpt; ++k) {
+      const int p = tid + k * kCeThreads;
+      v[k] = p < P ? x[p] : -INFINITY;
+      m = fmaxf(m, v[k]);
+    }
+  } else {
+    for (int p = tid; p < P; p += kCeThreads) m = fmaxf(m, x[p]);
+  }
+  m = ce_block_max(m, red);
+  float s = 0.f;
+  if (IN_REGS) {
+#pragma unroll
+    for (int k = 0; k < kCeVpt; ++k) { v[k] = expf(v[k] - m); s += v[k]; }  // exp(-inf) = 0 for the tail
+  } else {
+    for (int p = tid; p < P; p += kCeThreads) s += expf(x[p] - m);
+  }
+  s = ce_block_sum(s, red);
+  const float lse = m + logf(s);
+  const float inv = 1.0f / s;
+  if (!ignored && tid == 0) {
+    atomicAdd(loss_sum, lse - x[tgt]);
+    atomicAdd(count, 1);
+  }
+  if (IN_REGS) {
+#pragma unroll
+    for (int k = 0; k < kCeVpt; ++k) {
+      const int p = tid + k * kCeThreads;
+      if (p < P) {
+        const float sm = v[k] * inv;
+        if (g) g[p] = ignored ? 0.f : (sm - (p == tgt ? 1.f : 0.f));
+        if (logprob) logprob[row * (int64_t)P + p] = logf(fmaxf(sm, 1e-45f)) ;
+      }
+    }
+  } else {
+    for (int p = tid; p < P; p += kCeThreads) {
+      const float lp = x[p] - lse;
+      if (g) g[p] = ignored ? 0.f : (expf(lp) - (p == tgt ? 1.f : 0.f));
+      if (logprob) logprob[row * (int64_t)P + p] = lp;
+    }
+  }
+}
+
+__global__ void scale_by_count_kernel(float* data, int64_t n, float numerator, const int32_t* count) {
+  const float f = numerator / (float)max(1, *count);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    data[i] *= f;
+}
+
+}  // namespace pk2
+
+using namespace pk2;
+
+extern "C" int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_t* targets,
+                                      int64_t ignore_index, int64_t rows, int32_t P, float* loss_sum,
+                                      int32_t* count, float* grad, int64_t grad_row_stride,
+                                      float* logprob_out, void* stream_) {
+  PK2_REQUIRE(logits && targets && loss_sum && count && rows >= 0 && P > 0, "softmax_ce: bad args");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PK2_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
+  PK2_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+  if (rows == 0) return PK2_OK;
+  if (P <= kCeThreads * kCeVpt && !logprob_out) {
+    hipLaunchKernelGGL(softmax_ce_kernel<true>, dim3((unsigned)rows), dim3(kCeThreads), 0, stream, logits,
+                       row_stride, targets, ignore_index, P, loss_sum, count, grad, grad_row_stride,
+                       logprob_out);
+  } else {
+    hipLaunchKernelGGL(softmax_ce_kernel<false>, dim3((unsigned)rows), dim3(kCeThreads), 0, stream, logits,
+                       row_stride, targets, ignore_index, P, loss_sum, count, grad, grad_row_stride,
+                       logprob_out);
+  }
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
+
+extern "C" int pk2_scale_by_count(float* data, int64_t n, float numerator, const int32_t* count_den,
+                                  void* stream_) {
+  PK2_REQUIRE(data && count_den && n >= 0, "scale_by_count: bad args");
+  if (n == 0) return PK2_OK;
+  int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+  hipLaunchKernelGGL(scale_by_count_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     data, n, numerator, count_den);
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}

@@ -1,0 +1,94 @@
+"""On-device 80-dim log-mel filterbank front end (libpk2hip.so).
+
+Replaces DataGeneratorTrain._logfbank_extractor + cmn (reference data/sr_dataset.py:279-296,
+365-366) and the roll/unfold frame subsampling of bin/train_chain.py:251-255 for waveforms that
+are already in HBM.  The mel matrix of the reference is the table data/mel80_window.txt, produced
+(per the comment at data/sr_dataset.py:270-273) by librosa.filters.mel(16000, 512, n_mels=80,
+fmax=7690, htk=True); ``mel_filterbank()`` below regenerates it bit for bit (pinned by
+tests/golden/fbank.npz), and ``load_mel(path)`` reads a user-supplied table in the same format.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+def mel_filterbank(sr=16000, n_fft=512, n_mels=80, fmin=0.0, fmax=7690.0):
+    """HTK-scale triangular mel filters with Slaney area normalisation, [n_mels, n_fft/2+1] f32."""
+    def hz2mel(f):
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+
+    def mel2hz(m):
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    fftfreqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    mel_f = mel2hz(np.linspace(hz2mel(fmin), hz2mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    w = np.zeros((n_mels, n_fft // 2 + 1))
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def load_mel(path):
+    with open(path) as f:
+        rows = [np.asarray([np.float32(v) for v in line.rstrip("\n").split(",")]) for line in f if line.strip()]
+    mel = np.vstack(rows).astype(np.float32)
+    assert mel.shape == (80, 257), mel.shape
+    return mel
+
+
+def num_frames(num_samples):
+    return int(_lib.lib().pk2_fbank_num_frames(int(num_samples)))
+
+
+class FbankExtractor:
+    def __init__(self, mel=None):
+        mel = mel_filterbank() if mel is None else np.ascontiguousarray(mel, dtype=np.float32)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().pk2_fbank_create(_lib.ptr(mel), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().pk2_fbank_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __call__(self, wav, wav_lengths, apply_cmn=True):
+        """wav: CUDA f32 1-D tensor holding the utterances back to back; wav_lengths: list of sample
+        counts.  Returns (feats [sum_T, 80] CUDA f32, frames list, row_off CUDA int64 [N+1])."""
+        _lib.require_gpu()
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.is_contiguous()
+        n = len(wav_lengths)
+        wav_off = np.zeros(n + 1, dtype=np.int64)
+        wav_off[1:] = np.cumsum(wav_lengths)
+        frames = [num_frames(l) for l in wav_lengths]
+        row_off_h = np.zeros(n + 1, dtype=np.int64)
+        row_off_h[1:] = np.cumsum(frames)
+        row_off = torch.from_numpy(row_off_h).to(wav.device, non_blocking=False)
+        feats = torch.empty(int(row_off_h[-1]), 80, dtype=torch.float32, device=wav.device)
+        _lib.check(_lib.lib().pk2_fbank_compute(self._h, _lib.ptr(wav), _lib.ptr(wav_off), n, _lib.ptr(feats),
+                                                _lib.ptr(row_off), 1 if apply_cmn else 0,
+                                                _lib.stream_ptr(wav.device)))
+        return feats, frames, row_off
+
+    @staticmethod
+    def pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=False):
+        """Zero-pad to max(frames), torch.roll by `shift` along time, keep every `subsample`-th frame
+        (reference bin/train_chain.py:251-255; with subsample=1, shift=0 it is SeqDataloader's padding,
+        data/dataloader.py:96-103).  Returns [N, T', 80] or [T', N, 80]."""
+        n = len(frames)
+        max_t = int(max(frames))
+        out_t = (max_t - 1) // subsample + 1
+        shape = (out_t, n, 80) if time_major else (n, out_t, 80)
+        x = torch.empty(*shape, dtype=torch.float32, device=feats.device)
+        _lib.check(_lib.lib().pk2_pad_roll_subsample(_lib.ptr(feats), _lib.ptr(row_off), n, max_t, int(shift),
+                                                     int(subsample), _lib.ptr(x), out_t, 1 if time_major else 0,
+                                                     _lib.stream_ptr(feats.device)))
+        return x

@@ -1,0 +1,180 @@
+"""Seeded synthetic inputs shaped like the LibriSpeech recipe.
+
+There is no dataset, Kaldi model directory or den.fst in this environment, so
+bench.py and the tests draw LibriSpeech-shaped utterances, pdf alignments, a
+denominator graph and per-utterance numerator FSTs from these generators.
+Nothing here is on the timed path.
+"""
+import numpy as np
+
+
+def utterance_durations(rng, n):
+    """Seconds; clip(Gamma(k=4.2, theta=2.93), 1.3, 34.9), mean ~12.3 s."""
+    return np.clip(rng.gamma(4.2, 2.93, size=n), 1.3, 34.9)
+
+
+def waveform(rng, seconds, sr=16000):
+    """0.05*N(0,1) low-passed by y[n] = x[n] + 0.9 y[n-1], peak-normalised to 0.5."""
+    n = int(round(sr * seconds))
+    x = (0.05 * rng.standard_normal(n)).astype(np.float64)
+    try:
+        from scipy.signal import lfilter
+        y = lfilter([1.0], [1.0, -0.9], x)
+    except Exception:  # pragma: no cover
+        y = np.empty_like(x)
+        acc = 0.0
+        for i in range(n):
+            acc = x[i] + 0.9 * acc
+            y[i] = acc
+    y *= 0.5 / max(1e-9, np.abs(y).max())
+    return y.astype(np.float32)
+
+
+def num_fbank_frames(n_samples):
+    """Frames produced by the reference extractor for an n_samples wav
+    (reference simulation/freq_analysis.py:64-69 after data/sr_dataset.py:288
+    dropped one sample): ceil((N-1-400)/160)+1."""
+    m = n_samples - 1
+    if m <= 400:
+        return 1
+    return -(-(m - 400) // 160) + 1
+
+
+def pdf_alignment(rng, num_frames, num_pdfs):
+    """Piecewise-constant pdf ids; segment length 3+Geometric(0.12) frames."""
+    out = np.empty(num_frames, dtype=np.int64)
+    t = 0
+    prev = None
+    while t < num_frames:
+        seg = 3 + int(rng.geometric(0.12))
+        pid = int(rng.integers(0, num_pdfs))
+        if prev is not None and pid == prev:
+            pid = (pid + 1) % num_pdfs
+        if num_frames - t < 3 and prev is not None:
+            pid = prev  # a <3-frame tail is merged into the previous segment
+        out[t:t + seg] = pid
+        prev = pid
+        t += seg
+    return out
+
+
+def den_graph_arcs(num_states=30000, num_arcs=1000000, num_pdfs=6048, seed=0):
+    """Phone-structured synthetic denominator graph.
+
+    States come in pairs (a 2-state left-to-right "phone"): the entry state has
+    a self loop and a forward arc to the exit state; the exit state has a self
+    loop and 1+Poisson fan-out arcs to entry states of other phones (a phone
+    bigram).  Every state carries one pdf, emitted by arcs *entering* it.  Arc
+    probabilities are Dirichlet-normalised per source state.  Returns a dict of
+    numpy arrays (src, dst, pdf int32; prob float32), start state 0.
+    """
+    rng = np.random.default_rng(seed)
+    S = int(num_states) // 2 * 2
+    n_ph = S // 2
+    state_pdf = rng.integers(0, num_pdfs, size=S)
+    entry = np.arange(n_ph) * 2
+    exit_ = entry + 1
+    fixed = 3 * n_ph  # entry self, entry->exit, exit self
+    fan_total = max(n_ph, int(num_arcs) - fixed)
+    lam = max(0.0, fan_total / n_ph - 1.0)
+    fan = 1 + rng.poisson(lam, size=n_ph)
+    src = [entry, entry, exit_, np.repeat(exit_, fan)]
+    # destinations: a skewed pool (some phones are far more frequent successors)
+    pop = rng.gamma(0.7, 1.0, size=n_ph)
+    pop /= pop.sum()
+    fan_dst = rng.choice(n_ph, size=int(fan.sum()), p=pop) * 2
+    dst = [entry, exit_, exit_, fan_dst]
+    src = np.concatenate(src)
+    dst = np.concatenate(dst)
+    # make sure every entry state is reachable: phone i's exit -> phone (i+1)'s entry
+    src = np.concatenate([src, exit_])
+    dst = np.concatenate([dst, np.roll(entry, -1)])
+    w = rng.gamma(1.0, 1.0, size=src.shape[0]) + 1e-3
+    tot = np.bincount(src, weights=w, minlength=S)
+    prob = w / tot[src]
+    pdf = state_pdf[dst]
+    order = np.lexsort((dst, src))
+    return dict(num_states=S, start=0, num_pdfs=int(num_pdfs),
+                src=src[order].astype(np.int32), dst=dst[order].astype(np.int32),
+                pdf=pdf[order].astype(np.int32), prob=prob[order].astype(np.float32))
+
+
+def numerator_fst_from_alignment(ali, subsample=3, tolerance=5):
+    """Simplified stand-in for Kaldi's alignment -> Supervision pipeline
+    (reference bin/train_chain.py:262-272 with SupervisionOptions :184-188;
+    SURVEY Appendix A.3): T' = ceil(T/3); segment i occupying frames [b,e)
+    may be emitted on subsampled frames [ceil(max(0,b-tol)/3), ceil(min(e+tol,T)/3));
+    one pdf per segment, at least one frame per segment, unit weights.
+
+    State (i, t) = "t frames consumed, last one from segment i".  Returns a
+    dict of arrays for chain.Supervision: arcs sorted by source time, with
+    ``frame_offsets[t]`` the first arc whose source state sits at frame t.
+    """
+    ali = np.asarray(ali)
+    T = ali.shape[0]
+    Tp = -(-T // subsample)
+    change = np.flatnonzero(np.diff(ali)) + 1
+    b = np.concatenate([[0], change])
+    e = np.concatenate([change, [T]])
+    seg_pdf = ali[b]
+    n_seg = b.shape[0]
+    lo = -(-np.maximum(0, b - tolerance) // subsample)
+    hi = -(-np.minimum(e + tolerance, T) // subsample)
+    hi = np.minimum(hi, Tp)
+    # reachable (i, t): forward pass then backward pass over the trellis
+    fwd = np.zeros((n_seg + 1, Tp + 1), dtype=bool)  # row 0 = start pseudo-segment -1
+    fwd[0, 0] = True
+    for t in range(Tp):
+        prev = fwd[:, t]
+        allowed = (lo <= t) & (t < hi)
+        stay = prev[1:] & allowed
+        adv = prev[:-1] & allowed
+        fwd[1:, t + 1] = stay | adv
+    bwd = np.zeros_like(fwd)
+    bwd[n_seg, Tp] = fwd[n_seg, Tp]
+    if not bwd[n_seg, Tp]:
+        raise ValueError("alignment admits no path under the tolerance windows")
+    for t in range(Tp - 1, -1, -1):
+        allowed = (lo <= t) & (t < hi)
+        nxt = bwd[1:, t + 1] & allowed          # arcs entering segment i at t+1 need frame t allowed for i
+        bwd[1:, t] |= nxt                      # stay: (i,t)->(i,t+1)
+        bwd[:-1, t] |= nxt                     # advance: (i-1,t)->(i,t+1)
+        bwd[:, t] &= fwd[:, t]
+    live = fwd & bwd
+    sid = -np.ones(live.shape, dtype=np.int64)
+    # number states in time-major order so the FST is top-sorted
+    ii, tt = np.nonzero(live.T)[1], np.nonzero(live.T)[0]
+    sid[ii, tt] = np.arange(ii.shape[0])
+    state_time = tt.copy()
+    src, dst, pdf = [], [], []
+    offsets = [0]
+    for t in range(Tp):
+        allowed = (lo <= t) & (t < hi)
+        for kind in (0, 1):  # 0 = stay, 1 = advance
+            if kind == 0:
+                ok = live[1:, t] & live[1:, t + 1] & allowed
+                s_ = sid[1:, t][ok]
+            else:
+                ok = live[:-1, t] & live[1:, t + 1] & allowed
+                s_ = sid[:-1, t][ok]
+            d_ = sid[1:, t + 1][ok]
+            src.append(s_); dst.append(d_); pdf.append(seg_pdf[ok])
+        offsets.append(offsets[-1] + src[-1].shape[0] + src[-2].shape[0])
+    src = np.concatenate(src); dst = np.concatenate(dst); pdf = np.concatenate(pdf)
+    return dict(num_states=int(ii.shape[0]), frames=int(Tp),
+                src=src.astype(np.int32), dst=dst.astype(np.int32), pdf=pdf.astype(np.int32),
+                weight=np.zeros(src.shape[0], dtype=np.float32),
+                frame_offsets=np.asarray(offsets, dtype=np.int32),
+                state_time=state_time.astype(np.int32),
+                final_states=np.asarray([sid[n_seg, Tp]], dtype=np.int32),
+                final_weights=np.zeros(1, dtype=np.float32))
+
+
+def minibatch(rng, batch, num_pdfs, sr=16000):
+    """One LibriSpeech-shaped minibatch: list of (wav f32[N], alignment i64[T])."""
+    out = []
+    for d in utterance_durations(rng, batch):
+        wav = waveform(rng, float(d), sr)
+        T = num_fbank_frames(wav.shape[0])
+        out.append((wav, pdf_alignment(rng, T, num_pdfs)))
+    return out

@@ -1,0 +1,87 @@
+"""Host-side mirror of the reference interface: parameter names / initialisation, synthetic
+supervision builder, Horovod-shaped shim over gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+from pykaldi2_amd import hvd, lstm, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_lstmam_state_dict_and_default_init_match_reference(golden):
+    pin = golden("lstm_init")
+    torch.manual_seed(0)
+    m = lstm.LSTMAM(80, 5768, 512, 3, 0.2, True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(pin["__keys"])
+    assert sum(v.numel() for v in sd.values()) == int(pin["__num_params"]) == 20944520
+    for k, v in sd.items():
+        assert np.array_equal(v.reshape(-1)[:16].numpy(), pin[k]), k
+
+
+def test_flat_layout_keeps_directions_adjacent():
+    m = lstm.LSTMAM(20, 37, 64, 2, 0.0, True)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat, gflat = m.flat_parameters()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    w_ih, w_hh, b_ih, b_hh = m._layer_views(1)
+    assert torch.equal(w_ih[:256], m.lstm.weight_ih_l1) and torch.equal(w_ih[256:], m.lstm.weight_ih_l1_reverse)
+    assert torch.equal(w_hh[256:], m.lstm.weight_hh_l1_reverse) and torch.equal(b_hh[256:], m.lstm.bias_hh_l1_reverse)
+    assert flat.data_ptr() % 256 == 0 and gflat.shape == flat.shape
+    assert set(m._buckets) == {"output_layer", "lstm.l0", "lstm.l1"}
+
+
+def test_synthetic_supervision_is_a_valid_time_synchronous_fst():
+    rng = np.random.default_rng(5)
+    for T in (9, 100, 301, 1199):
+        ali = synth.pdf_alignment(rng, T, 6048)
+        f = synth.numerator_fst_from_alignment(ali)
+        Tp = -(-T // 3)
+        assert f["frames"] == Tp and f["frame_offsets"][-1] == len(f["src"])
+        t_src = f["state_time"][f["src"]]
+        assert (np.diff(t_src) >= 0).all() and (f["state_time"][f["dst"]] == t_src + 1).all()
+        assert f["state_time"][f["final_states"][0]] == Tp and f["state_time"][0] == 0
+        for t in range(Tp):
+            assert f["frame_offsets"][t + 1] > f["frame_offsets"][t]
+
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+from pykaldi2_amd import hvd
+hvd.init(backend="gloo")
+assert hvd.size() == 2
+torch.manual_seed(hvd.rank())
+model = torch.nn.Linear(4, 3)
+hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+w0 = model.weight.detach().clone()
+opt = hvd.DistributedOptimizer(torch.optim.SGD(model.parameters(), lr=0.5), named_parameters=model.named_parameters())
+x = torch.full((2, 4), float(hvd.rank() + 1))
+opt.zero_grad(); model(x).sum().backward(); opt.step()
+# averaged gradient of sum(Wx+b) wrt W = mean over ranks of column sums = (2*1 + 2*2)/2 = 3
+expect = w0 - 0.5 * 3.0
+assert torch.allclose(model.weight, expect, atol=1e-6), (model.weight, expect)
+t = torch.tensor([float(hvd.rank())]); hvd.allreduce_(t); assert t.item() == 0.5
+print("OK", hvd.rank())
+hvd.shutdown()
+'''
+
+
+def test_hvd_shim_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % dict(root=ROOT))
+    port = str(29600 + os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)

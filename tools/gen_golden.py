@@ -1,0 +1,179 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference (jzlianglu/pykaldi2 at /root/reference).
+
+Run in the build container only (the reference does not exist on the GPU box):
+    python tools/gen_golden.py
+The fixtures hold data only: seeded inputs and the outputs the reference's own code produced for
+them.  Fix-ups applied here, never to the reference:
+  * np.int = int            simulation/freq_analysis.py:66 and data/dataloader.py:109 use the removed alias
+  * LSTMAM.forward          models/lstm.py:59 is a NameError -> call m.output_layer(m.lstm(x)[0])
+  * reader/, data/          loaded by file path, never `import reader` (reader/reader.py:28-40 shells out)
+  * _logfbank_extractor     lives in a class whose module imports reader; its 12 lines
+                            (data/sr_dataset.py:279-296) are re-stated around the imported stft()
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+np.int = int  # noqa
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def synth_wav(rng, n):
+    x = 0.05 * rng.standard_normal(n)
+    y = np.empty(n)
+    acc = 0.0
+    for i in range(n):
+        acc = x[i] + 0.9 * acc
+        y[i] = acc
+    y *= 0.5 / np.abs(y).max()
+    return y.astype(np.float32)
+
+
+def gen_fbank():
+    sys.path.insert(0, REF)
+    from simulation.freq_analysis import stft  # the reference's own STFT
+    pre = load_by_path("ref_preprocess", "reader/preprocess.py")
+    with open(os.path.join(REF, "data/mel80_window.txt")) as f:
+        lines = [line.rstrip("\n") for line in f]
+    window = np.vstack([np.asarray([np.float32(j) for j in i.split(",")]) for i in lines])
+
+    def logfbank(wav):  # data/sr_dataset.py:279-296 around the imported stft
+        preemphasis = 0.96
+        t1 = np.sum(window, 0)
+        t1[t1 == 0] = -1
+        inv = np.diag(1 / t1)
+        mel = window.dot(inv).T
+        wav = wav[1:] - preemphasis * wav[:-1]
+        S = stft(wav, n_fft=512, hop_length=160, win_length=400, window=np.hamming(400), center=False).T
+        spec_power = np.abs(S) ** 2
+        return np.log(spec_power.T.dot(mel * 32768 ** 2) + 1)
+
+    rng = np.random.default_rng(7)
+    out = dict(mel=window)
+    lens = [401, 560, 561, 562, 4000, 16401, 33333]
+    out["lens"] = np.asarray(lens)
+    for i, n in enumerate(lens):
+        wav = synth_wav(rng, n)
+        if i == 4:
+            wav[:] = 0.0  # all-zero input -> log(0+1) = 0 exactly
+        fb = logfbank(wav)
+        out["wav%d" % i] = wav
+        out["fbank%d" % i] = np.asarray(fb)
+        out["cmn%d" % i] = np.asarray(pre.cmn(fb, axis=0)).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fbank.npz"), **out)
+    print("fbank", {k: v.shape for k, v in out.items() if k.startswith("fbank")}, out["fbank0"].dtype)
+
+
+def gen_lstm():
+    lstm_mod = load_by_path("ref_lstm", "models/lstm.py")
+    out = {}
+    for tag, (D_in, P, H, Lr, bi, B, T) in dict(small=(20, 37, 64, 2, True, 3, 7),
+                                                uni=(16, 11, 64, 1, False, 2, 5)).items():
+        torch.manual_seed(0)
+        m = lstm_mod.LSTMAM(D_in, P, H, Lr, 0.0, bi)
+        x = torch.randn(B, T, D_in)
+        logits = m.output_layer(m.lstm(x)[0])
+        w = torch.randn(B, T, P)
+        (logits * w).sum().backward()
+        out[tag + "_cfg"] = np.asarray([D_in, P, H, Lr, int(bi), B, T])
+        out[tag + "_x"] = x.numpy()
+        out[tag + "_w"] = w.numpy()
+        out[tag + "_logits"] = logits.detach().numpy()
+        for k, v in m.state_dict().items():
+            out[tag + "_param_" + k] = v.numpy().copy()
+        for k, v in m.named_parameters():
+            out[tag + "_grad_" + k] = v.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "lstm.npz"), **out)
+    print("lstm keys", len(out))
+    # default-initialisation pin at the real size: a few weights of the 3x512 model after manual_seed(0)
+    torch.manual_seed(0)
+    m = lstm_mod.LSTMAM(80, 5768, 512, 3, 0.2, True)
+    sd = m.state_dict()
+    pin = {k: v.reshape(-1)[:16].numpy().copy() for k, v in sd.items()}
+    pin["__num_params"] = np.asarray(sum(v.numel() for v in sd.values()))
+    pin["__keys"] = np.asarray(list(sd.keys()))
+    np.savez_compressed(os.path.join(OUT, "lstm_init.npz"), **pin)
+
+
+def gen_ce_optim_misc():
+    utils = load_by_path("ref_utils", "utils/utils.py")
+    dl = load_by_path("ref_dataloader", "data/dataloader.py")
+    out = {}
+    # CrossEntropyLoss(ignore_index=-100), mean and sum (bin/train_ce.py:134; bin/train_se.py:214)
+    torch.manual_seed(1)
+    logits = (3 * torch.randn(23, 301)).requires_grad_()
+    tgt = torch.randint(0, 301, (23,))
+    tgt[[2, 9, 22]] = -100
+    for red in ("mean", "sum"):
+        logits.grad = None
+        loss = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction=red)(logits, tgt)
+        loss.backward()
+        out["ce_loss_" + red] = loss.detach().numpy()
+        out["ce_grad_" + red] = logits.grad.numpy().copy()
+    out["ce_logits"] = logits.detach().numpy()
+    out["ce_targets"] = tgt.numpy()
+    # noam_decay (utils/utils.py:49-53)
+    steps = np.asarray([1, 10, 3999, 4000, 4001, 100000])
+    out["noam_steps"] = steps
+    out["noam_lr"] = np.asarray([utils.noam_decay(int(s), 4000, 1e-3) for s in steps])
+    # Adam(amsgrad) + clip_grad_norm_ (bin/train_ce.py:123,195) and SGD(momentum) (bin/train_se.py:127)
+    torch.manual_seed(2)
+    p0 = torch.randn(1000)
+    grads = [torch.randn(1000) * s for s in (0.1, 3.0, 0.5)]
+    out["opt_p0"] = p0.numpy().copy()
+    out["opt_grads"] = np.stack([g.numpy() for g in grads])
+    for name, mk in dict(adam=lambda p: torch.optim.Adam([p], lr=1e-2, amsgrad=True),
+                         sgd=lambda p: torch.optim.SGD([p], lr=1e-2, momentum=0.9)).items():
+        p = torch.nn.Parameter(p0.clone())
+        opt = mk(p)
+        norms, traj = [], []
+        for g in grads:
+            opt.zero_grad()
+            p.grad = g.clone()
+            norms.append(float(torch.nn.utils.clip_grad_norm_([p], 5.0)))
+            opt.step()
+            traj.append(p.detach().numpy().copy())
+        out["opt_%s_norms" % name] = np.asarray(norms)
+        out["opt_%s_traj" % name] = np.stack(traj)
+    # SeqDataloader.collate_fn / ChunkDataloader.collate_fn (data/dataloader.py:55-63,94-136)
+    rng = np.random.default_rng(3)
+
+    class Dummy:
+        test_only = False
+    lens = [7, 5, 9]
+    feats = [rng.standard_normal((n, 80)).astype(np.float32) for n in lens]
+    labels = [rng.integers(0, 100, size=(n, 1)) for n in lens]
+    batch = [(f, "utt%d" % i, l, np.zeros((1, 3), dtype=np.int64)) for i, (f, l) in enumerate(zip(feats, labels))]
+    data = dl.SeqDataloader.collate_fn(Dummy(), batch)
+    out["collate_lens"] = np.asarray(lens)
+    out["collate_feats"] = np.concatenate(feats)
+    out["collate_labels"] = np.concatenate(labels)
+    out["collate_x"] = data["x"].numpy()
+    out["collate_y"] = data["y"].numpy()
+    out["collate_num_frs"] = np.asarray(data["num_frs"])
+    # frame subsampling of bin/train_chain.py:251-255 for epochs 0..2
+    x = data["x"]
+    for epoch in range(3):
+        shift = (epoch % 3) * -1
+        xs = torch.roll(x.to(torch.float32), shift, 1).unfold(1, 1, 3).squeeze(-1)
+        out["subsample_e%d" % epoch] = xs.numpy()
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+    print("misc keys", len(out))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_fbank()
+    gen_lstm()
+    gen_ce_optim_misc()
