@@ -1,0 +1,272 @@
+"""iRTF benchmark of the LF-MMI training step (BASELINE.json: 3x512 BLSTM LF-MMI, LibriSpeech-shaped
+utterances, batch 4 x var-len per GPU, train_chain.py semantics) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one minibatch of raw waveforms already resident in HBM:
+fbank+CMN+subsample -> 3x512 BLSTM forward -> LF-MMI (numerator + denominator forward-backward)
+-> BLSTM backward -> gradient all-reduce (N>1) -> Noam lr, global-norm clip, Adam(amsgrad).
+Weak scaling: every rank processes its own 4-utterance minibatch per step.
+The per-utterance supervision FSTs are built on the host before the timed region (the role of the
+reference's DataLoader workers / alignment tools); their upload to the GPU is inside the step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pykaldi2_amd import chain, fbank, hvd, lstm, ops, optim, synth, utils  # noqa: E402
+
+P = 6048            # configs/mmi.yaml label_size
+S_DEN, A_DEN = 30000, 1000000
+HBM_PEAK_GBS = 8000.0
+
+
+def make_batches(rng, n_unique, batch, device):
+    out = []
+    for _ in range(n_unique):
+        mb = synth.minibatch(rng, batch, P)
+        lens = [w.shape[0] for w, _ in mb]
+        wav = torch.from_numpy(np.concatenate([w for w, _ in mb])).to(device)
+        sups = [chain.Supervision(synth.numerator_fst_from_alignment(a), label_dim=P) for _, a in mb]
+        out.append(dict(wav=wav, lens=lens, sups=sups, seconds=sum(lens) / 16000.0, host=mb))
+    return out
+
+
+class Trainer:
+    def __init__(self, device, den, base_lr=1e-3, xent=0.1):
+        torch.manual_seed(0)
+        self.model = lstm.LSTMAM(80, P, 512, 3, 0.0, True).to(device)
+        self.base_opt = optim.Adam(self.model, lr=base_lr, amsgrad=True)
+        hvd.broadcast_parameters(self.model.state_dict(), root_rank=0)
+        self.opt = hvd.DistributedOptimizer(self.base_opt, named_parameters=self.model.named_parameters())
+        self.fb = fbank.FbankExtractor()
+        self.den = den
+        self.opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=xent)
+        self.base_lr = base_lr
+        self.step_no = 0
+        self.last = {}
+
+    def step(self, mb, epoch=0, events=None):
+        def mark(name):
+            if events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                events.append((name, e))
+        mark("start")
+        feats, frames, row_off = self.fb(mb["wav"], mb["lens"])
+        x = self.fb.pad_roll_subsample(feats, row_off, frames, shift=-(epoch % 3), subsample=3, time_major=True)
+        mark("fbank")
+        logits = self.model.forward_time_major(x)
+        mark("lstm_fwd")
+        loss = ops.ChainObjtiveBatch.apply(logits.transpose(0, 1), self.den, mb["sups"], self.opts)
+        mark("chain")
+        self.opt.zero_grad()
+        loss.backward()
+        mark("lstm_bwd")
+        self.step_no += 1
+        lr = utils.noam_decay(self.step_no, 4000, self.base_lr)
+        for grp in self.opt.param_groups:
+            grp["lr"] = lr
+        norm = optim.clip_grad_norm_(self.opt, 5.0)
+        self.opt.step()
+        mark("optim")
+        self.last = dict(loss=loss, norm=norm, logits=logits, frames=frames)
+        return loss
+
+
+def den_roofline(den, logits_bf, lens, reps=5):
+    """Times the denominator forward-backward (one C-ABI call = T forward + T backward frame kernels)
+    with events on the stream it is launched on.  Algorithmic bytes: SURVEY.md 8(d)."""
+    for _ in range(2):
+        chain.den_forward_backward(den, logits_bf, lens, 1e-4)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        chain.den_forward_backward(den, logits_bf, lens, 1e-4)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    Tsum, Tmax = int(sum(lens)), int(max(lens))
+    byts = Tsum * 4 * (3 * P + 2 * (S_DEN + 1)) + 24 * A_DEN * Tmax
+    ach = byts / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                traffic=None, kernel="den_fwd_step<4>+den_bwd_step<4> (one denominator forward-backward call)",
+                ms_per_launch=round(ms, 3), algorithmic_bytes=byts)
+
+
+def usable_cores():
+    """Cores this process may really use (affinity mask and cgroup quota), capped at 32."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline_worker(seed, threads):
+    """Runs in a child process (no HIP context, bounded by a timeout): the same step on the host.
+    numpy front end (oracle), the reference's torch CPU model path (nn.LSTM + nn.Linear,
+    models/lstm.py:45-54), the C port of the chain objective, Adam(amsgrad) + clip."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import chain_c, chain_ref, frontend_ref
+    torch.set_num_threads(threads)
+    g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
+    pi = chain_ref.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
+                                     g["prob"].astype(np.float64), 0)
+    rng = np.random.default_rng(seed)
+    host = synth.minibatch(rng, 4, P)
+    sups = [chain.Supervision(synth.numerator_fst_from_alignment(a), label_dim=P) for _, a in host]
+    seconds = sum(w.shape[0] for w, _ in host) / 16000.0
+    torch.manual_seed(0)
+    rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
+    lin = torch.nn.Linear(1024, P)
+    params = list(rnn.parameters()) + list(lin.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True)
+    mel = fbank.mel_filterbank()
+    t0 = time.time()
+    feats = [frontend_ref.cmn(frontend_ref.logfbank(w, mel)).astype(np.float32) for w, _ in host]
+    x = torch.from_numpy(frontend_ref.pad_roll_subsample(feats, 0, 3).copy())
+    logits = lin(rnn(x)[0])
+    out, grad = chain_c.chain_batch(g, pi, logits.detach().numpy(), sups, 1e-4, 0.1)
+    opt.zero_grad()
+    logits.backward(torch.from_numpy(-grad))
+    torch.nn.utils.clip_grad_norm_(params, 5.0)
+    opt.step()
+    dt = time.time() - t0
+    print(json.dumps(dict(value=round(seconds / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
+                          kind="port",
+                          sample="1 minibatch of 4 utterances (%.1f s audio): numpy fbank oracle + torch CPU 3x512 "
+                                 "BLSTM fwd/bwd + C port of the LF-MMI objective (OpenMP over sequences) + Adam; "
+                                 "%.1f s wall on %d threads" % (seconds, dt, threads))), flush=True)
+
+
+def cpu_baseline(seed, timeout=240):
+    import subprocess
+    threads = usable_cores()
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(seed), str(threads)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return dict(value=None, cores=threads, kind="port", sample="cpu baseline failed: " + r.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, cores=threads, kind="port", sample="cpu baseline exceeded %d s" % timeout)
+
+
+def log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.time()
+
+
+def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    hvd.init()
+    rank, world = hvd.rank(), hvd.size()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    dev = torch.device("cuda", hvd.local_rank())
+    torch.cuda.set_device(dev)
+
+    log("rank %d/%d: building synthetic den graph" % (rank, world))
+    g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
+    den = chain.DenominatorGraph(g, P)
+    log("den graph ready")
+    rng = np.random.default_rng(1234 + rank)
+    n_unique = min(args.steps + args.warmup, 8)
+    batches = make_batches(rng, n_unique, args.batch, dev)
+    log("%d minibatches ready" % n_unique)
+    tr = Trainer(dev, den)
+
+    for i in range(args.warmup):
+        tr.step(batches[i % n_unique])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    audio = 0.0
+    for i in range(args.steps):
+        mb = batches[(args.warmup + i) % n_unique]
+        tr.step(mb)
+        audio += mb["seconds"]
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    log("timed region done: %.3f s" % dt)
+    stats = torch.tensor([dt, audio], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        asum = stats[1:2].clone()
+        torch.distributed.all_reduce(asum, op=torch.distributed.ReduceOp.SUM)
+        dt, audio = float(tmax.item()), float(asum.item())
+    loss_val = float(tr.last["loss"].item())
+
+    if rank != 0:
+        hvd.shutdown()
+        return
+    # per-phase breakdown of one extra (untimed) step
+    events = []
+    mb = batches[0]
+    tr.step(mb, events=events)
+    torch.cuda.synchronize()
+    breakdown = {events[i][0]: round(events[i - 1][1].elapsed_time(events[i][1]), 3) for i in range(1, len(events))}
+    # roofline of the denominator forward-backward on this minibatch's logits
+    lens = [s.frames_per_sequence for s in mb["sups"]]
+    logits_bf = tr.last["logits"].detach().transpose(0, 1)
+    roof = den_roofline(den, logits_bf, lens)
+    log("roofline done")
+    result = {
+        "metric": "iRTF (hrs audio/hr) 3x512 BLSTM LF-MMI, LibriSpeech-shaped synthetic utterances",
+        "value": round(audio / dt, 2), "unit": "hours of audio per wall-clock hour",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
+        "pdf alignments, 30k-state/1M-arc denominator graph; random-init 3x512 BLSTM; supervision FSTs "
+        "prebuilt on the host)",
+        "config": {"workload": "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
+                               "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"
+                               % args.batch,
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P}},
+        "roofline": roof, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (child process, %d cores)" % usable_cores())
+        result["cpu_baseline"] = cpu_baseline(1234)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result), flush=True)
+    hvd.shutdown()
+
+
+if __name__ == "__main__":
+    main()

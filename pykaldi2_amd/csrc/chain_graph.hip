@@ -1,0 +1,281 @@
+// Denominator graph of the LF-MMI objective: host-side construction and C ABI (gfx950 library).
+//
+// Replaces kaldi.chain.DenominatorGraph (reference bin/train_chain.py:167,202): reads den.fst
+// (OpenFst binary) or arc arrays, computes initial_probs (Kaldi's 100-iteration rule, SURVEY.md
+// Appendix A.2) and lays the arcs out for the MI355X kernels of chain_den.hip: three orderings
+// (by destination for alpha, by source for beta, by pdf for the occupancies), each cut into
+// workgroup chunks of whole rows and stored lane-interleaved (chain_internal.h).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "chain_internal.h"
+
+namespace pk2 {
+
+// ----------------------------------------------------------------------------------------
+// host: graph construction
+// ----------------------------------------------------------------------------------------
+static void build_ordering(int64_t A, int num_rows, const int32_t* key, const int32_t* a,
+                           const int32_t* b, const float* prob, const float* piprob,
+                           HostOrdering* out) {
+  // counting sort by key (stable)
+  std::vector<int64_t> ptr(num_rows + 1, 0);
+  for (int64_t i = 0; i < A; ++i) ptr[key[i] + 1]++;
+  for (int r = 0; r < num_rows; ++r) ptr[r + 1] += ptr[r];
+  std::vector<int64_t> perm(A);
+  {
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < A; ++i) perm[cur[key[i]]++] = i;
+  }
+  out->arcs.clear(); out->meta.clear(); out->wb_off.assign(1, 0);
+  out->row0.clear(); out->nrows.clear(); out->atomic.clear();
+
+  struct Piece { int row; int64_t lo, hi; };  // arcs [lo,hi) of sorted list belong to `row`
+  auto emit_chunk = [&](const std::vector<Piece>& pieces, int row0, int nrows, int atomic) {
+    // sorted arcs of this chunk, each tagged with its chunk-local row
+    std::vector<int64_t> idx; std::vector<int> lrow;
+    for (const Piece& p : pieces) {
+      for (int64_t k = p.lo; k < p.hi; ++k) { idx.push_back(perm[k]); lrow.push_back(p.row - row0); }
+      // a row without arcs gets one null arc so that chunk-local rows stay consecutive
+      if (p.lo == p.hi) { idx.push_back(-1); lrow.push_back(p.row - row0); }
+    }
+    const int per_wb = 64 * kK;
+    int64_t n = (int64_t)idx.size();
+    int64_t padded = std::max<int64_t>(per_wb, (n + per_wb - 1) / per_wb * per_wb);
+    int last_row = nrows - 1;
+    int nwb = (int)(padded / per_wb);
+    size_t base_arc = out->arcs.size(), base_meta = out->meta.size();
+    out->arcs.resize(base_arc + padded);
+    out->meta.resize(base_meta + (size_t)nwb * 64);
+    for (int wb = 0; wb < nwb; ++wb) {
+      for (int lane = 0; lane < 64; ++lane) {
+        uint32_t mask = 0; int c0 = 0;
+        for (int j = 0; j < kK; ++j) {
+          int64_t s = (int64_t)wb * per_wb + (int64_t)lane * kK + j;
+          int4 rec; int row_here, row_next;
+          if (s < n && idx[s] < 0) {
+            rec.x = 0; rec.y = 0; rec.z = 0; rec.w = 0;
+            row_here = lrow[s];
+          } else if (s < n) {
+            int64_t i = idx[s];
+            rec.x = a[i]; rec.y = b[i];
+            rec.z = __builtin_bit_cast(int, prob[i]);
+            rec.w = __builtin_bit_cast(int, piprob[i]);
+            row_here = lrow[s];
+          } else {
+            rec.x = 0; rec.y = 0; rec.z = 0; rec.w = 0;  // null arc: contributes exactly 0
+            row_here = last_row;
+          }
+          row_next = (s + 1 < n) ? lrow[s + 1] : last_row;
+          if (j == 0) c0 = row_here;
+          if (j == kK - 1 || row_next != row_here) mask |= (1u << j);
+          out->arcs[base_arc + ((size_t)wb * kK + j) * 64 + lane] = rec;
+        }
+        out->meta[base_meta + (size_t)wb * 64 + lane] = (uint32_t)c0 | (mask << 16);
+      }
+    }
+    out->wb_off.push_back(out->wb_off.back() + nwb);
+    out->row0.push_back(row0);
+    out->nrows.push_back(nrows);
+    out->atomic.push_back(atomic);
+  };
+
+  std::vector<Piece> cur; int cur_row0 = 0; int64_t cur_arcs = 0;
+  auto flush = [&](int next_row) {
+    if (!cur.empty()) emit_chunk(cur, cur_row0, (int)cur.size(), 0);
+    cur.clear(); cur_arcs = 0; cur_row0 = next_row;
+  };
+  for (int r = 0; r < num_rows; ++r) {
+    int64_t lo = ptr[r], hi = ptr[r + 1], len = hi - lo;
+    if (len > kChunkArcs) {
+      flush(r);
+      for (int64_t s = lo; s < hi; s += kChunkArcs) {
+        std::vector<Piece> one{{r, s, std::min(hi, s + kChunkArcs)}};
+        emit_chunk(one, r, 1, 1);
+      }
+      cur_row0 = r + 1;
+      continue;
+    }
+    const int64_t len_eff = std::max<int64_t>(len, 1);  // empty rows carry one null arc
+    if (cur_arcs + len_eff > kChunkArcs || (int)cur.size() + 1 > kMaxRows) flush(r);
+    cur.push_back({r, lo, hi});
+    cur_arcs += len_eff;
+  }
+  flush(num_rows);
+  out->n_chunks = (int)out->row0.size();
+}
+
+static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src, const int32_t* dst,
+                       const int32_t* pdf, const float* prob, int32_t start, pk2_den_graph** out) {
+  PK2_REQUIRE(S > 0 && P > 0 && A > 0 && start >= 0 && start < S, "den graph: bad sizes");
+  PK2_REQUIRE(P <= 65536, "den graph: num_pdfs %d > 65536 unsupported", P);
+  for (int64_t i = 0; i < A; ++i) {
+    PK2_REQUIRE(src[i] >= 0 && src[i] < S && dst[i] >= 0 && dst[i] < S && pdf[i] >= 0 && pdf[i] < P,
+                "den graph: arc %lld out of range", (long long)i);
+  }
+  auto* g = new pk2_den_graph();
+  g->S = S; g->P = P; g->A = A; g->start = start;
+  // initial_probs: Kaldi DenominatorGraph::SetInitialProbs: 100 iterations
+  // of the normalised forward recursion from the start state, averaged (double precision).
+  {
+    std::vector<double> cur(S, 0.0), nxt(S), avg(S, 0.0);
+    cur[start] = 1.0;
+    const int iters = 100;
+    for (int it = 0; it < iters; ++it) {
+      for (int s = 0; s < S; ++s) avg[s] += cur[s] / iters;
+      std::fill(nxt.begin(), nxt.end(), 0.0);
+      for (int64_t i = 0; i < A; ++i) nxt[dst[i]] += cur[src[i]] * (double)prob[i];
+      double tot = 0.0;
+      for (int s = 0; s < S; ++s) tot += nxt[s];
+      for (int s = 0; s < S; ++s) cur[s] = nxt[s] / tot;
+    }
+    g->pi.resize(S);
+    double ps = 0.0;
+    for (int s = 0; s < S; ++s) { g->pi[s] = (float)avg[s]; ps += (double)g->pi[s]; }
+    g->pi_sum = ps;
+  }
+  std::vector<float> piprob(A);
+  for (int64_t i = 0; i < A; ++i) piprob[i] = g->pi[src[i]] * prob[i];
+  build_ordering(A, S, dst, src, pdf, prob, piprob.data(), &g->h_fwd);   // alpha: rows = dst
+  build_ordering(A, S, src, dst, pdf, prob, piprob.data(), &g->h_bwd);   // beta : rows = src
+  build_ordering(A, P, pdf, src, dst, prob, piprob.data(), &g->h_gam);   // gamma: rows = pdf
+  *out = g;
+  return PK2_OK;
+}
+
+template <typename T>
+static int upload_vec(pk2_den_graph* g, const std::vector<T>& v, const T** dptr) {
+  void* d = nullptr;
+  PK2_HIP(hipMalloc(&d, std::max<size_t>(16, v.size() * sizeof(T))));
+  g->allocs.push_back(d);
+  if (!v.empty()) PK2_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dptr = static_cast<const T*>(d);
+  return PK2_OK;
+}
+
+static int upload_ordering(pk2_den_graph* g, const HostOrdering& h, DevOrdering* d) {
+  int rc;
+  if ((rc = upload_vec(g, h.arcs, &d->arcs))) return rc;
+  if ((rc = upload_vec(g, h.meta, &d->meta))) return rc;
+  if ((rc = upload_vec(g, h.wb_off, &d->wb_off))) return rc;
+  if ((rc = upload_vec(g, h.row0, &d->row0))) return rc;
+  if ((rc = upload_vec(g, h.nrows, &d->nrows))) return rc;
+  if ((rc = upload_vec(g, h.atomic, &d->atomic))) return rc;
+  d->n_chunks = h.n_chunks;
+  return PK2_OK;
+}
+
+int den_upload(pk2_den_graph* g) {
+  if (g->uploaded) return PK2_OK;
+  int rc;
+  PK2_HIP(hipGetDevice(&g->device));
+  if ((rc = upload_ordering(g, g->h_fwd, &g->fwd))) return rc;
+  if ((rc = upload_ordering(g, g->h_bwd, &g->bwd))) return rc;
+  if ((rc = upload_ordering(g, g->h_gam, &g->gam))) return rc;
+  const float* dpi = nullptr;
+  if ((rc = upload_vec(g, g->pi, &dpi))) return rc;
+  g->d_pi = const_cast<float*>(dpi);
+  g->uploaded = true;
+  return PK2_OK;
+}
+
+}  // namespace pk2
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+using namespace pk2;
+
+extern "C" int pk2_den_graph_create(int32_t num_states, int32_t num_pdfs, int64_t num_arcs,
+                                    const int32_t* arc_src, const int32_t* arc_dst,
+                                    const int32_t* arc_pdf, const float* arc_prob,
+                                    int32_t start_state, pk2_den_graph** out) {
+  PK2_REQUIRE(arc_src && arc_dst && arc_pdf && arc_prob && out, "den graph: null pointer");
+  return build_graph(num_states, num_pdfs, num_arcs, arc_src, arc_dst, arc_pdf, arc_prob,
+                     start_state, out);
+}
+
+// OpenFst binary StdVectorFst: header, optional symbol tables are not
+// supported (Kaldi writes den.fst without them), then per state {f32 final, i64 narcs,
+// arcs {i32 ilabel, i32 olabel, f32 weight, i32 nextstate}}.
+extern "C" int pk2_den_graph_from_openfst(const char* path, int32_t num_pdfs, pk2_den_graph** out) {
+  PK2_REQUIRE(path && out, "den graph: null pointer");
+  FILE* f = fopen(path, "rb");
+  if (!f) { set_error("cannot open %s", path); return PK2_ERR_IO; }
+  auto fail = [&](const char* why) { fclose(f); set_error("%s: %s", path, why); return (int)PK2_ERR_IO; };
+  auto rd = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
+  int32_t magic;
+  if (!rd(&magic, 4) || magic != 2125659606) return fail("bad magic");
+  auto rdstr = [&](std::string* s) {
+    int32_t n;
+    if (!rd(&n, 4) || n < 0 || n > 4096) return false;
+    s->resize(n);
+    return n == 0 || rd(&(*s)[0], n);
+  };
+  std::string fst_type, arc_type;
+  if (!rdstr(&fst_type) || !rdstr(&arc_type)) return fail("bad header");
+  if (fst_type != "vector" || arc_type != "standard") return fail("not a vector/standard FST");
+  int32_t version, flags; uint64_t props; int64_t start, nstates, narcs_hdr;
+  if (!rd(&version, 4) || !rd(&flags, 4) || !rd(&props, 8) || !rd(&start, 8) || !rd(&nstates, 8) ||
+      !rd(&narcs_hdr, 8))
+    return fail("short header");
+  if (flags & 3) return fail("embedded symbol tables are not supported");
+  if (nstates <= 0 || nstates > (1 << 30)) return fail("bad state count");
+  std::vector<int32_t> src, dst, pdf; std::vector<float> prob;
+  for (int64_t s = 0; s < nstates; ++s) {
+    float fin; int64_t na;
+    if (!rd(&fin, 4) || !rd(&na, 8) || na < 0) return fail("truncated state");
+    for (int64_t k = 0; k < na; ++k) {
+      int32_t il, ol, ns; float w;
+      if (!rd(&il, 4) || !rd(&ol, 4) || !rd(&w, 4) || !rd(&ns, 4)) return fail("truncated arc");
+      if (il <= 0) return fail("epsilon / negative ilabel in den.fst");
+      src.push_back((int32_t)s); dst.push_back(ns); pdf.push_back(il - 1); prob.push_back(expf(-w));
+    }
+  }
+  fclose(f);
+  return build_graph((int32_t)nstates, num_pdfs, (int64_t)src.size(), src.data(), dst.data(),
+                     pdf.data(), prob.data(), (int32_t)start, out);
+}
+
+extern "C" int pk2_den_graph_destroy(pk2_den_graph* g) {
+  if (!g) return PK2_OK;
+  for (void* p : g->allocs) (void)hipFree(p);
+  delete g;
+  return PK2_OK;
+}
+
+extern "C" int pk2_den_graph_info(const pk2_den_graph* g, int32_t* num_states, int32_t* num_pdfs,
+                                  int64_t* num_arcs) {
+  PK2_REQUIRE(g, "den graph: null handle");
+  if (num_states) *num_states = g->S;
+  if (num_pdfs) *num_pdfs = g->P;
+  if (num_arcs) *num_arcs = g->A;
+  return PK2_OK;
+}
+
+extern "C" int pk2_den_graph_initial_probs(const pk2_den_graph* g, float* host_out) {
+  PK2_REQUIRE(g && host_out, "den graph: null pointer");
+  memcpy(host_out, g->pi.data(), g->pi.size() * sizeof(float));
+  return PK2_OK;
+}
+
+// Test hook: copies one host-side ordering out (which: 0 = by dst, 1 = by src, 2 = by pdf).
+// Sizes are queried by passing null buffers.
+extern "C" int pk2_den_graph_debug_ordering(const pk2_den_graph* g, int which, int64_t* n_arcs_padded,
+                                            int32_t* n_chunks, int32_t* arcs_out /* int4 */,
+                                            uint32_t* meta_out, int32_t* wb_off_out,
+                                            int32_t* row0_out, int32_t* nrows_out,
+                                            int32_t* atomic_out) {
+  PK2_REQUIRE(g && which >= 0 && which < 3, "debug ordering: bad args");
+  const HostOrdering& h = which == 0 ? g->h_fwd : (which == 1 ? g->h_bwd : g->h_gam);
+  if (n_arcs_padded) *n_arcs_padded = (int64_t)h.arcs.size();
+  if (n_chunks) *n_chunks = h.n_chunks;
+  if (arcs_out) memcpy(arcs_out, h.arcs.data(), h.arcs.size() * sizeof(int4));
+  if (meta_out) memcpy(meta_out, h.meta.data(), h.meta.size() * sizeof(uint32_t));
+  if (wb_off_out) memcpy(wb_off_out, h.wb_off.data(), h.wb_off.size() * sizeof(int32_t));
+  if (row0_out) memcpy(row0_out, h.row0.data(), h.row0.size() * sizeof(int32_t));
+  if (nrows_out) memcpy(nrows_out, h.nrows.data(), h.nrows.size() * sizeof(int32_t));
+  if (atomic_out) memcpy(atomic_out, h.atomic.data(), h.atomic.size() * sizeof(int32_t));
+  return PK2_OK;
+}

@@ -20,9 +20,10 @@ namespace pk2 {
 //    then c++" (set where a row ends and at j = kK-1).
 constexpr int kK = 8;
 constexpr int kChunkArcs = 4096;
-constexpr int kMaxRows = 2048;
-constexpr int kDenThreads = 512;
-constexpr int kDenWaves = kDenThreads / 64;
+constexpr int kMaxRows = 1024;
+constexpr int kDenWaves = 8;                       // wavefronts working on one chunk
+constexpr int kDenThreads = kDenWaves * 64;        // forward: one chunk per workgroup
+constexpr int kDenBwdThreads = 2 * kDenThreads;    // backward: a beta chunk and a gamma chunk per workgroup
 
 struct HostOrdering {
   std::vector<int4> arcs;        // {a, b, prob bits, pi*prob bits}

@@ -2,15 +2,19 @@
 //
 // Replaces the cuDNN RNN under nn.LSTM (reference models/lstm.py:49-58): gate order i,f,g,o,
 // h0 = c0 = 0, every sequence runs over all T frames (the reference does not pack, so padding
-// frames are processed too).  The input projections (x W_ih^T + b_ih + b_hh for all frames) and
-// all weight gradients are large GEMMs done by pk2_gemm_f32; this file is the serial part.
+// frames are processed too).  The input projections (x W_ih^T + b_ih for all frames) and all
+// weight gradients are large GEMMs done by pk2_gemm_f32; this file is the serial part.
 //
-// One launch per time step, both directions in the same launch (blockIdx.y).  The recurrent
-// product h_{t-1} W_hh^T runs on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32):
+// One kernel launch per time step, both directions in the same launch (blockIdx.y); the T
+// launches of a layer are replayed from cached hipGraphs (step_graph.h), so the host is not in
+// the loop.  The recurrent product h_{t-1} W_hh^T runs on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact f32):
 //  * forward: a workgroup owns 4 hidden units = 16 gate rows (one 16-wide MFMA N tile); its 4
 //    wavefronts split K = H, each holding its slice of those 16 W_hh rows in 32 VGPRs; batch rows
 //    are the MFMA M dimension (tiles of 16); partial tiles meet in LDS, then the gate
-//    activations, c_t and h_t are computed in the same kernel (fused pointwise).
+//    activations, c_t and h_t are computed in the same kernel (fused pointwise).  The pointwise
+//    operands (input projection, bias, c_{t-1}) are fetched before the MFMA phase so their
+//    latency hides behind it.
 //  * backward: a workgroup owns 16 hidden units (N tile) and splits K = 4H over 16 wavefronts;
 //    d h_{t-1} = dgates_t W_hh is fused with the gate derivative of step t-1.
 // W_hh slices are re-read from L2 every step (4 MB per direction stays L2 resident; each
@@ -19,6 +23,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "step_graph.h"
 
 namespace pk2 {
 
@@ -43,8 +48,12 @@ struct LstmFwdParams {
 
 // KS = number of 4-wide MFMA k-steps per wave (H / 4 waves / 4).
 template <int KS>
-__global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(LstmFwdParams p, int step) {
+__global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams* __restrict__ pp,
+                                                             const StepCounter* __restrict__ cnt, int local) {
   __shared__ float part[4][16][17];   // per-wave partial 16x16 tiles (padded)
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const LstmFwdParams p = *pp;
   const int d = blockIdx.y;
   const int u0 = blockIdx.x * kFwdUnits;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -55,7 +64,7 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(LstmFwdParams p, in
   const int li = lane & 15, kq = lane >> 4;
 
   // B operand: column j = li -> gate g = j/4, unit u0 + j%4 -> row g*H + u0 + j%4 of W_hh[d]
-  f32x4 wf[KS / 4 > 0 ? KS / 4 : 1];
+  f32x4 wf[KS / 4];
   const int kbase = w * (KS * 4) + kq * KS;   // this lane's contiguous k-run of length KS
   if (!first) {
     const float* wrow = p.whh + ((size_t)d * 4 * H + (size_t)(li >> 2) * H + u0 + (li & 3)) * H + kbase;
@@ -64,10 +73,25 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(LstmFwdParams p, in
   }
   const size_t yrow = (size_t)D * H;
   for (int mt = 0; mt < (B + 15) / 16; ++mt) {
+    // pointwise operands of thread (i = batch row in tile, u = unit), fetched early
+    const int pi_ = tid >> 2, pu = tid & 3;
+    const int pb = mt * 16 + pi_;
+    const bool pw_active = tid < 64 && pb < B;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    float cprev = 0.f;
+    if (pw_active) {
+      const float* gxr = p.gx + ((size_t)t * B + pb) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + pu;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pre[g] = gxr[(size_t)g * H];
+        if (p.bhh) pre[g] += p.bhh[(size_t)d * 4 * H + (size_t)g * H + u0 + pu];
+      }
+      if (!first) cprev = p.cells[(((size_t)d * T + tp) * B + pb) * H + u0 + pu];
+    }
     if (!first) {
       const int b = mt * 16 + li;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 af[KS / 4 > 0 ? KS / 4 : 1];
+      f32x4 af[KS / 4];
       if (b < B) {
         const float* hrow = p.y + ((size_t)tp * B + b) * yrow + (size_t)d * H + kbase;
 #pragma unroll
@@ -88,30 +112,20 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(LstmFwdParams p, in
       for (int r = 0; r < 4; ++r) part[w][kq * 4 + r][li] = acc0[r] + acc1[r];
     }
     __syncthreads();
-    // fused gates: thread (i = batch row in tile, u = unit) for tid < 64
-    if (tid < 64) {
-      const int i = tid >> 2, u = tid & 3;
-      const int b = mt * 16 + i;
-      if (b < B) {
-        float pre[4];
-        const float* gxr = p.gx + ((size_t)t * B + b) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + u;
+    if (pw_active) {
+      if (!first) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float s = gxr[(size_t)g * H];
-          if (p.bhh) s += p.bhh[(size_t)d * 4 * H + (size_t)g * H + u0 + u];
-          if (!first) s += (part[0][i][g * 4 + u] + part[1][i][g * 4 + u]) + (part[2][i][g * 4 + u] + part[3][i][g * 4 + u]);
-          pre[g] = s;
-        }
-        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-        const size_t cidx = (((size_t)d * T + t) * B + b) * H + u0 + u;
-        const float cprev = first ? 0.f : p.cells[(((size_t)d * T + tp) * B + b) * H + u0 + u];
-        const float c = fg * cprev + ig * gg;
-        const float h = og * tanhf(c);
-        p.cells[cidx] = c;
-        p.y[((size_t)t * B + b) * yrow + (size_t)d * H + u0 + u] = h;
-        float* gr = p.gates + (((size_t)d * T + t) * B + b) * 4 * H + u0 + u;
-        gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
+        for (int g = 0; g < 4; ++g)
+          pre[g] += (part[0][pi_][g * 4 + pu] + part[1][pi_][g * 4 + pu]) +
+                    (part[2][pi_][g * 4 + pu] + part[3][pi_][g * 4 + pu]);
       }
+      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      const float c = fg * cprev + ig * gg;
+      const float h = og * tanhf(c);
+      p.cells[(((size_t)d * T + t) * B + pb) * H + u0 + pu] = c;
+      p.y[((size_t)t * B + pb) * yrow + (size_t)d * H + u0 + pu] = h;
+      float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
+      gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
     }
     __syncthreads();
   }
@@ -129,8 +143,12 @@ struct LstmBwdParams {
 
 // KS = 4-wide MFMA k-steps per wave (4H / 16 waves / 4).
 template <int KS>
-__global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(LstmBwdParams p, int step) {
+__global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams* __restrict__ pp,
+                                                             const StepCounter* __restrict__ cnt, int local) {
   __shared__ float part[16][16][17];
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const LstmBwdParams p = *pp;
   const int d = blockIdx.y;
   const int k0 = blockIdx.x * kBwdUnits;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -145,7 +163,7 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(LstmBwdParams p, in
   const int li = lane & 15, kq = lane >> 4;
   const int G4 = 4 * H;
 
-  f32x4 wf[KS / 4 > 0 ? KS / 4 : 1];
+  f32x4 wf[KS / 4];
   const int rbase = w * (KS * 4) + kq * KS;        // run of gate rows r handled by this lane
   if (!last_fwd) {
     const float* wrow = p.whhT + ((size_t)d * H + k0 + li) * G4 + rbase;
@@ -153,10 +171,23 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(LstmBwdParams p, in
     for (int q = 0; q < KS / 4; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + q * 4);
   }
   for (int mt = 0; mt < (B + 15) / 16; ++mt) {
+    // pointwise operands of thread (i, j) fetched before the MFMA phase
+    const int pi_ = tid >> 4, pj = tid & 15;
+    const int pb = mt * 16 + pi_, pk = k0 + pj;
+    const bool pw_active = tid < 256 && pb < B;
+    float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dcin = 0.f;
+    if (pw_active) {
+      dh = p.dy[((size_t)t * B + pb) * ((size_t)D * H) + (size_t)d * H + pk];
+      const float* gr = p.gates + (((size_t)d * T + t) * B + pb) * G4 + pk;
+      ig = gr[0]; fg = gr[(size_t)H]; gg = gr[(size_t)2 * H]; og = gr[(size_t)3 * H];
+      c = p.cells[(((size_t)d * T + t) * B + pb) * H + pk];
+      if (!first_fwd) cprev = p.cells[(((size_t)d * T + tp) * B + pb) * H + pk];
+      if (!last_fwd) dcin = p.dc[((size_t)d * B + pb) * H + pk];
+    }
     if (!last_fwd) {
       const int b = mt * 16 + li;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 af[KS / 4 > 0 ? KS / 4 : 1];
+      f32x4 af[KS / 4];
       if (b < B) {
         const float* grow = p.dgx + ((size_t)tn * B + b) * ((size_t)D * G4) + (size_t)d * G4 + rbase;
 #pragma unroll
@@ -176,31 +207,21 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(LstmBwdParams p, in
       for (int r = 0; r < 4; ++r) part[w][kq * 4 + r][li] = acc0[r] + acc1[r];
     }
     __syncthreads();
-    if (tid < 256) {
-      const int i = tid >> 4, j = tid & 15;
-      const int b = mt * 16 + i, k = k0 + j;
-      if (b < B) {
-        float dh = p.dy[((size_t)t * B + b) * ((size_t)D * H) + (size_t)d * H + k];
-        if (!last_fwd) {
-          float s = 0.f;
+    if (pw_active) {
+      if (!last_fwd) {
+        float s = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < 16; ++ww) s += part[ww][i][j];
-          dh += s;
-        }
-        const float* gr = p.gates + (((size_t)d * T + t) * B + b) * G4 + k;
-        const float ig = gr[0], fg = gr[(size_t)H], gg = gr[(size_t)2 * H], og = gr[(size_t)3 * H];
-        const float c = p.cells[(((size_t)d * T + t) * B + b) * H + k];
-        const float cprev = first_fwd ? 0.f : p.cells[(((size_t)d * T + tp) * B + b) * H + k];
-        const float tc = tanhf(c);
-        float* dcp = p.dc + ((size_t)d * B + b) * H + k;
-        const float dcv = (last_fwd ? 0.f : *dcp) + dh * og * (1.f - tc * tc);
-        *dcp = dcv * fg;
-        float* o = p.dgx + ((size_t)t * B + b) * ((size_t)D * G4) + (size_t)d * G4 + k;
-        o[0] = dcv * gg * ig * (1.f - ig);
-        o[(size_t)H] = dcv * cprev * fg * (1.f - fg);
-        o[(size_t)2 * H] = dcv * ig * (1.f - gg * gg);
-        o[(size_t)3 * H] = dh * tc * og * (1.f - og);
+        for (int ww = 0; ww < 16; ++ww) s += part[ww][pi_][pj];
+        dh += s;
       }
+      const float tc = tanhf(c);
+      const float dcv = dcin + dh * og * (1.f - tc * tc);
+      p.dc[((size_t)d * B + pb) * H + pk] = dcv * fg;
+      float* o = p.dgx + ((size_t)t * B + pb) * ((size_t)D * G4) + (size_t)d * G4 + pk;
+      o[0] = dcv * gg * ig * (1.f - ig);
+      o[(size_t)H] = dcv * cprev * fg * (1.f - fg);
+      o[(size_t)2 * H] = dcv * ig * (1.f - gg * gg);
+      o[(size_t)3 * H] = dh * tc * og * (1.f - og);
     }
     __syncthreads();
   }
@@ -220,27 +241,46 @@ __global__ void __launch_bounds__(256) transpose_whh(const float* __restrict__ w
   for (int k = ty; k < 32; k += 8) dst[(size_t)(k0 + k) * 4 * H + r0 + tx] = tile[tx][k];
 }
 
+static StepGraphs g_graphs;
+static std::map<std::pair<int, hipStream_t>, ParamSlot<LstmFwdParams>> g_fwd_slots;
+static std::map<std::pair<int, hipStream_t>, ParamSlot<LstmBwdParams>> g_bwd_slots;
+
+template <typename K, typename P>
+static void launch_step(K kernel, dim3 grid, dim3 block, hipStream_t s, const P* pb, const StepCounter* c, int j) {
+  hipLaunchKernelGGL(kernel, grid, block, 0, s, pb, c, j);
+}
+
 }  // namespace pk2
 
 using namespace pk2;
 
+static bool lstm_h_ok(int H) { return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024; }
+
 extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float* bhh, int32_t B, int32_t T,
                                   int32_t H, int32_t D, float* y, float* gates, float* cells, void* stream_) {
   PK2_REQUIRE(gx && whh && y && gates && cells && B > 0 && T > 0 && (D == 1 || D == 2), "lstm_fwd: bad args");
-  PK2_REQUIRE(H % 64 == 0 && (H == 512 || H == 256 || H == 128 || H == 64 || H == 1024),
-              "lstm_fwd: hidden size %d unsupported (64,128,256,512,1024)", H);
+  PK2_REQUIRE(lstm_h_ok(H), "lstm_fwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ParamSlot<LstmFwdParams>* slot;
+  int rc = get_param_slot(g_fwd_slots, H * 4 + D, stream, &slot);
+  if (rc) return rc;
   LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D};
+  hipLaunchKernelGGL(param_block_store<LstmFwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
   dim3 grid(H / kFwdUnits, D), block(kFwdThreads);
-  for (int s = 0; s < T; ++s) {
+  const LstmFwdParams* pb = slot->params;
+  const StepCounter* c = slot->counter;
+  char key[64];
+  snprintf(key, sizeof(key), "lstm_fwd_H%d_D%d_%p", H, D, (void*)stream);
+  rc = g_graphs.run(key, T, slot->counter, stream, [&](hipStream_t s, int j) {
     switch (H) {
-      case 64: hipLaunchKernelGGL(lstm_fwd_step<4>, grid, block, 0, stream, p, s); break;
-      case 128: hipLaunchKernelGGL(lstm_fwd_step<8>, grid, block, 0, stream, p, s); break;
-      case 256: hipLaunchKernelGGL(lstm_fwd_step<16>, grid, block, 0, stream, p, s); break;
-      case 512: hipLaunchKernelGGL(lstm_fwd_step<32>, grid, block, 0, stream, p, s); break;
-      default: hipLaunchKernelGGL(lstm_fwd_step<64>, grid, block, 0, stream, p, s); break;
+      case 64: launch_step(lstm_fwd_step<4>, grid, block, s, pb, c, j); break;
+      case 128: launch_step(lstm_fwd_step<8>, grid, block, s, pb, c, j); break;
+      case 256: launch_step(lstm_fwd_step<16>, grid, block, s, pb, c, j); break;
+      case 512: launch_step(lstm_fwd_step<32>, grid, block, s, pb, c, j); break;
+      default: launch_step(lstm_fwd_step<64>, grid, block, s, pb, c, j); break;
     }
-  }
+  });
+  if (rc) return rc;
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
@@ -254,23 +294,31 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
                                   void* stream_) {
   PK2_REQUIRE(dy && whh && gates && cells && dgx && scratch && B > 0 && T > 0 && (D == 1 || D == 2),
               "lstm_bwd: bad args");
-  PK2_REQUIRE(H % 64 == 0 && (H == 512 || H == 256 || H == 128 || H == 64 || H == 1024),
-              "lstm_bwd: hidden size %d unsupported (64,128,256,512,1024)", H);
+  PK2_REQUIRE(lstm_h_ok(H), "lstm_bwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* whhT = scratch;
   float* dc = scratch + (size_t)D * H * 4 * H;
   hipLaunchKernelGGL(transpose_whh, dim3(H / 32, 4 * H / 32, D), dim3(256), 0, stream, whh, whhT, H);
+  ParamSlot<LstmBwdParams>* slot;
+  int rc = get_param_slot(g_bwd_slots, H * 4 + D, stream, &slot);
+  if (rc) return rc;
   LstmBwdParams p{dy, whhT, gates, cells, dgx, dc, B, T, H, D};
+  hipLaunchKernelGGL(param_block_store<LstmBwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
   dim3 grid(H / kBwdUnits, D), block(kBwdThreads);
-  for (int s = 0; s < T; ++s) {
+  const LstmBwdParams* pb = slot->params;
+  const StepCounter* c = slot->counter;
+  char key[64];
+  snprintf(key, sizeof(key), "lstm_bwd_H%d_D%d_%p", H, D, (void*)stream);
+  rc = g_graphs.run(key, T, slot->counter, stream, [&](hipStream_t s, int j) {
     switch (H) {
-      case 64: hipLaunchKernelGGL(lstm_bwd_step<4>, grid, block, 0, stream, p, s); break;
-      case 128: hipLaunchKernelGGL(lstm_bwd_step<8>, grid, block, 0, stream, p, s); break;
-      case 256: hipLaunchKernelGGL(lstm_bwd_step<16>, grid, block, 0, stream, p, s); break;
-      case 512: hipLaunchKernelGGL(lstm_bwd_step<32>, grid, block, 0, stream, p, s); break;
-      default: hipLaunchKernelGGL(lstm_bwd_step<64>, grid, block, 0, stream, p, s); break;
+      case 64: launch_step(lstm_bwd_step<4>, grid, block, s, pb, c, j); break;
+      case 128: launch_step(lstm_bwd_step<8>, grid, block, s, pb, c, j); break;
+      case 256: launch_step(lstm_bwd_step<16>, grid, block, s, pb, c, j); break;
+      case 512: launch_step(lstm_bwd_step<32>, grid, block, s, pb, c, j); break;
+      default: launch_step(lstm_bwd_step<64>, grid, block, s, pb, c, j); break;
     }
-  }
+  });
+  if (rc) return rc;
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

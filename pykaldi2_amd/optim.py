@@ -37,7 +37,7 @@ class _FlatOptimizer:
     def measure_grad_norm(self, max_norm):
         p, g = self._flat()
         L = _lib.lib()
-        if self._norm is None or self._norm.device != g.device:
+        if getattr(self, "_norm_buf", None) is None or self._norm_buf.device != g.device:
             self._norm_buf = torch.empty(1, dtype=torch.float32, device=g.device)
         if self._ws is None or self._ws.device != g.device:
             self._ws = torch.empty(L.pk2_grad_norm_workspace_bytes(g.numel()), dtype=torch.uint8, device=g.device)

@@ -1,0 +1,114 @@
+"""HIP LF-MMI kernels against the CPU oracle (through the C ABI).  Tolerances: objective 1e-3 rel
+(north star), occupancies / gradient 1e-4 abs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain_ref as R
+from pykaldi2_amd import chain, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(S, A, P, seed):
+    g = synth.den_graph_arcs(S, A, P, seed)
+    return g, chain.DenominatorGraph(g, P), R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, P)
+
+
+@pytest.mark.parametrize("S,A,P,lens,leaky", [
+    (8, 30, 5, [6], 1e-2),
+    (200, 3000, 40, [51, 17, 33], 1e-4),
+    (2000, 60000, 600, [101, 80, 57, 90, 13], 1e-4),     # 5 sequences -> two groups of 4
+    (200, 20000, 11, [40, 25], 1e-3),                      # forces split ("atomic") rows
+])
+def test_denominator_matches_oracle(S, A, P, lens, leaky):
+    g, G, ref = _mk(S, A, P, seed=S)
+    if A == 20000:
+        g["dst"][:6000] = 5
+        G = chain.DenominatorGraph(g, P)
+        ref = R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, P)
+    rng = np.random.default_rng(1)
+    T = max(lens)
+    lg = rng.normal(0, 3, size=(len(lens), T, P)).astype(np.float32)
+    lg[0, 0, 0] = 45.0   # exercises the +-30 clamp
+    x = torch.from_numpy(lg).cuda()
+    lp, gamma = chain.den_forward_backward(G, x, lens, leaky)
+    lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, _ = R.den_forward_backward(lg[n, :Tn].astype(np.float64), ref, leaky)
+        assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp) + 1e-4, (n, lp[n], want_lp)
+        err = np.abs(gamma[n, :Tn] - want_g).max()
+        assert err < 1e-4, (n, err)
+        assert np.abs(gamma[n, :Tn].sum(1) - 1).max() < 1e-4
+        assert not gamma[n, Tn:].any()
+
+
+def _sup(ali, P):
+    return chain.Supervision(synth.numerator_fst_from_alignment(ali), label_dim=P)
+
+
+def _ref_fst(s):
+    return R.NumFstRef(s.num_states, s.src, s.dst, s.pdf, s.arc_weight, s.final_states, s.final_weights, s.state_time)
+
+
+@pytest.mark.parametrize("xent", [0.0, 0.1])
+def test_chain_objf_and_deriv_matches_oracle(xent):
+    S, A, P = 2000, 60000, 600
+    g, G, ref = _mk(S, A, P, seed=11)
+    rng = np.random.default_rng(3)
+    frames = [301, 160, 250, 90]
+    sups = [_sup(synth.pdf_alignment(rng, T, P), P) for T in frames]
+    lens = [s.frames_per_sequence for s in sups]
+    Tm = max(lens)
+    lg = rng.normal(0, 2, size=(4, Tm + 3, P)).astype(np.float32)
+    # time-major storage exposed batch-first (what LSTMAM.forward_time_major().transpose gives)
+    x = torch.from_numpy(lg).cuda().transpose(0, 1).contiguous().transpose(0, 1)
+    opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=xent)
+    out, grad = chain.compute_chain_objf_and_deriv(opts, G, sups, x)
+    out, grad = out.cpu().numpy(), grad.cpu().numpy()
+    for n in range(4):
+        objf, want, aux = R.chain_objf_and_deriv(lg[n, :lens[n]].astype(np.float64), ref, _ref_fst(sups[n]),
+                                                 leaky=1e-4, xent_regularize=xent)
+        assert abs(out[1, n] - aux["num"]) <= 1e-3 * abs(aux["num"]), (n, out[1, n], aux["num"])
+        assert abs(out[2, n] - aux["den"]) <= 1e-3 * abs(aux["den"]), (n, out[2, n], aux["den"])
+        assert abs(out[0, n] - objf) <= 1e-3 * abs(objf), (n, out[0, n], objf)
+        assert np.abs(grad[n, :lens[n]] - want).max() < 1e-4, (n, np.abs(grad[n, :lens[n]] - want).max())
+        assert not grad[n, lens[n]:].any()
+
+
+def test_reference_operator_convention_and_nan_guard():
+    """ChainObjtiveFunction returns +objf and hands -grad to autograd whatever grad_out is
+    (reference ops/ops.py:273-280); a NaN logit zeroes that sequence's gradient and gives -10/frame."""
+    S, A, P = 200, 3000, 40
+    g, G, ref = _mk(S, A, P, seed=5)
+    rng = np.random.default_rng(4)
+    sup = _sup(synth.pdf_alignment(rng, 91, P), P)
+    T = sup.frames_per_sequence
+    lg = rng.normal(0, 2, size=(T, P)).astype(np.float32)
+    opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4)
+    x = torch.from_numpy(lg).cuda().requires_grad_()
+    loss = ops.ChainObjtiveFunction.apply(x, G, sup, opts)
+    (7.0 * loss).backward()
+    objf, want, _ = R.chain_objf_and_deriv(lg.astype(np.float64), ref, _ref_fst(sup), leaky=1e-4)
+    assert abs(loss.item() - objf) <= 1e-3 * abs(objf)
+    assert np.abs(x.grad.cpu().numpy() + want).max() < 1e-4
+    bad = lg.copy(); bad[3, 5] = np.nan
+    out, grad = chain.compute_chain_objf_and_deriv(opts, G, [sup], torch.from_numpy(bad).cuda().unsqueeze(0))
+    assert out[0, 0].item() == -10.0 * T and not grad.any().item()
+
+
+def test_full_size_graph_properties():
+    """BASELINE-size graph (S=30k, A=1M, P=6048): size-independent properties instead of the oracle:
+    occupancies sum to 1 per frame, gradient sums to 0, batch order does not matter."""
+    g = synth.den_graph_arcs(30000, 1000000, 6048, seed=0)
+    G = chain.DenominatorGraph(g, 6048)
+    rng = np.random.default_rng(9)
+    lens = [130, 77, 101, 64]
+    x = torch.from_numpy(rng.normal(0, 2, size=(4, 130, 6048)).astype(np.float32)).cuda()
+    lp, gamma = chain.den_forward_backward(G, x, lens, 1e-4)
+    for n, T in enumerate(lens):
+        assert (gamma[n, :T].sum(1) - 1).abs().max().item() < 2e-4
+    perm = [2, 0, 3, 1]
+    lp2, gamma2 = chain.den_forward_backward(G, x[perm].contiguous(), [lens[i] for i in perm], 1e-4)
+    assert (lp2 - lp[perm]).abs().max().item() <= 1e-4 * lp.abs().max().item()
+    assert (gamma2 - gamma[perm]).abs().max().item() < 1e-5

@@ -1,0 +1,150 @@
+"""HIP front end, LSTM, CE, GEMM and optimiser kernels against reference-generated goldens and
+the reference PyTorch CPU path (nn.LSTM + nn.Linear, exactly what models/lstm.py:45-54 builds)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend_ref as F
+from pykaldi2_amd import _lib, fbank, lstm, ops, optim
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fbank_cmn_match_reference_golden(golden):
+    g = golden("fbank")
+    fb = fbank.FbankExtractor()
+    lens = [int(n) for n in g["lens"]]
+    wav = torch.from_numpy(np.concatenate([g["wav%d" % i] for i in range(len(lens))])).cuda()
+    feats, frames, row_off = fb(wav, lens, apply_cmn=False)
+    feats_c, _, _ = fb(wav, lens, apply_cmn=True)
+    feats, feats_c = feats.cpu().numpy(), feats_c.cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(frames)])
+    for i in range(len(lens)):
+        want = g["fbank%d" % i]
+        got = feats[off[i]:off[i + 1]]
+        assert got.shape == want.shape
+        # log-mel values are O(10); f32 FFT vs the reference's f64 FFT rounded to complex64
+        assert np.abs(got - want).max() < 2e-3, (i, np.abs(got - want).max())
+        assert np.abs(feats_c[off[i]:off[i + 1]] - g["cmn%d" % i]).max() < 2e-3
+    assert not feats[off[4]:off[5]].any()
+
+
+def test_pad_roll_subsample_matches_reference_golden(golden):
+    g = golden("misc")
+    lens = [int(v) for v in g["collate_lens"]]
+    feats = torch.from_numpy(g["collate_feats"]).cuda()
+    row_off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64).cuda()
+    x = fbank.FbankExtractor.pad_roll_subsample(feats, row_off, lens)
+    assert np.array_equal(x.cpu().numpy(), g["collate_x"])
+    for e in range(3):
+        xs = fbank.FbankExtractor.pad_roll_subsample(feats, row_off, lens, shift=-(e % 3), subsample=3)
+        assert np.array_equal(xs.cpu().numpy(), g["subsample_e%d" % e])
+        xt = fbank.FbankExtractor.pad_roll_subsample(feats, row_off, lens, shift=-(e % 3), subsample=3, time_major=True)
+        assert np.array_equal(xt.transpose(0, 1).cpu().numpy(), g["subsample_e%d" % e])
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 257, 130, 80), (0, 0, 100, 37, 515), (1, 0, 300, 64, 1601),
+                                         (0, 1, 1600, 2048, 1024), (1, 1, 33, 129, 18)])
+def test_gemm_f32_matches_float64(ta, tb, M, N, K):
+    rng = np.random.default_rng(M + N)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    want = 0.5 * ((A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)) + bias + 2.0 * C0
+    a, b, c, bs = (torch.from_numpy(v).cuda() for v in (A, B, C0.copy(), bias))
+    lstm._gemm(ta, tb, M, N, K, lstm._p(a), A.shape[1], lstm._p(b), B.shape[1], lstm._p(c), N, bias=lstm._p(bs),
+               alpha=0.5, beta=2.0)
+    err = np.abs(c.cpu().numpy() - want).max()
+    assert err < 2e-4 * np.sqrt(K), err
+
+
+def _load_golden_model(g, tag):
+    D_in, P, H, Lr, bi, B, T = [int(v) for v in g[tag + "_cfg"]]
+    m = lstm.LSTMAM(D_in, P, H, Lr, 0.0, bool(bi))
+    sd = {k[len(tag + "_param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
+    m.load_state_dict(sd)
+    return m.cuda(), (D_in, P, H, Lr, bi, B, T)
+
+
+@pytest.mark.parametrize("tag", ["small", "uni"])
+def test_lstmam_matches_reference_golden(golden, tag):
+    g = golden("lstm")
+    m, _ = _load_golden_model(g, tag)
+    x = torch.from_numpy(g[tag + "_x"]).cuda()
+    logits = m(x)
+    assert logits.is_contiguous()
+    err = (logits.cpu() - torch.from_numpy(g[tag + "_logits"])).abs().max().item()
+    assert err < 2e-5, err
+    (logits * torch.from_numpy(g[tag + "_w"]).cuda()).sum().backward()
+    for name, p in m.named_parameters():
+        want = g[tag + "_grad_" + name]
+        e = np.abs(p.grad.cpu().numpy() - want).max()
+        assert e < 1e-4 * max(1.0, np.abs(want).max()), (name, e)
+
+
+def test_blstm_3x512_posteriors_match_torch_cpu():
+    """CE frame posteriors within 1e-4 rel of the reference PyTorch CPU path (north star)."""
+    torch.manual_seed(0)
+    B, T, P = 4, 23, 5768
+    m = lstm.LSTMAM(80, P, 512, 3, 0.0, True)
+    ref_lstm = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
+    ref_out = torch.nn.Linear(1024, P)
+    ref_lstm.load_state_dict({k[5:]: v for k, v in m.state_dict().items() if k.startswith("lstm.")})
+    ref_out.load_state_dict({k[13:]: v for k, v in m.state_dict().items() if k.startswith("output_layer.")})
+    x = torch.randn(B, T, 80)
+    tgt = torch.randint(0, P, (B, T))
+    tgt[1, 20:] = -100
+    ref_logits = ref_out(ref_lstm(x)[0])
+    ref_loss = torch.nn.CrossEntropyLoss(ignore_index=-100)(ref_logits.view(-1, P), tgt.view(-1))
+    ref_loss.backward()
+    m = m.cuda()
+    logits = m(x.cuda())
+    post = torch.softmax(logits.double().cpu(), -1)
+    ref_post = torch.softmax(ref_logits.double().detach(), -1)
+    rel = ((post - ref_post).abs() / ref_post.clamp_min(1e-30)).max().item()
+    assert rel < 1e-4, rel
+    loss = ops.CrossEntropyLoss(ignore_index=-100)(logits.view(-1, P), tgt.cuda().view(-1))
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    loss.backward()
+    refg = dict(list(("lstm." + k, v.grad) for k, v in ref_lstm.named_parameters()) +
+                list(("output_layer." + k, v.grad) for k, v in ref_out.named_parameters()))
+    for name, p in m.named_parameters():
+        want = refg[name]
+        e = (p.grad.cpu() - want).abs().max().item()
+        assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
+
+
+def test_cross_entropy_matches_reference_golden(golden):
+    g = golden("misc")
+    for red in ("mean", "sum"):
+        x = torch.from_numpy(g["ce_logits"]).cuda().requires_grad_()
+        loss = ops.CrossEntropyLoss(ignore_index=-100, reduction=red)(x, torch.from_numpy(g["ce_targets"]).cuda())
+        loss.backward()
+        assert abs(loss.item() - float(g["ce_loss_" + red])) < 1e-5 * abs(float(g["ce_loss_" + red]))
+        assert np.abs(x.grad.cpu().numpy() - g["ce_grad_" + red]).max() < 1e-6
+
+
+class _Flat:
+    def __init__(self, p):
+        self.p, self.g = p, torch.zeros_like(p)
+
+    def flat_parameters(self):
+        return self.p, self.g
+
+    def parameters(self):
+        return [self.p]
+
+
+@pytest.mark.parametrize("name", ["adam", "sgd"])
+def test_fused_optimisers_match_reference_golden(golden, name):
+    g = golden("misc")
+    model = _Flat(torch.from_numpy(g["opt_p0"].copy()).cuda())
+    opt = optim.Adam(model, lr=1e-2, amsgrad=True) if name == "adam" else optim.SGD(model, lr=1e-2, momentum=0.9)
+    for i, grad in enumerate(g["opt_grads"]):
+        opt.zero_grad()
+        model.g.copy_(torch.from_numpy(grad))
+        norm = optim.clip_grad_norm_(opt, 5.0)
+        opt.step()
+        assert abs(norm.item() - g["opt_%s_norms" % name][i]) < 1e-4 * g["opt_%s_norms" % name][i]
+        assert np.abs(model.p.cpu().numpy() - g["opt_%s_traj" % name][i]).max() < 2e-6

@@ -32,7 +32,7 @@ def test_flat_layout_keeps_directions_adjacent():
     w_ih, w_hh, b_ih, b_hh = m._layer_views(1)
     assert torch.equal(w_ih[:256], m.lstm.weight_ih_l1) and torch.equal(w_ih[256:], m.lstm.weight_ih_l1_reverse)
     assert torch.equal(w_hh[256:], m.lstm.weight_hh_l1_reverse) and torch.equal(b_hh[256:], m.lstm.bias_hh_l1_reverse)
-    assert flat.data_ptr() % 256 == 0 and gflat.shape == flat.shape
+    assert flat.data_ptr() % 64 == 0 and gflat.shape == flat.shape
     assert set(m._buckets) == {"output_layer", "lstm.l0", "lstm.l1"}
 
 
