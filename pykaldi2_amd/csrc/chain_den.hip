@@ -23,6 +23,7 @@
 //    about two dependent memory round trips; the T launches are replayed from cached hipGraphs.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "chain_internal.h"
 #include "step_graph.h"
@@ -86,6 +87,8 @@ struct DenParams {
   float* alpha; float* beta; float* xs; float* gamma;
   float* apart; float* bpart; float* asum; float* inv_tot;
   const int32_t* lengths;
+  const int32_t* ps_off;    // states grouped by pdf (only when pdf is a function of the state)
+  const int32_t* ps_state;
   int S, P, Tmax;
   float leaky, pi_sum;
 };
@@ -145,31 +148,21 @@ __global__ void __launch_bounds__(256) den_init(DenParams p) {
   }
 }
 
-constexpr int kXvFwd = 16;   // float4 of exp(logits) staged per thread (512 threads): P*NG <= 32768
-constexpr int kXvBwd = 8;    // same for the 1024-thread backward workgroup
-
-// Stages n4 float4 of exp(logits) (plus a scalar tail) through registers into LDS.
-template <int XV, int THREADS>
-struct XStage {
-  float4 r[XV];
-  __device__ __forceinline__ void load(const float* src, int n4) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-#pragma unroll
-    for (int k = 0; k < XV; ++k) {
-      const int i = threadIdx.x + k * THREADS;
-      if (i < n4) r[k] = s4[i];
-    }
+// Copies n4 float4 of exp(logits) from global memory straight into LDS with the gfx950 LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, destination = wave-uniform base + lane*16,
+// no VGPR round trip).  Asynchronous; the next __syncthreads() drains it.
+__device__ __forceinline__ void glds16(const float* gsrc_lane, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int NWAVES>
+__device__ __forceinline__ void stage_x_async(const float* src, float* dst, int n4) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = w; k * 64 < n4; k += NWAVES) {
+    const int i = k * 64 + lane;
+    if (i < n4) glds16(src + (size_t)i * 4, dst + (size_t)k * 256);
   }
-  __device__ __forceinline__ void store(float* dst, const float* src, int n4, int total) {
-    float4* d4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-    for (int k = 0; k < XV; ++k) {
-      const int i = threadIdx.x + k * THREADS;
-      if (i < n4) d4[i] = r[k];
-    }
-    for (int i = n4 * 4 + threadIdx.x; i < total; i += THREADS) dst[i] = src[i];
-  }
-};
+}
 
 // One frame of the alpha recursion: alpha[t+1] from alpha[t].
 template <int NG>
@@ -178,7 +171,7 @@ __global__ void __launch_bounds__(kDenThreads) den_fwd_step(const DenParams* __r
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = cnt->base + local;
   if (t >= cnt->T) return;
-  const DenParams p = *pp;
+  const DenParams& p = *pp;  // fields are read with scalar loads; a by-value copy would live in scratch
   float* xs_l = smem;                              // P*NG
   float* acc = xs_l + (size_t)p.P * NG;            // kMaxRows*NG
   float* red = acc + (size_t)2 * kMaxRows * NG;    // 16*NG   (same carve as the backward kernel)
@@ -202,8 +195,7 @@ __global__ void __launch_bounds__(kDenThreads) den_fwd_step(const DenParams* __r
   }
   const float* xsrc = p.xs + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
   const int n4 = p.P * NG / 4;
-  XStage<kXvFwd, kDenThreads> xst;
-  xst.load(xsrc, n4);
+  stage_x_async<kDenWaves>(xsrc, xs_l, n4);
   int wb = wb0 + w;
   int4 rec[kK];
   float a[kK][NG];
@@ -216,7 +208,7 @@ __global__ void __launch_bounds__(kDenThreads) den_fwd_step(const DenParams* __r
     for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)rec[j].x * NG, a[j]);
   }
   // ---- LDS: stage exp(logits), clear the accumulator, reduce the partials ------------------
-  xst.store(xs_l, xsrc, n4, p.P * NG);
+  for (int i = n4 * 4 + tid; i < p.P * NG; i += kDenThreads) xs_l[i] = xsrc[i];
   for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
   block_sum<NG, kDenWaves>(as, red);
   if (chunk == 0 && tid == 0) stv<NG>(p.asum + frame * NG, as);
@@ -312,14 +304,14 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
-  const DenParams p = *pp;
+  const DenParams& p = *pp;  // fields are read with scalar loads; a by-value copy would live in scratch
   const int t = p.Tmax - 1 - step;
   float* xs_l = smem;
   float* accB = xs_l + (size_t)p.P * NG;
   float* accG = accB + (size_t)kMaxRows * NG;
   float* red = accG + (size_t)kMaxRows * NG;
   const int g = blockIdx.y, tid = threadIdx.x;
-  const int half = tid >> 9, th = tid & (kDenThreads - 1);
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 9), th = tid & (kDenThreads - 1);
   const int lane = tid & 63, wh = th >> 6;
   const int ncb = p.bwd.n_chunks, ncg = p.gam.n_chunks;
   const bool beta_role = half == 0;
@@ -346,8 +338,8 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   }
   const size_t xoff = ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
   const int n4 = p.P * NG / 4;
-  XStage<kXvBwd, kDenBwdThreads> xst;
-  xst.load(p.xs + xoff, n4);
+  const float* xsrc = p.xs + xoff;
+  stage_x_async<2 * kDenWaves>(xsrc, xs_l, n4);
   int wb = wb0 + wh;
   int4 rec[KG];
   float av[KG][NG], bv[KG][NG];
@@ -373,7 +365,7 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   ldv<NG>(p.asum + frame * NG, as);
 
   // ---- LDS: stage exp(logits), clear accumulators, reduce sum pi*beta' of frame t+1 ---------
-  xst.store(xs_l, p.xs + xoff, n4, p.P * NG);
+  for (int i = n4 * 4 + tid; i < p.P * NG; i += kDenBwdThreads) xs_l[i] = xsrc[i];
   for (int i = th; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
   block_sum<NG, 2 * kDenWaves>(lB, red);
   // beta[t+1][d] = beta'[t+1][d] + leaky * sum_k pi[k] beta'[t+1][k]   (t+1 <  T_n)
@@ -471,6 +463,165 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   if (tid == 0 && chunk < ncb) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
 }
 
+// One frame of the beta recursion only (occupancies come from den_gamma_states afterwards).
+template <int NG>
+__global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __restrict__ pp,
+                                                             const StepCounter* __restrict__ cnt, int local) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const DenParams& p = *pp;
+  const int t = p.Tmax - 1 - step;
+  float* xs_l = smem;
+  float* acc = xs_l + (size_t)p.P * NG;
+  float* red = acc + (size_t)2 * kMaxRows * NG;
+  const int g = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int ncb = p.bwd.n_chunks;
+  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * NG;
+  const int wb0 = p.bwd.wb_off[chunk], wb1 = p.bwd.wb_off[chunk + 1];
+  const int nrows = p.bwd.nrows[chunk];
+
+  float lB[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) lB[n] = 0.f;
+  for (int i = tid; i < ncb; i += kDenThreads) {
+    float v[NG];
+    ldv<NG>(p.bpart + ((frame + 1) * ncb + i) * NG, v);
+#pragma unroll
+    for (int n = 0; n < NG; ++n) lB[n] += v[n];
+  }
+  const float* xsrc = p.xs + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
+  const int n4 = p.P * NG / 4;
+  stage_x_async<kDenWaves>(xsrc, xs_l, n4);
+  int wb = wb0 + w;
+  int4 rec[kK];
+  float b[kK][NG];
+  uint32_t meta = 0;
+  if (wb < wb1) {
+    meta = p.bwd.meta[(size_t)wb * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < kK; ++j) ldv<NG>(beta_n + (size_t)rec[j].x * NG, b[j]);
+  }
+  float as[NG];
+  ldv<NG>(p.asum + frame * NG, as);
+  for (int i = n4 * 4 + tid; i < p.P * NG; i += kDenThreads) xs_l[i] = xsrc[i];
+  for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
+  block_sum<NG, kDenWaves>(lB, red);
+  float cst[NG], inv_as[NG];
+  bool gat[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int T = p.lengths[g * NG + n];
+    gat[n] = (t + 1) < T;
+    lB[n] = gat[n] ? p.leaky * lB[n] : 0.f;
+    cst[n] = ((t + 1) == T) ? p.inv_tot[g * NG + n] * (1.0f + p.leaky * p.pi_sum) : 0.f;
+    inv_as[n] = 1.0f / as[n];
+  }
+  while (wb < wb1) {
+    int c = meta & 0xffffu;
+    const uint32_t mask = meta >> 16;
+    float sum[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) sum[n] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kK; ++j) {
+      const float prob = __int_as_float(rec[j].z);
+      float xv[NG];
+      ldv<NG>(xs_l + (size_t)rec[j].y * NG, xv);
+#pragma unroll
+      for (int n = 0; n < NG; ++n) sum[n] += prob * xv[n] * (gat[n] ? b[j][n] + lB[n] : cst[n]);
+      if ((mask >> j) & 1u) {
+#pragma unroll
+        for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
+        ++c;
+      }
+    }
+    wb += kDenWaves;
+    if (wb < wb1) {
+      meta = p.bwd.meta[(size_t)wb * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < kK; ++j) ldv<NG>(beta_n + (size_t)rec[j].x * NG, b[j]);
+    }
+  }
+  __syncthreads();
+  float* beta_t = p.beta + frame * (size_t)p.S * NG;
+  const int row0 = p.bwd.row0[chunk];
+  const bool atomic = p.bwd.atomic[chunk] != 0;
+  float loc[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) loc[n] = 0.f;
+  for (int r = tid; r < nrows; r += kDenThreads) {
+    float v[NG];
+    const float pis = p.pi[row0 + r];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n] * inv_as[n]; loc[n] += pis * v[n]; }
+    float* o = beta_t + (size_t)(row0 + r) * NG;
+    if (atomic) {
+#pragma unroll
+      for (int n = 0; n < NG; ++n) atomicAdd(o + n, v[n]);
+    } else {
+      stv<NG>(o, v);
+    }
+  }
+  block_sum<NG, kDenWaves>(loc, red);
+  if (tid == 0) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
+}
+
+// Occupancies without touching the arcs, for graphs whose pdf is a function of the destination
+// state: the arcs entering state d at frame t carry total posterior alpha[t+1,d] * beta[t+1,d]
+// (alpha before, beta after the leaky-HMM term), so
+//   gamma[t,p] = sum_{d : pdf(d) = p} alpha[t+1,d] * beta[t+1,d].
+// No serial dependence: one launch covers all frames.
+template <int NG>
+__global__ void __launch_bounds__(256) den_gamma_states(DenParams p) {
+  __shared__ float red[4 * NG];
+  const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int ncb = p.bwd.n_chunks;
+  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
+  float lB[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) lB[n] = 0.f;
+  for (int i = tid; i < ncb; i += 256) {
+    float v[NG];
+    ldv<NG>(p.bpart + ((frame + 1) * ncb + i) * NG, v);
+#pragma unroll
+    for (int n = 0; n < NG; ++n) lB[n] += v[n];
+  }
+  block_sum<NG, 4>(lB, red);
+  float cst[NG];
+  bool gat[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int T = p.lengths[g * NG + n];
+    gat[n] = (t + 1) < T;
+    lB[n] = gat[n] ? p.leaky * lB[n] : 0.f;
+    cst[n] = ((t + 1) == T) ? p.inv_tot[g * NG + n] * (1.0f + p.leaky * p.pi_sum) : 0.f;
+  }
+  const float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * NG;
+  float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
+  for (int pdf = tid; pdf < p.P; pdf += 256) {
+    float v[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) v[n] = 0.f;
+    for (int k = p.ps_off[pdf]; k < p.ps_off[pdf + 1]; ++k) {
+      const int s = p.ps_state[k];
+      float a[NG], b[NG];
+      ldv<NG>(alpha_n + (size_t)s * NG, a);
+      ldv<NG>(beta_n + (size_t)s * NG, b);
+#pragma unroll
+      for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] + lB[n] : cst[n]);
+    }
+    stv<NG>(gam_t + (size_t)pdf * NG, v);
+  }
+}
+
 // Kaldi's consistency check: sum_h alpha'[0,h] beta'[0,h] (should be 1 per sequence).
 template <int NG>
 __global__ void __launch_bounds__(kDenThreads) den_check(DenParams p, float* check) {
@@ -526,9 +677,8 @@ static size_t den_lds_bytes(int P, int NG) {
 
 int den_choose_ng(const pk2_den_graph* g) {
   const size_t limit = 160 * 1024;
-  // the staging registers cover kXvBwd * 1024 float4 = 32768 floats of exp(logits)
   for (int ng : {4, 2, 1})
-    if (den_lds_bytes(g->P, ng) <= limit && (size_t)g->P * ng <= (size_t)kXvBwd * kDenBwdThreads * 4) return ng;
+    if (den_lds_bytes(g->P, ng) <= limit) return ng;
   return 0;
 }
 
@@ -590,6 +740,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   p.alpha = b.alpha; p.beta = b.beta; p.xs = b.xs; p.gamma = b.gamma;
   p.apart = b.apart; p.bpart = b.bpart; p.asum = b.asum; p.inv_tot = b.inv_tot;
   p.lengths = b.lengths;
+  p.ps_off = g->d_ps_off; p.ps_state = g->d_ps_state;
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
   p.leaky = leaky; p.pi_sum = (float)g->pi_sum;
 
@@ -599,6 +750,8 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_fwd_step<NG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_bwd_step<NG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_beta_step<NG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[NG] = true;
   }
@@ -621,12 +774,23 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   });
   if (rc) return rc;
   hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
-  const dim3 gridB(std::max(g->bwd.n_chunks, g->gam.n_chunks), G);
-  snprintf(key, sizeof(key), "den_bwd_%d_%u_%d_%zu_%p", NG, gridB.x, G, lds, (void*)stream);
-  rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
-    hipLaunchKernelGGL(den_bwd_step<NG>, gridB, dim3(kDenBwdThreads), lds, s, pb, cnt, j);
-  });
-  if (rc) return rc;
+  const bool state_gamma = g->state_pdf_unique && getenv("PK2_DEN_ARC_GAMMA") == nullptr;
+  if (state_gamma) {
+    const dim3 gridB(g->bwd.n_chunks, G);
+    snprintf(key, sizeof(key), "den_beta_%d_%u_%d_%zu_%p", NG, gridB.x, G, lds, (void*)stream);
+    rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
+      hipLaunchKernelGGL(den_beta_step<NG>, gridB, dim3(kDenThreads), lds, s, pb, cnt, j);
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(den_gamma_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, p);
+  } else {
+    const dim3 gridB(std::max(g->bwd.n_chunks, g->gam.n_chunks), G);
+    snprintf(key, sizeof(key), "den_bwd_%d_%u_%d_%zu_%p", NG, gridB.x, G, lds, (void*)stream);
+    rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
+      hipLaunchKernelGGL(den_bwd_step<NG>, gridB, dim3(kDenBwdThreads), lds, s, pb, cnt, j);
+    });
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(den_check<NG>, dim3(G), dim3(kDenThreads), 0, stream, p, b.check);
   PK2_LAUNCH_CHECK();
   return PK2_OK;

@@ -140,6 +140,24 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src, cons
   build_ordering(A, S, dst, src, pdf, prob, piprob.data(), &g->h_fwd);   // alpha: rows = dst
   build_ordering(A, S, src, dst, pdf, prob, piprob.data(), &g->h_bwd);   // beta : rows = src
   build_ordering(A, P, pdf, src, dst, prob, piprob.data(), &g->h_gam);   // gamma: rows = pdf
+  // pdf as a function of the destination state?
+  {
+    std::vector<int32_t> spdf(S, -1);
+    bool unique = true;
+    for (int64_t i = 0; i < A && unique; ++i) {
+      if (spdf[dst[i]] < 0) spdf[dst[i]] = pdf[i];
+      else if (spdf[dst[i]] != pdf[i]) unique = false;
+    }
+    g->state_pdf_unique = unique;
+    if (unique) {
+      g->ps_off.assign(P + 1, 0);
+      for (int s = 0; s < S; ++s) if (spdf[s] >= 0) g->ps_off[spdf[s] + 1]++;
+      for (int p = 0; p < P; ++p) g->ps_off[p + 1] += g->ps_off[p];
+      g->ps_state.assign(std::max(1, g->ps_off[P]), 0);
+      std::vector<int32_t> cur(g->ps_off.begin(), g->ps_off.end() - 1);
+      for (int s = 0; s < S; ++s) if (spdf[s] >= 0) g->ps_state[cur[spdf[s]]++] = s;
+    }
+  }
   *out = g;
   return PK2_OK;
 }
@@ -175,6 +193,10 @@ int den_upload(pk2_den_graph* g) {
   if ((rc = upload_ordering(g, g->h_gam, &g->gam))) return rc;
   const float* dpi = nullptr;
   if ((rc = upload_vec(g, g->pi, &dpi))) return rc;
+  if (g->state_pdf_unique) {
+    if ((rc = upload_vec(g, g->ps_off, &g->d_ps_off))) return rc;
+    if ((rc = upload_vec(g, g->ps_state, &g->d_ps_state))) return rc;
+  }
   g->d_pi = const_cast<float*>(dpi);
   g->uploaded = true;
   return PK2_OK;

@@ -51,6 +51,13 @@ struct pk2_den_graph {
   int32_t S = 0, P = 0, start = 0;
   int64_t A = 0;
   std::vector<float> pi;
+  // When every state's incoming arcs carry one pdf ("pdf is a function of the destination
+  // state"), the occupancy of pdf p at frame t is sum_{d in states(p)} alpha[t+1,d]*beta[t+1,d]
+  // and needs no arc traversal: states grouped by pdf (CSR).  Otherwise the arc-based pass runs.
+  bool state_pdf_unique = false;
+  std::vector<int32_t> ps_off, ps_state;
+  const int32_t* d_ps_off = nullptr;
+  const int32_t* d_ps_state = nullptr;
   double pi_sum = 0.0;
   pk2::HostOrdering h_fwd, h_bwd, h_gam;  // keyed by dst / src / pdf
   // device copies, created lazily on the first compute call

@@ -15,8 +15,8 @@
 //    activations, c_t and h_t are computed in the same kernel (fused pointwise).  The pointwise
 //    operands (input projection, bias, c_{t-1}) are fetched before the MFMA phase so their
 //    latency hides behind it.
-//  * backward: a workgroup owns 16 hidden units (N tile) and splits K = 4H over 16 wavefronts;
-//    d h_{t-1} = dgates_t W_hh is fused with the gate derivative of step t-1.
+//  * backward: a workgroup owns 4 hidden units (4 live columns of the N tile) and splits K = 4H
+//    over 16 wavefronts; d h_{t-1} = dgates_t W_hh is fused with the gate derivative of step t-1.
 // W_hh slices are re-read from L2 every step (4 MB per direction stays L2 resident; each
 // workgroup always reads the same slice, and consecutive launches place block b on XCD b%8).
 // All activations are time-major ([T][B][...]) so "previous step" is a constant row offset.
@@ -32,7 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kFwdThreads = 256;    // 4 waves, K = H split 4 ways
 constexpr int kFwdUnits = 4;        // hidden units per workgroup (x4 gates = 16 MFMA columns)
 constexpr int kBwdThreads = 1024;   // 16 waves, K = 4H split 16 ways
-constexpr int kBwdUnits = 16;       // hidden units per workgroup (16 MFMA columns)
+constexpr int kBwdUnits = 4;        // hidden units per workgroup (4 of the 16 MFMA columns carry data:
+                                    // the matrix work is negligible at these batch sizes, and 4x more
+                                    // workgroups spread the W_hh^T read over the whole chip)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -165,16 +167,18 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams
 
   f32x4 wf[KS / 4];
   const int rbase = w * (KS * 4) + kq * KS;        // run of gate rows r handled by this lane
-  if (!last_fwd) {
+#pragma unroll
+  for (int q = 0; q < KS / 4; ++q) wf[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!last_fwd && li < kBwdUnits) {
     const float* wrow = p.whhT + ((size_t)d * H + k0 + li) * G4 + rbase;
 #pragma unroll
     for (int q = 0; q < KS / 4; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + q * 4);
   }
   for (int mt = 0; mt < (B + 15) / 16; ++mt) {
     // pointwise operands of thread (i, j) fetched before the MFMA phase
-    const int pi_ = tid >> 4, pj = tid & 15;
+    const int pi_ = tid >> 2, pj = tid & 3;
     const int pb = mt * 16 + pi_, pk = k0 + pj;
-    const bool pw_active = tid < 256 && pb < B;
+    const bool pw_active = tid < 64 && pb < B;
     float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dcin = 0.f;
     if (pw_active) {
       dh = p.dy[((size_t)t * B + pb) * ((size_t)D * H) + (size_t)d * H + pk];
