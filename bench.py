@@ -103,7 +103,8 @@ def den_roofline(den, logits_bf, lens, reps=5):
     byts = Tsum * 4 * (3 * P + 2 * (S_DEN + 1)) + 24 * A_DEN * Tmax
     ach = byts / (ms * 1e-3) / 1e9
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=None, kernel="den_fwd_step<4>+den_bwd_step<4> (one denominator forward-backward call)",
+                traffic=None, kernel="pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; "
+                "forward frame t and backward frame Tmax-1-t share a launch)",
                 ms_per_launch=round(ms, 3), algorithmic_bytes=byts)
 
 
@@ -187,6 +188,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
+    ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
     args = ap.parse_args()
 
     hvd.init()
@@ -199,6 +202,32 @@ def main():
     g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
     den = chain.DenominatorGraph(g, P)
     log("den graph ready")
+    if args.lstm_only:
+        from pykaldi2_amd import _lib
+        T, B, H, D = 589, 4, 512, 2
+        gx = torch.randn(T, B, D * 4 * H, device=dev) * 0.1
+        whh = torch.randn(D, 4 * H, H, device=dev) * 0.04
+        y = torch.empty(T, B, D * H, device=dev); gates = torch.empty(D, T, B, 4 * H, device=dev)
+        cells = torch.empty(D, T, B, H, device=dev)
+        L = _lib.lib()
+        def run():
+            _lib.check(L.pk2_lstm_layer_fwd(_lib.ptr(gx), _lib.ptr(whh), None, B, T, H, D, _lib.ptr(y), _lib.ptr(gates),
+                                            _lib.ptr(cells), _lib.stream_ptr()))
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        print("lstm_fwd us/step %.2f" % (1e3 * e0.elapsed_time(e1) / 5 / T), flush=True)
+        return
+    if args.den_only:
+        lens = [589, 410, 377, 502]
+        x = torch.randn(4, max(lens), P, device=dev)
+        print(json.dumps(den_roofline(den, x, lens)), flush=True)
+        return
     rng = np.random.default_rng(1234 + rank)
     n_unique = min(args.steps + args.warmup, 8)
     batches = make_batches(rng, n_unique, args.batch, dev)

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "chain_internal.h"
 #include "step_graph.h"
@@ -89,8 +90,10 @@ struct DenParams {
   const int32_t* lengths;
   const int32_t* ps_off;    // states grouped by pdf (only when pdf is a function of the state)
   const int32_t* ps_state;
+  const int32_t* state_pdf;  // [S] pdf emitted on entering the state (-1: no incoming arc)
   int S, P, Tmax;
   float leaky, pi_sum;
+  int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop
 };
 
 // ----------------------------------------------------------------------------------------
@@ -463,26 +466,246 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   if (tid == 0 && chunk < ncb) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
 }
 
-// One frame of the beta recursion only (occupancies come from den_gamma_states afterwards).
+// c[g][t][n] = sum_k pi[k] btilde'[t,k]  (fixed-order reduction of the backward partials)
 template <int NG>
-__global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __restrict__ pp,
-                                                             const StepCounter* __restrict__ cnt, int local) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int step = cnt->base + local;
-  if (step >= cnt->T) return;
-  const DenParams& p = *pp;
-  const int t = p.Tmax - 1 - step;
-  float* xs_l = smem;
-  float* acc = xs_l + (size_t)p.P * NG;
-  float* red = acc + (size_t)2 * kMaxRows * NG;
-  const int g = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+__global__ void __launch_bounds__(256) den_csum(DenParams p, float* csum) {
+  __shared__ float red[4 * NG];
+  const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int ncb = p.bwd.n_chunks;
+  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
+  float c[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) c[n] = 0.f;
+  for (int i = tid; i < ncb; i += 256) {
+    float v[NG];
+    ldv<NG>(p.bpart + (frame * ncb + i) * NG, v);
+#pragma unroll
+    for (int n = 0; n < NG; ++n) c[n] += v[n];
+  }
+  block_sum<NG, 4>(c, red);
+  if (tid == 0) stv<NG>(csum + frame * NG, c);
+}
+
+// K[g][t][n]: true beta[t] = K[t] * betahat[t].  K[T] = sum(pi)/tot, log K[t] = log K[t+1] + log c[t]
+// - log asum[t]: a suffix sum in double precision (block scan, one workgroup per sequence).
+// check = (1 + leaky*sum(pi)) * K[0].
+template <int NG>
+__global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum, float* Kf, float* check) {
+  __shared__ double wsum[4];
+  __shared__ double carry_s;
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = p.lengths[g * NG + n];
+  const size_t f0 = (size_t)g * (p.Tmax + 1);
+  for (int t = T + 1 + tid; t <= p.Tmax; t += 256) Kf[(f0 + t) * NG + n] = 0.f;
+  if (T <= 0) { if (tid == 0) check[g * NG + n] = 1.f; return; }
+  const double lkT = log((double)p.pi_sum) + log((double)p.inv_tot[g * NG + n]);
+  if (tid == 0) { Kf[(f0 + T) * NG + n] = (float)exp(lkT); carry_s = lkT; }
+  __syncthreads();
+  // walk t = T-1 .. 0 in tiles of 256 (thread i of a tile handles t = hi - i)
+  for (int hi = T - 1; hi >= 0; hi -= 256) {
+    const int t = hi - tid;
+    double v = 0.0;
+    if (t >= 0) v = log((double)csum[(f0 + t) * NG + n]) - log((double)p.asum[(f0 + t) * NG + n]);
+    // inclusive scan over the tile
+    double x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    double off = carry_s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    const double lk = off + x;
+    if (t >= 0) Kf[(f0 + t) * NG + n] = (float)exp(lk);
+    __syncthreads();
+    if (tid == 255 || t == 0) { carry_s = lk; if (t == 0) check[g * NG + n] = (float)((1.0 + (double)p.leaky * p.pi_sum) * exp(lk)); }
+    __syncthreads();
+  }
+}
+
+// Occupancies without touching the arcs, for graphs whose pdf is a function of the destination
+// state: the arcs entering state d at frame t carry total posterior alpha[t+1,d] * beta[t+1,d]
+// (alpha before, beta after the leaky-HMM term), so
+//   gamma[t,p] = sum_{d : pdf(d) = p} alpha[t+1,d] * beta[t+1,d],
+//   beta[t+1,d] = K[t+1] * (btilde'[t+1,d]/c[t+1] + leaky)   (= K[T] * (1/sum(pi) + leaky) at t+1 = T).
+// No serial dependence: one launch covers all frames.
+template <int NG>
+__global__ void __launch_bounds__(256) den_gamma_states(DenParams p, const float* csum, const float* Kf) {
+  const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
+  float cv[NG], kv[NG], inv_c[NG], cst[NG];
+  bool gat[NG];
+  ldv<NG>(csum + (frame + 1) * NG, cv);
+  ldv<NG>(Kf + (frame + 1) * NG, kv);
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int T = p.lengths[g * NG + n];
+    gat[n] = (t + 1) < T;
+    inv_c[n] = (gat[n] && cv[n] > 0.f) ? 1.0f / cv[n] : 0.f;
+    cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
+  }
+  const float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * (2 * NG);   // {btilde'[NG], xd[NG]} per state
+  float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
+  for (int pdf = tid; pdf < p.P; pdf += 256) {
+    float v[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) v[n] = 0.f;
+    for (int k = p.ps_off[pdf]; k < p.ps_off[pdf + 1]; ++k) {
+      const int s = p.ps_state[k];
+      float a[NG], b[NG];
+      ldv<NG>(alpha_n + (size_t)s * NG, a);
+      ldv<NG>(beta_n + (size_t)s * (2 * NG), b);
+#pragma unroll
+      for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] * inv_c[n] + p.leaky : cst[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NG; ++n) v[n] *= kv[n];
+    stv<NG>(gam_t + (size_t)pdf * NG, v);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// "state-x" fast path, for graphs whose pdf is a function of the destination state.
+// exp(logit) of the pdf a state emits is then a per-STATE quantity xd[t][d] = x[t, pdf(d)]:
+//  * forward: it factors out of the arc sum, alpha[t+1,d] = xd[t][d]/asum * sum_arcs alpha'[t,s] prob;
+//  * backward: it is stored right behind beta'[t+1][d] ({beta'[NG], xd[NG]} = 32 B per state), so the
+//    one gather an arc needs anyway brings it along.
+// Neither kernel stages the P x NG table of exp(logits) in LDS (saves 97 KB of LDS and 24 MB of
+// L2 traffic per frame and direction); they keep only the 16 KB row accumulator.
+// ----------------------------------------------------------------------------------------
+// bx[g][t+1][d][NG + n] = exp(clamp(logit[seq(g,n)][t][pdf(d)]))   (1 for finished sequences)
+template <int NG>
+__global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ logits, int64_t seq_stride,
+                                                      int64_t frame_stride, const int32_t* __restrict__ lengths,
+                                                      const int32_t* __restrict__ state_pdf, float* __restrict__ bx,
+                                                      int S, int Tmax) {
+  const int t = blockIdx.x, g = blockIdx.y;
+  const float* rows[NG]; bool live[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    int seq = g * NG + n;
+    live[n] = t < lengths[seq];
+    rows[n] = logits + (int64_t)seq * seq_stride + (int64_t)t * frame_stride;
+  }
+  float* out = bx + ((size_t)g * (Tmax + 1) + t + 1) * (size_t)S * (2 * NG) + NG;
+  for (int d = threadIdx.x; d < S; d += 256) {
+    const int pdf = state_pdf[d];
+    float v[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+      float x = (live[n] && pdf >= 0) ? rows[n][pdf] : 0.f;
+      x = x < -30.f ? -30.f : (x > 30.f ? 30.f : x);   // keeps NaN (see den_exp_transpose)
+      v[n] = (live[n] && pdf >= 0) ? expf(x) : 1.0f;
+    }
+    stv<NG>(out + (size_t)d * (2 * NG), v);
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red) {
+  const int g = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int nc = p.fwd.n_chunks;
+  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
+  const float* alpha_t = p.alpha + frame * (size_t)p.S * NG;
+  const int wb0 = p.fwd.wb_off[chunk], wb1 = p.fwd.wb_off[chunk + 1];
+  const int nrows = p.fwd.nrows[chunk];
+  float as[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) as[n] = 0.f;
+  for (int i = tid; i < nc; i += kDenThreads) {
+    float v[NG];
+    ldv<NG>(p.apart + (frame * nc + i) * NG, v);
+#pragma unroll
+    for (int n = 0; n < NG; ++n) as[n] += v[n];
+  }
+  int wb = wb0 + w;
+  int4 rec[kK];
+  float a[kK][NG];
+  uint32_t meta = 0;
+  if (wb < wb1) {
+    meta = p.fwd.meta[(size_t)wb * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < kK; ++j) rec[j] = p.fwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)((p.debug & 1) ? 0 : rec[j].x) * NG, a[j]);
+  }
+  for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
+  block_sum<NG, kDenWaves>(as, red);
+  if (chunk == 0 && tid == 0) stv<NG>(p.asum + frame * NG, as);
+  float lk[NG], inv_as[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) { lk[n] = p.leaky * as[n]; inv_as[n] = 1.0f / as[n]; }
+  if (p.debug & 2) wb = wb1;
+  while (wb < wb1) {
+    int c = meta & 0xffffu;
+    const uint32_t mask = meta >> 16;
+    float sum[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) sum[n] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kK; ++j) {
+      const float prob = __int_as_float(rec[j].z), pr = __int_as_float(rec[j].w);
+#pragma unroll
+      for (int n = 0; n < NG; ++n) sum[n] += a[j][n] * prob + lk[n] * pr;
+      if ((mask >> j) & 1u) {
+#pragma unroll
+        for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
+        ++c;
+      }
+    }
+    wb += kDenWaves;
+    if (wb < wb1) {
+      meta = p.fwd.meta[(size_t)wb * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < kK; ++j) rec[j] = p.fwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)rec[j].x * NG, a[j]);
+    }
+  }
+  __syncthreads();
+  float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
+  const float* xd = p.beta + (frame + 1) * (size_t)p.S * (2 * NG) + NG;   // x[t, pdf(d)]
+  const int row0 = p.fwd.row0[chunk];
+  const bool atomic = p.fwd.atomic[chunk] != 0;
+  float loc[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) loc[n] = 0.f;
+  for (int r = tid; r < nrows; r += kDenThreads) {
+    float v[NG], xv[NG];
+    ldv<NG>(xd + (size_t)(row0 + r) * (2 * NG), xv);
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n] * xv[n] * inv_as[n]; loc[n] += v[n]; }
+    float* o = alpha_n + (size_t)(row0 + r) * NG;
+    if (atomic) {
+#pragma unroll
+      for (int n = 0; n < NG; ++n) atomicAdd(o + n, v[n]);
+    } else {
+      stv<NG>(o, v);
+    }
+  }
+  block_sum<NG, kDenWaves>(loc, red);
+  if (tid == 0) stv<NG>(p.apart + ((frame + 1) * nc + chunk) * NG, loc);
+}
+
+// Backward recursion of the state-x path.  It does NOT use the forward pass: instead of dividing by
+// the forward scale asum[t] it normalises itself -- frame t stores btilde'[t,s] = sum_arcs prob *
+// x[t,pdf] * betahat[t+1,d] unnormalised, with betahat[t+1,d] = btilde'[t+1,d]/c[t+1] + leaky and
+// c[t+1] = sum_k pi[k] btilde'[t+1,k] (reduced from the partials like the forward sums).  The true
+// beta is K[t] * betahat[t] with log K[t] = log K[t+1] + log c[t] - log asum[t], K[T] = sum(pi)/tot
+// (den_scales).  Forward and backward chains therefore run concurrently on two streams.
+template <int NG>
+__device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red) {
+  const int g = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int ncb = p.bwd.n_chunks;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
-  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * NG;
+  const float* bx_n = p.beta + (frame + 1) * (size_t)p.S * (2 * NG);
   const int wb0 = p.bwd.wb_off[chunk], wb1 = p.bwd.wb_off[chunk + 1];
   const int nrows = p.bwd.nrows[chunk];
-
   float lB[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) lB[n] = 0.f;
@@ -492,34 +715,33 @@ __global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __
 #pragma unroll
     for (int n = 0; n < NG; ++n) lB[n] += v[n];
   }
-  const float* xsrc = p.xs + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
-  const int n4 = p.P * NG / 4;
-  stage_x_async<kDenWaves>(xsrc, xs_l, n4);
   int wb = wb0 + w;
   int4 rec[kK];
-  float b[kK][NG];
+  float b[kK][NG], xv[kK][NG];
   uint32_t meta = 0;
   if (wb < wb1) {
     meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
     for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + j) * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) ldv<NG>(beta_n + (size_t)rec[j].x * NG, b[j]);
+    for (int j = 0; j < kK; ++j) {
+      const size_t gi = (p.debug & 1) ? 0 : rec[j].x;
+      ldv<NG>(bx_n + gi * (2 * NG), b[j]);
+      ldv<NG>(bx_n + gi * (2 * NG) + NG, xv[j]);
+    }
   }
-  float as[NG];
-  ldv<NG>(p.asum + frame * NG, as);
-  for (int i = n4 * 4 + tid; i < p.P * NG; i += kDenThreads) xs_l[i] = xsrc[i];
   for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
   block_sum<NG, kDenWaves>(lB, red);
-  float cst[NG], inv_as[NG];
+  // lB now holds c[t+1] = sum_k pi[k] btilde'[t+1,k]; the normalised beta-hat' has pi-weighted sum 1,
+  // so its leaky term is exactly `leaky`.  beta-hat[T_n] = 1/sum(pi) + leaky starts each sequence.
+  float cst[NG], inv_c[NG];
   bool gat[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) {
     const int T = p.lengths[g * NG + n];
     gat[n] = (t + 1) < T;
-    lB[n] = gat[n] ? p.leaky * lB[n] : 0.f;
-    cst[n] = ((t + 1) == T) ? p.inv_tot[g * NG + n] * (1.0f + p.leaky * p.pi_sum) : 0.f;
-    inv_as[n] = 1.0f / as[n];
+    inv_c[n] = (gat[n] && lB[n] > 0.f) ? 1.0f / lB[n] : 0.f;
+    cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
   while (wb < wb1) {
     int c = meta & 0xffffu;
@@ -530,10 +752,8 @@ __global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
       const float prob = __int_as_float(rec[j].z);
-      float xv[NG];
-      ldv<NG>(xs_l + (size_t)rec[j].y * NG, xv);
 #pragma unroll
-      for (int n = 0; n < NG; ++n) sum[n] += prob * xv[n] * (gat[n] ? b[j][n] + lB[n] : cst[n]);
+      for (int n = 0; n < NG; ++n) sum[n] += prob * xv[j][n] * (gat[n] ? b[j][n] * inv_c[n] + p.leaky : cst[n]);
       if ((mask >> j) & 1u) {
 #pragma unroll
         for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
@@ -546,11 +766,14 @@ __global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __
 #pragma unroll
       for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + j) * 64 + lane];
 #pragma unroll
-      for (int j = 0; j < kK; ++j) ldv<NG>(beta_n + (size_t)rec[j].x * NG, b[j]);
+      for (int j = 0; j < kK; ++j) {
+        ldv<NG>(bx_n + (size_t)rec[j].x * (2 * NG), b[j]);
+        ldv<NG>(bx_n + (size_t)rec[j].x * (2 * NG) + NG, xv[j]);
+      }
     }
   }
   __syncthreads();
-  float* beta_t = p.beta + frame * (size_t)p.S * NG;
+  float* bx_t = p.beta + frame * (size_t)p.S * (2 * NG);
   const int row0 = p.bwd.row0[chunk];
   const bool atomic = p.bwd.atomic[chunk] != 0;
   float loc[NG];
@@ -560,8 +783,8 @@ __global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __
     float v[NG];
     const float pis = p.pi[row0 + r];
 #pragma unroll
-    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n] * inv_as[n]; loc[n] += pis * v[n]; }
-    float* o = beta_t + (size_t)(row0 + r) * NG;
+    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n]; loc[n] += pis * v[n]; }
+    float* o = bx_t + (size_t)(row0 + r) * (2 * NG);
     if (atomic) {
 #pragma unroll
       for (int n = 0; n < NG; ++n) atomicAdd(o + n, v[n]);
@@ -573,53 +796,20 @@ __global__ void __launch_bounds__(kDenThreads) den_beta_step(const DenParams* __
   if (tid == 0) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
 }
 
-// Occupancies without touching the arcs, for graphs whose pdf is a function of the destination
-// state: the arcs entering state d at frame t carry total posterior alpha[t+1,d] * beta[t+1,d]
-// (alpha before, beta after the leaky-HMM term), so
-//   gamma[t,p] = sum_{d : pdf(d) = p} alpha[t+1,d] * beta[t+1,d].
-// No serial dependence: one launch covers all frames.
+// One launch = forward frame `step` (workgroups [0, nc_fwd)) AND backward frame Tmax-1-step
+// (workgroups [nc_fwd, nc_fwd + nc_bwd)): the two recursions are independent (see den_beta_frame_sx),
+// so the serial chain is Tmax launches long instead of 2*Tmax, and both halves share the chip.
 template <int NG>
-__global__ void __launch_bounds__(256) den_gamma_states(DenParams p) {
-  __shared__ float red[4 * NG];
-  const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-  const int ncb = p.bwd.n_chunks;
-  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
-  float lB[NG];
-#pragma unroll
-  for (int n = 0; n < NG; ++n) lB[n] = 0.f;
-  for (int i = tid; i < ncb; i += 256) {
-    float v[NG];
-    ldv<NG>(p.bpart + ((frame + 1) * ncb + i) * NG, v);
-#pragma unroll
-    for (int n = 0; n < NG; ++n) lB[n] += v[n];
-  }
-  block_sum<NG, 4>(lB, red);
-  float cst[NG];
-  bool gat[NG];
-#pragma unroll
-  for (int n = 0; n < NG; ++n) {
-    const int T = p.lengths[g * NG + n];
-    gat[n] = (t + 1) < T;
-    lB[n] = gat[n] ? p.leaky * lB[n] : 0.f;
-    cst[n] = ((t + 1) == T) ? p.inv_tot[g * NG + n] * (1.0f + p.leaky * p.pi_sum) : 0.f;
-  }
-  const float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
-  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * NG;
-  float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
-  for (int pdf = tid; pdf < p.P; pdf += 256) {
-    float v[NG];
-#pragma unroll
-    for (int n = 0; n < NG; ++n) v[n] = 0.f;
-    for (int k = p.ps_off[pdf]; k < p.ps_off[pdf + 1]; ++k) {
-      const int s = p.ps_state[k];
-      float a[NG], b[NG];
-      ldv<NG>(alpha_n + (size_t)s * NG, a);
-      ldv<NG>(beta_n + (size_t)s * NG, b);
-#pragma unroll
-      for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] + lB[n] : cst[n]);
-    }
-    stv<NG>(gam_t + (size_t)pdf * NG, v);
-  }
+__global__ void __launch_bounds__(kDenThreads) den_step_sx(const DenParams* __restrict__ pp,
+                                                           const StepCounter* __restrict__ cnt, int local) {
+  __shared__ __attribute__((aligned(16))) float acc[kMaxRows * NG];
+  __shared__ float red[kDenWaves * NG];
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const DenParams& p = *pp;
+  const int ncf = p.fwd.n_chunks;
+  if ((int)blockIdx.x < ncf) den_fwd_frame_sx<NG>(p, step, blockIdx.x, acc, red);
+  else den_beta_frame_sx<NG>(p, p.Tmax - 1 - step, blockIdx.x - ncf, acc, red);
 }
 
 // Kaldi's consistency check: sum_h alpha'[0,h] beta'[0,h] (should be 1 per sequence).
@@ -693,7 +883,7 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
   DenBuffers b;
   const size_t GN = (size_t)ge.G * ge.NG;
   b.alpha = c.take<float>(GN * (Tmax + 1) * (size_t)g->S);
-  b.beta = c.take<float>(GN * (Tmax + 1) * (size_t)g->S);
+  b.beta = c.take<float>(GN * (Tmax + 1) * (size_t)g->S * 2);   // {beta', xd} per state on the state-x path
   b.xs = c.take<float>(GN * (size_t)Tmax * g->P);
   b.gamma = c.take<float>(GN * (size_t)Tmax * g->P);
   b.apart = c.take<float>(GN * (Tmax + 1) * (size_t)g->h_fwd.n_chunks);
@@ -703,6 +893,8 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
   b.den_lp = c.take<float>(GN);
   b.check = c.take<float>(GN);
   b.lengths = c.take<int32_t>(GN);
+  b.csum = c.take<float>(GN * (Tmax + 1));
+  b.kscale = c.take<float>(GN * (Tmax + 1));
   if (geom) *geom = ge;
   if (buf) *buf = b;
   return c.bytes();
@@ -710,6 +902,22 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
 
 static StepGraphs g_den_graphs;
 static std::map<std::pair<int, hipStream_t>, ParamSlot<DenParams>> g_den_slots;
+
+// One internal side stream (+ fork/join events) per caller stream, created on first use.
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static std::map<hipStream_t, SideStream> g_side_streams;
+static int get_side_stream(hipStream_t main, SideStream** out) {
+  auto it = g_side_streams.find(main);
+  if (it == g_side_streams.end()) {
+    SideStream s;
+    PK2_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    PK2_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+    PK2_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    it = g_side_streams.emplace(main, s).first;
+  }
+  *out = &it->second;
+  return PK2_OK;
+}
 
 template <int NG>
 static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stride,
@@ -730,7 +938,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   }
   // alpha / beta / gamma rows of split ("atomic") chunks accumulate with atomics -> start at zero
   PK2_HIP(hipMemsetAsync(b.alpha, 0, GN * (Tmax + 1) * (size_t)g->S * sizeof(float), stream));
-  PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)g->S * sizeof(float), stream));
+  PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)g->S * 2 * sizeof(float), stream));
   PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
   PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * (size_t)g->h_bwd.n_chunks * sizeof(float), stream));
 
@@ -740,9 +948,10 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   p.alpha = b.alpha; p.beta = b.beta; p.xs = b.xs; p.gamma = b.gamma;
   p.apart = b.apart; p.bpart = b.bpart; p.asum = b.asum; p.inv_tot = b.inv_tot;
   p.lengths = b.lengths;
-  p.ps_off = g->d_ps_off; p.ps_state = g->d_ps_state;
+  p.ps_off = g->d_ps_off; p.ps_state = g->d_ps_state; p.state_pdf = g->d_state_pdf;
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
   p.leaky = leaky; p.pi_sum = (float)g->pi_sum;
+  p.debug = getenv("PK2_DEN_DEBUG") ? atoi(getenv("PK2_DEN_DEBUG")) : 0;
 
   const size_t lds = den_lds_bytes(g->P, NG);
   static bool attr_set[8] = {false};
@@ -750,8 +959,6 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_fwd_step<NG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_bwd_step<NG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_beta_step<NG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[NG] = true;
   }
@@ -762,28 +969,41 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   const DenParams* pb = slot->params;
   const StepCounter* cnt = slot->counter;
 
-  hipLaunchKernelGGL(den_exp_transpose<NG>, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride,
-                     frame_stride, b.lengths, b.xs, g->P, Tmax);
-  hipLaunchKernelGGL(den_init<NG>, dim3(std::min(256, (g->S + 255) / 256), G), dim3(256), 0, stream, p);
-  PK2_LAUNCH_CHECK();
+  // Two kernel families: the "state-x" fast path when every state's incoming arcs share one pdf
+  // (PK2_DEN_MODE=general forces the general one), else LDS-staged exp(logits) + arc-based occupancies.
+  const char* mode = getenv("PK2_DEN_MODE");
+  const bool sx = g->state_pdf_unique && !(mode && strcmp(mode, "general") == 0);
   char key[96];
-  const dim3 gridF(g->fwd.n_chunks, G);
-  snprintf(key, sizeof(key), "den_fwd_%d_%u_%d_%zu_%p", NG, gridF.x, G, lds, (void*)stream);
-  rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
-    hipLaunchKernelGGL(den_fwd_step<NG>, gridF, dim3(kDenThreads), lds, s, pb, cnt, j);
-  });
-  if (rc) return rc;
-  hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
-  const bool state_gamma = g->state_pdf_unique && getenv("PK2_DEN_ARC_GAMMA") == nullptr;
-  if (state_gamma) {
-    const dim3 gridB(g->bwd.n_chunks, G);
-    snprintf(key, sizeof(key), "den_beta_%d_%u_%d_%zu_%p", NG, gridB.x, G, lds, (void*)stream);
+  hipLaunchKernelGGL(den_init<NG>, dim3(std::min(256, (g->S + 255) / 256), G), dim3(256), 0, stream, p);
+  if (sx) {
+    hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride,
+                       b.lengths, g->d_state_pdf, b.beta, g->S, Tmax);
+    PK2_LAUNCH_CHECK();
+    // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
+    // share one launch
+    const dim3 gridS(g->fwd.n_chunks + g->bwd.n_chunks, G);
+    snprintf(key, sizeof(key), "den_sx_%d_%u_%d_%p", NG, gridS.x, G, (void*)stream);
     rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
-      hipLaunchKernelGGL(den_beta_step<NG>, gridB, dim3(kDenThreads), lds, s, pb, cnt, j);
+      hipLaunchKernelGGL(den_step_sx<NG>, gridS, dim3(kDenThreads), 0, s, pb, cnt, j);
     });
     if (rc) return rc;
-    hipLaunchKernelGGL(den_gamma_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
+    hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
+    hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
+    hipLaunchKernelGGL(den_gamma_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, p, b.csum, b.kscale);
+    PK2_LAUNCH_CHECK();
+    return PK2_OK;
   } else {
+    hipLaunchKernelGGL(den_exp_transpose<NG>, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride,
+                       frame_stride, b.lengths, b.xs, g->P, Tmax);
+    PK2_LAUNCH_CHECK();
+    const dim3 gridF(g->fwd.n_chunks, G);
+    snprintf(key, sizeof(key), "den_fwd_%d_%u_%d_%zu_%p", NG, gridF.x, G, lds, (void*)stream);
+    rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
+      hipLaunchKernelGGL(den_fwd_step<NG>, gridF, dim3(kDenThreads), lds, s, pb, cnt, j);
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
     const dim3 gridB(std::max(g->bwd.n_chunks, g->gam.n_chunks), G);
     snprintf(key, sizeof(key), "den_bwd_%d_%u_%d_%zu_%p", NG, gridB.x, G, lds, (void*)stream);
     rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {

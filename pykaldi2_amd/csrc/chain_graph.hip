@@ -149,6 +149,7 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src, cons
       else if (spdf[dst[i]] != pdf[i]) unique = false;
     }
     g->state_pdf_unique = unique;
+    if (unique) g->state_pdf = spdf;
     if (unique) {
       g->ps_off.assign(P + 1, 0);
       for (int s = 0; s < S; ++s) if (spdf[s] >= 0) g->ps_off[spdf[s] + 1]++;
@@ -196,6 +197,7 @@ int den_upload(pk2_den_graph* g) {
   if (g->state_pdf_unique) {
     if ((rc = upload_vec(g, g->ps_off, &g->d_ps_off))) return rc;
     if ((rc = upload_vec(g, g->ps_state, &g->d_ps_state))) return rc;
+    if ((rc = upload_vec(g, g->state_pdf, &g->d_state_pdf))) return rc;
   }
   g->d_pi = const_cast<float*>(dpi);
   g->uploaded = true;

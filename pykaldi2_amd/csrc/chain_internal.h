@@ -55,7 +55,8 @@ struct pk2_den_graph {
   // state"), the occupancy of pdf p at frame t is sum_{d in states(p)} alpha[t+1,d]*beta[t+1,d]
   // and needs no arc traversal: states grouped by pdf (CSR).  Otherwise the arc-based pass runs.
   bool state_pdf_unique = false;
-  std::vector<int32_t> ps_off, ps_state;
+  std::vector<int32_t> ps_off, ps_state, state_pdf;
+  const int32_t* d_state_pdf = nullptr;
   const int32_t* d_ps_off = nullptr;
   const int32_t* d_ps_state = nullptr;
   double pi_sum = 0.0;
@@ -90,6 +91,8 @@ struct DenBuffers {
   float* den_lp;  // [G*NG]
   float* check;   // [G*NG]
   int32_t* lengths;  // [G*NG] device copy (0 for the padding sequences)
+  float* csum;    // [G][Tmax+1][NG]  sum_k pi[k] btilde'[t,k]   (state-x path)
+  float* kscale;  // [G][Tmax+1][NG]  beta[t] = kscale[t] * betahat[t] (state-x path)
 };
 
 int den_choose_ng(const pk2_den_graph* g);

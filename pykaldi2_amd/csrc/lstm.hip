@@ -21,6 +21,7 @@
 // workgroup always reads the same slice, and consecutive launches place block b on XCD b%8).
 // All activations are time-major ([T][B][...]) so "previous step" is a constant row offset.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "step_graph.h"
@@ -46,6 +47,7 @@ struct LstmFwdParams {
   float* gates;       // [D][T][B][4H]
   float* cells;       // [D][T][B][H]
   int B, T, H, D;
+  int debug;          // PK2_LSTM_DEBUG ablation bits (profiling only)
 };
 
 // KS = number of 4-wide MFMA k-steps per wave (H / 4 waves / 4).
@@ -67,8 +69,10 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
 
   // B operand: column j = li -> gate g = j/4, unit u0 + j%4 -> row g*H + u0 + j%4 of W_hh[d]
   f32x4 wf[KS / 4];
+#pragma unroll
+  for (int q = 0; q < KS / 4; ++q) wf[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int kbase = w * (KS * 4) + kq * KS;   // this lane's contiguous k-run of length KS
-  if (!first) {
+  if (!first && !(p.debug & 1)) {
     const float* wrow = p.whh + ((size_t)d * 4 * H + (size_t)(li >> 2) * H + u0 + (li & 3)) * H + kbase;
 #pragma unroll
     for (int q = 0; q < KS / 4; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + q * 4);
@@ -81,7 +85,7 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
     const bool pw_active = tid < 64 && pb < B;
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     float cprev = 0.f;
-    if (pw_active) {
+    if (pw_active && !(p.debug & 32)) {
       const float* gxr = p.gx + ((size_t)t * B + pb) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + pu;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
       const int b = mt * 16 + li;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       f32x4 af[KS / 4];
-      if (b < B) {
+      if (b < B && !(p.debug & 2)) {
         const float* hrow = p.y + ((size_t)tp * B + b) * yrow + (size_t)d * H + kbase;
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(hrow + q * 4);
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
         for (int q = 0; q < KS / 4; ++q) af[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int q = 0; q < KS / 4; ++q) {
+      for (int q = 0; q < ((p.debug & 4) ? 1 : KS / 4); ++q) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][0], wf[q][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][1], wf[q][1], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][2], wf[q][2], acc0, 0, 0, 0);
@@ -121,13 +125,20 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
           pre[g] += (part[0][pi_][g * 4 + pu] + part[1][pi_][g * 4 + pu]) +
                     (part[2][pi_][g * 4 + pu] + part[3][pi_][g * 4 + pu]);
       }
-      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-      const float c = fg * cprev + ig * gg;
-      const float h = og * tanhf(c);
+      float ig, fg, gg, og, c, h;
+      if (p.debug & 8) {
+        ig = pre[0]; fg = pre[1]; gg = pre[2]; og = pre[3]; c = fg * cprev + ig * gg; h = og * c;
+      } else {
+        ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
+        c = fg * cprev + ig * gg;
+        h = og * tanhf(c);
+      }
       p.cells[(((size_t)d * T + t) * B + pb) * H + u0 + pu] = c;
       p.y[((size_t)t * B + pb) * yrow + (size_t)d * H + u0 + pu] = h;
-      float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
-      gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
+      if (!(p.debug & 16)) {
+        float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
+        gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
+      }
     }
     __syncthreads();
   }
@@ -268,7 +279,8 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
   ParamSlot<LstmFwdParams>* slot;
   int rc = get_param_slot(g_fwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;
-  LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D};
+  LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D,
+                  getenv("PK2_LSTM_DEBUG") ? atoi(getenv("PK2_LSTM_DEBUG")) : 0};
   hipLaunchKernelGGL(param_block_store<LstmFwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
   dim3 grid(H / kFwdUnits, D), block(kFwdThreads);
   const LstmFwdParams* pb = slot->params;

@@ -46,8 +46,51 @@ class StepGraphs {
     return PK2_OK;
   }
 
+  // Two independent chains (each its own counter) replayed as the two parallel branches of one graph.
+  template <typename LaunchA, typename LaunchB>
+  int run2(const std::string& key, int T, StepCounter* ca, StepCounter* cb, hipStream_t stream, LaunchA la,
+           LaunchB lb) {
+    hipLaunchKernelGGL(step_counter_set, dim3(1), dim3(1), 0, stream, ca, T);
+    hipLaunchKernelGGL(step_counter_set, dim3(1), dim3(1), 0, stream, cb, T);
+    int done = 0;
+    while (done < T) {
+      const int len = (T - done >= kBig) ? kBig : kSmall;
+      hipGraphExec_t exec;
+      auto it = cache_.find({key, len});
+      if (it != cache_.end()) {
+        exec = it->second;
+      } else {
+        if (!cap_) PK2_HIP(hipStreamCreateWithFlags(&cap_, hipStreamNonBlocking));
+        if (!cap2_) {
+          PK2_HIP(hipStreamCreateWithFlags(&cap2_, hipStreamNonBlocking));
+          PK2_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+          PK2_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        }
+        hipGraph_t graph;
+        PK2_HIP(hipStreamBeginCapture(cap_, hipStreamCaptureModeThreadLocal));
+        PK2_HIP(hipEventRecord(ev_fork_, cap_));
+        PK2_HIP(hipStreamWaitEvent(cap2_, ev_fork_, 0));
+        for (int j = 0; j < len; ++j) la(cap_, j);
+        hipLaunchKernelGGL(step_counter_bump, dim3(1), dim3(1), 0, cap_, ca, len);
+        for (int j = 0; j < len; ++j) lb(cap2_, j);
+        hipLaunchKernelGGL(step_counter_bump, dim3(1), dim3(1), 0, cap2_, cb, len);
+        PK2_HIP(hipEventRecord(ev_join_, cap2_));
+        PK2_HIP(hipStreamWaitEvent(cap_, ev_join_, 0));
+        PK2_HIP(hipStreamEndCapture(cap_, &graph));
+        PK2_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        PK2_HIP(hipGraphDestroy(graph));
+        cache_[{key, len}] = exec;
+      }
+      PK2_HIP(hipGraphLaunch(exec, stream));
+      done += len;
+    }
+    return PK2_OK;
+  }
+
  private:
   static constexpr int kBig = 64, kSmall = 8;
+  hipStream_t cap2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::map<std::pair<std::string, int>, hipGraphExec_t> cache_;
   hipStream_t cap_ = nullptr;
 

@@ -10,21 +10,30 @@ from pykaldi2_amd import chain, ops, synth
 pytestmark = pytest.mark.gpu
 
 
-def _mk(S, A, P, seed):
+def _mk(S, A, P, seed, arc_pdf=False):
     g = synth.den_graph_arcs(S, A, P, seed)
+    if arc_pdf:  # pdf no longer a function of the destination state -> general (arc-based) kernels
+        g["pdf"] = np.random.default_rng(seed).integers(0, P, size=g["pdf"].shape[0]).astype(np.int32)
     return g, chain.DenominatorGraph(g, P), R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, P)
 
 
+@pytest.mark.parametrize("path", ["state_x", "general_forced", "arc_pdf"])
 @pytest.mark.parametrize("S,A,P,lens,leaky", [
     (8, 30, 5, [6], 1e-2),
     (200, 3000, 40, [51, 17, 33], 1e-4),
     (2000, 60000, 600, [101, 80, 57, 90, 13], 1e-4),     # 5 sequences -> two groups of 4
     (200, 20000, 11, [40, 25], 1e-3),                      # forces split ("atomic") rows
 ])
-def test_denominator_matches_oracle(S, A, P, lens, leaky):
-    g, G, ref = _mk(S, A, P, seed=S)
+def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
+    """Both kernel families: the state-x fast path (pdf is a function of the destination state) and
+    the general LDS-staged / arc-based-occupancy path (forced by env, and on a graph that needs it)."""
+    if path == "general_forced":
+        monkeypatch.setenv("PK2_DEN_MODE", "general")
+    g, G, ref = _mk(S, A, P, seed=S, arc_pdf=(path == "arc_pdf"))
     if A == 20000:
         g["dst"][:6000] = 5
+        if path != "arc_pdf":
+            g["pdf"][:6000] = g["pdf"][0]
         G = chain.DenominatorGraph(g, P)
         ref = R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, P)
     rng = np.random.default_rng(1)
@@ -51,10 +60,10 @@ def _ref_fst(s):
     return R.NumFstRef(s.num_states, s.src, s.dst, s.pdf, s.arc_weight, s.final_states, s.final_weights, s.state_time)
 
 
-@pytest.mark.parametrize("xent", [0.0, 0.1])
-def test_chain_objf_and_deriv_matches_oracle(xent):
+@pytest.mark.parametrize("xent,arc_pdf", [(0.0, False), (0.1, False), (0.1, True)])
+def test_chain_objf_and_deriv_matches_oracle(xent, arc_pdf):
     S, A, P = 2000, 60000, 600
-    g, G, ref = _mk(S, A, P, seed=11)
+    g, G, ref = _mk(S, A, P, seed=11, arc_pdf=arc_pdf)
     rng = np.random.default_rng(3)
     frames = [301, 160, 250, 90]
     sups = [_sup(synth.pdf_alignment(rng, T, P), P) for T in frames]
