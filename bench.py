@@ -102,8 +102,16 @@ def den_roofline(den, logits_bf, lens, reps=5):
     Tsum, Tmax = int(sum(lens)), int(max(lens))
     byts = Tsum * 4 * (3 * P + 2 * (S_DEN + 1)) + 24 * A_DEN * Tmax
     ach = byts / (ms * 1e-3) / 1e9
+    # HBM bytes per call from the committed PMC passes of this same command (`bench.py --den-only`);
+    # counters cannot be read live, so this is the profile's number for the fixed --den-only workload.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_den_traffic.json")) as f:
+            traffic = int(json.load(f)["traffic_bytes_raw"])
+    except Exception:
+        pass
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=None, kernel="pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; "
+                traffic=traffic, kernel="pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; "
                 "forward frame t and backward frame Tmax-1-t share a launch)",
                 ms_per_launch=round(ms, 3), algorithmic_bytes=byts)
 

@@ -904,9 +904,8 @@ static StepGraphs g_den_graphs;
 static std::map<std::pair<int, hipStream_t>, ParamSlot<DenParams>> g_den_slots;
 
 // One internal side stream (+ fork/join events) per caller stream, created on first use.
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static std::map<hipStream_t, SideStream> g_side_streams;
-static int get_side_stream(hipStream_t main, SideStream** out) {
+int get_side_stream(hipStream_t main, SideStream** out) {
   auto it = g_side_streams.find(main);
   if (it == g_side_streams.end()) {
     SideStream s;

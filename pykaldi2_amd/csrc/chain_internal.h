@@ -105,6 +105,11 @@ int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64
                 const int32_t* lengths_host, const DenGeom& geom, const DenBuffers& buf,
                 float leaky, hipStream_t stream);
 
+// Internal side stream (+ fork/join events) paired with a caller stream: the numerator runs there while
+// the denominator occupies the caller's stream.
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+int get_side_stream(hipStream_t main, SideStream** out);
+
 // Numerator.
 struct NumBuffers {
   float* score;     // [total_arcs]

@@ -120,14 +120,23 @@ extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* lo
   size_t need = chain_carve(g, N, Tmax, bound, bound, workspace, &ge, &db, &nbuf, &flags, &ldev);
   PK2_REQUIRE(workspace_bytes >= need, "chain_objf_and_deriv: workspace %zu < %zu", workspace_bytes, need);
 
-  // 1. gradient buffer starts at zero; the numerator adds (1 + xent_regularize) * w * posterior
-  hipLaunchKernelGGL(zero_rows, dim3(Tmax, N), dim3(256), 0, stream, grad, gss, gfs, g->P, Tmax);
-  int rc = num_compute(num, logits, seq_stride, frame_stride, lengths, N,
-                       weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, stream);
+  // 1. gradient buffer starts at zero; the numerator adds (1 + xent_regularize) * w * posterior.
+  //    It is a latency-bound one-workgroup-per-sequence kernel: it runs on the side stream while the
+  //    denominator uses the caller's stream.
+  SideStream* side;
+  int rc = get_side_stream(stream, &side);
   if (rc) return rc;
+  hipLaunchKernelGGL(zero_rows, dim3(Tmax, N), dim3(256), 0, stream, grad, gss, gfs, g->P, Tmax);
+  PK2_HIP(hipEventRecord(side->fork, stream));
+  PK2_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+  rc = num_compute(num, logits, seq_stride, frame_stride, lengths, N,
+                   weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, side->stream);
+  if (rc) return rc;
+  PK2_HIP(hipEventRecord(side->join, side->stream));
   // 2. denominator
   rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream);
   if (rc) return rc;
+  PK2_HIP(hipStreamWaitEvent(stream, side->join, 0));
   // 3. objective, guards, gradient = numerator - denominator occupancies
   hipLaunchKernelGGL(chain_flags, dim3((N + 63) / 64), dim3(64), 0, stream, nbuf.num_lp, db.den_lp,
                      db.check, db.lengths, N, weight, out, flags);

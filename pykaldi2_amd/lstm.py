@@ -120,13 +120,31 @@ class _LstmAmFunction(torch.autograd.Function):
         gflat = m._grad_flat()
         views = m._grad_views(gflat)
         y_last = ctx.saved[-1][1]
-        # output layer: dW = dlogits^T y, db = colsum(dlogits), dy = dlogits W
+        # The serial chain is  dlogits -> dy -> recurrence(l=L-1) -> dy -> recurrence(l=L-2) ...; the
+        # weight / bias gradients hang off it.  They are throughput-bound GEMMs, the recurrences are
+        # latency-bound step kernels, so the weight gradients go to a side stream and overlap.
+        main = torch.cuda.current_stream(dev)
+        side = m._side_stream(dev)
+
+        def on_side(fn, *tensors):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+            for t_ in tensors:
+                t_.record_stream(side)
+
+        # output layer: dy = dlogits W (critical path), dW = dlogits^T y, db = colsum(dlogits)
         gw, gb = views["output_layer.weight"], views["output_layer.bias"]
-        _gemm(1, 0, P, D * H, rows, _p(dlogits), P, _p(y_last), D * H, _p(gw), D * H)
-        _lib.check(L.pk2_colsum_f32(_p(dlogits), P, rows, P, 0.0, _p(gb), sp))
         dy = torch.empty(T, B, D * H, device=dev, dtype=torch.float32)
         _gemm(0, 0, rows, D * H, P, _p(dlogits), P, _p(m.output_layer.weight), D * H, _p(dy), D * H)
-        m._bucket_ready("output_layer")
+
+        def out_grads():
+            _gemm(1, 0, P, D * H, rows, _p(dlogits), P, _p(y_last), D * H, _p(gw), D * H)
+            _lib.check(L.pk2_colsum_f32(_p(dlogits), P, rows, P, 0.0, _p(gb), _lib.stream_ptr()))
+            m._bucket_ready("output_layer")
+        on_side(out_grads, dlogits, y_last)
         scratch = torch.empty(L.pk2_lstm_bwd_scratch_floats(B, H, D), device=dev, dtype=torch.float32)
         dx = None
         for l in range(Lr - 1, -1, -1):
@@ -138,28 +156,42 @@ class _LstmAmFunction(torch.autograd.Function):
             _lib.check(L.pk2_lstm_layer_bwd(_p(dy), _p(w_hh), _p(gates), _p(cells), B, T, H, D, _p(dgx),
                                             _p(scratch), sp))
             G = D * 4 * H
-            # bias gradients (b_ih and b_hh receive the same sum)
-            _lib.check(L.pk2_colsum_f32(_p(dgx), G, rows, G, 0.0, _p(gb_ih), sp))
-            gb_hh.copy_(gb_ih)
-            # dW_ih (both directions at once) = dgx^T inp
-            _gemm(1, 0, G, in_size, rows, _p(dgx), G, _p(inp), in_size, _p(gw_ih), in_size)
-            # dW_hh[d] = sum_t dg_d[t]^T h_d[t-1]  (reverse direction: h_d[t+1]); time-major => row shift by B
-            if T > 1:
-                k = (T - 1) * B
-                _gemm(1, 0, 4 * H, H, k, _p(dgx, B * G), G, _p(y), D * H, _p(gw_hh), H)
-                if D == 2:
-                    _gemm(1, 0, 4 * H, H, k, _p(dgx, 4 * H), G, _p(y, B * D * H + H), D * H,
-                          _p(gw_hh, 4 * H * H), H)
-            else:
-                gw_hh.zero_()
+
+            def layer_grads(dgx=dgx, inp=inp, y=y, in_size=in_size, gw_ih=gw_ih, gw_hh=gw_hh, gb_ih=gb_ih,
+                            gb_hh=gb_hh, l=l):
+                # bias gradients (b_ih and b_hh receive the same sum)
+                _lib.check(L.pk2_colsum_f32(_p(dgx), G, rows, G, 0.0, _p(gb_ih), _lib.stream_ptr()))
+                gb_hh.copy_(gb_ih)
+                # dW_ih (both directions at once) = dgx^T inp
+                _gemm(1, 0, G, in_size, rows, _p(dgx), G, _p(inp), in_size, _p(gw_ih), in_size)
+                # dW_hh[d] = sum_t dg_d[t]^T h_d[t-1] (reverse direction: h_d[t+1]); time-major => row shift by B
+                if T > 1:
+                    k = (T - 1) * B
+                    _gemm(1, 0, 4 * H, H, k, _p(dgx, B * G), G, _p(y), D * H, _p(gw_hh), H)
+                    if D == 2:
+                        _gemm(1, 0, 4 * H, H, k, _p(dgx, 4 * H), G, _p(y, B * D * H + H), D * H,
+                              _p(gw_hh, 4 * H * H), H)
+                else:
+                    gw_hh.zero_()
+                m._bucket_ready("lstm.l%d" % l)
+            # critical path first (next layer's dy), weight gradients on the side stream
             if l > 0 or ctx.need_dx:
                 dprev = torch.empty(T, B, in_size, device=dev, dtype=torch.float32)
+                ev = torch.cuda.Event()
+                ev.record(main)
                 _gemm(0, 0, rows, in_size, G, _p(dgx), G, _p(w_ih), in_size, _p(dprev), in_size)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    layer_grads()
+                for t_ in (dgx, inp, y):
+                    t_.record_stream(side)
                 if l > 0:
                     dy = dprev
                 else:
                     dx = dprev
-            m._bucket_ready("lstm.l%d" % l)
+            else:
+                on_side(layer_grads, dgx, inp, y)
+        main.wait_stream(side)
         # Parameter gradients are published directly as views of the flat gradient buffer
         # (p.grad = gradient of THIS backward, which is what zero_grad -> backward -> step needs);
         # autograd gets None for them so nothing is copied or double-counted.
@@ -257,6 +289,13 @@ class LSTMAM(nn.Module):
             n = D * 4 * H * cols
             return flat[o:o + n].view(D * 4 * H, cols) if cols > 1 else flat[o:o + D * 4 * H]
         return seg("weight_ih", in_size), seg("weight_hh", H), seg("bias_ih", 1), seg("bias_hh", 1)
+
+    def _side_stream(self, dev):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != dev:
+            st = torch.cuda.Stream(device=dev)
+            self._side = st
+        return st
 
     def _bucket_ready(self, name):
         if self._bucket_hook is not None:

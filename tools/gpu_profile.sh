@@ -1,0 +1,24 @@
+#!/bin/bash
+# GPU box: produce the artefacts kept under profiles/ (kernel-trace stats of the bench command, HBM counters of
+# the denominator call in separate --pmc passes) plus the bench JSON line.
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 900 python bench.py --gpus 1 --steps ${STEPS:-20} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
+echo "bench exit $?" >> gpurun_out/summary.txt
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
+echo "rocprof bench exit $?" >> $R/gpurun_out/summary.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_$c -o den -- python $R/bench.py --den-only > $R/gpurun_out/pmc_$c.log 2>&1
+  echo "pmc $c exit $?" >> $R/gpurun_out/summary.txt
+done
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/den_trace -o den -- python $R/bench.py --den-only > $R/gpurun_out/den_trace.log 2>&1
+cd $R
+python tools/prof_stats.py gpurun_out/prof/bench_results.db 30 > gpurun_out/r01_bench_kernel_stats.txt
+python tools/prof_stats.py gpurun_out/den_trace/den_results.db 12 > gpurun_out/r01_den_kernel_stats.txt
+python tools/pmc_stats.py gpurun_out/pmc_FETCH_SIZE/den_results.db > gpurun_out/r01_den_pmc.txt
+python tools/pmc_stats.py gpurun_out/pmc_WRITE_SIZE/den_results.db >> gpurun_out/r01_den_pmc.txt
+grep -o '{"bound.*' gpurun_out/den_trace.log > gpurun_out/r01_den_only.json
+rm -rf gpurun_out/prof gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/den_trace
+cat gpurun_out/summary.txt; cat gpurun_out/bench.json
