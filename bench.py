@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
     ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
+    ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
     args = ap.parse_args()
 
     hvd.init()
@@ -210,6 +211,26 @@ def main():
     g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
     den = chain.DenominatorGraph(g, P)
     log("den graph ready")
+    if args.gemm_only:
+        from pykaldi2_amd.lstm import _gemm, _p
+        shapes = [(0, 1, 2356, 4096, 1024), (0, 1, 2356, 6048, 1024), (1, 0, 6048, 1024, 2356), (0, 0, 2356, 1024, 6048),
+                  (1, 0, 4096, 1024, 2356), (1, 0, 2048, 512, 2352), (0, 0, 2356, 1024, 4096), (0, 1, 2356, 4096, 80),
+                  (0, 1, 20480, 4096, 1024), (0, 1, 4096, 4096, 4096)]
+        for ta, tb, M, N, K in shapes:
+            A = torch.randn((K, M) if ta else (M, K), device=dev)
+            Bm = torch.randn((N, K) if tb else (K, N), device=dev)
+            C = torch.empty(M, N, device=dev)
+            for _ in range(3):
+                _gemm(ta, tb, M, N, K, _p(A), A.shape[1], _p(Bm), Bm.shape[1], _p(C), N)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                _gemm(ta, tb, M, N, K, _p(A), A.shape[1], _p(Bm), Bm.shape[1], _p(C), N)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print("gemm ta=%d tb=%d M=%5d N=%5d K=%5d  %7.1f us  %6.1f TFLOP/s" % (ta, tb, M, N, K, 1e3 * ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+        return
     if args.lstm_only:
         from pykaldi2_amd import _lib
         T, B, H, D = 589, 4, 512, 2

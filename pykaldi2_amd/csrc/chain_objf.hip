@@ -3,6 +3,7 @@
 // (reference ops/ops.py:267), all on the device, no host round trip (reference
 // ops/ops.py:255,261,269-271 copy [T,P] logits to the host and the gradient back per utterance).
 #include <algorithm>
+#include <cstdlib>
 
 #include "chain_internal.h"
 
@@ -121,22 +122,29 @@ extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* lo
   PK2_REQUIRE(workspace_bytes >= need, "chain_objf_and_deriv: workspace %zu < %zu", workspace_bytes, need);
 
   // 1. gradient buffer starts at zero; the numerator adds (1 + xent_regularize) * w * posterior.
-  //    It is a latency-bound one-workgroup-per-sequence kernel: it runs on the side stream while the
+  //    It is a latency-bound one-workgroup-per-sequence kernel; it can run on a side stream while the
   //    denominator uses the caller's stream.
-  SideStream* side;
-  int rc = get_side_stream(stream, &side);
+  // (side stream only with PK2_SIDE_STREAM=1: on ROCm 7.2 a second active stream slows the graph-replayed
+  //  frame chain of the denominator more than the overlap returns)
+  const char* ss = getenv("PK2_SIDE_STREAM");
+  const bool use_side = ss != nullptr && ss[0] == '1';
+  SideStream* side = nullptr;
+  int rc = use_side ? get_side_stream(stream, &side) : 0;
   if (rc) return rc;
+  hipStream_t num_stream = use_side ? side->stream : stream;
   hipLaunchKernelGGL(zero_rows, dim3(Tmax, N), dim3(256), 0, stream, grad, gss, gfs, g->P, Tmax);
-  PK2_HIP(hipEventRecord(side->fork, stream));
-  PK2_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+  if (use_side) {
+    PK2_HIP(hipEventRecord(side->fork, stream));
+    PK2_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+  }
   rc = num_compute(num, logits, seq_stride, frame_stride, lengths, N,
-                   weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, side->stream);
+                   weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, num_stream);
   if (rc) return rc;
-  PK2_HIP(hipEventRecord(side->join, side->stream));
+  if (use_side) PK2_HIP(hipEventRecord(side->join, side->stream));
   // 2. denominator
   rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream);
   if (rc) return rc;
-  PK2_HIP(hipStreamWaitEvent(stream, side->join, 0));
+  if (use_side) PK2_HIP(hipStreamWaitEvent(stream, side->join, 0));
   // 3. objective, guards, gradient = numerator - denominator occupancies
   hipLaunchKernelGGL(chain_flags, dim3((N + 63) / 64), dim3(64), 0, stream, nbuf.num_lp, db.den_lp,
                      db.check, db.lengths, N, weight, out, flags);

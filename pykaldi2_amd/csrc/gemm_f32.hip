@@ -11,6 +11,7 @@
 // conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  The next k-tile is
 // prefetched into registers while the current one is multiplied.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -18,23 +19,30 @@ namespace pk2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_LD = 132;  // padded leading dimension of the [BK][128] LDS tiles
+constexpr int BK = 16;
 constexpr int kGemmThreads = 256;
+// TILES = MFMA tiles per wave per dimension: block tile (64*TILES)^2.  TILES = 2 (128x128) for large
+// grids; TILES = 1 (64x64) when 128x128 tiles would leave the 256 CUs with fewer than ~2 workgroups
+// each (one wave per SIMD cannot hide its own LDS/global latency).
+template <int TILES> struct Geo {
+  static constexpr int BMN = 64 * TILES;        // block tile edge
+  static constexpr int LD = BMN + 4;            // padded leading dimension of the [BK][BMN] LDS tiles
+  static constexpr int LPK = 16 * TILES;        // lanes covering one k-row when the row dim is contiguous
+};
 
 // Loads the 128 x 16 (rows x k) slab of an operand into registers.
 //   KCONTIG: element (r, k) at base[r*ld + k]  -> thread owns float4 along k of 2 rows
 //  !KCONTIG: element (r, k) at base[k*ld + r]  -> thread owns float4 along r of 2 k's
 // Out-of-range elements read as 0.  `vec` = base/ld allow aligned float4 loads.
-template <bool KCONTIG>
+template <bool KCONTIG, int TILES>
 __device__ __forceinline__ void load_slab(const float* __restrict__ base, int64_t ld, int r0, int k0,
-                                          int R, int K, bool vec, float4 (&reg)[2]) {
+                                          int R, int K, bool vec, float4 (&reg)[TILES]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < TILES; ++h) {
     int r, k;
     if (KCONTIG) { r = (tid >> 2) + h * 64; k = (tid & 3) * 4; }
-    else         { k = (tid >> 5) + h * 8;  r = (tid & 31) * 4; }
+    else         { k = tid / Geo<TILES>::LPK + h * (kGemmThreads / Geo<TILES>::LPK); r = (tid % Geo<TILES>::LPK) * 4; }
     const int gr = r0 + r, gk = k0 + k;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KCONTIG) {
@@ -66,80 +74,82 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ base, int64_
   }
 }
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_slab(float* __restrict__ tile, const float4 (&reg)[2]) {
+template <bool KCONTIG, int TILES>
+__device__ __forceinline__ void store_slab(float* __restrict__ tile, const float4 (&reg)[TILES]) {
   const int tid = threadIdx.x;
+  constexpr int LD = Geo<TILES>::LD;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < TILES; ++h) {
     if (KCONTIG) {
       const int r = (tid >> 2) + h * 64, k = (tid & 3) * 4;
-      tile[(k + 0) * LDS_LD + r] = reg[h].x;
-      tile[(k + 1) * LDS_LD + r] = reg[h].y;
-      tile[(k + 2) * LDS_LD + r] = reg[h].z;
-      tile[(k + 3) * LDS_LD + r] = reg[h].w;
+      tile[(k + 0) * LD + r] = reg[h].x;
+      tile[(k + 1) * LD + r] = reg[h].y;
+      tile[(k + 2) * LD + r] = reg[h].z;
+      tile[(k + 3) * LD + r] = reg[h].w;
     } else {
-      const int k = (tid >> 5) + h * 8, r = (tid & 31) * 4;
-      *reinterpret_cast<float4*>(&tile[k * LDS_LD + r]) = reg[h];
+      const int k = tid / Geo<TILES>::LPK + h * (kGemmThreads / Geo<TILES>::LPK), r = (tid % Geo<TILES>::LPK) * 4;
+      *reinterpret_cast<float4*>(&tile[k * LD + r]) = reg[h];
     }
   }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int TILES>
 __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, int K, float alpha,
                                                                 const float* __restrict__ A, int64_t lda,
                                                                 const float* __restrict__ B, int64_t ldb,
                                                                 float beta, float* __restrict__ C, int64_t ldc,
                                                                 const float* __restrict__ bias, bool vecA,
                                                                 bool vecB) {
+  constexpr int LDS_LD = Geo<TILES>::LD, BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
   __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TILES][TILES];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TILES; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TILES; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[2];
+  float4 ra[TILES], rb[TILES];
   // A is "k-contiguous" when not transposed ([M,K]); B is k-contiguous when transposed ([N,K]).
-  load_slab<!TA>(A, lda, m0, 0, M, K, vecA, ra);
-  load_slab<TB>(B, ldb, n0, 0, N, K, vecB, rb);
+  load_slab<!TA, TILES>(A, lda, m0, 0, M, K, vecA, ra);
+  load_slab<TB, TILES>(B, ldb, n0, 0, N, K, vecB, rb);
   const int nk = (K + BK - 1) / BK;
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // previous tile fully consumed
-    store_slab<!TA>(As, ra);
-    store_slab<TB>(Bs, rb);
+    store_slab<!TA, TILES>(As, ra);
+    store_slab<TB, TILES>(Bs, rb);
     __syncthreads();
     if (kt + 1 < nk) {
-      load_slab<!TA>(A, lda, m0, (kt + 1) * BK, M, K, vecA, ra);
-      load_slab<TB>(B, ldb, n0, (kt + 1) * BK, N, K, vecB, rb);
+      load_slab<!TA, TILES>(A, lda, m0, (kt + 1) * BK, M, K, vecA, ra);
+      load_slab<TB, TILES>(B, ldb, n0, (kt + 1) * BK, N, K, vecB, rb);
     }
     const int kq = lane >> 5, li = lane & 31;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[2];
+      float a[TILES], b[TILES];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[(kk + kq) * LDS_LD + wm + i * 32 + li];
+      for (int i = 0; i < TILES; ++i) a[i] = As[(kk + kq) * LDS_LD + wm + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + kq) * LDS_LD + wn + j * 32 + li];
+      for (int j = 0; j < TILES; ++j) b[j] = Bs[(kk + kq) * LDS_LD + wn + j * 32 + li];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TILES; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TILES; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TILES; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TILES; ++j) {
       const int gc = n0 + wn + j * 32 + col_l;
       if (gc >= N) continue;
       const float bv = bias ? bias[gc] : 0.f;
@@ -185,10 +195,20 @@ extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const bool vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
   const bool vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(kGemmThreads);
-#define PK2_GEMM(TA, TB)                                                                               \
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, ldb, \
-                     beta, C, ldc, bias, vecA, vecB)
+  const int64_t big_tiles = (int64_t)((N + 127) / 128) * ((M + 127) / 128);
+  const char* force = getenv("PK2_GEMM_TILES");
+  const int tiles = force ? atoi(force) : (big_tiles >= 512 ? 2 : 1);
+  const int edge = 64 * tiles;
+  dim3 grid((N + edge - 1) / edge, (M + edge - 1) / edge), block(kGemmThreads);
+#define PK2_GEMM(TA, TB)                                                                                   \
+  do {                                                                                                     \
+    if (tiles == 2)                                                                                        \
+      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, block, 0, stream, M, N, K, alpha, A, lda, B,  \
+                         ldb, beta, C, ldc, bias, vecA, vecB);                                             \
+    else                                                                                                   \
+      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, block, 0, stream, M, N, K, alpha, A, lda, B,  \
+                         ldb, beta, C, ldc, bias, vecA, vecB);                                             \
+  } while (0)
   if (!transa && !transb) PK2_GEMM(false, false);
   else if (!transa && transb) PK2_GEMM(false, true);
   else if (transa && !transb) PK2_GEMM(true, false);

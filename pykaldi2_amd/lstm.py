@@ -18,6 +18,7 @@ array; within a layer the two directions' matrices are adjacent, so both
 directions share one GEMM.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -121,10 +122,12 @@ class _LstmAmFunction(torch.autograd.Function):
         views = m._grad_views(gflat)
         y_last = ctx.saved[-1][1]
         # The serial chain is  dlogits -> dy -> recurrence(l=L-1) -> dy -> recurrence(l=L-2) ...; the
-        # weight / bias gradients hang off it.  They are throughput-bound GEMMs, the recurrences are
-        # latency-bound step kernels, so the weight gradients go to a side stream and overlap.
+        # weight / bias gradients hang off it and could overlap it on a side stream (PK2_SIDE_STREAM=1).
+        # Measured on MI355X / ROCm 7.2: a second active stream slows the graph-replayed step chains of
+        # the main stream by ~25 % (52.6 vs 48.5 ms per step), more than the overlap returns, so the
+        # default keeps everything on the caller's stream.
         main = torch.cuda.current_stream(dev)
-        side = m._side_stream(dev)
+        side = m._side_stream(dev) if os.environ.get("PK2_SIDE_STREAM") == "1" else main
 
         def on_side(fn, *tensors):
             ev = torch.cuda.Event()

@@ -85,3 +85,67 @@ def test_hvd_shim_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs)
+
+
+FLAT_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %(root)r)
+from pykaldi2_amd import hvd
+hvd.init(backend="gloo")
+rank, size = hvd.rank(), hvd.size()
+
+class FlatModel:
+    """Stands in for LSTMAM: flat parameter / gradient buffers, buckets published as backward proceeds."""
+    def __init__(self):
+        self.p = torch.arange(8, dtype=torch.float32)
+        self.g = torch.zeros(8)
+        self._bucket_hook = None
+    def flat_parameters(self):
+        return self.p, self.g
+    def parameters(self):
+        return [self.p]
+    def backward(self):
+        self.g[4:] = float(rank + 1)            # "output layer" bucket is produced first
+        if self._bucket_hook: self._bucket_hook("output_layer", self.g[4:])
+        self.g[:4] = 10.0 * (rank + 1)
+        if self._bucket_hook: self._bucket_hook("lstm.l0", self.g[:4])
+
+class PlainSGD:
+    def __init__(self, model, lr):
+        self.model, self.lr, self.grad_scale = model, lr, 1.0
+        self.param_groups = [dict(lr=lr, params=model.parameters())]
+    def zero_grad(self): pass
+    def measure_grad_norm(self, max_norm):
+        return (self.model.g.norm() * self.grad_scale).reshape(1)
+    def step(self):
+        p, g = self.model.flat_parameters()
+        p -= self.lr * self.grad_scale * g
+
+m = FlatModel()
+opt = hvd.DistributedOptimizer(PlainSGD(m, 0.5))
+assert m._bucket_hook is not None and abs(opt.grad_scale - 0.5) < 1e-12
+opt.zero_grad(); m.backward()
+norm = opt.measure_grad_norm(5.0)             # synchronises the buckets first
+opt.step()
+# summed gradient: [30]*4 + [3]*4, averaged -> [15]*4 + [1.5]*4
+expect = torch.arange(8, dtype=torch.float32) - 0.5 * torch.tensor([15.0] * 4 + [1.5] * 4)
+assert torch.allclose(m.p, expect), (m.p, expect)
+assert abs(norm.item() - torch.tensor([15.0] * 4 + [1.5] * 4).norm().item()) < 1e-5
+print("OK", rank)
+hvd.shutdown()
+'''
+
+
+def test_hvd_flat_bucketed_allreduce_world_size_2_gloo(tmp_path):
+    script = tmp_path / "f.py"
+    script.write_text(FLAT_WORKER % dict(root=ROOT))
+    port = str(29900 + os.getpid() % 90)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)
