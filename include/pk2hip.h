@@ -147,6 +147,12 @@ int pk2_pad_roll_subsample(const float* feats, const int64_t* feat_row_off, int3
                            int32_t max_t, int32_t shift, int32_t subsample, float* x,
                            int32_t out_t, int32_t time_major, void* stream);
 
+/* y = (x - mean) / std per feature dimension: GlobalMeanVarianceNormalization.apply_on_ndarray
+ * (reference reader/preprocess.py:211-229, applied at data/sr_dataset.py:184-185).  x, y: device f32
+ * [rows][dim]; mean, std: device f32 [dim]. */
+int pk2_mvn_apply(const float* x, const float* mean, const float* stdv, int64_t rows, int32_t dim,
+                  float* y, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Fused log-softmax + NLL + gradient.  Replaces nn.CrossEntropyLoss
  * (ignore_index=-100; reduction mean: reference bin/train_ce.py:134,189;
@@ -205,6 +211,12 @@ int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, co
                        float* scratch, void* stream);
 /* The W_hh gradient dwhh[d] = sum_t dgates[d][t]^T h[d][t-1] (t+1 for the reverse direction)
  * is one pk2_gemm_f32 by the caller over row-shifted slices of dgx and y. */
+
+/* Inverted dropout y = x * m/(1-p), m ~ Bernoulli(1-p), with a counter-based mask that is a pure
+ * function of (seed, element index): calling it again on the gradient with the same seed applies the
+ * same mask (no mask storage).  Replaces nn.LSTM's inter-layer dropout (reference models/lstm.py:49-54,
+ * configs/ce.yaml:19).  x == y allowed. */
+int pk2_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------ *
  * Optimiser: global-norm clip + Adam(amsgrad) / SGD(momentum) over one flat

@@ -51,3 +51,16 @@ def pad_roll_subsample(feat_list, shift=0, subsample=1):
         x[i, :f.shape[0]] = f
     x = np.roll(x, shift, axis=1)
     return x[:, ::subsample]
+
+
+def utt2seg(data, seg_len, seg_shift):
+    """_utt2seg on a [T, D] matrix (reference data/sr_dataset.py:40-52 works on the transpose):
+    n_seg = floor((T - seg_len) / seg_shift) + 1 non-overlapping-by-shift windows, tail dropped."""
+    T = data.shape[0]
+    n_seg = int(np.floor((T - seg_len) / seg_shift)) + 1
+    return [data[i * seg_shift:i * seg_shift + seg_len] for i in range(max(0, n_seg))]
+
+
+def mvn_apply(x, mean_vec, std_vec):
+    """GlobalMeanVarianceNormalization.apply_on_ndarray (reference reader/preprocess.py:211-229)."""
+    return (x - mean_vec) / std_vec

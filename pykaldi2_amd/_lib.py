@@ -48,6 +48,7 @@ SIGNATURES = {
     "pk2_fbank_num_frames": (_i32, [_i64]),
     "pk2_fbank_compute": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "pk2_pad_roll_subsample": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "pk2_mvn_apply": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "pk2_softmax_ce_fwd_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "pk2_scale_by_count": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "pk2_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64,
@@ -56,6 +57,7 @@ SIGNATURES = {
     "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pk2_dropout_f32": (C.c_int, [_vp, _vp, _i64, _f32, C.c_uint64, _vp]),
     "pk2_grad_norm": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "pk2_grad_norm_workspace_bytes": (_sz, [_i64]),
     "pk2_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32,

@@ -119,6 +119,17 @@ __global__ void __launch_bounds__(256) pad_roll_subsample_kernel(const float* __
   }
 }
 
+// y[r][d] = (x[r][d] - mean[d]) / std[d]   (GlobalMeanVarianceNormalization.apply_on_ndarray,
+// reference reader/preprocess.py:211-229)
+__global__ void __launch_bounds__(256) mvn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ stdv, int64_t total, int D,
+                                                        float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    y[i] = (x[i] - mean[d]) / stdv[d];
+  }
+}
+
 static int fbank_upload(pk2_fbank* fb) {
   if (fb->uploaded) return PK2_OK;
   auto up = [&](const std::vector<float>& h, float** d) -> int {
@@ -214,6 +225,18 @@ extern "C" int pk2_pad_roll_subsample(const float* feats, const int64_t* feat_ro
   const int blocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
   hipLaunchKernelGGL(pad_roll_subsample_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      feats, feat_row_off, num_utts, max_t, shift, subsample, x, out_t, time_major);
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
+
+extern "C" int pk2_mvn_apply(const float* x, const float* mean, const float* stdv, int64_t rows, int32_t dim,
+                             float* y, void* stream_) {
+  PK2_REQUIRE(x && mean && stdv && y && rows >= 0 && dim > 0, "mvn_apply: bad args");
+  const int64_t total = rows * dim;
+  if (total == 0) return PK2_OK;
+  const int blocks = (int)std::min<int64_t>(4096, (total + 255) / 256);
+  hipLaunchKernelGGL(mvn_apply_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), x, mean, stdv,
+                     total, dim, y);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -92,3 +92,48 @@ class FbankExtractor:
                                                      int(subsample), _lib.ptr(x), out_t, 1 if time_major else 0,
                                                      _lib.stream_ptr(feats.device)))
         return x
+
+
+def utt2seg(feats, seg_len, seg_shift):
+    """Cuts one utterance [T, D] into segments [n_seg, seg_len, D], n_seg = floor((T-seg_len)/seg_shift)+1,
+    the tail is dropped (reference data/sr_dataset.py:40-52, used for CE chunks at :374-382).  Pure
+    re-indexing: a strided view of the feature tensor, materialised once."""
+    T = feats.shape[0]
+    n_seg = (T - seg_len) // seg_shift + 1 if T >= seg_len else 0
+    if n_seg <= 0:
+        return feats.new_zeros((0, seg_len) + tuple(feats.shape[1:]))
+    inner = int(np.prod(feats.shape[1:])) if feats.dim() > 1 else 1
+    f = feats.contiguous()
+    view = f.as_strided((n_seg, seg_len) + tuple(f.shape[1:]), (seg_shift * inner, inner) + tuple(f.stride()[1:]))
+    return view.contiguous()
+
+
+class GlobalMeanVarianceNormalization:
+    """Apply side of reader/preprocess.py:89-229: (x - mean_vec) / std_vec with the pickled [1, D] vectors
+    (std floored at 1e-2 when it was estimated, :141-149).  Estimation stays a host-side, one-off step."""
+
+    def __init__(self, mean_vec, std_vec):
+        self.mean_vec = np.ascontiguousarray(mean_vec, dtype=np.float32).reshape(1, -1)
+        self.std_vec = np.ascontiguousarray(std_vec, dtype=np.float32).reshape(1, -1)
+        self._dev = None
+
+    @classmethod
+    def from_stats(cls, mean_stats, var_stats, n_frame):
+        """learn_mean_and_variance_from_stats (reader/preprocess.py:141-151)."""
+        mean = np.asarray(mean_stats, dtype=np.float32).reshape(-1, 1) / n_frame
+        std = np.sqrt(np.asarray(var_stats, dtype=np.float32).reshape(-1, 1) / n_frame - mean ** 2)
+        std = np.maximum(std, 1e-2)
+        std[np.isnan(std)] = 1.0
+        std[np.isinf(std)] = 1.0
+        return cls(mean.T, std.T)
+
+    def apply_on_tensor(self, x):
+        _lib.require_gpu()
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.mean_vec.shape[1]
+        if self._dev is None or self._dev[0].device != x.device:
+            self._dev = (torch.from_numpy(self.mean_vec).to(x.device), torch.from_numpy(self.std_vec).to(x.device))
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().pk2_mvn_apply(_lib.ptr(x), _lib.ptr(self._dev[0]), _lib.ptr(self._dev[1]),
+                                            x.numel() // x.shape[-1], x.shape[-1], _lib.ptr(y),
+                                            _lib.stream_ptr(x.device)))
+        return y

@@ -83,6 +83,7 @@ class _LstmAmFunction(torch.autograd.Function):
         sp = _lib.stream_ptr()
         rows = T * B
         saved = []
+        seeds = []
         inp = x_tm.contiguous()
         for l in range(Lr):
             w_ih, w_hh, b_ih, b_hh = m._layer_views(l)
@@ -97,13 +98,21 @@ class _LstmAmFunction(torch.autograd.Function):
             saved.append((inp, y, gates, cells))
             inp = y
             if m.dropout > 0 and m.training and l + 1 < Lr:
-                raise _lib.Pk2Error("inter-layer dropout > 0 is not implemented yet in the HIP path")
+                # nn.LSTM semantics: dropout on the outputs of every layer but the last; the recurrence
+                # itself keeps reading the undropped h (y).  The seed comes from torch's CPU generator.
+                seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+                seeds.append(seed)
+                inp = torch.empty_like(y)
+                _lib.check(L.pk2_dropout_f32(_p(y), _p(inp), y.numel(), float(m.dropout), seed, sp))
+            else:
+                seeds.append(None)
         P = m.output_size
         logits = torch.empty(T, B, P, device=dev, dtype=torch.float32)
         _gemm(0, 1, rows, P, D * H, _p(inp), D * H, _p(m.output_layer.weight), D * H, _p(logits), P,
               bias=_p(m.output_layer.bias))
         ctx.model = m
         ctx.saved = saved
+        ctx.seeds = seeds
         ctx.shape = (T, B, Din)
         ctx.need_dx = x_tm.requires_grad
         return logits
@@ -190,6 +199,8 @@ class _LstmAmFunction(torch.autograd.Function):
                     t_.record_stream(side)
                 if l > 0:
                     dy = dprev
+                    if ctx.seeds[l - 1] is not None:  # same mask and scale as the forward dropout of layer l-1
+                        _lib.check(L.pk2_dropout_f32(_p(dy), _p(dy), dy.numel(), float(m.dropout), ctx.seeds[l - 1], sp))
                 else:
                     dx = dprev
             else:

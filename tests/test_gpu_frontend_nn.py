@@ -148,3 +148,47 @@ def test_fused_optimisers_match_reference_golden(golden, name):
         opt.step()
         assert abs(norm.item() - g["opt_%s_norms" % name][i]) < 1e-4 * g["opt_%s_norms" % name][i]
         assert np.abs(model.p.cpu().numpy() - g["opt_%s_traj" % name][i]).max() < 2e-6
+
+
+def test_chunking_and_mvn_match_reference_golden(golden):
+    g = golden("chunk_mvn")
+    for i in range(5):
+        x = fbank.utt2seg(torch.from_numpy(g["feats%d" % i]).cuda(), 80, 80)
+        y = fbank.utt2seg(torch.from_numpy(g["labels%d" % i]).cuda(), 80, 80)
+        assert np.array_equal(x.cpu().numpy(), g["seg_x%d" % i]) and np.array_equal(y.cpu().numpy(), g["seg_y%d" % i])
+    mvn = fbank.GlobalMeanVarianceNormalization(g["mvn_mean"], g["mvn_std"])
+    out = mvn.apply_on_tensor(torch.from_numpy(g["mvn_in"]).cuda()).cpu().numpy()
+    assert np.abs(out - g["mvn_out"]).max() <= 1e-6 * np.abs(g["mvn_out"]).max()
+
+
+def test_dropout_is_an_unbiased_mask_and_backward_reuses_it():
+    torch.manual_seed(3)
+    m = lstm.LSTMAM(20, 11, 64, 2, 0.5, True).cuda().train()
+    x = torch.randn(3, 9, 20).cuda()
+    torch.manual_seed(5)
+    a = m(x)
+    torch.manual_seed(5)
+    b = m(x)
+    assert torch.equal(a, b)                      # same seed -> same mask
+    torch.manual_seed(6)
+    assert not torch.equal(a, m(x))
+    m.eval()
+    e = m(x)
+    # raw kernel: keep fraction and scaling
+    v = torch.ones(1 << 20, device="cuda")
+    out = torch.empty_like(v)
+    _lib.check(_lib.lib().pk2_dropout_f32(_lib.ptr(v), _lib.ptr(out), v.numel(), 0.2, 1234, _lib.stream_ptr()))
+    keep = (out != 0).float().mean().item()
+    assert abs(keep - 0.8) < 2e-3 and torch.allclose(out[out != 0], torch.tensor(1.25, device="cuda"))
+    # gradient check by finite differences through the dropped network (mask fixed by the seed)
+    m.train()
+    xg = x.clone().requires_grad_()
+    torch.manual_seed(9)
+    w = torch.randn_like(e)
+    torch.manual_seed(7)
+    (m(xg) * w).sum().backward()
+    gx = xg.grad.clone()
+    d = torch.zeros_like(x); d[1, 4, 3] = 1e-2
+    torch.manual_seed(7); f1 = (m(x + d) * w).sum().item()
+    torch.manual_seed(7); f0 = (m(x - d) * w).sum().item()
+    assert abs((f1 - f0) / 2e-2 - gx[1, 4, 3].item()) < 2e-2 * max(1.0, abs(gx[1, 4, 3].item()))

@@ -36,3 +36,18 @@ def test_noam_decay_matches_reference(golden):
     g = golden("misc")
     for s, lr in zip(g["noam_steps"], g["noam_lr"]):
         assert utils.noam_decay(int(s), 4000, 1e-3) == lr
+
+
+def test_chunking_and_mvn_match_reference(golden):
+    g = golden("chunk_mvn")
+    for i in range(5):
+        segs = F.utt2seg(g["feats%d" % i], 80, 80)
+        want = g["seg_x%d" % i]
+        assert len(segs) == want.shape[0]
+        if segs:
+            assert np.array_equal(np.stack(segs), want)
+            assert np.array_equal(np.stack(F.utt2seg(g["labels%d" % i], 80, 80)), g["seg_y%d" % i])
+    assert np.array_equal(F.mvn_apply(g["mvn_in"], g["mvn_mean"], g["mvn_std"]), g["mvn_out"])
+    # the std floor of learn_mean_and_variance_from_stats (reader/preprocess.py:141-149)
+    m = fb_mod.GlobalMeanVarianceNormalization.from_stats(np.full(4, 20.0), np.full(4, 40.0), 10)
+    assert np.array_equal(m.mean_vec, np.full((1, 4), 2.0, np.float32)) and np.array_equal(m.std_vec, np.full((1, 4), 1e-2, np.float32))

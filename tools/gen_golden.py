@@ -172,8 +172,45 @@ def gen_ce_optim_misc():
     print("misc keys", len(out))
 
 
+def gen_chunk_mvn():
+    """_utt2seg (data/sr_dataset.py:40-52; only that function is compiled: importing the module would import
+    `reader`) and GlobalMeanVarianceNormalization (reader/preprocess.py:89-229)."""
+    import ast
+    src = open(os.path.join(REF, "data/sr_dataset.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "_utt2seg"][0]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "ref:_utt2seg", "exec"), ns)
+    utt2seg = ns["_utt2seg"]
+    pre = load_by_path("ref_preprocess2", "reader/preprocess.py")
+    rng = np.random.default_rng(11)
+    out = {}
+    for i, T in enumerate([79, 80, 81, 255, 401]):
+        feats = rng.standard_normal((T, 80)).astype(np.float32)
+        labels = rng.integers(0, 5768, size=(T, 1))
+        fs = utt2seg(feats.T, 80, 80)
+        ls = utt2seg(labels.T, 80, 80)
+        out["feats%d" % i] = feats
+        out["labels%d" % i] = labels
+        out["seg_x%d" % i] = np.stack([f.T for f in fs]) if fs else np.zeros((0, 80, 80), np.float32)
+        out["seg_y%d" % i] = np.stack([l.T for l in ls]) if ls else np.zeros((0, 80, 1), np.int64)
+    mvn = pre.GlobalMeanVarianceNormalization()
+    mvn.initialize_stats(80)
+    data = [(3.0 * rng.standard_normal((50 + 7 * k, 80)) + 5.0).astype(np.float32) for k in range(6)]
+    data[0][:, 3] = 2.0                       # constant dimension -> std floored at 1e-2
+    for d in data:
+        mvn.accumulate_stats(d)
+    mvn.learn_mean_and_variance_from_stats()
+    out["mvn_mean"] = mvn.mean_vec
+    out["mvn_std"] = mvn.std_vec
+    out["mvn_in"] = data[2]
+    out["mvn_out"] = mvn.apply_on_ndarray(data[2])
+    np.savez_compressed(os.path.join(OUT, "chunk_mvn.npz"), **out)
+    print("chunk_mvn keys", len(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_chunk_mvn()
     gen_fbank()
     gen_lstm()
     gen_ce_optim_misc()
