@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""LF-MMI ("chain") training on MI355X -- command line of the reference's bin/train_chain.py
+(same flags, same YAML schema, same checkpoint format chain.model.{epoch}.tar = {'model','optimizer',
+'epoch'}), running on libpk2hip.so.
+
+  python -m torch.distributed.run --nproc-per-node 8 bin/train_chain.py -config configs/mmi.yaml \
+      -data configs/data.yaml -exp_dir exp/chain -chain_dir exp/chain_tree -lr 1e-3 -batch_size 4
+
+Differences from the reference, by necessity (no Kaldi here): the denominator
+graph is read from <chain_dir>/den.fst by the library's own OpenFst reader; the per-utterance
+supervision is built from the pdf alignment (`label`) with +-5-frame tolerance at the subsampled rate
+(pykaldi2_amd.synth.numerator_fst_from_alignment) instead of Kaldi's phone-level
+alignment_to_proto_supervision / proto_supervision_to_supervision (needs tree + transition model);
+-synthetic trains on the seeded LibriSpeech-shaped generator and a synthetic denominator graph.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch as th
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pykaldi2_amd import chain, data, fbank, hvd, lstm, ops, optim, synth, utils  # noqa: E402
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-config")
+    parser.add_argument("-data", help="data yaml file")
+    parser.add_argument("-dataPath", default='', type=str, help="path of data files")
+    parser.add_argument("-seed_model", default='', help="the seed nerual network model")
+    parser.add_argument("-exp_dir", help="the directory to save the outputs")
+    parser.add_argument("-transform", help="feature transformation matrix or mvn statistics")
+    parser.add_argument("-ali_dir", help="the directory to load trans_model and tree used for alignments")
+    parser.add_argument("-lang_dir", help="the lexicon directory to load L.fst")
+    parser.add_argument("-chain_dir", help="the directory to load trans_model, tree and den.fst for chain model")
+    parser.add_argument("-lr", type=float, default=1e-3, help="set the base learning rate")
+    parser.add_argument("-warmup_steps", default=4000, type=int, help="the number of warmup steps to adjust the learning rate")
+    parser.add_argument("-xent_regularize", default=0, type=float, help="cross-entropy regularization weight")
+    parser.add_argument("-momentum", default=0, type=float, help="set the momentum")
+    parser.add_argument("-weight_decay", default=1e-4, type=float, help="set the L2 regularization weight")
+    parser.add_argument("-batch_size", default=32, type=int, help="Override the batch size in the config")
+    parser.add_argument("-data_loader_threads", default=0, type=int, help="number of workers for data loading")
+    parser.add_argument("-max_grad_norm", default=5, type=float, help="max_grad_norm for gradient clipping")
+    parser.add_argument("-sweep_size", default=100, type=float, help="process n hours of data per sweep (default:100)")
+    parser.add_argument("-num_epochs", default=1, type=int, help="number of training epochs (default:1)")
+    parser.add_argument("-anneal_lr_epoch", default=2, type=int, help="start to anneal the learning rate from this epoch")
+    parser.add_argument("-anneal_lr_ratio", default=0.5, type=float, help="the ratio to anneal the learning rate ratio")
+    parser.add_argument('-print_freq', default=10, type=int, metavar='N', help='print frequency (default: 10)')
+    parser.add_argument('-save_freq', default=1000, type=int, metavar='N', help='save model frequency (default: 1000)')
+    parser.add_argument('-synthetic', action='store_true', help='seeded synthetic utterances and denominator graph')
+    parser.add_argument('-den_states', default=30000, type=int, help='(synthetic) denominator graph states')
+    parser.add_argument('-den_arcs', default=1000000, type=int, help='(synthetic) denominator graph arcs')
+    args = parser.parse_args()
+
+    with open(args.config) as f:
+        config = yaml.safe_load(f)
+    config["sweep_size"] = args.sweep_size
+    if args.data and not args.synthetic:
+        with open(args.data) as f:
+            d = yaml.safe_load(f)
+            config["source_paths"] = [j for i, j in d['clean_source'].items()]
+    config["synthetic"] = args.synthetic
+    config["data_path"] = args.dataPath
+    print("pytorch version:{}".format(th.__version__))
+    print("Experiment starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
+
+    hvd.init()
+    th.cuda.set_device(hvd.local_rank())
+    dev = th.device("cuda", hvd.local_rank())
+    print("Run experiments with world size {}".format(hvd.size()))
+    if args.exp_dir and not os.path.isdir(args.exp_dir):
+        os.makedirs(args.exp_dir, exist_ok=True)
+
+    mc = config["model_config"]
+    P = mc["label_size"]
+    model = lstm.LSTMAM(mc["feat_dim"], P, mc["hidden_size"], mc["num_layers"], mc["dropout"], True).to(dev)
+    if args.seed_model:   # weights only; a "module." prefix is stripped (reference bin/train_chain.py:147-160)
+        sd = th.load(args.seed_model, map_location="cpu")["model"]
+        model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()})
+    optimizer = optim.Adam(model, lr=args.lr, amsgrad=True)
+    hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+    hvd.broadcast_optimizer_state(optimizer, root_rank=0)
+    optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters())
+
+    if args.synthetic:
+        den = chain.DenominatorGraph(synth.den_graph_arcs(args.den_states, args.den_arcs, P, seed=0), P)
+    else:
+        den_path = os.path.join(args.chain_dir or "", "den.fst")
+        if not os.path.isfile(den_path):
+            sys.stderr.write('ERROR: The chain denominator graph {} does not exist!\n'.format(den_path))
+            sys.exit(0)
+        den = chain.DenominatorGraph(den_path, P)
+    supervision_opts = chain.SupervisionOptions()
+    chain_opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=args.xent_regularize)
+    source = data.make_source(config, P, hvd.rank(), hvd.size())
+    fb = fbank.FbankExtractor()
+
+    model.train()
+    for epoch in range(args.num_epochs):
+        run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev)
+        if hvd.rank() == 0 and args.exp_dir:
+            th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
+                    args.exp_dir + '/chain.model.' + str(epoch) + '.tar')
+    hvd.shutdown()
+
+
+def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev):
+    batch_time = utils.AverageMeter('Time', ':6.3f')
+    losses = utils.AverageMeter('Loss', ':.4e')
+    grad_norm = utils.AverageMeter('grad_norm', ':.4e')
+    n_batches = max(1, int(args.sweep_size * 3600 / (12.3 * args.batch_size)))
+    progress = utils.ProgressMeter(n_batches, batch_time, losses, grad_norm, prefix="Epoch: [{}]".format(epoch))
+    sub = supervision_opts.frame_subsampling_factor
+    end = time.time()
+    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
+        frame_shift = (epoch % sub) * -1
+        feats, frames, row_off = fb(batch["wav"], batch["lens"])
+        x = fb.pad_roll_subsample(feats, row_off, frames, shift=frame_shift, subsample=sub, time_major=True)
+        sups = [chain.Supervision(synth.numerator_fst_from_alignment(np.asarray(y)[:T], sub, supervision_opts.left_tolerance),
+                                  label_dim=den.num_pdfs()) for y, T in zip(batch["y"], frames)]
+        prediction = model.forward_time_major(x).transpose(0, 1)
+        loss = ops.ChainObjtiveBatch.apply(prediction, den, sups, chain_opts)
+        optimizer.zero_grad()
+        loss.backward()
+        step = n_batches * epoch + i + 1
+        lr = utils.noam_decay(step, args.warmup_steps, args.lr)
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = lr
+        norm = optim.clip_grad_norm_(optimizer, args.max_grad_norm)
+        optimizer.step()
+        if i % args.print_freq == 0:   # .item() synchronises: only when printing
+            grad_norm.update(norm.item())
+            losses.update(loss.item() / float(np.sum(frames)))
+            batch_time.update(time.time() - end)
+            if hvd.rank() == 0:
+                progress.print(i)
+        end = time.time()
+        if hvd.rank() == 0 and args.exp_dir and i > 0 and i % args.save_freq == 0:
+            th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict()},
+                    args.exp_dir + '/chain.model.' + str(i) + '.tar')
+
+
+if __name__ == '__main__':
+    main()

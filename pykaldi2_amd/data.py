@@ -1,0 +1,127 @@
+"""Minibatch sources for the training CLIs: raw waveforms go to the GPU, features are computed there.
+
+The reference's data layer (reference data/sr_dataset.py, data/dataloader.py, reader/*) reads 16 kHz
+wavs out of zip archives, joins them with per-utterance label files by utterance id and computes
+fbank+CMN in DataLoader workers.  Here the host only decodes PCM and ships it; fbank / CMN / chunking /
+padding run on the device (pykaldi2_amd.fbank).  Two sources share one interface:
+
+* ``ZipWavSource``  -- the reference's on-disk formats: a zip of wav files
+  (``clean_source/{n}/wav``), ``label`` = text file ``utt_id pdf pdf ...`` (CE targets, 100 fps),
+  ``aux_label`` = same format with transition ids.  Utterances are the sorted intersection of the
+  archive members and the label keys (reference reader/stream.py:563-588).
+* ``SyntheticSource`` -- the seeded LibriSpeech-shaped generator of SURVEY.md 8(d) (no dataset here).
+
+Batch dict (cf. reference data/dataloader.py:128-134): ``wav`` (1-D CUDA f32, utterances back to
+back), ``lens`` (samples), ``y`` (list of int64 pdf alignments, one per utterance), ``aux`` (list),
+``utt_ids``, ``seconds``.
+"""
+import io
+import os
+import wave
+import zipfile
+
+import numpy as np
+import torch
+
+from . import synth
+
+
+def read_label_file(path):
+    """``utt_id id id id ...`` per line (reference example/librispeech/README.md:40-44)."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            parts = line.split()
+            if len(parts) >= 2:
+                out[parts[0]] = np.asarray(parts[1:], dtype=np.int64)
+    return out
+
+
+def decode_wav(data):
+    """RIFF PCM16 mono/multi-channel -> float32 in [-1, 1) (first channel), like reader/zip_io.py:145."""
+    with wave.open(io.BytesIO(data)) as w:
+        assert w.getsampwidth() == 2, "only 16-bit PCM wav is supported"
+        n, ch = w.getnframes(), w.getnchannels()
+        pcm = np.frombuffer(w.readframes(n), dtype="<i2").reshape(-1, ch)[:, 0]
+        sr = w.getframerate()
+    return (pcm.astype(np.float32) / 32768.0), sr
+
+
+class ZipWavSource:
+    def __init__(self, sources, data_path="", seed=0, rank=0, world=1):
+        self.items = []   # (zip path, member, utt_id, labels, aux)
+        for src in sources:
+            zpath = os.path.join(data_path, src["wav"]) if data_path else src["wav"]
+            labels = read_label_file(os.path.join(data_path, src["label"]) if data_path else src["label"]) \
+                if src.get("label") else {}
+            aux = read_label_file(os.path.join(data_path, src["aux_label"]) if data_path else src["aux_label"]) \
+                if src.get("aux_label") else {}
+            with zipfile.ZipFile(zpath) as z:
+                members = sorted(m for m in z.namelist() if m.lower().endswith(".wav"))
+            for m in members:
+                utt = os.path.splitext(os.path.basename(m))[0]
+                if labels and utt not in labels:
+                    continue
+                self.items.append((zpath, m, utt, labels.get(utt), aux.get(utt)))
+        assert self.items, "no utterance found"
+        self.rng = np.random.default_rng(seed + rank)
+        self._zips = {}
+        self.rank, self.world = rank, world
+
+    def __len__(self):
+        return len(self.items)
+
+    def _read(self, zpath, member):
+        z = self._zips.get(zpath)
+        if z is None:
+            z = self._zips[zpath] = zipfile.ZipFile(zpath)
+        wav, sr = decode_wav(z.read(member))
+        assert sr == 16000, "%s: expected 16 kHz audio" % member
+        return wav
+
+    def draw(self):
+        zpath, member, utt, lab, aux = self.items[int(self.rng.integers(len(self.items)))]
+        wav = self._read(zpath, member)
+        T = synth.num_fbank_frames(wav.shape[0])
+        if lab is not None:   # truncate to min(n_label, n_fbank) like data/sr_dataset.py:349-363
+            n = min(T, lab.shape[0])
+            lab = lab[:n]
+            wav = wav[:401 + 160 * (n - 1)] if n < T else wav
+        return wav, lab, aux, utt
+
+
+class SyntheticSource:
+    def __init__(self, num_pdfs, seed=0, rank=0, world=1):
+        self.num_pdfs = num_pdfs
+        self.rng = np.random.default_rng(1234 + seed + rank)
+        self.count = 0
+
+    def __len__(self):
+        return 1 << 30
+
+    def draw(self):
+        d = float(synth.utterance_durations(self.rng, 1)[0])
+        wav = synth.waveform(self.rng, d)
+        T = synth.num_fbank_frames(wav.shape[0])
+        self.count += 1
+        return wav, synth.pdf_alignment(self.rng, T, self.num_pdfs), None, "synth-%d" % self.count
+
+
+def make_source(config, num_pdfs, rank=0, world=1):
+    if config.get("synthetic") or not config.get("source_paths"):
+        return SyntheticSource(num_pdfs, rank=rank, world=world)
+    return ZipWavSource(config["source_paths"], config.get("data_path", ""), rank=rank, world=world)
+
+
+def sequence_batches(source, batch_size, hours, device):
+    """Whole-utterance minibatches until `hours` of audio have been drawn (the reference's sweep_size,
+    data/sr_dataset.py:226)."""
+    budget = hours * 3600.0
+    while budget > 0:
+        utts = [source.draw() for _ in range(batch_size)]
+        lens = [u[0].shape[0] for u in utts]
+        wav = torch.from_numpy(np.concatenate([u[0] for u in utts])).to(device, non_blocking=True)
+        seconds = sum(lens) / 16000.0
+        budget -= seconds
+        yield dict(wav=wav, lens=lens, y=[u[1] for u in utts], aux=[u[2] for u in utts],
+                   utt_ids=[u[3] for u in utts], seconds=seconds)

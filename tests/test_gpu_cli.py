@@ -1,0 +1,44 @@
+"""The training command lines run end to end on synthetic data (tiny model) and write the reference's
+checkpoint format."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(tmp_path, name, label_size, seq):
+    cfg = dict(data_config=dict(frame_len=400, frame_shift=160, seg_len=80, seg_shift=80, sequence_mode=seq,
+                                load_label=True, use_cmn=True, simulation_prob=0),
+               model_config=dict(feat_dim=80, hidden_size=64, dropout=0.1, num_layers=2, label_size=label_size))
+    p = tmp_path / name
+    p.write_text(yaml.safe_dump(cfg))
+    return str(p)
+
+
+def test_train_chain_cli_synthetic(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_chain.py"), "-config",
+                          _cfg(tmp_path, "mmi.yaml", 120, True), "-exp_dir", str(tmp_path / "exp"), "-lr", "1e-3",
+                          "-batch_size", "2", "-sweep_size", "0.02", "-print_freq", "1", "-xent_regularize", "0.1",
+                          "-synthetic", "-den_states", "400", "-den_arcs", "6000"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Epoch: [0]" in out.stdout and "grad_norm" in out.stdout
+    ck = torch.load(tmp_path / "exp" / "chain.model.0.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch"} and "lstm.weight_hh_l1_reverse" in ck["model"]
+
+
+def test_train_ce_cli_synthetic(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_ce.py"), "-train_config",
+                          _cfg(tmp_path, "ce.yaml", 120, False), "-exp_dir", str(tmp_path / "exp"), "-lr", "1e-3",
+                          "-batch_size", "16", "-sweep_size", "0.05", "-print_freq", "1", "-synthetic"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Epoch: [0]" in out.stdout and "Loss" in out.stdout
+    ck = torch.load(tmp_path / "exp" / "model.0.tar", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 0 and "output_layer.bias" in ck["model"]
