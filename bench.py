@@ -179,6 +179,59 @@ def cpu_baseline(seed, timeout=240):
         return dict(value=None, cores=threads, kind="port", sample="cpu baseline exceeded %d s" % timeout)
 
 
+def ce_workload(args, dev, rank, world):
+    """configs[1]: CE on 256 chunks of 80 frames per step from raw waveforms in HBM: fbank + CMN per utterance,
+    chunking, 3x512 BLSTM (dropout 0.2, configs/ce.yaml), fused softmax-CE, clip 5, Adam(amsgrad, lr 1e-4)."""
+    PC, CH, BATCH = 5768, 80, 256
+    rng = np.random.default_rng(99 + rank)
+    torch.manual_seed(0)
+    model = lstm.LSTMAM(80, PC, 512, 3, 0.2, True).to(dev).train()
+    opt = hvd.DistributedOptimizer(optim.Adam(model, lr=1e-4, amsgrad=True), named_parameters=model.named_parameters())
+    crit = ops.CrossEntropyLoss(ignore_index=-100)
+    fb = fbank.FbankExtractor()
+    batches = []
+    for _ in range(3):
+        utts, chunks = [], 0
+        while chunks < BATCH:
+            w = synth.waveform(rng, float(synth.utterance_durations(rng, 1)[0]))
+            T = synth.num_fbank_frames(w.shape[0])
+            utts.append((w, synth.pdf_alignment(rng, T, PC)))
+            chunks += T // CH
+        lens = [w.shape[0] for w, _ in utts]
+        batches.append(dict(wav=torch.from_numpy(np.concatenate([w for w, _ in utts])).to(dev), lens=lens,
+                            labels=[torch.from_numpy(a).to(dev).unsqueeze(1) for _, a in utts]))
+
+    def step(mb):
+        feats, frames, row_off = fb(mb["wav"], mb["lens"])
+        off = np.concatenate([[0], np.cumsum(frames)])
+        xs = [fbank.utt2seg(feats[off[n]:off[n + 1]], CH, CH) for n in range(len(frames))]
+        ys = [fbank.utt2seg(l, CH, CH) for l in mb["labels"]]
+        x, y = torch.cat(xs)[:BATCH], torch.cat(ys)[:BATCH]
+        logits = model.forward_time_major(x.transpose(0, 1).contiguous())          # [T=80, B=256, P]
+        loss = crit(logits.transpose(0, 1), y.squeeze(2))
+        opt.zero_grad()
+        loss.backward()
+        optim.clip_grad_norm_(opt, 5.0)
+        opt.step()
+        return loss
+    for i in range(args.warmup):
+        step(batches[i % 3])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(batches[i % 3])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio = args.steps * BATCH * CH * 0.01
+    if rank == 0:
+        print(json.dumps({"metric": "iRTF (hrs audio/hr) 3x512 BLSTM CE, 256x80 chunks (secondary workload, configs[1])",
+                          "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "loss": round(float(loss.item()), 4),
+                          "reference_published": "README.md:43-45: 190 iRTF (64x80, 1 V100), 520 iRTF (256x80, 4 V100)"}),
+              flush=True)
+    hvd.shutdown()
+
+
 def log(msg):
     sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
     sys.stderr.flush()
@@ -199,6 +252,8 @@ def main():
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
     ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
     ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
+    ap.add_argument("--ce", action="store_true", help="secondary workload configs[1]: 3x512 BLSTM CE, 256 x 80-frame "
+                    "chunks per step (not the headline metric)")
     args = ap.parse_args()
 
     hvd.init()
@@ -207,6 +262,8 @@ def main():
     dev = torch.device("cuda", hvd.local_rank())
     torch.cuda.set_device(dev)
 
+    if args.ce:
+        return ce_workload(args, dev, rank, world)
     log("rank %d/%d: building synthetic den graph" % (rank, world))
     g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
     den = chain.DenominatorGraph(g, P)

@@ -47,14 +47,17 @@ struct LstmFwdParams {
   float* gates;       // [D][T][B][4H]
   float* cells;       // [D][T][B][H]
   int B, T, H, D;
-  int debug;          // PK2_LSTM_DEBUG ablation bits (profiling only)
 };
 
 // KS = number of 4-wide MFMA k-steps per wave (H / 4 waves / 4).
+// Batch rows are processed in groups of kFwdTileGroup MFMA M-tiles (64 rows): all matrix work of a
+// group, ONE barrier, then the gate math of the group's 64 x 4 (row, unit) pairs on all 256 threads.
+constexpr int kFwdTileGroup = 4;
+
 template <int KS>
 __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams* __restrict__ pp,
                                                              const StepCounter* __restrict__ cnt, int local) {
-  __shared__ float part[4][16][17];   // per-wave partial 16x16 tiles (padded)
+  __shared__ float part[kFwdTileGroup][4][16][17];   // [tile][wave] partial 16x16 tiles (padded)
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
   const LstmFwdParams p = *pp;
@@ -69,23 +72,23 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
 
   // B operand: column j = li -> gate g = j/4, unit u0 + j%4 -> row g*H + u0 + j%4 of W_hh[d]
   f32x4 wf[KS / 4];
-#pragma unroll
-  for (int q = 0; q < KS / 4; ++q) wf[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int kbase = w * (KS * 4) + kq * KS;   // this lane's contiguous k-run of length KS
-  if (!first && !(p.debug & 1)) {
+  if (!first) {
     const float* wrow = p.whh + ((size_t)d * 4 * H + (size_t)(li >> 2) * H + u0 + (li & 3)) * H + kbase;
 #pragma unroll
     for (int q = 0; q < KS / 4; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + q * 4);
   }
   const size_t yrow = (size_t)D * H;
-  for (int mt = 0; mt < (B + 15) / 16; ++mt) {
-    // pointwise operands of thread (i = batch row in tile, u = unit), fetched early
-    const int pi_ = tid >> 2, pu = tid & 3;
-    const int pb = mt * 16 + pi_;
-    const bool pw_active = tid < 64 && pb < B;
+  const int ntiles = (B + 15) / 16;
+  for (int mt0 = 0; mt0 < ntiles; mt0 += kFwdTileGroup) {
+    const int ng = min(kFwdTileGroup, ntiles - mt0);
+    // gate-math operands of thread (tile tg, batch row i, unit u), fetched before the matrix phase
+    const int tg = tid >> 6, pi_ = (tid >> 2) & 15, pu = tid & 3;
+    const int pb = (mt0 + tg) * 16 + pi_;
+    const bool pw_active = tg < ng && pb < B;
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     float cprev = 0.f;
-    if (pw_active && !(p.debug & 32)) {
+    if (pw_active) {
       const float* gxr = p.gx + ((size_t)t * B + pb) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + pu;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -95,50 +98,45 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
       if (!first) cprev = p.cells[(((size_t)d * T + tp) * B + pb) * H + u0 + pu];
     }
     if (!first) {
-      const int b = mt * 16 + li;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 af[KS / 4];
-      if (b < B && !(p.debug & 2)) {
-        const float* hrow = p.y + ((size_t)tp * B + b) * yrow + (size_t)d * H + kbase;
+      for (int g2 = 0; g2 < ng; ++g2) {
+        const int b = (mt0 + g2) * 16 + li;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 af[KS / 4];
+        if (b < B) {
+          const float* hrow = p.y + ((size_t)tp * B + b) * yrow + (size_t)d * H + kbase;
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(hrow + q * 4);
-      } else {
+          for (int q = 0; q < KS / 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(hrow + q * 4);
+        } else {
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) af[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < KS / 4; ++q) af[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][0], wf[q][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][1], wf[q][1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][2], wf[q][2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][3], wf[q][3], acc1, 0, 0, 0);
+        }
+        // C layout: row (batch) = (lane>>4)*4 + r, col = lane&15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[g2][w][kq * 4 + r][li] = acc0[r] + acc1[r];
       }
-#pragma unroll
-      for (int q = 0; q < ((p.debug & 4) ? 1 : KS / 4); ++q) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][0], wf[q][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][1], wf[q][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][2], wf[q][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][3], wf[q][3], acc1, 0, 0, 0);
-      }
-      // C layout: row (batch) = (lane>>4)*4 + r, col = lane&15
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part[w][kq * 4 + r][li] = acc0[r] + acc1[r];
     }
     __syncthreads();
     if (pw_active) {
       if (!first) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          pre[g] += (part[0][pi_][g * 4 + pu] + part[1][pi_][g * 4 + pu]) +
-                    (part[2][pi_][g * 4 + pu] + part[3][pi_][g * 4 + pu]);
+          pre[g] += (part[tg][0][pi_][g * 4 + pu] + part[tg][1][pi_][g * 4 + pu]) +
+                    (part[tg][2][pi_][g * 4 + pu] + part[tg][3][pi_][g * 4 + pu]);
       }
-      float ig, fg, gg, og, c, h;
-      if (p.debug & 8) {
-        ig = pre[0]; fg = pre[1]; gg = pre[2]; og = pre[3]; c = fg * cprev + ig * gg; h = og * c;
-      } else {
-        ig = sigmoidf_(pre[0]); fg = sigmoidf_(pre[1]); gg = tanhf(pre[2]); og = sigmoidf_(pre[3]);
-        c = fg * cprev + ig * gg;
-        h = og * tanhf(c);
-      }
+      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      const float c = fg * cprev + ig * gg;
+      const float h = og * tanhf(c);
       p.cells[(((size_t)d * T + t) * B + pb) * H + u0 + pu] = c;
       p.y[((size_t)t * B + pb) * yrow + (size_t)d * H + u0 + pu] = h;
-      if (!(p.debug & 16)) {
-        float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
-        gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
-      }
+      float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
+      gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
     }
     __syncthreads();
   }
@@ -154,11 +152,13 @@ struct LstmBwdParams {
   int B, T, H, D;
 };
 
-// KS = 4-wide MFMA k-steps per wave (4H / 16 waves / 4).
+// KS = 4-wide MFMA k-steps per wave (4H / 16 waves / 4).  Batch rows in groups of kBwdTileGroup M-tiles.
+constexpr int kBwdTileGroup = 2;
+
 template <int KS>
 __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams* __restrict__ pp,
                                                              const StepCounter* __restrict__ cnt, int local) {
-  __shared__ float part[16][16][17];
+  __shared__ float part[kBwdTileGroup][16][16][17];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
   const LstmBwdParams p = *pp;
@@ -185,11 +185,13 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams
 #pragma unroll
     for (int q = 0; q < KS / 4; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + q * 4);
   }
-  for (int mt = 0; mt < (B + 15) / 16; ++mt) {
-    // pointwise operands of thread (i, j) fetched before the MFMA phase
-    const int pi_ = tid >> 2, pj = tid & 3;
-    const int pb = mt * 16 + pi_, pk = k0 + pj;
-    const bool pw_active = tid < 64 && pb < B;
+  const int ntiles = (B + 15) / 16;
+  for (int mt0 = 0; mt0 < ntiles; mt0 += kBwdTileGroup) {
+    const int ng = min(kBwdTileGroup, ntiles - mt0);
+    // pointwise operands of thread (tile tg, row i, unit j) fetched before the MFMA phase
+    const int tg = tid >> 6, pi_ = (tid >> 2) & 15, pj = tid & 3;
+    const int pb = (mt0 + tg) * 16 + pi_, pk = k0 + pj;
+    const bool pw_active = tg < ng && pb < B;
     float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dcin = 0.f;
     if (pw_active) {
       dh = p.dy[((size_t)t * B + pb) * ((size_t)D * H) + (size_t)d * H + pk];
@@ -200,33 +202,35 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams
       if (!last_fwd) dcin = p.dc[((size_t)d * B + pb) * H + pk];
     }
     if (!last_fwd) {
-      const int b = mt * 16 + li;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 af[KS / 4];
-      if (b < B) {
-        const float* grow = p.dgx + ((size_t)tn * B + b) * ((size_t)D * G4) + (size_t)d * G4 + rbase;
+      for (int g2 = 0; g2 < ng; ++g2) {
+        const int b = (mt0 + g2) * 16 + li;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 af[KS / 4];
+        if (b < B) {
+          const float* grow = p.dgx + ((size_t)tn * B + b) * ((size_t)D * G4) + (size_t)d * G4 + rbase;
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(grow + q * 4);
-      } else {
+          for (int q = 0; q < KS / 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(grow + q * 4);
+        } else {
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) af[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < KS / 4; ++q) af[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][0], wf[q][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][1], wf[q][1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][2], wf[q][2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][3], wf[q][3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[g2][w][kq * 4 + r][li] = acc0[r] + acc1[r];
       }
-#pragma unroll
-      for (int q = 0; q < KS / 4; ++q) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][0], wf[q][0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][1], wf[q][1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][2], wf[q][2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][3], wf[q][3], acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part[w][kq * 4 + r][li] = acc0[r] + acc1[r];
     }
     __syncthreads();
     if (pw_active) {
       if (!last_fwd) {
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 16; ++ww) s += part[ww][pi_][pj];
+        for (int ww = 0; ww < 16; ++ww) s += part[tg][ww][pi_][pj];
         dh += s;
       }
       const float tc = tanhf(c);
@@ -279,8 +283,7 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
   ParamSlot<LstmFwdParams>* slot;
   int rc = get_param_slot(g_fwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;
-  LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D,
-                  getenv("PK2_LSTM_DEBUG") ? atoi(getenv("PK2_LSTM_DEBUG")) : 0};
+  LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D};
   hipLaunchKernelGGL(param_block_store<LstmFwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
   dim3 grid(H / kFwdUnits, D), block(kFwdThreads);
   const LstmFwdParams* pb = slot->params;
