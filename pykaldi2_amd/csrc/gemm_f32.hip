@@ -167,21 +167,26 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
   }
 }
 
-// out[n] = beta*out[n] + sum_m A[m][n]
+// out[n] (+)= sum_m A[m][n].  Rows are split over blockIdx.y; each workgroup reduces its slab of 64 columns
+// (4 row partitions of 64 threads, LDS combine) and adds one value per column with a global float atomic.
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int64_t lda, int M, int N,
-                                                     float beta, float* __restrict__ out) {
+                                                     int rows_per_block, float* __restrict__ out) {
   __shared__ float red[4][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
   float acc = 0.f;
   if (n < N)
-    for (int m = part; m < M; m += 4) acc += A[(int64_t)m * lda + n];
+    for (int m = m0 + part; m < m1; m += 4) acc += A[(int64_t)m * lda + n];
   red[part][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (part == 0 && n < N) {
-    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    out[n] = (beta != 0.f ? beta * out[n] : 0.f) + s;
-  }
+  if (part == 0 && n < N)
+    atomicAdd(out + n, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+__global__ void scale_vec_kernel(float* v, int n, float beta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = beta == 0.f ? 0.f : beta * v[i];
 }
 
 }  // namespace pk2
@@ -221,8 +226,13 @@ extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N
 extern "C" int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,
                               void* stream_) {
   PK2_REQUIRE(A && out && M > 0 && N > 0, "colsum_f32: bad args");
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream_), A,
-                     lda, M, N, beta, out);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (beta != 1.f) hipLaunchKernelGGL(scale_vec_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, out, N, beta);
+  const int col_blocks = (N + 63) / 64;
+  const int splits = std::max(1, std::min((M + 63) / 64, 1024 / col_blocks));
+  const int rows_per_block = (M + splits - 1) / splits;
+  hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, (M + rows_per_block - 1) / rows_per_block), dim3(256), 0, stream,
+                     A, lda, M, N, rows_per_block, out);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
   }
   const size_t yrow = (size_t)D * H;
   const int ntiles = (B + 15) / 16;
-  for (int mt0 = 0; mt0 < ntiles; mt0 += kFwdTileGroup) {
+  {
+    const int mt0 = blockIdx.z * kFwdTileGroup;   // one group of M-tiles per workgroup (grid.z covers the batch)
     const int ng = min(kFwdTileGroup, ntiles - mt0);
     // gate-math operands of thread (tile tg, batch row i, unit u), fetched before the matrix phase
     const int tg = tid >> 6, pi_ = (tid >> 2) & 15, pu = tid & 3;
@@ -138,7 +139,6 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
       float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
       gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
     }
-    __syncthreads();
   }
 }
 
@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams
     for (int q = 0; q < KS / 4; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + q * 4);
   }
   const int ntiles = (B + 15) / 16;
-  for (int mt0 = 0; mt0 < ntiles; mt0 += kBwdTileGroup) {
+  {
+    const int mt0 = blockIdx.z * kBwdTileGroup;   // one group of M-tiles per workgroup
     const int ng = min(kBwdTileGroup, ntiles - mt0);
     // pointwise operands of thread (tile tg, row i, unit j) fetched before the MFMA phase
     const int tg = tid >> 6, pi_ = (tid >> 2) & 15, pj = tid & 3;
@@ -242,7 +243,6 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams
       o[(size_t)2 * H] = dcv * ig * (1.f - gg * gg);
       o[(size_t)3 * H] = dh * tc * og * (1.f - og);
     }
-    __syncthreads();
   }
 }
 
@@ -285,11 +285,12 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
   if (rc) return rc;
   LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D};
   hipLaunchKernelGGL(param_block_store<LstmFwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
-  dim3 grid(H / kFwdUnits, D), block(kFwdThreads);
+  const int zf = ((B + 15) / 16 + kFwdTileGroup - 1) / kFwdTileGroup;
+  dim3 grid(H / kFwdUnits, D, zf), block(kFwdThreads);
   const LstmFwdParams* pb = slot->params;
   const StepCounter* c = slot->counter;
   char key[64];
-  snprintf(key, sizeof(key), "lstm_fwd_H%d_D%d_%p", H, D, (void*)stream);
+  snprintf(key, sizeof(key), "lstm_fwd_H%d_D%d_Z%d_%p", H, D, zf, (void*)stream);
   rc = g_graphs.run(key, T, slot->counter, stream, [&](hipStream_t s, int j) {
     switch (H) {
       case 64: launch_step(lstm_fwd_step<4>, grid, block, s, pb, c, j); break;
@@ -323,11 +324,12 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
   if (rc) return rc;
   LstmBwdParams p{dy, whhT, gates, cells, dgx, dc, B, T, H, D};
   hipLaunchKernelGGL(param_block_store<LstmBwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
-  dim3 grid(H / kBwdUnits, D), block(kBwdThreads);
+  const int zb = ((B + 15) / 16 + kBwdTileGroup - 1) / kBwdTileGroup;
+  dim3 grid(H / kBwdUnits, D, zb), block(kBwdThreads);
   const LstmBwdParams* pb = slot->params;
   const StepCounter* c = slot->counter;
   char key[64];
-  snprintf(key, sizeof(key), "lstm_bwd_H%d_D%d_%p", H, D, (void*)stream);
+  snprintf(key, sizeof(key), "lstm_bwd_H%d_D%d_Z%d_%p", H, D, zb, (void*)stream);
   rc = g_graphs.run(key, T, slot->counter, stream, [&](hipStream_t s, int j) {
     switch (H) {
       case 64: launch_step(lstm_bwd_step<4>, grid, block, s, pb, c, j); break;
