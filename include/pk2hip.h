@@ -178,6 +178,13 @@ int pk2_scale_by_count(float* data, int64_t n, float numerator, const int32_t* c
 int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                  int64_t ldc, const float* bias, void* stream);
+/* Batched form: matrix triple z = i0*n1 + i1 (i0 < n0, i1 < n1) lives at offsets i0*stride?0 + i1*stride?1
+ * (in floats) from A / B / C; no bias.  Used for the per-(utterance, head) attention products of
+ * TransformerAM (reference models/transformer.py:60, nn.MultiheadAttention). */
+int pk2_gemm_f32_batched(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                         const float* A, int64_t lda, int64_t strideA0, int64_t strideA1, const float* B,
+                         int64_t ldb, int64_t strideB0, int64_t strideB1, float beta, float* C, int64_t ldc,
+                         int64_t strideC0, int64_t strideC1, int32_t n0, int32_t n1, void* stream);
 /* out[n] (+)= sum_m A[m][n]  (bias gradients). */
 int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,
                    void* stream);
@@ -211,6 +218,28 @@ int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, co
                        float* scratch, void* stream);
 /* The W_hh gradient dwhh[d] = sum_t dgates[d][t]^T h[d][t-1] (t+1 for the reverse direction)
  * is one pk2_gemm_f32 by the caller over row-shifted slices of dgx and y. */
+
+/* ------------------------------------------------------------------ *
+ * Row-wise pieces of TransformerAM (reference models/transformer.py:52-94: nn.TransformerEncoderLayer
+ * post-norm + ReLU FFN, Conv1d(k=3)+ReLU per layer, final LayerNorm).
+ * ------------------------------------------------------------------ */
+/* s = x + res (res may be NULL); y = LayerNorm(s) * gamma + beta.  sum_out (may be NULL) receives s; mean,
+ * rstd [rows] are saved for the backward pass. */
+int pk2_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int64_t rows,
+                      int32_t C, float eps, float* sum_out, float* y, float* mean, float* rstd, void* stream);
+/* ds = gradient wrt s; dgamma / dbeta are ACCUMULATED (+=). */
+int pk2_layernorm_bwd(const float* dy, const float* s, const float* mean, const float* rstd,
+                      const float* gamma, int64_t rows, int32_t C, float* ds, float* dgamma, float* dbeta,
+                      void* stream);
+/* scores [B*H][T][T] <- softmax over the last axis of (scores + src_mask[T][T]) with columns j where
+ * key_padding[b][j] != 0 set to -inf, in place (src_mask / key_padding may be NULL). */
+int pk2_softmax_mask_fwd(float* scores, const float* src_mask, const uint8_t* key_padding, int32_t B, int32_t H,
+                         int32_t T, void* stream);
+/* dP <- P * (dP - rowsum(dP * P)), in place. */
+int pk2_softmax_bwd(const float* P, float* dP, int32_t BH, int32_t T, void* stream);
+int pk2_relu_fwd(float* x, int64_t n, void* stream);                 /* in place */
+int pk2_relu_bwd(const float* y, float* dy, int64_t n, void* stream); /* dy <- dy * (y > 0) */
+int pk2_add_inplace(float* a, const float* b, int64_t n, void* stream);
 
 /* Inverted dropout y = x * m/(1-p), m ~ Bernoulli(1-p), with a counter-based mask that is a pure
  * function of (seed, element index): calling it again on the gradient with the same seed applies the

@@ -53,6 +53,15 @@ SIGNATURES = {
     "pk2_scale_by_count": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "pk2_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64,
                                _vp, _vp]),
+    "pk2_gemm_f32_batched": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64,
+                                       _f32, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "pk2_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "pk2_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "pk2_softmax_mask_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pk2_softmax_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "pk2_relu_fwd": (C.c_int, [_vp, _i64, _vp]),
+    "pk2_relu_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "pk2_add_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pk2_colsum_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _vp]),
     "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),

@@ -93,14 +93,23 @@ __device__ __forceinline__ void store_slab(float* __restrict__ tile, const float
   }
 }
 
+// Batched form: blockIdx.z = i0 * n1 + i1 selects a matrix triple at offsets i0*s?0 + i1*s?1 (floats).
+struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; };
+
 template <bool TA, bool TB, int TILES>
 __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, int K, float alpha,
                                                                 const float* __restrict__ A, int64_t lda,
                                                                 const float* __restrict__ B, int64_t ldb,
                                                                 float beta, float* __restrict__ C, int64_t ldc,
                                                                 const float* __restrict__ bias, bool vecA,
-                                                                bool vecB) {
+                                                                bool vecB, GemmBatch bt) {
   constexpr int LDS_LD = Geo<TILES>::LD, BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
+  {
+    const int i0 = blockIdx.z / bt.n1, i1 = blockIdx.z % bt.n1;
+    A += i0 * bt.sA0 + i1 * bt.sA1;
+    B += i0 * bt.sB0 + i1 * bt.sB1;
+    C += i0 * bt.sC0 + i1 * bt.sC1;
+  }
   __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -193,26 +202,24 @@ __global__ void scale_vec_kernel(float* v, int n, float beta) {
 
 using namespace pk2;
 
-extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
-                            const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
-                            int64_t ldc, const float* bias, void* stream_) {
-  PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const bool vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
-  const bool vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
-  const int64_t big_tiles = (int64_t)((N + 127) / 128) * ((M + 127) / 128);
+static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                       const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
+                       int n0, const GemmBatch& bt, bool aligned_strides, hipStream_t stream) {
+  const bool vecA = aligned_strides && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
+  const bool vecB = aligned_strides && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
+  const int64_t big_tiles = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * n0 * bt.n1;
   const char* force = getenv("PK2_GEMM_TILES");
   const int tiles = force ? atoi(force) : (big_tiles >= 512 ? 2 : 1);
   const int edge = 64 * tiles;
-  dim3 grid((N + edge - 1) / edge, (M + edge - 1) / edge), block(kGemmThreads);
+  dim3 grid((N + edge - 1) / edge, (M + edge - 1) / edge, n0 * bt.n1), block(kGemmThreads);
 #define PK2_GEMM(TA, TB)                                                                                   \
   do {                                                                                                     \
     if (tiles == 2)                                                                                        \
       hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, block, 0, stream, M, N, K, alpha, A, lda, B,  \
-                         ldb, beta, C, ldc, bias, vecA, vecB);                                             \
+                         ldb, beta, C, ldc, bias, vecA, vecB, bt);                                         \
     else                                                                                                   \
       hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, block, 0, stream, M, N, K, alpha, A, lda, B,  \
-                         ldb, beta, C, ldc, bias, vecA, vecB);                                             \
+                         ldb, beta, C, ldc, bias, vecA, vecB, bt);                                         \
   } while (0)
   if (!transa && !transb) PK2_GEMM(false, false);
   else if (!transa && transb) PK2_GEMM(false, true);
@@ -221,6 +228,28 @@ extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N
 #undef PK2_GEMM
   PK2_LAUNCH_CHECK();
   return PK2_OK;
+}
+
+extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                            const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                            int64_t ldc, const float* bias, void* stream_) {
+  PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
+  GemmBatch bt{1, 0, 0, 0, 0, 0, 0};
+  return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, true,
+                     static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int pk2_gemm_f32_batched(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                                    const float* A, int64_t lda, int64_t strideA0, int64_t strideA1,
+                                    const float* B, int64_t ldb, int64_t strideB0, int64_t strideB1, float beta,
+                                    float* C, int64_t ldc, int64_t strideC0, int64_t strideC1, int32_t n0,
+                                    int32_t n1, void* stream_) {
+  PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && n0 > 0 && n1 > 0 && (int64_t)n0 * n1 <= 65535,
+              "gemm_f32_batched: bad args");
+  GemmBatch bt{n1, strideA0, strideA1, strideB0, strideB1, strideC0, strideC1};
+  const bool aligned = ((strideA0 | strideA1 | strideB0 | strideB1) & 3) == 0;
+  return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, n0, bt, aligned,
+                     static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,

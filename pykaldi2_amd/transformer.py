@@ -1,0 +1,322 @@
+"""TransformerAM -- drop-in for reference models/transformer.py:69-94 running on libpk2hip.so.
+
+Same constructor, same ``state_dict`` keys (``input_layer.*``, ``output_layer.*``, ``pos_encoder.pe``,
+``transformer.layers.{i}.encoder_layer.{self_attn.in_proj_weight, self_attn.in_proj_bias,
+self_attn.out_proj.*, linear1.*, linear2.*, norm1.*, norm2.*}``, ``transformer.layers.{i}.conv1d.*``,
+``transformer.norm.*``) and the same default initialisation: the parameter containers are the torch
+modules the reference instantiates, created in the reference's order (all encoder layers start as copies
+of one initialised layer, like ``nn.TransformerEncoder``'s deep copies), but **none of their forward
+methods is used**.  ``forward(x[T,B,D], src_mask, src_key_padding_mask) -> [T,B,P]``:
+
+    Linear(80->C) -> n x [ post-norm encoder layer (MHA + ReLU FFN) -> Conv1d(C,C,k=3,pad=1) over time
+    -> ReLU ] -> LayerNorm -> Linear(C->P);  positional encoding disabled (models/transformer.py:90).
+
+Arithmetic: f32 MFMA GEMMs (`pk2_gemm_f32`, batched per (utterance, head) for QK^T and PV), masked
+softmax, LayerNorm(+residual), ReLU, counter-based dropout -- all HIP kernels of libpk2hip.so.  The
+attention is the unfused form (scores materialised in HBM); a fused flash-style kernel is future work.
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .lstm import _gemm, _p
+
+
+class PositionalEncoding(nn.Module):
+    """Kept for checkpoint compatibility (buffer ``pe``); the reference never applies it."""
+
+    def __init__(self, dim_model, dropout=0, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, dim_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, dim_model, 2).float() * (-math.log(10000.0) / dim_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe.unsqueeze(0).transpose(0, 1))
+
+
+class _LayerParams(nn.Module):
+    def __init__(self, dim_model, nheads, dim_feedforward, dropout, kernel_size, stride):
+        super().__init__()
+        self.encoder_layer = nn.TransformerEncoderLayer(dim_model, nheads, dim_feedforward, dropout)
+        self.conv1d = nn.Conv1d(dim_model, dim_model, kernel_size, stride=stride, padding=1)
+
+
+class _EncoderParams(nn.Module):
+    def __init__(self, layer, nlayers, norm):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(nlayers)])
+        self.norm = norm
+
+
+def _bgemm(ta, tb, M, N, K, alpha, A, lda, sA0, sA1, B, ldb, sB0, sB1, beta, C, ldc, sC0, sC1, n0, n1):
+    _lib.check(_lib.lib().pk2_gemm_f32_batched(int(ta), int(tb), M, N, K, alpha, A, lda, sA0, sA1, B, ldb, sB0, sB1,
+                                               beta, C, ldc, sC0, sC1, n0, n1, _lib.stream_ptr()))
+
+
+def _colsum(A, lda, M, N, out):
+    _lib.check(_lib.lib().pk2_colsum_f32(A, lda, M, N, 0.0, out, _lib.stream_ptr()))
+
+
+def _dropout(x, p, seed, out=None):
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().pk2_dropout_f32(_p(x), _p(out), x.numel(), float(p), seed, _lib.stream_ptr()))
+    return out
+
+
+def _seed():
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
+
+
+class _TransformerFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, src_mask, key_pad, *params):
+        m = model
+        L = _lib.lib()
+        sp = _lib.stream_ptr()
+        T, B, Din = x.shape
+        C, H, F, P = m.dim_model, m.nheads, m.dim_feedforward, m.output_size
+        d = C // H
+        R = T * B
+        dev = x.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        drop = m.dropout if m.training else 0.0
+        x = x.contiguous()
+        h = new(R, C)
+        _gemm(0, 1, R, C, Din, _p(x), Din, _p(m.input_layer.weight), Din, _p(h), C, bias=_p(m.input_layer.bias))
+        saved = []
+        for lp in m.transformer.layers:
+            e = lp.encoder_layer
+            a = e.self_attn
+            s = dict(h_in=h)
+            qkv = new(R, 3 * C)
+            _gemm(0, 1, R, 3 * C, C, _p(h), C, _p(a.in_proj_weight), C, _p(qkv), 3 * C, bias=_p(a.in_proj_bias))
+            Pm = new(B * H, T, T)
+            _bgemm(0, 1, T, T, d, 1.0 / math.sqrt(d), _p(qkv), B * 3 * C, 3 * C, d, _p(qkv, C), B * 3 * C, 3 * C, d,
+                   0.0, _p(Pm), T, H * T * T, T * T, B, H)
+            _lib.check(L.pk2_softmax_mask_fwd(_p(Pm), _p(src_mask) if src_mask is not None else None,
+                                              _p(key_pad) if key_pad is not None else None, B, H, T, sp))
+            s["seed_attn"] = _seed() if drop > 0 else None
+            Pd = _dropout(Pm, drop, s["seed_attn"]) if drop > 0 else Pm
+            cx = new(R, C)
+            _bgemm(0, 0, T, d, T, 1.0, _p(Pd), T, H * T * T, T * T, _p(qkv, 2 * C), B * 3 * C, 3 * C, d, 0.0,
+                   _p(cx), B * C, C, d, B, H)
+            ao = new(R, C)
+            _gemm(0, 1, R, C, C, _p(cx), C, _p(a.out_proj.weight), C, _p(ao), C, bias=_p(a.out_proj.bias))
+            s["seed1"] = _seed() if drop > 0 else None
+            if drop > 0:
+                _dropout(ao, drop, s["seed1"], ao)
+            s1, x1, mu1, rs1 = new(R, C), new(R, C), new(R), new(R)
+            _lib.check(L.pk2_layernorm_fwd(_p(ao), _p(h), _p(e.norm1.weight), _p(e.norm1.bias), R, C, e.norm1.eps,
+                                           _p(s1), _p(x1), _p(mu1), _p(rs1), sp))
+            f1 = new(R, F)
+            _gemm(0, 1, R, F, C, _p(x1), C, _p(e.linear1.weight), C, _p(f1), F, bias=_p(e.linear1.bias))
+            _lib.check(L.pk2_relu_fwd(_p(f1), f1.numel(), sp))
+            s["seedf"] = _seed() if drop > 0 else None
+            f1d = _dropout(f1, drop, s["seedf"]) if drop > 0 else f1
+            f2 = new(R, C)
+            _gemm(0, 1, R, C, F, _p(f1d), F, _p(e.linear2.weight), F, _p(f2), C, bias=_p(e.linear2.bias))
+            s["seed2"] = _seed() if drop > 0 else None
+            if drop > 0:
+                _dropout(f2, drop, s["seed2"], f2)
+            s2, x2, mu2, rs2 = new(R, C), new(R, C), new(R), new(R)
+            _lib.check(L.pk2_layernorm_fwd(_p(f2), _p(x1), _p(e.norm2.weight), _p(e.norm2.bias), R, C, e.norm2.eps,
+                                           _p(s2), _p(x2), _p(mu2), _p(rs2), sp))
+            # Conv1d(k=3, pad=1) over time = three GEMMs over row-shifted slices (time-major: t-1 <-> row - B)
+            Wp = lp.conv1d.weight.detach().permute(2, 0, 1).contiguous()   # [3][Cout][Cin]
+            y = new(R, C)
+            _gemm(0, 1, R, C, C, _p(x2), C, _p(Wp, C * C), C, _p(y), C, bias=_p(lp.conv1d.bias))
+            if T > 1:
+                _gemm(0, 1, R - B, C, C, _p(x2), C, _p(Wp, 0), C, _p(y, B * C), C, beta=1.0)
+                _gemm(0, 1, R - B, C, C, _p(x2, B * C), C, _p(Wp, 2 * C * C), C, _p(y), C, beta=1.0)
+            _lib.check(L.pk2_relu_fwd(_p(y), y.numel(), sp))
+            s.update(qkv=qkv, P=Pm, Pd=Pd, cx=cx, s1=s1, x1=x1, mu1=mu1, rs1=rs1, f1=f1, f1d=f1d, s2=s2, x2=x2,
+                     mu2=mu2, rs2=rs2, Wp=Wp, y=y)
+            saved.append(s)
+            h = y
+        nf = m.transformer.norm
+        hn, muf, rsf = new(R, C), new(R), new(R)
+        _lib.check(L.pk2_layernorm_fwd(_p(h), None, _p(nf.weight), _p(nf.bias), R, C, nf.eps, None, _p(hn), _p(muf),
+                                       _p(rsf), sp))
+        logits = new(T, B, P)
+        _gemm(0, 1, R, P, C, _p(hn), C, _p(m.output_layer.weight), C, _p(logits), P, bias=_p(m.output_layer.bias))
+        ctx.model, ctx.saved, ctx.x, ctx.final = m, saved, x, (h, hn, muf, rsf)
+        ctx.shape, ctx.drop = (T, B, Din), drop
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.model
+        L = _lib.lib()
+        sp = _lib.stream_ptr()
+        T, B, Din = ctx.shape
+        C, H, F, P = m.dim_model, m.nheads, m.dim_feedforward, m.output_size
+        d = C // H
+        R = T * B
+        drop = ctx.drop
+        dev = dlogits.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        dlogits = dlogits.contiguous()
+        g = m._grad_views()
+        hL, hn, muf, rsf = ctx.final
+
+        def lin_grads(dout, inp, in_dim, out_dim, wname, bname):
+            _gemm(1, 0, out_dim, in_dim, R, _p(dout), out_dim, _p(inp), in_dim, _p(g[wname]), in_dim)
+            _colsum(_p(dout), out_dim, R, out_dim, _p(g[bname]))
+
+        lin_grads(dlogits, hn, C, P, "output_layer.weight", "output_layer.bias")
+        dhn = new(R, C)
+        _gemm(0, 0, R, C, P, _p(dlogits), P, _p(m.output_layer.weight), C, _p(dhn), C)
+        nf = m.transformer.norm
+        g["transformer.norm.weight"].zero_(); g["transformer.norm.bias"].zero_()
+        dh = new(R, C)
+        _lib.check(L.pk2_layernorm_bwd(_p(dhn), _p(hL), _p(muf), _p(rsf), _p(nf.weight), R, C, _p(dh),
+                                       _p(g["transformer.norm.weight"]), _p(g["transformer.norm.bias"]), sp))
+        for li in range(len(m.transformer.layers) - 1, -1, -1):
+            lp = m.transformer.layers[li]
+            e = lp.encoder_layer
+            a = e.self_attn
+            s = ctx.saved[li]
+            pre = "transformer.layers.%d." % li
+            # ReLU + Conv1d
+            _lib.check(L.pk2_relu_bwd(_p(s["y"]), _p(dh), dh.numel(), sp))     # dh := dc
+            dc = dh
+            _colsum(_p(dc), C, R, C, _p(g[pre + "conv1d.bias"]))
+            dWp = new(3, C, C)
+            _gemm(1, 0, C, C, R, _p(dc), C, _p(s["x2"]), C, _p(dWp, C * C), C)
+            dx2 = new(R, C)
+            _gemm(0, 0, R, C, C, _p(dc), C, _p(s["Wp"], C * C), C, _p(dx2), C)
+            if T > 1:
+                _gemm(1, 0, C, C, R - B, _p(dc, B * C), C, _p(s["x2"]), C, _p(dWp, 0), C)
+                _gemm(1, 0, C, C, R - B, _p(dc), C, _p(s["x2"], B * C), C, _p(dWp, 2 * C * C), C)
+                _gemm(0, 0, R - B, C, C, _p(dc, B * C), C, _p(s["Wp"], 0), C, _p(dx2), C, beta=1.0)
+                _gemm(0, 0, R - B, C, C, _p(dc), C, _p(s["Wp"], 2 * C * C), C, _p(dx2, B * C), C, beta=1.0)
+            else:
+                dWp[0].zero_(); dWp[2].zero_()
+            g[pre + "conv1d.weight"].copy_(dWp.permute(1, 2, 0))
+            # LayerNorm 2 (+ residual)
+            for n_ in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"):
+                g[pre + "encoder_layer." + n_].zero_()
+            ds2 = new(R, C)
+            _lib.check(L.pk2_layernorm_bwd(_p(dx2), _p(s["s2"]), _p(s["mu2"]), _p(s["rs2"]), _p(e.norm2.weight), R, C,
+                                           _p(ds2), _p(g[pre + "encoder_layer.norm2.weight"]),
+                                           _p(g[pre + "encoder_layer.norm2.bias"]), sp))
+            df2 = _dropout(ds2, drop, s["seed2"]) if drop > 0 else ds2
+            # FFN
+            lin_grads(df2, s["f1d"], F, C, pre + "encoder_layer.linear2.weight", pre + "encoder_layer.linear2.bias")
+            df1 = new(R, F)
+            _gemm(0, 0, R, F, C, _p(df2), C, _p(e.linear2.weight), F, _p(df1), F)
+            if drop > 0:
+                _dropout(df1, drop, s["seedf"], df1)
+            _lib.check(L.pk2_relu_bwd(_p(s["f1"]), _p(df1), df1.numel(), sp))
+            lin_grads(df1, s["x1"], C, F, pre + "encoder_layer.linear1.weight", pre + "encoder_layer.linear1.bias")
+            dx1 = ds2 if drop == 0 else ds2    # residual branch: d x1 = d s2 (+ FFN path below)
+            _gemm(0, 0, R, C, F, _p(df1), F, _p(e.linear1.weight), C, _p(dx1), C, beta=1.0)
+            # LayerNorm 1 (+ residual)
+            ds1 = new(R, C)
+            _lib.check(L.pk2_layernorm_bwd(_p(dx1), _p(s["s1"]), _p(s["mu1"]), _p(s["rs1"]), _p(e.norm1.weight), R, C,
+                                           _p(ds1), _p(g[pre + "encoder_layer.norm1.weight"]),
+                                           _p(g[pre + "encoder_layer.norm1.bias"]), sp))
+            dao = _dropout(ds1, drop, s["seed1"]) if drop > 0 else ds1
+            lin_grads(dao, s["cx"], C, C, pre + "encoder_layer.self_attn.out_proj.weight",
+                      pre + "encoder_layer.self_attn.out_proj.bias")
+            dcx = new(R, C)
+            _gemm(0, 0, R, C, C, _p(dao), C, _p(a.out_proj.weight), C, _p(dcx), C)
+            # attention: dP = dctx V^T ; dV = Pd^T dctx ; dS = softmax'(P, dP) ; dQ = a dS K ; dK = a dS^T Q
+            qkv = s["qkv"]
+            dqkv = new(R, 3 * C)
+            dP = new(B * H, T, T)
+            _bgemm(0, 1, T, T, d, 1.0, _p(dcx), B * C, C, d, _p(qkv, 2 * C), B * 3 * C, 3 * C, d, 0.0, _p(dP), T,
+                   H * T * T, T * T, B, H)
+            _bgemm(1, 0, T, d, T, 1.0, _p(s["Pd"]), T, H * T * T, T * T, _p(dcx), B * C, C, d, 0.0,
+                   _p(dqkv, 2 * C), B * 3 * C, 3 * C, d, B, H)
+            if drop > 0:
+                _dropout(dP, drop, s["seed_attn"], dP)
+            _lib.check(L.pk2_softmax_bwd(_p(s["P"]), _p(dP), B * H, T, sp))
+            sc = 1.0 / math.sqrt(d)
+            _bgemm(0, 0, T, d, T, sc, _p(dP), T, H * T * T, T * T, _p(qkv, C), B * 3 * C, 3 * C, d, 0.0,
+                   _p(dqkv), B * 3 * C, 3 * C, d, B, H)
+            _bgemm(1, 0, T, d, T, sc, _p(dP), T, H * T * T, T * T, _p(qkv), B * 3 * C, 3 * C, d, 0.0,
+                   _p(dqkv, C), B * 3 * C, 3 * C, d, B, H)
+            lin_grads(dqkv, s["h_in"], C, 3 * C, pre + "encoder_layer.self_attn.in_proj_weight",
+                      pre + "encoder_layer.self_attn.in_proj_bias")
+            dh = ds1 if drop == 0 else ds1     # residual branch of the attention block
+            _gemm(0, 0, R, C, 3 * C, _p(dqkv), 3 * C, _p(a.in_proj_weight), C, _p(dh), C, beta=1.0)
+            ctx.saved[li] = None
+        lin_grads(dh, ctx.x.view(R, Din), Din, C, "input_layer.weight", "input_layer.bias")
+        dx = None
+        if ctx.x.requires_grad:
+            dx = new(T, B, Din)
+            _gemm(0, 0, R, Din, C, _p(dh), C, _p(m.input_layer.weight), Din, _p(dx), Din)
+        params = dict(m.named_parameters())
+        for name, v in g.items():
+            p_ = params[name]
+            if p_.grad is None or p_.grad.data_ptr() != v.data_ptr():
+                p_.grad = v
+        return (dx, None, None, None) + (None,) * len(m._param_names)
+
+
+class TransformerAM(nn.Module):
+    def __init__(self, dim_feat, dim_model, nheads, dim_feedforward, nlayers, dropout, output_size, kernel_size=3,
+                 stride=1):
+        super().__init__()
+        assert kernel_size == 3 and stride == 1, "the HIP path implements the reference default Conv1d(k=3, stride=1, pad=1)"
+        assert dim_model % nheads == 0
+        self.dim_feat, self.dim_model, self.nheads = dim_feat, dim_model, nheads
+        self.dim_feedforward, self.nlayers, self.dropout, self.output_size = dim_feedforward, nlayers, dropout, output_size
+        # the reference's construction order (models/transformer.py:80-86) -> identical default initialisation
+        self.pos_encoder = PositionalEncoding(dim_model, dropout)
+        self.input_layer = nn.Linear(dim_feat, dim_model)
+        self.output_layer = nn.Linear(dim_model, output_size)
+        encoder_norm = nn.LayerNorm(dim_model)
+        encoder_layer = _LayerParams(dim_model, nheads, dim_feedforward, dropout, kernel_size, stride)
+        self.transformer = _EncoderParams(encoder_layer, nlayers, encoder_norm)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._flat = self._gflat = self._layout = None
+
+    # ---- flat parameter / gradient buffers (fused optimiser, all-reduce) -------------------------------
+    def _ensure_flat(self):
+        params = dict(self.named_parameters())
+        first = params[self._param_names[0]]
+        if self._flat is not None and self._flat.device == first.device and all(
+                params[n].data_ptr() == self._flat.data_ptr() + 4 * o for n, (o, _) in self._layout.items()):
+            return
+        layout, off = {}, 0
+        for n in self._param_names:
+            layout[n] = (off, params[n].numel())
+            off += (params[n].numel() + 63) // 64 * 64
+        flat = torch.zeros(off, dtype=torch.float32, device=first.device)
+        for n, (o, c) in layout.items():
+            flat[o:o + c].copy_(params[n].data.reshape(-1))
+            params[n].data = flat[o:o + c].view(params[n].shape)
+        self._flat, self._layout, self._gflat = flat, layout, None
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        if self._gflat is None or self._gflat.device != self._flat.device:
+            self._gflat = torch.zeros_like(self._flat)
+        return self._flat, self._gflat
+
+    def _grad_views(self):
+        _, gflat = self.flat_parameters()
+        params = dict(self.named_parameters())
+        return {n: gflat[o:o + c].view(params[n].shape) for n, (o, c) in self._layout.items()}
+
+    def forward(self, data, src_mask=None, src_key_padding_mask=None):
+        """data [T,B,D]; src_mask [T,T] additive float (-inf = blocked) or None; src_key_padding_mask [B,T] bool,
+        True = padding (reference bin/train_transformer_se.py:245-257)."""
+        _lib.require_gpu()
+        assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 3
+        self._ensure_flat()
+        kp = None
+        if src_key_padding_mask is not None:
+            kp = src_key_padding_mask.to(device=data.device, dtype=torch.uint8).contiguous()
+        sm = None
+        if src_mask is not None:
+            sm = src_mask.to(device=data.device, dtype=torch.float32).contiguous()
+        params = [p for _, p in self.named_parameters()]
+        return _TransformerFunction.apply(data, self, sm, kp, *params)
