@@ -45,9 +45,14 @@ def make_batches(rng, n_unique, batch, device):
 
 
 class Trainer:
-    def __init__(self, device, den, base_lr=1e-3, xent=0.1):
+    def __init__(self, device, den, base_lr=1e-3, xent=0.1, arch="blstm"):
         torch.manual_seed(0)
-        self.model = lstm.LSTMAM(80, P, 512, 3, 0.0, True).to(device)
+        self.arch = arch
+        if arch == "transformer":   # configs[4]: 12-layer TransformerAM (dim 512, 8 heads, FFN 2048), secondary workload
+            from pykaldi2_amd import transformer
+            self.model = transformer.TransformerAM(80, 512, 8, 2048, 12, 0.0, P).to(device)
+        else:
+            self.model = lstm.LSTMAM(80, P, 512, 3, 0.0, True).to(device)
         self.base_opt = optim.Adam(self.model, lr=base_lr, amsgrad=True)
         hvd.broadcast_parameters(self.model.state_dict(), root_rank=0)
         self.opt = hvd.DistributedOptimizer(self.base_opt, named_parameters=self.model.named_parameters())
@@ -68,7 +73,14 @@ class Trainer:
         feats, frames, row_off = self.fb(mb["wav"], mb["lens"])
         x = self.fb.pad_roll_subsample(feats, row_off, frames, shift=-(epoch % 3), subsample=3, time_major=True)
         mark("fbank")
-        logits = self.model.forward_time_major(x)
+        if self.arch == "transformer":
+            Tp = x.shape[0]
+            kpm = torch.ones(len(frames), Tp, dtype=torch.bool)
+            for n_, f_ in enumerate(frames):
+                kpm[n_, :-(-f_ // 3)] = False
+            logits = self.model(x, None, kpm.to(x.device))
+        else:
+            logits = self.model.forward_time_major(x)
         mark("lstm_fwd")
         loss = ops.ChainObjtiveBatch.apply(logits.transpose(0, 1), self.den, mb["sups"], self.opts)
         mark("chain")
@@ -252,6 +264,8 @@ def main():
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
     ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
     ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
+    ap.add_argument("--transformer", action="store_true", help="secondary workload configs[4]: 12-layer TransformerAM "
+                    "LF-MMI instead of the BLSTM")
     ap.add_argument("--ce", action="store_true", help="secondary workload configs[1]: 3x512 BLSTM CE, 256 x 80-frame "
                     "chunks per step (not the headline metric)")
     args = ap.parse_args()
@@ -318,7 +332,7 @@ def main():
     n_unique = min(args.steps + args.warmup, 8)
     batches = make_batches(rng, n_unique, args.batch, dev)
     log("%d minibatches ready" % n_unique)
-    tr = Trainer(dev, den)
+    tr = Trainer(dev, den, arch="transformer" if args.transformer else "blstm")
 
     for i in range(args.warmup):
         tr.step(batches[i % n_unique])
@@ -367,7 +381,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
         "pdf alignments, 30k-state/1M-arc denominator graph; random-init 3x512 BLSTM; supervision FSTs "
         "prebuilt on the host)",
-        "config": {"workload": "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
+        "config": {"workload": ("SECONDARY configs[4]: 12-layer TransformerAM LF-MMI; " if args.transformer else "") +
+                               "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
                                "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"
                                % args.batch,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
