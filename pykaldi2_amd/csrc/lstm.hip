@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kFwdThreads = 256;    // 4 waves, K = H split 4 ways
 constexpr int kFwdUnits = 4;        // hidden units per workgroup (x4 gates = 16 MFMA columns)
-constexpr int kBwdThreads = 1024;   // 16 waves, K = 4H split 16 ways
+constexpr int kBwdWavesDefault = 16; // K = 4H split over this many wavefronts (PK2_LSTM_BWD_WAVES = 8 | 16)
 constexpr int kBwdUnits = 4;        // hidden units per workgroup (4 of the 16 MFMA columns carry data:
                                     // the matrix work is negligible at these batch sizes, and 4x more
                                     // workgroups spread the W_hh^T read over the whole chip)
@@ -155,10 +155,10 @@ struct LstmBwdParams {
 // KS = 4-wide MFMA k-steps per wave (4H / 16 waves / 4).  Batch rows in groups of kBwdTileGroup M-tiles.
 constexpr int kBwdTileGroup = 2;
 
-template <int KS>
-__global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams* __restrict__ pp,
-                                                             const StepCounter* __restrict__ cnt, int local) {
-  __shared__ float part[kBwdTileGroup][16][16][17];
+template <int KS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) lstm_bwd_step(const LstmBwdParams* __restrict__ pp,
+                                                            const StepCounter* __restrict__ cnt, int local) {
+  __shared__ float part[kBwdTileGroup][WAVES][16][17];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
   const LstmBwdParams p = *pp;
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(kBwdThreads) lstm_bwd_step(const LstmBwdParams
       if (!last_fwd) {
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 16; ++ww) s += part[tg][ww][pi_][pj];
+        for (int ww = 0; ww < WAVES; ++ww) s += part[tg][ww][pi_][pj];
         dh += s;
       }
       const float tc = tanhf(c);
@@ -325,19 +325,23 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
   LstmBwdParams p{dy, whhT, gates, cells, dgx, dc, B, T, H, D};
   hipLaunchKernelGGL(param_block_store<LstmBwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
   const int zb = ((B + 15) / 16 + kBwdTileGroup - 1) / kBwdTileGroup;
-  dim3 grid(H / kBwdUnits, D, zb), block(kBwdThreads);
+  const char* wenv = getenv("PK2_LSTM_BWD_WAVES");
+  const int waves = (wenv && atoi(wenv) == 8) ? 8 : kBwdWavesDefault;
+  dim3 grid(H / kBwdUnits, D, zb), block(waves * 64);
   const LstmBwdParams* pb = slot->params;
   const StepCounter* c = slot->counter;
   char key[64];
-  snprintf(key, sizeof(key), "lstm_bwd_H%d_D%d_Z%d_%p", H, D, zb, (void*)stream);
+  snprintf(key, sizeof(key), "lstm_bwd_H%d_D%d_Z%d_W%d_%p", H, D, zb, waves, (void*)stream);
   rc = g_graphs.run(key, T, slot->counter, stream, [&](hipStream_t s, int j) {
+#define PK2_BWD(HH)                                                                                  \
+  case HH:                                                                                           \
+    if (waves == 8) launch_step(lstm_bwd_step<HH / 8, 8>, grid, block, s, pb, c, j);                 \
+    else launch_step(lstm_bwd_step<HH / 16, 16>, grid, block, s, pb, c, j);                          \
+    break;
     switch (H) {
-      case 64: launch_step(lstm_bwd_step<4>, grid, block, s, pb, c, j); break;
-      case 128: launch_step(lstm_bwd_step<8>, grid, block, s, pb, c, j); break;
-      case 256: launch_step(lstm_bwd_step<16>, grid, block, s, pb, c, j); break;
-      case 512: launch_step(lstm_bwd_step<32>, grid, block, s, pb, c, j); break;
-      default: launch_step(lstm_bwd_step<64>, grid, block, s, pb, c, j); break;
+      PK2_BWD(64) PK2_BWD(128) PK2_BWD(256) PK2_BWD(512) PK2_BWD(1024)
     }
+#undef PK2_BWD
   });
   if (rc) return rc;
   PK2_LAUNCH_CHECK();
