@@ -121,3 +121,20 @@ def test_full_size_graph_properties():
     lp2, gamma2 = chain.den_forward_backward(G, x[perm].contiguous(), [lens[i] for i in perm], 1e-4)
     assert (lp2 - lp[perm]).abs().max().item() <= 1e-4 * lp.abs().max().item()
     assert (gamma2 - gamma[perm]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("P,arc_pdf", [(9000, False), (9000, True), (20000, False), (20000, True)])
+def test_denominator_large_pdf_counts_use_narrower_groups(P, arc_pdf):
+    """P = 9000 / 20000: exp(logits) for 4 interleaved sequences no longer fits LDS in the general kernels, so the
+    library interleaves 2 / 1 sequences per group; both kernel families must still match the oracle."""
+    g, G, ref = _mk(300, 5000, P, seed=21, arc_pdf=arc_pdf)
+    rng = np.random.default_rng(2)
+    lens = [9, 1, 6]
+    lg = rng.normal(0, 2, size=(3, 9, P)).astype(np.float32)
+    lp, gamma = chain.den_forward_backward(G, torch.from_numpy(lg).cuda(), lens, 1e-4)
+    lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, _ = R.den_forward_backward(lg[n, :Tn].astype(np.float64), ref, 1e-4)
+        assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp) + 1e-4, (n, lp[n], want_lp)
+        assert np.abs(gamma[n, :Tn] - want_g).max() < 1e-4
+        assert not gamma[n, Tn:].any()
