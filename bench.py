@@ -312,7 +312,7 @@ def main():
         L = _lib.lib()
         def run():
             _lib.check(L.pk2_lstm_layer_fwd(_lib.ptr(gx), _lib.ptr(whh), None, B, T, H, D, _lib.ptr(y), _lib.ptr(gates),
-                                            _lib.ptr(cells), _lib.stream_ptr()))
+                                            _lib.ptr(cells), None, _lib.stream_ptr()))
         for _ in range(2):
             run()
         torch.cuda.synchronize()

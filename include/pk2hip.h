@@ -206,9 +206,12 @@ int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta
  * cells: device f32 [D][T][B][H] c_t (saved for backward).
  * H in {64,128,256,512,1024}.
  * ------------------------------------------------------------------ */
+/* workspace: device f32, pk2_lstm_fwd_workspace_floats(B,H,D) floats (0 for small batches: may be NULL).
+ * For B >= 32 the recurrence is tiled as a GEMM with W_hh rows regrouped per hidden unit in it. */
+size_t pk2_lstm_fwd_workspace_floats(int32_t B, int32_t H, int32_t num_dirs);
 int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float* bhh, int32_t B, int32_t T,
                        int32_t H, int32_t num_dirs, float* y, float* gates, float* cells,
-                       void* stream);
+                       void* workspace, void* stream);
 /* dy: device f32 [T][B][D*H] gradient wrt y.  dgx: device f32 [T][B][D*4H]
  * receives the gradient wrt the pre-activations (= gradient wrt gx).
  * scratch: device f32, at least pk2_lstm_bwd_scratch_floats(B,H,D). */

@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL: loads the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpk2hip.so")
+LIB_PATH = os.environ.get("PK2_LIB") or os.path.join(_HERE, "libpk2hip.so")   # PK2_LIB: experiment builds
 
 
 class Pk2Error(RuntimeError):
@@ -63,7 +63,8 @@ SIGNATURES = {
     "pk2_relu_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pk2_add_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pk2_colsum_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _vp]),
-    "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pk2_lstm_fwd_workspace_floats": (_sz, [_i32, _i32, _i32]),
+    "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pk2_dropout_f32": (C.c_int, [_vp, _vp, _i64, _f32, C.c_uint64, _vp]),

@@ -12,11 +12,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libpk2hip.so")
+# experiment builds: PK2_BUILD_TAG=name PK2_EXTRA_FLAGS="-DPK2_DEN_K=4" -> libpk2hip_name.so (select with PK2_LIB)
+_TAG = os.environ.get("PK2_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "libpk2hip" + ("_" + _TAG if _TAG else "") + ".so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
+    os.environ.get("PK2_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

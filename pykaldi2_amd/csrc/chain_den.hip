@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   float* accG = accB + (size_t)kMaxRows * NG;
   float* red = accG + (size_t)kMaxRows * NG;
   const int g = blockIdx.y, tid = threadIdx.x;
-  const int half = __builtin_amdgcn_readfirstlane(tid >> 9), th = tid & (kDenThreads - 1);
+  const int half = __builtin_amdgcn_readfirstlane(tid / kDenThreads), th = tid % kDenThreads;
   const int lane = tid & 63, wh = th >> 6;
   const int ncb = p.bwd.n_chunks, ncg = p.gam.n_chunks;
   const bool beta_role = half == 0;

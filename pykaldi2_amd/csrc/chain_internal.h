@@ -18,10 +18,17 @@ namespace pk2 {
 //  * meta[wb*64+lane] = c0 | (mask << 16): c0 = chunk-local row of the lane's
 //    first arc, bit j of mask = "flush the running sum into row c after arc j,
 //    then c++" (set where a row ends and at j = kK-1).
-constexpr int kK = 8;
-constexpr int kChunkArcs = 4096;
+// (the three tuning constants can be overridden at build time: -DPK2_DEN_K=.. -DPK2_DEN_CHUNK=.. for experiments)
+#ifndef PK2_DEN_K
+#define PK2_DEN_K 8
+#endif
+#ifndef PK2_DEN_CHUNK
+#define PK2_DEN_CHUNK 4096
+#endif
+constexpr int kK = PK2_DEN_K;
+constexpr int kChunkArcs = PK2_DEN_CHUNK;
 constexpr int kMaxRows = 1024;
-constexpr int kDenWaves = 8;                       // wavefronts working on one chunk
+constexpr int kDenWaves = kChunkArcs / (64 * kK);  // wavefronts working on one chunk (one wave block each)
 constexpr int kDenThreads = kDenWaves * 64;        // forward: one chunk per workgroup
 constexpr int kDenBwdThreads = 2 * kDenThreads;    // backward: a beta chunk and a gamma chunk per workgroup
 

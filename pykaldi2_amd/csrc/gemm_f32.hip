@@ -14,84 +14,9 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 namespace pk2 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 16;
-constexpr int kGemmThreads = 256;
-// TILES = MFMA tiles per wave per dimension: block tile (64*TILES)^2.  TILES = 2 (128x128) for large
-// grids; TILES = 1 (64x64) when 128x128 tiles would leave the 256 CUs with fewer than ~2 workgroups
-// each (one wave per SIMD cannot hide its own LDS/global latency).
-template <int TILES> struct Geo {
-  static constexpr int BMN = 64 * TILES;        // block tile edge
-  static constexpr int LD = BMN + 4;            // padded leading dimension of the [BK][BMN] LDS tiles
-  static constexpr int LPK = 16 * TILES;        // lanes covering one k-row when the row dim is contiguous
-};
-
-// Loads the 128 x 16 (rows x k) slab of an operand into registers.
-//   KCONTIG: element (r, k) at base[r*ld + k]  -> thread owns float4 along k of 2 rows
-//  !KCONTIG: element (r, k) at base[k*ld + r]  -> thread owns float4 along r of 2 k's
-// Out-of-range elements read as 0.  `vec` = base/ld allow aligned float4 loads.
-template <bool KCONTIG, int TILES>
-__device__ __forceinline__ void load_slab(const float* __restrict__ base, int64_t ld, int r0, int k0,
-                                          int R, int K, bool vec, float4 (&reg)[TILES]) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int h = 0; h < TILES; ++h) {
-    int r, k;
-    if (KCONTIG) { r = (tid >> 2) + h * 64; k = (tid & 3) * 4; }
-    else         { k = tid / Geo<TILES>::LPK + h * (kGemmThreads / Geo<TILES>::LPK); r = (tid % Geo<TILES>::LPK) * 4; }
-    const int gr = r0 + r, gk = k0 + k;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KCONTIG) {
-      if (gr < R) {
-        const float* p = base + (int64_t)gr * ld + gk;
-        if (vec && gk + 3 < K) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gk + 0 < K) v.x = p[0];
-          if (gk + 1 < K) v.y = p[1];
-          if (gk + 2 < K) v.z = p[2];
-          if (gk + 3 < K) v.w = p[3];
-        }
-      }
-    } else {
-      if (gk < K) {
-        const float* p = base + (int64_t)gk * ld + gr;
-        if (vec && gr + 3 < R) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (gr + 0 < R) v.x = p[0];
-          if (gr + 1 < R) v.y = p[1];
-          if (gr + 2 < R) v.z = p[2];
-          if (gr + 3 < R) v.w = p[3];
-        }
-      }
-    }
-    reg[h] = v;
-  }
-}
-
-template <bool KCONTIG, int TILES>
-__device__ __forceinline__ void store_slab(float* __restrict__ tile, const float4 (&reg)[TILES]) {
-  const int tid = threadIdx.x;
-  constexpr int LD = Geo<TILES>::LD;
-#pragma unroll
-  for (int h = 0; h < TILES; ++h) {
-    if (KCONTIG) {
-      const int r = (tid >> 2) + h * 64, k = (tid & 3) * 4;
-      tile[(k + 0) * LD + r] = reg[h].x;
-      tile[(k + 1) * LD + r] = reg[h].y;
-      tile[(k + 2) * LD + r] = reg[h].z;
-      tile[(k + 3) * LD + r] = reg[h].w;
-    } else {
-      const int k = tid / Geo<TILES>::LPK + h * (kGemmThreads / Geo<TILES>::LPK), r = (tid % Geo<TILES>::LPK) * 4;
-      *reinterpret_cast<float4*>(&tile[k * LD + r]) = reg[h];
-    }
-  }
-}
 
 // Batched form: blockIdx.z = i0 * n1 + i1 selects a matrix triple at offsets i0*s?0 + i1*s?1 (floats).
 struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; };

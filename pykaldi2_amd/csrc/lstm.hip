@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_tile.h"
 #include "step_graph.h"
 
 namespace pk2 {
@@ -47,6 +48,7 @@ struct LstmFwdParams {
   float* gates;       // [D][T][B][4H]
   float* cells;       // [D][T][B][H]
   int B, T, H, D;
+  const float* whh_units;  // [D][H][4][H] rows regrouped (unit, gate) for the large-batch kernel (or null)
 };
 
 // KS = number of 4-wide MFMA k-steps per wave (H / 4 waves / 4).
@@ -150,6 +152,8 @@ struct LstmBwdParams {
   float* dgx;          // [T][B][D*4H]
   float* dc;           // [D][B][H] running dL/dc carried between steps
   int B, T, H, D;
+  const float* whh;    // [D][4H][H] untransposed (large-batch kernels)
+  float* dh_part;      // [kBigSplitK][D][B][H] split-K partial sums of dgates W_hh (large-batch kernels)
 };
 
 // KS = 4-wide MFMA k-steps per wave (4H / 16 waves / 4).  Batch rows in groups of kBwdTileGroup M-tiles.
@@ -246,6 +250,189 @@ __global__ void __launch_bounds__(WAVES * 64) lstm_bwd_step(const LstmBwdParams*
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// Large-batch step kernels (B >= kBigBatch, e.g. the CE configuration 256 x 80).  At these sizes the
+// recurrence is a real GEMM ([B, H] x [H, 4H] per direction and step), so it is tiled like one: 64 x 64
+// output tiles through the LDS staging of gemm_tile.h (v_mfma_f32_32x32x2_f32), W_hh rows regrouped so that
+// a tile's 64 columns are the 4 gates of 16 hidden units, and the gate math fused into the epilogue.
+// ----------------------------------------------------------------------------------------
+constexpr int kBigBatch = 32;
+constexpr int kBigSplitK = 4;
+
+// whh_units[d][u][g][k] = whh[d][g*H + u][k]
+__global__ void __launch_bounds__(256) regroup_whh_units(const float* __restrict__ whh, float* __restrict__ out, int H) {
+  const int d = blockIdx.z, u = blockIdx.x, g = blockIdx.y;
+  const float* src = whh + ((size_t)d * 4 * H + (size_t)g * H + u) * H;
+  float* dst = out + (((size_t)d * H + u) * 4 + g) * H;
+  for (int k = threadIdx.x; k < H; k += 256) dst[k] = src[k];
+}
+
+__global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __restrict__ pp,
+                                                         const StepCounter* __restrict__ cnt, int local) {
+  constexpr int LD = Geo<1>::LD;
+  __shared__ __attribute__((aligned(16))) float As[BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  __shared__ float Cs[64][65];
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const LstmFwdParams p = *pp;
+  const int d = blockIdx.y, u0 = blockIdx.x * 16, m0 = blockIdx.z * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int H = p.H, B = p.B, T = p.T, D = p.D;
+  const int t = d == 0 ? step : T - 1 - step;
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const bool first = step == 0;
+  const size_t yrow = (size_t)D * H;
+  // gate-math operands of the 4 (row, unit) items of this thread, fetched before the matrix phase
+  float pre[4][4], cprev[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + j * 256, i = idx >> 4, u = idx & 15, b = m0 + i;
+    cprev[j] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[j][g] = 0.f;
+    if (b < B) {
+      const float* gxr = p.gx + ((size_t)t * B + b) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pre[j][g] = gxr[(size_t)g * H];
+        if (p.bhh) pre[j][g] += p.bhh[(size_t)d * 4 * H + (size_t)g * H + u0 + u];
+      }
+      if (!first) cprev[j] = p.cells[(((size_t)d * T + tp) * B + b) * H + u0 + u];
+    }
+  }
+  if (!first) {
+    const float* A = p.y + (size_t)tp * B * yrow + (size_t)d * H;               // h_{prev}: row b, k contiguous
+    const float* Bw = p.whh_units + ((size_t)d * H + u0) * 4 * H;              // 64 rows (unit, gate), k contiguous
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 ra[1], rb[1];
+    load_slab<true, 1>(A, (int64_t)yrow, m0, 0, B, H, true, ra);
+    load_slab<true, 1>(Bw, H, 0, 0, 64, H, true, rb);
+    const int nk = H / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      store_slab<true, 1>(As, ra);
+      store_slab<true, 1>(Bs, rb);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        load_slab<true, 1>(A, (int64_t)yrow, m0, (kt + 1) * BK, B, H, true, ra);
+        load_slab<true, 1>(Bw, H, 0, (kt + 1) * BK, 64, H, true, rb);
+      }
+      const int kq = lane >> 5, li = lane & 31;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + kq) * LD + wm + li], Bs[(kk + kq) * LD + wn + li], acc, 0, 0, 0);
+    }
+    const int col = wn + (lane & 31), rh = 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Cs[wm + (r & 3) + 8 * (r >> 2) + rh][col] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + j * 256, i = idx >> 4, u = idx & 15, b = m0 + i;
+    if (b < B) {
+      float v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) v[g] = pre[j][g] + (first ? 0.f : Cs[i][u * 4 + g]);
+      const float ig = sigmoidf_(v[0]), fg = sigmoidf_(v[1]), gg = tanhf(v[2]), og = sigmoidf_(v[3]);
+      const float c = fg * cprev[j] + ig * gg;
+      const float h = og * tanhf(c);
+      p.cells[(((size_t)d * T + t) * B + b) * H + u0 + u] = c;
+      p.y[((size_t)t * B + b) * yrow + (size_t)d * H + u0 + u] = h;
+      float* gr = p.gates + (((size_t)d * T + t) * B + b) * 4 * H + u0 + u;
+      gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
+    }
+  }
+}
+
+// dh_part[s][d][b][k] = sum_{r in K-slice s} dgates[tn][b][r] * W_hh[d][r][k]   (64 x 64 tiles, split-K)
+__global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __restrict__ pp,
+                                                       const StepCounter* __restrict__ cnt, int local) {
+  constexpr int LD = Geo<1>::LD;
+  __shared__ __attribute__((aligned(16))) float As[BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  const int step = cnt->base + local;
+  if (step >= cnt->T || step == 0) return;     // the first backward step has no recurrent gradient
+  const LstmBwdParams p = *pp;
+  const int d = blockIdx.y / kBigSplitK, sk = blockIdx.y % kBigSplitK;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int H = p.H, B = p.B, T = p.T, D = p.D, G4 = 4 * H;
+  const int fstep = T - 1 - step;
+  const int t = d == 0 ? fstep : T - 1 - fstep;
+  const int tn = d == 0 ? t + 1 : t - 1;
+  const int klen = G4 / kBigSplitK, kbeg = sk * klen;
+  const float* A = p.dgx + (size_t)tn * B * ((size_t)D * G4) + (size_t)d * G4 + kbeg;   // rows b, r contiguous
+  const float* Bw = p.whh + (size_t)d * G4 * H + (size_t)kbeg * H;                      // [r][k]: (k=r, n) at r*H + n
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[1], rb[1];
+  load_slab<true, 1>(A, (int64_t)D * G4, m0, 0, B, klen, true, ra);
+  load_slab<false, 1>(Bw, H, n0, 0, H, klen, true, rb);
+  const int nk = klen / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_slab<true, 1>(As, ra);
+    store_slab<false, 1>(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_slab<true, 1>(A, (int64_t)D * G4, m0, (kt + 1) * BK, B, klen, true, ra);
+      load_slab<false, 1>(Bw, H, n0, (kt + 1) * BK, H, klen, true, rb);
+    }
+    const int kq = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + kq) * LD + wm + li], Bs[(kk + kq) * LD + wn + li], acc, 0, 0, 0);
+  }
+  float* out = p.dh_part + (((size_t)sk * D + d) * B) * H;
+  const int col = n0 + wn + (lane & 31), rh = 4 * (lane >> 5);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = m0 + wm + (r & 3) + 8 * (r >> 2) + rh;
+    if (b < B) out[(size_t)b * H + col] = acc[r];
+  }
+}
+
+// Gate derivatives of forward step fstep from dh = dy + sum_s dh_part (one thread per (direction, row, unit)).
+__global__ void __launch_bounds__(256) lstm_bwd_pointwise_big(const LstmBwdParams* __restrict__ pp,
+                                                              const StepCounter* __restrict__ cnt, int local) {
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const LstmBwdParams p = *pp;
+  const int H = p.H, B = p.B, T = p.T, D = p.D, G4 = 4 * H;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)D * B * H) return;
+  const int k = (int)(idx % H), b = (int)((idx / H) % B), d = (int)(idx / ((int64_t)H * B));
+  const int fstep = T - 1 - step;
+  const int t = d == 0 ? fstep : T - 1 - fstep;
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const bool last_fwd = step == 0, first_fwd = fstep == 0;
+  float dh = p.dy[((size_t)t * B + b) * ((size_t)D * H) + (size_t)d * H + k];
+  if (!last_fwd) {
+#pragma unroll
+    for (int s = 0; s < kBigSplitK; ++s) dh += p.dh_part[(((size_t)s * D + d) * B + b) * H + k];
+  }
+  const float* gr = p.gates + (((size_t)d * T + t) * B + b) * G4 + k;
+  const float ig = gr[0], fg = gr[(size_t)H], gg = gr[(size_t)2 * H], og = gr[(size_t)3 * H];
+  const float c = p.cells[(((size_t)d * T + t) * B + b) * H + k];
+  const float cprev = first_fwd ? 0.f : p.cells[(((size_t)d * T + tp) * B + b) * H + k];
+  float* dcp = p.dc + ((size_t)d * B + b) * H + k;
+  const float tc = tanhf(c);
+  const float dcv = (last_fwd ? 0.f : *dcp) + dh * og * (1.f - tc * tc);
+  *dcp = dcv * fg;
+  float* o = p.dgx + ((size_t)t * B + b) * ((size_t)D * G4) + (size_t)d * G4 + k;
+  o[0] = dcv * gg * ig * (1.f - ig);
+  o[(size_t)H] = dcv * cprev * fg * (1.f - fg);
+  o[(size_t)2 * H] = dcv * ig * (1.f - gg * gg);
+  o[(size_t)3 * H] = dh * tc * og * (1.f - og);
+}
+
 // whhT[d][k][r] = whh[d][r][k]
 __global__ void __launch_bounds__(256) transpose_whh(const float* __restrict__ whh, float* __restrict__ whhT,
                                                      int H) {
@@ -275,16 +462,37 @@ using namespace pk2;
 
 static bool lstm_h_ok(int H) { return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024; }
 
+extern "C" size_t pk2_lstm_fwd_workspace_floats(int32_t B, int32_t H, int32_t D) {
+  return B >= kBigBatch ? (size_t)D * 4 * H * H : 0;
+}
+
 extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float* bhh, int32_t B, int32_t T,
-                                  int32_t H, int32_t D, float* y, float* gates, float* cells, void* stream_) {
+                                  int32_t H, int32_t D, float* y, float* gates, float* cells, void* workspace,
+                                  void* stream_) {
   PK2_REQUIRE(gx && whh && y && gates && cells && B > 0 && T > 0 && (D == 1 || D == 2), "lstm_fwd: bad args");
   PK2_REQUIRE(lstm_h_ok(H), "lstm_fwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ParamSlot<LstmFwdParams>* slot;
   int rc = get_param_slot(g_fwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;
-  LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D};
+  const bool big = B >= kBigBatch && workspace != nullptr && H % 64 == 0;
+  float* wu = static_cast<float*>(workspace);
+  if (big) hipLaunchKernelGGL(regroup_whh_units, dim3(H, 4, D), dim3(256), 0, stream, whh, wu, H);
+  LstmFwdParams p{gx, whh, bhh, y, gates, cells, B, T, H, D, big ? wu : nullptr};
   hipLaunchKernelGGL(param_block_store<LstmFwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
+  if (big) {
+    dim3 gridb(H / 16, D, (B + 63) / 64);
+    const LstmFwdParams* pbb = slot->params;
+    const StepCounter* cb = slot->counter;
+    char keyb[64];
+    snprintf(keyb, sizeof(keyb), "lstm_fwd_big_H%d_D%d_Z%d_%p", H, D, (int)gridb.z, (void*)stream);
+    rc = g_graphs.run(keyb, T, slot->counter, stream, [&](hipStream_t s, int j) {
+      hipLaunchKernelGGL(lstm_fwd_step_big, gridb, dim3(256), 0, s, pbb, cb, j);
+    });
+    if (rc) return rc;
+    PK2_LAUNCH_CHECK();
+    return PK2_OK;
+  }
   const int zf = ((B + 15) / 16 + kFwdTileGroup - 1) / kFwdTileGroup;
   dim3 grid(H / kFwdUnits, D, zf), block(kFwdThreads);
   const LstmFwdParams* pb = slot->params;
@@ -306,7 +514,7 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
 }
 
 extern "C" size_t pk2_lstm_bwd_scratch_floats(int32_t B, int32_t H, int32_t D) {
-  return (size_t)D * H * 4 * H + (size_t)D * B * H + 64;
+  return (size_t)D * H * 4 * H + (size_t)D * B * H + 64 + (B >= kBigBatch ? (size_t)kBigSplitK * D * B * H : 0);
 }
 
 extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, const float* cells,
@@ -322,8 +530,25 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
   ParamSlot<LstmBwdParams>* slot;
   int rc = get_param_slot(g_bwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;
-  LstmBwdParams p{dy, whhT, gates, cells, dgx, dc, B, T, H, D};
+  const bool big = B >= kBigBatch && H % 64 == 0 && (4 * H / kBigSplitK) % BK == 0;
+  float* dh_part = dc + (size_t)D * B * H + 64;
+  LstmBwdParams p{dy, whhT, gates, cells, dgx, dc, B, T, H, D, whh, dh_part};
   hipLaunchKernelGGL(param_block_store<LstmBwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
+  if (big) {
+    const LstmBwdParams* pbb = slot->params;
+    const StepCounter* cb = slot->counter;
+    dim3 gridg(H / 64, D * kBigSplitK, (B + 63) / 64);
+    const int pw_blocks = (int)(((int64_t)D * B * H + 255) / 256);
+    char keyb[64];
+    snprintf(keyb, sizeof(keyb), "lstm_bwd_big_H%d_D%d_Z%d_%d_%p", H, D, (int)gridg.z, pw_blocks, (void*)stream);
+    rc = g_graphs.run(keyb, T, slot->counter, stream, [&](hipStream_t s, int j) {
+      hipLaunchKernelGGL(lstm_bwd_dh_big, gridg, dim3(256), 0, s, pbb, cb, j);
+      hipLaunchKernelGGL(lstm_bwd_pointwise_big, dim3(pw_blocks), dim3(256), 0, s, pbb, cb, j);
+    });
+    if (rc) return rc;
+    PK2_LAUNCH_CHECK();
+    return PK2_OK;
+  }
   const int zb = ((B + 15) / 16 + kBwdTileGroup - 1) / kBwdTileGroup;
   const char* wenv = getenv("PK2_LSTM_BWD_WAVES");
   const int waves = (wenv && atoi(wenv) == 8) ? 8 : kBwdWavesDefault;

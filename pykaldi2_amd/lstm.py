@@ -94,7 +94,10 @@ class _LstmAmFunction(torch.autograd.Function):
             y = torch.empty(T, B, D * H, device=dev, dtype=torch.float32)
             gates = torch.empty(D, T, B, 4 * H, device=dev, dtype=torch.float32)
             cells = torch.empty(D, T, B, H, device=dev, dtype=torch.float32)
-            _lib.check(L.pk2_lstm_layer_fwd(_p(gx), _p(w_hh), _p(b_hh), B, T, H, D, _p(y), _p(gates), _p(cells), sp))
+            nws = L.pk2_lstm_fwd_workspace_floats(B, H, D)
+            ws = torch.empty(nws, device=dev, dtype=torch.float32) if nws else None
+            _lib.check(L.pk2_lstm_layer_fwd(_p(gx), _p(w_hh), _p(b_hh), B, T, H, D, _p(y), _p(gates), _p(cells),
+                                            _p(ws) if ws is not None else None, sp))
             saved.append((inp, y, gates, cells))
             inp = y
             if m.dropout > 0 and m.training and l + 1 < Lr:

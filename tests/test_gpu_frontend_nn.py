@@ -115,6 +115,33 @@ def test_blstm_3x512_posteriors_match_torch_cpu():
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
 
 
+@pytest.mark.parametrize("B,T,H,bi", [(70, 9, 128, True), (256, 5, 512, True), (33, 6, 64, False)])
+def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
+    """B >= 32 takes the GEMM-tiled recurrence kernels (ragged last 64-row tile at B=70 / 33)."""
+    torch.manual_seed(1)
+    P, Din = 50, 40
+    m = lstm.LSTMAM(Din, P, H, 2, 0.0, bi)
+    ref_lstm = torch.nn.LSTM(Din, H, 2, batch_first=True, bidirectional=bi)
+    ref_out = torch.nn.Linear(H * (2 if bi else 1), P)
+    ref_lstm.load_state_dict({k[5:]: v for k, v in m.state_dict().items() if k.startswith("lstm.")})
+    ref_out.load_state_dict({k[13:]: v for k, v in m.state_dict().items() if k.startswith("output_layer.")})
+    x = torch.randn(B, T, Din)
+    w = torch.randn(B, T, P)
+    ref_logits = ref_out(ref_lstm(x)[0])
+    (ref_logits * w).sum().backward()
+    m = m.cuda()
+    logits = m(x.cuda())
+    err = (logits.cpu() - ref_logits.detach()).abs().max().item()
+    assert err < 2e-5, err
+    (logits * w.cuda()).sum().backward()
+    refg = dict(list(("lstm." + k, v.grad) for k, v in ref_lstm.named_parameters()) +
+                list(("output_layer." + k, v.grad) for k, v in ref_out.named_parameters()))
+    for name, p in m.named_parameters():
+        want = refg[name]
+        e = (p.grad.cpu() - want).abs().max().item()
+        assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
+
+
 def test_cross_entropy_matches_reference_golden(golden):
     g = golden("misc")
     for red in ("mean", "sum"):
