@@ -286,7 +286,8 @@ def main():
         from pykaldi2_amd.lstm import _gemm, _p
         shapes = [(0, 1, 2356, 4096, 1024), (0, 1, 2356, 6048, 1024), (1, 0, 6048, 1024, 2356), (0, 0, 2356, 1024, 6048),
                   (1, 0, 4096, 1024, 2356), (1, 0, 2048, 512, 2352), (0, 0, 2356, 1024, 4096), (0, 1, 2356, 4096, 80),
-                  (0, 1, 20480, 4096, 1024), (0, 1, 4096, 4096, 4096)]
+                  (0, 1, 20480, 4096, 1024), (0, 1, 4096, 4096, 4096),
+                  (1, 0, 4096, 1024, 20480), (1, 0, 2048, 512, 20480), (1, 0, 5768, 1024, 20480), (0, 0, 20480, 1024, 4096)]
         for ta, tb, M, N, K in shapes:
             A = torch.randn((K, M) if ta else (M, K), device=dev)
             Bm = torch.randn((N, K) if tb else (K, N), device=dev)

@@ -19,7 +19,9 @@
 namespace pk2 {
 
 // Batched form: blockIdx.z = i0 * n1 + i1 selects a matrix triple at offsets i0*s?0 + i1*s?1 (floats).
-struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; };
+// Split-K form (ksplit > 1): blockIdx.z = batch * ksplit + slice; a slice covers klen k's and adds alpha * its
+// partial product into C with float atomics (C already holds beta * C + bias, see gemm_prescale_kernel).
+struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, klen; };
 
 template <bool TA, bool TB, int TILES>
 __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, int K, float alpha,
@@ -29,8 +31,15 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
                                                                 const float* __restrict__ bias, bool vecA,
                                                                 bool vecB, GemmBatch bt) {
   constexpr int LDS_LD = Geo<TILES>::LD, BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
+  int kbeg = 0;
   {
-    const int i0 = blockIdx.z / bt.n1, i1 = blockIdx.z % bt.n1;
+    int z = blockIdx.z;
+    if (bt.ksplit > 1) {
+      kbeg = (z % bt.ksplit) * bt.klen;
+      z /= bt.ksplit;
+      K = min(K, kbeg + bt.klen);
+    }
+    const int i0 = z / bt.n1, i1 = z % bt.n1;
     A += i0 * bt.sA0 + i1 * bt.sA1;
     B += i0 * bt.sB0 + i1 * bt.sB1;
     C += i0 * bt.sC0 + i1 * bt.sC1;
@@ -51,17 +60,17 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
 
   float4 ra[TILES], rb[TILES];
   // A is "k-contiguous" when not transposed ([M,K]); B is k-contiguous when transposed ([N,K]).
-  load_slab<!TA, TILES>(A, lda, m0, 0, M, K, vecA, ra);
-  load_slab<TB, TILES>(B, ldb, n0, 0, N, K, vecB, rb);
-  const int nk = (K + BK - 1) / BK;
+  load_slab<!TA, TILES>(A, lda, m0, kbeg, M, K, vecA, ra);
+  load_slab<TB, TILES>(B, ldb, n0, kbeg, N, K, vecB, rb);
+  const int nk = (K - kbeg + BK - 1) / BK;
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // previous tile fully consumed
     store_slab<!TA, TILES>(As, ra);
     store_slab<TB, TILES>(Bs, rb);
     __syncthreads();
     if (kt + 1 < nk) {
-      load_slab<!TA, TILES>(A, lda, m0, (kt + 1) * BK, M, K, vecA, ra);
-      load_slab<TB, TILES>(B, ldb, n0, (kt + 1) * BK, N, K, vecB, rb);
+      load_slab<!TA, TILES>(A, lda, m0, kbeg + (kt + 1) * BK, M, K, vecA, ra);
+      load_slab<TB, TILES>(B, ldb, n0, kbeg + (kt + 1) * BK, N, K, vecB, rb);
     }
     const int kq = lane >> 5, li = lane & 31;
 #pragma unroll
@@ -86,6 +95,14 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
     for (int j = 0; j < TILES; ++j) {
       const int gc = n0 + wn + j * 32 + col_l;
       if (gc >= N) continue;
+      if (bt.ksplit > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gr = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (gr < M) atomicAdd(C + (int64_t)gr * ldc + gc, alpha * acc[i][j][r]);
+        }
+        continue;
+      }
       const float bv = bias ? bias[gc] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -98,6 +115,19 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
         }
       }
     }
+  }
+}
+
+// C = beta * C + bias ahead of a split-K product (blockIdx.z = batch entry).
+__global__ void __launch_bounds__(256) gemm_prescale_kernel(int M, int N, float beta, float* __restrict__ C,
+                                                            int64_t ldc, const float* __restrict__ bias, GemmBatch bt) {
+  C += (blockIdx.z / bt.n1) * bt.sC0 + (blockIdx.z % bt.n1) * bt.sC1;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float bv = bias ? bias[n] : 0.f;
+  for (int m = blockIdx.y; m < M; m += gridDim.y) {
+    float* o = C + (int64_t)m * ldc + n;
+    *o = beta == 0.f ? bv : beta * (*o) + bv;
   }
 }
 
@@ -129,14 +159,31 @@ using namespace pk2;
 
 static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha, const float* A, int64_t lda,
                        const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
-                       int n0, const GemmBatch& bt, bool aligned_strides, hipStream_t stream) {
+                       int n0, const GemmBatch& bt_in, bool aligned_strides, hipStream_t stream) {
+  GemmBatch bt = bt_in;
   const bool vecA = aligned_strides && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
   const bool vecB = aligned_strides && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const int64_t big_tiles = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * n0 * bt.n1;
   const char* force = getenv("PK2_GEMM_TILES");
-  const int tiles = force ? atoi(force) : (big_tiles >= 512 ? 2 : 1);
+  int tiles = force ? atoi(force) : (big_tiles >= 512 ? 2 : 1);
+  // Deep-K products with few output tiles (the weight gradients: K = frames): 128x128 tiles over K slices.
+  bt.ksplit = 1;
+  bt.klen = K;
+  const char* fsplit = getenv("PK2_GEMM_SPLITK");
+  if (big_tiles <= 256 && K >= 2048 && (!fsplit || atoi(fsplit) != 1)) {   // (measured: no gain above one tile per CU)
+    int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / 512);
+    if (fsplit && atoi(fsplit) > 1) ks = atoi(fsplit);
+    if (ks > 1 && (int64_t)n0 * bt.n1 * ks <= 65535) {
+      tiles = 2;
+      bt.klen = ((K + ks - 1) / ks + BK - 1) / BK * BK;
+      bt.ksplit = (K + bt.klen - 1) / bt.klen;
+      if (beta != 1.f || bias)
+        hipLaunchKernelGGL(gemm_prescale_kernel, dim3((N + 255) / 256, std::min(M, 256), n0 * bt.n1), dim3(256), 0,
+                           stream, M, N, beta, C, ldc, bias, bt);
+    }
+  }
   const int edge = 64 * tiles;
-  dim3 grid((N + edge - 1) / edge, (M + edge - 1) / edge, n0 * bt.n1), block(kGemmThreads);
+  dim3 grid((N + edge - 1) / edge, (M + edge - 1) / edge, n0 * bt.n1 * bt.ksplit), block(kGemmThreads);
 #define PK2_GEMM(TA, TB)                                                                                   \
   do {                                                                                                     \
     if (tiles == 2)                                                                                        \
@@ -159,7 +206,7 @@ extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N
                             const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                             int64_t ldc, const float* bias, void* stream_) {
   PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
-  GemmBatch bt{1, 0, 0, 0, 0, 0, 0};
+  GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
   return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, true,
                      static_cast<hipStream_t>(stream_));
 }
@@ -171,7 +218,7 @@ extern "C" int pk2_gemm_f32_batched(int32_t transa, int32_t transb, int32_t M, i
                                     int32_t n1, void* stream_) {
   PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && n0 > 0 && n1 > 0 && (int64_t)n0 * n1 <= 65535,
               "gemm_f32_batched: bad args");
-  GemmBatch bt{n1, strideA0, strideA1, strideB0, strideB1, strideC0, strideC1};
+  GemmBatch bt{n1, strideA0, strideA1, strideB0, strideB1, strideC0, strideC1, 1, 0};
   const bool aligned = ((strideA0 | strideA1 | strideB0 | strideB1) & 3) == 0;
   return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, n0, bt, aligned,
                      static_cast<hipStream_t>(stream_));

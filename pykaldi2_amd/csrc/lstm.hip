@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(WAVES * 64) lstm_bwd_step(const LstmBwdParams*
 // ----------------------------------------------------------------------------------------
 constexpr int kBigBatch = 32;
 constexpr int kBigSplitK = 4;
+constexpr int kBigSlabs = 4;     // k-slabs of BK staged per iteration (64 k)
 
 // whh_units[d][u][g][k] = whh[d][g*H + u][k]
 __global__ void __launch_bounds__(256) regroup_whh_units(const float* __restrict__ whh, float* __restrict__ out, int H) {
@@ -270,8 +271,8 @@ __global__ void __launch_bounds__(256) regroup_whh_units(const float* __restrict
 __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __restrict__ pp,
                                                          const StepCounter* __restrict__ cnt, int local) {
   constexpr int LD = Geo<1>::LD;
-  __shared__ __attribute__((aligned(16))) float As[BK * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LD];
   __shared__ float Cs[64][65];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
@@ -308,23 +309,35 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 ra[1], rb[1];
-    load_slab<true, 1>(A, (int64_t)yrow, m0, 0, B, H, true, ra);
-    load_slab<true, 1>(Bw, H, 0, 0, 64, H, true, rb);
-    const int nk = H / BK;
+    // kBigSlabs k-slabs of 16 per stage: one workgroup per CU has to keep enough bytes in flight by itself
+    float4 ra[kBigSlabs][1], rb[kBigSlabs][1];
+#pragma unroll
+    for (int q = 0; q < kBigSlabs; ++q) {
+      load_slab<true, 1>(A, (int64_t)yrow, m0, q * BK, B, H, true, ra[q]);
+      load_slab<true, 1>(Bw, H, 0, q * BK, 64, H, true, rb[q]);
+    }
+    const int nk = H / (BK * kBigSlabs);
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
-      store_slab<true, 1>(As, ra);
-      store_slab<true, 1>(Bs, rb);
+#pragma unroll
+      for (int q = 0; q < kBigSlabs; ++q) {
+        store_slab<true, 1>(As[q], ra[q]);
+        store_slab<true, 1>(Bs[q], rb[q]);
+      }
       __syncthreads();
       if (kt + 1 < nk) {
-        load_slab<true, 1>(A, (int64_t)yrow, m0, (kt + 1) * BK, B, H, true, ra);
-        load_slab<true, 1>(Bw, H, 0, (kt + 1) * BK, 64, H, true, rb);
+#pragma unroll
+        for (int q = 0; q < kBigSlabs; ++q) {
+          load_slab<true, 1>(A, (int64_t)yrow, m0, ((kt + 1) * kBigSlabs + q) * BK, B, H, true, ra[q]);
+          load_slab<true, 1>(Bw, H, 0, ((kt + 1) * kBigSlabs + q) * BK, 64, H, true, rb[q]);
+        }
       }
       const int kq = lane >> 5, li = lane & 31;
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + kq) * LD + wm + li], Bs[(kk + kq) * LD + wn + li], acc, 0, 0, 0);
+      for (int q = 0; q < kBigSlabs; ++q)
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[q][(kk + kq) * LD + wm + li], Bs[q][(kk + kq) * LD + wn + li], acc, 0, 0, 0);
     }
     const int col = wn + (lane & 31), rh = 4 * (lane >> 5);
 #pragma unroll
@@ -353,8 +366,8 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
 __global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __restrict__ pp,
                                                        const StepCounter* __restrict__ cnt, int local) {
   constexpr int LD = Geo<1>::LD;
-  __shared__ __attribute__((aligned(16))) float As[BK * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LD];
   const int step = cnt->base + local;
   if (step >= cnt->T || step == 0) return;     // the first backward step has no recurrent gradient
   const LstmBwdParams p = *pp;
@@ -372,23 +385,34 @@ __global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __re
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 ra[1], rb[1];
-  load_slab<true, 1>(A, (int64_t)D * G4, m0, 0, B, klen, true, ra);
-  load_slab<false, 1>(Bw, H, n0, 0, H, klen, true, rb);
-  const int nk = klen / BK;
+  float4 ra[kBigSlabs][1], rb[kBigSlabs][1];
+#pragma unroll
+  for (int q = 0; q < kBigSlabs; ++q) {
+    load_slab<true, 1>(A, (int64_t)D * G4, m0, q * BK, B, klen, true, ra[q]);
+    load_slab<false, 1>(Bw, H, n0, q * BK, H, klen, true, rb[q]);
+  }
+  const int nk = klen / (BK * kBigSlabs);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
-    store_slab<true, 1>(As, ra);
-    store_slab<false, 1>(Bs, rb);
+#pragma unroll
+    for (int q = 0; q < kBigSlabs; ++q) {
+      store_slab<true, 1>(As[q], ra[q]);
+      store_slab<false, 1>(Bs[q], rb[q]);
+    }
     __syncthreads();
     if (kt + 1 < nk) {
-      load_slab<true, 1>(A, (int64_t)D * G4, m0, (kt + 1) * BK, B, klen, true, ra);
-      load_slab<false, 1>(Bw, H, n0, (kt + 1) * BK, H, klen, true, rb);
+#pragma unroll
+      for (int q = 0; q < kBigSlabs; ++q) {
+        load_slab<true, 1>(A, (int64_t)D * G4, m0, ((kt + 1) * kBigSlabs + q) * BK, B, klen, true, ra[q]);
+        load_slab<false, 1>(Bw, H, n0, ((kt + 1) * kBigSlabs + q) * BK, H, klen, true, rb[q]);
+      }
     }
     const int kq = lane >> 5, li = lane & 31;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(kk + kq) * LD + wm + li], Bs[(kk + kq) * LD + wn + li], acc, 0, 0, 0);
+    for (int q = 0; q < kBigSlabs; ++q)
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[q][(kk + kq) * LD + wm + li], Bs[q][(kk + kq) * LD + wn + li], acc, 0, 0, 0);
   }
   float* out = p.dh_part + (((size_t)sk * D + d) * B) * H;
   const int col = n0 + wn + (lane & 31), rh = 4 * (lane >> 5);
@@ -530,7 +554,7 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
   ParamSlot<LstmBwdParams>* slot;
   int rc = get_param_slot(g_bwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;
-  const bool big = B >= kBigBatch && H % 64 == 0 && (4 * H / kBigSplitK) % BK == 0;
+  const bool big = B >= kBigBatch && H % 64 == 0;   // K-slice 4H / kBigSplitK = H: whole stages of 64
   float* dh_part = dc + (size_t)D * B * H + 64;
   LstmBwdParams p{dy, whhT, gates, cells, dgx, dc, B, T, H, D, whh, dh_part};
   hipLaunchKernelGGL(param_block_store<LstmBwdParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
