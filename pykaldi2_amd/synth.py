@@ -178,3 +178,69 @@ def minibatch(rng, batch, num_pdfs, sr=16000):
         T = num_fbank_frames(wav.shape[0])
         out.append((wav, pdf_alignment(rng, T, num_pdfs)))
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# Lattice path (train_se): transition model, decoding graph, transition-id alignments
+# ----------------------------------------------------------------------------------------
+def transition_model_arrays(num_pdfs):
+    """A context-independent 3-state left-to-right model over num_pdfs // 3 phones, in Kaldi's numbering:
+    transition-ids are 1-based, two per HMM state (self-loop, then forward), pdf = 3*(phone-1) + hmm_state.
+    Returns dict(tid2pdf, tid2phone [index 0 unused], num_phones, silence_phones)."""
+    num_phones = num_pdfs // 3
+    n = 6 * num_phones
+    tid = np.arange(1, n + 1)
+    tid2pdf = np.concatenate([[-1], (tid - 1) // 2]).astype(np.int32)
+    tid2phone = np.concatenate([[0], (tid - 1) // 6 + 1]).astype(np.int32)
+    return dict(tid2pdf=tid2pdf, tid2phone=tid2phone, num_phones=num_phones, silence_phones=[1])
+
+
+def decoding_graph_arcs(num_words=2000, num_pdfs=5768, seed=0, max_phones=5):
+    """Synthetic HCLG-shaped decoding graph: a word loop over `num_words` pronunciations of 2..max_phones
+    phones, every phone 3 HMM states with a self-loop and a forward arc (ilabels = transition-ids of
+    transition_model_arrays), word entry = epsilon arc carrying a Zipf unigram cost, word exit = epsilon arc
+    back to the loop state (so tokens cross two epsilon arcs between words).  Returns dict(num_states, start,
+    src, dst, ilabel, weight, final)."""
+    rng = np.random.default_rng(seed)
+    num_phones = num_pdfs // 3
+    p = 1.0 / np.arange(1, num_words + 1)
+    p /= p.sum()
+    src, dst, ilab, w = [], [], [], []
+    loop = 0
+    n_states = 1
+    lp_self, lp_fwd = -np.log(0.6), -np.log(0.4)
+    for wd in range(num_words):
+        k = int(rng.integers(2, max_phones + 1))
+        phones = rng.integers(1, num_phones + 1, size=k)
+        if wd == 0:
+            phones = np.array([1, 1])      # a silence "word"
+        first = n_states
+        src.append(loop); dst.append(first); ilab.append(0); w.append(-np.log(p[wd]))
+        for ph in phones:
+            for hs in range(3):
+                s = n_states
+                n_states += 1
+                base = 1 + 2 * (3 * (int(ph) - 1) + hs)
+                src.append(s); dst.append(s); ilab.append(base); w.append(lp_self)
+                src.append(s); dst.append(s + 1); ilab.append(base + 1); w.append(lp_fwd)
+        end = n_states        # word-end state reached by the last forward arc
+        n_states += 1
+        src.append(end); dst.append(loop); ilab.append(0); w.append(0.0)
+    final = np.full(n_states, np.inf, np.float32)
+    final[loop] = 0.0
+    return dict(num_states=n_states, start=loop, src=np.asarray(src, np.int32), dst=np.asarray(dst, np.int32),
+                ilabel=np.asarray(ilab, np.int32), weight=np.asarray(w, np.float32), final=final)
+
+
+def tid_alignment(rng, num_frames, num_pdfs):
+    """A transition-id alignment (reference aux_label): phones drawn uniformly, each HMM state held for
+    1 + Geometric(0.4) frames = self-loop ids followed by one forward id."""
+    num_phones = num_pdfs // 3
+    out = []
+    while len(out) < num_frames:
+        ph = int(rng.integers(1, num_phones + 1))
+        for hs in range(3):
+            base = 1 + 2 * (3 * (ph - 1) + hs)
+            d = int(rng.geometric(0.4))
+            out.extend([base] * (d - 1) + [base + 1])
+    return np.asarray(out[:num_frames], np.int64)
