@@ -28,7 +28,8 @@ typedef enum {
   PK2_ERR_INVALID = -1,   /* bad argument */
   PK2_ERR_HIP = -2,       /* HIP runtime error (see pk2_last_error) */
   PK2_ERR_LIMIT = -3,     /* size exceeds a documented kernel limit */
-  PK2_ERR_IO = -4         /* file could not be read / bad format */
+  PK2_ERR_IO = -4,        /* file could not be read / bad format */
+  PK2_ERR_NUMERIC = -5    /* a device computation failed (e.g. the decoder lost every token) */
 } pk2_status;
 
 const char* pk2_last_error(void);
@@ -270,6 +271,87 @@ int pk2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int pk2_sgd_step(float* param, const float* grad, float* momentum_buf /* NULL = none */,
                  int64_t n, float lr, float momentum, float weight_decay, int32_t first_step,
                  float max_norm, const float* norm, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Lattice path: on-the-fly lattice generation + lattice forward-backward for the MMI / sMBR / MPFE
+ * criteria.  Replaces, for a whole minibatch and on the device, what MMIFunction / sMBRFunction do per
+ * utterance on the CPU through PyKaldi (reference ops/ops.py:55-66, 133-146):
+ *   asr_decoder.decode(loglikes)  [Kaldi LatticeFasterDecoder over HCLG, determinize_lattice = False,
+ *                                  reference bin/train_se.py:172-183]
+ *   scale_lattice + lattice_forward_backward_mmi(trans_model, lat, trans_ids, True, False, True)
+ *   lattice_forward_backward_mpe_variants(trans_model, silence_phones, lat, trans_ids, criterion, True)
+ *   Posterior.to_pdf_matrix(trans_model)
+ * One workgroup per utterance; the lattices stay in the caller's workspace (device memory).
+ * ------------------------------------------------------------------ */
+typedef struct pk2_decode_graph pk2_decode_graph;
+
+/* HCLG as arc arrays: ilabel = transition-id (0 = epsilon), weight = tropical cost, final_cost[s] = +inf for
+ * non-final states.  Output labels (words) are not needed by any criterion and are not stored. */
+int pk2_decode_graph_create(int32_t num_states, int32_t start_state, int64_t num_arcs,
+                            const int32_t* arc_src, const int32_t* arc_dst, const int32_t* arc_ilabel,
+                            const float* arc_weight, const float* final_cost, pk2_decode_graph** out);
+/* HCLG.fst in OpenFst binary form ("vector" or "const" container, "standard" arcs;
+ * reference bin/train_se.py:145,180). */
+int pk2_decode_graph_from_openfst(const char* path, pk2_decode_graph** out);
+int pk2_decode_graph_destroy(pk2_decode_graph* g);
+int pk2_decode_graph_info(const pk2_decode_graph* g, int32_t* num_states, int64_t* num_arcs,
+                          int32_t* max_ilabel);
+
+/* LatticeFasterDecoderOptions (reference bin/train_se.py:173-178; YAML decoder_config) + pool sizing. */
+typedef struct {
+  float beam;             /* 13 */
+  float lattice_beam;     /* 7 */
+  float beam_delta;       /* 0.5 */
+  float acoustic_scale;   /* 0.1 */
+  int32_t max_active;     /* 7000 */
+  int32_t min_active;     /* 200 */
+  int32_t tokens_per_frame;  /* pool size per utterance = (T+1) * this; 0 = max_active */
+  int32_t links_per_frame;   /* pool size per utterance = (T+1) * this; 0 = 3 * max_active */
+} pk2_decoder_opts;
+
+/* Layout of one minibatch of lattices (host object; lengths = frames per utterance). */
+typedef struct pk2_lattice_batch pk2_lattice_batch;
+int pk2_lattice_batch_create(const pk2_decode_graph* g, const int32_t* lengths_host, int32_t num_seq,
+                             const pk2_decoder_opts* opts, pk2_lattice_batch** out);
+size_t pk2_lattice_batch_bytes(const pk2_lattice_batch* b);
+int pk2_lattice_batch_destroy(pk2_lattice_batch* b);
+
+/* Decodes all utterances: loglikes[n][t][pdf] at n*seq_stride + t*frame_stride + pdf (device f32, the
+ * acoustic model output minus the log prior, reference bin/train_se.py:241); tid2pdf: device i32
+ * [num_tids + 1] (index 0 unused).  Asynchronous on `stream`; the lattices are left in `workspace`
+ * (pk2_lattice_batch_bytes bytes, device). */
+int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, int64_t seq_stride,
+                       int64_t frame_stride, int32_t num_pdfs, const int32_t* tid2pdf, int32_t num_tids,
+                       void* workspace, void* stream);
+/* Synchronises `stream` and reports per utterance: status (0 ok, 1 token pool overflow, 2 link pool
+ * overflow, 3 no surviving token, 4 epsilon closure did not converge), tokens and links created, cost of
+ * the best path.  Returns PK2_ERR_LIMIT / PK2_ERR_NUMERIC if any utterance failed.  Any output may be NULL. */
+int pk2_lattice_summary(const pk2_lattice_batch* b, const void* workspace, int32_t* status,
+                        int32_t* num_tokens, int32_t* num_links, float* best_cost, void* stream);
+/* MMI: post[n][t][pdf] (+)= numerator - denominator posterior (lattice scaled by lm_scale / acoustic_scale
+ * first, as fst::ScaleLattice does: float weights multiplied in double and stored back as float; 1.0 / 0.2
+ * at reference ops/ops.py:58); frames whose reference transition-id is not in the lattice
+ * are dropped when drop_frames != 0.  ref_tids: device i32, utterance n at n*ref_stride.  post rows must
+ * be zero on entry.  lat_like: device f64[num_seq] = total log-likelihood of each lattice. */
+int pk2_lattice_mmi(const pk2_lattice_batch* b, void* workspace, const int32_t* ref_tids,
+                    int64_t ref_stride, const int32_t* tid2pdf, double lm_scale, double acoustic_scale,
+                    int32_t drop_frames, float* post, int64_t post_seq_stride,
+                    int64_t post_frame_stride, double* lat_like, void* stream);
+/* sMBR (criterion 0) / MPFE (criterion 1): post (+)= arc posterior * (expected accuracy through the arc -
+ * expected accuracy); score: device f64[num_seq] = expected frame accuracy.  tid2phone: device i32
+ * [num_tids + 1]; phone_is_silence: device u8 [num_phones + 1]. */
+int pk2_lattice_mpe(const pk2_lattice_batch* b, void* workspace, const int32_t* ref_tids,
+                    int64_t ref_stride, const int32_t* tid2pdf, const int32_t* tid2phone,
+                    const uint8_t* phone_is_silence, int32_t criterion, int32_t one_silence_class,
+                    double lm_scale, double acoustic_scale, float* post, int64_t post_seq_stride,
+                    int64_t post_frame_stride, double* score, void* stream);
+/* Test / tooling hook: copies the pruned lattice of utterance n to host arrays (synchronises `stream`).
+ * Call with null arrays to get the counts.  Tokens are renumbered frame by frame; link_ac is the acoustic
+ * cost with the acoustic scale removed. */
+int pk2_lattice_export(const pk2_lattice_batch* b, const void* workspace, int32_t n, int32_t* num_tokens,
+                       int32_t* num_links, int32_t* tok_frame, int32_t* tok_state, float* tok_cost,
+                       float* tok_final, int32_t* link_src, int32_t* link_dst, int32_t* link_tid,
+                       float* link_graph, float* link_ac, void* stream);
 
 #ifdef __cplusplus
 }

@@ -332,7 +332,9 @@ def lattice_forward_backward(lat, lm_scale=1.0, ac_scale=1.0):
     """LatticeForwardBackward (lattice-functions.cc): returns (tot_like, alpha, beta, link_like, order, A)."""
     A, order = _topo_links(lat)
     nt = A["tok_state"].shape[0]
-    like = -(lm_scale * A["link_graph"].astype(np.float64) + ac_scale * A["link_ac"].astype(np.float64))
+    # fst::ScaleLattice multiplies the float weights by the double scales and stores floats again
+    like = -((lm_scale * A["link_graph"].astype(np.float64)).astype(np.float32).astype(np.float64) +
+             (ac_scale * A["link_ac"].astype(np.float64)).astype(np.float32).astype(np.float64))
     alpha = np.full(nt, -math.inf)
     beta = np.full(nt, -math.inf)
     alpha[lat.start_tok] = 0.0
@@ -341,7 +343,7 @@ def lattice_forward_backward(lat, lm_scale=1.0, ac_scale=1.0):
     tot = -math.inf
     for k in range(nt):
         if A["tok_final"][k] != INF:
-            f = -lm_scale * float(A["tok_final"][k])
+            f = -float(np.float32(lm_scale * float(A["tok_final"][k])))
             beta[k] = f
             tot = _logadd(tot, alpha[k] + f)
     for l in reversed(order):
@@ -404,7 +406,7 @@ def lattice_mpe(lat, trans_ids, tid2pdf, tid2phone, silence_phones, num_pdfs, cr
     tot_score = 0.0
     for k in range(nt):
         if A["tok_final"][k] != INF:
-            tot_score += math.exp(alpha[k] - lm_scale * float(A["tok_final"][k]) - tot) * a_s[k]
+            tot_score += math.exp(alpha[k] - float(np.float32(lm_scale * float(A["tok_final"][k]))) - tot) * a_s[k]
     b_s = np.zeros(nt)
     for l in reversed(order):
         s, d = A["link_src"][l], A["link_dst"][l]
@@ -439,10 +441,11 @@ def brute_force_lattice(lat, trans_ids, tid2pdf, tid2phone, silence_phones, num_
 
     def walk(k, ll, links):
         if A["tok_final"][k] != INF:
-            paths.append((ll - lm_scale * float(A["tok_final"][k]), list(links)))
+            paths.append((ll - float(np.float32(lm_scale * float(A["tok_final"][k]))), list(links)))
         for l in outs.get(k, []):
             links.append(l)
-            walk(int(A["link_dst"][l]), ll - (lm_scale * float(A["link_graph"][l]) + ac_scale * float(A["link_ac"][l])), links)
+            walk(int(A["link_dst"][l]), ll - (float(np.float32(lm_scale * float(A["link_graph"][l]))) +
+                                             float(np.float32(ac_scale * float(A["link_ac"][l])))), links)
             links.pop()
 
     walk(lat.start_tok, 0.0, [])

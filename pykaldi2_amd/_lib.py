@@ -25,6 +25,13 @@ class NumBatch(C.Structure):
                 ("total_arcs", C.c_int64)]
 
 
+class DecoderOpts(C.Structure):
+    """pk2_decoder_opts"""
+    _fields_ = [("beam", C.c_float), ("lattice_beam", C.c_float), ("beam_delta", C.c_float),
+                ("acoustic_scale", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
+                ("tokens_per_frame", C.c_int32), ("links_per_frame", C.c_int32)]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/pk2hip.h one to one
@@ -43,6 +50,20 @@ SIGNATURES = {
                                            _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "pk2_chain_den_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _f32, _vp, _vp, _i64, _i64,
                                         _vp, _sz, _vp]),
+    "pk2_decode_graph_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pk2_decode_graph_from_openfst": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pk2_decode_graph_destroy": (C.c_int, [_vp]),
+    "pk2_decode_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
+    "pk2_lattice_batch_create": (C.c_int, [_vp, _vp, _i32, C.POINTER(DecoderOpts), C.POINTER(_vp)]),
+    "pk2_lattice_batch_bytes": (_sz, [_vp]),
+    "pk2_lattice_batch_destroy": (C.c_int, [_vp]),
+    "pk2_lattice_decode": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "pk2_lattice_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pk2_lattice_mmi": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_double, C.c_double, _i32, _vp, _i64, _i64, _vp, _vp]),
+    "pk2_lattice_mpe": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _vp, _i64, _i64,
+                                  _vp, _vp]),
+    "pk2_lattice_export": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _vp]),
     "pk2_fbank_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pk2_fbank_destroy": (C.c_int, [_vp]),
     "pk2_fbank_num_frames": (_i32, [_i64]),

@@ -20,6 +20,9 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
     os.environ.get("PK2_EXTRA_FLAGS", "").split()
+# hipcc defaults to -ffp-contract=fast, which fuses a*b+c across statements and ignores `#pragma clang fp
+# contract(off)`; the decoder's costs must round like the oracle's separate float32 operations.
+FILE_FLAGS = {"lattice_decode.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():
@@ -45,7 +48,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r
 

@@ -10,6 +10,7 @@
 #include <numeric>
 
 #include "chain_internal.h"
+#include "openfst_io.h"
 
 namespace pk2 {
 
@@ -220,46 +221,21 @@ extern "C" int pk2_den_graph_create(int32_t num_states, int32_t num_pdfs, int64_
                      start_state, out);
 }
 
-// OpenFst binary StdVectorFst: header, optional symbol tables are not
-// supported (Kaldi writes den.fst without them), then per state {f32 final, i64 narcs,
-// arcs {i32 ilabel, i32 olabel, f32 weight, i32 nextstate}}.
+// den.fst in OpenFst binary form (openfst_io.h): ilabel = pdf + 1, weight = -log prob.
 extern "C" int pk2_den_graph_from_openfst(const char* path, int32_t num_pdfs, pk2_den_graph** out) {
   PK2_REQUIRE(path && out, "den graph: null pointer");
-  FILE* f = fopen(path, "rb");
-  if (!f) { set_error("cannot open %s", path); return PK2_ERR_IO; }
-  auto fail = [&](const char* why) { fclose(f); set_error("%s: %s", path, why); return (int)PK2_ERR_IO; };
-  auto rd = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
-  int32_t magic;
-  if (!rd(&magic, 4) || magic != 2125659606) return fail("bad magic");
-  auto rdstr = [&](std::string* s) {
-    int32_t n;
-    if (!rd(&n, 4) || n < 0 || n > 4096) return false;
-    s->resize(n);
-    return n == 0 || rd(&(*s)[0], n);
-  };
-  std::string fst_type, arc_type;
-  if (!rdstr(&fst_type) || !rdstr(&arc_type)) return fail("bad header");
-  if (fst_type != "vector" || arc_type != "standard") return fail("not a vector/standard FST");
-  int32_t version, flags; uint64_t props; int64_t start, nstates, narcs_hdr;
-  if (!rd(&version, 4) || !rd(&flags, 4) || !rd(&props, 8) || !rd(&start, 8) || !rd(&nstates, 8) ||
-      !rd(&narcs_hdr, 8))
-    return fail("short header");
-  if (flags & 3) return fail("embedded symbol tables are not supported");
-  if (nstates <= 0 || nstates > (1 << 30)) return fail("bad state count");
-  std::vector<int32_t> src, dst, pdf; std::vector<float> prob;
-  for (int64_t s = 0; s < nstates; ++s) {
-    float fin; int64_t na;
-    if (!rd(&fin, 4) || !rd(&na, 8) || na < 0) return fail("truncated state");
-    for (int64_t k = 0; k < na; ++k) {
-      int32_t il, ol, ns; float w;
-      if (!rd(&il, 4) || !rd(&ol, 4) || !rd(&w, 4) || !rd(&ns, 4)) return fail("truncated arc");
-      if (il <= 0) return fail("epsilon / negative ilabel in den.fst");
-      src.push_back((int32_t)s); dst.push_back(ns); pdf.push_back(il - 1); prob.push_back(expf(-w));
-    }
+  FstArrays fst;
+  const std::string why = read_openfst(path, &fst);
+  if (!why.empty()) { set_error("%s: %s", path, why.c_str()); return PK2_ERR_IO; }
+  std::vector<int32_t> pdf(fst.ilabel.size());
+  std::vector<float> prob(fst.ilabel.size());
+  for (size_t a = 0; a < fst.ilabel.size(); ++a) {
+    if (fst.ilabel[a] <= 0) { set_error("%s: epsilon / negative ilabel in den.fst", path); return PK2_ERR_IO; }
+    pdf[a] = fst.ilabel[a] - 1;
+    prob[a] = expf(-fst.weight[a]);
   }
-  fclose(f);
-  return build_graph((int32_t)nstates, num_pdfs, (int64_t)src.size(), src.data(), dst.data(),
-                     pdf.data(), prob.data(), (int32_t)start, out);
+  return build_graph((int32_t)fst.num_states, num_pdfs, (int64_t)pdf.size(), fst.src.data(), fst.dst.data(),
+                     pdf.data(), prob.data(), (int32_t)fst.start, out);
 }
 
 extern "C" int pk2_den_graph_destroy(pk2_den_graph* g) {

@@ -1,0 +1,503 @@
+// On-the-fly lattice generation on gfx950: frame-synchronous token passing over HCLG with beam /
+// max-active / min-active pruning, followed by lattice-beam pruning of the recorded links.
+//
+// Replaces `asr_decoder.decode(loglikes)` = Kaldi LatticeFasterDecoder with determinize_lattice = False
+// (reference ops/ops.py:55,133; bin/train_se.py:172-183), restated in oracle/lattice_ref.py::decode
+// (GetCutoff, ProcessEmitting, ProcessNonemitting, PruneForwardLinks[Final]).
+//
+// One workgroup (1024 threads) per utterance, one launch per minibatch -- see lattice_internal.h.  Inside a
+// frame the workgroup
+//   1. reduces the frame's token costs to the pruning cutoff (exact k-th smallest by a 3-pass radix select
+//      in LDS when max_active / min_active bind),
+//   2. stages the frame's log-likelihood row in LDS,
+//   3. walks the emitting arcs of the surviving tokens twice: first for the best new cost (-> next cutoff =
+//      best + adaptive beam), then to create tokens (atomicMin on a dense per-state table; the thread that
+//      lowers an empty slot owns the new token) and links,
+//   4. closes the new frame over epsilon arcs by rounds of relaxations to the exact fixed point, then
+//      records the epsilon links from the final costs.
+// All cost arithmetic is float32 in the oracle's order, (cur + acoustic) + graph, without FMA contraction,
+// so token costs and the kept link set are bit-identical to the oracle's.
+#include <cmath>
+
+#include "lattice_internal.h"
+
+// Costs must round exactly like the oracle's separate float32 multiply / add steps.  HIP's __fmul_rn /
+// __fadd_rn are plain operators and hipcc's default -ffp-contract=fast ignores contraction pragmas, so this
+// file is compiled with -ffp-contract=off (pykaldi2_amd/build.py FILE_FLAGS).
+
+namespace pk2 {
+
+constexpr int kLatThreads = 1024;
+constexpr int kLatWaves = kLatThreads / 64;
+constexpr int kMaxPdfsLds = 8192;
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kMaxEpsRounds = 256;
+
+__device__ __forceinline__ uint32_t enc_cost(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_cost(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+template <typename T>
+__device__ __forceinline__ T ld_coherent(const T* p) {   // bypasses the vector L1 (values written by atomics)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct DecodeParams {
+  DevDecodeGraph g;
+  LatPtrs L;
+  const float* loglikes; int64_t seq_stride, frame_stride; int32_t P;
+  const int32_t* tid2pdf; int32_t num_tids;
+  float beam, lattice_beam, beam_delta, ac_scale;
+  int32_t max_active, min_active;
+};
+
+struct Shared {
+  float ll[kMaxPdfsLds];
+  uint32_t hist[2048];
+  float redf[kLatWaves];
+  int redi[kLatWaves];
+  int n_new;      // tokens appended to the frame being built
+  int n_link;     // links appended to the segment being built
+  int status;
+  uint32_t sel_prefix; int sel_k;
+};
+
+__device__ __forceinline__ float block_min(float v, Shared& sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh.redf[0];
+#pragma unroll
+  for (int k = 1; k < kLatWaves; ++k) r = fminf(r, sh.redf[k]);
+  return r;
+}
+__device__ __forceinline__ int block_sum_i(int v, Shared& sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.redi[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = 0;
+#pragma unroll
+  for (int k = 0; k < kLatWaves; ++k) r += sh.redi[k];
+  return r;
+}
+
+// k-th smallest (0-based) of cost[0..n): radix select on the order-preserving keys, 11 + 11 + 10 bits.
+__device__ float kth_smallest(const float* cost, int n, int k, Shared& sh) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0, mask = 0;
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = tid; i < 2048; i += kLatThreads) sh.hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kLatThreads) {
+      const uint32_t key = enc_cost(cost[i]);
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shifts[pass]) & ((1u << bits[pass]) - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int kk = k;
+      uint32_t b = 0;
+      const uint32_t nb = 1u << bits[pass];
+      for (; b < nb; ++b) {
+        const int c = (int)sh.hist[b];
+        if (kk < c) break;
+        kk -= c;
+      }
+      sh.sel_prefix = prefix | (b << shifts[pass]);
+      sh.sel_k = kk;
+    }
+    __syncthreads();
+    prefix = sh.sel_prefix;
+    k = sh.sel_k;
+    mask |= ((1u << bits[pass]) - 1) << shifts[pass];
+    __syncthreads();
+  }
+  return dec_cost(prefix);
+}
+
+// Epsilon closure of the frame whose tokens start at f0 (utterance-local), then the frame's epsilon links.
+// On entry sh.n_new = tokens already in the frame with their costs in the state table and tok_cost = +inf
+// ("cost at the last expansion").  On exit tok_cost holds the final costs, the table is clean again and
+// *tok_end / *link_end are advanced.
+__device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, uint32_t* stc, int32_t* stt, int f0,
+                            float cutoff, int* link_end, int* tok_end, int seg_index) {
+  const int tid = threadIdx.x;
+  int32_t* ts = p.L.tok_state + U.tok_base;
+  float* tc = p.L.tok_cost + U.tok_base;
+  const uint32_t kcut = enc_cost(cutoff);
+  int rounds = 0;
+  while (true) {
+    __syncthreads();
+    const int cnt = sh.n_new;
+    int changed = 0;
+    for (int i = f0 + tid; i < f0 + cnt; i += kLatThreads) {
+      const int s = ts[i];
+      const float c = dec_cost(ld_coherent(&stc[s]));
+      if (c < tc[i]) {
+        tc[i] = c;
+        if (c < cutoff) {
+          for (int a = p.g.n_off[s]; a < p.g.n_off[s + 1]; ++a) {
+            const float tot = c + p.g.n_w[a];
+            const uint32_t k = enc_cost(tot);
+            if (k < kcut) {
+              const int d = p.g.n_dst[a];
+              const uint32_t old = atomicMin(&stc[d], k);
+              if (k < old) {
+                changed = 1;
+                if (old == kEmpty) {
+                  const int idx = atomicAdd(&sh.n_new, 1);
+                  if (f0 + idx < U.tok_cap) {
+                    ts[f0 + idx] = d;
+                    tc[f0 + idx] = INFINITY;
+                    __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  } else {
+                    sh.status = kLatTokenOverflow;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    changed = __syncthreads_or(changed);
+    if (!changed || sh.status != kLatOk) break;
+    if (++rounds > kMaxEpsRounds) { if (tid == 0) sh.status = kLatEpsilonLoop; break; }
+  }
+  __syncthreads();
+  if (sh.status != kLatOk) return;
+  const int cnt = sh.n_new;
+  // epsilon links from the final costs
+  int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
+  int32_t* ltid = p.L.link_tid + U.link_base;
+  float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
+  const int l0 = *link_end;
+  for (int i = f0 + tid; i < f0 + cnt; i += kLatThreads) {
+    const float c = tc[i];
+    if (c < cutoff) {
+      const int s = ts[i];
+      for (int a = p.g.n_off[s]; a < p.g.n_off[s + 1]; ++a) {
+        const float tot = c + p.g.n_w[a];
+        if (tot < cutoff) {
+          const int li = l0 + atomicAdd(&sh.n_link, 1);
+          if (li < U.link_cap) {
+            lsrc[li] = i;
+            ldst[li] = f0 + ld_coherent(&stt[p.g.n_dst[a]]);
+            ltid[li] = 0;
+            lgr[li] = p.g.n_w[a];
+            lac[li] = 0.f;
+          } else {
+            sh.status = kLatLinkOverflow;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // reset the table entries of the frame; prepare the token arrays the pruning pass uses
+  float* te = p.L.tok_extra + U.tok_base;
+  int32_t* tl = p.L.tok_level + U.tok_base;
+  for (int i = f0 + tid; i < f0 + cnt; i += kLatThreads) {
+    const int s = ts[i];
+    stc[s] = kEmpty;
+    stt[s] = -1;
+    te[i] = INFINITY;
+    tl[i] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *tok_end = f0 + cnt;
+    *link_end = min(l0 + sh.n_link, U.link_cap);
+    p.L.seg_off[U.frame_base + seg_index + 1] = *link_end;
+    sh.n_new = 0;
+    sh.n_link = 0;
+  }
+  __syncthreads();
+}
+
+// In-place compaction of the links [l0, l1) that satisfy keep(l); returns the number kept (all threads).
+template <typename Keep>
+__device__ int compact_links(const DecodeParams& p, const LatUtt& U, Shared& sh, int l0, int l1, float ac_mul, Keep keep) {
+  int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
+  int32_t* ltid = p.L.link_tid + U.link_base;
+  float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int out = l0;
+  for (int base = l0; base < l1; base += kLatThreads) {
+    const int l = base + tid;
+    int s = 0, d = 0, t = 0; float g = 0.f, a = 0.f;
+    bool k = false;
+    if (l < l1) {
+      s = lsrc[l]; d = ldst[l]; t = ltid[l]; g = lgr[l]; a = lac[l];
+      k = keep(s, d, g, a);
+    }
+    const unsigned long long bal = __ballot(k);
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) sh.redi[w] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < kLatWaves; ++q) {
+      const int c = sh.redi[q];
+      if (q < w) before += c;
+      total += c;
+    }
+    if (k) {
+      const int o = out + before + within;
+      lsrc[o] = s; ldst[o] = d; ltid[o] = t; lgr[o] = g; lac[o] = __fmul_rn(a, ac_mul);
+    }
+    out += total;
+    __syncthreads();
+  }
+  return out - l0;
+}
+
+__global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p) {
+  __shared__ Shared sh;
+  __shared__ int s_tok_end, s_link_end;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const LatUtt U = p.L.utt[n];
+  const int T = U.T;
+  uint32_t* stc = p.L.st_cost + (size_t)n * p.g.S;
+  int32_t* stt = p.L.st_tok + (size_t)n * p.g.S;
+  int32_t* ts = p.L.tok_state + U.tok_base;
+  float* tc = p.L.tok_cost + U.tok_base;
+  float* te = p.L.tok_extra + U.tok_base;
+  float* tf = p.L.tok_final + U.tok_base;
+  int32_t* ftok = p.L.frame_tok + U.frame_base;
+  int32_t* seg = p.L.seg_off + U.frame_base;
+  int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
+  int32_t* ltid = p.L.link_tid + U.link_base;
+  float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
+
+  if (tid == 0) {
+    sh.status = kLatOk; sh.n_new = 1; sh.n_link = 0;
+    s_tok_end = 0; s_link_end = 0;
+    ts[0] = p.g.start; tc[0] = INFINITY;
+    stc[p.g.start] = enc_cost(0.f);
+    stt[p.g.start] = 0;
+    ftok[0] = 0; seg[0] = 0;
+  }
+  __syncthreads();
+  close_frame(p, U, sh, stc, stt, 0, p.beam, &s_link_end, &s_tok_end, 0);   // InitDecoding: ProcessNonemitting(beam)
+  if (tid == 0) ftok[1] = s_tok_end;
+  __syncthreads();
+
+  for (int t = 0; t < T && sh.status == kLatOk; ++t) {
+    const int f0 = ftok[t], f1 = s_tok_end, nt = f1 - f0;
+    // ---- GetCutoff ----
+    float lmin = INFINITY;
+    for (int i = f0 + tid; i < f1; i += kLatThreads) lmin = fminf(lmin, tc[i]);
+    const float best = block_min(lmin, sh);
+    const float beam_cutoff = best + p.beam;
+    int c_lt = 0, c_le = 0;
+    for (int i = f0 + tid; i < f1; i += kLatThreads) { c_lt += tc[i] < beam_cutoff; c_le += tc[i] <= beam_cutoff; }
+    c_lt = block_sum_i(c_lt, sh);
+    c_le = block_sum_i(c_le, sh);
+    float cur_cutoff = beam_cutoff, adaptive = p.beam;
+    if (nt > p.max_active && c_lt > p.max_active) {
+      cur_cutoff = kth_smallest(tc + f0, nt, p.max_active, sh);
+      adaptive = (cur_cutoff - best) + p.beam_delta;
+    } else if (p.min_active > 0 && nt > p.min_active && c_le <= p.min_active) {
+      cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
+      adaptive = (cur_cutoff - best) + p.beam_delta;
+    }
+    // ---- acoustic scores of the frame ----
+    const float* row = p.loglikes + (int64_t)n * p.seq_stride + (int64_t)t * p.frame_stride;
+    for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
+    __syncthreads();
+    // ---- pass 1: best new cost ----
+    float nmin = INFINITY;
+    for (int i = f0 + tid; i < f1; i += kLatThreads) {
+      const float c = tc[i];
+      if (c <= cur_cutoff) {
+        const int s = ts[i];
+        for (int a = p.g.e_off[s]; a < p.g.e_off[s + 1]; ++a) {
+          const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[p.g.e_tid[a]]]);
+          nmin = fminf(nmin, __fadd_rn(__fadd_rn(c, ac), p.g.e_w[a]));
+        }
+      }
+    }
+    nmin = block_min(nmin, sh);
+    if (!(nmin < INFINITY)) { if (tid == 0) sh.status = kLatNoSurvivor; __syncthreads(); break; }
+    const float next_cutoff = nmin + adaptive;
+    // ---- pass 2: tokens and links of frame t+1 ----
+    const int l0 = s_link_end;
+    for (int i = f0 + tid; i < f1; i += kLatThreads) {
+      const float c = tc[i];
+      if (c <= cur_cutoff) {
+        const int s = ts[i];
+        for (int a = p.g.e_off[s]; a < p.g.e_off[s + 1]; ++a) {
+          const int tidl = p.g.e_tid[a];
+          const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl]]);
+          const float gw = p.g.e_w[a];
+          const float tot = __fadd_rn(__fadd_rn(c, ac), gw);
+          if (tot < next_cutoff) {
+            const int d = p.g.e_dst[a];
+            const uint32_t old = atomicMin(&stc[d], enc_cost(tot));
+            if (old == kEmpty) {
+              const int idx = atomicAdd(&sh.n_new, 1);
+              if (f1 + idx < U.tok_cap) {
+                ts[f1 + idx] = d;
+                tc[f1 + idx] = INFINITY;
+                __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } else {
+                sh.status = kLatTokenOverflow;
+              }
+            }
+            const int li = l0 + atomicAdd(&sh.n_link, 1);
+            if (li < U.link_cap) {
+              lsrc[li] = i; ldst[li] = d /* state for now */; ltid[li] = tidl; lgr[li] = gw; lac[li] = ac;
+            } else {
+              sh.status = kLatLinkOverflow;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (sh.status != kLatOk) break;
+    const int l1 = l0 + sh.n_link;
+    for (int l = l0 + tid; l < l1; l += kLatThreads) ldst[l] = f1 + ld_coherent(&stt[ldst[l]]);
+    __syncthreads();
+    if (tid == 0) { s_link_end = l1; seg[2 * t + 2] = l1; sh.n_link = 0; }
+    __syncthreads();
+    close_frame(p, U, sh, stc, stt, f1, next_cutoff, &s_link_end, &s_tok_end, 2 * t + 2);
+    if (tid == 0) ftok[t + 2] = s_tok_end;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (sh.status != kLatOk) {
+    if (tid == 0) { p.L.utt[n].status = sh.status; p.L.utt[n].n_tok = s_tok_end; p.L.utt[n].n_link = s_link_end; }
+    return;
+  }
+
+  // ---- final costs (ComputeFinalCosts) ----
+  const int fT0 = ftok[T], fT1 = s_tok_end;
+  int anyf = 0;
+  for (int i = fT0 + tid; i < fT1; i += kLatThreads) anyf |= (p.g.final_cost[ts[i]] < INFINITY);
+  anyf = __syncthreads_or(anyf);
+  float bmin = INFINITY;
+  for (int i = fT0 + tid; i < fT1; i += kLatThreads) {
+    const float fc = anyf ? p.g.final_cost[ts[i]] : 0.f;
+    tf[i] = fc;
+    if (fc < INFINITY) bmin = fminf(bmin, tc[i] + fc);
+  }
+  const float best_final = block_min(bmin, sh);
+  for (int i = fT0 + tid; i < fT1; i += kLatThreads) {
+    const float fc = tf[i];
+    te[i] = fc < INFINITY ? (tc[i] + fc) - best_final : INFINITY;
+  }
+  __syncthreads();
+
+  // ---- lattice-beam pruning, last frame first (PruneForwardLinksFinal / PruneForwardLinks) ----
+  uint32_t* teu = reinterpret_cast<uint32_t*>(te);   // extra costs are >= 0: their bit patterns order like the floats
+  const float lbeam = p.lattice_beam;
+  const float inv_scale = 1.0f / p.ac_scale;
+  int32_t* kept = p.L.seg_kept + U.frame_base;
+  int32_t* tl = p.L.tok_level + U.tok_base;
+  int32_t* maxlev = p.L.frame_maxlev + U.frame_base;
+  for (int t = T; t >= 0; --t) {
+    // epsilon links inside frame t, to the fixed point
+    const int e0 = seg[2 * t], e1 = seg[2 * t + 1];
+    for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
+      int changed = 0;
+      for (int l = e0 + tid; l < e1; l += kLatThreads) {
+        const int s = lsrc[l], d = ldst[l];
+        const float ed = __uint_as_float(ld_coherent(&teu[d]));
+        if (ed < INFINITY) {
+          float le = ed + ((tc[s] + lgr[l]) - tc[d]);
+          if (le <= lbeam) {
+            le = fmaxf(le, 0.f);
+            const uint32_t k = __float_as_uint(le);
+            if (k < atomicMin(&teu[s], k)) changed = 1;
+          }
+        }
+      }
+      if (!__syncthreads_or(changed)) break;
+    }
+    const int ke = compact_links(p, U, sh, e0, e1, 1.0f, [&](int s, int d, float g, float a) {
+      const float ed = __uint_as_float(ld_coherent(&teu[d]));
+      return ed < INFINITY && (ed + ((tc[s] + g) - tc[d])) <= lbeam;
+    });
+    if (tid == 0) kept[2 * t] = ke;
+    // epsilon DAG depth of the frame's tokens (order of the forward-backward inside the frame)
+    for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
+      int changed = 0;
+      for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) {
+        const int lv = ld_coherent(&tl[lsrc[l]]) + 1;
+        if (lv > atomicMax(&tl[ldst[l]], lv)) changed = 1;
+      }
+      if (!__syncthreads_or(changed)) break;
+    }
+    float lm = 0.f;
+    for (int i = ftok[t] + tid; i < ftok[t + 1]; i += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[i]));
+    const int lev_max = (int)(-block_min(-lm, sh));
+    if (tid == 0) maxlev[t] = lev_max;
+    // emitting links t-1 -> t
+    if (t > 0) {
+      const int m0 = seg[2 * t - 1], m1 = seg[2 * t];
+      for (int l = m0 + tid; l < m1; l += kLatThreads) {
+        const int s = lsrc[l], d = ldst[l];
+        const float ed = __uint_as_float(ld_coherent(&teu[d]));
+        if (ed < INFINITY) {
+          float le = ed + (__fadd_rn(__fadd_rn(tc[s], lac[l]), lgr[l]) - tc[d]);
+          if (le <= lbeam) atomicMin(&teu[s], __float_as_uint(fmaxf(le, 0.f)));
+        }
+      }
+      __syncthreads();
+      const int km = compact_links(p, U, sh, m0, m1, inv_scale, [&](int s, int d, float g, float a) {
+        const float ed = __uint_as_float(ld_coherent(&teu[d]));
+        return ed < INFINITY && (ed + (__fadd_rn(__fadd_rn(tc[s], a), g) - tc[d])) <= lbeam;
+      });
+      if (tid == 0) kept[2 * t - 1] = km;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    LatUtt* o = p.L.utt + n;
+    o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
+  }
+}
+
+}  // namespace pk2
+
+using namespace pk2;
+
+extern "C" int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, int64_t seq_stride,
+                                  int64_t frame_stride, int32_t num_pdfs, const int32_t* tid2pdf, int32_t num_tids,
+                                  void* workspace, void* stream_) {
+  PK2_REQUIRE(b && loglikes && tid2pdf && workspace, "lattice decode: null pointer");
+  PK2_REQUIRE(num_pdfs > 0 && num_pdfs <= kMaxPdfsLds, "lattice decode: num_pdfs %d exceeds the LDS row limit %d",
+              num_pdfs, kMaxPdfsLds);
+  PK2_REQUIRE(num_tids >= b->graph->max_ilabel, "lattice decode: HCLG uses transition-id %d but the model has %d",
+              b->graph->max_ilabel, num_tids);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int rc = decode_graph_upload(const_cast<pk2_decode_graph*>(b->graph));
+  if (rc) return rc;
+  LatPtrs L;
+  lattice_carve(b, workspace, &L);
+  PK2_HIP(hipMemcpyAsync(L.utt, b->utt.data(), sizeof(LatUtt) * b->N, hipMemcpyHostToDevice, stream));
+  PK2_HIP(hipMemsetAsync(L.st_cost, 0xFF, sizeof(uint32_t) * (size_t)b->N * b->graph->S, stream));
+  PK2_HIP(hipMemsetAsync(L.st_tok, 0xFF, sizeof(int32_t) * (size_t)b->N * b->graph->S, stream));
+  PK2_HIP(hipMemsetAsync(L.seg_kept, 0, sizeof(int32_t) * (size_t)b->frame_total, stream));
+  DecodeParams p;
+  p.g = b->graph->dev; p.L = L;
+  p.loglikes = loglikes; p.seq_stride = seq_stride; p.frame_stride = frame_stride; p.P = num_pdfs;
+  p.tid2pdf = tid2pdf; p.num_tids = num_tids;
+  p.beam = b->opts.beam; p.lattice_beam = b->opts.lattice_beam; p.beam_delta = b->opts.beam_delta;
+  p.ac_scale = b->opts.acoustic_scale; p.max_active = b->opts.max_active; p.min_active = b->opts.min_active;
+  hipLaunchKernelGGL(lat_decode_kernel, dim3(b->N), dim3(kLatThreads), 0, stream, p);
+  PK2_LAUNCH_CHECK();
+  b->decoded = true;
+  return PK2_OK;
+}

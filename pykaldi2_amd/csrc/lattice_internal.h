@@ -1,0 +1,92 @@
+// Internal declarations of the lattice path (MMIFunction / sMBRFunction):
+// lattice_graph.hip (decoding graph, batch layout, export), lattice_decode.hip (token passing + lattice
+// pruning), lattice_fb.hip (lattice forward-backward: MMI, sMBR, MPFE).
+//
+// MI355X design: the reference decodes every utterance on the CPU with Kaldi's LatticeFasterDecoder, copies
+// the lattice posteriors to the GPU and loops over utterances in Python (reference ops/ops.py:55-66,
+// bin/train_se.py:237-249).  Here the whole minibatch is decoded on the device, ONE WORKGROUP PER UTTERANCE
+// inside one launch: utterances are independent, so the frame-synchronous recursion needs workgroup barriers
+// only, never a grid-wide one, and the lattices never leave HBM.  Per utterance the workspace holds
+//   * a dense per-state table {best cost, token index} for the frame being built (reset sparsely),
+//   * frame-layered token arrays and link arrays (pools sized from the utterance length: 288 GB of HBM make
+//     Kaldi's periodic pruning unnecessary; one backward pruning pass runs after the last frame),
+//   * the forward/backward quantities of the lattice forward-backward in float64 (as Kaldi).
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace pk2 {
+
+struct DevDecodeGraph {
+  const int32_t* e_off = nullptr;   // [S+1] emitting arcs (ilabel > 0) in CSR by source state
+  const int32_t* e_dst = nullptr;
+  const int32_t* e_tid = nullptr;
+  const float* e_w = nullptr;
+  const int32_t* n_off = nullptr;   // [S+1] non-emitting (epsilon-input) arcs
+  const int32_t* n_dst = nullptr;
+  const float* n_w = nullptr;
+  const float* final_cost = nullptr;  // [S], +inf = not final
+  int32_t S = 0, start = 0;
+};
+
+// Per-utterance record (device copy in the workspace; the result fields are written by the decoder).
+struct LatUtt {
+  int64_t tok_base, link_base, frame_base;   // element offsets of this utterance in the pools / frame tables
+  int32_t T, tok_cap, link_cap;
+  int32_t n_tok, n_link, status, any_final;
+  float best_cost;
+};
+
+enum LatStatus : int32_t {
+  kLatOk = 0,
+  kLatTokenOverflow = 1,
+  kLatLinkOverflow = 2,
+  kLatNoSurvivor = 3,       // every token was pruned at some frame
+  kLatEpsilonLoop = 4,      // epsilon closure did not converge (epsilon cycle with non-positive cost?)
+  kLatNotDecoded = 5,
+};
+
+// Arrays of the workspace (device pointers).
+struct LatPtrs {
+  LatUtt* utt;
+  uint32_t* st_cost;   // [N][S] order-preserving encoding of the float cost, 0xFFFFFFFF = no token
+  int32_t* st_tok;     // [N][S] frame-local token index
+  int32_t* tok_state; float* tok_cost; float* tok_extra; float* tok_final; int32_t* tok_level;
+  double* alpha; double* beta; double* acc_f; double* acc_b;
+  int32_t* link_src; int32_t* link_dst; int32_t* link_tid; float* link_graph; float* link_ac;
+  int32_t* frame_tok;    // per utterance [T+2]: first token of each frame (utterance-local), [T+1] = end
+  int32_t* seg_off;      // per utterance [2(T+1)+1]: link segments: 2t = epsilon links inside frame t, 2t+1 = t -> t+1
+  int32_t* seg_kept;     // per utterance [2(T+1)]: links of the segment that survive lattice pruning (compacted to its front)
+  int32_t* frame_maxlev; // per utterance [T+1]: depth of the epsilon DAG inside the frame
+  double* ref_post;      // per utterance [T]
+};
+
+}  // namespace pk2
+
+struct pk2_decode_graph {
+  int32_t S = 0, start = 0, max_ilabel = 0;
+  int64_t A = 0;
+  std::vector<int32_t> e_off, e_dst, e_tid, n_off, n_dst;
+  std::vector<float> e_w, n_w, final_cost;
+  bool uploaded = false;
+  int device = -1;
+  pk2::DevDecodeGraph dev;
+  std::vector<void*> allocs;
+};
+
+struct pk2_lattice_batch {
+  const pk2_decode_graph* graph = nullptr;
+  int32_t N = 0, Tmax = 0;
+  pk2_decoder_opts opts;
+  std::vector<pk2::LatUtt> utt;
+  int64_t tok_total = 0, link_total = 0, frame_total = 0;
+  size_t bytes = 0;
+  bool decoded = false;
+};
+
+namespace pk2 {
+int decode_graph_upload(pk2_decode_graph* g);
+// Carves the workspace (base may be null: returns the size only).
+size_t lattice_carve(const pk2_lattice_batch* b, void* base, LatPtrs* out);
+}  // namespace pk2

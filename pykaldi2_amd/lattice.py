@@ -1,0 +1,298 @@
+"""Host mirror of the PyKaldi objects behind the reference's lattice-based criteria (reference
+ops/ops.py:41-75,119-156; bin/train_se.py:145-184):
+
+  kaldi.hmm.TransitionModel                         -> TransitionModel (transition-id -> pdf / phone tables)
+  kaldi.decoder.LatticeFasterDecoderOptions         -> LatticeFasterDecoderOptions
+  kaldi.asr.MappedLatticeFasterRecognizer           -> MappedLatticeFasterRecognizer (.decode / .decode_batch)
+  kaldi.lat.functions.lattice_forward_backward_mmi  -> LatticeBatch.mmi
+  ... lattice_forward_backward_mpe_variants         -> LatticeBatch.mpe
+
+Everything runs on the device through the C ABI (pk2_lattice_*): one workgroup per utterance decodes and
+prunes the lattice, the lattice forward-backward reads it in place.  Nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class LatticeFasterDecoderOptions:
+    """Kaldi's LatticeFasterDecoderConfig fields the reference sets (bin/train_se.py:173-178) and the other
+    pruning knobs at their Kaldi defaults."""
+
+    def __init__(self, beam=16.0, lattice_beam=10.0, max_active=2 ** 31 - 1, min_active=200, beam_delta=0.5):
+        self.beam, self.lattice_beam = beam, lattice_beam
+        self.max_active, self.min_active, self.beam_delta = max_active, min_active, beam_delta
+        self.determinize_lattice = False   # raw state-level lattices, as the reference asks for
+        # pool sizing of the device lattices: tokens / links per frame on average (None = from max_active)
+        self.tokens_per_frame = None
+        self.links_per_frame = None
+
+
+class TransitionModel:
+    """transition-id -> pdf-id / phone tables (all a lattice criterion needs from Kaldi's TransitionModel).
+    transition-ids are 1-based; index 0 of both tables is unused."""
+
+    def __init__(self, tid2pdf, tid2phone):
+        self.tid2pdf = np.ascontiguousarray(tid2pdf, dtype=np.int32)
+        self.tid2phone = np.ascontiguousarray(tid2phone, dtype=np.int32)
+        assert self.tid2pdf.shape == self.tid2phone.shape and self.tid2pdf.ndim == 1
+        self._dev = {}
+
+    @classmethod
+    def from_arrays(cls, d):
+        return cls(d["tid2pdf"], d["tid2phone"])
+
+    @classmethod
+    def read(cls, path):
+        """Kaldi text-format transition model (`copy-transition-model --binary=false`), [upstream knowledge
+        of the format: <TransitionModel> <Topology> ... </Topology> <Triples>|<Tuples> n ... ].  Transition
+        ids enumerate, for every tuple in file order, the transitions of its HMM state in topology order."""
+        with open(path, "rb") as f:
+            head = f.read(2)
+            if head == b"\0B":
+                raise ValueError("%s: binary transition models are not supported; convert with "
+                                 "copy-transition-model --binary=false" % path)
+            toks = (head + f.read()).decode().split()
+        pos = toks.index("<Topology>")
+        phone_entry, entries = {}, []
+        i = pos + 1
+        while toks[i] != "</Topology>":
+            if toks[i] == "<TopologyEntry>":
+                i += 1
+                assert toks[i] == "<ForPhones>"
+                i += 1
+                phones = []
+                while toks[i] != "</ForPhones>":
+                    phones.append(int(toks[i])); i += 1
+                i += 1
+                states = []
+                while toks[i] != "</TopologyEntry>":
+                    assert toks[i] == "<State>"
+                    i += 2   # <State> index
+                    dsts = []
+                    if toks[i] in ("<PdfClass>",):
+                        i += 2
+                    elif toks[i] == "<ForwardPdfClass>":
+                        i += 4   # <ForwardPdfClass> a <SelfLoopPdfClass> b
+                    while toks[i] == "<Transition>":
+                        dsts.append(int(toks[i + 1])); i += 3
+                    assert toks[i] == "</State>"
+                    i += 1
+                    states.append(dsts)
+                i += 1
+                for ph in phones:
+                    phone_entry[ph] = len(entries)
+                entries.append(states)
+            else:
+                i += 1
+        i += 1
+        tag = toks[i]
+        assert tag in ("<Triples>", "<Tuples>"), tag
+        n = int(toks[i + 1])
+        i += 2
+        width = 3 if tag == "<Triples>" else 4
+        tid2pdf, tid2phone = [-1], [0]
+        for _ in range(n):
+            vals = [int(x) for x in toks[i:i + width]]
+            i += width
+            phone, hmm_state = vals[0], vals[1]
+            fwd_pdf, loop_pdf = vals[2], vals[-1]
+            for dst_state in entries[phone_entry[phone]][hmm_state]:
+                # in a <Tuples> model the self-loop (the transition back to hmm_state) carries its own pdf
+                tid2pdf.append(loop_pdf if dst_state == hmm_state else fwd_pdf)
+                tid2phone.append(phone)
+        return cls(tid2pdf, tid2phone)
+
+    def num_transition_ids(self):
+        return int(self.tid2pdf.shape[0] - 1)
+
+    def num_pdfs(self):
+        return int(self.tid2pdf.max() + 1)
+
+    def transition_id_to_pdf(self, tid):
+        return int(self.tid2pdf[tid])
+
+    def transition_id_to_phone(self, tid):
+        return int(self.tid2phone[tid])
+
+    def device_tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.tid2pdf).to(device), torch.from_numpy(self.tid2phone).to(device))
+        return self._dev[key]
+
+    def silence_mask(self, silence_phones, device):
+        m = np.zeros(int(self.tid2phone.max()) + 2, np.uint8)
+        for ph in silence_phones:
+            if 0 <= int(ph) < m.shape[0]:
+                m[int(ph)] = 1
+        return torch.from_numpy(m).to(device)
+
+
+class DecodeGraph:
+    """HCLG (kaldi.fstext.StdVectorFst read from HCLG.fst, reference bin/train_se.py:145,180)."""
+
+    def __init__(self, graph):
+        L = _lib.lib()
+        h = C.c_void_p()
+        if isinstance(graph, (str, bytes)):
+            _lib.check(L.pk2_decode_graph_from_openfst(graph.encode() if isinstance(graph, str) else graph, C.byref(h)))
+        else:
+            src = np.ascontiguousarray(graph["src"], np.int32); dst = np.ascontiguousarray(graph["dst"], np.int32)
+            il = np.ascontiguousarray(graph["ilabel"], np.int32); w = np.ascontiguousarray(graph["weight"], np.float32)
+            fin = np.ascontiguousarray(graph["final"], np.float32)
+            assert fin.shape[0] == int(graph["num_states"])
+            _lib.check(L.pk2_decode_graph_create(int(graph["num_states"]), int(graph["start"]), src.shape[0],
+                                                 src.ctypes.data, dst.ctypes.data, il.ctypes.data, w.ctypes.data,
+                                                 fin.ctypes.data, C.byref(h)))
+        self._h = h
+        ns, na, mi = C.c_int32(), C.c_int64(), C.c_int32()
+        _lib.check(L.pk2_decode_graph_info(h, C.byref(ns), C.byref(na), C.byref(mi)))
+        self.num_states, self.num_arcs, self.max_ilabel = ns.value, na.value, mi.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().pk2_decode_graph_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class LatticeBatch:
+    """The lattices of one minibatch, resident in a device workspace."""
+
+    def __init__(self, handle, workspace, lengths, device, trans_model, num_pdfs, graph=None):
+        self._graph = graph   # the C batch object points into the graph handle: keep it alive
+        self._h, self.workspace, self.lengths = handle, workspace, list(lengths)
+        self.device, self.trans_model, self.num_pdfs = device, trans_model, num_pdfs
+        self.status = self.num_tokens = self.num_links = self.best_cost = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().pk2_lattice_batch_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _ref(self, trans_ids):
+        N, Tmax = len(self.lengths), max(self.lengths)
+        ref = np.zeros((N, Tmax), np.int32)
+        for n, ids in enumerate(trans_ids):
+            ids = np.asarray(ids, np.int64).reshape(-1)
+            assert ids.shape[0] >= self.lengths[n], "alignment of utterance %d is shorter than its %d frames" % (n, self.lengths[n])
+            assert ids.min() >= 1 and ids.max() <= self.trans_model.num_transition_ids()
+            ref[n, :self.lengths[n]] = ids[:self.lengths[n]]
+        return torch.from_numpy(ref).to(self.device)
+
+    def mmi(self, trans_ids, lm_scale=1.0, acoustic_scale=0.2, drop_frames=True):
+        """-> (lat_like f64 [N], post f32 [N, Tmax, P] = numerator - denominator posteriors)."""
+        N, Tmax = len(self.lengths), max(self.lengths)
+        ref = self._ref(trans_ids)
+        post = torch.zeros(N, Tmax, self.num_pdfs, device=self.device)
+        out = torch.empty(N, dtype=torch.float64, device=self.device)
+        t2p, _ = self.trans_model.device_tables(self.device)
+        _lib.check(_lib.lib().pk2_lattice_mmi(self._h, _lib.ptr(self.workspace), _lib.ptr(ref), ref.stride(0), _lib.ptr(t2p),
+                                              float(lm_scale), float(acoustic_scale), int(bool(drop_frames)), _lib.ptr(post),
+                                              post.stride(0), post.stride(1), _lib.ptr(out), _lib.stream_ptr(self.device)))
+        return out, post
+
+    def mpe(self, trans_ids, criterion, silence_phones, one_silence_class=True, lm_scale=1.0, acoustic_scale=1.0):
+        """-> (expected frame accuracy f64 [N], post f32 [N, Tmax, P])."""
+        assert criterion in ("smbr", "mpfe")
+        N, Tmax = len(self.lengths), max(self.lengths)
+        ref = self._ref(trans_ids)
+        post = torch.zeros(N, Tmax, self.num_pdfs, device=self.device)
+        out = torch.empty(N, dtype=torch.float64, device=self.device)
+        t2p, t2ph = self.trans_model.device_tables(self.device)
+        sil = self.trans_model.silence_mask(silence_phones, self.device)
+        _lib.check(_lib.lib().pk2_lattice_mpe(self._h, _lib.ptr(self.workspace), _lib.ptr(ref), ref.stride(0), _lib.ptr(t2p),
+                                              _lib.ptr(t2ph), _lib.ptr(sil), 1 if criterion == "mpfe" else 0,
+                                              int(bool(one_silence_class)), float(lm_scale), float(acoustic_scale),
+                                              _lib.ptr(post), post.stride(0), post.stride(1), _lib.ptr(out),
+                                              _lib.stream_ptr(self.device)))
+        return out, post
+
+    def export(self, n):
+        """Pruned lattice of utterance n as host arrays (tests / tooling)."""
+        L = _lib.lib()
+        nt, nl = C.c_int32(), C.c_int32()
+        sp = _lib.stream_ptr(self.device)
+        _lib.check(L.pk2_lattice_export(self._h, _lib.ptr(self.workspace), n, C.byref(nt), C.byref(nl), None, None, None,
+                                        None, None, None, None, None, None, sp))
+        a = dict(tok_frame=np.empty(nt.value, np.int32), tok_state=np.empty(nt.value, np.int32),
+                 tok_cost=np.empty(nt.value, np.float32), tok_final=np.empty(nt.value, np.float32),
+                 link_src=np.empty(nl.value, np.int32), link_dst=np.empty(nl.value, np.int32),
+                 link_tid=np.empty(nl.value, np.int32), link_graph=np.empty(nl.value, np.float32),
+                 link_ac=np.empty(nl.value, np.float32))
+        _lib.check(L.pk2_lattice_export(self._h, _lib.ptr(self.workspace), n, C.byref(nt), C.byref(nl),
+                                        a["tok_frame"].ctypes.data, a["tok_state"].ctypes.data, a["tok_cost"].ctypes.data,
+                                        a["tok_final"].ctypes.data, a["link_src"].ctypes.data, a["link_dst"].ctypes.data,
+                                        a["link_tid"].ctypes.data, a["link_graph"].ctypes.data, a["link_ac"].ctypes.data, sp))
+        return a
+
+
+class MappedLatticeFasterRecognizer:
+    """On-the-fly lattice generator with the reference's construction signature
+    (bin/train_se.py:180-183: `MappedLatticeFasterRecognizer.from_files(trans_model, HCLG, words_txt,
+    acoustic_scale=..., decoder_opts=...)`)."""
+
+    def __init__(self, trans_model, graph, acoustic_scale=0.1, decoder_opts=None):
+        self.trans_model = trans_model
+        self.graph = graph if isinstance(graph, DecodeGraph) else DecodeGraph(graph)
+        self.acoustic_scale = float(acoustic_scale)
+        self.decoder_opts = decoder_opts or LatticeFasterDecoderOptions()
+        assert self.graph.max_ilabel <= trans_model.num_transition_ids(), "HCLG uses transition-ids the model lacks"
+
+    @classmethod
+    def from_files(cls, trans_model_path, graph_path, words_txt=None, acoustic_scale=0.1, decoder_opts=None):
+        return cls(TransitionModel.read(trans_model_path), DecodeGraph(graph_path), acoustic_scale, decoder_opts)
+
+    def _opts(self, grow):
+        o = self.decoder_opts
+        max_active = int(min(o.max_active, 2 ** 31 - 1))
+        tpf = o.tokens_per_frame or min(max_active, 20000)
+        lpf = o.links_per_frame or 3 * tpf
+        return _lib.DecoderOpts(float(o.beam), float(o.lattice_beam), float(o.beam_delta), self.acoustic_scale,
+                                max_active, int(o.min_active), int(min(tpf * grow, 2 ** 30)), int(min(lpf * grow, 2 ** 30)))
+
+    def decode_batch(self, loglikes, lengths):
+        """loglikes: CUDA f32 [N, Tmax, P] (unit pdf stride); lengths: frames per utterance.
+        Returns a LatticeBatch.  Lattice pools that turn out too small are quadrupled and the decode repeated."""
+        _lib.require_gpu()
+        assert loglikes.dim() == 3 and loglikes.stride(2) == 1 and loglikes.dtype == torch.float32
+        L = _lib.lib()
+        dev = loglikes.device
+        N, P = loglikes.shape[0], loglikes.shape[2]
+        lens = np.ascontiguousarray(lengths, np.int32)
+        assert lens.shape[0] == N and lens.max() <= loglikes.shape[1]
+        t2p, _ = self.trans_model.device_tables(dev)
+        grow = 1
+        for _ in range(8):
+            h = C.c_void_p()
+            opts = self._opts(grow)
+            _lib.check(L.pk2_lattice_batch_create(self.graph._h, lens.ctypes.data, N, C.byref(opts), C.byref(h)))
+            ws = torch.empty(L.pk2_lattice_batch_bytes(h), dtype=torch.uint8, device=dev)
+            batch = LatticeBatch(h, ws, lens.tolist(), dev, self.trans_model, P, self.graph)
+            _lib.check(L.pk2_lattice_decode(h, _lib.ptr(loglikes), loglikes.stride(0), loglikes.stride(1), P, _lib.ptr(t2p),
+                                            self.trans_model.num_transition_ids(), _lib.ptr(ws), _lib.stream_ptr(dev)))
+            status = np.zeros(N, np.int32); ntok = np.zeros(N, np.int32); nlink = np.zeros(N, np.int32)
+            best = np.zeros(N, np.float32)
+            rc = L.pk2_lattice_summary(h, _lib.ptr(ws), status.ctypes.data, ntok.ctypes.data, nlink.ctypes.data,
+                                       best.ctypes.data, _lib.stream_ptr(dev))
+            batch.status, batch.num_tokens, batch.num_links, batch.best_cost = status, ntok, nlink, best
+            if rc == 0:
+                return batch
+            if not np.all((status == 0) | (status == 1) | (status == 2)):
+                _lib.check(rc)
+            del batch, ws
+            grow *= 4
+        _lib.check(rc)
+
+    def decode(self, loglikes):
+        """One utterance [T, P] -> LatticeBatch of one (the reference's per-utterance call, ops/ops.py:55)."""
+        return self.decode_batch(loglikes.unsqueeze(0), [loglikes.shape[0]])

@@ -11,9 +11,9 @@ minus its derivative regardless of ``grad_out`` (ops/ops.py:276-280), so
 the reference, nothing is copied to the host and the saved tensor is not
 modified in place.
 
-MMIFunction / sMBRFunction (lattice-based, ops/ops.py:41-75,119-156) need an
-on-the-fly WFST decoder; they are scoped for a later round (SURVEY.md 8(f)
-rank 3) and raise NotImplementedError rather than silently doing something else.
+MMIFunction / sMBRFunction (lattice-based, ops/ops.py:41-75,119-156) decode on the device
+(lattice.MappedLatticeFasterRecognizer) and run the lattice forward-backward there; LatticeBatchFunction
+is the whole-minibatch form.
 """
 import numpy as np
 import torch
@@ -110,16 +110,61 @@ class CrossEntropyLoss(torch.nn.Module):
         return _CrossEntropyFunction.apply(logits, targets, self.ignore_index, self.reduction)
 
 
-def _lattice_op(name):
-    class _Unavailable(Function):
-        @staticmethod
-        def forward(ctx, *args):
-            raise NotImplementedError(
-                "%s needs on-the-fly lattice generation (a WFST beam-search decoder over HCLG); it is "
-                "scheduled after the LF-MMI path (SURVEY.md 8(f) rank 3)" % name)
-    _Unavailable.__name__ = name
-    return _Unavailable
+class MMIFunction(Function):
+    """Lattice MMI for one utterance with the reference's signature (ops/ops.py:41-75):
+    ``MMIFunction.apply(loglikes[T, P], asr_decoder, trans_model, trans_ids)``.  Forward returns the lattice
+    log-likelihood (as the reference does); backward returns -(numerator - denominator posteriors)
+    regardless of grad_out.  asr_decoder = lattice.MappedLatticeFasterRecognizer."""
+
+    @staticmethod
+    def forward(ctx, loglikes, asr_decoder, trans_model, trans_ids):
+        lat = asr_decoder.decode(loglikes.detach().contiguous())
+        like, post = lat.mmi([trans_ids], 1.0, 0.2, True)     # lattice_scale(1.0, 0.2), drop_frames, cancel
+        ctx.save_for_backward(post[0])
+        return like[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        post, = ctx.saved_tensors
+        return -post, None, None, None
 
 
-MMIFunction = _lattice_op("MMIFunction")
-sMBRFunction = _lattice_op("sMBRFunction")
+class sMBRFunction(Function):
+    """sMBR / MPFE for one utterance (ops/ops.py:119-156):
+    ``sMBRFunction.apply(loglikes, asr_decoder, trans_model, trans_ids, criterion, silence_phones)``.
+    Forward returns the expected frame accuracy; backward its negated derivative."""
+
+    @staticmethod
+    def forward(ctx, loglikes, asr_decoder, trans_model, trans_ids, criterion, silence_phones):
+        lat = asr_decoder.decode(loglikes.detach().contiguous())
+        score, post = lat.mpe([trans_ids], criterion, silence_phones, True)
+        ctx.save_for_backward(post[0])
+        return score[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        post, = ctx.saved_tensors
+        return -post, None, None, None, None, None
+
+
+class LatticeBatchFunction(Function):
+    """All utterances of a minibatch in one decode + one forward-backward launch: replaces the reference's
+    per-utterance Python loop (bin/train_se.py:237-249).  prediction: [N, Tmax, P] log-likelihoods (log prior
+    already subtracted); returns the summed criterion."""
+
+    @staticmethod
+    def forward(ctx, prediction, lengths, asr_decoder, trans_model, trans_ids, criterion, silence_phones):
+        lat = asr_decoder.decode_batch(prediction.detach().contiguous(), lengths)
+        if criterion == "mmi":
+            val, post = lat.mmi(trans_ids, 1.0, 0.2, True)
+        else:
+            val, post = lat.mpe(trans_ids, criterion, silence_phones, True)
+        ctx.save_for_backward(post)
+        ctx.per_sequence = val
+        ctx.lattice = lat
+        return val.sum().to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        post, = ctx.saved_tensors
+        return -post, None, None, None, None, None, None

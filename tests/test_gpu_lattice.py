@@ -1,0 +1,204 @@
+"""GPU parity tests of the lattice path (row a10: MMIFunction / sMBRFunction) through the C ABI:
+device decoder + lattice pruning vs oracle/lattice_ref.py::decode (token costs and link sets bit-exact),
+lattice forward-backward (MMI, sMBR, MPFE) vs the oracle's float64 restatement of Kaldi."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lattice_ref as lr
+from pykaldi2_amd import lattice, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(num_words, num_pdfs, T, seed, max_phones=3, scale=2.0):
+    rng = np.random.default_rng(seed)
+    g = synth.decoding_graph_arcs(num_words, num_pdfs, seed=seed, max_phones=max_phones)
+    tm = synth.transition_model_arrays(num_pdfs)
+    ll = (scale * rng.standard_normal((T, num_pdfs))).astype(np.float32)
+    return g, tm, ll, rng
+
+
+def _ref_graph(g):
+    return lr.DecodeGraphRef(g["num_states"], g["start"], g["src"], g["dst"], g["ilabel"], g["weight"], g["final"])
+
+
+def _recognizer(g, tm, beam, lattice_beam, ac, max_active=2 ** 31 - 1, min_active=200):
+    o = lattice.LatticeFasterDecoderOptions(beam=beam, lattice_beam=lattice_beam, max_active=max_active, min_active=min_active)
+    return lattice.MappedLatticeFasterRecognizer(lattice.TransitionModel.from_arrays(tm), g, ac, o)
+
+
+def _canon(a):
+    toks = sorted(zip(a["tok_frame"].tolist(), a["tok_state"].tolist(), a["tok_cost"].tolist(), a["tok_final"].tolist()))
+    fr, st = a["tok_frame"], a["tok_state"]
+    links = sorted((int(fr[s]), int(st[s]), int(st[d]), int(t), float(g), float(c))
+                   for s, d, t, g, c in zip(a["link_src"], a["link_dst"], a["link_tid"], a["link_graph"], a["link_ac"]))
+    return toks, links
+
+
+CASES = [
+    # words pdfs T seed beam lat_beam ac max_active min_active
+    (6, 12, 8, 0, 30.0, 3.0, 1.0, 2 ** 31 - 1, 200),
+    (40, 60, 40, 1, 8.0, 4.0, 0.5, 2 ** 31 - 1, 0),
+    (200, 150, 60, 2, 13.0, 7.0, 0.1, 300, 200),      # max_active binds (flat scores at acoustic scale 0.1)
+    (60, 90, 30, 3, 4.0, 2.0, 1.0, 10000, 40),        # narrow beams
+    (300, 300, 120, 4, 10.0, 5.0, 0.3, 700, 200),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_decoder_matches_oracle(case):
+    nw, P, T, seed, beam, lb, ac, maxa, mina = case
+    g, tm, ll, _ = _setup(nw, P, T, seed)
+    want = lr.decode(_ref_graph(g), ll, tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac))
+    rec = _recognizer(g, tm, beam, lb, ac, maxa, mina)
+    lat = rec.decode(torch.from_numpy(ll).cuda())
+    assert lat.status[0] == 0
+    assert lat.best_cost[0] == np.float32(want.best_cost)
+    got_t, got_l = _canon(lat.export(0))
+    want_t, want_l = _canon(want.arrays())
+    assert len(got_t) == len(want_t) and len(got_l) == len(want_l), (len(got_t), len(want_t), len(got_l), len(want_l))
+    assert got_t == want_t          # bit-exact token costs
+    assert got_l == want_l          # identical link set, bit-exact graph / acoustic costs
+
+
+def _ali_near_lattice(rng, lat_ref, P):
+    ali = synth.tid_alignment(rng, lat_ref.T, P)
+    A = lat_ref.arrays()
+    for l in range(A["link_src"].shape[0]):
+        if A["link_tid"][l] != 0 and rng.random() < 0.05:
+            ali[A["tok_frame"][A["link_src"][l]]] = A["link_tid"][l]
+    return ali
+
+
+@pytest.mark.parametrize("case", CASES[:3])
+def test_mmi_matches_oracle(case):
+    nw, P, T, seed, beam, lb, ac, maxa, mina = case
+    g, tm, ll, rng = _setup(nw, P, T, seed)
+    want = lr.decode(_ref_graph(g), ll, tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac))
+    ali = _ali_near_lattice(rng, want, P)
+    rec = _recognizer(g, tm, beam, lb, ac, maxa, mina)
+    lat = rec.decode(torch.from_numpy(ll).cuda())
+    for drop in (True, False):
+        like, post = lat.mmi([ali], 1.0, 0.2, drop)
+        wl, wp = lr.lattice_mmi(want, ali, tm["tid2pdf"], P, 1.0, 0.2, drop)
+        assert abs(like.item() - wl) < 1e-9 * max(1.0, abs(wl))
+        assert np.abs(post[0].cpu().numpy() - wp).max() < 2e-6
+
+
+@pytest.mark.parametrize("criterion", ["smbr", "mpfe"])
+def test_mpe_matches_oracle(criterion):
+    nw, P, T, seed, beam, lb, ac, maxa, mina = CASES[1]
+    g, tm, ll, rng = _setup(nw, P, T, seed)
+    want = lr.decode(_ref_graph(g), ll, tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac))
+    ali = _ali_near_lattice(rng, want, P)
+    rec = _recognizer(g, tm, beam, lb, ac, maxa, mina)
+    lat = rec.decode(torch.from_numpy(ll).cuda())
+    for osc in (True, False):
+        score, post = lat.mpe([ali], criterion, tm["silence_phones"], osc)
+        ws, wp = lr.lattice_mpe(want, ali, tm["tid2pdf"], tm["tid2phone"], tm["silence_phones"], P, criterion, osc)
+        assert abs(score.item() - ws) < 1e-9 * max(1.0, abs(ws))
+        assert np.abs(post[0].cpu().numpy() - wp).max() < 2e-6 * max(1.0, np.abs(wp).max())
+
+
+def test_ragged_batch_and_ops():
+    P, beam, lb, ac = 60, 9.0, 4.0, 0.5
+    g, tm, _, rng = _setup(50, P, 1, 7)
+    lens = [23, 40, 11]
+    lls = [(2.0 * rng.standard_normal((T, P))).astype(np.float32) for T in lens]
+    x = torch.zeros(3, max(lens), P)
+    for n, a in enumerate(lls):
+        x[n, :lens[n]] = torch.from_numpy(a)
+    x = x.cuda().requires_grad_()
+    rec = _recognizer(g, tm, beam, lb, ac, min_active=0)
+    tmod = rec.trans_model
+    refs, alis = [], []
+    for n in range(3):
+        want = lr.decode(_ref_graph(g), lls[n], tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, 2 ** 31 - 1, 0, 0.5, ac))
+        refs.append(want)
+        alis.append(_ali_near_lattice(rng, want, P))
+    # whole minibatch, MMI
+    val = ops.LatticeBatchFunction.apply(x, lens, rec, tmod, alis, "mmi", None)
+    val.backward()
+    tot = 0.0
+    for n in range(3):
+        wl, wp = lr.lattice_mmi(refs[n], alis[n], tm["tid2pdf"], P, 1.0, 0.2, True)
+        tot += wl
+        assert np.abs(-x.grad[n, :lens[n]].cpu().numpy() - wp).max() < 2e-6
+        assert x.grad[n, lens[n]:].abs().sum().item() == 0.0
+    assert abs(val.item() - tot) < 1e-4 * abs(tot)
+    # per-utterance operators with the reference's signatures
+    for n in (0, 2):
+        xn = torch.from_numpy(lls[n]).cuda().requires_grad_()
+        v = ops.MMIFunction.apply(xn, rec, tmod, alis[n].tolist())
+        v.backward()
+        wl, wp = lr.lattice_mmi(refs[n], alis[n], tm["tid2pdf"], P, 1.0, 0.2, True)
+        assert abs(v.item() - wl) < 1e-4 * abs(wl) and np.abs(-xn.grad.cpu().numpy() - wp).max() < 2e-6
+        xn = torch.from_numpy(lls[n]).cuda().requires_grad_()
+        v = ops.sMBRFunction.apply(xn, rec, tmod, alis[n].tolist(), "smbr", tm["silence_phones"])
+        v.backward()
+        ws, wp = lr.lattice_mpe(refs[n], alis[n], tm["tid2pdf"], tm["tid2phone"], tm["silence_phones"], P, "smbr", True)
+        assert abs(v.item() - ws) < 1e-5 * max(1.0, abs(ws)) and np.abs(-xn.grad.cpu().numpy() - wp).max() < 2e-6
+
+
+def test_pool_overflow_is_retried_with_larger_pools():
+    nw, P, T, seed, beam, lb, ac, maxa, mina = CASES[1]
+    g, tm, ll, _ = _setup(nw, P, T, seed)
+    rec = _recognizer(g, tm, beam, lb, ac, maxa, mina)
+    full = _canon(rec.decode(torch.from_numpy(ll).cuda()).export(0))
+    rec.decoder_opts.tokens_per_frame, rec.decoder_opts.links_per_frame = 4, 4
+    lat = rec.decode(torch.from_numpy(ll).cuda())
+    assert lat.status[0] == 0 and _canon(lat.export(0)) == full
+
+
+def _write_fst(path, g, kind):
+    """OpenFst binary writer for the test (vector / const containers, tropical 'standard' arcs)."""
+    S = g["num_states"]
+    order = np.argsort(g["src"], kind="stable")
+    src, dst, il, w = g["src"][order], g["dst"][order], g["ilabel"][order], g["weight"][order]
+    counts = np.bincount(src, minlength=S)
+
+    def s(x):
+        return struct.pack("<i", len(x)) + x
+
+    flags = 4 if kind == "const_aligned" else 0
+    head = struct.pack("<i", 2125659606) + s(b"const" if kind.startswith("const") else b"vector") + s(b"standard")
+    head += struct.pack("<iiQqqq", 2, flags, 0, g["start"], S, len(src))
+    body = b""
+    if kind == "vector":
+        a = 0
+        for st in range(S):
+            body += struct.pack("<fq", float(g["final"][st]), int(counts[st]))
+            for _ in range(counts[st]):
+                body += struct.pack("<iifi", int(il[a]), 0, float(w[a]), int(dst[a])); a += 1
+    else:
+        def pad(b, pos):
+            return b + b"\0" * ((16 - (pos + len(b)) % 16) % 16) if kind == "const_aligned" else b
+        head = pad(head, 0)
+        pos, states = 0, b""
+        for st in range(S):
+            nie = int((il[pos:pos + counts[st]] == 0).sum())
+            states += struct.pack("<fIIII", float(g["final"][st]), pos, int(counts[st]), nie, int(counts[st]))
+            pos += int(counts[st])
+        states = pad(states, len(head))
+        arcs = b"".join(struct.pack("<iifi", int(il[a]), 0, float(w[a]), int(dst[a])) for a in range(len(src)))
+        body = states + arcs
+    with open(path, "wb") as f:
+        f.write(head + body)
+
+
+@pytest.mark.parametrize("kind", ["vector", "const", "const_aligned"])
+def test_hclg_from_openfst_file(tmp_path, kind):
+    nw, P, T, seed, beam, lb, ac, maxa, mina = CASES[1]
+    g, tm, ll, _ = _setup(nw, P, T, seed)
+    path = str(tmp_path / "HCLG.fst")
+    _write_fst(path, g, kind)
+    graph = lattice.DecodeGraph(path)
+    assert (graph.num_states, graph.num_arcs) == (g["num_states"], len(g["src"]))
+    o = lattice.LatticeFasterDecoderOptions(beam=beam, lattice_beam=lb, max_active=maxa, min_active=mina)
+    rec = lattice.MappedLatticeFasterRecognizer(lattice.TransitionModel.from_arrays(tm), graph, ac, o)
+    a = _canon(rec.decode(torch.from_numpy(ll).cuda()).export(0))
+    b = _canon(_recognizer(g, tm, beam, lb, ac, maxa, mina).decode(torch.from_numpy(ll).cuda()).export(0))
+    assert a == b
