@@ -244,6 +244,87 @@ def ce_workload(args, dev, rank, world):
     hvd.shutdown()
 
 
+def se_workload(args, dev, rank, world):
+    """configs[3]: lattice MMI (train_se.py) with on-the-fly lattices: `--batch` var-len utterances per GPU at
+    100 fps, 3x512 BLSTM, P=5768, word-loop HCLG, decoder_config of the reference's se.yaml (beam 13,
+    lattice_beam 7, max_active 7000, acoustic_scale 0.1), CE regulariser 0.1, clip 5, SGD."""
+    from pykaldi2_amd import data, lattice, se
+    PS = 5768
+    batch = args.batch if args.batch != 4 else 8
+    torch.manual_seed(0)
+    model = lstm.LSTMAM(80, PS, 512, 3, 0.0, True).to(dev).train()
+    opt = hvd.DistributedOptimizer(optim.SGD(model, lr=1e-5, momentum=0.9), named_parameters=model.named_parameters())
+    crit = ops.CrossEntropyLoss(ignore_index=-100, reduction="sum")
+    fb = fbank.FbankExtractor()
+    tm = synth.transition_model_arrays(PS)
+    trans_model = lattice.TransitionModel.from_arrays(tm)
+    o = lattice.LatticeFasterDecoderOptions(beam=13.0, lattice_beam=7.0, max_active=7000, min_active=200)
+    words = int(os.environ.get("PK2_SE_WORDS", "20000"))
+    log("building the synthetic HCLG (%d words)" % words)
+    g = synth.decoding_graph_arcs(words, PS, seed=0)
+    rec = lattice.MappedLatticeFasterRecognizer(trans_model, g, acoustic_scale=0.1, decoder_opts=o)
+    log("HCLG: %d states, %d arcs" % (rec.graph.num_states, rec.graph.num_arcs))
+    log_prior = se.log_prior_from_counts(np.ones(PS)).to(dev)
+    src = data.SyntheticSource(PS, seed=7, rank=rank, world=world, with_tids=True)
+    batches = []
+    for _ in range(3):
+        utts = [src.draw() for _ in range(batch)]
+        lens = [u[0].shape[0] for u in utts]
+        batches.append(dict(wav=torch.from_numpy(np.concatenate([u[0] for u in utts])).to(dev), lens=lens,
+                            y=[u[1] for u in utts], aux=[u[2] for u in utts], seconds=sum(lens) / 16000.0))
+    crit_name = os.environ.get("PK2_SE_CRITERION", "mmi")
+
+    def step(mb):
+        loss, se_val, ce, frames = se.sequence_loss(model, fb, mb, rec, trans_model, log_prior, crit_name,
+                                                    tm["silence_phones"], 0.1, crit)
+        opt.zero_grad()
+        loss.backward()
+        optim.clip_grad_norm_(opt, 5.0)
+        opt.step()
+        return loss, frames
+    for i in range(max(1, args.warmup)):
+        step(batches[i % 3])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    audio = 0.0
+    for i in range(args.steps):
+        loss, frames = step(batches[i % 3])
+        audio += float(np.sum(frames)) * 0.01
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # breakdown of the lattice part on the last minibatch (outside the timed region)
+    mb = batches[(args.steps - 1) % 3]
+    with torch.no_grad():
+        feats, frames, row_off = fb(mb["wav"], mb["lens"])
+        x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=True)
+        ll = model.forward_time_major(x).transpose(0, 1) - log_prior
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        lat = rec.decode_batch(ll, [int(t) for t in frames])
+        ev[1].record()
+        if crit_name == "mmi":
+            lat.mmi(mb["aux"], 1.0, 0.2, True)
+        else:
+            lat.mpe(mb["aux"], crit_name, tm["silence_phones"], True)
+        ev[2].record()
+        torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps({"metric": "iRTF (hrs audio/hr) 3x512 BLSTM lattice-%s, on-the-fly lattices (secondary workload, configs[3])" % crit_name.upper(),
+                          "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "batch_per_gpu": batch,
+                          "hclg": {"states": rec.graph.num_states, "arcs": rec.graph.num_arcs},
+                          "lattice_ms": {"decode_and_prune": round(ev[0].elapsed_time(ev[1]), 2),
+                                         "forward_backward": round(ev[1].elapsed_time(ev[2]), 2)},
+                          "lattice_tokens_per_frame": round(float(lat.num_tokens.sum()) / float(np.sum(frames)), 1),
+                          "lattice_links_per_frame": round(float(lat.num_links.sum()) / float(np.sum(frames)), 1),
+                          "loss": round(float(loss.item()), 2),
+                          "reference_published": "README.md:47-49: lattice MMI 16.7 iRTF (1 V100, 4 utterances), 34.5 iRTF (4 V100)"}),
+              flush=True)
+    hvd.shutdown()
+
+
 def log(msg):
     sys.stderr.write("[bench %.1fs] %s\n" % (time.time() - T_START, msg))
     sys.stderr.flush()
@@ -266,6 +347,8 @@ def main():
     ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
     ap.add_argument("--transformer", action="store_true", help="secondary workload configs[4]: 12-layer TransformerAM "
                     "LF-MMI instead of the BLSTM")
+    ap.add_argument("--se", action="store_true", help="secondary workload configs[3]: lattice MMI with on-the-fly lattices "
+                    "(PK2_SE_CRITERION=smbr|mpfe for the other criteria)")
     ap.add_argument("--ce", action="store_true", help="secondary workload configs[1]: 3x512 BLSTM CE, 256 x 80-frame "
                     "chunks per step (not the headline metric)")
     args = ap.parse_args()
@@ -278,6 +361,8 @@ def main():
 
     if args.ce:
         return ce_workload(args, dev, rank, world)
+    if args.se:
+        return se_workload(args, dev, rank, world)
     log("rank %d/%d: building synthetic den graph" % (rank, world))
     g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
     den = chain.DenominatorGraph(g, P)

@@ -32,6 +32,8 @@ constexpr int kLatWaves = kLatThreads / 64;
 constexpr int kMaxPdfsLds = 8192;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kMaxEpsRounds = 256;
+constexpr int kHeavyDegree = 48;   // states with more arcs than this (word-loop / silence states: 10^4 and more)
+constexpr int kMaxHeavy = 2048;    // are deferred and expanded by all 1024 threads, an arc per thread
 
 __device__ __forceinline__ uint32_t enc_cost(float f) {
   const uint32_t u = __float_as_uint(f);
@@ -63,6 +65,9 @@ struct Shared {
   int n_link;     // links appended to the segment being built
   int status;
   uint32_t sel_prefix; int sel_k;
+  int n_heavy;                       // tokens whose arcs the whole workgroup walks together
+  int heavy_tok[kMaxHeavy];
+  float heavy_cost[kMaxHeavy];
 };
 
 __device__ __forceinline__ float block_min(float v, Shared& sh) {
@@ -102,17 +107,28 @@ __device__ float kth_smallest(const float* cost, int n, int k, Shared& sh) {
       if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shifts[pass]) & ((1u << bits[pass]) - 1)], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int kk = k;
-      uint32_t b = 0;
-      const uint32_t nb = 1u << bits[pass];
-      for (; b < nb; ++b) {
-        const int c = (int)sh.hist[b];
-        if (kk < c) break;
-        kk -= c;
+    if (tid < 64) {
+      // wave 0: lane q owns bins [q*nb/64, (q+1)*nb/64); wave prefix sum, then the owning lane scans its bins
+      const int nb = 1 << bits[pass], per = nb / 64;
+      int mine = 0;
+      for (int b = 0; b < per; ++b) mine += (int)sh.hist[tid * per + b];
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += y;
       }
-      sh.sel_prefix = prefix | (b << shifts[pass]);
-      sh.sel_k = kk;
+      const int before = incl - mine;
+      if (k >= before && k < incl) {
+        int kk = k - before, b = 0;
+        for (; b < per; ++b) {
+          const int c = (int)sh.hist[tid * per + b];
+          if (kk < c) break;
+          kk -= c;
+        }
+        sh.sel_prefix = prefix | ((uint32_t)(tid * per + b) << shifts[pass]);
+        sh.sel_k = kk;
+      }
     }
     __syncthreads();
     prefix = sh.sel_prefix;
@@ -121,6 +137,37 @@ __device__ float kth_smallest(const float* cost, int n, int k, Shared& sh) {
     __syncthreads();
   }
   return dec_cost(prefix);
+}
+
+// Applies body(i, cost, arc) to every arc (CSR `off`) of the tokens i in [i0, i1) that `active` accepts.
+// Light states are walked by the token's thread; heavy ones are queued in LDS and then walked by the whole
+// workgroup, an arc per thread.  Contains workgroup barriers: call from uniform control flow.
+template <typename Active, typename Body>
+__device__ __forceinline__ void for_each_arc(Shared& sh, int i0, int i1, const int32_t* ts, const int32_t* off,
+                                             Active active, Body body) {
+  const int tid = threadIdx.x;
+  for (int i = i0 + tid; i < i1; i += kLatThreads) {
+    float c;
+    if (!active(i, &c)) continue;
+    const int s = ts[i];
+    const int a0 = off[s], a1 = off[s + 1];
+    if (a1 - a0 > kHeavyDegree) {
+      const int h = atomicAdd(&sh.n_heavy, 1);
+      if (h < kMaxHeavy) { sh.heavy_tok[h] = i; sh.heavy_cost[h] = c; continue; }
+    }
+    for (int a = a0; a < a1; ++a) body(i, c, a);
+  }
+  __syncthreads();
+  const int nh = min(sh.n_heavy, kMaxHeavy);
+  for (int h = 0; h < nh; ++h) {
+    const int i = sh.heavy_tok[h];
+    const float c = sh.heavy_cost[h];
+    const int s = ts[i];
+    for (int a = off[s] + tid; a < off[s + 1]; a += kLatThreads) body(i, c, a);
+  }
+  __syncthreads();
+  if (tid == 0) sh.n_heavy = 0;
+  __syncthreads();
 }
 
 // Epsilon closure of the frame whose tokens start at f0 (utterance-local), then the frame's epsilon links.
@@ -138,36 +185,35 @@ __device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, 
     __syncthreads();
     const int cnt = sh.n_new;
     int changed = 0;
-    for (int i = f0 + tid; i < f0 + cnt; i += kLatThreads) {
-      const int s = ts[i];
-      const float c = dec_cost(ld_coherent(&stc[s]));
-      if (c < tc[i]) {
-        tc[i] = c;
-        if (c < cutoff) {
-          for (int a = p.g.n_off[s]; a < p.g.n_off[s + 1]; ++a) {
-            const float tot = c + p.g.n_w[a];
-            const uint32_t k = enc_cost(tot);
-            if (k < kcut) {
-              const int d = p.g.n_dst[a];
-              const uint32_t old = atomicMin(&stc[d], k);
-              if (k < old) {
-                changed = 1;
-                if (old == kEmpty) {
-                  const int idx = atomicAdd(&sh.n_new, 1);
-                  if (f0 + idx < U.tok_cap) {
-                    ts[f0 + idx] = d;
-                    tc[f0 + idx] = INFINITY;
-                    __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  } else {
-                    sh.status = kLatTokenOverflow;
-                  }
-                }
-              }
-            }
-          }
-        }
-      }
-    }
+    for_each_arc(sh, f0, f0 + cnt, ts, p.g.n_off,
+                 [&](int i, float* c) {
+                   const float cc = dec_cost(ld_coherent(&stc[ts[i]]));
+                   if (!(cc < tc[i])) return false;      // not improved since its last expansion
+                   tc[i] = cc;
+                   *c = cc;
+                   return cc < cutoff;
+                 },
+                 [&](int i, float c, int a) {
+                   const float tot = c + p.g.n_w[a];
+                   const uint32_t k = enc_cost(tot);
+                   if (k < kcut) {
+                     const int d = p.g.n_dst[a];
+                     const uint32_t old = atomicMin(&stc[d], k);
+                     if (k < old) {
+                       changed = 1;
+                       if (old == kEmpty) {
+                         const int idx = atomicAdd(&sh.n_new, 1);
+                         if (f0 + idx < U.tok_cap) {
+                           ts[f0 + idx] = d;
+                           tc[f0 + idx] = INFINITY;
+                           __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                         } else {
+                           sh.status = kLatTokenOverflow;
+                         }
+                       }
+                     }
+                   }
+                 });
     changed = __syncthreads_or(changed);
     if (!changed || sh.status != kLatOk) break;
     if (++rounds > kMaxEpsRounds) { if (tid == 0) sh.status = kLatEpsilonLoop; break; }
@@ -180,28 +226,23 @@ __device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, 
   int32_t* ltid = p.L.link_tid + U.link_base;
   float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
   const int l0 = *link_end;
-  for (int i = f0 + tid; i < f0 + cnt; i += kLatThreads) {
-    const float c = tc[i];
-    if (c < cutoff) {
-      const int s = ts[i];
-      for (int a = p.g.n_off[s]; a < p.g.n_off[s + 1]; ++a) {
-        const float tot = c + p.g.n_w[a];
-        if (tot < cutoff) {
-          const int li = l0 + atomicAdd(&sh.n_link, 1);
-          if (li < U.link_cap) {
-            lsrc[li] = i;
-            ldst[li] = f0 + ld_coherent(&stt[p.g.n_dst[a]]);
-            ltid[li] = 0;
-            lgr[li] = p.g.n_w[a];
-            lac[li] = 0.f;
-          } else {
-            sh.status = kLatLinkOverflow;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
+  for_each_arc(sh, f0, f0 + cnt, ts, p.g.n_off,
+               [&](int i, float* c) { *c = tc[i]; return tc[i] < cutoff; },
+               [&](int i, float c, int a) {
+                 const float tot = c + p.g.n_w[a];
+                 if (tot < cutoff) {
+                   const int li = l0 + atomicAdd(&sh.n_link, 1);
+                   if (li < U.link_cap) {
+                     lsrc[li] = i;
+                     ldst[li] = f0 + ld_coherent(&stt[p.g.n_dst[a]]);
+                     ltid[li] = 0;
+                     lgr[li] = p.g.n_w[a];
+                     lac[li] = 0.f;
+                   } else {
+                     sh.status = kLatLinkOverflow;
+                   }
+                 }
+               });
   // reset the table entries of the frame; prepare the token arrays the pruning pass uses
   float* te = p.L.tok_extra + U.tok_base;
   int32_t* tl = p.L.tok_level + U.tok_base;
@@ -280,7 +321,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
   float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
 
   if (tid == 0) {
-    sh.status = kLatOk; sh.n_new = 1; sh.n_link = 0;
+    sh.status = kLatOk; sh.n_new = 1; sh.n_link = 0; sh.n_heavy = 0;
     s_tok_end = 0; s_link_end = 0;
     ts[0] = p.g.start; tc[0] = INFINITY;
     stc[p.g.start] = enc_cost(0.f);
@@ -317,53 +358,45 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     __syncthreads();
     // ---- pass 1: best new cost ----
     float nmin = INFINITY;
-    for (int i = f0 + tid; i < f1; i += kLatThreads) {
-      const float c = tc[i];
-      if (c <= cur_cutoff) {
-        const int s = ts[i];
-        for (int a = p.g.e_off[s]; a < p.g.e_off[s + 1]; ++a) {
-          const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[p.g.e_tid[a]]]);
-          nmin = fminf(nmin, __fadd_rn(__fadd_rn(c, ac), p.g.e_w[a]));
-        }
-      }
-    }
+    for_each_arc(sh, f0, f1, ts, p.g.e_off,
+                 [&](int i, float* c) { *c = tc[i]; return tc[i] <= cur_cutoff; },
+                 [&](int i, float c, int a) {
+                   const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[p.g.e_tid[a]]]);
+                   nmin = fminf(nmin, __fadd_rn(__fadd_rn(c, ac), p.g.e_w[a]));
+                 });
     nmin = block_min(nmin, sh);
     if (!(nmin < INFINITY)) { if (tid == 0) sh.status = kLatNoSurvivor; __syncthreads(); break; }
     const float next_cutoff = nmin + adaptive;
     // ---- pass 2: tokens and links of frame t+1 ----
     const int l0 = s_link_end;
-    for (int i = f0 + tid; i < f1; i += kLatThreads) {
-      const float c = tc[i];
-      if (c <= cur_cutoff) {
-        const int s = ts[i];
-        for (int a = p.g.e_off[s]; a < p.g.e_off[s + 1]; ++a) {
-          const int tidl = p.g.e_tid[a];
-          const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl]]);
-          const float gw = p.g.e_w[a];
-          const float tot = __fadd_rn(__fadd_rn(c, ac), gw);
-          if (tot < next_cutoff) {
-            const int d = p.g.e_dst[a];
-            const uint32_t old = atomicMin(&stc[d], enc_cost(tot));
-            if (old == kEmpty) {
-              const int idx = atomicAdd(&sh.n_new, 1);
-              if (f1 + idx < U.tok_cap) {
-                ts[f1 + idx] = d;
-                tc[f1 + idx] = INFINITY;
-                __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              } else {
-                sh.status = kLatTokenOverflow;
-              }
-            }
-            const int li = l0 + atomicAdd(&sh.n_link, 1);
-            if (li < U.link_cap) {
-              lsrc[li] = i; ldst[li] = d /* state for now */; ltid[li] = tidl; lgr[li] = gw; lac[li] = ac;
-            } else {
-              sh.status = kLatLinkOverflow;
-            }
-          }
-        }
-      }
-    }
+    for_each_arc(sh, f0, f1, ts, p.g.e_off,
+                 [&](int i, float* c) { *c = tc[i]; return tc[i] <= cur_cutoff; },
+                 [&](int i, float c, int a) {
+                   const int tidl = p.g.e_tid[a];
+                   const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl]]);
+                   const float gw = p.g.e_w[a];
+                   const float tot = __fadd_rn(__fadd_rn(c, ac), gw);
+                   if (tot < next_cutoff) {
+                     const int d = p.g.e_dst[a];
+                     const uint32_t old = atomicMin(&stc[d], enc_cost(tot));
+                     if (old == kEmpty) {
+                       const int idx = atomicAdd(&sh.n_new, 1);
+                       if (f1 + idx < U.tok_cap) {
+                         ts[f1 + idx] = d;
+                         tc[f1 + idx] = INFINITY;
+                         __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       } else {
+                         sh.status = kLatTokenOverflow;
+                       }
+                     }
+                     const int li = l0 + atomicAdd(&sh.n_link, 1);
+                     if (li < U.link_cap) {
+                       lsrc[li] = i; ldst[li] = d /* state for now */; ltid[li] = tidl; lgr[li] = gw; lac[li] = ac;
+                     } else {
+                       sh.status = kLatLinkOverflow;
+                     }
+                   }
+                 });
     __syncthreads();
     if (sh.status != kLatOk) break;
     const int l1 = l0 + sh.n_link;

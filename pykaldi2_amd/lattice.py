@@ -170,6 +170,7 @@ class LatticeBatch:
         self._h, self.workspace, self.lengths = handle, workspace, list(lengths)
         self.device, self.trans_model, self.num_pdfs = device, trans_model, num_pdfs
         self.status = self.num_tokens = self.num_links = self.best_cost = None
+        self.time_major = False
 
     def __del__(self):
         try:
@@ -189,11 +190,18 @@ class LatticeBatch:
             ref[n, :self.lengths[n]] = ids[:self.lengths[n]]
         return torch.from_numpy(ref).to(self.device)
 
+    def _zeros_post(self):
+        # same memory layout as the log-likelihoods (time-major when the model produced them time-major)
+        N, Tmax = len(self.lengths), max(self.lengths)
+        if self.time_major:
+            return torch.zeros(Tmax, N, self.num_pdfs, device=self.device).transpose(0, 1)
+        return torch.zeros(N, Tmax, self.num_pdfs, device=self.device)
+
     def mmi(self, trans_ids, lm_scale=1.0, acoustic_scale=0.2, drop_frames=True):
         """-> (lat_like f64 [N], post f32 [N, Tmax, P] = numerator - denominator posteriors)."""
         N, Tmax = len(self.lengths), max(self.lengths)
         ref = self._ref(trans_ids)
-        post = torch.zeros(N, Tmax, self.num_pdfs, device=self.device)
+        post = self._zeros_post()
         out = torch.empty(N, dtype=torch.float64, device=self.device)
         t2p, _ = self.trans_model.device_tables(self.device)
         _lib.check(_lib.lib().pk2_lattice_mmi(self._h, _lib.ptr(self.workspace), _lib.ptr(ref), ref.stride(0), _lib.ptr(t2p),
@@ -206,7 +214,7 @@ class LatticeBatch:
         assert criterion in ("smbr", "mpfe")
         N, Tmax = len(self.lengths), max(self.lengths)
         ref = self._ref(trans_ids)
-        post = torch.zeros(N, Tmax, self.num_pdfs, device=self.device)
+        post = self._zeros_post()
         out = torch.empty(N, dtype=torch.float64, device=self.device)
         t2p, t2ph = self.trans_model.device_tables(self.device)
         sil = self.trans_model.silence_mask(silence_phones, self.device)
@@ -247,6 +255,7 @@ class MappedLatticeFasterRecognizer:
         self.acoustic_scale = float(acoustic_scale)
         self.decoder_opts = decoder_opts or LatticeFasterDecoderOptions()
         assert self.graph.max_ilabel <= trans_model.num_transition_ids(), "HCLG uses transition-ids the model lacks"
+        self._grow = 1
 
     @classmethod
     def from_files(cls, trans_model_path, graph_path, words_txt=None, acoustic_scale=0.1, decoder_opts=None):
@@ -269,9 +278,9 @@ class MappedLatticeFasterRecognizer:
         dev = loglikes.device
         N, P = loglikes.shape[0], loglikes.shape[2]
         lens = np.ascontiguousarray(lengths, np.int32)
-        assert lens.shape[0] == N and lens.max() <= loglikes.shape[1]
+        assert lens.shape[0] == N and lens.max() == loglikes.shape[1], "pad the minibatch to its longest utterance"
         t2p, _ = self.trans_model.device_tables(dev)
-        grow = 1
+        grow = self._grow
         for _ in range(8):
             h = C.c_void_p()
             opts = self._opts(grow)
@@ -285,7 +294,9 @@ class MappedLatticeFasterRecognizer:
             rc = L.pk2_lattice_summary(h, _lib.ptr(ws), status.ctypes.data, ntok.ctypes.data, nlink.ctypes.data,
                                        best.ctypes.data, _lib.stream_ptr(dev))
             batch.status, batch.num_tokens, batch.num_links, batch.best_cost = status, ntok, nlink, best
+            batch.time_major = N > 1 and loglikes.stride(0) < loglikes.stride(1)
             if rc == 0:
+                self._grow = grow      # later minibatches start from pools that were large enough
                 return batch
             if not np.all((status == 0) | (status == 1) | (status == 2)):
                 _lib.check(rc)

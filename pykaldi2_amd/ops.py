@@ -154,7 +154,7 @@ class LatticeBatchFunction(Function):
 
     @staticmethod
     def forward(ctx, prediction, lengths, asr_decoder, trans_model, trans_ids, criterion, silence_phones):
-        lat = asr_decoder.decode_batch(prediction.detach().contiguous(), lengths)
+        lat = asr_decoder.decode_batch(prediction.detach(), lengths)
         if criterion == "mmi":
             val, post = lat.mmi(trans_ids, 1.0, 0.2, True)
         else:

@@ -42,3 +42,18 @@ def test_train_ce_cli_synthetic(tmp_path):
     assert "Epoch: [0]" in out.stdout and "Loss" in out.stdout
     ck = torch.load(tmp_path / "exp" / "model.0.tar", map_location="cpu", weights_only=False)
     assert ck["epoch"] == 0 and "output_layer.bias" in ck["model"]
+
+
+@pytest.mark.parametrize("criterion", ["mmi", "smbr"])
+def test_train_se_cli_synthetic(tmp_path, criterion):
+    cfg = yaml.safe_load(open(_cfg(tmp_path, "se.yaml", 120, True)))
+    cfg["decoder_config"] = dict(beam=9.0, lattice_beam=4.0, max_active=400, acoustic_scale=0.3, align_beam=10)
+    (tmp_path / "se.yaml").write_text(yaml.safe_dump(cfg))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_se.py"), "-config", str(tmp_path / "se.yaml"),
+                          "-exp_dir", str(tmp_path / "exp"), "-lr", "1e-4", "-momentum", "0.9", "-criterion", criterion,
+                          "-batch_size", "2", "-sweep_size", "0.02", "-print_freq", "1", "-synthetic", "-graph_words", "60"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Epoch: [0]" in out.stdout and "grad_norm" in out.stdout
+    ck = torch.load(tmp_path / "exp" / "model.se.0.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch"} and "lstm.weight_hh_l1_reverse" in ck["model"]

@@ -1,0 +1,144 @@
+"""Host-side readers of the lattice path (no GPU): HCLG.fst in OpenFst binary form through the C ABI, Kaldi's
+text transition model, the final.occs priors.  The byte fixtures are assembled here from the published formats
+(SURVEY.md Appendix C); Kaldi / OpenFst are not available to write them."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from pykaldi2_amd import _lib, lattice, se, synth
+
+
+def _write_fst(path, g, kind):
+    S = g["num_states"]
+    order = np.argsort(g["src"], kind="stable")
+    src, dst, il, w = g["src"][order], g["dst"][order], g["ilabel"][order], g["weight"][order]
+    counts = np.bincount(src, minlength=S)
+    s = lambda x: struct.pack("<i", len(x)) + x
+    flags = 4 if kind == "const_aligned" else 0
+    head = struct.pack("<i", 2125659606) + s(b"const" if kind.startswith("const") else b"vector") + s(b"standard")
+    head += struct.pack("<iiQqqq", 2, flags, 0, g["start"], S, len(src))
+    if kind == "vector":
+        body, a = b"", 0
+        for st in range(S):
+            body += struct.pack("<fq", float(g["final"][st]), int(counts[st]))
+            for _ in range(counts[st]):
+                body += struct.pack("<iifi", int(il[a]), 7, float(w[a]), int(dst[a])); a += 1
+    else:
+        pad = lambda b, pos: b + b"\0" * ((16 - (pos + len(b)) % 16) % 16) if kind == "const_aligned" else b
+        head = pad(head, 0)
+        pos, states = 0, b""
+        for st in range(S):
+            states += struct.pack("<fIIII", float(g["final"][st]), pos, int(counts[st]), 0, 0)
+            pos += int(counts[st])
+        states = pad(states, len(head))
+        body = states + b"".join(struct.pack("<iifi", int(il[a]), 7, float(w[a]), int(dst[a])) for a in range(len(src)))
+    with open(path, "wb") as f:
+        f.write(head + body)
+
+
+@pytest.mark.parametrize("kind", ["vector", "const", "const_aligned"])
+def test_decode_graph_from_openfst(tmp_path, kind):
+    g = synth.decoding_graph_arcs(12, 30, seed=3)
+    path = str(tmp_path / "HCLG.fst")
+    _write_fst(path, g, kind)
+    graph = lattice.DecodeGraph(path)
+    assert (graph.num_states, graph.num_arcs, graph.max_ilabel) == (g["num_states"], len(g["src"]), int(g["ilabel"].max()))
+
+
+def test_decode_graph_rejects_bad_files(tmp_path):
+    p = tmp_path / "bad.fst"
+    p.write_bytes(b"not an fst at all")
+    with pytest.raises(_lib.Pk2Error, match="bad magic"):
+        lattice.DecodeGraph(str(p))
+    g = synth.decoding_graph_arcs(5, 12, seed=0)
+    path = str(tmp_path / "trunc.fst")
+    _write_fst(path, g, "vector")
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(_lib.Pk2Error, match="truncated"):
+        lattice.DecodeGraph(path)
+    with pytest.raises(_lib.Pk2Error):
+        lattice.DecodeGraph(dict(num_states=2, start=0, src=[0], dst=[5], ilabel=[1], weight=[0.0], final=[0.0, 0.0]))
+
+
+TRANS_MODEL_TXT = """<TransitionModel>
+<Topology>
+<TopologyEntry>
+<ForPhones>
+2 3
+</ForPhones>
+<State> 0 <PdfClass> 0 <Transition> 0 0.75 <Transition> 1 0.25 </State>
+<State> 1 <PdfClass> 1 <Transition> 1 0.75 <Transition> 2 0.25 </State>
+<State> 2 </State>
+</TopologyEntry>
+<TopologyEntry>
+<ForPhones>
+1
+</ForPhones>
+<State> 0 <PdfClass> 0 <Transition> 0 0.5 <Transition> 1 0.25 <Transition> 2 0.25 </State>
+<State> 1 <PdfClass> 1 <Transition> 1 0.5 <Transition> 2 0.5 </State>
+<State> 2 </State>
+</TopologyEntry>
+</Topology>
+<Triples> 6
+1 0 0
+1 1 1
+2 0 2
+2 1 3
+3 0 4
+3 1 2
+</Triples>
+<LogProbs>
+ [ 0 -0.69 -1.38 -1.38 -0.69 -0.69 -0.28 -1.38 -0.28 -1.38 -0.28 -1.38 -0.28 -1.38 ]
+</LogProbs>
+</TransitionModel>
+"""
+
+
+def test_transition_model_text_reader(tmp_path):
+    p = tmp_path / "final.mdl.txt"
+    p.write_text(TRANS_MODEL_TXT)
+    tm = lattice.TransitionModel.read(str(p))
+    # phone 1: state 0 has 3 transitions, state 1 has 2; phones 2 and 3: 2 transitions per state
+    assert tm.num_transition_ids() == 3 + 2 + 2 + 2 + 2 + 2
+    assert tm.tid2pdf.tolist() == [-1, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 2, 2]
+    assert tm.tid2phone.tolist() == [0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3]
+    assert tm.num_pdfs() == 5 and tm.transition_id_to_pdf(12) == 2 and tm.transition_id_to_phone(12) == 3
+    chain_like = TRANS_MODEL_TXT.replace("<PdfClass> 0", "<ForwardPdfClass> 0 <SelfLoopPdfClass> 1").replace(
+        "<PdfClass> 1", "<ForwardPdfClass> 1 <SelfLoopPdfClass> 1")
+    chain_like = chain_like.replace("<Triples> 6\n1 0 0\n1 1 1\n2 0 2\n2 1 3\n3 0 4\n3 1 2", "<Tuples> 6\n1 0 0 5\n1 1 1 6\n2 0 2 7\n2 1 3 8\n3 0 4 9\n3 1 2 10")
+    chain_like = chain_like.replace("</Triples>", "</Tuples>")
+    p.write_text(chain_like)
+    tm2 = lattice.TransitionModel.read(str(p))
+    # the self-loop (transition back to the same HMM state) carries the self-loop pdf
+    assert tm2.tid2pdf.tolist() == [-1, 5, 0, 0, 6, 1, 7, 2, 8, 3, 9, 4, 10, 2]
+    (tmp_path / "bin.mdl").write_bytes(b"\0B<TransitionModel> ")
+    with pytest.raises(ValueError, match="binary"):
+        lattice.TransitionModel.read(str(tmp_path / "bin.mdl"))
+
+
+def test_prior_readers(tmp_path):
+    v = np.array([3.0, 1.0, 4.0, 2.0])
+    (tmp_path / "t.occs").write_text(" [ 3 1 4 2 ]\n")
+    assert np.allclose(se.read_kaldi_vector(str(tmp_path / "t.occs")), v)
+    (tmp_path / "fv.occs").write_bytes(b"\0BFV " + b"\x04" + struct.pack("<i", 4) + v.astype("<f4").tobytes())
+    assert np.allclose(se.read_kaldi_vector(str(tmp_path / "fv.occs")), v)
+    (tmp_path / "dm.occs").write_bytes(b"\0BDM " + b"\x04" + struct.pack("<i", 1) + b"\x04" + struct.pack("<i", 4) + v.astype("<f8").tobytes())
+    assert np.allclose(se.read_kaldi_vector(str(tmp_path / "dm.occs")), v)
+    lp = se.log_prior_from_counts(v)
+    assert np.allclose(lp.numpy(), np.log(v / v.sum()), atol=1e-6)
+
+
+def test_synthetic_tid_alignment_is_consistent():
+    rng = np.random.default_rng(0)
+    tm = synth.transition_model_arrays(30)
+    ali = synth.tid_alignment(rng, 200, 30)
+    assert ali.shape == (200,) and ali.min() >= 1 and ali.max() <= 60
+    pdf = tm["tid2pdf"][ali]
+    assert np.array_equal(pdf, (ali - 1) // 2)
+    # forward transitions (even ids) end an HMM state: the next frame starts the next state of the phone or a new phone
+    for t in range(199):
+        if ali[t] % 2 == 1:
+            assert ali[t + 1] in (ali[t], ali[t] + 1)
