@@ -56,7 +56,16 @@ struct DecodeParams {
   int32_t max_active, min_active;
 };
 
+#ifdef PK2_LAT_PROFILE
+#define LAT_T(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long now_ = wall_clock64(); sh.prof[k] += now_ - sh.prof_last; sh.prof_last = now_; } } while (0)
+#else
+#define LAT_T(k) do { } while (0)
+#endif
+
 struct Shared {
+#ifdef PK2_LAT_PROFILE
+  long long prof[16]; long long prof_last;
+#endif
   float ll[kMaxPdfsLds];
   uint32_t hist[2048];
   float redf[kLatWaves];
@@ -220,6 +229,7 @@ __device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, 
   }
   __syncthreads();
   if (sh.status != kLatOk) return;
+  LAT_T(4);
   const int cnt = sh.n_new;
   // epsilon links from the final costs
   int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
@@ -262,6 +272,7 @@ __device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, 
     sh.n_link = 0;
   }
   __syncthreads();
+  LAT_T(6);
 }
 
 // In-place compaction of the links [l0, l1) that satisfy keep(l); returns the number kept (all threads).
@@ -322,6 +333,10 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
 
   if (tid == 0) {
     sh.status = kLatOk; sh.n_new = 1; sh.n_link = 0; sh.n_heavy = 0;
+#ifdef PK2_LAT_PROFILE
+    for (int k = 0; k < 16; ++k) sh.prof[k] = 0;
+    sh.prof_last = wall_clock64();
+#endif
     s_tok_end = 0; s_link_end = 0;
     ts[0] = p.g.start; tc[0] = INFINITY;
     stc[p.g.start] = enc_cost(0.f);
@@ -352,10 +367,12 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
       cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
       adaptive = (cur_cutoff - best) + p.beam_delta;
     }
+    LAT_T(0);
     // ---- acoustic scores of the frame ----
     const float* row = p.loglikes + (int64_t)n * p.seq_stride + (int64_t)t * p.frame_stride;
     for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
     __syncthreads();
+    LAT_T(1);
     // ---- pass 1: best new cost ----
     float nmin = INFINITY;
     for_each_arc(sh, f0, f1, ts, p.g.e_off,
@@ -367,6 +384,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     nmin = block_min(nmin, sh);
     if (!(nmin < INFINITY)) { if (tid == 0) sh.status = kLatNoSurvivor; __syncthreads(); break; }
     const float next_cutoff = nmin + adaptive;
+    LAT_T(2);
     // ---- pass 2: tokens and links of frame t+1 ----
     const int l0 = s_link_end;
     for_each_arc(sh, f0, f1, ts, p.g.e_off,
@@ -404,6 +422,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     __syncthreads();
     if (tid == 0) { s_link_end = l1; seg[2 * t + 2] = l1; sh.n_link = 0; }
     __syncthreads();
+    LAT_T(3);
     close_frame(p, U, sh, stc, stt, f1, next_cutoff, &s_link_end, &s_tok_end, 2 * t + 2);
     if (tid == 0) ftok[t + 2] = s_tok_end;
     __syncthreads();
@@ -414,6 +433,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     return;
   }
 
+  LAT_T(7);
   // ---- final costs (ComputeFinalCosts) ----
   const int fT0 = ftok[T], fT1 = s_tok_end;
   int anyf = 0;
@@ -463,6 +483,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
       return ed < INFINITY && (ed + ((tc[s] + g) - tc[d])) <= lbeam;
     });
     if (tid == 0) kept[2 * t] = ke;
+    LAT_T(8);
     // epsilon DAG depth of the frame's tokens (order of the forward-backward inside the frame)
     for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
       int changed = 0;
@@ -476,6 +497,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     for (int i = ftok[t] + tid; i < ftok[t + 1]; i += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[i]));
     const int lev_max = (int)(-block_min(-lm, sh));
     if (tid == 0) maxlev[t] = lev_max;
+    LAT_T(9);
     // emitting links t-1 -> t
     if (t > 0) {
       const int m0 = seg[2 * t - 1], m1 = seg[2 * t];
@@ -495,7 +517,13 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
       if (tid == 0) kept[2 * t - 1] = km;
     }
     __syncthreads();
+    LAT_T(10);
   }
+#ifdef PK2_LAT_PROFILE
+  if (tid == 0 && n == 0)
+    printf("lat_decode utt0 T=%d (10 ns ticks): cutoff %lld ll %lld pass1 %lld pass2 %lld closure %lld epslinks %lld reset %lld | final %lld prune_eps %lld levels %lld prune_em %lld\n",
+           T, sh.prof[0], sh.prof[1], sh.prof[2], sh.prof[3], sh.prof[4], sh.prof[5], sh.prof[6], sh.prof[7], sh.prof[8], sh.prof[9], sh.prof[10]);
+#endif
   if (tid == 0) {
     LatUtt* o = p.L.utt + n;
     o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
