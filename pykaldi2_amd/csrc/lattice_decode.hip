@@ -74,6 +74,7 @@ struct Shared {
   int n_link;     // links appended to the segment being built
   int status;
   uint32_t sel_prefix; int sel_k;
+  int n_elist;                       // tokens of the frame being built that have epsilon arcs
   int n_heavy;                       // tokens whose arcs the whole workgroup walks together
   int heavy_tok[kMaxHeavy];
   float heavy_cost[kMaxHeavy];
@@ -148,14 +149,96 @@ __device__ float kth_smallest(const float* cost, int n, int k, Shared& sh) {
   return dec_cost(prefix);
 }
 
-// Applies body(i, cost, arc) to every arc (CSR `off`) of the tokens i in [i0, i1) that `active` accepts.
-// Light states are walked by the token's thread; heavy ones are queued in LDS and then walked by the whole
-// workgroup, an arc per thread.  Contains workgroup barriers: call from uniform control flow.
-template <typename Active, typename Body>
-__device__ __forceinline__ void for_each_arc(Shared& sh, int i0, int i1, const int32_t* ts, const int32_t* off,
-                                             Active active, Body body) {
+// k-th smallest (0-based) of cost[0..n) when it is known to lie in [lo, hi): one pass over 2047 linear bins of
+// [lo, hi) (the token costs of a frame share their exponent, so the radix select's first pass would pile every
+// key into a few LDS counters), then the exact radix select among the members of the selected bin.
+__device__ float kth_smallest_in_range(const float* cost, int n, int k, float lo, float hi, Shared& sh) {
   const int tid = threadIdx.x;
-  for (int i = i0 + tid; i < i1; i += kLatThreads) {
+  const float scale = 2047.0f / (hi - lo);
+  auto bin_of = [&](float c) { return c >= hi ? 2047 : min(2046, (int)((c - lo) * scale)); };
+  for (int i = tid; i < 2048; i += kLatThreads) sh.hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += kLatThreads) atomicAdd(&sh.hist[bin_of(cost[i])], 1u);
+  __syncthreads();
+  if (tid < 64) {
+    int mine = 0;
+    for (int b = 0; b < 32; ++b) mine += (int)sh.hist[tid * 32 + b];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o, 64);
+      if (tid >= o) incl += y;
+    }
+    const int before = incl - mine;
+    if (k >= before && k < incl) {
+      int kk = k - before, b = 0;
+      for (; b < 32; ++b) {
+        const int c = (int)sh.hist[tid * 32 + b];
+        if (kk < c) break;
+        kk -= c;
+      }
+      sh.sel_prefix = (uint32_t)(tid * 32 + b);
+      sh.sel_k = kk;
+    }
+  }
+  __syncthreads();
+  const int sel_bin = (int)sh.sel_prefix;
+  k = sh.sel_k;
+  __syncthreads();
+  // exact selection among the members of sel_bin
+  uint32_t prefix = 0, mask = 0;
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = tid; i < 2048; i += kLatThreads) sh.hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kLatThreads) {
+      const float c = cost[i];
+      if (bin_of(c) != sel_bin) continue;
+      const uint32_t key = enc_cost(c);
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shifts[pass]) & ((1u << bits[pass]) - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int nb = 1 << bits[pass], per = nb / 64;
+      int mine = 0;
+      for (int b = 0; b < per; ++b) mine += (int)sh.hist[tid * per + b];
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += y;
+      }
+      const int before = incl - mine;
+      if (k >= before && k < incl) {
+        int kk = k - before, b = 0;
+        for (; b < per; ++b) {
+          const int c = (int)sh.hist[tid * per + b];
+          if (kk < c) break;
+          kk -= c;
+        }
+        sh.sel_prefix = prefix | ((uint32_t)(tid * per + b) << shifts[pass]);
+        sh.sel_k = kk;
+      }
+    }
+    __syncthreads();
+    prefix = sh.sel_prefix;
+    k = sh.sel_k;
+    mask |= ((1u << bits[pass]) - 1) << shifts[pass];
+    __syncthreads();
+  }
+  return dec_cost(prefix);
+}
+
+// Applies body(i, cost, arc) to every arc (CSR `off`) of the tokens i = list[j], j in [0, n_list), that `active`
+// accepts.  Light states are walked by the entry's thread; heavy ones are queued in LDS and then walked by the
+// whole workgroup, an arc per thread.  Contains workgroup barriers: call from uniform control flow.
+template <typename Active, typename Body>
+__device__ __forceinline__ void for_each_arc(Shared& sh, const int32_t* list, int n_list, const int32_t* ts,
+                                             const int32_t* off, Active active, Body body) {
+  const int tid = threadIdx.x;
+  for (int j = tid; j < n_list; j += kLatThreads) {
+    const int i = list[j];
     float c;
     if (!active(i, &c)) continue;
     const int s = ts[i];
@@ -179,26 +262,52 @@ __device__ __forceinline__ void for_each_arc(Shared& sh, int i0, int i1, const i
   __syncthreads();
 }
 
-// Epsilon closure of the frame whose tokens start at f0 (utterance-local), then the frame's epsilon links.
-// On entry sh.n_new = tokens already in the frame with their costs in the state table and tok_cost = +inf
-// ("cost at the last expansion").  On exit tok_cost holds the final costs, the table is clean again and
-// *tok_end / *link_end are advanced.
-__device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, uint32_t* stc, int32_t* stt, int f0,
-                            float cutoff, int* link_end, int* tok_end, int seg_index) {
+// Per-utterance views of the workspace.  During decoding the float64 arrays of the forward-backward are
+// scratch: {first emitting arc, emitting degree} per token, the frame's arc work list, the list of the frame's
+// tokens that have epsilon arcs.
+struct UttView {
+  uint32_t* stc; int32_t* stt;
+  int32_t* ts; float* tc; float* te; float* tf; int32_t* tl;
+  int2* tarc;                                   // [tok_cap] {e_off[state], emitting degree}        (alpha region)
+  int32_t* work_tok; int32_t* work_arc;         // [tok_cap] each                                    (beta / acc_f)
+  float* work_tot; int32_t* elist;              // [tok_cap] each                                    (acc_b)
+  int32_t* ftok; int32_t* seg; int32_t* kept; int32_t* maxlev;
+  int32_t* lsrc; int32_t* ldst; int32_t* ltid; float* lgr; float* lac;
+  int tok_cap, link_cap;
+};
+
+// A token for state d was created at utterance-local index f0 + idx: record it; tokens with epsilon arcs join
+// the frame's epsilon list.
+__device__ __forceinline__ void register_token(const DecodeParams& p, const UttView& V, Shared& sh, int f0, int idx, int d) {
+  if (f0 + idx < V.tok_cap) {
+    V.ts[f0 + idx] = d;
+    V.tc[f0 + idx] = INFINITY;     // "cost at the last epsilon expansion"; the final cost is written when the frame closes
+    __hip_atomic_store(&V.stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.g.n_off[d + 1] > p.g.n_off[d]) {
+      const int e = atomicAdd(&sh.n_elist, 1);
+      if (e < V.tok_cap) V.elist[e] = f0 + idx; else sh.status = kLatTokenOverflow;
+    }
+  } else {
+    sh.status = kLatTokenOverflow;
+  }
+}
+
+// Epsilon closure of the frame whose tokens start at f0, the frame's epsilon links, final token costs, sparse
+// reset of the state table.  On entry sh.n_new tokens exist with their costs in the table.
+__device__ void close_frame(const DecodeParams& p, const UttView& V, Shared& sh, int f0, float cutoff, int* link_end,
+                            int* tok_end, int seg_index) {
   const int tid = threadIdx.x;
-  int32_t* ts = p.L.tok_state + U.tok_base;
-  float* tc = p.L.tok_cost + U.tok_base;
   const uint32_t kcut = enc_cost(cutoff);
   int rounds = 0;
   while (true) {
     __syncthreads();
-    const int cnt = sh.n_new;
+    const int ne = min(sh.n_elist, V.tok_cap);
     int changed = 0;
-    for_each_arc(sh, f0, f0 + cnt, ts, p.g.n_off,
+    for_each_arc(sh, V.elist, ne, V.ts, p.g.n_off,
                  [&](int i, float* c) {
-                   const float cc = dec_cost(ld_coherent(&stc[ts[i]]));
-                   if (!(cc < tc[i])) return false;      // not improved since its last expansion
-                   tc[i] = cc;
+                   const float cc = dec_cost(ld_coherent(&V.stc[V.ts[i]]));
+                   if (!(cc < V.tc[i])) return false;      // not improved since its last expansion
+                   V.tc[i] = cc;
                    *c = cc;
                    return cc < cutoff;
                  },
@@ -207,19 +316,10 @@ __device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, 
                    const uint32_t k = enc_cost(tot);
                    if (k < kcut) {
                      const int d = p.g.n_dst[a];
-                     const uint32_t old = atomicMin(&stc[d], k);
+                     const uint32_t old = atomicMin(&V.stc[d], k);
                      if (k < old) {
                        changed = 1;
-                       if (old == kEmpty) {
-                         const int idx = atomicAdd(&sh.n_new, 1);
-                         if (f0 + idx < U.tok_cap) {
-                           ts[f0 + idx] = d;
-                           tc[f0 + idx] = INFINITY;
-                           __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                         } else {
-                           sh.status = kLatTokenOverflow;
-                         }
-                       }
+                       if (old == kEmpty) register_token(p, V, sh, f0, atomicAdd(&sh.n_new, 1), d);
                      }
                    }
                  });
@@ -230,83 +330,108 @@ __device__ void close_frame(const DecodeParams& p, const LatUtt& U, Shared& sh, 
   __syncthreads();
   if (sh.status != kLatOk) return;
   LAT_T(4);
-  const int cnt = sh.n_new;
-  // epsilon links from the final costs
-  int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
-  int32_t* ltid = p.L.link_tid + U.link_base;
-  float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
+  const int cnt = sh.n_new, ne = sh.n_elist;
   const int l0 = *link_end;
-  for_each_arc(sh, f0, f0 + cnt, ts, p.g.n_off,
-               [&](int i, float* c) { *c = tc[i]; return tc[i] < cutoff; },
+  // epsilon links from the final costs (every listed token was last expanded at its final cost)
+  for_each_arc(sh, V.elist, ne, V.ts, p.g.n_off,
+               [&](int i, float* c) { *c = V.tc[i]; return V.tc[i] < cutoff; },
                [&](int i, float c, int a) {
                  const float tot = c + p.g.n_w[a];
                  if (tot < cutoff) {
                    const int li = l0 + atomicAdd(&sh.n_link, 1);
-                   if (li < U.link_cap) {
-                     lsrc[li] = i;
-                     ldst[li] = f0 + ld_coherent(&stt[p.g.n_dst[a]]);
-                     ltid[li] = 0;
-                     lgr[li] = p.g.n_w[a];
-                     lac[li] = 0.f;
+                   if (li < V.link_cap) {
+                     V.lsrc[li] = i;
+                     V.ldst[li] = f0 + ld_coherent(&V.stt[p.g.n_dst[a]]);
+                     V.ltid[li] = 0;
+                     V.lgr[li] = p.g.n_w[a];
+                     V.lac[li] = 0.f;
                    } else {
                      sh.status = kLatLinkOverflow;
                    }
                  }
                });
-  // reset the table entries of the frame; prepare the token arrays the pruning pass uses
-  float* te = p.L.tok_extra + U.tok_base;
-  int32_t* tl = p.L.tok_level + U.tok_base;
-  for (int i = f0 + tid; i < f0 + cnt; i += kLatThreads) {
-    const int s = ts[i];
-    stc[s] = kEmpty;
-    stt[s] = -1;
-    te[i] = INFINITY;
-    tl[i] = 0;
+  LAT_T(5);
+  // final costs, per-token arc ranges for the next frame's work list, sparse reset of the table
+  for (int i0 = f0 + tid; i0 < f0 + cnt; i0 += 4 * kLatThreads) {
+    int st[4]; uint32_t ck[4]; int a0[4], a1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (i0 + q * kLatThreads < f0 + cnt) st[q] = V.ts[i0 + q * kLatThreads];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * kLatThreads < f0 + cnt) { ck[q] = ld_coherent(&V.stc[st[q]]); a0[q] = p.g.e_off[st[q]]; a1[q] = p.g.e_off[st[q] + 1]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * kLatThreads;
+      if (i < f0 + cnt) {
+        V.tc[i] = dec_cost(ck[q]);
+        V.tarc[i] = make_int2(a0[q], a1[q] - a0[q]);
+        V.te[i] = INFINITY;
+        V.stc[st[q]] = kEmpty;
+        V.stt[st[q]] = -1;
+      }
+    }
   }
   __syncthreads();
   if (tid == 0) {
     *tok_end = f0 + cnt;
-    *link_end = min(l0 + sh.n_link, U.link_cap);
-    p.L.seg_off[U.frame_base + seg_index + 1] = *link_end;
+    *link_end = min(l0 + sh.n_link, V.link_cap);
+    V.seg[seg_index + 1] = *link_end;
     sh.n_new = 0;
     sh.n_link = 0;
+    sh.n_elist = 0;
   }
   __syncthreads();
   LAT_T(6);
 }
 
-// In-place compaction of the links [l0, l1) that satisfy keep(l); returns the number kept (all threads).
-template <typename Keep>
-__device__ int compact_links(const DecodeParams& p, const LatUtt& U, Shared& sh, int l0, int l1, float ac_mul, Keep keep) {
-  int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
-  int32_t* ltid = p.L.link_tid + U.link_base;
-  float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  int out = l0;
-  for (int base = l0; base < l1; base += kLatThreads) {
-    const int l = base + tid;
-    int s = 0, d = 0, t = 0; float g = 0.f, a = 0.f;
-    bool k = false;
-    if (l < l1) {
-      s = lsrc[l]; d = ldst[l]; t = ltid[l]; g = lgr[l]; a = lac[l];
-      k = keep(s, d, g, a);
-    }
-    const unsigned long long bal = __ballot(k);
-    const int within = __popcll(bal & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (lane == 0) sh.redi[w] = __popcll(bal);
-    __syncthreads();
-    int before = 0, total = 0;
+// Exclusive prefix over the workgroup of one int per thread; *total receives the sum.
+__device__ __forceinline__ int block_exclusive_scan(int v, Shared& sh, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
 #pragma unroll
-    for (int q = 0; q < kLatWaves; ++q) {
-      const int c = sh.redi[q];
-      if (q < w) before += c;
-      total += c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += y;
+  }
+  __syncthreads();
+  if (lane == 63) sh.redi[w] = incl;
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int q = 0; q < kLatWaves; ++q) {
+    const int c = sh.redi[q];
+    if (q < w) before += c;
+    tot += c;
+  }
+  *total = tot;
+  return before + incl - v;
+}
+
+// In-place compaction of the links [l0, l1), four consecutive links per thread and pass.  keep(s, d, g, a)
+// decides and may update the source token's extra cost.  Returns the number kept (all threads).
+template <typename Keep>
+__device__ int compact_links(const UttView& V, Shared& sh, int l0, int l1, float ac_mul, Keep keep) {
+  constexpr int KPT = 4;
+  const int tid = threadIdx.x;
+  int out = l0;
+  for (int base = l0; base < l1; base += KPT * kLatThreads) {
+    int s[KPT], d[KPT], t[KPT]; float g[KPT], a[KPT]; bool k[KPT];
+    const int lb = base + tid * KPT;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      const int l = lb + q;
+      k[q] = false;
+      if (l < l1) { s[q] = V.lsrc[l]; d[q] = V.ldst[l]; t[q] = V.ltid[l]; g[q] = V.lgr[l]; a[q] = V.lac[l]; }
     }
-    if (k) {
-      const int o = out + before + within;
-      lsrc[o] = s; ldst[o] = d; ltid[o] = t; lgr[o] = g; lac[o] = __fmul_rn(a, ac_mul);
-    }
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q)
+      if (lb + q < l1) { k[q] = keep(s[q], d[q], g[q], a[q]); mine += k[q]; }
+    int total;
+    int o = out + block_exclusive_scan(mine, sh, &total);   // barriers inside: every link of the pass is in registers
+#pragma unroll
+    for (int q = 0; q < KPT; ++q)
+      if (k[q]) { V.lsrc[o] = s[q]; V.ldst[o] = d[q]; V.ltid[o] = t[q]; V.lgr[o] = g[q]; V.lac[o] = __fmul_rn(a[q], ac_mul); ++o; }
     out += total;
     __syncthreads();
   }
@@ -319,32 +444,38 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
   const int n = blockIdx.x, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
   const int T = U.T;
-  uint32_t* stc = p.L.st_cost + (size_t)n * p.g.S;
-  int32_t* stt = p.L.st_tok + (size_t)n * p.g.S;
-  int32_t* ts = p.L.tok_state + U.tok_base;
-  float* tc = p.L.tok_cost + U.tok_base;
-  float* te = p.L.tok_extra + U.tok_base;
-  float* tf = p.L.tok_final + U.tok_base;
-  int32_t* ftok = p.L.frame_tok + U.frame_base;
-  int32_t* seg = p.L.seg_off + U.frame_base;
-  int32_t* lsrc = p.L.link_src + U.link_base; int32_t* ldst = p.L.link_dst + U.link_base;
-  int32_t* ltid = p.L.link_tid + U.link_base;
-  float* lgr = p.L.link_graph + U.link_base; float* lac = p.L.link_ac + U.link_base;
+  UttView V;
+  V.stc = p.L.st_cost + (size_t)n * p.g.S; V.stt = p.L.st_tok + (size_t)n * p.g.S;
+  V.ts = p.L.tok_state + U.tok_base; V.tc = p.L.tok_cost + U.tok_base; V.te = p.L.tok_extra + U.tok_base;
+  V.tf = p.L.tok_final + U.tok_base; V.tl = p.L.tok_level + U.tok_base;
+  V.tarc = reinterpret_cast<int2*>(p.L.alpha + U.tok_base);
+  V.work_tok = reinterpret_cast<int32_t*>(p.L.beta + U.tok_base);
+  V.work_arc = V.work_tok + U.tok_cap;
+  V.work_tot = reinterpret_cast<float*>(p.L.acc_f + U.tok_base);
+  V.elist = reinterpret_cast<int32_t*>(p.L.acc_b + U.tok_base);
+  V.ftok = p.L.frame_tok + U.frame_base; V.seg = p.L.seg_off + U.frame_base;
+  V.kept = p.L.seg_kept + U.frame_base; V.maxlev = p.L.frame_maxlev + U.frame_base;
+  V.lsrc = p.L.link_src + U.link_base; V.ldst = p.L.link_dst + U.link_base; V.ltid = p.L.link_tid + U.link_base;
+  V.lgr = p.L.link_graph + U.link_base; V.lac = p.L.link_ac + U.link_base;
+  V.tok_cap = U.tok_cap; V.link_cap = U.link_cap;
+  int32_t* ts = V.ts; float* tc = V.tc; float* te = V.te; float* tf = V.tf;
+  int32_t* ftok = V.ftok; int32_t* seg = V.seg;
+  int32_t* lsrc = V.lsrc; int32_t* ldst = V.ldst; int32_t* ltid = V.ltid; float* lgr = V.lgr; float* lac = V.lac;
+  const int work_cap = U.tok_cap;
 
   if (tid == 0) {
-    sh.status = kLatOk; sh.n_new = 1; sh.n_link = 0; sh.n_heavy = 0;
+    sh.status = kLatOk; sh.n_new = 1; sh.n_link = 0; sh.n_heavy = 0; sh.n_elist = 0;
 #ifdef PK2_LAT_PROFILE
     for (int k = 0; k < 16; ++k) sh.prof[k] = 0;
     sh.prof_last = wall_clock64();
 #endif
     s_tok_end = 0; s_link_end = 0;
-    ts[0] = p.g.start; tc[0] = INFINITY;
-    stc[p.g.start] = enc_cost(0.f);
-    stt[p.g.start] = 0;
+    V.stc[p.g.start] = enc_cost(0.f);
+    register_token(p, V, sh, 0, 0, p.g.start);
     ftok[0] = 0; seg[0] = 0;
   }
   __syncthreads();
-  close_frame(p, U, sh, stc, stt, 0, p.beam, &s_link_end, &s_tok_end, 0);   // InitDecoding: ProcessNonemitting(beam)
+  close_frame(p, V, sh, 0, p.beam, &s_link_end, &s_tok_end, 0);   // InitDecoding: ProcessNonemitting(beam)
   if (tid == 0) ftok[1] = s_tok_end;
   __syncthreads();
 
@@ -355,75 +486,123 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     for (int i = f0 + tid; i < f1; i += kLatThreads) lmin = fminf(lmin, tc[i]);
     const float best = block_min(lmin, sh);
     const float beam_cutoff = best + p.beam;
-    int c_lt = 0, c_le = 0;
-    for (int i = f0 + tid; i < f1; i += kLatThreads) { c_lt += tc[i] < beam_cutoff; c_le += tc[i] <= beam_cutoff; }
-    c_lt = block_sum_i(c_lt, sh);
-    c_le = block_sum_i(c_le, sh);
     float cur_cutoff = beam_cutoff, adaptive = p.beam;
-    if (nt > p.max_active && c_lt > p.max_active) {
-      cur_cutoff = kth_smallest(tc + f0, nt, p.max_active, sh);
-      adaptive = (cur_cutoff - best) + p.beam_delta;
-    } else if (p.min_active > 0 && nt > p.min_active && c_le <= p.min_active) {
-      cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
-      adaptive = (cur_cutoff - best) + p.beam_delta;
+    const bool chk_max = nt > p.max_active, chk_min = p.min_active > 0 && nt > p.min_active;
+    if (chk_max || chk_min) {
+      int c_lt = 0, c_le = 0;
+      for (int i = f0 + tid; i < f1; i += kLatThreads) { c_lt += tc[i] < beam_cutoff; c_le += tc[i] <= beam_cutoff; }
+      c_lt = block_sum_i(c_lt, sh);
+      c_le = block_sum_i(c_le, sh);
+      if (chk_max && c_lt > p.max_active) {
+        cur_cutoff = kth_smallest_in_range(tc + f0, nt, p.max_active, best, beam_cutoff, sh);
+        adaptive = (cur_cutoff - best) + p.beam_delta;
+      } else if (chk_min && c_le <= p.min_active) {
+        cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
+        adaptive = (cur_cutoff - best) + p.beam_delta;
+      }
     }
     LAT_T(0);
     // ---- acoustic scores of the frame ----
     const float* row = p.loglikes + (int64_t)n * p.seq_stride + (int64_t)t * p.frame_stride;
     for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
+    // ---- arc work list: one entry per emitting arc of the surviving tokens ----
+    int run = 0;          // arcs listed so far (all threads)
+    for (int base = f0; base < f1; base += 4 * kLatThreads) {
+      int2 ar[4];
+      int mine = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + tid * 4 + q;
+        ar[q] = make_int2(0, 0);
+        if (i < f1 && tc[i] <= cur_cutoff) ar[q] = V.tarc[i];
+        mine += ar[q].y;
+      }
+      int total;
+      int o = run + block_exclusive_scan(mine, sh, &total);
+      if (o + mine <= work_cap) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = base + tid * 4 + q;
+          for (int k = 0; k < ar[q].y; ++k) { V.work_tok[o + k] = i; V.work_arc[o + k] = ar[q].x + k; }
+          o += ar[q].y;
+        }
+      } else if (mine > 0) {
+        sh.status = kLatTokenOverflow;
+      }
+      run += total;
+    }
     __syncthreads();
+    if (sh.status != kLatOk) break;
+    const int n_arcs = run;
     LAT_T(1);
-    // ---- pass 1: best new cost ----
+    // ---- pass 1: cost of every listed arc, best new cost ----
     float nmin = INFINITY;
-    for_each_arc(sh, f0, f1, ts, p.g.e_off,
-                 [&](int i, float* c) { *c = tc[i]; return tc[i] <= cur_cutoff; },
-                 [&](int i, float c, int a) {
-                   const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[p.g.e_tid[a]]]);
-                   nmin = fminf(nmin, __fadd_rn(__fadd_rn(c, ac), p.g.e_w[a]));
-                 });
+    {
+      constexpr int U4 = 4;
+      for (int j0 = tid; j0 < n_arcs; j0 += U4 * kLatThreads) {
+        int a[U4], i[U4], tidl[U4]; float c[U4], gw[U4];
+#pragma unroll
+        for (int q = 0; q < U4; ++q) {
+          const int j = j0 + q * kLatThreads;
+          if (j < n_arcs) { a[q] = V.work_arc[j]; i[q] = V.work_tok[j]; }
+        }
+#pragma unroll
+        for (int q = 0; q < U4; ++q)
+          if (j0 + q * kLatThreads < n_arcs) { tidl[q] = p.g.e_tid[a[q]]; gw[q] = p.g.e_w[a[q]]; c[q] = tc[i[q]]; }
+#pragma unroll
+        for (int q = 0; q < U4; ++q) {
+          const int j = j0 + q * kLatThreads;
+          if (j < n_arcs) {
+            const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl[q]]]);
+            const float tot = __fadd_rn(__fadd_rn(c[q], ac), gw[q]);
+            V.work_tot[j] = tot;
+            nmin = fminf(nmin, tot);
+          }
+        }
+      }
+    }
     nmin = block_min(nmin, sh);
     if (!(nmin < INFINITY)) { if (tid == 0) sh.status = kLatNoSurvivor; __syncthreads(); break; }
     const float next_cutoff = nmin + adaptive;
     LAT_T(2);
     // ---- pass 2: tokens and links of frame t+1 ----
     const int l0 = s_link_end;
-    for_each_arc(sh, f0, f1, ts, p.g.e_off,
-                 [&](int i, float* c) { *c = tc[i]; return tc[i] <= cur_cutoff; },
-                 [&](int i, float c, int a) {
-                   const int tidl = p.g.e_tid[a];
-                   const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl]]);
-                   const float gw = p.g.e_w[a];
-                   const float tot = __fadd_rn(__fadd_rn(c, ac), gw);
-                   if (tot < next_cutoff) {
-                     const int d = p.g.e_dst[a];
-                     const uint32_t old = atomicMin(&stc[d], enc_cost(tot));
-                     if (old == kEmpty) {
-                       const int idx = atomicAdd(&sh.n_new, 1);
-                       if (f1 + idx < U.tok_cap) {
-                         ts[f1 + idx] = d;
-                         tc[f1 + idx] = INFINITY;
-                         __hip_atomic_store(&stt[d], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                       } else {
-                         sh.status = kLatTokenOverflow;
-                       }
-                     }
-                     const int li = l0 + atomicAdd(&sh.n_link, 1);
-                     if (li < U.link_cap) {
-                       lsrc[li] = i; ldst[li] = d /* state for now */; ltid[li] = tidl; lgr[li] = gw; lac[li] = ac;
-                     } else {
-                       sh.status = kLatLinkOverflow;
-                     }
-                   }
-                 });
+    for (int j0 = tid; j0 < n_arcs; j0 += 4 * kLatThreads) {
+      float tot[4]; int a[4], d[4], tidl[4], src[4]; float gw[4]; uint32_t old[4]; bool acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q * kLatThreads;
+        acc[q] = false;
+        if (j < n_arcs) { tot[q] = V.work_tot[j]; a[q] = V.work_arc[j]; src[q] = V.work_tok[j]; acc[q] = tot[q] < next_cutoff; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (acc[q]) { d[q] = p.g.e_dst[a[q]]; tidl[q] = p.g.e_tid[a[q]]; gw[q] = p.g.e_w[a[q]]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (acc[q]) old[q] = atomicMin(&V.stc[d[q]], enc_cost(tot[q]));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!acc[q]) continue;
+        if (old[q] == kEmpty) register_token(p, V, sh, f1, atomicAdd(&sh.n_new, 1), d[q]);
+        const int li = l0 + atomicAdd(&sh.n_link, 1);
+        if (li < V.link_cap) {
+          lsrc[li] = src[q]; ldst[li] = d[q] /* state for now */; ltid[li] = tidl[q]; lgr[li] = gw[q];
+          lac[li] = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl[q]]]);
+        } else {
+          sh.status = kLatLinkOverflow;
+        }
+      }
+    }
     __syncthreads();
     if (sh.status != kLatOk) break;
     const int l1 = l0 + sh.n_link;
-    for (int l = l0 + tid; l < l1; l += kLatThreads) ldst[l] = f1 + ld_coherent(&stt[ldst[l]]);
+    for (int l = l0 + tid; l < l1; l += kLatThreads) ldst[l] = f1 + ld_coherent(&V.stt[ldst[l]]);
     __syncthreads();
     if (tid == 0) { s_link_end = l1; seg[2 * t + 2] = l1; sh.n_link = 0; }
     __syncthreads();
     LAT_T(3);
-    close_frame(p, U, sh, stc, stt, f1, next_cutoff, &s_link_end, &s_tok_end, 2 * t + 2);
+    close_frame(p, V, sh, f1, next_cutoff, &s_link_end, &s_tok_end, 2 * t + 2);
     if (tid == 0) ftok[t + 2] = s_tok_end;
     __syncthreads();
   }
@@ -432,8 +611,8 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     if (tid == 0) { p.L.utt[n].status = sh.status; p.L.utt[n].n_tok = s_tok_end; p.L.utt[n].n_link = s_link_end; }
     return;
   }
-
   LAT_T(7);
+
   // ---- final costs (ComputeFinalCosts) ----
   const int fT0 = ftok[T], fT1 = s_tok_end;
   int anyf = 0;
@@ -450,19 +629,20 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     const float fc = tf[i];
     te[i] = fc < INFINITY ? (tc[i] + fc) - best_final : INFINITY;
   }
+  for (int i = tid; i < s_tok_end; i += kLatThreads) V.tl[i] = 0;
   __syncthreads();
 
   // ---- lattice-beam pruning, last frame first (PruneForwardLinksFinal / PruneForwardLinks) ----
   uint32_t* teu = reinterpret_cast<uint32_t*>(te);   // extra costs are >= 0: their bit patterns order like the floats
   const float lbeam = p.lattice_beam;
   const float inv_scale = 1.0f / p.ac_scale;
-  int32_t* kept = p.L.seg_kept + U.frame_base;
-  int32_t* tl = p.L.tok_level + U.tok_base;
-  int32_t* maxlev = p.L.frame_maxlev + U.frame_base;
+  int32_t* kept = V.kept;
+  int32_t* tl = V.tl;
+  int32_t* maxlev = V.maxlev;
   for (int t = T; t >= 0; --t) {
     // epsilon links inside frame t, to the fixed point
     const int e0 = seg[2 * t], e1 = seg[2 * t + 1];
-    for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
+    for (int rounds = 0; rounds < kMaxEpsRounds && e1 > e0; ++rounds) {
       int changed = 0;
       for (int l = e0 + tid; l < e1; l += kLatThreads) {
         const int s = lsrc[l], d = ldst[l];
@@ -478,41 +658,42 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
       }
       if (!__syncthreads_or(changed)) break;
     }
-    const int ke = compact_links(p, U, sh, e0, e1, 1.0f, [&](int s, int d, float g, float a) {
-      const float ed = __uint_as_float(ld_coherent(&teu[d]));
-      return ed < INFINITY && (ed + ((tc[s] + g) - tc[d])) <= lbeam;
-    });
+    int ke = 0;
+    if (e1 > e0)
+      ke = compact_links(V, sh, e0, e1, 1.0f, [&](int s, int d, float g, float a) {
+        const float ed = __uint_as_float(ld_coherent(&teu[d]));
+        return ed < INFINITY && (ed + ((tc[s] + g) - tc[d])) <= lbeam;
+      });
     if (tid == 0) kept[2 * t] = ke;
     LAT_T(8);
     // epsilon DAG depth of the frame's tokens (order of the forward-backward inside the frame)
-    for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
-      int changed = 0;
-      for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) {
-        const int lv = ld_coherent(&tl[lsrc[l]]) + 1;
-        if (lv > atomicMax(&tl[ldst[l]], lv)) changed = 1;
+    int lev_max = 0;
+    if (ke > 0) {
+      for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
+        int changed = 0;
+        for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) {
+          const int lv = ld_coherent(&tl[lsrc[l]]) + 1;
+          if (lv > atomicMax(&tl[ldst[l]], lv)) changed = 1;
+        }
+        if (!__syncthreads_or(changed)) break;
       }
-      if (!__syncthreads_or(changed)) break;
+      float lm = 0.f;
+      for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[ldst[l]]));
+      lev_max = (int)(-block_min(-lm, sh));
     }
-    float lm = 0.f;
-    for (int i = ftok[t] + tid; i < ftok[t + 1]; i += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[i]));
-    const int lev_max = (int)(-block_min(-lm, sh));
     if (tid == 0) maxlev[t] = lev_max;
     LAT_T(9);
-    // emitting links t-1 -> t
+    // emitting links t-1 -> t: the extra costs of frame t are final, so pruning, the source tokens' extra costs
+    // and the compaction share one pass
     if (t > 0) {
       const int m0 = seg[2 * t - 1], m1 = seg[2 * t];
-      for (int l = m0 + tid; l < m1; l += kLatThreads) {
-        const int s = lsrc[l], d = ldst[l];
+      const int km = compact_links(V, sh, m0, m1, inv_scale, [&](int s, int d, float g, float a) {
         const float ed = __uint_as_float(ld_coherent(&teu[d]));
-        if (ed < INFINITY) {
-          float le = ed + (__fadd_rn(__fadd_rn(tc[s], lac[l]), lgr[l]) - tc[d]);
-          if (le <= lbeam) atomicMin(&teu[s], __float_as_uint(fmaxf(le, 0.f)));
-        }
-      }
-      __syncthreads();
-      const int km = compact_links(p, U, sh, m0, m1, inv_scale, [&](int s, int d, float g, float a) {
-        const float ed = __uint_as_float(ld_coherent(&teu[d]));
-        return ed < INFINITY && (ed + (__fadd_rn(__fadd_rn(tc[s], a), g) - tc[d])) <= lbeam;
+        if (!(ed < INFINITY)) return false;
+        const float le = ed + (__fadd_rn(__fadd_rn(tc[s], a), g) - tc[d]);
+        if (!(le <= lbeam)) return false;
+        atomicMin(&teu[s], __float_as_uint(fmaxf(le, 0.f)));
+        return true;
       });
       if (tid == 0) kept[2 * t - 1] = km;
     }
@@ -521,7 +702,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
   }
 #ifdef PK2_LAT_PROFILE
   if (tid == 0 && n == 0)
-    printf("lat_decode utt0 T=%d (10 ns ticks): cutoff %lld ll %lld pass1 %lld pass2 %lld closure %lld epslinks %lld reset %lld | final %lld prune_eps %lld levels %lld prune_em %lld\n",
+    printf("lat_decode utt0 T=%d (10 ns ticks): cutoff %lld worklist %lld pass1 %lld pass2 %lld closure %lld epslinks %lld finalise %lld | final %lld prune_eps %lld levels %lld prune_em %lld\n",
            T, sh.prof[0], sh.prof[1], sh.prof[2], sh.prof[3], sh.prof[4], sh.prof[5], sh.prof[6], sh.prof[7], sh.prof[8], sh.prof[9], sh.prof[10]);
 #endif
   if (tid == 0) {
