@@ -128,6 +128,28 @@ def den_roofline(den, logits_bf, lens, reps=5):
                 ms_per_launch=round(ms, 3), algorithmic_bytes=byts)
 
 
+def gemm_mfma_roofline(dev, rows, reps=10):
+    """MFMA utilisation of the BLSTM GEMMs (north star): the layer-1/2 input projection of this minibatch,
+    [rows, 1024] x [1024, 4096] (both directions' gates), f32 MFMA, timed with events on the launch stream."""
+    from pykaldi2_amd.lstm import _gemm, _p
+    M, N, K = int(rows), 4096, 1024
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        _gemm(0, 1, M, N, K, _p(A), K, _p(W), K, _p(C), N)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _gemm(0, 1, M, N, K, _p(A), K, _p(W), K, _p(C), N)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(tf, 1), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4),
+                kernel="pk2::gemm_f32_kernel (v_mfma_f32_32x32x2_f32): BLSTM input projection %d x %d x %d" % (M, N, K),
+                ms_per_launch=round(ms, 4))
+
+
 def usable_cores():
     """Cores this process may really use (affinity mask and cgroup quota), capped at 32."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -473,7 +495,7 @@ def main():
                                % args.batch,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P}},
-        "roofline": roof, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
+        "roofline": roof, "roofline_lstm_gemm": gemm_mfma_roofline(dev, len(lens) * max(lens)), "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
     }
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline (child process, %d cores)" % usable_cores())

@@ -14,11 +14,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c exit $?" >> $R/gpurun_out/summary.txt
 done
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/den_trace -o den -- python $R/bench.py --den-only > $R/gpurun_out/den_trace.log 2>&1
+for w in ce se; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o $w -- python $R/bench.py --$w --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$w.log 2>&1
+  echo "rocprof $w exit $?" >> $R/gpurun_out/summary.txt
+done
 cd $R
+python tools/prof_stats.py gpurun_out/prof_ce/ce_results.db 16 > gpurun_out/r01_ce_kernel_stats.txt
+python tools/prof_stats.py gpurun_out/prof_se/se_results.db 16 > gpurun_out/r01_se_kernel_stats.txt
+grep -h '"metric"' gpurun_out/prof_ce.log gpurun_out/prof_se.log > gpurun_out/r01_secondary_bench.json
 python tools/prof_stats.py gpurun_out/prof/bench_results.db 30 > gpurun_out/r01_bench_kernel_stats.txt
 python tools/prof_stats.py gpurun_out/den_trace/den_results.db 12 > gpurun_out/r01_den_kernel_stats.txt
 python tools/pmc_stats.py gpurun_out/pmc_FETCH_SIZE/den_results.db > gpurun_out/r01_den_pmc.txt
 python tools/pmc_stats.py gpurun_out/pmc_WRITE_SIZE/den_results.db >> gpurun_out/r01_den_pmc.txt
 grep -o '{"bound.*' gpurun_out/den_trace.log > gpurun_out/r01_den_only.json
-rm -rf gpurun_out/prof gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/den_trace
+rm -rf gpurun_out/prof gpurun_out/prof_ce gpurun_out/prof_se gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/den_trace
 cat gpurun_out/summary.txt; cat gpurun_out/bench.json
