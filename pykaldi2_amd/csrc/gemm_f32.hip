@@ -44,8 +44,14 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
     B += i0 * bt.sB0 + i1 * bt.sB1;
     C += i0 * bt.sC0 + i1 * bt.sC1;
   }
-  __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
+  // kSlabs slabs of BK = 16 k are staged per barrier pair.  Two slabs (32 k per iteration) were measured in the
+  // same job against one: equal or slower on every shape of the model (bench.py --gemm-only), so one it is.
+#ifndef PK2_GEMM_SLABS
+#define PK2_GEMM_SLABS 1
+#endif
+  constexpr int kSlabs = PK2_GEMM_SLABS;
+  __shared__ __attribute__((aligned(16))) float As[kSlabs][BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[kSlabs][BK * LDS_LD];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
@@ -58,33 +64,45 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[TILES], rb[TILES];
+  float4 ra[kSlabs][TILES], rb[kSlabs][TILES];
   // A is "k-contiguous" when not transposed ([M,K]); B is k-contiguous when transposed ([N,K]).
-  load_slab<!TA, TILES>(A, lda, m0, kbeg, M, K, vecA, ra);
-  load_slab<TB, TILES>(B, ldb, n0, kbeg, N, K, vecB, rb);
-  const int nk = (K - kbeg + BK - 1) / BK;
+#pragma unroll
+  for (int q = 0; q < kSlabs; ++q) {
+    load_slab<!TA, TILES>(A, lda, m0, kbeg + q * BK, M, K, vecA, ra[q]);
+    load_slab<TB, TILES>(B, ldb, n0, kbeg + q * BK, N, K, vecB, rb[q]);
+  }
+  const int nk = (K - kbeg + kSlabs * BK - 1) / (kSlabs * BK);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // previous tile fully consumed
-    store_slab<!TA, TILES>(As, ra);
-    store_slab<TB, TILES>(Bs, rb);
+#pragma unroll
+    for (int q = 0; q < kSlabs; ++q) {
+      store_slab<!TA, TILES>(As[q], ra[q]);
+      store_slab<TB, TILES>(Bs[q], rb[q]);
+    }
     __syncthreads();
     if (kt + 1 < nk) {
-      load_slab<!TA, TILES>(A, lda, m0, kbeg + (kt + 1) * BK, M, K, vecA, ra);
-      load_slab<TB, TILES>(B, ldb, n0, kbeg + (kt + 1) * BK, N, K, vecB, rb);
+#pragma unroll
+      for (int q = 0; q < kSlabs; ++q) {
+        load_slab<!TA, TILES>(A, lda, m0, kbeg + ((kt + 1) * kSlabs + q) * BK, M, K, vecA, ra[q]);
+        load_slab<TB, TILES>(B, ldb, n0, kbeg + ((kt + 1) * kSlabs + q) * BK, N, K, vecB, rb[q]);
+      }
     }
     const int kq = lane >> 5, li = lane & 31;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TILES], b[TILES];
+    for (int q = 0; q < kSlabs; ++q) {
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) a[i] = As[(kk + kq) * LDS_LD + wm + i * 32 + li];
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[TILES], b[TILES];
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) b[j] = Bs[(kk + kq) * LDS_LD + wn + j * 32 + li];
+        for (int i = 0; i < TILES; ++i) a[i] = As[q][(kk + kq) * LDS_LD + wm + i * 32 + li];
 #pragma unroll
-      for (int i = 0; i < TILES; ++i)
+        for (int j = 0; j < TILES; ++j) b[j] = Bs[q][(kk + kq) * LDS_LD + wn + j * 32 + li];
 #pragma unroll
-        for (int j = 0; j < TILES; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TILES; ++i)
+#pragma unroll
+          for (int j = 0; j < TILES; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
