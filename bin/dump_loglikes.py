@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Writes the acoustic model's log-likelihoods (logits - log prior) of a set of utterances to a Kaldi matrix
+archive -- command line of the reference's bin/dump_loglikes.py (same flags; the archive is what Kaldi's
+latgen-faster-mapped reads), running on libpk2hip.so: fbank + CMN + BLSTM forward on the device.
+
+  python bin/dump_loglikes.py -config configs/ce.yaml -model_path exp/ce/model.ce.0.tar -data_path dev.zip \
+      -prior_path exp/tri/final.occs -out_file exp/ce/loglikes.ark
+
+Checkpoints of the reference's NnetAM(LSTMStack) (keys `nnet.lstm.*`) and of LSTMAM (`lstm.*`), with or without
+DataParallel's `module.` prefix, load unchanged.  -synthetic draws seeded utterances and uses uniform priors.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch as th
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pykaldi2_amd import data, fbank, kaldi_io, lstm, se  # noqa: E402
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-config")
+    parser.add_argument("-model_path")
+    parser.add_argument("-data_path")
+    parser.add_argument("-prior_path", help="the path to load the final.occs file")
+    parser.add_argument("-transform", help="feature transformation matrix or mvn statistics")
+    parser.add_argument("-out_file", help="write out the log-probs to this file")
+    parser.add_argument("-batch_size", default=32, type=int, help="Override the batch size in the config")
+    parser.add_argument("-sweep_size", default=200, type=float, help="process n hours of data per sweep (default:60)")
+    parser.add_argument("-data_loader_threads", default=4, type=int, help="number of workers for data loading")
+    parser.add_argument("-synthetic", type=int, default=0, help="dump this many seeded synthetic utterances instead")
+    args = parser.parse_args()
+
+    with open(args.config) as f:
+        config = yaml.safe_load(f)
+    config["sweep_size"] = args.sweep_size
+    print("job starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
+    dev = th.device("cuda", 0)
+    mc = config["model_config"]
+    P = mc["label_size"]
+    model = lstm.LSTMAM(mc["feat_dim"], P, mc["hidden_size"], mc["num_layers"], mc["dropout"], True).to(dev)
+    if args.model_path:
+        assert os.path.isfile(args.model_path), "ERROR: model file {} does not exit!".format(args.model_path)
+        sd = th.load(args.model_path, map_location="cpu")["model"]
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        sd = {(k[5:] if k.startswith("nnet.") else k): v for k, v in sd.items()}   # NnetAM(LSTMStack) -> LSTMAM keys
+        model.load_state_dict(sd)
+        print("=> loaded checkpoint '{}' ".format(args.model_path))
+    if args.prior_path:
+        log_prior = se.log_prior_from_counts(se.read_kaldi_vector(args.prior_path)).to(dev)
+    else:
+        log_prior = se.log_prior_from_counts(np.ones(P)).to(dev)
+    transform = None
+    if args.transform and os.path.isfile(args.transform):
+        transform = fbank.GlobalMeanVarianceNormalization.load(args.transform)
+    if args.synthetic:
+        source = data.SyntheticSource(P, seed=11)
+        utts = [source.draw() for _ in range(args.synthetic)]
+    else:
+        source = data.ZipWavSource([dict(wav=args.data_path)])
+        utts = [(source._read(z, m), None, None, u) for z, m, u, _, _ in source.items]
+    fb = fbank.FbankExtractor()
+    model.eval()
+    n_batches = (len(utts) + args.batch_size - 1) // args.batch_size
+    with th.no_grad(), kaldi_io.MatrixWriter("ark:" + args.out_file) as llout:
+        for i in range(n_batches):
+            chunk = utts[i * args.batch_size:(i + 1) * args.batch_size]
+            lens = [u[0].shape[0] for u in chunk]
+            wav = th.from_numpy(np.concatenate([u[0] for u in chunk])).to(dev)
+            feats, frames, row_off = fb(wav, lens)
+            if transform is not None:
+                feats = transform(feats)
+            x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=True)
+            prediction = model.forward_time_major(x).transpose(0, 1)
+            # save only the unpadded part of each utterance in the batch
+            for j in range(len(chunk)):
+                llout[chunk[j][3]] = prediction[j, :frames[j], :] - log_prior
+            print("Process batch [{}/{}]".format(i + 1, n_batches))
+
+
+if __name__ == '__main__':
+    main()

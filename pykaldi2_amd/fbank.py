@@ -127,6 +127,36 @@ class GlobalMeanVarianceNormalization:
         std[np.isinf(std)] = 1.0
         return cls(mean.T, std.T)
 
+    @classmethod
+    def load(cls, path):
+        """The `-transform` file of the reference CLIs: a pickle of reader.preprocess.GlobalMeanVarianceNormalization
+        (bin/train_ce.py:98-100).  Only its mean_vec / std_vec (and the mean_norm / var_norm switches) are needed,
+        so the object is rebuilt as a plain attribute bag instead of importing the reference's class."""
+        import pickle
+
+        class _Bag:
+            def __setstate__(self, state):
+                self.__dict__.update(state)
+
+        class _Unpickler(pickle.Unpickler):
+            def find_class(self, module, name):
+                if module.startswith("numpy") or module in ("builtins", "collections", "_codecs"):
+                    return super().find_class(module, name)
+                return _Bag
+
+        with open(path, "rb") as f:
+            o = _Unpickler(f).load()
+        mean = np.asarray(o.mean_vec, np.float32).reshape(1, -1)
+        std = np.asarray(o.std_vec, np.float32).reshape(1, -1)
+        if not getattr(o, "mean_norm", True):
+            mean = np.zeros_like(mean)
+        if not getattr(o, "var_norm", True):
+            std = np.ones_like(std)
+        return cls(mean, std)
+
+    def __call__(self, x):
+        return self.apply_on_tensor(x)
+
     def apply_on_tensor(self, x):
         _lib.require_gpu()
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.mean_vec.shape[1]

@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 import yaml
@@ -57,3 +58,13 @@ def test_train_se_cli_synthetic(tmp_path, criterion):
     assert "Epoch: [0]" in out.stdout and "grad_norm" in out.stdout
     ck = torch.load(tmp_path / "exp" / "model.se.0.tar", map_location="cpu", weights_only=False)
     assert set(ck) == {"model", "optimizer", "epoch"} and "lstm.weight_hh_l1_reverse" in ck["model"]
+
+
+def test_dump_loglikes_cli_synthetic(tmp_path):
+    from pykaldi2_amd import kaldi_io
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "dump_loglikes.py"), "-config",
+                          _cfg(tmp_path, "ce.yaml", 120, True), "-out_file", str(tmp_path / "ll.ark"), "-batch_size", "2",
+                          "-synthetic", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    mats = list(kaldi_io.read_matrix_ark(str(tmp_path / "ll.ark")))
+    assert len(mats) == 3 and all(m.shape[1] == 120 and m.shape[0] > 100 and np.isfinite(m).all() for _, m in mats)

@@ -142,3 +142,49 @@ def test_synthetic_tid_alignment_is_consistent():
     for t in range(199):
         if ali[t] % 2 == 1:
             assert ali[t + 1] in (ali[t], ali[t] + 1)
+
+
+def test_kaldi_matrix_ark_roundtrip(tmp_path):
+    from pykaldi2_amd import kaldi_io
+    rng = np.random.default_rng(0)
+    mats = {"utt-a": rng.standard_normal((5, 7)).astype(np.float32), "utt-b": rng.standard_normal((1, 3)).astype(np.float32)}
+    path = str(tmp_path / "ll.ark")
+    with kaldi_io.MatrixWriter("ark:" + path) as w:
+        for k, m in mats.items():
+            w[k] = m
+    raw = open(path, "rb").read()
+    assert raw.startswith(b"utt-a \0BFM \x04\x05\x00\x00\x00\x04\x07\x00\x00\x00")      # Kaldi's binary matrix header
+    got = dict(kaldi_io.read_matrix_ark(path))
+    assert list(got) == ["utt-a", "utt-b"] and all(np.array_equal(got[k], mats[k]) for k in mats)
+    (tmp_path / "t.ark").write_text("utt-c  [\n  1 2 3\n  4 5 6 ]\n")
+    (k, m), = kaldi_io.read_matrix_ark(str(tmp_path / "t.ark"))
+    assert k == "utt-c" and np.array_equal(m, np.array([[1, 2, 3], [4, 5, 6]], np.float32))
+
+
+def test_mvn_transform_pickle_of_the_reference_class(tmp_path):
+    """-transform files are pickles of reader.preprocess.GlobalMeanVarianceNormalization; they load without that
+    module being importable."""
+    import pickle
+    import sys
+    import types
+    from pykaldi2_amd import fbank
+    mod = types.ModuleType("reader.preprocess")
+    pkg = types.ModuleType("reader")
+
+    class GlobalMeanVarianceNormalization:
+        pass
+    GlobalMeanVarianceNormalization.__module__ = "reader.preprocess"
+    GlobalMeanVarianceNormalization.__qualname__ = "GlobalMeanVarianceNormalization"
+    mod.GlobalMeanVarianceNormalization = GlobalMeanVarianceNormalization
+    sys.modules["reader"], sys.modules["reader.preprocess"] = pkg, mod
+    try:
+        o = GlobalMeanVarianceNormalization()
+        o.mean_vec = np.arange(80, dtype=np.float32).reshape(1, 80)
+        o.std_vec = np.full((1, 80), 2.0, np.float32)
+        o.mean_norm, o.var_norm = True, True
+        with open(tmp_path / "mvn.pkl", "wb") as f:
+            pickle.dump(o, f)
+    finally:
+        del sys.modules["reader"], sys.modules["reader.preprocess"]
+    t = fbank.GlobalMeanVarianceNormalization.load(str(tmp_path / "mvn.pkl"))
+    assert np.array_equal(t.mean_vec, o.mean_vec) and np.array_equal(t.std_vec, o.std_vec)
