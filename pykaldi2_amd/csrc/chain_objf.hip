@@ -126,8 +126,11 @@ extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* lo
   //    denominator uses the caller's stream.
   // (side stream only with PK2_SIDE_STREAM=1: on ROCm 7.2 a second active stream slows the graph-replayed
   //  frame chain of the denominator more than the overlap returns)
+  // PK2_NUM_SIDE=1 moves only the numerator: measured chain 15.3 -> 14.3 ms (the overlap works) but the next
+  // step's graph-replayed LSTM forward 10.5 -> 12.6 ms once a second stream has been active: net loss, default off.
   const char* ss = getenv("PK2_SIDE_STREAM");
-  const bool use_side = ss != nullptr && ss[0] == '1';
+  const char* ns = getenv("PK2_NUM_SIDE");
+  const bool use_side = (ss != nullptr && ss[0] == '1') || (ns != nullptr && ns[0] == '1');
   SideStream* side = nullptr;
   int rc = use_side ? get_side_stream(stream, &side) : 0;
   if (rc) return rc;
