@@ -9,7 +9,7 @@ model.se.{epoch}.tar = {'model','optimizer','epoch'}), running on libpk2hip.so.
 
 Lattices are generated, pruned and consumed on the device for the whole minibatch (pykaldi2_amd.lattice); the
 reference decodes each utterance on the CPU with Kaldi (ops/ops.py:55).  Differences by necessity (no Kaldi
-here, DESIGN.md section 7): `-trans_model` must be in Kaldi's text form (copy-transition-model --binary=false);
+here, DESIGN.md section 7): `-trans_model` is read in Kaldi's binary or text form by the library's own reader;
 `words.txt` is not needed (no criterion uses word labels); -synthetic trains on the seeded generators
 (LibriSpeech-shaped utterances, a word-loop HCLG, a 3-state monophone transition model, uniform priors).
 """

@@ -47,15 +47,14 @@ class TransitionModel:
 
     @classmethod
     def read(cls, path):
-        """Kaldi text-format transition model (`copy-transition-model --binary=false`), [upstream knowledge
-        of the format: <TransitionModel> <Topology> ... </Topology> <Triples>|<Tuples> n ... ].  Transition
-        ids enumerate, for every tuple in file order, the transitions of its HMM state in topology order."""
+        """Kaldi transition model, text (`copy-transition-model --binary=false`) or binary (`final.mdl`) form
+        [upstream knowledge of the formats: <TransitionModel> <Topology> ... </Topology> <Triples>|<Tuples> n ... ].
+        Transition ids enumerate, for every tuple in file order, the transitions of its HMM state in topology order."""
         with open(path, "rb") as f:
             head = f.read(2)
             if head == b"\0B":
-                raise ValueError("%s: binary transition models are not supported; convert with "
-                                 "copy-transition-model --binary=false" % path)
-            toks = (head + f.read()).decode().split()
+                return cls._read_binary(f.read(), path)
+            toks = (head + f.read()).decode(errors="replace").split()
         pos = toks.index("<Topology>")
         phone_entry, entries = {}, []
         i = pos + 1
@@ -104,6 +103,74 @@ class TransitionModel:
                 # in a <Tuples> model the self-loop (the transition back to hmm_state) carries its own pdf
                 tid2pdf.append(loop_pdf if dst_state == hmm_state else fwd_pdf)
                 tid2phone.append(phone)
+        return cls(tid2pdf, tid2phone)
+
+    @classmethod
+    def _read_binary(cls, raw, path):
+        """Kaldi binary form (`final.mdl`, `0.trans_mdl`; anything after </TransitionModel>, e.g. the GMMs, is
+        ignored).  [upstream knowledge: TransitionModel::Read / HmmTopology::Read -- tokens are "<Name> ", an
+        int32 / float is a size byte 4 followed by 4 little-endian bytes, an integer vector is a size byte 4, an
+        int32 count and the raw values; the topology is dumped as phones, phone2idx, entries (a leading -1 marks
+        the non-HMM form with separate self-loop pdf classes)]"""
+        import struct
+        pos = 0
+
+        def token(expect=None):
+            nonlocal pos
+            end = raw.index(b" ", pos)
+            t = raw[pos:end].decode()
+            pos = end + 1
+            if expect is not None and t != expect:
+                raise ValueError("%s: expected %s, found %s" % (path, expect, t))
+            return t
+
+        def i32():
+            nonlocal pos
+            assert raw[pos] == 4, "%s: bad int marker at byte %d" % (path, pos)
+            v = struct.unpack_from("<i", raw, pos + 1)[0]
+            pos += 5
+            return v
+
+        def ivec():
+            nonlocal pos
+            assert raw[pos] == 4
+            n = struct.unpack_from("<i", raw, pos + 1)[0]
+            v = list(struct.unpack_from("<%di" % n, raw, pos + 5))
+            pos += 5 + 4 * n
+            return v
+
+        token("<TransitionModel>")
+        token("<Topology>")
+        phones, phone2idx = ivec(), ivec()
+        sz = i32()
+        is_hmm = True
+        if sz == -1:
+            is_hmm = False
+            sz = i32()
+        entries = []
+        for _ in range(sz):
+            states = []
+            for _ in range(i32()):
+                i32()                      # forward pdf class
+                if not is_hmm:
+                    i32()                  # self-loop pdf class
+                dsts = []
+                for _ in range(i32()):
+                    dsts.append(i32())
+                    i32()                  # probability (float, same 5-byte encoding)
+                states.append(dsts)
+            entries.append(states)
+        token("</Topology>")
+        tag = token()
+        assert tag in ("<Triples>", "<Tuples>"), tag
+        tid2pdf, tid2phone = [-1], [0]
+        for _ in range(i32()):
+            phone, hmm_state, fwd_pdf = i32(), i32(), i32()
+            loop_pdf = i32() if tag == "<Tuples>" else fwd_pdf
+            for dst_state in entries[phone2idx[phone]][hmm_state]:
+                tid2pdf.append(loop_pdf if dst_state == hmm_state else fwd_pdf)
+                tid2phone.append(phone)
+        token("</Triples>" if tag == "<Triples>" else "</Tuples>")
         return cls(tid2pdf, tid2phone)
 
     def num_transition_ids(self):

@@ -114,9 +114,25 @@ def test_transition_model_text_reader(tmp_path):
     tm2 = lattice.TransitionModel.read(str(p))
     # the self-loop (transition back to the same HMM state) carries the self-loop pdf
     assert tm2.tid2pdf.tolist() == [-1, 5, 0, 0, 6, 1, 7, 2, 8, 3, 9, 4, 10, 2]
-    (tmp_path / "bin.mdl").write_bytes(b"\0B<TransitionModel> ")
-    with pytest.raises(ValueError, match="binary"):
-        lattice.TransitionModel.read(str(tmp_path / "bin.mdl"))
+    # the same model in Kaldi's binary form (assembled from the published encoding), GMM payload after it ignored
+    i32 = lambda v: b"\x04" + struct.pack("<i", v)
+    f32 = lambda v: b"\x04" + struct.pack("<f", v)
+    ivec = lambda v: b"\x04" + struct.pack("<i", len(v)) + struct.pack("<%di" % len(v), *v)
+
+    def entry(states):
+        out = i32(len(states))
+        for pdf_class, trans in states:
+            out += i32(pdf_class) + i32(len(trans)) + b"".join(i32(d) + f32(p) for d, p in trans)
+        return out
+    e23 = [(0, [(0, 0.75), (1, 0.25)]), (1, [(1, 0.75), (2, 0.25)]), (-1, [])]
+    e1 = [(0, [(0, 0.5), (1, 0.25), (2, 0.25)]), (1, [(1, 0.5), (2, 0.5)]), (-1, [])]
+    raw = (b"\0B<TransitionModel> <Topology> " + ivec([1, 2, 3]) + ivec([-1, 1, 0, 0]) + i32(2) + entry(e23) + entry(e1) +
+           b"</Topology> <Triples> " + i32(6) +
+           b"".join(i32(a) + i32(b) + i32(c) for a, b, c in [(1, 0, 0), (1, 1, 1), (2, 0, 2), (2, 1, 3), (3, 0, 4), (3, 1, 2)]) +
+           b"</Triples> <LogProbs> FV " + i32(2) + struct.pack("<2f", 0.0, -0.69) + b"</LogProbs> </TransitionModel> <DIMENSION> junk")
+    (tmp_path / "final.mdl").write_bytes(raw)
+    tmb = lattice.TransitionModel.read(str(tmp_path / "final.mdl"))
+    assert tmb.tid2pdf.tolist() == tm.tid2pdf.tolist() and tmb.tid2phone.tolist() == tm.tid2phone.tolist()
 
 
 def test_prior_readers(tmp_path):
