@@ -269,10 +269,11 @@ struct UttView {
   uint32_t* stc; int32_t* stt;
   int32_t* ts; float* tc; float* te; float* tf; int32_t* tl;
   int2* tarc;                                   // [tok_cap] {e_off[state], emitting degree}        (alpha region)
-  int32_t* work_tok; int32_t* work_arc;         // [tok_cap] each                                    (beta / acc_f)
-  float* work_tot; int32_t* elist;              // [tok_cap] each                                    (acc_b)
+  int2* work;                                   // [tok_cap] {token, emitting arc}                   (beta region)
+  float* work_tot; int32_t* elist;              // [tok_cap] each                                    (acc_f / acc_b)
   int32_t* ftok; int32_t* seg; int32_t* kept; int32_t* maxlev;
-  int32_t* lsrc; int32_t* ldst; int32_t* ltid; float* lgr; float* lac;
+  int4* lrec; float* lac;                       // links: {src token, dst token, transition-id, graph cost bits}, acoustic cost
+  const int4* erec;                             // packed emitting arcs {dst state, transition-id, weight bits, pdf}
   int tok_cap, link_cap;
 };
 
@@ -340,10 +341,7 @@ __device__ void close_frame(const DecodeParams& p, const UttView& V, Shared& sh,
                  if (tot < cutoff) {
                    const int li = l0 + atomicAdd(&sh.n_link, 1);
                    if (li < V.link_cap) {
-                     V.lsrc[li] = i;
-                     V.ldst[li] = f0 + ld_coherent(&V.stt[p.g.n_dst[a]]);
-                     V.ltid[li] = 0;
-                     V.lgr[li] = p.g.n_w[a];
+                     V.lrec[li] = make_int4(i, f0 + ld_coherent(&V.stt[p.g.n_dst[a]]), 0, __float_as_int(p.g.n_w[a]));
                      V.lac[li] = 0.f;
                    } else {
                      sh.status = kLatLinkOverflow;
@@ -415,27 +413,34 @@ __device__ int compact_links(const UttView& V, Shared& sh, int l0, int l1, float
   const int tid = threadIdx.x;
   int out = l0;
   for (int base = l0; base < l1; base += KPT * kLatThreads) {
-    int s[KPT], d[KPT], t[KPT]; float g[KPT], a[KPT]; bool k[KPT];
+    int4 r[KPT]; float a[KPT]; bool k[KPT];
     const int lb = base + tid * KPT;
 #pragma unroll
     for (int q = 0; q < KPT; ++q) {
       const int l = lb + q;
       k[q] = false;
-      if (l < l1) { s[q] = V.lsrc[l]; d[q] = V.ldst[l]; t[q] = V.ltid[l]; g[q] = V.lgr[l]; a[q] = V.lac[l]; }
+      if (l < l1) { r[q] = V.lrec[l]; a[q] = V.lac[l]; }
     }
     int mine = 0;
 #pragma unroll
     for (int q = 0; q < KPT; ++q)
-      if (lb + q < l1) { k[q] = keep(s[q], d[q], g[q], a[q]); mine += k[q]; }
+      if (lb + q < l1) { k[q] = keep(r[q].x, r[q].y, __int_as_float(r[q].w), a[q]); mine += k[q]; }
     int total;
     int o = out + block_exclusive_scan(mine, sh, &total);   // barriers inside: every link of the pass is in registers
 #pragma unroll
     for (int q = 0; q < KPT; ++q)
-      if (k[q]) { V.lsrc[o] = s[q]; V.ldst[o] = d[q]; V.ltid[o] = t[q]; V.lgr[o] = g[q]; V.lac[o] = __fmul_rn(a[q], ac_mul); ++o; }
+      if (k[q]) { V.lrec[o] = r[q]; V.lac[o] = __fmul_rn(a[q], ac_mul); ++o; }
     out += total;
     __syncthreads();
   }
   return out - l0;
+}
+
+// Packs the emitting arcs of HCLG with the pdf of their transition-id (one 16-byte gather per arc in the decoder).
+__global__ void __launch_bounds__(256) lat_pack_arcs(DevDecodeGraph g, const int32_t* __restrict__ tid2pdf, int64_t n,
+                                                     int4* __restrict__ out) {
+  const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a < n) out[a] = make_int4(g.e_dst[a], g.e_tid[a], __float_as_int(g.e_w[a]), tid2pdf[g.e_tid[a]]);
 }
 
 __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p) {
@@ -449,18 +454,17 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
   V.ts = p.L.tok_state + U.tok_base; V.tc = p.L.tok_cost + U.tok_base; V.te = p.L.tok_extra + U.tok_base;
   V.tf = p.L.tok_final + U.tok_base; V.tl = p.L.tok_level + U.tok_base;
   V.tarc = reinterpret_cast<int2*>(p.L.alpha + U.tok_base);
-  V.work_tok = reinterpret_cast<int32_t*>(p.L.beta + U.tok_base);
-  V.work_arc = V.work_tok + U.tok_cap;
+  V.work = reinterpret_cast<int2*>(p.L.beta + U.tok_base);
   V.work_tot = reinterpret_cast<float*>(p.L.acc_f + U.tok_base);
   V.elist = reinterpret_cast<int32_t*>(p.L.acc_b + U.tok_base);
   V.ftok = p.L.frame_tok + U.frame_base; V.seg = p.L.seg_off + U.frame_base;
   V.kept = p.L.seg_kept + U.frame_base; V.maxlev = p.L.frame_maxlev + U.frame_base;
-  V.lsrc = p.L.link_src + U.link_base; V.ldst = p.L.link_dst + U.link_base; V.ltid = p.L.link_tid + U.link_base;
-  V.lgr = p.L.link_graph + U.link_base; V.lac = p.L.link_ac + U.link_base;
+  V.lrec = p.L.link_rec + U.link_base; V.lac = p.L.link_ac + U.link_base;
+  V.erec = p.L.e_rec;
   V.tok_cap = U.tok_cap; V.link_cap = U.link_cap;
   int32_t* ts = V.ts; float* tc = V.tc; float* te = V.te; float* tf = V.tf;
   int32_t* ftok = V.ftok; int32_t* seg = V.seg;
-  int32_t* lsrc = V.lsrc; int32_t* ldst = V.ldst; int32_t* ltid = V.ltid; float* lgr = V.lgr; float* lac = V.lac;
+  int4* lrec = V.lrec; float* lac = V.lac;
   const int work_cap = U.tok_cap;
 
   if (tid == 0) {
@@ -523,7 +527,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = base + tid * 4 + q;
-          for (int k = 0; k < ar[q].y; ++k) { V.work_tok[o + k] = i; V.work_arc[o + k] = ar[q].x + k; }
+          for (int k = 0; k < ar[q].y; ++k) V.work[o + k] = make_int2(i, ar[q].x + k);
           o += ar[q].y;
         }
       } else if (mine > 0) {
@@ -540,21 +544,19 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     {
       constexpr int U4 = 4;
       for (int j0 = tid; j0 < n_arcs; j0 += U4 * kLatThreads) {
-        int a[U4], i[U4], tidl[U4]; float c[U4], gw[U4];
-#pragma unroll
-        for (int q = 0; q < U4; ++q) {
-          const int j = j0 + q * kLatThreads;
-          if (j < n_arcs) { a[q] = V.work_arc[j]; i[q] = V.work_tok[j]; }
-        }
+        int2 wk[U4]; int4 er[U4]; float c[U4];
 #pragma unroll
         for (int q = 0; q < U4; ++q)
-          if (j0 + q * kLatThreads < n_arcs) { tidl[q] = p.g.e_tid[a[q]]; gw[q] = p.g.e_w[a[q]]; c[q] = tc[i[q]]; }
+          if (j0 + q * kLatThreads < n_arcs) wk[q] = V.work[j0 + q * kLatThreads];
+#pragma unroll
+        for (int q = 0; q < U4; ++q)
+          if (j0 + q * kLatThreads < n_arcs) { er[q] = V.erec[wk[q].y]; c[q] = tc[wk[q].x]; }
 #pragma unroll
         for (int q = 0; q < U4; ++q) {
           const int j = j0 + q * kLatThreads;
           if (j < n_arcs) {
-            const float ac = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl[q]]]);
-            const float tot = __fadd_rn(__fadd_rn(c[q], ac), gw[q]);
+            const float ac = -__fmul_rn(p.ac_scale, sh.ll[er[q].w]);
+            const float tot = __fadd_rn(__fadd_rn(c[q], ac), __int_as_float(er[q].z));
             V.work_tot[j] = tot;
             nmin = fminf(nmin, tot);
           }
@@ -568,27 +570,28 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     // ---- pass 2: tokens and links of frame t+1 ----
     const int l0 = s_link_end;
     for (int j0 = tid; j0 < n_arcs; j0 += 4 * kLatThreads) {
-      float tot[4]; int a[4], d[4], tidl[4], src[4]; float gw[4]; uint32_t old[4]; bool acc[4];
+      float tot[4]; int2 wk[4]; int4 er[4]; uint32_t old[4]; bool acc[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j = j0 + q * kLatThreads;
         acc[q] = false;
-        if (j < n_arcs) { tot[q] = V.work_tot[j]; a[q] = V.work_arc[j]; src[q] = V.work_tok[j]; acc[q] = tot[q] < next_cutoff; }
+        if (j < n_arcs) { tot[q] = V.work_tot[j]; acc[q] = tot[q] < next_cutoff; }
+        if (acc[q]) wk[q] = V.work[j];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (acc[q]) { d[q] = p.g.e_dst[a[q]]; tidl[q] = p.g.e_tid[a[q]]; gw[q] = p.g.e_w[a[q]]; }
+        if (acc[q]) er[q] = V.erec[wk[q].y];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (acc[q]) old[q] = atomicMin(&V.stc[d[q]], enc_cost(tot[q]));
+        if (acc[q]) old[q] = atomicMin(&V.stc[er[q].x], enc_cost(tot[q]));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (!acc[q]) continue;
-        if (old[q] == kEmpty) register_token(p, V, sh, f1, atomicAdd(&sh.n_new, 1), d[q]);
+        if (old[q] == kEmpty) register_token(p, V, sh, f1, atomicAdd(&sh.n_new, 1), er[q].x);
         const int li = l0 + atomicAdd(&sh.n_link, 1);
         if (li < V.link_cap) {
-          lsrc[li] = src[q]; ldst[li] = d[q] /* state for now */; ltid[li] = tidl[q]; lgr[li] = gw[q];
-          lac[li] = -__fmul_rn(p.ac_scale, sh.ll[p.tid2pdf[tidl[q]]]);
+          lrec[li] = make_int4(wk[q].x, er[q].x /* state for now */, er[q].y, er[q].z);
+          lac[li] = -__fmul_rn(p.ac_scale, sh.ll[er[q].w]);
         } else {
           sh.status = kLatLinkOverflow;
         }
@@ -597,7 +600,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     __syncthreads();
     if (sh.status != kLatOk) break;
     const int l1 = l0 + sh.n_link;
-    for (int l = l0 + tid; l < l1; l += kLatThreads) ldst[l] = f1 + ld_coherent(&V.stt[ldst[l]]);
+    for (int l = l0 + tid; l < l1; l += kLatThreads) lrec[l].y = f1 + ld_coherent(&V.stt[lrec[l].y]);
     __syncthreads();
     if (tid == 0) { s_link_end = l1; seg[2 * t + 2] = l1; sh.n_link = 0; }
     __syncthreads();
@@ -645,10 +648,11 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
     for (int rounds = 0; rounds < kMaxEpsRounds && e1 > e0; ++rounds) {
       int changed = 0;
       for (int l = e0 + tid; l < e1; l += kLatThreads) {
-        const int s = lsrc[l], d = ldst[l];
+        const int4 r = lrec[l];
+        const int s = r.x, d = r.y;
         const float ed = __uint_as_float(ld_coherent(&teu[d]));
         if (ed < INFINITY) {
-          float le = ed + ((tc[s] + lgr[l]) - tc[d]);
+          float le = ed + ((tc[s] + __int_as_float(r.w)) - tc[d]);
           if (le <= lbeam) {
             le = fmaxf(le, 0.f);
             const uint32_t k = __float_as_uint(le);
@@ -672,13 +676,14 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
       for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
         int changed = 0;
         for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) {
-          const int lv = ld_coherent(&tl[lsrc[l]]) + 1;
-          if (lv > atomicMax(&tl[ldst[l]], lv)) changed = 1;
+          const int4 r = lrec[l];
+          const int lv = ld_coherent(&tl[r.x]) + 1;
+          if (lv > atomicMax(&tl[r.y], lv)) changed = 1;
         }
         if (!__syncthreads_or(changed)) break;
       }
       float lm = 0.f;
-      for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[ldst[l]]));
+      for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[lrec[l].y]));
       lev_max = (int)(-block_min(-lm, sh));
     }
     if (tid == 0) maxlev[t] = lev_max;
@@ -738,6 +743,9 @@ extern "C" int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, i
   p.tid2pdf = tid2pdf; p.num_tids = num_tids;
   p.beam = b->opts.beam; p.lattice_beam = b->opts.lattice_beam; p.beam_delta = b->opts.beam_delta;
   p.ac_scale = b->opts.acoustic_scale; p.max_active = b->opts.max_active; p.min_active = b->opts.min_active;
+  const int64_t n_emit = (int64_t)b->graph->e_dst.size();
+  if (n_emit > 0)
+    hipLaunchKernelGGL(lat_pack_arcs, dim3((unsigned)((n_emit + 255) / 256)), dim3(256), 0, stream, p.g, tid2pdf, n_emit, L.e_rec);
   hipLaunchKernelGGL(lat_decode_kernel, dim3(b->N), dim3(kLatThreads), 0, stream, p);
   PK2_LAUNCH_CHECK();
   b->decoded = true;

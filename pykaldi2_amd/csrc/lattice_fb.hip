@@ -99,9 +99,8 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
   const int32_t* seg = p.L.seg_off + U.frame_base;
   const int32_t* kept = p.L.seg_kept + U.frame_base;
   const int32_t* maxlev = p.L.frame_maxlev + U.frame_base;
-  const int32_t* lsrc = p.L.link_src + U.link_base; const int32_t* ldst = p.L.link_dst + U.link_base;
-  const int32_t* ltid = p.L.link_tid + U.link_base;
-  const float* lgr = p.L.link_graph + U.link_base; const float* lac = p.L.link_ac + U.link_base;
+  const int4* lrec = p.L.link_rec + U.link_base;      // {src token, dst token, transition-id, graph cost bits}
+  const float* lac = p.L.link_ac + U.link_base;
   const int32_t* tl = p.L.tok_level + U.tok_base;
   const float* tf = p.L.tok_final + U.tok_base;
   double* alpha = p.L.alpha + U.tok_base; double* beta = p.L.beta + U.tok_base;
@@ -109,7 +108,9 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
   const int32_t* ref = p.ref_tids + (int64_t)n * p.ref_stride;
   double* ref_post = p.L.ref_post + U.frame_base;
   // fst::ScaleLattice stores the scaled weights as floats; the forward-backward then sums them in double
-  auto like = [&](int l) { return -((double)(float)(p.lm_scale * (double)lgr[l]) + (double)(float)(p.ac_scale * (double)lac[l])); };
+  auto like = [&](const int4& r, int l) {
+    return -((double)(float)(p.lm_scale * (double)__int_as_float(r.w)) + (double)(float)(p.ac_scale * (double)lac[l]));
+  };
   auto final_like = [&](int i) { return -(double)(float)(p.lm_scale * (double)tf[i]); };
 
   for (int i = tid; i < nt; i += kFbThreads) { alpha[i] = -INFINITY; beta[i] = -INFINITY; af[i] = 0.0; ab[i] = 0.0; }
@@ -122,13 +123,18 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
   for (int t = 0; t <= T; ++t) {
     if (t > 0) {
       const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) atomic_log_add(&alpha[ldst[l]], ldc(&alpha[lsrc[l]]) + like(l));
+      for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        const int4 r = lrec[l];
+        atomic_log_add(&alpha[r.y], ldc(&alpha[r.x]) + like(r, l));
+      }
       __syncthreads();
     }
     const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
     for (int lev = 0; lev < maxlev[t]; ++lev) {
-      for (int l = e0 + tid; l < e1; l += kFbThreads)
-        if (tl[lsrc[l]] == lev) atomic_log_add(&alpha[ldst[l]], ldc(&alpha[lsrc[l]]) + like(l));
+      for (int l = e0 + tid; l < e1; l += kFbThreads) {
+        const int4 r = lrec[l];
+        if (tl[r.x] == lev) atomic_log_add(&alpha[r.y], ldc(&alpha[r.x]) + like(r, l));
+      }
       __syncthreads();
     }
   }
@@ -150,13 +156,18 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
   for (int t = T; t >= 0; --t) {
     const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
     for (int lev = maxlev[t] - 1; lev >= 0; --lev) {
-      for (int l = e0 + tid; l < e1; l += kFbThreads)
-        if (tl[lsrc[l]] == lev) atomic_log_add(&beta[lsrc[l]], ldc(&beta[ldst[l]]) + like(l));
+      for (int l = e0 + tid; l < e1; l += kFbThreads) {
+        const int4 r = lrec[l];
+        if (tl[r.x] == lev) atomic_log_add(&beta[r.x], ldc(&beta[r.y]) + like(r, l));
+      }
       __syncthreads();
     }
     if (t > 0) {
       const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) atomic_log_add(&beta[lsrc[l]], ldc(&beta[ldst[l]]) + like(l));
+      for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        const int4 r = lrec[l];
+        atomic_log_add(&beta[r.x], ldc(&beta[r.y]) + like(r, l));
+      }
       __syncthreads();
     }
   }
@@ -167,16 +178,20 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
     for (int t = 0; t < T; ++t) {
       const int m0 = seg[2 * t + 1], m1 = m0 + kept[2 * t + 1];
       const int r = ref[t];
-      for (int l = m0 + tid; l < m1; l += kFbThreads)
-        if (ltid[l] == r) atomicAdd(&ref_post[t], exp(ldc(&alpha[lsrc[l]]) + like(l) + ldc(&beta[ldst[l]]) - tot));
+      for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        const int4 q = lrec[l];
+        if (q.z == r) atomicAdd(&ref_post[t], exp(ldc(&alpha[q.x]) + like(q, l) + ldc(&beta[q.y]) - tot));
+      }
     }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
       if (p.drop_frames && ldc(&ref_post[t]) == 0.0) continue;
       const int m0 = seg[2 * t + 1], m1 = m0 + kept[2 * t + 1];
       float* row = post + (int64_t)t * p.post_frame_stride;
-      for (int l = m0 + tid; l < m1; l += kFbThreads)
-        atomicAdd(&row[p.tid2pdf[ltid[l]]], -(float)exp(ldc(&alpha[lsrc[l]]) + like(l) + ldc(&beta[ldst[l]]) - tot));
+      for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        const int4 q = lrec[l];
+        atomicAdd(&row[p.tid2pdf[q.z]], -(float)exp(ldc(&alpha[q.x]) + like(q, l) + ldc(&beta[q.y]) - tot));
+      }
       if (tid == 0) atomicAdd(&row[p.tid2pdf[ref[t]]], 1.0f);
     }
     if (tid == 0) p.out[n] = tot;
@@ -189,16 +204,18 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
       const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
       const int r = ref[t - 1];
       for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int s = lsrc[l], d = ldst[l];
-        atomicAdd(&af[d], exp(ldc(&alpha[s]) + like(l) - ldc(&alpha[d])) * (ldc(&af[s]) + frame_acc(p, ltid[l], r)));
+        const int4 q = lrec[l];
+        const int s = q.x, d = q.y;
+        atomicAdd(&af[d], exp(ldc(&alpha[s]) + like(q, l) - ldc(&alpha[d])) * (ldc(&af[s]) + frame_acc(p, q.z, r)));
       }
       __syncthreads();
     }
     const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
     for (int lev = 0; lev < maxlev[t]; ++lev) {
       for (int l = e0 + tid; l < e1; l += kFbThreads) {
-        const int s = lsrc[l], d = ldst[l];
-        if (tl[s] == lev) atomicAdd(&af[d], exp(ldc(&alpha[s]) + like(l) - ldc(&alpha[d])) * ldc(&af[s]));
+        const int4 q = lrec[l];
+        const int s = q.x, d = q.y;
+        if (tl[s] == lev) atomicAdd(&af[d], exp(ldc(&alpha[s]) + like(q, l) - ldc(&alpha[d])) * ldc(&af[s]));
       }
       __syncthreads();
     }
@@ -212,9 +229,10 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
     const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
     for (int lev = maxlev[t] - 1; lev >= 0; --lev) {
       for (int l = e0 + tid; l < e1; l += kFbThreads) {
-        const int s = lsrc[l], d = ldst[l];
+        const int4 q = lrec[l];
+        const int s = q.x, d = q.y;
         const double bs = ldc(&beta[s]), bd = ldc(&beta[d]);
-        if (tl[s] == lev && bs > -INFINITY && bd > -INFINITY) atomicAdd(&ab[s], exp(bd + like(l) - bs) * ldc(&ab[d]));
+        if (tl[s] == lev && bs > -INFINITY && bd > -INFINITY) atomicAdd(&ab[s], exp(bd + like(q, l) - bs) * ldc(&ab[d]));
       }
       __syncthreads();
     }
@@ -222,10 +240,11 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
       const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
       const int r = ref[t - 1];
       for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int s = lsrc[l], d = ldst[l];
+        const int4 q = lrec[l];
+        const int s = q.x, d = q.y;
         const double bs = ldc(&beta[s]), bd = ldc(&beta[d]);
         if (bs > -INFINITY && bd > -INFINITY)
-          atomicAdd(&ab[s], exp(bd + like(l) - bs) * (ldc(&ab[d]) + frame_acc(p, ltid[l], r)));
+          atomicAdd(&ab[s], exp(bd + like(q, l) - bs) * (ldc(&ab[d]) + frame_acc(p, q.z, r)));
       }
       __syncthreads();
     }
@@ -235,12 +254,13 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
     const int r = ref[t];
     float* row = post + (int64_t)t * p.post_frame_stride;
     for (int l = m0 + tid; l < m1; l += kFbThreads) {
-      const int s = lsrc[l], d = ldst[l];
+      const int4 q = lrec[l];
+      const int s = q.x, d = q.y;
       const double bd = ldc(&beta[d]);
       if (bd == -INFINITY) continue;
-      const double pr = exp(ldc(&alpha[s]) + like(l) + bd - tot);
-      const double diff = ldc(&af[s]) + frame_acc(p, ltid[l], r) + ldc(&ab[d]) - tot_score;
-      atomicAdd(&row[p.tid2pdf[ltid[l]]], (float)(pr * diff));
+      const double pr = exp(ldc(&alpha[s]) + like(q, l) + bd - tot);
+      const double diff = ldc(&af[s]) + frame_acc(p, q.z, r) + ldc(&ab[d]) - tot_score;
+      atomicAdd(&row[p.tid2pdf[q.z]], (float)(pr * diff));
     }
   }
   if (tid == 0) p.out[n] = tot_score;

@@ -122,9 +122,9 @@ size_t lattice_carve(const pk2_lattice_batch* b, void* base, LatPtrs* out) {
   L.tok_level = c.take<int32_t>(b->tok_total);
   L.alpha = c.take<double>(b->tok_total); L.beta = c.take<double>(b->tok_total);
   L.acc_f = c.take<double>(b->tok_total); L.acc_b = c.take<double>(b->tok_total);
-  L.link_src = c.take<int32_t>(b->link_total); L.link_dst = c.take<int32_t>(b->link_total);
-  L.link_tid = c.take<int32_t>(b->link_total); L.link_graph = c.take<float>(b->link_total);
+  L.link_rec = c.take<int4>(b->link_total);
   L.link_ac = c.take<float>(b->link_total);
+  L.e_rec = c.take<int4>(b->graph->e_dst.size());
   L.frame_tok = c.take<int32_t>(b->frame_total); L.seg_off = c.take<int32_t>(b->frame_total);
   L.seg_kept = c.take<int32_t>(b->frame_total); L.frame_maxlev = c.take<int32_t>(b->frame_total);
   L.ref_post = c.take<double>(b->frame_total);
@@ -253,21 +253,20 @@ extern "C" int pk2_lattice_export(const pk2_lattice_batch* b, const void* worksp
   if (link_src || link_dst || link_tid || link_graph || link_ac) {
     // emitting links into frame t, then the epsilon links of frame t (the oracle's order)
     int64_t w = 0;
-    std::vector<int32_t> a, d2, ti; std::vector<float> gr, ac;
+    std::vector<int4> rec; std::vector<float> ac;
     auto seg_copy = [&](int32_t s) -> int {
       const int32_t k = kept[s];
-      a.resize(k); d2.resize(k); ti.resize(k); gr.resize(k); ac.resize(k);
+      rec.resize(k); ac.resize(k);
       const int64_t o = u.link_base + seg[s];
-      PK2_HIP(d2h(a.data(), L.link_src + o, 4 * (size_t)k)); PK2_HIP(d2h(d2.data(), L.link_dst + o, 4 * (size_t)k));
-      PK2_HIP(d2h(ti.data(), L.link_tid + o, 4 * (size_t)k)); PK2_HIP(d2h(gr.data(), L.link_graph + o, 4 * (size_t)k));
+      PK2_HIP(d2h(rec.data(), L.link_rec + o, sizeof(int4) * (size_t)k));
       PK2_HIP(d2h(ac.data(), L.link_ac + o, 4 * (size_t)k));
       PK2_HIP(hipStreamSynchronize(stream));
       for (int32_t i = 0; i < k; ++i, ++w) {
-        if (remap[a[i]] < 0 || remap[d2[i]] < 0) { set_error("lattice export: kept link touches a pruned token"); return PK2_ERR_NUMERIC; }
-        if (link_src) link_src[w] = remap[a[i]];
-        if (link_dst) link_dst[w] = remap[d2[i]];
-        if (link_tid) link_tid[w] = ti[i];
-        if (link_graph) link_graph[w] = gr[i];
+        if (remap[rec[i].x] < 0 || remap[rec[i].y] < 0) { set_error("lattice export: kept link touches a pruned token"); return PK2_ERR_NUMERIC; }
+        if (link_src) link_src[w] = remap[rec[i].x];
+        if (link_dst) link_dst[w] = remap[rec[i].y];
+        if (link_tid) link_tid[w] = rec[i].z;
+        if (link_graph) link_graph[w] = __builtin_bit_cast(float, rec[i].w);
         if (link_ac) link_ac[w] = ac[i];
       }
       return PK2_OK;

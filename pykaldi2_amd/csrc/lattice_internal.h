@@ -54,7 +54,9 @@ struct LatPtrs {
   int32_t* st_tok;     // [N][S] frame-local token index
   int32_t* tok_state; float* tok_cost; float* tok_extra; float* tok_final; int32_t* tok_level;
   double* alpha; double* beta; double* acc_f; double* acc_b;
-  int32_t* link_src; int32_t* link_dst; int32_t* link_tid; float* link_graph; float* link_ac;
+  int4* link_rec;        // {source token, destination token, transition-id (0 = epsilon), graph cost bits}: one 16-byte access per link
+  float* link_ac;        // acoustic cost
+  int4* e_rec;           // per call: emitting arcs of HCLG packed as {dst state, transition-id, weight bits, pdf}
   int32_t* frame_tok;    // per utterance [T+2]: first token of each frame (utterance-local), [T+1] = end
   int32_t* seg_off;      // per utterance [2(T+1)+1]: link segments: 2t = epsilon links inside frame t, 2t+1 = t -> t+1
   int32_t* seg_kept;     // per utterance [2(T+1)]: links of the segment that survive lattice pruning (compacted to its front)
