@@ -202,3 +202,68 @@ def test_hclg_from_openfst_file(tmp_path, kind):
     a = _canon(rec.decode(torch.from_numpy(ll).cuda()).export(0))
     b = _canon(_recognizer(g, tm, beam, lb, ac, maxa, mina).decode(torch.from_numpy(ll).cuda()).export(0))
     assert a == b
+
+
+def _custom_graph(seed, n_states=40, fan=200, num_pdfs=30, with_final=True):
+    """A graph with a hub state that has `fan` emitting arcs and `fan` epsilon arcs (both beyond the decoder's
+    per-thread degree limit) plus random sparse structure."""
+    rng = np.random.default_rng(seed)
+    ntid = 6 * (num_pdfs // 3)
+    src, dst, il, w = [], [], [], []
+    for k in range(fan):          # hub 0: heavy emitting and epsilon fans
+        src.append(0); dst.append(1 + k % (n_states - 1)); il.append(1 + int(rng.integers(ntid))); w.append(float(rng.uniform(0.1, 3.0)))
+        src.append(0); dst.append(1 + int(rng.integers(n_states - 1))); il.append(0); w.append(float(rng.uniform(0.5, 4.0)))
+    for s in range(1, n_states):
+        for _ in range(3):
+            src.append(s); dst.append(int(rng.integers(n_states))); il.append(1 + int(rng.integers(ntid))); w.append(float(rng.uniform(0.1, 2.0)))
+        src.append(s); dst.append(s); il.append(1 + int(rng.integers(ntid))); w.append(0.3)
+        if s % 7 == 0:
+            src.append(s); dst.append(0); il.append(0); w.append(0.2)      # back to the hub, no epsilon cycle (hub -> s is emitting or one-way)
+    # remove epsilon arcs hub -> s for the states that have an epsilon arc back (keeps the epsilon graph acyclic)
+    back = {s for s in range(1, n_states) if s % 7 == 0}
+    keep = [i for i in range(len(src)) if not (src[i] == 0 and il[i] == 0 and dst[i] in back)]
+    src, dst, il, w = ([x[i] for i in keep] for x in (src, dst, il, w))
+    final = np.full(n_states, np.inf, np.float32)
+    if with_final:
+        final[0] = 0.5
+        final[3] = 0.0
+    return dict(num_states=n_states, start=0, src=np.asarray(src, np.int32), dst=np.asarray(dst, np.int32),
+                ilabel=np.asarray(il, np.int32), weight=np.asarray(w, np.float32), final=final)
+
+
+@pytest.mark.parametrize("with_final", [True, False])
+@pytest.mark.parametrize("T", [1, 17])
+def test_heavy_states_short_utterances_and_missing_finals(with_final, T):
+    P = 30
+    g = _custom_graph(5, with_final=with_final)
+    tm = synth.transition_model_arrays(P)
+    rng = np.random.default_rng(T)
+    ll = (1.5 * rng.standard_normal((T, P))).astype(np.float32)
+    want = lr.decode(_ref_graph(g), ll, tm["tid2pdf"], lr.DecoderOptionsRef(7.0, 3.0, 2 ** 31 - 1, 0, 0.5, 0.7))
+    rec = _recognizer(g, tm, 7.0, 3.0, 0.7, min_active=0)
+    lat = rec.decode(torch.from_numpy(ll).cuda())
+    assert lat.best_cost[0] == np.float32(want.best_cost)
+    assert _canon(lat.export(0)) == _canon(want.arrays())
+    ali = _ali_near_lattice(rng, want, P)
+    like, post = lat.mmi([ali], 1.0, 0.2, True)
+    wl, wp = lr.lattice_mmi(want, ali, tm["tid2pdf"], P, 1.0, 0.2, True)
+    assert abs(like.item() - wl) < 1e-9 * max(1.0, abs(wl)) and np.abs(post[0].cpu().numpy() - wp).max() < 2e-6
+
+
+def test_decoder_failures_are_reported():
+    from pykaldi2_amd import _lib
+    P = 30
+    g, tm, ll, _ = _setup(20, P, 12, 3)
+    # a beam below the cheapest word entry: the start token has nowhere to go
+    rec = _recognizer(g, tm, 0.5, 0.25, 1.0, min_active=0)
+    with pytest.raises(_lib.Pk2Error, match="no surviving token"):
+        rec.decode(torch.from_numpy(ll).cuda())
+    # HCLG with transition-ids the model does not have
+    g2 = dict(g); g2["ilabel"] = g["ilabel"].copy(); g2["ilabel"][g2["ilabel"] > 0] += 1000
+    with pytest.raises(AssertionError):
+        _recognizer(g2, tm, 8.0, 4.0, 1.0)
+    # more pdfs than the LDS row holds
+    big = torch.zeros(4, 9000, device="cuda")
+    rec = _recognizer(g, tm, 8.0, 4.0, 1.0)
+    with pytest.raises(_lib.Pk2Error, match="LDS row limit"):
+        rec.decode(big)
