@@ -936,9 +936,18 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     hipLaunchKernelGGL(store_ints, dim3(1), dim3(64), 0, stream, pack, cnt, b.lengths + base);
   }
   // alpha / beta / gamma rows of split ("atomic") chunks accumulate with atomics -> start at zero
-  PK2_HIP(hipMemsetAsync(b.alpha, 0, GN * (Tmax + 1) * (size_t)g->S * sizeof(float), stream));
-  PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)g->S * 2 * sizeof(float), stream));
-  PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
+  // (on the state-x path every alpha / beta' row and every occupancy is written by a plain store unless a row is
+  // split over several chunks, and values of frames beyond a sequence's end are only ever selected away, never used
+  // in arithmetic: the 0.9 GB of fills per call are skipped then)
+  const char* mode0 = getenv("PK2_DEN_MODE");
+  const bool sx0 = g->state_pdf_unique && !(mode0 && strcmp(mode0, "general") == 0);
+  auto any_atomic = [](const HostOrdering& h) { for (int32_t a : h.atomic) if (a) return true; return false; };
+  const bool need_fill = !sx0 || any_atomic(g->h_fwd) || any_atomic(g->h_bwd);
+  if (need_fill) {
+    PK2_HIP(hipMemsetAsync(b.alpha, 0, GN * (Tmax + 1) * (size_t)g->S * sizeof(float), stream));
+    PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)g->S * 2 * sizeof(float), stream));
+    PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
+  }
   PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * (size_t)g->h_bwd.n_chunks * sizeof(float), stream));
 
   DenParams p;
