@@ -27,6 +27,7 @@
 #include <cstring>
 
 #include "chain_internal.h"
+#include "chain_num.h"
 #include "step_graph.h"
 
 namespace pk2 {
@@ -532,8 +533,8 @@ __global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum
 //   beta[t+1,d] = K[t+1] * (btilde'[t+1,d]/c[t+1] + leaky)   (= K[T] * (1/sum(pi) + leaky) at t+1 = T).
 // No serial dependence: one launch covers all frames.
 template <int NG>
-__global__ void __launch_bounds__(256) den_gamma_states(DenParams p, const float* csum, const float* Kf) {
-  const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const float* csum, const float* Kf, int t, int g) {
+  const int tid = threadIdx.x;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
   float cv[NG], kv[NG], inv_c[NG], cst[NG];
   bool gat[NG];
@@ -565,6 +566,23 @@ __global__ void __launch_bounds__(256) den_gamma_states(DenParams p, const float
     for (int n = 0; n < NG; ++n) v[n] *= kv[n];
     stv<NG>(gam_t + (size_t)pdf * NG, v);
   }
+}
+
+template <int NG>
+__global__ void __launch_bounds__(256) den_gamma_states(DenParams p, const float* csum, const float* Kf) {
+  den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y);
+}
+
+// The same launch also carries the numerator: workgroups x >= Tmax of group 0 run the forward-backward of one
+// supervision FST each (chain_num.h).  The numerator is a ~1 ms latency-bound job of one workgroup per sequence;
+// here it overlaps the occupancy pass instead of holding the stream alone.
+template <int NG>
+__global__ void __launch_bounds__(256) den_gamma_states_num(DenParams p, const float* csum, const float* Kf, NumParams np,
+                                                            int n_seq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < p.Tmax) { den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y); return; }
+  const int n = (int)blockIdx.x - p.Tmax;
+  if (blockIdx.y == 0 && n < n_seq) num_fwd_bwd_body(np, n, smem);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -921,7 +939,7 @@ int get_side_stream(hipStream_t main, SideStream** out) {
 template <int NG>
 static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stride,
                          int64_t frame_stride, const int32_t* lengths_host, const DenGeom& ge,
-                         const DenBuffers& b, float leaky, hipStream_t stream) {
+                         const DenBuffers& b, float leaky, hipStream_t stream, const NumDeferred* tail) {
   const int Tmax = ge.Tmax, G = ge.G;
   const size_t GN = (size_t)G * NG;
   // lengths travel as kernel arguments (no dependence on the lifetime of the caller's host array);
@@ -998,7 +1016,18 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
     hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
     hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
-    hipLaunchKernelGGL(den_gamma_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, p, b.csum, b.kscale);
+    if (tail && tail->valid) {
+      static bool attr_n[8] = {false};
+      if (!attr_n[NG]) {
+        PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_gamma_states_num<NG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_n[NG] = true;
+      }
+      hipLaunchKernelGGL(den_gamma_states_num<NG>, dim3(Tmax + tail->N, G), dim3(256), tail->lds, stream, p, b.csum,
+                         b.kscale, tail->p, tail->N);
+    } else {
+      hipLaunchKernelGGL(den_gamma_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, p, b.csum, b.kscale);
+    }
     PK2_LAUNCH_CHECK();
     return PK2_OK;
   } else {
@@ -1021,12 +1050,13 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   }
   hipLaunchKernelGGL(den_check<NG>, dim3(G), dim3(kDenThreads), 0, stream, p, b.check);
   PK2_LAUNCH_CHECK();
+  if (tail && tail->valid) return num_launch_deferred(*tail, stream);
   return PK2_OK;
 }
 
 int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64_t frame_stride,
                 const int32_t* lengths_host, const DenGeom& ge, const DenBuffers& b, float leaky,
-                hipStream_t stream) {
+                hipStream_t stream, const NumDeferred* tail) {
   int rc = den_upload(g);
   if (rc) return rc;
   if (den_choose_ng(g) == 0) {
@@ -1034,9 +1064,9 @@ int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64
     return PK2_ERR_LIMIT;
   }
   switch (ge.NG) {
-    case 4: return den_compute_t<4>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream);
-    case 2: return den_compute_t<2>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream);
-    default: return den_compute_t<1>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream);
+    case 4: return den_compute_t<4>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail);
+    case 2: return den_compute_t<2>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail);
+    default: return den_compute_t<1>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail);
   }
 }
 

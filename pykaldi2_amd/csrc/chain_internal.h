@@ -105,12 +105,13 @@ struct DenBuffers {
 int den_choose_ng(const pk2_den_graph* g);
 size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, DenBuffers* buf,
                      void* base);
+struct NumDeferred;
 int den_upload(pk2_den_graph* g);
 // Runs exp-transpose, T forward steps, finalize, T backward steps.  Leaves
 // gamma / den_lp / check in `buf`.
 int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64_t frame_stride,
                 const int32_t* lengths_host, const DenGeom& geom, const DenBuffers& buf,
-                float leaky, hipStream_t stream);
+                float leaky, hipStream_t stream, const NumDeferred* tail = nullptr);
 
 // Internal side stream (+ fork/join events) paired with a caller stream: the numerator runs there while
 // the denominator occupies the caller's stream.
@@ -118,6 +119,21 @@ struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, joi
 int get_side_stream(hipStream_t main, SideStream** out);
 
 // Numerator.
+// seqinfo[n] = {frame_off base index, length, state count, final lo, final hi, -, -, -}
+struct NumParams {
+  const int32_t* arc_src; const int32_t* arc_dst; const int32_t* arc_pdf; const float* arc_w;
+  const int32_t* frame_off; const int32_t* final_state; const float* final_w;
+  const int32_t* seqinfo;
+  const float* logits; int64_t seq_stride, frame_stride;
+  float* score; float* frame_max; float* num_lp;
+  float* grad; int64_t gseq_stride, gframe_stride;
+  float scale;
+};
+
+// A numerator whose forward-backward launch has been handed to the denominator (see chain_num.h).
+struct NumDeferred { NumParams p; size_t lds = 0; int N = 0; bool valid = false; };
+int num_launch_deferred(const NumDeferred& d, hipStream_t stream);
+
 struct NumBuffers {
   float* score;     // [total_arcs]
   float* frame_max; // [sum lengths]
@@ -129,6 +145,6 @@ size_t num_workspace(int N, int64_t total_arcs, int64_t total_frames, NumBuffers
 int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride,
                 int64_t frame_stride, const int32_t* lengths_host, int N, float scale, float* grad,
                 int64_t grad_seq_stride, int64_t grad_frame_stride, const NumBuffers& buf,
-                hipStream_t stream);
+                hipStream_t stream, NumDeferred* defer = nullptr);
 
 }  // namespace pk2

@@ -16,22 +16,11 @@
 #include <vector>
 
 #include "chain_internal.h"
+#include "chain_num.h"
 
 namespace pk2 {
 
-constexpr int kNumThreads = 256;
 constexpr int kNumMaxStates = 18000;  // 2 * 18000 * 4 B = 144 KB of LDS
-
-// seqinfo[n] = {frame_off base index, length, state count, final lo, final hi, -, -, -}
-struct NumParams {
-  const int32_t* arc_src; const int32_t* arc_dst; const int32_t* arc_pdf; const float* arc_w;
-  const int32_t* frame_off; const int32_t* final_state; const float* final_w;
-  const int32_t* seqinfo;
-  const float* logits; int64_t seq_stride, frame_stride;
-  float* score; float* frame_max; float* num_lp;
-  float* grad; int64_t gseq_stride, gframe_stride;
-  float scale;
-};
 
 // score[a] = -w[a] + logit[n][t(a)][pdf[a]];  frame_max[t] = max over the frame's arcs.
 __global__ void __launch_bounds__(kNumThreads) num_scores(NumParams p, int64_t frame_base_total) {
@@ -55,92 +44,9 @@ __global__ void __launch_bounds__(kNumThreads) num_scores(NumParams p, int64_t f
   }
 }
 
-__device__ __forceinline__ float block_sum_f(float v, float* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < kNumThreads / 64; ++k) s += red[k];
-  return s;
-}
-
 __global__ void __launch_bounds__(kNumThreads) num_fwd_bwd(NumParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int32_t* info = p.seqinfo + n * 8;
-  const int fbase = info[0], T = info[1], ns = info[2], flo = info[3], fhi = info[4];
-  float* al = smem;        // [ns] alpha, each frame's states carry that frame's (unknown) scale
-  float* be = smem + ns;   // [ns]
-  float* red = be + ns;    // [4]
-  for (int i = tid; i < 2 * ns; i += kNumThreads) smem[i] = 0.f;
-  __syncthreads();
-  if (tid == 0) al[0] = 1.f;
-  __syncthreads();
-
-  const float* fmax = p.frame_max + (fbase - n);
-  double logp = 0.0;
-  float inv_prev = 1.f;
-  for (int t = 0; t < T; ++t) {
-    const int lo = p.frame_off[fbase + t], hi = p.frame_off[fbase + t + 1];
-    const float m = fmax[t];
-    float z = 0.f;
-    for (int a = lo + tid; a < hi; a += kNumThreads) {
-      const float v = al[p.arc_src[a]] * inv_prev * expf(p.score[a] - m);
-      atomicAdd(&al[p.arc_dst[a]], v);
-      z += v;
-    }
-    z = block_sum_f(z, red);  // (also orders the LDS atomics before the next frame's reads)
-    logp += (double)m + log((double)z);
-    inv_prev = 1.f / z;
-  }
-  // final states
-  float zf = 0.f;
-  for (int k = flo + tid; k < fhi; k += kNumThreads) {
-    const int s = p.final_state[k];
-    const float e = expf(-p.final_w[k]);
-    zf += al[s] * inv_prev * e;
-    be[s] = e;
-  }
-  zf = block_sum_f(zf, red);
-  logp += log((double)zf);
-  if (tid == 0) p.num_lp[n] = (float)logp;
-
-  // backward: posteriors of a frame are normalised by their own sum
-  float* grow = p.grad + (int64_t)n * p.gseq_stride;
-  inv_prev = 1.f;
-  for (int t = T - 1; t >= 0; --t) {
-    const int lo = p.frame_off[fbase + t], hi = p.frame_off[fbase + t + 1];
-    const float m = fmax[t];
-    float zq = 0.f, zb = 0.f;
-    // a frame holds at most a few arcs per thread; keep the products in registers
-    float q[4]; int na = 0;
-    for (int a = lo + tid; a < hi; a += kNumThreads) {
-      const int s = p.arc_src[a];
-      const float u = expf(p.score[a] - m) * be[p.arc_dst[a]] * inv_prev;
-      atomicAdd(&be[s], u);
-      const float qq = al[s] * u;
-      if (na < 4) q[na] = qq;
-      ++na;
-      zq += qq; zb += u;
-    }
-    zq = block_sum_f(zq, red);
-    zb = block_sum_f(zb, red);
-    const float inv_q = p.scale / zq;
-    int k = 0;
-    for (int a = lo + tid; a < hi; a += kNumThreads, ++k) {
-      float qq;
-      if (k < 4) {
-        qq = q[k];
-      } else {  // > 1024 arcs in one frame: recompute (beta of the source is final by now,
-                // so rebuild u from the destination side)
-        qq = al[p.arc_src[a]] * expf(p.score[a] - m) * be[p.arc_dst[a]] * inv_prev;
-      }
-      atomicAdd(grow + (int64_t)t * p.gframe_stride + p.arc_pdf[a], qq * inv_q);
-    }
-    inv_prev = 1.f / zb;
-  }
+  num_fwd_bwd_body(p, blockIdx.x, smem);
 }
 
 size_t num_workspace(int N, int64_t total_arcs, int64_t total_frames, NumBuffers* buf, void* base) {
@@ -162,7 +68,7 @@ __global__ void store_info(InfoPack pack, int count, int32_t* out) {
 int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride,
                 int64_t frame_stride, const int32_t* lengths, int N, float scale, float* grad,
                 int64_t gseq_stride, int64_t gframe_stride, const NumBuffers& buf,
-                hipStream_t stream) {
+                hipStream_t stream, NumDeferred* defer) {
   PK2_REQUIRE(nb && nb->arc_src && nb->arc_dst && nb->arc_pdf && nb->arc_weight && nb->frame_off &&
                   nb->state_off && nb->final_state && nb->final_weight && nb->final_off,
               "numerator: null pointer in pk2_num_batch");
@@ -205,7 +111,18 @@ int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride
   }
   const int blocks_x = std::max(1, std::min(64, (Tmax + 3) / 4));
   hipLaunchKernelGGL(num_scores, dim3(blocks_x, N), dim3(kNumThreads), 0, stream, p, (int64_t)0);
+  if (defer) {   // the caller launches the forward-backward together with the denominator's occupancy kernel
+    defer->p = p; defer->lds = lds; defer->N = N; defer->valid = true;
+    PK2_LAUNCH_CHECK();
+    return PK2_OK;
+  }
   hipLaunchKernelGGL(num_fwd_bwd, dim3(N), dim3(kNumThreads), lds, stream, p);
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
+
+int num_launch_deferred(const NumDeferred& d, hipStream_t stream) {
+  hipLaunchKernelGGL(num_fwd_bwd, dim3(d.N), dim3(kNumThreads), d.lds, stream, d.p);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

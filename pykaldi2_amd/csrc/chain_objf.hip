@@ -140,12 +140,15 @@ extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* lo
     PK2_HIP(hipEventRecord(side->fork, stream));
     PK2_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
   }
+  // Default: the arc scores are computed here, the numerator forward-backward itself is handed to the denominator,
+  // whose occupancy kernel launch carries the numerator's workgroups (chain_num.h).
+  NumDeferred deferred;
   rc = num_compute(num, logits, seq_stride, frame_stride, lengths, N,
-                   weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, num_stream);
+                   weight * (1.0f + xent_regularize), grad, gss, gfs, nbuf, num_stream, use_side ? nullptr : &deferred);
   if (rc) return rc;
   if (use_side) PK2_HIP(hipEventRecord(side->join, side->stream));
   // 2. denominator
-  rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream);
+  rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream, use_side ? nullptr : &deferred);
   if (rc) return rc;
   if (use_side) PK2_HIP(hipStreamWaitEvent(stream, side->join, 0));
   // 3. objective, guards, gradient = numerator - denominator occupancies
