@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
                                                                 float beta, float* __restrict__ C, int64_t ldc,
                                                                 const float* __restrict__ bias, bool vecA,
                                                                 bool vecB, GemmBatch bt) {
-  constexpr int LDS_LD = Geo<TILES>::LD, BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
+  constexpr int BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
+  constexpr int LDA = Geo<TILES>::template ld<!TA>(), LDB = Geo<TILES>::template ld<TB>();   // per-operand LDS row pitch
   int kbeg = 0;
   {
     int z = blockIdx.z;
@@ -50,8 +51,8 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
 #define PK2_GEMM_SLABS 1
 #endif
   constexpr int kSlabs = PK2_GEMM_SLABS;
-  __shared__ __attribute__((aligned(16))) float As[kSlabs][BK * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[kSlabs][BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As[kSlabs][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[kSlabs][BK * LDB];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
@@ -74,12 +75,18 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
   const int nk = (K - kbeg + kSlabs * BK - 1) / (kSlabs * BK);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // previous tile fully consumed
+#ifdef PK2_GEMM_ABL_NOSTORE
+    if (kt == 0)
+#endif
 #pragma unroll
     for (int q = 0; q < kSlabs; ++q) {
       store_slab<!TA, TILES>(As[q], ra[q]);
       store_slab<TB, TILES>(Bs[q], rb[q]);
     }
     __syncthreads();
+#ifdef PK2_GEMM_ABL_NOLOAD
+    if (false)
+#endif
     if (kt + 1 < nk) {
 #pragma unroll
       for (int q = 0; q < kSlabs; ++q) {
@@ -94,14 +101,18 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
       for (int kk = 0; kk < BK; kk += 2) {
         float a[TILES], b[TILES];
 #pragma unroll
-        for (int i = 0; i < TILES; ++i) a[i] = As[q][(kk + kq) * LDS_LD + wm + i * 32 + li];
+        for (int i = 0; i < TILES; ++i) a[i] = As[q][(kk + kq) * LDA + wm + i * 32 + li];
 #pragma unroll
-        for (int j = 0; j < TILES; ++j) b[j] = Bs[q][(kk + kq) * LDS_LD + wn + j * 32 + li];
+        for (int j = 0; j < TILES; ++j) b[j] = Bs[q][(kk + kq) * LDB + wn + j * 32 + li];
 #pragma unroll
         for (int i = 0; i < TILES; ++i)
 #pragma unroll
           for (int j = 0; j < TILES; ++j)
+#ifdef PK2_GEMM_ABL_NOMFMA
+            acc[i][j][0] += a[i] * b[j];
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#endif
       }
     }
   }

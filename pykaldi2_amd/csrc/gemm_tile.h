@@ -15,8 +15,13 @@ constexpr int kGemmThreads = 256;
 // each (one wave per SIMD cannot hide its own LDS/global latency).
 template <int TILES> struct Geo {
   static constexpr int BMN = 64 * TILES;        // block tile edge
-  static constexpr int LD = BMN + 4;            // padded leading dimension of the [BK][BMN] LDS tiles
+  static constexpr int LD = BMN + 4;            // padded leading dimension of the [BK][BMN] LDS tiles (float4-aligned rows)
+  // Leading dimension when the operand is k-contiguous in memory: its LDS image is written with scalar stores,
+  // lane l -> (k = 4*(l&3)+j, row = l>>2).  LD = 2 (mod 8) spreads the four k's of a 32-lane half over all 32 banks
+  // (bank = 8*(l&3) + 2j + row); with LD = 4 (mod 32) lanes l and l+2 collide (2-way conflict on every store).
+  static constexpr int LDK = BMN + 2;
   static constexpr int LPK = 16 * TILES;        // lanes covering one k-row when the row dim is contiguous
+  template <bool KCONTIG> static constexpr int ld() { return KCONTIG ? LDK : LD; }
 };
 
 // Loads the 128 x 16 (rows x k) slab of an operand into registers.
@@ -66,7 +71,7 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ base, int64_
 template <bool KCONTIG, int TILES>
 __device__ __forceinline__ void store_slab(float* __restrict__ tile, const float4 (&reg)[TILES]) {
   const int tid = threadIdx.x;
-  constexpr int LD = Geo<TILES>::LD;
+  constexpr int LD = Geo<TILES>::template ld<KCONTIG>();
 #pragma unroll
   for (int h = 0; h < TILES; ++h) {
     if (KCONTIG) {

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) regroup_whh_units(const float* __restrict
 
 __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __restrict__ pp,
                                                          const StepCounter* __restrict__ cnt, int local) {
-  constexpr int LD = Geo<1>::LD;
+  constexpr int LD = Geo<1>::LDK;     // both operands are k-contiguous in memory
   __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LD];
   __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LD];
   __shared__ float Cs[64][65];
@@ -365,9 +365,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
 // dh_part[s][d][b][k] = sum_{r in K-slice s} dgates[tn][b][r] * W_hh[d][r][k]   (64 x 64 tiles, split-K)
 __global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __restrict__ pp,
                                                        const StepCounter* __restrict__ cnt, int local) {
-  constexpr int LD = Geo<1>::LD;
-  __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LD];
+  constexpr int LDA = Geo<1>::LDK, LDB = Geo<1>::LD;   // dgates rows are k-contiguous, W_hh is read [k][n]
+  __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LDB];
   const int step = cnt->base + local;
   if (step >= cnt->T || step == 0) return;     // the first backward step has no recurrent gradient
   const LstmBwdParams p = *pp;
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __re
     for (int q = 0; q < kBigSlabs; ++q)
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[q][(kk + kq) * LD + wm + li], Bs[q][(kk + kq) * LD + wn + li], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[q][(kk + kq) * LDA + wm + li], Bs[q][(kk + kq) * LDB + wn + li], acc, 0, 0, 0);
   }
   float* out = p.dh_part + (((size_t)sk * D + d) * B) * H;
   const int col = n0 + wn + (lane & 31), rh = 4 * (lane >> 5);
