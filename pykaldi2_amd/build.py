@@ -17,7 +17,12 @@ _TAG = os.environ.get("PK2_BUILD_TAG", "")
 OBJ = os.path.join(HERE, "build" + ("_" + _TAG if _TAG else ""))
 LIB = os.path.join(HERE, "libpk2hip" + ("_" + _TAG if _TAG else "") + ".so")
 ARCH = "gfx950"
+# -amdgpu-kernarg-preload-count: gfx950 hands the first kernel arguments to a wave in SGPRs instead of making it
+# fetch them from the kernarg segment; the per-time-step kernels (args = two pointers + an index, then one more
+# scalar load of the parameter block) start their real loads one memory round trip earlier
+# (measured: LSTM forward step 4.40 -> 4.16 us, denominator call 14.67 -> 14.55 ms).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+         "-mllvm", "-amdgpu-kernarg-preload-count=8",
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + \
     os.environ.get("PK2_EXTRA_FLAGS", "").split()
 # hipcc defaults to -ffp-contract=fast, which fuses a*b+c across statements and ignores `#pragma clang fp
