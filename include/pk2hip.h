@@ -307,6 +307,7 @@ typedef struct {
   int32_t min_active;     /* 200 */
   int32_t tokens_per_frame;  /* pool size per utterance = (T+1) * this; 0 = max_active */
   int32_t links_per_frame;   /* pool size per utterance = (T+1) * this; 0 = 3 * max_active */
+  /* (the Python wrapper passes 2 * max_active / 6 * max_active and quadruples them after an overflow report) */
 } pk2_decoder_opts;
 
 /* Layout of one minibatch of lattices (host object; lengths = frames per utterance). */

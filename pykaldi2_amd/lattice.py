@@ -331,7 +331,8 @@ class MappedLatticeFasterRecognizer:
     def _opts(self, grow):
         o = self.decoder_opts
         max_active = int(min(o.max_active, 2 ** 31 - 1))
-        tpf = o.tokens_per_frame or min(max_active, 20000)
+        # a frame holds the <= max_active expanded tokens' successors: 2x max_active covers the measured ~1.2x with room
+        tpf = o.tokens_per_frame or min(2 * max_active, 40000)
         lpf = o.links_per_frame or 3 * tpf
         return _lib.DecoderOpts(float(o.beam), float(o.lattice_beam), float(o.beam_delta), self.acoustic_scale,
                                 max_active, int(o.min_active), int(min(tpf * grow, 2 ** 30)), int(min(lpf * grow, 2 ** 30)))
