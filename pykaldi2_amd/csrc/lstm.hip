@@ -251,6 +251,102 @@ __global__ void __launch_bounds__(WAVES * 64) lstm_bwd_step(const LstmBwdParams*
 }
 
 // ----------------------------------------------------------------------------------------
+// Small-batch backward step on v_mfma_f32_4x4x1_16b_f32.
+// With a batch of 4 and 4 hidden units per workgroup the product dh[b][k] = sum_r dgates[b][r] W_hh[r][k] is a
+// 4 x 2048 x 4 job: a 16x16x4 MFMA tile would be 15/16 padding (the 16-wave kernel above spends 1.7 us per step in
+// the matrix pipe at 1/16 utilisation).  The 4x4x1 instruction computes 16 INDEPENDENT 4x4 outer products per
+// issue (lane l feeds block l/4: row/column l%4; layout verified with tools/ubench/mfma4x4_layout.hip), so the 16
+// blocks take 16 different gate rows r: every lane streams its own run of H/16 consecutive r's of one batch row
+// and one unit (all 64 lanes load, 8 cycles per instruction, 4 waves instead of 16), the 16 block results are
+// added with four shuffle rounds, the four waves meet in LDS.  Batches of 5..31 rows loop over groups of 4.
+// ----------------------------------------------------------------------------------------
+constexpr int kX4MaxGroups = 8;
+
+template <int H>
+__global__ void __launch_bounds__(256) lstm_bwd_step_x4(const LstmBwdParams* __restrict__ pp,
+                                                        const StepCounter* __restrict__ cnt, int local) {
+  constexpr int NR = H / 16;                       // gate rows per lane = MFMAs per wave and batch group
+  constexpr int G4 = 4 * H;
+  __shared__ float part[kX4MaxGroups][4][4][4];    // [batch group][wave][batch row i][unit j]
+  const int step = cnt->base + local;
+  if (step >= cnt->T) return;
+  const LstmBwdParams p = *pp;
+  const int d = blockIdx.y;
+  const int k0 = blockIdx.x * 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int blk = lane >> 2, q = lane & 3;
+  const int B = p.B, T = p.T, D = p.D;
+  const int fstep = T - 1 - step;
+  const int t = d == 0 ? fstep : T - 1 - fstep;
+  const int tn = d == 0 ? t + 1 : t - 1;
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const bool last_fwd = step == 0, first_fwd = fstep == 0;
+  const int ngroups = (B + 3) >> 2;
+  const int rbase = w * H + blk * NR;              // wave w covers gate rows [w*H, (w+1)*H), block blk a run of NR
+
+  f32x4 wf[NR / 4];                                // W_hh^T[k0 + q][rbase ..]
+  if (!last_fwd) {
+    const float* wrow = p.whhT + ((size_t)d * H + k0 + q) * G4 + rbase;
+#pragma unroll
+    for (int n = 0; n < NR / 4; ++n) wf[n] = *reinterpret_cast<const f32x4*>(wrow + n * 4);
+  }
+  // pointwise operands of thread (group pg, batch row pi, unit pj), fetched before the matrix phase
+  const int pg = tid >> 4, pi_ = (tid >> 2) & 3, pj = tid & 3;
+  const int pb = pg * 4 + pi_, pk = k0 + pj;
+  const bool pw_active = pg < ngroups && pb < B;
+  float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f, dcin = 0.f;
+  if (pw_active) {
+    dh = p.dy[((size_t)t * B + pb) * ((size_t)D * H) + (size_t)d * H + pk];
+    const float* gr = p.gates + (((size_t)d * T + t) * B + pb) * G4 + pk;
+    ig = gr[0]; fg = gr[(size_t)H]; gg = gr[(size_t)2 * H]; og = gr[(size_t)3 * H];
+    c = p.cells[(((size_t)d * T + t) * B + pb) * H + pk];
+    if (!first_fwd) cprev = p.cells[(((size_t)d * T + tp) * B + pb) * H + pk];
+    if (!last_fwd) dcin = p.dc[((size_t)d * B + pb) * H + pk];
+  }
+  if (!last_fwd) {
+    for (int g = 0; g < ngroups; ++g) {
+      const int b = g * 4 + q;
+      f32x4 af[NR / 4];
+      if (b < B) {
+        const float* grow = p.dgx + ((size_t)tn * B + b) * ((size_t)D * G4) + (size_t)d * G4 + rbase;
+#pragma unroll
+        for (int n = 0; n < NR / 4; ++n) af[n] = *reinterpret_cast<const f32x4*>(grow + n * 4);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NR / 4; ++n) af[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < NR / 4; ++n) {
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(af[n][0], wf[n][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(af[n][1], wf[n][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(af[n][2], wf[n][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(af[n][3], wf[n][3], acc1, 0, 0, 0);
+      }
+      // register r of lane l = D_block(l/4)[row r][column l%4]: add the 16 blocks
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc0[r] + acc1[r];
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 4) part[g][w][r][lane] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (pw_active) {
+    if (!last_fwd) dh += (part[pg][0][pi_][pj] + part[pg][1][pi_][pj]) + (part[pg][2][pi_][pj] + part[pg][3][pi_][pj]);
+    const float tc = tanhf(c);
+    const float dcv = dcin + dh * og * (1.f - tc * tc);
+    p.dc[((size_t)d * B + pb) * H + pk] = dcv * fg;
+    float* o = p.dgx + ((size_t)t * B + pb) * ((size_t)D * G4) + (size_t)d * G4 + pk;
+    o[0] = dcv * gg * ig * (1.f - ig);
+    o[(size_t)H] = dcv * cprev * fg * (1.f - fg);
+    o[(size_t)2 * H] = dcv * ig * (1.f - gg * gg);
+    o[(size_t)3 * H] = dh * tc * og * (1.f - og);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // Large-batch step kernels (B >= kBigBatch, e.g. the CE configuration 256 x 80).  At these sizes the
 // recurrence is a real GEMM ([B, H] x [H, 4H] per direction and step), so it is tiled like one: 64 x 64
 // output tiles through the LDS staging of gemm_tile.h (v_mfma_f32_32x32x2_f32), W_hh rows regrouped so that
@@ -568,6 +664,27 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
     rc = g_graphs.run(keyb, T, slot->counter, stream, [&](hipStream_t s, int j) {
       hipLaunchKernelGGL(lstm_bwd_dh_big, gridg, dim3(256), 0, s, pbb, cb, j);
       hipLaunchKernelGGL(lstm_bwd_pointwise_big, dim3(pw_blocks), dim3(256), 0, s, pbb, cb, j);
+    });
+    if (rc) return rc;
+    PK2_LAUNCH_CHECK();
+    return PK2_OK;
+  }
+  // batches below 32 rows: the 4x4x1-MFMA kernel (PK2_LSTM_BWD_X4=0 keeps the 16x16x4 one)
+  static const bool use_x4 = [] { const char* e = getenv("PK2_LSTM_BWD_X4"); return !(e && atoi(e) == 0); }();
+  if (use_x4 && B <= 4 * kX4MaxGroups) {
+    dim3 gridx(H / 4, D, 1);
+    const LstmBwdParams* pbx = slot->params;
+    const StepCounter* cx = slot->counter;
+    char keyx[64];
+    snprintf(keyx, sizeof(keyx), "lstm_bwd_x4_H%d_D%d_%p", H, D, (void*)stream);
+    rc = g_graphs.run(keyx, T, slot->counter, stream, [&](hipStream_t s, int j) {
+      switch (H) {
+        case 64: launch_step(lstm_bwd_step_x4<64>, gridx, dim3(256), s, pbx, cx, j); break;
+        case 128: launch_step(lstm_bwd_step_x4<128>, gridx, dim3(256), s, pbx, cx, j); break;
+        case 256: launch_step(lstm_bwd_step_x4<256>, gridx, dim3(256), s, pbx, cx, j); break;
+        case 512: launch_step(lstm_bwd_step_x4<512>, gridx, dim3(256), s, pbx, cx, j); break;
+        default: launch_step(lstm_bwd_step_x4<1024>, gridx, dim3(256), s, pbx, cx, j); break;
+      }
     });
     if (rc) return rc;
     PK2_LAUNCH_CHECK();

@@ -115,9 +115,11 @@ def test_blstm_3x512_posteriors_match_torch_cpu():
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
 
 
-@pytest.mark.parametrize("B,T,H,bi", [(70, 9, 128, True), (256, 5, 512, True), (33, 6, 64, False)])
+@pytest.mark.parametrize("B,T,H,bi", [(70, 9, 128, True), (256, 5, 512, True), (33, 6, 64, False),
+                                      (7, 9, 128, True), (20, 6, 256, True), (3, 11, 64, False), (31, 4, 512, True)])
 def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
-    """B >= 32 takes the GEMM-tiled recurrence kernels (ragged last 64-row tile at B=70 / 33)."""
+    """B >= 32 takes the GEMM-tiled recurrence kernels (ragged last 64-row tile at B=70 / 33); smaller batches the
+    step kernels that loop over groups of 4 batch rows (4x4x1 MFMA)."""
     torch.manual_seed(1)
     P, Din = 50, 40
     m = lstm.LSTMAM(Din, P, H, 2, 0.0, bi)
