@@ -94,8 +94,26 @@ struct DenParams {
   const int32_t* state_pdf;  // [S] pdf emitted on entering the state (-1: no incoming arc)
   int S, P, Tmax;
   float leaky, pi_sum;
-  int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop
+  int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop, 4 = load half of the arc records
 };
+
+#ifdef PK2_DEN_PROFILE
+// Phase timers of the state-x frame kernel (10 ns ticks of the constant-rate counter), workgroup 0 of each direction.
+__device__ unsigned long long g_den_prof[2][8];
+#define DEN_T(dir, k) do { if (threadIdx.x == 0 && chunk == 0) { const long long now_ = wall_clock64(); atomicAdd(&g_den_prof[dir][k], (unsigned long long)(now_ - prof_last_)); prof_last_ = now_; } } while (0)
+#define DEN_T0() long long prof_last_ = wall_clock64()
+__global__ void den_prof_print(int frames) {
+  for (int dir = 0; dir < 2; ++dir) {
+    printf("den_step_sx %s wg0, avg 10ns-ticks per frame over %d frames: prologue+issue %llu | wait partials(block_sum) %llu | accumulate (records+gathers arrive) %llu | barrier %llu | epilogue rows %llu | final block_sum+store %llu\n",
+           dir ? "bwd" : "fwd", frames, g_den_prof[dir][0] / frames, g_den_prof[dir][1] / frames, g_den_prof[dir][2] / frames,
+           g_den_prof[dir][3] / frames, g_den_prof[dir][4] / frames, g_den_prof[dir][5] / frames);
+    for (int k = 0; k < 8; ++k) g_den_prof[dir][k] = 0;
+  }
+}
+#else
+#define DEN_T(dir, k) do { } while (0)
+#define DEN_T0() do { } while (0)
+#endif
 
 // ----------------------------------------------------------------------------------------
 // kernels
@@ -624,6 +642,7 @@ __global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ 
 
 template <int NG>
 __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red) {
+  DEN_T0();
   const int g = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int nc = p.fwd.n_chunks;
@@ -647,12 +666,14 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   if (wb < wb1) {
     meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) rec[j] = p.fwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+    for (int j = 0; j < kK; ++j) rec[j] = p.fwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)((p.debug & 1) ? 0 : rec[j].x) * NG, a[j]);
   }
   for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
+  DEN_T(0, 0);
   block_sum<NG, kDenWaves>(as, red);
+  DEN_T(0, 1);
   if (chunk == 0 && tid == 0) stv<NG>(p.asum + frame * NG, as);
   float lk[NG], inv_as[NG];
 #pragma unroll
@@ -684,7 +705,9 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
       for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)rec[j].x * NG, a[j]);
     }
   }
+  DEN_T(0, 2);
   __syncthreads();
+  DEN_T(0, 3);
   float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
   const float* xd = p.beta + (frame + 1) * (size_t)p.S * (2 * NG) + NG;   // x[t, pdf(d)]
   const int row0 = p.fwd.row0[chunk];
@@ -705,8 +728,10 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
       stv<NG>(o, v);
     }
   }
+  DEN_T(0, 4);
   block_sum<NG, kDenWaves>(loc, red);
   if (tid == 0) stv<NG>(p.apart + ((frame + 1) * nc + chunk) * NG, loc);
+  DEN_T(0, 5);
 }
 
 // Backward recursion of the state-x path.  It does NOT use the forward pass: instead of dividing by
@@ -717,6 +742,7 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
 // (den_scales).  Forward and backward chains therefore run concurrently on two streams.
 template <int NG>
 __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red) {
+  DEN_T0();
   const int g = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int ncb = p.bwd.n_chunks;
@@ -740,7 +766,7 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   if (wb < wb1) {
     meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+    for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
       const size_t gi = (p.debug & 1) ? 0 : rec[j].x;
@@ -749,7 +775,9 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     }
   }
   for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
+  DEN_T(1, 0);
   block_sum<NG, kDenWaves>(lB, red);
+  DEN_T(1, 1);
   // lB now holds c[t+1] = sum_k pi[k] btilde'[t+1,k]; the normalised beta-hat' has pi-weighted sum 1,
   // so its leaky term is exactly `leaky`.  beta-hat[T_n] = 1/sum(pi) + leaky starts each sequence.
   float cst[NG], inv_c[NG];
@@ -790,7 +818,9 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
       }
     }
   }
+  DEN_T(1, 2);
   __syncthreads();
+  DEN_T(1, 3);
   float* bx_t = p.beta + frame * (size_t)p.S * (2 * NG);
   const int row0 = p.bwd.row0[chunk];
   const bool atomic = p.bwd.atomic[chunk] != 0;
@@ -810,8 +840,10 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
       stv<NG>(o, v);
     }
   }
+  DEN_T(1, 4);
   block_sum<NG, kDenWaves>(loc, red);
   if (tid == 0) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
+  DEN_T(1, 5);
 }
 
 // One launch = forward frame `step` (workgroups [0, nc_fwd)) AND backward frame Tmax-1-step
@@ -1013,6 +1045,9 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
       hipLaunchKernelGGL(den_step_sx<NG>, gridS, dim3(kDenThreads), 0, s, pb, cnt, j);
     });
     if (rc) return rc;
+#ifdef PK2_DEN_PROFILE
+    hipLaunchKernelGGL(den_prof_print, dim3(1), dim3(1), 0, stream, Tmax);
+#endif
     hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
     hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
     hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
