@@ -307,7 +307,7 @@ def se_workload(args, dev, rank, world):
     for i in range(max(1, args.warmup)):
         step(batches[i % 3])
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     t0 = time.perf_counter()
     audio = 0.0
@@ -445,7 +445,7 @@ def main():
     for i in range(args.warmup):
         tr.step(batches[i % n_unique])
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     t0 = time.perf_counter()
     audio = 0.0
@@ -454,12 +454,12 @@ def main():
         tr.step(mb)
         audio += mb["seconds"]
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     log("timed region done: %.3f s" % dt)
     stats = torch.tensor([dt, audio], dtype=torch.float64, device=dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         tmax = stats[0:1].clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         asum = stats[1:2].clone()

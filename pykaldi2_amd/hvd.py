@@ -23,14 +23,17 @@ import os
 import torch
 import torch.distributed as dist
 
-_state = dict(initialized=False, rank=0, size=1, local_rank=0)
+_state = dict(initialized=False, rank=0, size=1, local_rank=0, group=False)
 
 
 def init(backend=None):
     if _state["initialized"]:
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # PK2_HVD_SINGLE_RANK_GROUP=1 (tests): create the process group and run every collective even with one
+    # rank, so the RCCL + side-stream path can be exercised on a one-GPU box.
+    forced = os.environ.get("PK2_HVD_SINGLE_RANK_GROUP") == "1" and "RANK" in os.environ
+    if world > 1 or forced:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -40,14 +43,14 @@ def init(backend=None):
             torch.cuda.set_device(local)
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
-        _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local)
+        _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local, group=True)
     _state["initialized"] = True
 
 
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()
-    _state.update(initialized=False, rank=0, size=1, local_rank=0)
+    _state.update(initialized=False, rank=0, size=1, local_rank=0, group=False)
 
 
 def size():
@@ -62,9 +65,14 @@ def local_rank():
     return _state["local_rank"]
 
 
+def _collective():
+    """True when gradients have to be exchanged (more than one rank, or the forced single-rank group)."""
+    return _state["group"]
+
+
 def broadcast_parameters(params, root_rank=0):
     """params: a state_dict or an iterable of (name, tensor) (reference bin/train_ce.py:127)."""
-    if size() == 1:
+    if not _collective():
         return
     items = params.items() if hasattr(params, "items") else params
     for _, t in sorted(items, key=lambda kv: kv[0]):
@@ -75,7 +83,7 @@ def broadcast_parameters(params, root_rank=0):
 def broadcast_optimizer_state(optimizer, root_rank=0):
     """Broadcasts tensors held in the optimiser state (reference bin/train_ce.py:128).  State created
     lazily on the first step (the usual case at start-up) needs no exchange."""
-    if size() == 1:
+    if not _collective():
         return
     sd = optimizer.state_dict()
 
@@ -92,7 +100,7 @@ def broadcast_optimizer_state(optimizer, root_rank=0):
 
 
 def allreduce_(tensor, average=True):
-    if size() > 1:
+    if _collective():
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         if average:
             tensor.div_(size())
@@ -114,7 +122,7 @@ class DistributedOptimizer:
         self._flat = hasattr(optimizer, "model") and hasattr(optimizer.model, "flat_parameters")
         self._handles = []
         self._side = None
-        if self._flat and size() > 1:
+        if self._flat and _collective():
             optimizer.model._bucket_hook = self._on_bucket
             optimizer.grad_scale = 1.0 / size()
         self._pending = set()
@@ -152,7 +160,7 @@ class DistributedOptimizer:
         return self._opt.measure_grad_norm(max_norm)
 
     def step(self, *a, **k):
-        if size() > 1:
+        if _collective():
             if self._flat:
                 self.synchronize()
             else:

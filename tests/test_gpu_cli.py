@@ -68,3 +68,23 @@ def test_dump_loglikes_cli_synthetic(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     mats = list(kaldi_io.read_matrix_ark(str(tmp_path / "ll.ark")))
     assert len(mats) == 3 and all(m.shape[1] == 120 and m.shape[0] > 100 and np.isfinite(m).all() for _, m in mats)
+
+
+def test_bench_rccl_path_single_rank_group():
+    """The driver's N>1 launch line with one rank: process group over RCCL, bucketed gradient all-reduce on the
+    side stream while the step graphs replay, barrier-bracketed timing.  With one rank the exchange is the
+    identity, so the objective after the same steps must equal the run without a process group."""
+    import json
+    base = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, PK2_HVD_SINGLE_RANK_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541"] + base,
+                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert dist.returncode == 0, dist.stdout[-2000:] + dist.stderr[-3000:]
+    solo = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert solo.returncode == 0, solo.stdout[-2000:] + solo.stderr[-3000:]
+    a = json.loads(dist.stdout.strip().splitlines()[-1])
+    b = json.loads(solo.stdout.strip().splitlines()[-1])
+    assert a["n_gpus"] == 1 and a["config"]["parallelism"] == "dp1"
+    # split-K GEMMs accumulate with float atomics: equal up to summation order
+    assert abs(a["last_objf_per_frame"] - b["last_objf_per_frame"]) <= 2e-3 * abs(b["last_objf_per_frame"]) + 1e-4
