@@ -9,8 +9,9 @@ One step = one pass of the hot path over one minibatch of raw waveforms already 
 fbank+CMN+subsample -> 3x512 BLSTM forward -> LF-MMI (numerator + denominator forward-backward)
 -> BLSTM backward -> gradient all-reduce (N>1) -> Noam lr, global-norm clip, Adam(amsgrad).
 Weak scaling: every rank processes its own 4-utterance minibatch per step.
-The per-utterance supervision FSTs are built on the host before the timed region (the role of the
-reference's DataLoader workers / alignment tools); their upload to the GPU is inside the step.
+The per-utterance supervisions are built inside the step from the transition-id alignments (SplitToPhones ->
+proto-supervision -> supervision: host-side entries of libpk2hip.so, as the reference does per utterance at
+bin/train_chain.py:262-272) and uploaded to the GPU.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -33,14 +34,32 @@ S_DEN, A_DEN = 30000, 1000000
 HBM_PEAK_GBS = 8000.0
 
 
+_chain_model = None
+
+
+def chain_model():
+    """Synthetic tree + transition model of the chain system (also the alignment model of the label files)."""
+    global _chain_model
+    if _chain_model is None:
+        tree, tm = synth.chain_model(P, seed=0)
+        _chain_model = (chain.MappedAligner(tm), tree, tm, chain.SupervisionOptions())
+    return _chain_model
+
+
+def build_supervisions(alis):
+    """reference bin/train_chain.py:262-272, per utterance: alignment -> phones -> proto-supervision -> supervision
+    (host-side C ABI entries of libpk2hip.so)."""
+    aligner, tree, tm, sopts = chain_model()
+    return [chain.supervision_from_alignment(aligner, tree, tm, sopts, a) for a in alis]
+
+
 def make_batches(rng, n_unique, batch, device):
     out = []
     for _ in range(n_unique):
-        mb = synth.minibatch(rng, batch, P)
+        mb = synth.minibatch(rng, batch, P, ali_model=chain_model()[2])
         lens = [w.shape[0] for w, _ in mb]
         wav = torch.from_numpy(np.concatenate([w for w, _ in mb])).to(device)
-        sups = [chain.Supervision(synth.numerator_fst_from_alignment(a), label_dim=P) for _, a in mb]
-        out.append(dict(wav=wav, lens=lens, sups=sups, seconds=sum(lens) / 16000.0, host=mb))
+        out.append(dict(wav=wav, lens=lens, alis=[a for _, a in mb], seconds=sum(lens) / 16000.0, host=mb))
     return out
 
 
@@ -82,7 +101,8 @@ class Trainer:
         else:
             logits = self.model.forward_time_major(x)
         mark("lstm_fwd")
-        loss = ops.ChainObjtiveBatch.apply(logits.transpose(0, 1), self.den, mb["sups"], self.opts)
+        sups = build_supervisions(mb["alis"])    # host work, runs while the device is still in the forward pass
+        loss = ops.ChainObjtiveBatch.apply(logits.transpose(0, 1), self.den, sups, self.opts)
         mark("chain")
         self.opt.zero_grad()
         loss.backward()
@@ -94,7 +114,7 @@ class Trainer:
         norm = optim.clip_grad_norm_(self.opt, 5.0)
         self.opt.step()
         mark("optim")
-        self.last = dict(loss=loss, norm=norm, logits=logits, frames=frames)
+        self.last = dict(loss=loss, norm=norm, logits=logits, frames=frames, sups=sups)
         return loss
 
 
@@ -173,8 +193,7 @@ def cpu_baseline_worker(seed, threads):
     pi = chain_ref.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
                                      g["prob"].astype(np.float64), 0)
     rng = np.random.default_rng(seed)
-    host = synth.minibatch(rng, 4, P)
-    sups = [chain.Supervision(synth.numerator_fst_from_alignment(a), label_dim=P) for _, a in host]
+    host = synth.minibatch(rng, 4, P, ali_model=chain_model()[2])
     seconds = sum(w.shape[0] for w, _ in host) / 16000.0
     torch.manual_seed(0)
     rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
@@ -186,6 +205,7 @@ def cpu_baseline_worker(seed, threads):
     feats = [frontend_ref.cmn(frontend_ref.logfbank(w, mel)).astype(np.float32) for w, _ in host]
     x = torch.from_numpy(frontend_ref.pad_roll_subsample(feats, 0, 3).copy())
     logits = lin(rnn(x)[0])
+    sups = build_supervisions([a for _, a in host])
     out, grad = chain_c.chain_batch(g, pi, logits.detach().numpy(), sups, 1e-4, 0.1)
     opt.zero_grad()
     logits.backward(torch.from_numpy(-grad))
@@ -477,7 +497,7 @@ def main():
     torch.cuda.synchronize()
     breakdown = {events[i][0]: round(events[i - 1][1].elapsed_time(events[i][1]), 3) for i in range(1, len(events))}
     # roofline of the denominator forward-backward on this minibatch's logits
-    lens = [s.frames_per_sequence for s in mb["sups"]]
+    lens = [s.frames_per_sequence for s in tr.last["sups"]]
     logits_bf = tr.last["logits"].detach().transpose(0, 1)
     roof = den_roofline(den, logits_bf, lens)
     log("roofline done")
@@ -487,8 +507,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
-        "pdf alignments, 30k-state/1M-arc denominator graph; random-init 3x512 BLSTM; supervision FSTs "
-        "prebuilt on the host)",
+        "transition-id alignments over a synthetic left-biphone tree, 30k-state/1M-arc denominator graph; "
+        "random-init 3x512 BLSTM; supervisions built from the alignments inside the step)",
         "config": {"workload": ("SECONDARY configs[4]: 12-layer TransformerAM LF-MMI; " if args.transformer else "") +
                                "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
                                "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"

@@ -6,12 +6,12 @@
   python -m torch.distributed.run --nproc-per-node 8 bin/train_chain.py -config configs/mmi.yaml \
       -data configs/data.yaml -exp_dir exp/chain -chain_dir exp/chain_tree -lr 1e-3 -batch_size 4
 
-Differences from the reference, by necessity (no Kaldi here): the denominator
-graph is read from <chain_dir>/den.fst by the library's own OpenFst reader; the per-utterance
-supervision is built from the pdf alignment (`label`) with +-5-frame tolerance at the subsampled rate
-(pykaldi2_amd.synth.numerator_fst_from_alignment) instead of Kaldi's phone-level
-alignment_to_proto_supervision / proto_supervision_to_supervision (needs tree + transition model);
--synthetic trains on the seeded LibriSpeech-shaped generator and a synthetic denominator graph.
+No Kaldi here: <chain_dir>/den.fst, <chain_dir>/0.trans_mdl, <chain_dir>/tree and
+<ali_dir>/final.mdl are read by the library's own readers, and the per-utterance supervision is built from the
+transition-id alignment (`label`) by the library's SplitToPhones / AlignmentToProtoSupervision /
+ProtoSupervisionToSupervision (pykaldi2_amd.chain, csrc/chain_sup.hip), with the reference's options
+(frame_subsampling_factor 3, tolerances 5, convert_to_pdfs).  -synthetic trains on the seeded
+LibriSpeech-shaped generator with a synthetic denominator graph, tree and transition model.
 """
 import argparse
 import json
@@ -25,6 +25,8 @@ import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pykaldi2_amd import chain, data, fbank, hvd, lstm, ops, optim, synth, utils  # noqa: E402
+from pykaldi2_amd.lattice import TransitionModel  # noqa: E402
+from pykaldi2_amd.tree import ContextDependency  # noqa: E402
 
 
 def main():
@@ -89,27 +91,39 @@ def main():
 
     if args.synthetic:
         den = chain.DenominatorGraph(synth.den_graph_arcs(args.den_states, args.den_arcs, P, seed=0), P)
+        chain_tree, chain_trans_model = synth.chain_model(P, seed=0)
+        aligner = chain.MappedAligner(chain_trans_model)
     else:
         den_path = os.path.join(args.chain_dir or "", "den.fst")
-        if not os.path.isfile(den_path):
-            sys.stderr.write('ERROR: The chain denominator graph {} does not exist!\n'.format(den_path))
-            sys.exit(0)
+        chain_model_path = os.path.join(args.chain_dir or "", "0.trans_mdl")
+        for what, path in (("chain denominator graph", den_path), ("trans_model", chain_model_path),
+                           ("chain tree", os.path.join(args.chain_dir or "", "tree")),
+                           ("alignment model", os.path.join(args.ali_dir or "", "final.mdl"))):
+            if not os.path.isfile(path):     # reference bin/train_chain.py:171-177: message, exit status 0
+                sys.stderr.write('ERROR: The {} {} does not exist!\n'.format(what, path))
+                sys.exit(0)
         den = chain.DenominatorGraph(den_path, P)
+        chain_trans_model = TransitionModel.read(chain_model_path)
+        chain_tree = ContextDependency.read(os.path.join(args.chain_dir, "tree"))
+        aligner = chain.MappedAligner.from_files(os.path.join(args.ali_dir, "final.mdl"), os.path.join(args.ali_dir, "tree"),
+                                                 os.path.join(args.lang_dir or "", "L.fst"), None,
+                                                 os.path.join(args.lang_dir or "", "phones/disambig.int"))
     supervision_opts = chain.SupervisionOptions()
     chain_opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=args.xent_regularize)
-    source = data.make_source(config, P, hvd.rank(), hvd.size())
+    source = data.make_source(config, P, hvd.rank(), hvd.size(), ali_model=aligner.transition_model)
+    sup_model = (aligner, chain_tree, chain_trans_model)
     fb = fbank.FbankExtractor()
 
     model.train()
     for epoch in range(args.num_epochs):
-        run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev)
+        run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model)
         if hvd.rank() == 0 and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/chain.model.' + str(epoch) + '.tar')
     hvd.shutdown()
 
 
-def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev):
+def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model):
     batch_time = utils.AverageMeter('Time', ':6.3f')
     losses = utils.AverageMeter('Loss', ':.4e')
     grad_norm = utils.AverageMeter('grad_norm', ':.4e')
@@ -121,8 +135,9 @@ def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, 
         frame_shift = (epoch % sub) * -1
         feats, frames, row_off = fb(batch["wav"], batch["lens"])
         x = fb.pad_roll_subsample(feats, row_off, frames, shift=frame_shift, subsample=sub, time_major=True)
-        sups = [chain.Supervision(synth.numerator_fst_from_alignment(np.asarray(y)[:T], sub, supervision_opts.left_tolerance),
-                                  label_dim=den.num_pdfs()) for y, T in zip(batch["y"], frames)]
+        aligner, tree, trans_model = sup_model
+        sups = [chain.supervision_from_alignment(aligner, tree, trans_model, supervision_opts, np.asarray(y)[:T])
+                for y, T in zip(batch["y"], frames)]    # reference bin/train_chain.py:262-272
         prediction = model.forward_time_major(x).transpose(0, 1)
         loss = ops.ChainObjtiveBatch.apply(prediction, den, sups, chain_opts)
         optimizer.zero_grad()

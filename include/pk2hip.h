@@ -119,6 +119,74 @@ int pk2_chain_den_fwd_bwd(const pk2_den_graph* g, const float* logits, int64_t s
                           size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ *
+ * Chain supervision of one utterance from its alignment (host-side integer work, no device memory).
+ * Replaces, for bin/train_chain.py:262-272 of the reference,
+ *   aligner.to_phone_alignment(trans_ids)                       (Kaldi SplitToPhones),
+ *   kaldi.chain.alignment_to_proto_supervision(opts, phones, durations),
+ *   kaldi.chain.proto_supervision_to_supervision(tree, trans_model, proto, convert_to_pdfs=True).
+ * Kaldi composes the phone sequence with the context and H transducers, adds self-loops (reordered) and
+ * composes with a time-enforcing FST; the frame-synchronous acceptor those operations define is built
+ * here directly: state = (frames consumed, phone instance, HMM state of the last frame), see
+ * csrc/chain_sup.hip.  Arc weights are 0 (Kaldi builds H with transition_scale = 0 and adds the self-loops
+ * with self_loop_scale = 0).
+ * ------------------------------------------------------------------ */
+/* Splits a transition-id alignment into phones.  Tables are indexed by transition-id (1-based, entry 0
+ * unused): tid_tstate = transition-state, tid_phone, tid_flags bit 0 = self-loop, bit 1 = transition to the
+ * final HMM state.  phones / durations: capacity T.  Returns PK2_ERR_INVALID for a transition-id out of
+ * range; *ok = 0 when the alignment is not a complete sequence of phones (Kaldi's SplitToPhones returns
+ * false: the pieces are still produced). */
+int pk2_split_to_phones(const int32_t* tid_tstate, const int32_t* tid_phone, const uint8_t* tid_flags,
+                        int32_t num_tids, const int32_t* alignment, int32_t T, int32_t* phones,
+                        int32_t* durations, int32_t* num_phones, int32_t* ok);
+
+/* HMM topologies + context-dependency tree of the chain model (0.trans_mdl and tree of the reference's
+ * -chain_dir).
+ * Topology: phone2entry[max_phone+1] (-1 = phone without topology); entry e owns the HMM states
+ *   entry_state_off[e] .. entry_state_off[e+1]; per state forward / self-loop pdf-class (-1 = non-emitting
+ *   final state) and its transitions trans_dst[state_trans_off[s] .. state_trans_off[s+1]) given as HMM
+ *   state indices inside the entry.
+ * Tuples (optional, num_tuples = 0 skips the check): {phone, hmm_state, forward_pdf, self_loop_pdf} rows of
+ *   the transition model; a (phone, state, pdfs) combination the tree produces that is not among them is an
+ *   error, as in TransitionModel::TupleToTransitionState.
+ * Tree: context width N, central position P, and the EventMap flattened to nodes
+ *   kind 0 (constant): a = pdf-id;
+ *   kind 1 (table):    key, children = pool[a .. a+b) (node index, -1 = null);
+ *   kind 2 (split):    key, yes-set = pool[a .. a+b) sorted ascending, yes child = pool[a+b], no child = pool[a+b+1];
+ *   keys: -1 = pdf-class, 0..N-1 = phone at that window position.  Node 0 is the root. */
+typedef struct pk2_sup_model pk2_sup_model;
+pk2_sup_model* pk2_sup_model_create(int32_t max_phone, const int32_t* phone2entry, int32_t num_entries,
+                                    const int32_t* entry_state_off, const int32_t* state_fwd_class,
+                                    const int32_t* state_loop_class, const int32_t* state_trans_off,
+                                    const int32_t* trans_dst, int32_t num_tuples, const int32_t* tuples,
+                                    int32_t context_width, int32_t central_position, int32_t num_nodes,
+                                    const int32_t* node_kind, const int32_t* node_key, const int32_t* node_a,
+                                    const int32_t* node_b, int32_t pool_size, const int32_t* pool);
+void pk2_sup_model_destroy(pk2_sup_model* m);
+/* ContextDependency::Compute: window[N] phones (0 = beyond the utterance) -> pdf-id; PK2_ERR_INVALID when the
+ * tree has no answer. */
+int pk2_sup_model_pdf(const pk2_sup_model* m, const int32_t* window, int32_t pdf_class, int32_t* pdf);
+
+/* AlignmentToProtoSupervision + ProtoSupervisionToSupervision (convert_to_pdfs = true).
+ * frames = ceil(sum(durations) / subsampling); phone i spanning frames [b, e) of the alignment may be emitted
+ * on subsampled frames ceil(max(0, b - left_tolerance) / f) .. ceil(min(T, e + right_tolerance) / f) - 1;
+ * the per-frame test is on the phone identity (TimeEnforcerFst).  Returns null (pk2_last_error) when no
+ * path satisfies the constraints or a phone has no topology / tree answer / tuple. */
+typedef struct pk2_supervision pk2_supervision;
+pk2_supervision* pk2_supervision_create(const pk2_sup_model* m, const int32_t* phones,
+                                        const int32_t* durations, int32_t num_phones, int32_t subsampling,
+                                        int32_t left_tolerance, int32_t right_tolerance);
+void pk2_supervision_destroy(pk2_supervision* s);
+void pk2_supervision_sizes(const pk2_supervision* s, int32_t* frames, int32_t* num_states, int32_t* num_arcs,
+                           int32_t* num_final, int32_t* num_allowed);
+/* Arrays in the layout of pk2_num_batch for one sequence: arcs sorted by the frame of their source state,
+ * frame_off[frames+1], states numbered in time order (state 0 initial), state_time[num_states].
+ * allowed_off[frames+1] / allowed_phones: the ProtoSupervision's sorted allowed-phone sets.  Null pointers
+ * are skipped. */
+int pk2_supervision_copy(const pk2_supervision* s, int32_t* arc_src, int32_t* arc_dst, int32_t* arc_pdf,
+                         float* arc_weight, int32_t* frame_off, int32_t* state_time, int32_t* final_state,
+                         float* final_weight, int32_t* allowed_off, int32_t* allowed_phones);
+
+/* ------------------------------------------------------------------ *
  * 80-dim log-mel filterbank + CMN + frame subsampling.
  * Replaces DataGeneratorTrain._logfbank_extractor (reference
  * data/sr_dataset.py:279-296 over simulation/freq_analysis.py:113-150),

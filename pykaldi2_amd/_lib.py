@@ -50,6 +50,16 @@ SIGNATURES = {
                                            _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "pk2_chain_den_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _f32, _vp, _vp, _i64, _i64,
                                         _vp, _sz, _vp]),
+    "pk2_split_to_phones": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "pk2_sup_model_create": (_vp, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp,
+                                   _vp, _vp, _i32, _vp]),
+    "pk2_sup_model_destroy": (None, [_vp]),
+    "pk2_sup_model_pdf": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
+    "pk2_supervision_create": (_vp, [_vp, _vp, _vp, _i32, _i32, _i32, _i32]),
+    "pk2_supervision_destroy": (None, [_vp]),
+    "pk2_supervision_sizes": (None, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
+                                     C.POINTER(_i32)]),
+    "pk2_supervision_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pk2_decode_graph_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "pk2_decode_graph_from_openfst": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "pk2_decode_graph_destroy": (C.c_int, [_vp]),

@@ -5,6 +5,9 @@
   ChainTrainingOptions                       bin/train_chain.py:191-193
   SupervisionOptions                         bin/train_chain.py:184-188
   Supervision                                bin/train_chain.py:271-272
+  MappedAligner.to_phone_alignment           bin/train_chain.py:195-200,263
+  alignment_to_proto_supervision             bin/train_chain.py:271
+  proto_supervision_to_supervision           bin/train_chain.py:272
   compute_chain_objf_and_deriv(...)          ops/ops.py:265
 
 ``den_fst`` may be a path to an OpenFst binary ``den.fst`` or a dict of arc
@@ -119,6 +122,151 @@ class Supervision:
         self.final_weights = np.ascontiguousarray(fst["final_weights"], dtype=np.float32)
         self.state_time = fst.get("state_time")
         assert self.frame_offsets.shape[0] == self.frames_per_sequence + 1
+
+
+class ProtoSupervision:
+    """kaldi.chain.ProtoSupervision: the phone sequence with durations and the tolerance options; the
+    allowed-phone sets are produced (with the supervision) by pk2_supervision_create."""
+
+    def __init__(self, opts, phones, durations):
+        self.phones = np.ascontiguousarray(phones, dtype=np.int32)
+        self.durations = np.ascontiguousarray(durations, dtype=np.int32)
+        if self.phones.ndim != 1 or self.phones.shape != self.durations.shape or self.phones.shape[0] == 0:
+            raise ValueError("phones and durations must be non-empty lists of equal length")
+        self.frame_subsampling_factor = int(opts.frame_subsampling_factor)
+        self.left_tolerance, self.right_tolerance = int(opts.left_tolerance), int(opts.right_tolerance)
+
+
+def alignment_to_proto_supervision(opts, phones, durations):
+    """kaldi.chain.alignment_to_proto_supervision (reference bin/train_chain.py:271)."""
+    return ProtoSupervision(opts, phones, durations)
+
+
+class _SupModel:
+    """pk2_sup_model of a (tree, transition model) pair."""
+
+    def __init__(self, tree, trans_model):
+        if trans_model.entries is None:
+            raise ValueError("the transition model carries no topology (read it from 0.trans_mdl / final.mdl)")
+        max_phone = max(trans_model.phone2entry)
+        p2e = np.full(max_phone + 1, -1, np.int32)
+        for ph, e in trans_model.phone2entry.items():
+            p2e[ph] = e
+        e_off, fwd, loop, t_off, t_dst = [0], [], [], [0], []
+        for states in trans_model.entries:
+            for f, l, dsts in states:
+                fwd.append(f); loop.append(l); t_dst.extend(dsts); t_off.append(len(t_dst))
+            e_off.append(len(fwd))
+        arr = lambda v: np.ascontiguousarray(v, dtype=np.int32)   # noqa: E731
+        e_off, fwd, loop, t_off, t_dst = arr(e_off), arr(fwd), arr(loop), arr(t_off), arr(t_dst)
+        tuples = arr(trans_model.tuples)
+        L = _lib.lib()
+        self._h = L.pk2_sup_model_create(max_phone, _lib.ptr(p2e), len(trans_model.entries), _lib.ptr(e_off),
+                                         _lib.ptr(fwd), _lib.ptr(loop), _lib.ptr(t_off), _lib.ptr(t_dst),
+                                         tuples.shape[0], _lib.ptr(tuples), tree.N, tree.P, tree.kind.shape[0],
+                                         _lib.ptr(tree.kind), _lib.ptr(tree.key), _lib.ptr(tree.a), _lib.ptr(tree.b),
+                                         tree.pool.shape[0], _lib.ptr(tree.pool))
+        if not self._h:
+            raise _lib.Pk2Error(L.pk2_last_error().decode())
+        self.label_dim = trans_model.num_pdfs()
+
+    def pdf(self, window, pdf_class):
+        w = np.ascontiguousarray(window, dtype=np.int32)
+        out = C.c_int32()
+        _lib.check(_lib.lib().pk2_sup_model_pdf(self._h, _lib.ptr(w), int(pdf_class), C.byref(out)))
+        return out.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().pk2_sup_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_sup_models = {}
+
+
+def supervision_model(tree, trans_model):
+    key = (id(tree), id(trans_model))
+    hit = _sup_models.get(key)
+    if hit is None or hit[0] is not tree or hit[1] is not trans_model:
+        hit = _sup_models[key] = (tree, trans_model, _SupModel(tree, trans_model))
+    return hit[2]
+
+
+def proto_supervision_to_supervision(tree, trans_model, proto, convert_to_pdfs=True, with_allowed=False):
+    """kaldi.chain.proto_supervision_to_supervision (reference bin/train_chain.py:272).  Raises when no path
+    satisfies the time constraints (Kaldi returns false with a warning)."""
+    if not convert_to_pdfs:
+        raise NotImplementedError("only convert_to_pdfs=True (reference bin/train_chain.py:185) is built")
+    m = supervision_model(tree, trans_model)
+    L = _lib.lib()
+    h = L.pk2_supervision_create(m._h, _lib.ptr(proto.phones), _lib.ptr(proto.durations), proto.phones.shape[0],
+                                 proto.frame_subsampling_factor, proto.left_tolerance, proto.right_tolerance)
+    if not h:
+        raise _lib.Pk2Error(L.pk2_last_error().decode())
+    try:
+        n = [C.c_int32() for _ in range(5)]
+        L.pk2_supervision_sizes(h, *[C.byref(v) for v in n])
+        frames, ns, na, nf, nal = (v.value for v in n)
+        src, dst, pdf = (np.empty(na, np.int32) for _ in range(3))
+        w, foff, stime = np.empty(na, np.float32), np.empty(frames + 1, np.int32), np.empty(ns, np.int32)
+        fin, finw = np.empty(nf, np.int32), np.empty(nf, np.float32)
+        aoff = np.empty(frames + 1, np.int32) if with_allowed else None
+        aph = np.empty(nal, np.int32) if with_allowed else None
+        _lib.check(L.pk2_supervision_copy(h, _lib.ptr(src), _lib.ptr(dst), _lib.ptr(pdf), _lib.ptr(w), _lib.ptr(foff),
+                                          _lib.ptr(stime), _lib.ptr(fin), _lib.ptr(finw), _lib.ptr(aoff), _lib.ptr(aph)))
+    finally:
+        L.pk2_supervision_destroy(h)
+    sup = Supervision(dict(num_states=ns, frames=frames, src=src, dst=dst, pdf=pdf, weight=w, frame_offsets=foff,
+                           state_time=stime, final_states=fin, final_weights=finw), label_dim=m.label_dim)
+    if with_allowed:
+        sup.allowed_phones = [aph[aoff[t]:aoff[t + 1]].tolist() for t in range(frames)]
+    return sup
+
+
+def split_to_phones(trans_model, alignment):
+    """Kaldi's SplitToPhones on a transition-id alignment -> (ok, [(phone, start, duration)])."""
+    if trans_model.tid2tstate is None:
+        raise ValueError("the transition model carries no topology (read it from final.mdl)")
+    ali = np.ascontiguousarray(alignment, dtype=np.int32)
+    T = ali.shape[0]
+    phones, durs = np.empty(max(T, 1), np.int32), np.empty(max(T, 1), np.int32)
+    n, ok = C.c_int32(), C.c_int32()
+    _lib.check(_lib.lib().pk2_split_to_phones(_lib.ptr(trans_model.tid2tstate), _lib.ptr(trans_model.tid2phone),
+                                              _lib.ptr(trans_model.tid_flags), trans_model.num_transition_ids(),
+                                              _lib.ptr(ali), T, _lib.ptr(phones), _lib.ptr(durs), C.byref(n),
+                                              C.byref(ok)))
+    starts = np.concatenate([[0], np.cumsum(durs[:n.value])[:-1]]) if n.value else []
+    return bool(ok.value), [(int(p), int(s), int(d)) for p, s, d in zip(phones[:n.value], starts, durs[:n.value])]
+
+
+def supervision_from_alignment(aligner, tree, trans_model, opts, trans_ids):
+    """The per-utterance block of reference bin/train_chain.py:262-272 as one call."""
+    phone_ali = aligner.to_phone_alignment(trans_ids)
+    proto = alignment_to_proto_supervision(opts, [item[0] for item in phone_ali], [item[2] for item in phone_ali])
+    return proto_supervision_to_supervision(tree, trans_model, proto, opts.convert_to_pdfs)
+
+
+class MappedAligner:
+    """The one use the reference makes of kaldi.alignment.MappedAligner (bin/train_chain.py:195-200,263):
+    to_phone_alignment on the transition-ids of the label files.  The decoding side of the aligner (tree, L.fst,
+    beams) is not needed for that and is ignored."""
+
+    def __init__(self, trans_model):
+        self.transition_model = trans_model
+
+    @classmethod
+    def from_files(cls, model_rxfilename, tree_rxfilename=None, lexicon_rxfilename=None, symbols_filename=None,
+                   disambig_rxfilename=None, **unused):
+        from .lattice import TransitionModel
+        return cls(TransitionModel.read(model_rxfilename))
+
+    def to_phone_alignment(self, alignment, phones=None):
+        """-> [(phone, start frame, duration)]."""
+        return split_to_phones(self.transition_model, alignment)[1]
 
 
 class _SupervisionBatch:

@@ -91,9 +91,10 @@ class ZipWavSource:
 
 
 class SyntheticSource:
-    def __init__(self, num_pdfs, seed=0, rank=0, world=1, with_tids=False):
+    def __init__(self, num_pdfs, seed=0, rank=0, world=1, with_tids=False, ali_model=None):
         self.num_pdfs = num_pdfs
         self.with_tids = with_tids     # also draw a transition-id alignment (aux_label) for the lattice criteria
+        self.ali_model = ali_model     # chain training: `label` holds transition-ids of this TransitionModel
         self.rng = np.random.default_rng(1234 + seed + rank)
         self.count = 0
 
@@ -105,15 +106,17 @@ class SyntheticSource:
         wav = synth.waveform(self.rng, d)
         T = synth.num_fbank_frames(wav.shape[0])
         self.count += 1
+        if self.ali_model is not None:
+            return wav, synth.phone_tid_alignment(self.rng, T, self.ali_model)[0], None, "synth-%d" % self.count
         if self.with_tids:
             tids = synth.tid_alignment(self.rng, T, self.num_pdfs)
             return wav, (tids - 1) // 2, tids, "synth-%d" % self.count      # pdf of a transition-id (synth.transition_model_arrays)
         return wav, synth.pdf_alignment(self.rng, T, self.num_pdfs), None, "synth-%d" % self.count
 
 
-def make_source(config, num_pdfs, rank=0, world=1, with_tids=False):
+def make_source(config, num_pdfs, rank=0, world=1, with_tids=False, ali_model=None):
     if config.get("synthetic") or not config.get("source_paths"):
-        return SyntheticSource(num_pdfs, rank=rank, world=world, with_tids=with_tids)
+        return SyntheticSource(num_pdfs, rank=rank, world=world, with_tids=with_tids, ali_model=ali_model)
     return ZipWavSource(config["source_paths"], config.get("data_path", ""), rank=rank, world=world)
 
 

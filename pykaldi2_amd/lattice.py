@@ -32,18 +32,44 @@ class LatticeFasterDecoderOptions:
 
 
 class TransitionModel:
-    """transition-id -> pdf-id / phone tables (all a lattice criterion needs from Kaldi's TransitionModel).
-    transition-ids are 1-based; index 0 of both tables is unused."""
+    """Kaldi's TransitionModel as tables.  transition-id -> pdf-id / phone is all a lattice criterion needs;
+    a model read from a file (or built with from_topology) also keeps the HMM topologies, the tuples and
+    transition-id -> transition-state / self-loop / final flags, which splitting an alignment into phones and the
+    chain supervision need.  transition-ids are 1-based; index 0 of every table is unused."""
 
     def __init__(self, tid2pdf, tid2phone):
         self.tid2pdf = np.ascontiguousarray(tid2pdf, dtype=np.int32)
         self.tid2phone = np.ascontiguousarray(tid2phone, dtype=np.int32)
         assert self.tid2pdf.shape == self.tid2phone.shape and self.tid2pdf.ndim == 1
         self._dev = {}
+        self.phone2entry = self.entries = self.tuples = self.tid2tstate = self.tid_flags = None
 
     @classmethod
     def from_arrays(cls, d):
         return cls(d["tid2pdf"], d["tid2phone"])
+
+    @classmethod
+    def from_topology(cls, phone2entry, entries, tuples):
+        """phone2entry: {phone: entry index}; entries[e] = HMM states [(forward pdf-class, self-loop pdf-class,
+        [destination states])] with the non-emitting final state last (classes -1); tuples = (phone, hmm_state,
+        forward pdf, self-loop pdf) in transition-state order.  Transition ids enumerate, for every tuple in
+        order, the transitions of its HMM state in topology order (TransitionModel::ComputeDerived)."""
+        tid2pdf, tid2phone, tid2tstate, flags = [-1], [0], [0], [0]
+        for ts, (phone, hmm_state, fwd_pdf, loop_pdf) in enumerate(tuples, start=1):
+            states = entries[phone2entry[phone]]
+            for dst_state in states[hmm_state][2]:
+                loop = dst_state == hmm_state
+                tid2pdf.append(loop_pdf if loop else fwd_pdf)   # a self-loop may carry its own pdf (<Tuples>)
+                tid2phone.append(phone)
+                tid2tstate.append(ts)
+                flags.append((1 if loop else 0) | (2 if dst_state == len(states) - 1 else 0))
+        m = cls(tid2pdf, tid2phone)
+        m.phone2entry = {int(k): int(v) for k, v in phone2entry.items()}
+        m.entries = [[(int(f), int(l), [int(d) for d in dsts]) for f, l, dsts in st] for st in entries]
+        m.tuples = np.asarray(tuples, dtype=np.int32).reshape(-1, 4)
+        m.tid2tstate = np.asarray(tid2tstate, dtype=np.int32)
+        m.tid_flags = np.asarray(flags, dtype=np.uint8)
+        return m
 
     @classmethod
     def read(cls, path):
@@ -71,16 +97,18 @@ class TransitionModel:
                 while toks[i] != "</TopologyEntry>":
                     assert toks[i] == "<State>"
                     i += 2   # <State> index
-                    dsts = []
+                    dsts, fwd_class, loop_class = [], -1, -1
                     if toks[i] in ("<PdfClass>",):
+                        fwd_class = loop_class = int(toks[i + 1])
                         i += 2
                     elif toks[i] == "<ForwardPdfClass>":
+                        fwd_class, loop_class = int(toks[i + 1]), int(toks[i + 3])
                         i += 4   # <ForwardPdfClass> a <SelfLoopPdfClass> b
                     while toks[i] == "<Transition>":
                         dsts.append(int(toks[i + 1])); i += 3
                     assert toks[i] == "</State>"
                     i += 1
-                    states.append(dsts)
+                    states.append((fwd_class, loop_class, dsts))
                 i += 1
                 for ph in phones:
                     phone_entry[ph] = len(entries)
@@ -93,17 +121,12 @@ class TransitionModel:
         n = int(toks[i + 1])
         i += 2
         width = 3 if tag == "<Triples>" else 4
-        tid2pdf, tid2phone = [-1], [0]
+        tuples = []
         for _ in range(n):
             vals = [int(x) for x in toks[i:i + width]]
             i += width
-            phone, hmm_state = vals[0], vals[1]
-            fwd_pdf, loop_pdf = vals[2], vals[-1]
-            for dst_state in entries[phone_entry[phone]][hmm_state]:
-                # in a <Tuples> model the self-loop (the transition back to hmm_state) carries its own pdf
-                tid2pdf.append(loop_pdf if dst_state == hmm_state else fwd_pdf)
-                tid2phone.append(phone)
-        return cls(tid2pdf, tid2phone)
+            tuples.append((vals[0], vals[1], vals[2], vals[-1]))
+        return cls.from_topology(phone_entry, entries, tuples)
 
     @classmethod
     def _read_binary(cls, raw, path):
@@ -151,27 +174,24 @@ class TransitionModel:
         for _ in range(sz):
             states = []
             for _ in range(i32()):
-                i32()                      # forward pdf class
+                fwd_class = loop_class = i32()
                 if not is_hmm:
-                    i32()                  # self-loop pdf class
+                    loop_class = i32()
                 dsts = []
                 for _ in range(i32()):
                     dsts.append(i32())
                     i32()                  # probability (float, same 5-byte encoding)
-                states.append(dsts)
+                states.append((fwd_class, loop_class, dsts))
             entries.append(states)
         token("</Topology>")
         tag = token()
         assert tag in ("<Triples>", "<Tuples>"), tag
-        tid2pdf, tid2phone = [-1], [0]
+        tuples = []
         for _ in range(i32()):
             phone, hmm_state, fwd_pdf = i32(), i32(), i32()
-            loop_pdf = i32() if tag == "<Tuples>" else fwd_pdf
-            for dst_state in entries[phone2idx[phone]][hmm_state]:
-                tid2pdf.append(loop_pdf if dst_state == hmm_state else fwd_pdf)
-                tid2phone.append(phone)
+            tuples.append((phone, hmm_state, fwd_pdf, i32() if tag == "<Tuples>" else fwd_pdf))
         token("</Triples>" if tag == "<Triples>" else "</Tuples>")
-        return cls(tid2pdf, tid2phone)
+        return cls.from_topology({ph: phone2idx[ph] for ph in phones}, entries, tuples)
 
     def num_transition_ids(self):
         return int(self.tid2pdf.shape[0] - 1)

@@ -170,13 +170,14 @@ def numerator_fst_from_alignment(ali, subsample=3, tolerance=5):
                 final_weights=np.zeros(1, dtype=np.float32))
 
 
-def minibatch(rng, batch, num_pdfs, sr=16000):
-    """One LibriSpeech-shaped minibatch: list of (wav f32[N], alignment i64[T])."""
+def minibatch(rng, batch, num_pdfs, sr=16000, ali_model=None):
+    """One LibriSpeech-shaped minibatch: list of (wav f32[N], alignment i64[T]); the alignment holds pdf-ids,
+    or transition-ids of `ali_model` (a TransitionModel: the label files of chain training)."""
     out = []
     for d in utterance_durations(rng, batch):
         wav = waveform(rng, float(d), sr)
         T = num_fbank_frames(wav.shape[0])
-        out.append((wav, pdf_alignment(rng, T, num_pdfs)))
+        out.append((wav, phone_tid_alignment(rng, T, ali_model)[0] if ali_model is not None else pdf_alignment(rng, T, num_pdfs)))
     return out
 
 
@@ -244,3 +245,96 @@ def tid_alignment(rng, num_frames, num_pdfs):
             d = int(rng.geometric(0.4))
             out.extend([base] * (d - 1) + [base + 1])
     return np.asarray(out[:num_frames], np.int64)
+
+
+# ----------------------------------------------------------------------------------------
+# Chain model for the supervision builder: tree + transition model + transition-id alignments
+# ----------------------------------------------------------------------------------------
+CHAIN_TOPO = [(0, 1, [0, 1]), (-1, -1, [])]                         # Kaldi's chain topology: one emitting state
+BAKIS_TOPO = [(0, 0, [0, 1]), (1, 1, [1, 2]), (2, 2, [2, 3]), (-1, -1, [])]
+SKIP_TOPO = [(0, 1, [0, 1, 2]), (2, 2, [1, 2]), (-1, -1, [])]       # state 0 may skip state 1; state 1 loops second
+
+
+def chain_model(num_pdfs, seed=0, mixed_topologies=False):
+    """A left-biphone chain model in Kaldi's terms: returns (tree, trans_model).
+    tree: ContextDependency with N = 2, P = 1 -- table on the central phone, split on the left phone (a random
+    half of the phones, sometimes with 0 = utterance start), table on the pdf-class, constant leaves.
+    Phones use the chain topology (forward pdf-class 0, self-loop pdf-class 1: 4 pdfs per phone); with
+    mixed_topologies every third phone is a 3-state Bakis model and every fifth a 2-state model with a skip."""
+    from .lattice import TransitionModel
+    from .tree import ContextDependency
+    rng = np.random.default_rng(seed)
+    entries = [CHAIN_TOPO, BAKIS_TOPO, SKIP_TOPO]
+    phone2entry, tuples, kids, next_pdf, ph = {}, [], [None], 0, 0
+    while True:
+        e = (1 if (ph + 1) % 3 == 0 else 2 if (ph + 1) % 5 == 0 else 0) if mixed_topologies else 0
+        classes = sorted({c for f, l, _ in entries[e][:-1] for c in (f, l)})
+        if next_pdf + 2 * len(classes) > num_pdfs:
+            break
+        ph += 1
+        phone2entry[ph] = e
+        branch = []
+        for _ in range(2):
+            leaf = [None] * (max(classes) + 1)
+            for c in classes:
+                leaf[c] = ("CE", next_pdf)
+                next_pdf += 1
+            branch.append(leaf)
+        kids.append((branch[0], branch[1]))
+    num_phones = ph
+    root_kids = [None]
+    for p in range(1, num_phones + 1):
+        yes = rng.choice(num_phones + 1, size=max(1, (num_phones + 1) // 2), replace=False)
+        b0, b1 = kids[p]
+        root_kids.append(("SE", 0, [int(v) for v in yes], ("TE", -1, b0), ("TE", -1, b1)))
+        for leaf in (b0, b1):
+            for hs, (f, l, _) in enumerate(entries[phone2entry[p]][:-1]):
+                tuples.append((p, hs, leaf[f][1], leaf[l][1]))
+    tree = ContextDependency.from_nested(2, 1, ("TE", 1, root_kids))
+    tm = TransitionModel.from_topology(phone2entry, entries, sorted(set(tuples)))
+    return tree, tm
+
+
+def phone_tid_alignment(rng, num_frames, trans_model, reorder=True):
+    """A transition-id alignment of exactly `num_frames` frames from `trans_model` (the reference's label
+    files): random phones, a random path through each phone's HMM, 3 + Geometric(0.12) frames per phone split
+    over the HMM states of the path; with `reorder` the self-loops follow the forward transition (Kaldi's
+    default graphs), otherwise they precede it.  Returns (tids i64[T], phones, durations)."""
+    first_tid = {}
+    for tid in range(1, trans_model.num_transition_ids() + 1):
+        first_tid.setdefault(int(trans_model.tid2tstate[tid]), tid)
+    by_state = {}
+    for ts, (p, hs, _, _) in enumerate(trans_model.tuples.tolist(), start=1):
+        by_state.setdefault((p, hs), []).append(ts)
+    phone_ids = sorted(trans_model.phone2entry)
+    tids, phones, durs = [], [], []
+    last_loop = None      # (position of the last self-loop run, its transition-id): where a short tail is absorbed
+    while len(tids) < num_frames:
+        p = int(phone_ids[rng.integers(len(phone_ids))])
+        states = trans_model.entries[trans_model.phone2entry[p]]
+        path, hs = [], 0
+        while hs != len(states) - 1:
+            fwd = [k for k, d in enumerate(states[hs][2]) if d != hs]
+            k = fwd[int(rng.integers(len(fwd)))]
+            path.append((hs, k))
+            hs = states[hs][2][k]
+        remaining = num_frames - len(tids)
+        if len(path) > remaining:
+            if last_loop is None:
+                raise ValueError("num_frames too small for one phone")
+            at, loop = last_loop
+            tids[at:at] = [loop] * remaining
+            durs[-1] += remaining
+            break
+        total = max(len(path), min(int(rng.geometric(0.12)) + 3, remaining))
+        piece = []
+        for j, (hs, k) in enumerate(path):
+            dsts = states[hs][2]
+            ts = by_state[(p, hs)][int(rng.integers(len(by_state[(p, hs)])))]
+            hold = total // len(path) + (1 if j < total % len(path) else 0) if hs in dsts else 1
+            loops = [first_tid[ts] + dsts.index(hs)] * (hold - 1)
+            if hs in dsts:
+                last_loop = (len(tids) + len(piece) + (1 if reorder else 0), first_tid[ts] + dsts.index(hs))
+            piece.extend([first_tid[ts] + k] + loops if reorder else loops + [first_tid[ts] + k])
+        tids.extend(piece); phones.append(p); durs.append(len(piece))
+    return np.asarray(tids, np.int64), phones, durs

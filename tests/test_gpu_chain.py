@@ -85,6 +85,39 @@ def test_chain_objf_and_deriv_matches_oracle(xent, arc_pdf):
         assert not grad[n, lens[n]:].any()
 
 
+def test_chain_objf_with_supervisions_built_from_alignments():
+    """The reference's per-utterance pipeline end to end (bin/train_chain.py:262-272 -> ops/ops.py:265): the
+    supervisions come from transition-id alignments through SplitToPhones / proto-supervision / supervision
+    (mixed HMM topologies, left-biphone tree); objective and derivative against the oracle, and with zero
+    logits the numerator log-probability is the log of the number of paths the oracle counts."""
+    from oracle import supervision_ref as SR
+    S, A, P = 2000, 60000, 600
+    g, G, ref = _mk(S, A, P, seed=12)
+    tree, tm = synth.chain_model(P, seed=4, mixed_topologies=True)
+    rm = SR.TransitionModelRef(tm.phone2entry, tm.entries, tm.tuples.tolist())
+    aligner, sopts = chain.MappedAligner(tm), chain.SupervisionOptions()
+    rng = np.random.default_rng(8)
+    alis = [synth.phone_tid_alignment(rng, T, tm, T % 2 == 0)[0] for T in (280, 95, 402, 33)]
+    sups = [chain.supervision_from_alignment(aligner, tree, tm, sopts, a) for a in alis]
+    lens = [s.frames_per_sequence for s in sups]
+    assert lens == [-(-a.shape[0] // 3) for a in alis]
+    lg = rng.normal(0, 2, size=(4, max(lens), P)).astype(np.float32)
+    opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=0.1)
+    out, grad = chain.compute_chain_objf_and_deriv(opts, G, sups, torch.from_numpy(lg).cuda())
+    out, grad = out.cpu().numpy(), grad.cpu().numpy()
+    for n in range(4):
+        objf, want, aux = R.chain_objf_and_deriv(lg[n, :lens[n]].astype(np.float64), ref, _ref_fst(sups[n]),
+                                                 leaky=1e-4, xent_regularize=0.1)
+        assert abs(out[0, n] - objf) <= 1e-3 * abs(objf), (n, out[0, n], objf)
+        assert np.abs(grad[n, :lens[n]] - want).max() < 1e-4
+    out0, _ = chain.compute_chain_objf_and_deriv(opts, G, sups, torch.zeros(4, max(lens), P, device="cuda"))
+    for n, a in enumerate(alis):
+        pieces = aligner.to_phone_alignment(a)
+        phones, durs = [p for p, _, _ in pieces], [d for _, _, d in pieces]
+        count = SR.count_paths(rm, tree.compute, tree.N, tree.P, phones, SR.alignment_to_proto_supervision(phones, durs))
+        assert abs(out0[1, n].item() - np.log(float(count))) <= 1e-3 * np.log(float(count)) + 1e-4, (n, count)
+
+
 def test_reference_operator_convention_and_nan_guard():
     """ChainObjtiveFunction returns +objf and hands -grad to autograd whatever grad_out is
     (reference ops/ops.py:273-280); a NaN logit zeroes that sequence's gradient and gives -10/frame."""
