@@ -24,14 +24,25 @@ import torch as th
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pykaldi2_amd import data, fbank, hvd, lattice, lstm, ops, optim, se, synth, utils  # noqa: E402
+from pykaldi2_amd import data, fbank, hvd, lattice, lstm, ops, optim, se, synth, transformer, utils  # noqa: E402
 
 
-def main():
+def main(arch="blstm"):
+    """arch = "transformer": the command line of the reference's bin/train_transformer_se.py (TransformerAM built
+    from -dim_model / -nheads / -ff_size / -nlayers / -dropout, -look_ahead attention mask, -dataPath)."""
     parser = argparse.ArgumentParser()
     parser.add_argument("-config")
     parser.add_argument("-data", help="data yaml file")
-    parser.add_argument("-data_path", default='', type=str, help="path of data files")
+    if arch == "transformer":
+        parser.add_argument("-dataPath", dest="data_path", default='', type=str, help="path of data files")
+        parser.add_argument("-dropout", default=0, type=float, help="set the dropout ratio")
+        parser.add_argument("-nheads", default=4, type=int, help="the number of attention heads")
+        parser.add_argument("-dim_model", default=512, type=int, help="the model dimension")
+        parser.add_argument("-ff_size", default=2048, type=int, help="the size of feed-forward layer")
+        parser.add_argument("-nlayers", default=6, type=int, help="the number of layers")
+        parser.add_argument("-look_ahead", default=-1, type=int, help="the number of frames to look ahead")
+    else:
+        parser.add_argument("-data_path", default='', type=str, help="path of data files")
     parser.add_argument("-seed_model", default='', help="the seed nerual network model")
     parser.add_argument("-exp_dir", help="the directory to save the outputs")
     parser.add_argument("-transform", help="feature transformation matrix or mvn statistics")
@@ -75,7 +86,13 @@ def main():
 
     mc = config["model_config"]
     P = mc["label_size"]
-    model = lstm.LSTMAM(mc["feat_dim"], P, mc["hidden_size"], mc["num_layers"], mc["dropout"], True).to(dev)
+    forward = None
+    if arch == "transformer":     # reference bin/train_transformer_se.py:128
+        model = transformer.TransformerAM(mc["feat_dim"], args.dim_model, args.nheads, args.ff_size, args.nlayers,
+                                          args.dropout, P).to(dev)
+        forward = lambda m, x, frames: transformer.padded_forward(m, x, frames, args.look_ahead)   # noqa: E731
+    else:
+        model = lstm.LSTMAM(mc["feat_dim"], P, mc["hidden_size"], mc["num_layers"], mc["dropout"], True).to(dev)
     if args.seed_model:
         if not os.path.isfile(args.seed_model):
             sys.stderr.write('ERROR: The model file %s does not exist!\n' % (args.seed_model))
@@ -124,14 +141,16 @@ def main():
 
     model.train()
     for epoch in range(args.num_epochs):
-        run_train_epoch(model, optimizer, log_prior.to(dev), source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev)
+        run_train_epoch(model, optimizer, log_prior.to(dev), source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev,
+                        forward)
         if hvd.rank() == 0 and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.se.' + str(epoch) + '.tar')
     hvd.shutdown()
 
 
-def run_train_epoch(model, optimizer, log_prior, source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev):
+def run_train_epoch(model, optimizer, log_prior, source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev,
+                    forward=None):
     batch_time = utils.AverageMeter('Time', ':6.3f')
     losses = utils.AverageMeter('Loss', ':.4e')
     grad_norm = utils.AverageMeter('grad_norm', ':.4e')
@@ -141,7 +160,7 @@ def run_train_epoch(model, optimizer, log_prior, source, fb, epoch, asr_decoder,
     end = time.time()
     for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
         loss, se_val, ce_loss, frames = se.sequence_loss(model, fb, batch, asr_decoder, trans_model, log_prior, args.criterion,
-                                                         silence_ids, args.ce_ratio, ce_criterion)
+                                                         silence_ids, args.ce_ratio, ce_criterion, forward)
         optimizer.zero_grad()
         loss.backward()
         norm = optim.clip_grad_norm_(optimizer, args.max_grad_norm)

@@ -44,12 +44,17 @@ def log_prior_from_counts(counts):
     return torch.tensor(np.log(c / c.sum()), dtype=torch.float32)
 
 
-def sequence_loss(model, fb, batch, asr_decoder, trans_model, log_prior, criterion, silence_ids, ce_ratio, ce_criterion):
+def sequence_loss(model, fb, batch, asr_decoder, trans_model, log_prior, criterion, silence_ids, ce_ratio, ce_criterion,
+                  forward=None):
     """Forward of one minibatch: batch = dict(wav, lens, y = pdf alignments, aux = transition-id alignments)
-    from pykaldi2_amd.data.  Returns (loss, se_value, ce_loss, frames)."""
+    from pykaldi2_amd.data.  `forward(model, x[Tmax, N, 80], frames) -> [N, Tmax, P]` replaces the BLSTM call
+    (TransformerAM with its masks: bin/train_transformer_se.py).  Returns (loss, se_value, ce_loss, frames)."""
     feats, frames, row_off = fb(batch["wav"], batch["lens"])
     x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=True)      # [Tmax, N, 80]
-    prediction = model.forward_time_major(x).transpose(0, 1)                                       # [N, Tmax, P] view
+    if forward is not None:
+        prediction = forward(model, x, frames)
+    else:
+        prediction = model.forward_time_major(x).transpose(0, 1)                                   # [N, Tmax, P] view
     N, Tmax = prediction.shape[0], prediction.shape[1]
     y = np.full((N, Tmax), -100, np.int64)
     for n, lab in enumerate(batch["y"]):

@@ -320,3 +320,19 @@ class TransformerAM(nn.Module):
             sm = src_mask.to(device=data.device, dtype=torch.float32).contiguous()
         params = [p for _, p in self.named_parameters()]
         return _TransformerFunction.apply(data, self, sm, kp, *params)
+
+
+def padded_forward(model, x, frames, look_ahead=-1):
+    """The masks of reference bin/train_transformer_se.py:242-257 (= train_transformer_ce.py:188-201) around one
+    forward: x [T, B, D] time-major, zero-padded; frames[b] valid frames of utterance b.  key_padding_mask is True
+    on padding; with look_ahead > -1 frame t may attend to frames <= t + look_ahead.  Returns [B, T, P] (a
+    transposed view of the model's [T, B, P] output)."""
+    T, B = x.shape[0], x.shape[1]
+    kpm = torch.ones(B, T, dtype=torch.bool)
+    for b, n in enumerate(frames):
+        kpm[b, :int(n)] = False
+    src_mask = None
+    if look_ahead > -1:
+        keep = torch.tril(torch.ones(T, T), diagonal=look_ahead)
+        src_mask = torch.zeros(T, T).masked_fill(keep == 0, float("-inf")).to(x.device)
+    return model(x, src_mask, kpm.to(x.device)).transpose(0, 1)

@@ -60,6 +60,34 @@ def test_train_se_cli_synthetic(tmp_path, criterion):
     assert set(ck) == {"model", "optimizer", "epoch"} and "lstm.weight_hh_l1_reverse" in ck["model"]
 
 
+def test_train_transformer_ce_cli_synthetic(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_transformer_ce.py"), "-train_config",
+                          _cfg(tmp_path, "ce.yaml", 120, True), "-exp_dir", str(tmp_path / "exp"), "-lr", "1e-3",
+                          "-batch_size", "3", "-sweep_size", "0.02", "-print_freq", "1", "-synthetic", "-nlayers", "2",
+                          "-dim_model", "64", "-nheads", "4", "-ff_size", "128", "-look_ahead", "6", "-warmup_step", "10"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Epoch: [0]" in out.stdout and "grad_norm" in out.stdout
+    ck = torch.load(tmp_path / "exp" / "model.0.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch"}
+    assert "transformer.layers.1.encoder_layer.self_attn.in_proj_weight" in ck["model"] and "output_layer.weight" in ck["model"]
+
+
+def test_train_transformer_se_cli_synthetic(tmp_path):
+    cfg = yaml.safe_load(open(_cfg(tmp_path, "se.yaml", 120, True)))
+    cfg["decoder_config"] = dict(beam=9.0, lattice_beam=4.0, max_active=400, acoustic_scale=0.3, align_beam=10)
+    (tmp_path / "se.yaml").write_text(yaml.safe_dump(cfg))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_transformer_se.py"), "-config", str(tmp_path / "se.yaml"),
+                          "-exp_dir", str(tmp_path / "exp"), "-lr", "1e-4", "-momentum", "0.9", "-criterion", "mmi",
+                          "-batch_size", "2", "-sweep_size", "0.02", "-print_freq", "1", "-synthetic", "-graph_words", "60",
+                          "-nlayers", "2", "-dim_model", "64", "-nheads", "4", "-ff_size", "128", "-dataPath", ""],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Epoch: [0]" in out.stdout and "grad_norm" in out.stdout
+    ck = torch.load(tmp_path / "exp" / "model.se.0.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch"} and "transformer.layers.0.conv1d.weight" in ck["model"]
+
+
 def test_dump_loglikes_cli_synthetic(tmp_path):
     from pykaldi2_amd import kaldi_io
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "dump_loglikes.py"), "-config",
