@@ -405,10 +405,6 @@ def main():
         return ce_workload(args, dev, rank, world)
     if args.se:
         return se_workload(args, dev, rank, world)
-    log("rank %d/%d: building synthetic den graph" % (rank, world))
-    g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
-    den = chain.DenominatorGraph(g, P)
-    log("den graph ready")
     if args.gemm_only:
         from pykaldi2_amd.lstm import _gemm, _p
         shapes = [(0, 1, 2356, 4096, 1024), (0, 1, 2356, 6048, 1024), (1, 0, 6048, 1024, 2356), (0, 0, 2356, 1024, 6048),
@@ -451,6 +447,10 @@ def main():
         e1.record(); torch.cuda.synchronize()
         print("lstm_fwd us/step %.2f" % (1e3 * e0.elapsed_time(e1) / 5 / T), flush=True)
         return
+    log("rank %d/%d: building synthetic den graph" % (rank, world))
+    g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
+    den = chain.DenominatorGraph(g, P)
+    log("den graph ready")
     if args.den_only:
         lens = [589, 410, 377, 502]
         x = torch.randn(4, max(lens), P, device=dev)

@@ -13,6 +13,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_$c -o den -- python $R/bench.py --den-only > $R/gpurun_out/pmc_$c.log 2>&1
   echo "pmc $c exit $?" >> $R/gpurun_out/summary.txt
 done
+# MFMA busy cycles of the f32 GEMM kernel (LSTM input projections / output layer shapes), own pass, counters only
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_mfma -o gemm -- python $R/bench.py --gemm-only > $R/gpurun_out/pmc_mfma.log 2>&1
+echo "pmc mfma exit $?" >> $R/gpurun_out/summary.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/den_trace -o den -- python $R/bench.py --den-only > $R/gpurun_out/den_trace.log 2>&1
 for w in ce se; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o $w -- python $R/bench.py --$w --steps 3 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$w.log 2>&1
@@ -26,6 +29,8 @@ python tools/prof_stats.py gpurun_out/prof/bench_results.db 30 > gpurun_out/r01_
 python tools/prof_stats.py gpurun_out/den_trace/den_results.db 12 > gpurun_out/r01_den_kernel_stats.txt
 python tools/pmc_stats.py gpurun_out/pmc_FETCH_SIZE/den_results.db > gpurun_out/r01_den_pmc.txt
 python tools/pmc_stats.py gpurun_out/pmc_WRITE_SIZE/den_results.db >> gpurun_out/r01_den_pmc.txt
+python tools/pmc_stats.py gpurun_out/pmc_mfma/gemm_results.db > gpurun_out/r01_gemm_mfma_pmc.txt
+grep gemm gpurun_out/pmc_mfma.log >> gpurun_out/r01_gemm_mfma_pmc.txt
 grep -o '{"bound.*' gpurun_out/den_trace.log > gpurun_out/r01_den_only.json
-rm -rf gpurun_out/prof gpurun_out/prof_ce gpurun_out/prof_se gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/den_trace
+rm -rf gpurun_out/prof gpurun_out/prof_ce gpurun_out/prof_se gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mfma gpurun_out/den_trace
 cat gpurun_out/summary.txt; cat gpurun_out/bench.json
