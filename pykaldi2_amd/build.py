@@ -27,7 +27,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
     os.environ.get("PK2_EXTRA_FLAGS", "").split()
 # hipcc defaults to -ffp-contract=fast, which fuses a*b+c across statements and ignores `#pragma clang fp
 # contract(off)`; the decoder's costs must round like the oracle's separate float32 operations.
-FILE_FLAGS = {"lattice_decode.hip": ["-ffp-contract=off"]}
+FILE_FLAGS = {"lattice_decode.hip": ["-ffp-contract=off"], "lattice_decode_frames.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():

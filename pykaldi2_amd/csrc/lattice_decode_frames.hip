@@ -1,0 +1,495 @@
+// On-the-fly lattice generation, launch-per-frame variant: a TEAM of workgroups per utterance.
+//
+// lattice_decode.hip gives every utterance one workgroup for the whole decode: with the 8 utterances per GPU of
+// the lattice-MMI configuration 248 of the 256 CUs idle while 8 run a serial chain of ~125 us frames.  Here a
+// frame is cut into a few kernels with no barrier wider than a workgroup inside; between them the kernel boundary
+// is the (cheapest) grid barrier, and the launches of 64 frames are replayed from one hipGraph:
+//
+//   cutoff     (1 workgroup / utterance)  GetCutoff: best cost (reduced by the previous frame's finalise), beam,
+//                                         exact k-th smallest cost when max_active / min_active bind
+//   list       (G workgroups / utterance) arc work list of the surviving tokens -- every workgroup reserves a
+//                                         region with one atomicAdd, the order of a bag of arcs is irrelevant --
+//                                         arc costs, atomicMin of the best new cost
+//   expand                                atomicMin into the per-state table, new tokens, emitting links
+//   fix+round0                            link destinations (state -> token), first epsilon relaxation round
+//   round 1..R                            further rounds; each returns at once when the previous one changed nothing
+//   tail       (1 workgroup / utterance)  finishes deeper epsilon chains to the exact fixed point (normally a no-op)
+//   eps links                             epsilon links from the final costs
+//   finalise                              final token costs, arc ranges, sparse table reset, best cost of the frame
+//
+// The epsilon list is shared by index ownership (entry e belongs to team thread e mod team size) and a launch only
+// walks the entries that existed at the launch boundary, so workgroups never read another workgroup's plain
+// stores of the same launch; everything that crosses workgroups inside a launch is an agent-scope atomic (state
+// table, counters).  Token costs and the kept link SET are those of the one-workgroup decoder and of the oracle
+// (minima and sets do not depend on the order of the atomics); token and link numbering differ.
+// Final costs and lattice pruning run in finish_and_prune (one workgroup per utterance), unchanged.
+#include <map>
+
+#include "lattice_decode_common.h"
+#include "step_graph.h"
+
+namespace pk2 {
+
+template <typename T>
+__device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct TeamCtx {
+  UttView V;
+  LatFrame* F;
+  int n, wg, G, t, T;
+  bool live;
+};
+
+// Common prologue: frame index t = base + local - 1 (step 0 is InitDecoding's closure, "frame -1").
+__device__ __forceinline__ TeamCtx team_ctx(const DecodeParams& p, const StepCounter* cnt, int local) {
+  TeamCtx c;
+  c.n = blockIdx.y; c.wg = blockIdx.x; c.G = gridDim.x;
+  c.t = cnt->base + local - 1;
+  const LatUtt U = p.L.utt[c.n];
+  c.T = U.T;
+  c.V = make_view(p, c.n, U);
+  c.F = p.L.frame + c.n;
+  c.live = cnt->base + local < cnt->T && c.t < c.T && c.F->status == kLatOk;
+  return c;
+}
+
+// The last workgroup of the team to get here returns true (all of its threads); the caller's thread 0 then does
+// the bookkeeping of the launch.  Counters it reads were bumped by returning atomics that completed before the
+// workgroup barrier.
+__device__ __forceinline__ bool team_last(LatFrame* F, int G, int* s_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(&F->arrive, 1);
+    *s_flag = old == G - 1;
+    if (old == G - 1) st_coherent(&F->arrive, 0);
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+// Slot allocation from a team-wide counter with ONE atomic per wave: the lanes that are active here and `want` a slot
+// are counted by ballot, the first of them reserves the run.  (A per-lane atomicAdd on the one counter of an
+// utterance serialises: 25k of them per frame cost 300 us.)  Call from any control flow; lanes of a wave always
+// belong to one utterance.
+__device__ __forceinline__ int wave_alloc(int32_t* counter, bool want) {
+  const unsigned long long mask = __ballot(want);
+  if (!want) return -1;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, leader, 64);
+  return base + __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Called by every lane that created the token of state d (old == kEmpty); others pass create = false.
+__device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int fb, int d,
+                                                    bool create = true) {
+  const int idx = wave_alloc(&F->n_new, create);
+  bool eps = false;
+  if (create) {
+    if (fb + idx < V.tok_cap) {
+      V.ts[fb + idx] = d;
+      V.tc[fb + idx] = INFINITY;
+      st_coherent(&V.stt[d], idx);
+      eps = p.g.n_off[d + 1] > p.g.n_off[d];
+    } else {
+      st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+    }
+  }
+  const int e = wave_alloc(&F->n_elist, eps);
+  if (eps) {
+    if (e < V.tok_cap) V.elist[e] = fb + idx; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+  }
+}
+
+// One relaxation round over the epsilon-list entries [0, ne) owned by this workgroup.  Returns (to all threads)
+// whether this workgroup lowered a cost.
+__device__ __forceinline__ int eps_round(const DecodeParams& p, const UttView& V, LatFrame* F, Shared& sh, int fb,
+                                         float cutoff, int ne, int wg, int G) {
+  const uint32_t kcut = enc_cost(cutoff);
+  int changed = 0;
+  for_each_arc(sh, V.elist, ne, V.ts, p.g.n_off,
+               [&](int i, float* c) {
+                 const float cc = dec_cost(ld_coherent(&V.stc[V.ts[i]]));
+                 if (!(cc < V.tc[i])) return false;      // not improved since its last expansion
+                 V.tc[i] = cc;
+                 *c = cc;
+                 return cc < cutoff;
+               },
+               [&](int i, float c, int a) {
+                 const float tot = c + p.g.n_w[a];
+                 const uint32_t k = enc_cost(tot);
+                 if (k < kcut) {
+                   const int d = p.g.n_dst[a];
+                   const uint32_t old = atomicMin(&V.stc[d], k);
+                   if (k < old) {
+                     // another round is needed only if the state that got cheaper has epsilon arcs of its own
+                     if (p.g.n_off[d + 1] > p.g.n_off[d]) changed = 1;
+                     if (old == kEmpty) team_register_token(p, V, F, fb, d);
+                   }
+                 }
+               },
+               wg * kLatThreads + (int)threadIdx.x, G * kLatThreads);
+  return __syncthreads_or(changed);
+}
+
+// ---- step 0 only: the start token ----
+__global__ void lat_frames_init(const DecodeParams p) {
+  const int n = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const LatUtt U = p.L.utt[n];
+  const UttView V = make_view(p, n, U);
+  LatFrame* F = p.L.frame + n;
+  F->f0 = 0; F->f1 = 0; F->link_end = 0; F->n_new = 0; F->n_link = 0; F->n_elist = 0; F->n_arcs = 0; F->ne_snap = 0;
+  F->best_key = kEmpty; F->best_next = kEmpty; F->nmin_key = kEmpty;
+  F->cur_cutoff = INFINITY; F->adaptive = p.beam; F->build_cutoff = p.beam;   // InitDecoding: ProcessNonemitting(beam)
+  F->status = kLatOk; F->arrive = 0;
+  for (int r = 0; r <= kLatEpsRounds; ++r) F->changed[r] = 0;
+  V.stc[p.g.start] = enc_cost(0.f);
+  team_register_token(p, V, F, 0, p.g.start);
+  F->ne_snap = F->n_elist;
+  V.ftok[0] = 0; V.seg[0] = 0;
+}
+
+// ---- GetCutoff ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live || c.t < 0) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.n_heavy = 0;
+  LatFrame* F = c.F;
+  const float* tc = c.V.tc;
+  const int f0 = F->f0, f1 = F->f1, nt = f1 - f0;
+  const float best = dec_cost(F->best_key);
+  const float beam_cutoff = best + p.beam;
+  float cur_cutoff = beam_cutoff, adaptive = p.beam;
+  const bool chk_max = nt > p.max_active, chk_min = p.min_active > 0 && nt > p.min_active;
+  if (chk_max || chk_min) {
+    int c_lt = 0, c_le = 0;
+    for (int i = f0 + tid; i < f1; i += kLatThreads) { c_lt += tc[i] < beam_cutoff; c_le += tc[i] <= beam_cutoff; }
+    c_lt = block_sum_i(c_lt, sh);
+    c_le = block_sum_i(c_le, sh);
+    if (chk_max && c_lt > p.max_active) {
+      cur_cutoff = kth_smallest_in_range(tc + f0, nt, p.max_active, best, beam_cutoff, sh);
+      adaptive = (cur_cutoff - best) + p.beam_delta;
+    } else if (chk_min && c_le <= p.min_active) {
+      cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
+      adaptive = (cur_cutoff - best) + p.beam_delta;
+    }
+  }
+  if (tid == 0) { F->cur_cutoff = cur_cutoff; F->adaptive = adaptive; F->n_arcs = 0; F->nmin_key = kEmpty; }
+}
+
+// ---- arc work list of the surviving tokens, arc costs, best new cost ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  __shared__ int s_base;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live || c.t < 0) return;
+  const int tid = threadIdx.x;
+  const UttView& V = c.V;
+  LatFrame* F = c.F;
+  const float* tc = V.tc;
+  const int f0 = F->f0, f1 = F->f1;
+  const float cur_cutoff = F->cur_cutoff;
+  const float* row = p.loglikes + (int64_t)c.n * p.seq_stride + (int64_t)c.t * p.frame_stride;
+  for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
+  float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
+  float nmin = INFINITY;
+  for (int base = f0 + c.wg * 4 * kLatThreads; base < f1; base += c.G * 4 * kLatThreads) {
+    int2 ar[4];
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = base + tid * 4 + q;
+      ar[q] = make_int2(0, 0);
+      if (i < f1 && tc[i] <= cur_cutoff) ar[q] = V.tarc[i];
+      mine += ar[q].y;
+    }
+    int total;
+    const int rel = block_exclusive_scan(mine, sh, &total);
+    if (tid == 0) s_base = total > 0 ? atomicAdd(&F->n_arcs, total) : 0;
+    __syncthreads();
+    const int b0 = s_base;
+    int o = b0 + rel;
+    if (b0 + total <= V.tok_cap) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + tid * 4 + q;
+        for (int k = 0; k < ar[q].y; ++k) V.work[o + k] = make_int2(i, ar[q].x + k);
+        o += ar[q].y;
+      }
+    } else {
+      if (tid == 0) st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+      total = 0;
+    }
+    __syncthreads();
+    for (int j = b0 + tid; j < b0 + total; j += kLatThreads) {
+      const int2 wk = V.work[j];
+      const int4 er = V.erec[wk.y];
+      const float ac = -__fmul_rn(p.ac_scale, sh.ll[er.w]);
+      const float tot = __fadd_rn(__fadd_rn(tc[wk.x], ac), __int_as_float(er.z));
+      wcost[j] = make_float2(tot, ac);
+      nmin = fminf(nmin, tot);
+    }
+    __syncthreads();
+  }
+  nmin = block_min(nmin, sh);
+  if (tid == 0 && nmin < INFINITY) atomicMin(&F->nmin_key, enc_cost(nmin));
+}
+
+// ---- tokens and emitting links of frame t+1 ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ int s_flag;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live || c.t < 0) return;
+  const int tid = threadIdx.x;
+  const UttView& V = c.V;
+  LatFrame* F = c.F;
+  const float nmin = dec_cost(F->nmin_key);
+  if (!(nmin < INFINITY)) {
+    if (c.wg == 0 && tid == 0) F->status = kLatNoSurvivor;     // seen by the next launch
+    return;
+  }
+  const float next_cutoff = nmin + F->adaptive;
+  const int n_arcs = F->n_arcs, l0 = F->link_end, fb = F->f1;
+  const float2* wcost = reinterpret_cast<const float2*>(V.work_tot);
+  const int stride = c.G * kLatThreads;
+  for (int j0 = c.wg * kLatThreads + tid; j0 < n_arcs; j0 += 4 * stride) {
+    float2 tc2[4]; int2 wk[4]; int4 er[4]; uint32_t old[4]; bool acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q * stride;
+      acc[q] = false;
+      if (j < n_arcs) { tc2[q] = wcost[j]; acc[q] = tc2[q].x < next_cutoff; }
+      if (acc[q]) wk[q] = V.work[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (acc[q]) er[q] = V.erec[wk[q].y];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (acc[q]) old[q] = atomicMin(&V.stc[er[q].x], enc_cost(tc2[q].x));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      team_register_token(p, V, F, fb, acc[q] ? er[q].x : 0, acc[q] && old[q] == kEmpty);
+      const int li = l0 + wave_alloc(&F->n_link, acc[q]);
+      if (!acc[q]) continue;
+      if (li < V.link_cap) {
+        V.lrec[li] = make_int4(wk[q].x, er[q].x /* state for now */, er[q].y, er[q].z);
+        V.lac[li] = tc2[q].y;
+      } else {
+        st_coherent(&F->status, (int32_t)kLatLinkOverflow);
+      }
+    }
+  }
+  if (team_last(F, c.G, &s_flag) && tid == 0) {
+    F->ne_snap = min(ld_coherent(&F->n_elist), V.tok_cap);
+    F->build_cutoff = next_cutoff;
+  }
+}
+
+// ---- link destinations (state -> token index), epsilon relaxation round 0 ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_round0(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  __shared__ int s_flag;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live) return;
+  const int tid = threadIdx.x;
+  const UttView& V = c.V;
+  LatFrame* F = c.F;
+  if (tid == 0) sh.n_heavy = 0;
+  const int fb = F->f1, l0 = F->link_end, nl = min(F->n_link, V.link_cap - l0);
+  for (int l = l0 + c.wg * kLatThreads + tid; l < l0 + nl; l += c.G * kLatThreads) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
+  __syncthreads();
+  const int changed = eps_round(p, V, F, sh, fb, F->build_cutoff, F->ne_snap, c.wg, c.G);
+  if (changed && tid == 0) st_coherent(&F->changed[0], 1);
+  if (team_last(F, c.G, &s_flag) && tid == 0) {
+    F->link_end = l0 + nl;
+    V.seg[2 * c.t + 2] = l0 + nl;
+    st_coherent(&F->n_link, 0);
+    F->ne_snap = min(ld_coherent(&F->n_elist), V.tok_cap);
+  }
+}
+
+// ---- epsilon relaxation round r >= 1 ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_round(const DecodeParams p, const StepCounter* cnt, int local, int r) {
+  __shared__ Shared sh;
+  __shared__ int s_flag;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live) return;
+  LatFrame* F = c.F;
+  if (!F->changed[r - 1]) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.n_heavy = 0;
+  __syncthreads();
+  const int changed = eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, F->ne_snap, c.wg, c.G);
+  if (changed && tid == 0) st_coherent(&F->changed[r], 1);
+  if (team_last(F, c.G, &s_flag) && tid == 0) F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+}
+
+// ---- deeper epsilon chains: one workgroup relaxes to the fixed point ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_tail(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live) return;
+  LatFrame* F = c.F;
+  if (!F->changed[kLatEpsRounds]) return;
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.n_heavy = 0;
+  __syncthreads();
+  for (int rounds = 0; ; ++rounds) {
+    const int ne = min(ld_coherent(&F->n_elist), c.V.tok_cap);   // single workgroup: its own appends, ordered by the barriers
+    if (!eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, ne, 0, 1)) break;
+    if (ld_coherent(&F->status) != kLatOk) break;
+    if (rounds > kMaxEpsRounds) { if (tid == 0) F->status = kLatEpsilonLoop; break; }
+  }
+  __syncthreads();
+  if (tid == 0) F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+}
+
+// ---- epsilon links from the final costs ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_eps_links(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live) return;
+  const int tid = threadIdx.x;
+  const UttView& V = c.V;
+  LatFrame* F = c.F;
+  if (tid == 0) sh.n_heavy = 0;
+  __syncthreads();
+  const int fb = F->f1, l0 = F->link_end;
+  const float cutoff = F->build_cutoff;
+  for_each_arc(sh, V.elist, F->ne_snap, V.ts, p.g.n_off,
+               [&](int i, float* cc) { *cc = dec_cost(V.stc[V.ts[i]]); return *cc < cutoff; },
+               [&](int i, float cc, int a) {
+                 const float tot = cc + p.g.n_w[a];
+                 const int li = l0 + wave_alloc(&F->n_link, tot < cutoff);
+                 if (tot < cutoff) {
+                   if (li < V.link_cap) {
+                     V.lrec[li] = make_int4(i, fb + V.stt[p.g.n_dst[a]], 0, __float_as_int(p.g.n_w[a]));
+                     V.lac[li] = 0.f;
+                   } else {
+                     st_coherent(&F->status, (int32_t)kLatLinkOverflow);
+                   }
+                 }
+               },
+               c.wg * kLatThreads + tid, c.G * kLatThreads);
+}
+
+// ---- final costs of the new frame, arc ranges for its work list, sparse reset of the state table ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_finalise(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ int s_flag;
+  const TeamCtx c = team_ctx(p, cnt, local);
+  if (!c.live) return;
+  const int tid = threadIdx.x;
+  const UttView& V = c.V;
+  LatFrame* F = c.F;
+  const int fb = F->f1, cnt_new = min(F->n_new, V.tok_cap - fb);
+  uint32_t kmin = kEmpty;
+  const int stride = c.G * kLatThreads;
+  for (int i0 = fb + c.wg * kLatThreads + tid; i0 < fb + cnt_new; i0 += 4 * stride) {
+    int st[4]; uint32_t ck[4]; int a0[4], a1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (i0 + q * stride < fb + cnt_new) st[q] = V.ts[i0 + q * stride];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (i0 + q * stride < fb + cnt_new) { ck[q] = V.stc[st[q]]; a0[q] = p.g.e_off[st[q]]; a1[q] = p.g.e_off[st[q] + 1]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + q * stride;
+      if (i < fb + cnt_new) {
+        V.tc[i] = dec_cost(ck[q]);
+        V.tarc[i] = make_int2(a0[q], a1[q] - a0[q]);
+        V.te[i] = INFINITY;
+        V.stc[st[q]] = kEmpty;
+        V.stt[st[q]] = -1;
+        kmin = min(kmin, ck[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+  if ((tid & 63) == 0 && kmin != kEmpty) atomicMin(&F->best_next, kmin);
+  if (team_last(F, c.G, &s_flag) && tid == 0) {
+    const int tok_end = fb + cnt_new;
+    const int link_end = min(F->link_end + ld_coherent(&F->n_link), V.link_cap);
+    V.seg[2 * c.t + 3] = link_end;
+    V.ftok[c.t + 2] = tok_end;
+    F->f0 = fb; F->f1 = tok_end; F->link_end = link_end;
+    F->best_key = ld_coherent(&F->best_next);
+    st_coherent(&F->best_next, kEmpty);
+    st_coherent(&F->n_new, 0); st_coherent(&F->n_link, 0); st_coherent(&F->n_elist, 0);
+    F->ne_snap = 0;
+    for (int r = 0; r <= kLatEpsRounds; ++r) st_coherent(&F->changed[r], 0);
+  }
+}
+
+// ---- after the last frame: final costs + lattice-beam pruning, or the failure report ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodeParams p) {
+  __shared__ Shared sh;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const LatUtt U = p.L.utt[n];
+  const UttView V = make_view(p, n, U);
+  const LatFrame* F = p.L.frame + n;
+  if (tid == 0) {
+    sh.n_heavy = 0;
+#ifdef PK2_LAT_PROFILE
+    for (int k = 0; k < 16; ++k) sh.prof[k] = 0;
+    sh.prof_last = wall_clock64();
+#endif
+  }
+  __syncthreads();
+  if (F->status != kLatOk) {
+    if (tid == 0) { p.L.utt[n].status = F->status; p.L.utt[n].n_tok = F->f1; p.L.utt[n].n_link = F->link_end; }
+    return;
+  }
+  finish_and_prune(p, V, sh, n, U.T, F->f1, F->link_end);
+}
+
+static StepGraphs g_lat_graphs;
+static std::map<hipStream_t, StepCounter*> g_lat_counters;
+
+// The kernels take the call's parameters BY VALUE: a pointer to a parameter block would put one more dependent
+// memory round trip (~1 us) in front of each of the ~11 launches of a frame.  The values are baked into the
+// captured graph, so graphs are cached per parameter content (a training loop decodes into the same workspace
+// with the same options step after step; the per-utterance geometry lives in the workspace, not in the
+// parameters).  At most kMaxLatGraphs parameter sets are kept; beyond that the function returns 1 and the caller
+// uses the one-workgroup decoder.
+constexpr size_t kMaxLatGraphs = 8;
+static std::map<std::string, int> g_lat_keys;
+
+int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream) {
+  StepCounter*& counter = g_lat_counters[stream];
+  if (!counter) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&counter), sizeof(StepCounter)));
+  const StepCounter* cnt = counter;
+  hipLaunchKernelGGL(lat_frames_init, dim3(N), dim3(64), 0, stream, p);
+  PK2_LAUNCH_CHECK();
+  std::string raw(reinterpret_cast<const char*>(&p), sizeof(p));
+  raw += "|" + std::to_string(N) + "|" + std::to_string(team) + "|" + std::to_string((uintptr_t)stream);
+  auto it = g_lat_keys.find(raw);
+  if (it == g_lat_keys.end()) {
+    if (g_lat_keys.size() >= kMaxLatGraphs) return 1;   // the caller decodes with the one-workgroup kernel instead
+    it = g_lat_keys.emplace(raw, (int)g_lat_keys.size()).first;
+  }
+  char key[64];
+  snprintf(key, sizeof(key), "lat_frames_%d", it->second);
+  const dim3 one(1, N), all(team, N), thr(kLatThreads);
+  int rc = g_lat_graphs.run(key, Tmax + 1, counter, stream, [&](hipStream_t s, int j) {
+    hipLaunchKernelGGL(lat_frames_cutoff, one, thr, 0, s, p, cnt, j);
+    hipLaunchKernelGGL(lat_frames_list, all, thr, 0, s, p, cnt, j);
+    hipLaunchKernelGGL(lat_frames_expand, all, thr, 0, s, p, cnt, j);
+    hipLaunchKernelGGL(lat_frames_round0, all, thr, 0, s, p, cnt, j);
+    for (int r = 1; r <= kLatEpsRounds; ++r) hipLaunchKernelGGL(lat_frames_round, all, thr, 0, s, p, cnt, j, r);
+    hipLaunchKernelGGL(lat_frames_tail, one, thr, 0, s, p, cnt, j);
+    hipLaunchKernelGGL(lat_frames_eps_links, all, thr, 0, s, p, cnt, j);
+    hipLaunchKernelGGL(lat_frames_finalise, all, thr, 0, s, p, cnt, j);
+  });
+  if (rc) return rc;
+  hipLaunchKernelGGL(lat_frames_finish, dim3(N), thr, 0, stream, p);
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
+
+}  // namespace pk2

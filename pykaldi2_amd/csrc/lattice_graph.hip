@@ -128,6 +128,7 @@ size_t lattice_carve(const pk2_lattice_batch* b, void* base, LatPtrs* out) {
   L.frame_tok = c.take<int32_t>(b->frame_total); L.seg_off = c.take<int32_t>(b->frame_total);
   L.seg_kept = c.take<int32_t>(b->frame_total); L.frame_maxlev = c.take<int32_t>(b->frame_total);
   L.ref_post = c.take<double>(b->frame_total);
+  L.frame = c.take<LatFrame>(N);
   if (out) *out = L;
   return c.bytes();
 }

@@ -47,6 +47,23 @@ enum LatStatus : int32_t {
   kLatNotDecoded = 5,
 };
 
+// Decoding state of one utterance between the launches of a frame (lattice_decode_frames.hip: a team of workgroups
+// per utterance, several launches per frame).  Counters are bumped with agent-scope atomics; the plain fields are
+// written by the last workgroup of a launch to finish and read by the next launch.
+constexpr int kLatEpsRounds = 3;   // epsilon relaxation launches per frame after round 0; a one-workgroup tail finishes deeper chains
+struct LatFrame {
+  int32_t f0, f1;              // tokens of the frame being expanded (utterance-local); new tokens are appended at f1
+  int32_t link_end;            // links of all closed segments
+  int32_t n_new, n_link, n_elist, n_arcs;
+  int32_t ne_snap;             // epsilon-list entries present at the launch boundary
+  uint32_t best_key;           // best final cost of [f0, f1), order-preserving encoding
+  uint32_t best_next;          // same for the frame being built
+  uint32_t nmin_key;           // best cost over the frame's arcs
+  float cur_cutoff, adaptive, build_cutoff;
+  int32_t status, arrive;
+  int32_t changed[kLatEpsRounds + 1];
+};
+
 // Arrays of the workspace (device pointers).
 struct LatPtrs {
   LatUtt* utt;
@@ -62,6 +79,7 @@ struct LatPtrs {
   int32_t* seg_kept;     // per utterance [2(T+1)]: links of the segment that survive lattice pruning (compacted to its front)
   int32_t* frame_maxlev; // per utterance [T+1]: depth of the epsilon DAG inside the frame
   double* ref_post;      // per utterance [T]
+  LatFrame* frame;       // [N]
 };
 
 }  // namespace pk2
