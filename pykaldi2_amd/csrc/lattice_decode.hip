@@ -204,6 +204,17 @@ __global__ void __launch_bounds__(kLatThreads) lat_decode_kernel(DecodeParams p)
 #endif
 }
 
+// Second half of the lattice pruning: link removal and epsilon-DAG depths, frames dealt round-robin to the
+// workgroups of an utterance (prune_segments).
+constexpr int kPruneTeam = 32;
+__global__ void __launch_bounds__(kLatThreads) lat_prune_segments(DecodeParams p) {
+  __shared__ Shared sh;
+  const int n = blockIdx.y;
+  const LatUtt U = p.L.utt[n];
+  if (U.status != kLatOk) return;
+  prune_segments(p, make_view(p, n, U), sh, U.T, blockIdx.x, gridDim.x);
+}
+
 }  // namespace pk2
 
 using namespace pk2;
@@ -235,9 +246,9 @@ extern "C" int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, i
   const int64_t n_emit = (int64_t)b->graph->e_dst.size();
   if (n_emit > 0)
     hipLaunchKernelGGL(lat_pack_arcs, dim3((unsigned)((n_emit + 255) / 256)), dim3(256), 0, stream, p.g, tid2pdf, n_emit, L.e_rec);
-  // PK2_LAT_DECODER=wg: one workgroup per utterance, one launch (this file); =frames: a team of PK2_LAT_TEAM
-  // workgroups per utterance, a few launches per frame (lattice_decode_frames.hip).
-  static const bool frames = [] { const char* e = getenv("PK2_LAT_DECODER"); return e && strcmp(e, "frames") == 0; }();
+  // Default: a team of PK2_LAT_TEAM workgroups per utterance, a few launches per frame (lattice_decode_frames.hip);
+  // PK2_LAT_DECODER=wg: one workgroup per utterance, one launch (this file).
+  static const bool frames = [] { const char* e = getenv("PK2_LAT_DECODER"); return !(e && strcmp(e, "wg") == 0); }();
   static const int team = [] { const char* e = getenv("PK2_LAT_TEAM"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
   rc = frames ? lattice_decode_frames(p, b->N, b->Tmax, team, stream) : 1;
   if (rc < 0) return rc;
@@ -245,6 +256,8 @@ extern "C" int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, i
     hipLaunchKernelGGL(lat_decode_kernel, dim3(b->N), dim3(kLatThreads), 0, stream, p);
     PK2_LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(lat_prune_segments, dim3(kPruneTeam, b->N), dim3(kLatThreads), 0, stream, p);
+  PK2_LAUNCH_CHECK();
   b->decoded = true;
   return PK2_OK;
 }

@@ -438,8 +438,11 @@ __device__ int compact_links(const UttView& V, Shared& sh, int l0, int l1, float
   return out - l0;
 }
 
-// Final costs (ComputeFinalCosts) and lattice-beam pruning, last frame first (PruneForwardLinksFinal /
-// PruneForwardLinks), of a decoded utterance with tok_end tokens and link_end links; one workgroup.
+// Final costs (ComputeFinalCosts) and the token "extra costs" of lattice-beam pruning, last frame first
+// (PruneForwardLinksFinal / PruneForwardLinks), of a decoded utterance with tok_end tokens and link_end links; one
+// workgroup.  This is the only serial part of the pruning: whether a link survives is a function of the final extra
+// costs alone, so the links are dropped, and the epsilon-DAG depths computed, afterwards by prune_segments, segment
+// by segment in parallel.
 __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared& sh, int n, int T, int s_tok_end,
                                  int s_link_end) {
   const int tid = threadIdx.x;
@@ -468,10 +471,6 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
   // ---- lattice-beam pruning, last frame first (PruneForwardLinksFinal / PruneForwardLinks) ----
   uint32_t* teu = reinterpret_cast<uint32_t*>(te);   // extra costs are >= 0: their bit patterns order like the floats
   const float lbeam = p.lattice_beam;
-  const float inv_scale = 1.0f / p.ac_scale;
-  int32_t* kept = V.kept;
-  int32_t* tl = V.tl;
-  int32_t* maxlev = V.maxlev;
   for (int t = T; t >= 0; --t) {
     // epsilon links inside frame t, to the fixed point
     const int e0 = seg[2 * t], e1 = seg[2 * t + 1];
@@ -492,14 +491,56 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
       }
       if (!__syncthreads_or(changed)) break;
     }
+    LAT_T(8);
+    // emitting links t-1 -> t: the extra costs of frame t are final; they give the extra costs of their sources
+    if (t > 0) {
+      const int m0 = seg[2 * t - 1], m1 = seg[2 * t];
+      for (int l0 = m0 + tid; l0 < m1; l0 += 4 * kLatThreads) {
+        int4 r[4]; float a[4], ed[4], cs[4], cd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (l0 + q * kLatThreads < m1) { r[q] = lrec[l0 + q * kLatThreads]; a[q] = V.lac[l0 + q * kLatThreads]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (l0 + q * kLatThreads < m1) { ed[q] = __uint_as_float(ld_coherent(&teu[r[q].y])); cs[q] = tc[r[q].x]; cd[q] = tc[r[q].y]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (l0 + q * kLatThreads >= m1 || !(ed[q] < INFINITY)) continue;
+          const float le = ed[q] + (__fadd_rn(__fadd_rn(cs[q], a[q]), __int_as_float(r[q].w)) - cd[q]);
+          if (le <= lbeam) atomicMin(&teu[r[q].x], __float_as_uint(fmaxf(le, 0.f)));
+        }
+      }
+    }
+    __syncthreads();
+    LAT_T(10);
+  }
+  if (tid == 0) {
+    LatUtt* o = p.L.utt + n;
+    o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
+  }
+}
+
+// Drops the links that lattice pruning rejects (in-place compaction of every segment; the acoustic scale is removed
+// from the kept emitting links) and computes the depth of the epsilon DAG inside each frame, for the frames
+// first, first + stride, ...: independent per frame once finish_and_prune has fixed the extra costs.
+__device__ void prune_segments(const DecodeParams& p, const UttView& V, Shared& sh, int T, int first, int stride) {
+  const int tid = threadIdx.x;
+  const float* tc = V.tc;
+  const uint32_t* teu = reinterpret_cast<const uint32_t*>(V.te);
+  const int32_t* seg = V.seg;
+  int4* lrec = V.lrec;
+  int32_t* tl = V.tl;
+  const float lbeam = p.lattice_beam;
+  const float inv_scale = 1.0f / p.ac_scale;
+  for (int t = first; t <= T; t += stride) {
+    const int e0 = seg[2 * t], e1 = seg[2 * t + 1];
     int ke = 0;
     if (e1 > e0)
       ke = compact_links(V, sh, e0, e1, 1.0f, [&](int s, int d, float g, float a) {
-        const float ed = __uint_as_float(ld_coherent(&teu[d]));
+        const float ed = __uint_as_float(teu[d]);
         return ed < INFINITY && (ed + ((tc[s] + g) - tc[d])) <= lbeam;
       });
-    if (tid == 0) kept[2 * t] = ke;
-    LAT_T(8);
+    if (tid == 0) V.kept[2 * t] = ke;
     // epsilon DAG depth of the frame's tokens (order of the forward-backward inside the frame)
     int lev_max = 0;
     if (ke > 0) {
@@ -516,28 +557,16 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
       for (int l = e0 + tid; l < e0 + ke; l += kLatThreads) lm = fmaxf(lm, (float)ld_coherent(&tl[lrec[l].y]));
       lev_max = (int)(-block_min(-lm, sh));
     }
-    if (tid == 0) maxlev[t] = lev_max;
-    LAT_T(9);
-    // emitting links t-1 -> t: the extra costs of frame t are final, so pruning, the source tokens' extra costs
-    // and the compaction share one pass
+    if (tid == 0) V.maxlev[t] = lev_max;
     if (t > 0) {
       const int m0 = seg[2 * t - 1], m1 = seg[2 * t];
       const int km = compact_links(V, sh, m0, m1, inv_scale, [&](int s, int d, float g, float a) {
-        const float ed = __uint_as_float(ld_coherent(&teu[d]));
-        if (!(ed < INFINITY)) return false;
-        const float le = ed + (__fadd_rn(__fadd_rn(tc[s], a), g) - tc[d]);
-        if (!(le <= lbeam)) return false;
-        atomicMin(&teu[s], __float_as_uint(fmaxf(le, 0.f)));
-        return true;
+        const float ed = __uint_as_float(teu[d]);
+        return ed < INFINITY && (ed + (__fadd_rn(__fadd_rn(tc[s], a), g) - tc[d])) <= lbeam;
       });
-      if (tid == 0) kept[2 * t - 1] = km;
+      if (tid == 0) V.kept[2 * t - 1] = km;
     }
     __syncthreads();
-    LAT_T(10);
-  }
-  if (tid == 0) {
-    LatUtt* o = p.L.utt + n;
-    o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
   }
 }
 

@@ -145,6 +145,7 @@ __global__ void lat_frames_init(const DecodeParams p) {
   F->cur_cutoff = INFINITY; F->adaptive = p.beam; F->build_cutoff = p.beam;   // InitDecoding: ProcessNonemitting(beam)
   F->status = kLatOk; F->arrive = 0;
   for (int r = 0; r <= kLatEpsRounds; ++r) F->changed[r] = 0;
+  F->ll_base = p.loglikes + (int64_t)n * p.seq_stride; F->ll_stride = p.frame_stride;
   V.stc[p.g.start] = enc_cost(0.f);
   team_register_token(p, V, F, 0, p.g.start);
   F->ne_snap = F->n_elist;
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
   const float* tc = V.tc;
   const int f0 = F->f0, f1 = F->f1;
   const float cur_cutoff = F->cur_cutoff;
-  const float* row = p.loglikes + (int64_t)c.n * p.seq_stride + (int64_t)c.t * p.frame_stride;
+  const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
   for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
   float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
   float nmin = INFINITY;
@@ -466,7 +467,11 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
   const StepCounter* cnt = counter;
   hipLaunchKernelGGL(lat_frames_init, dim3(N), dim3(64), 0, stream, p);
   PK2_LAUNCH_CHECK();
-  std::string raw(reinterpret_cast<const char*>(&p), sizeof(p));
+  // the log-likelihood tensor is the one pointer that moves from call to call: the frame kernels take it from the
+  // per-utterance state (written by lat_frames_init), not from the baked parameters
+  DecodeParams pk = p;
+  pk.loglikes = nullptr; pk.seq_stride = 0; pk.frame_stride = 0;
+  std::string raw(reinterpret_cast<const char*>(&pk), sizeof(pk));
   raw += "|" + std::to_string(N) + "|" + std::to_string(team) + "|" + std::to_string((uintptr_t)stream);
   auto it = g_lat_keys.find(raw);
   if (it == g_lat_keys.end()) {
@@ -477,14 +482,14 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
   snprintf(key, sizeof(key), "lat_frames_%d", it->second);
   const dim3 one(1, N), all(team, N), thr(kLatThreads);
   int rc = g_lat_graphs.run(key, Tmax + 1, counter, stream, [&](hipStream_t s, int j) {
-    hipLaunchKernelGGL(lat_frames_cutoff, one, thr, 0, s, p, cnt, j);
-    hipLaunchKernelGGL(lat_frames_list, all, thr, 0, s, p, cnt, j);
-    hipLaunchKernelGGL(lat_frames_expand, all, thr, 0, s, p, cnt, j);
-    hipLaunchKernelGGL(lat_frames_round0, all, thr, 0, s, p, cnt, j);
-    for (int r = 1; r <= kLatEpsRounds; ++r) hipLaunchKernelGGL(lat_frames_round, all, thr, 0, s, p, cnt, j, r);
-    hipLaunchKernelGGL(lat_frames_tail, one, thr, 0, s, p, cnt, j);
-    hipLaunchKernelGGL(lat_frames_eps_links, all, thr, 0, s, p, cnt, j);
-    hipLaunchKernelGGL(lat_frames_finalise, all, thr, 0, s, p, cnt, j);
+    hipLaunchKernelGGL(lat_frames_cutoff, one, thr, 0, s, pk, cnt, j);
+    hipLaunchKernelGGL(lat_frames_list, all, thr, 0, s, pk, cnt, j);
+    hipLaunchKernelGGL(lat_frames_expand, all, thr, 0, s, pk, cnt, j);
+    hipLaunchKernelGGL(lat_frames_round0, all, thr, 0, s, pk, cnt, j);
+    for (int r = 1; r <= kLatEpsRounds; ++r) hipLaunchKernelGGL(lat_frames_round, all, thr, 0, s, pk, cnt, j, r);
+    hipLaunchKernelGGL(lat_frames_tail, one, thr, 0, s, pk, cnt, j);
+    hipLaunchKernelGGL(lat_frames_eps_links, all, thr, 0, s, pk, cnt, j);
+    hipLaunchKernelGGL(lat_frames_finalise, all, thr, 0, s, pk, cnt, j);
   });
   if (rc) return rc;
   hipLaunchKernelGGL(lat_frames_finish, dim3(N), thr, 0, stream, p);

@@ -62,6 +62,8 @@ struct LatFrame {
   float cur_cutoff, adaptive, build_cutoff;
   int32_t status, arrive;
   int32_t changed[kLatEpsRounds + 1];
+  const float* ll_base;        // the utterance's log-likelihood rows (kept out of the graph-baked parameters)
+  int64_t ll_stride;
 };
 
 // Arrays of the workspace (device pointers).

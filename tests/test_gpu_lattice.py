@@ -267,3 +267,18 @@ def test_decoder_failures_are_reported():
     rec = _recognizer(g, tm, 8.0, 4.0, 1.0)
     with pytest.raises(_lib.Pk2Error, match="LDS row limit"):
         rec.decode(big)
+
+
+def test_one_workgroup_decoder_variant():
+    """The decoder variant selected by PK2_LAT_DECODER=wg (one workgroup per utterance, one launch; also the fallback
+    of the default launch-per-frame decoder) passes the same oracle comparisons.  The choice is read once per
+    process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_lattice.py"), "-q", "-m", "gpu",
+                          "-k", "matches_oracle or ragged or heavy or overflow"], env=dict(os.environ, PK2_LAT_DECODER="wg"),
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
