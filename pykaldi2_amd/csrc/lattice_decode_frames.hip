@@ -7,15 +7,15 @@
 //
 //   cutoff     (1 workgroup / utterance)  GetCutoff: best cost (reduced by the previous frame's finalise), beam,
 //                                         exact k-th smallest cost when max_active / min_active bind
-//   list       (G workgroups / utterance) arc work list of the surviving tokens -- every workgroup reserves a
+//   list       (G workgroups / utterance) sparse reset of the state table; arc work list of the surviving tokens -- every workgroup reserves a
 //                                         region with one atomicAdd, the order of a bag of arcs is irrelevant --
 //                                         arc costs, atomicMin of the best new cost
 //   expand                                atomicMin into the per-state table, new tokens, emitting links
 //   fix+round0                            link destinations (state -> token), first epsilon relaxation round
 //   round 1..R                            further rounds; each returns at once when the previous one changed nothing
 //   tail       (1 workgroup / utterance)  finishes deeper epsilon chains to the exact fixed point (normally a no-op)
-//   eps links                             epsilon links from the final costs
-//   finalise                              final token costs, arc ranges, sparse table reset, best cost of the frame
+//   close                                 epsilon links from the final costs, final token costs, arc ranges, best
+//                                         cost of the frame (the next frame's list launch clears the state table)
 //
 // The epsilon list is shared by index ownership (entry e belongs to team thread e mod team size) and a launch only
 // walks the entries that existed at the launch boundary, so workgroups never read another workgroup's plain
@@ -153,6 +153,71 @@ __global__ void lat_frames_init(const DecodeParams p) {
 }
 
 // ---- GetCutoff ----
+// Number of costs below hi = lo + beam and, when more than k of them are, the exact k-th smallest (0-based): one
+// pass builds 2047 linear bins of [lo, hi) (bin 2047 = the rest), which gives the count and the bin of the k-th;
+// a second pass collects that bin's members (a handful) in LDS, where each is ranked against the others.
+// Returns false when at most k costs lie below hi.  Falls back to kth_smallest_in_range for a crowded bin.
+__device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, Shared& sh, float* out) {
+  const int tid = threadIdx.x;
+  const float scale = 2047.0f / (hi - lo);
+  auto bin_of = [&](float c) { return c >= hi ? 2047 : min(2046, (int)((c - lo) * scale)); };
+  for (int i = tid; i < 2048; i += kLatThreads) sh.hist[i] = 0;
+  if (tid == 0) { sh.sel_k = -1; sh.redi[0] = 0; }
+  __syncthreads();
+  for (int i = tid; i < n; i += kLatThreads) atomicAdd(&sh.hist[bin_of(cost[i])], 1u);
+  __syncthreads();
+  if (tid < 64) {
+    int mine = 0;
+    for (int b = 0; b < 32; ++b) mine += (int)sh.hist[tid * 32 + b];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o, 64);
+      if (tid >= o) incl += y;
+    }
+    const int before = incl - mine;
+    const int c_lt = n - (int)sh.hist[2047];
+    if (c_lt > k && k >= before && k < incl) {
+      int kk = k - before, b = 0;
+      for (; b < 32; ++b) {
+        const int c = (int)sh.hist[tid * 32 + b];
+        if (kk < c) break;
+        kk -= c;
+      }
+      sh.sel_prefix = (uint32_t)(tid * 32 + b);
+      sh.sel_k = kk;
+    }
+  }
+  __syncthreads();
+  if (sh.sel_k < 0) return false;
+  const int sel_bin = (int)sh.sel_prefix, kk = sh.sel_k;
+  __syncthreads();
+  for (int i = tid; i < n; i += kLatThreads) {
+    const float c = cost[i];
+    if (bin_of(c) == sel_bin) {
+      const int m = atomicAdd(&sh.redi[0], 1);
+      if (m < 2048) sh.hist[m] = enc_cost(c);     // the bins are no longer needed
+    }
+  }
+  __syncthreads();
+  const int m = sh.redi[0];
+  if (m > 2048) {             // many equal costs: the general selection
+    __syncthreads();
+    *out = kth_smallest_in_range(cost, n, k, lo, hi, sh);
+    return true;
+  }
+  for (int i = tid; i < m; i += kLatThreads) {
+    const uint32_t key = sh.hist[i];
+    int lt = 0, le = 0;
+    for (int j = 0; j < m; ++j) { const uint32_t o = sh.hist[j]; lt += o < key; le += o <= key; }
+    if (lt <= kk && kk < le) sh.sel_prefix = key;
+  }
+  __syncthreads();
+  *out = dec_cost(sh.sel_prefix);
+  __syncthreads();
+  return true;
+}
+
 __global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodeParams p, const StepCounter* cnt, int local) {
   __shared__ Shared sh;
   const TeamCtx c = team_ctx(p, cnt, local);
@@ -166,15 +231,17 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodePar
   const float beam_cutoff = best + p.beam;
   float cur_cutoff = beam_cutoff, adaptive = p.beam;
   const bool chk_max = nt > p.max_active, chk_min = p.min_active > 0 && nt > p.min_active;
-  if (chk_max || chk_min) {
-    int c_lt = 0, c_le = 0;
-    for (int i = f0 + tid; i < f1; i += kLatThreads) { c_lt += tc[i] < beam_cutoff; c_le += tc[i] <= beam_cutoff; }
-    c_lt = block_sum_i(c_lt, sh);
+  bool bound = false;
+  if (chk_max) {          // c_lt > max_active  <=>  the max_active-th cost (0-based) exists below the beam cutoff
+    float kth;
+    bound = kth_below(tc + f0, nt, p.max_active, best, beam_cutoff, sh, &kth);
+    if (bound) { cur_cutoff = kth; adaptive = (cur_cutoff - best) + p.beam_delta; }
+  }
+  if (!bound && chk_min) {
+    int c_le = 0;
+    for (int i = f0 + tid; i < f1; i += kLatThreads) c_le += tc[i] <= beam_cutoff;
     c_le = block_sum_i(c_le, sh);
-    if (chk_max && c_lt > p.max_active) {
-      cur_cutoff = kth_smallest_in_range(tc + f0, nt, p.max_active, best, beam_cutoff, sh);
-      adaptive = (cur_cutoff - best) + p.beam_delta;
-    } else if (chk_min && c_le <= p.min_active) {
+    if (c_le <= p.min_active) {
       cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
       adaptive = (cur_cutoff - best) + p.beam_delta;
     }
@@ -194,6 +261,8 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
   const float* tc = V.tc;
   const int f0 = F->f0, f1 = F->f1;
   const float cur_cutoff = F->cur_cutoff;
+  // the frame's log-likelihood row staged in LDS (reading it per arc from L2 puts one more dependent round trip
+  // into the cost pass: measured +6 us per launch)
   const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
   for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
   float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
@@ -205,7 +274,14 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
     for (int q = 0; q < 4; ++q) {
       const int i = base + tid * 4 + q;
       ar[q] = make_int2(0, 0);
-      if (i < f1 && tc[i] <= cur_cutoff) ar[q] = V.tarc[i];
+      if (i < f1) {
+        if (tc[i] <= cur_cutoff) ar[q] = V.tarc[i];
+        // sparse reset of the state table: every token of the old frame passes here once, and nothing reads the
+        // table between the launch that closed the frame and the next expand
+        const int st = V.ts[i];
+        V.stc[st] = kEmpty;
+        V.stt[st] = -1;
+      }
       mine += ar[q].y;
     }
     int total;
@@ -350,9 +426,10 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_tail(const DecodeParam
   if (tid == 0) F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
 }
 
-// ---- epsilon links from the final costs ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_eps_links(const DecodeParams p, const StepCounter* cnt, int local) {
+// ---- the frame is closed: epsilon links from the final costs, final token costs, arc ranges, best cost ----
+__global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodeParams p, const StepCounter* cnt, int local) {
   __shared__ Shared sh;
+  __shared__ int s_flag;
   const TeamCtx c = team_ctx(p, cnt, local);
   if (!c.live) return;
   const int tid = threadIdx.x;
@@ -377,17 +454,8 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_eps_links(const Decode
                  }
                },
                c.wg * kLatThreads + tid, c.G * kLatThreads);
-}
-
-// ---- final costs of the new frame, arc ranges for its work list, sparse reset of the state table ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_finalise(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ int s_flag;
-  const TeamCtx c = team_ctx(p, cnt, local);
-  if (!c.live) return;
-  const int tid = threadIdx.x;
-  const UttView& V = c.V;
-  LatFrame* F = c.F;
-  const int fb = F->f1, cnt_new = min(F->n_new, V.tok_cap - fb);
+  // final costs and arc ranges of the new tokens (the state table is cleared by the next frame's list launch)
+  const int cnt_new = min(F->n_new, V.tok_cap - fb);
   uint32_t kmin = kEmpty;
   const int stride = c.G * kLatThreads;
   for (int i0 = fb + c.wg * kLatThreads + tid; i0 < fb + cnt_new; i0 += 4 * stride) {
@@ -404,8 +472,6 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finalise(const DecodeP
         V.tc[i] = dec_cost(ck[q]);
         V.tarc[i] = make_int2(a0[q], a1[q] - a0[q]);
         V.te[i] = INFINITY;
-        V.stc[st[q]] = kEmpty;
-        V.stt[st[q]] = -1;
         kmin = min(kmin, ck[q]);
       }
     }
@@ -488,8 +554,7 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
     hipLaunchKernelGGL(lat_frames_round0, all, thr, 0, s, pk, cnt, j);
     for (int r = 1; r <= kLatEpsRounds; ++r) hipLaunchKernelGGL(lat_frames_round, all, thr, 0, s, pk, cnt, j, r);
     hipLaunchKernelGGL(lat_frames_tail, one, thr, 0, s, pk, cnt, j);
-    hipLaunchKernelGGL(lat_frames_eps_links, all, thr, 0, s, pk, cnt, j);
-    hipLaunchKernelGGL(lat_frames_finalise, all, thr, 0, s, pk, cnt, j);
+    hipLaunchKernelGGL(lat_frames_close, all, thr, 0, s, pk, cnt, j);
   });
   if (rc) return rc;
   hipLaunchKernelGGL(lat_frames_finish, dim3(N), thr, 0, stream, p);

@@ -50,7 +50,7 @@ enum LatStatus : int32_t {
 // Decoding state of one utterance between the launches of a frame (lattice_decode_frames.hip: a team of workgroups
 // per utterance, several launches per frame).  Counters are bumped with agent-scope atomics; the plain fields are
 // written by the last workgroup of a launch to finish and read by the next launch.
-constexpr int kLatEpsRounds = 3;   // epsilon relaxation launches per frame after round 0; a one-workgroup tail finishes deeper chains
+constexpr int kLatEpsRounds = 2;   // epsilon relaxation launches per frame after round 0; a one-workgroup tail finishes deeper chains
 struct LatFrame {
   int32_t f0, f1;              // tokens of the frame being expanded (utterance-local); new tokens are appended at f1
   int32_t link_end;            // links of all closed segments
