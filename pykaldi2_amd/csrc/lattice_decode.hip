@@ -250,9 +250,10 @@ extern "C" int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, i
   // PK2_LAT_DECODER=wg: one workgroup per utterance, one launch (this file).
   static const bool frames = [] { const char* e = getenv("PK2_LAT_DECODER"); return !(e && strcmp(e, "wg") == 0); }();
   static const int team = [] { const char* e = getenv("PK2_LAT_TEAM"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-  rc = frames ? lattice_decode_frames(p, b->N, b->Tmax, team, stream) : 1;
-  if (rc < 0) return rc;
-  if (rc > 0) {
+  if (frames) {
+    rc = lattice_decode_frames(p, b->N, b->Tmax, team, stream);
+    if (rc) return rc;
+  } else {
     hipLaunchKernelGGL(lat_decode_kernel, dim3(b->N), dim3(kLatThreads), 0, stream, p);
     PK2_LAUNCH_CHECK();
   }

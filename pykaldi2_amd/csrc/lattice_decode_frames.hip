@@ -522,10 +522,12 @@ static std::map<hipStream_t, StepCounter*> g_lat_counters;
 // memory round trip (~1 us) in front of each of the ~11 launches of a frame.  The values are baked into the
 // captured graph, so graphs are cached per parameter content (a training loop decodes into the same workspace
 // with the same options step after step; the per-utterance geometry lives in the workspace, not in the
-// parameters).  At most kMaxLatGraphs parameter sets are kept; beyond that the function returns 1 and the caller
-// uses the one-workgroup decoder.
+// parameters).  At most kMaxLatGraphs parameter sets are kept; the least recently used one is dropped (after a
+// stream synchronisation: its graphs may still be running).
 constexpr size_t kMaxLatGraphs = 8;
-static std::map<std::string, int> g_lat_keys;
+struct LatGraphSlot { int id; uint64_t last_use; };
+static std::map<std::string, LatGraphSlot> g_lat_keys;
+static uint64_t g_lat_clock = 0;
 
 int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream) {
   StepCounter*& counter = g_lat_counters[stream];
@@ -540,12 +542,23 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
   std::string raw(reinterpret_cast<const char*>(&pk), sizeof(pk));
   raw += "|" + std::to_string(N) + "|" + std::to_string(team) + "|" + std::to_string((uintptr_t)stream);
   auto it = g_lat_keys.find(raw);
-  if (it == g_lat_keys.end()) {
-    if (g_lat_keys.size() >= kMaxLatGraphs) return 1;   // the caller decodes with the one-workgroup kernel instead
-    it = g_lat_keys.emplace(raw, (int)g_lat_keys.size()).first;
-  }
   char key[64];
-  snprintf(key, sizeof(key), "lat_frames_%d", it->second);
+  if (it == g_lat_keys.end()) {
+    int id = (int)g_lat_keys.size();
+    if (g_lat_keys.size() >= kMaxLatGraphs) {
+      auto old = g_lat_keys.begin();
+      for (auto q = g_lat_keys.begin(); q != g_lat_keys.end(); ++q)
+        if (q->second.last_use < old->second.last_use) old = q;
+      PK2_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>((uintptr_t)std::stoull(old->first.substr(old->first.rfind('|') + 1)))));
+      snprintf(key, sizeof(key), "lat_frames_%d", old->second.id);
+      g_lat_graphs.erase(key);
+      id = old->second.id;
+      g_lat_keys.erase(old);
+    }
+    it = g_lat_keys.emplace(raw, LatGraphSlot{id, 0}).first;
+  }
+  it->second.last_use = ++g_lat_clock;
+  snprintf(key, sizeof(key), "lat_frames_%d", it->second.id);
   const dim3 one(1, N), all(team, N), thr(kLatThreads);
   int rc = g_lat_graphs.run(key, Tmax + 1, counter, stream, [&](hipStream_t s, int j) {
     hipLaunchKernelGGL(lat_frames_cutoff, one, thr, 0, s, pk, cnt, j);

@@ -88,6 +88,13 @@ class StepGraphs {
     return PK2_OK;
   }
 
+  // Destroys the cached graphs of `key` (all lengths).  The caller makes sure none of them is still executing.
+  void erase(const std::string& key) {
+    for (auto it = cache_.begin(); it != cache_.end();) {
+      if (it->first.first == key) { (void)hipGraphExecDestroy(it->second); it = cache_.erase(it); } else { ++it; }
+    }
+  }
+
  private:
   static constexpr int kBig = 64, kSmall = 8;
   // Graph lengths: the longest tier that fits the remaining steps (a last partial graph of kSmall early-exits).
