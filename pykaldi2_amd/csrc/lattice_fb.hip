@@ -8,9 +8,11 @@
 // Arithmetic follows Kaldi's lattice-functions.cc as restated in oracle/lattice_ref.py: log-domain alpha /
 // beta in float64; the expected-accuracy recursions (alpha_smbr / beta_smbr) in float64.
 //
-// One workgroup per utterance.  A lattice is processed frame by frame: the emitting links t-1 -> t in one
-// parallel sweep (log-add through a 64-bit compare-and-swap), then the epsilon links inside frame t level by
-// level of the epsilon DAG (levels computed by the decoder), workgroup barriers in between.
+// A lattice is processed frame by frame: the emitting links t-1 -> t in one parallel sweep (log-add through a 64-bit
+// compare-and-swap), then the epsilon links inside frame t level by level of the epsilon DAG (levels computed by
+// the pruning pass), workgroup barriers in between.  The alpha and the beta recursion of an utterance do not depend
+// on each other: they run side by side in two workgroups (so do the two expected-accuracy recursions of sMBR / MPFE),
+// and the posteriors, which are local to a frame, are computed by 64 workgroups per utterance.
 #include <cmath>
 
 #include "lattice_internal.h"
@@ -87,183 +89,216 @@ __device__ __forceinline__ double frame_acc(const FbParams& p, int tid_arc, int 
   return ok ? 1.0 : 0.0;
 }
 
-// MODE 0: MMI, MODE 1: sMBR / MPFE.
-template <int MODE>
-__global__ void __launch_bounds__(kFbThreads) lat_fb_kernel(FbParams p) {
+// Per-utterance views shared by the kernels below.
+struct FbView {
+  int T, nt;
+  const int32_t* ftok; const int32_t* seg; const int32_t* kept; const int32_t* maxlev;
+  const int4* lrec; const float* lac; const int32_t* tl; const float* tf;
+  double* alpha; double* beta; double* af; double* ab;
+  const int32_t* ref; double* ref_post;
+  LatFrame* F;
+};
+__device__ __forceinline__ FbView fb_view(const FbParams& p, int n, const LatUtt& U) {
+  FbView v;
+  v.T = U.T; v.nt = U.n_tok;
+  v.ftok = p.L.frame_tok + U.frame_base; v.seg = p.L.seg_off + U.frame_base;
+  v.kept = p.L.seg_kept + U.frame_base; v.maxlev = p.L.frame_maxlev + U.frame_base;
+  v.lrec = p.L.link_rec + U.link_base;      // {src token, dst token, transition-id, graph cost bits}
+  v.lac = p.L.link_ac + U.link_base;
+  v.tl = p.L.tok_level + U.tok_base; v.tf = p.L.tok_final + U.tok_base;
+  v.alpha = p.L.alpha + U.tok_base; v.beta = p.L.beta + U.tok_base;
+  v.af = p.L.acc_f + U.tok_base; v.ab = p.L.acc_b + U.tok_base;
+  v.ref = p.ref_tids + (int64_t)n * p.ref_stride;
+  v.ref_post = p.L.ref_post + U.frame_base;
+  v.F = p.L.frame + n;
+  return v;
+}
+// fst::ScaleLattice stores the scaled weights as floats; the forward-backward then sums them in double
+__device__ __forceinline__ double link_like(const FbParams& p, const FbView& v, const int4& r, int l) {
+  return -((double)(float)(p.lm_scale * (double)__int_as_float(r.w)) + (double)(float)(p.ac_scale * (double)v.lac[l]));
+}
+__device__ __forceinline__ double final_like(const FbParams& p, const FbView& v, int i) {
+  return -(double)(float)(p.lm_scale * (double)v.tf[i]);
+}
+
+// alpha (workgroup x = 0) and beta (x = 1) are independent recursions: they run side by side.  x = 0 also leaves the
+// total log-likelihood in the utterance's frame state.
+__global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p) {
   __shared__ double red[kFbWaves];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.y, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
-  if (U.status != kLatOk) { if (tid == 0) p.out[n] = NAN; return; }
-  const int T = U.T, nt = U.n_tok;
-  const int32_t* ftok = p.L.frame_tok + U.frame_base;
-  const int32_t* seg = p.L.seg_off + U.frame_base;
-  const int32_t* kept = p.L.seg_kept + U.frame_base;
-  const int32_t* maxlev = p.L.frame_maxlev + U.frame_base;
-  const int4* lrec = p.L.link_rec + U.link_base;      // {src token, dst token, transition-id, graph cost bits}
-  const float* lac = p.L.link_ac + U.link_base;
-  const int32_t* tl = p.L.tok_level + U.tok_base;
-  const float* tf = p.L.tok_final + U.tok_base;
-  double* alpha = p.L.alpha + U.tok_base; double* beta = p.L.beta + U.tok_base;
-  double* af = p.L.acc_f + U.tok_base; double* ab = p.L.acc_b + U.tok_base;
-  const int32_t* ref = p.ref_tids + (int64_t)n * p.ref_stride;
-  double* ref_post = p.L.ref_post + U.frame_base;
-  // fst::ScaleLattice stores the scaled weights as floats; the forward-backward then sums them in double
-  auto like = [&](const int4& r, int l) {
-    return -((double)(float)(p.lm_scale * (double)__int_as_float(r.w)) + (double)(float)(p.ac_scale * (double)lac[l]));
-  };
-  auto final_like = [&](int i) { return -(double)(float)(p.lm_scale * (double)tf[i]); };
-
-  for (int i = tid; i < nt; i += kFbThreads) { alpha[i] = -INFINITY; beta[i] = -INFINITY; af[i] = 0.0; ab[i] = 0.0; }
-  for (int t = tid; t < T; t += kFbThreads) ref_post[t] = 0.0;
-  __syncthreads();
-  if (tid == 0) alpha[0] = 0.0;
-  __syncthreads();
-
-  // ---- forward ----
-  for (int t = 0; t <= T; ++t) {
-    if (t > 0) {
-      const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int4 r = lrec[l];
-        atomic_log_add(&alpha[r.y], ldc(&alpha[r.x]) + like(r, l));
-      }
-      __syncthreads();
-    }
-    const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
-    for (int lev = 0; lev < maxlev[t]; ++lev) {
-      for (int l = e0 + tid; l < e1; l += kFbThreads) {
-        const int4 r = lrec[l];
-        if (tl[r.x] == lev) atomic_log_add(&alpha[r.y], ldc(&alpha[r.x]) + like(r, l));
-      }
-      __syncthreads();
-    }
-  }
-  // total likelihood over the final tokens (stable log-sum-exp)
-  const int fT0 = ftok[T], fT1 = ftok[T + 1];
-  double mx = -INFINITY;
-  for (int i = fT0 + tid; i < fT1; i += kFbThreads)
-    if (tf[i] < INFINITY) mx = fmax(mx, ldc(&alpha[i]) + final_like(i));
-  mx = block_max_d(mx, red);
-  double sm = 0.0;
-  for (int i = fT0 + tid; i < fT1; i += kFbThreads)
-    if (tf[i] < INFINITY) sm += exp(ldc(&alpha[i]) + final_like(i) - mx);
-  sm = block_sum_d(sm, red);
-  const double tot = mx + log(sm);
-  // ---- backward ----
-  for (int i = fT0 + tid; i < fT1; i += kFbThreads)
-    if (tf[i] < INFINITY) beta[i] = final_like(i);
-  __syncthreads();
-  for (int t = T; t >= 0; --t) {
-    const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
-    for (int lev = maxlev[t] - 1; lev >= 0; --lev) {
-      for (int l = e0 + tid; l < e1; l += kFbThreads) {
-        const int4 r = lrec[l];
-        if (tl[r.x] == lev) atomic_log_add(&beta[r.x], ldc(&beta[r.y]) + like(r, l));
-      }
-      __syncthreads();
-    }
-    if (t > 0) {
-      const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int4 r = lrec[l];
-        atomic_log_add(&beta[r.x], ldc(&beta[r.y]) + like(r, l));
-      }
-      __syncthreads();
-    }
-  }
-  float* post = p.post + (int64_t)n * p.post_seq_stride;
-
-  if (MODE == 0) {
-    // denominator posterior of the reference transition-id per frame (MergePosteriors' drop_frames test)
-    for (int t = 0; t < T; ++t) {
-      const int m0 = seg[2 * t + 1], m1 = m0 + kept[2 * t + 1];
-      const int r = ref[t];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int4 q = lrec[l];
-        if (q.z == r) atomicAdd(&ref_post[t], exp(ldc(&alpha[q.x]) + like(q, l) + ldc(&beta[q.y]) - tot));
-      }
-    }
+  if (U.status != kLatOk) { if (tid == 0 && blockIdx.x == 0) p.out[n] = NAN; return; }
+  const FbView v = fb_view(p, n, U);
+  const int T = v.T;
+  const int fT0 = v.ftok[T], fT1 = v.ftok[T + 1];
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < v.nt; i += kFbThreads) { v.alpha[i] = -INFINITY; v.af[i] = 0.0; }
+    for (int t = tid; t < T; t += kFbThreads) v.ref_post[t] = 0.0;
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-      if (p.drop_frames && ldc(&ref_post[t]) == 0.0) continue;
-      const int m0 = seg[2 * t + 1], m1 = m0 + kept[2 * t + 1];
-      float* row = post + (int64_t)t * p.post_frame_stride;
-      for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int4 q = lrec[l];
-        atomicAdd(&row[p.tid2pdf[q.z]], -(float)exp(ldc(&alpha[q.x]) + like(q, l) + ldc(&beta[q.y]) - tot));
+    if (tid == 0) v.alpha[0] = 0.0;
+    __syncthreads();
+    for (int t = 0; t <= T; ++t) {
+      if (t > 0) {
+        const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
+        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+          const int4 r = v.lrec[l];
+          atomic_log_add(&v.alpha[r.y], ldc(&v.alpha[r.x]) + link_like(p, v, r, l));
+        }
+        __syncthreads();
       }
-      if (tid == 0) atomicAdd(&row[p.tid2pdf[ref[t]]], 1.0f);
+      const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
+      for (int lev = 0; lev < v.maxlev[t]; ++lev) {
+        for (int l = e0 + tid; l < e1; l += kFbThreads) {
+          const int4 r = v.lrec[l];
+          if (v.tl[r.x] == lev) atomic_log_add(&v.alpha[r.y], ldc(&v.alpha[r.x]) + link_like(p, v, r, l));
+        }
+        __syncthreads();
+      }
     }
-    if (tid == 0) p.out[n] = tot;
-    return;
+    // total likelihood over the final tokens (stable log-sum-exp)
+    double mx = -INFINITY;
+    for (int i = fT0 + tid; i < fT1; i += kFbThreads)
+      if (v.tf[i] < INFINITY) mx = fmax(mx, ldc(&v.alpha[i]) + final_like(p, v, i));
+    mx = block_max_d(mx, red);
+    double sm = 0.0;
+    for (int i = fT0 + tid; i < fT1; i += kFbThreads)
+      if (v.tf[i] < INFINITY) sm += exp(ldc(&v.alpha[i]) + final_like(p, v, i) - mx);
+    sm = block_sum_d(sm, red);
+    if (tid == 0) v.F->fb_tot = mx + log(sm);
+  } else {
+    for (int i = tid; i < v.nt; i += kFbThreads) { v.beta[i] = -INFINITY; v.ab[i] = 0.0; }
+    __syncthreads();
+    for (int i = fT0 + tid; i < fT1; i += kFbThreads)
+      if (v.tf[i] < INFINITY) v.beta[i] = final_like(p, v, i);
+    __syncthreads();
+    for (int t = T; t >= 0; --t) {
+      const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
+      for (int lev = v.maxlev[t] - 1; lev >= 0; --lev) {
+        for (int l = e0 + tid; l < e1; l += kFbThreads) {
+          const int4 r = v.lrec[l];
+          if (v.tl[r.x] == lev) atomic_log_add(&v.beta[r.x], ldc(&v.beta[r.y]) + link_like(p, v, r, l));
+        }
+        __syncthreads();
+      }
+      if (t > 0) {
+        const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
+        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+          const int4 r = v.lrec[l];
+          atomic_log_add(&v.beta[r.x], ldc(&v.beta[r.y]) + link_like(p, v, r, l));
+        }
+        __syncthreads();
+      }
+    }
   }
+}
 
-  // ---- sMBR / MPFE: expected accuracy forward (alpha_smbr) ----
-  for (int t = 0; t <= T; ++t) {
-    if (t > 0) {
-      const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
-      const int r = ref[t - 1];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int4 q = lrec[l];
-        const int s = q.x, d = q.y;
-        atomicAdd(&af[d], exp(ldc(&alpha[s]) + like(q, l) - ldc(&alpha[d])) * (ldc(&af[s]) + frame_acc(p, q.z, r)));
+// sMBR / MPFE: the expected-accuracy recursions, forward (x = 0, needs alpha) and backward (x = 1, needs beta).
+__global__ void __launch_bounds__(kFbThreads) lat_fb_accuracy(FbParams p) {
+  __shared__ double red[kFbWaves];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const LatUtt U = p.L.utt[n];
+  if (U.status != kLatOk) return;
+  const FbView v = fb_view(p, n, U);
+  const int T = v.T;
+  if (blockIdx.x == 0) {
+    for (int t = 0; t <= T; ++t) {
+      if (t > 0) {
+        const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
+        const int r = v.ref[t - 1];
+        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+          const int4 q = v.lrec[l];
+          const int s = q.x, d = q.y;
+          atomicAdd(&v.af[d], exp(v.alpha[s] + link_like(p, v, q, l) - v.alpha[d]) * (ldc(&v.af[s]) + frame_acc(p, q.z, r)));
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
+      for (int lev = 0; lev < v.maxlev[t]; ++lev) {
+        for (int l = e0 + tid; l < e1; l += kFbThreads) {
+          const int4 q = v.lrec[l];
+          const int s = q.x, d = q.y;
+          if (v.tl[s] == lev) atomicAdd(&v.af[d], exp(v.alpha[s] + link_like(p, v, q, l) - v.alpha[d]) * ldc(&v.af[s]));
+        }
+        __syncthreads();
+      }
     }
-    const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
-    for (int lev = 0; lev < maxlev[t]; ++lev) {
-      for (int l = e0 + tid; l < e1; l += kFbThreads) {
-        const int4 q = lrec[l];
-        const int s = q.x, d = q.y;
-        if (tl[s] == lev) atomicAdd(&af[d], exp(ldc(&alpha[s]) + like(q, l) - ldc(&alpha[d])) * ldc(&af[s]));
+    const int fT0 = v.ftok[T], fT1 = v.ftok[T + 1];
+    const double tot = v.F->fb_tot;
+    double sc = 0.0;
+    for (int i = fT0 + tid; i < fT1; i += kFbThreads)
+      if (v.tf[i] < INFINITY) sc += exp(v.alpha[i] + final_like(p, v, i) - tot) * ldc(&v.af[i]);
+    sc = block_sum_d(sc, red);
+    if (tid == 0) v.F->fb_score = sc;
+  } else {
+    for (int t = T; t >= 0; --t) {
+      const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
+      for (int lev = v.maxlev[t] - 1; lev >= 0; --lev) {
+        for (int l = e0 + tid; l < e1; l += kFbThreads) {
+          const int4 q = v.lrec[l];
+          const int s = q.x, d = q.y;
+          const double bs = v.beta[s], bd = v.beta[d];
+          if (v.tl[s] == lev && bs > -INFINITY && bd > -INFINITY) atomicAdd(&v.ab[s], exp(bd + link_like(p, v, q, l) - bs) * ldc(&v.ab[d]));
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      if (t > 0) {
+        const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
+        const int r = v.ref[t - 1];
+        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+          const int4 q = v.lrec[l];
+          const int s = q.x, d = q.y;
+          const double bs = v.beta[s], bd = v.beta[d];
+          if (bs > -INFINITY && bd > -INFINITY)
+            atomicAdd(&v.ab[s], exp(bd + link_like(p, v, q, l) - bs) * (ldc(&v.ab[d]) + frame_acc(p, q.z, r)));
+        }
+        __syncthreads();
+      }
     }
   }
-  double sc = 0.0;
-  for (int i = fT0 + tid; i < fT1; i += kFbThreads)
-    if (tf[i] < INFINITY) sc += exp(ldc(&alpha[i]) + final_like(i) - tot) * ldc(&af[i]);
-  const double tot_score = block_sum_d(sc, red);
-  // ---- expected accuracy backward (beta_smbr) ----
-  for (int t = T; t >= 0; --t) {
-    const int e0 = seg[2 * t], e1 = e0 + kept[2 * t];
-    for (int lev = maxlev[t] - 1; lev >= 0; --lev) {
-      for (int l = e0 + tid; l < e1; l += kFbThreads) {
-        const int4 q = lrec[l];
-        const int s = q.x, d = q.y;
-        const double bs = ldc(&beta[s]), bd = ldc(&beta[d]);
-        if (tl[s] == lev && bs > -INFINITY && bd > -INFINITY) atomicAdd(&ab[s], exp(bd + like(q, l) - bs) * ldc(&ab[d]));
-      }
-      __syncthreads();
-    }
-    if (t > 0) {
-      const int m0 = seg[2 * t - 1], m1 = m0 + kept[2 * t - 1];
-      const int r = ref[t - 1];
-      for (int l = m0 + tid; l < m1; l += kFbThreads) {
-        const int4 q = lrec[l];
-        const int s = q.x, d = q.y;
-        const double bs = ldc(&beta[s]), bd = ldc(&beta[d]);
-        if (bs > -INFINITY && bd > -INFINITY)
-          atomicAdd(&ab[s], exp(bd + like(q, l) - bs) * (ldc(&ab[d]) + frame_acc(p, q.z, r)));
-      }
-      __syncthreads();
-    }
-  }
-  for (int t = 0; t < T; ++t) {
-    const int m0 = seg[2 * t + 1], m1 = m0 + kept[2 * t + 1];
-    const int r = ref[t];
+}
+
+// Posteriors, frame by frame in parallel (frames dealt round-robin to the workgroups of an utterance).
+// MODE 0: MMI (numerator - denominator with MergePosteriors' drop_frames test), MODE 1: sMBR / MPFE.
+template <int MODE>
+__global__ void __launch_bounds__(kFbThreads) lat_fb_posteriors(FbParams p) {
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const LatUtt U = p.L.utt[n];
+  if (U.status != kLatOk) return;
+  const FbView v = fb_view(p, n, U);
+  const double tot = v.F->fb_tot, tot_score = v.F->fb_score;
+  float* post = p.post + (int64_t)n * p.post_seq_stride;
+  if (blockIdx.x == 0 && tid == 0) p.out[n] = MODE == 0 ? tot : tot_score;
+  for (int t = blockIdx.x; t < v.T; t += gridDim.x) {
+    const int m0 = v.seg[2 * t + 1], m1 = m0 + v.kept[2 * t + 1];
+    const int r = v.ref[t];
     float* row = post + (int64_t)t * p.post_frame_stride;
-    for (int l = m0 + tid; l < m1; l += kFbThreads) {
-      const int4 q = lrec[l];
-      const int s = q.x, d = q.y;
-      const double bd = ldc(&beta[d]);
-      if (bd == -INFINITY) continue;
-      const double pr = exp(ldc(&alpha[s]) + like(q, l) + bd - tot);
-      const double diff = ldc(&af[s]) + frame_acc(p, q.z, r) + ldc(&ab[d]) - tot_score;
-      atomicAdd(&row[p.tid2pdf[q.z]], (float)(pr * diff));
+    if (MODE == 0) {
+      // denominator posterior of the reference transition-id (MergePosteriors' drop_frames test)
+      for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        const int4 q = v.lrec[l];
+        if (q.z == r) atomicAdd(&v.ref_post[t], exp(v.alpha[q.x] + link_like(p, v, q, l) + v.beta[q.y] - tot));
+      }
+      __syncthreads();
+      const bool drop = p.drop_frames && ldc(&v.ref_post[t]) == 0.0;
+      if (!drop) {
+        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+          const int4 q = v.lrec[l];
+          atomicAdd(&row[p.tid2pdf[q.z]], -(float)exp(v.alpha[q.x] + link_like(p, v, q, l) + v.beta[q.y] - tot));
+        }
+        if (tid == 0) atomicAdd(&row[p.tid2pdf[r]], 1.0f);
+      }
+    } else {
+      for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        const int4 q = v.lrec[l];
+        const int s = q.x, d = q.y;
+        const double bd = v.beta[d];
+        if (bd == -INFINITY) continue;
+        const double pr = exp(v.alpha[s] + link_like(p, v, q, l) + bd - tot);
+        const double diff = v.af[s] + frame_acc(p, q.z, r) + v.ab[d] - tot_score;
+        atomicAdd(&row[p.tid2pdf[q.z]], (float)(pr * diff));
+      }
     }
   }
-  if (tid == 0) p.out[n] = tot_score;
 }
 
 }  // namespace pk2
@@ -273,8 +308,14 @@ using namespace pk2;
 static int fb_launch(int mode, const pk2_lattice_batch* b, void* workspace, FbParams& p, hipStream_t stream) {
   PK2_REQUIRE(b->decoded, "lattice forward-backward: pk2_lattice_decode has not run on this batch");
   lattice_carve(b, workspace, &p.L);
-  if (mode == 0) hipLaunchKernelGGL(lat_fb_kernel<0>, dim3(b->N), dim3(kFbThreads), 0, stream, p);
-  else hipLaunchKernelGGL(lat_fb_kernel<1>, dim3(b->N), dim3(kFbThreads), 0, stream, p);
+  const dim3 two(2, b->N), many(64, b->N), thr(kFbThreads);
+  hipLaunchKernelGGL(lat_fb_alpha_beta, two, thr, 0, stream, p);
+  if (mode == 0) {
+    hipLaunchKernelGGL(lat_fb_posteriors<0>, many, thr, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(lat_fb_accuracy, two, thr, 0, stream, p);
+    hipLaunchKernelGGL(lat_fb_posteriors<1>, many, thr, 0, stream, p);
+  }
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -65,6 +65,7 @@ struct LatFrame {
   int32_t changed[kLatEpsRounds + 1];
   const float* ll_base;        // the utterance's log-likelihood rows (kept out of the graph-baked parameters)
   int64_t ll_stride;
+  double fb_tot, fb_score;     // lattice forward-backward: total log-likelihood, expected accuracy
 };
 
 // Arrays of the workspace (device pointers).
