@@ -53,10 +53,10 @@ def build_supervisions(alis):
     return [chain.supervision_from_alignment(aligner, tree, tm, sopts, a) for a in alis]
 
 
-def make_batches(rng, n_unique, batch, device):
+def make_batches(rng, n_unique, batch, device, duration_rng=None):
     out = []
     for _ in range(n_unique):
-        mb = synth.minibatch(rng, batch, P, ali_model=chain_model()[2])
+        mb = synth.minibatch(rng, batch, P, ali_model=chain_model()[2], duration_rng=duration_rng)
         lens = [w.shape[0] for w, _ in mb]
         wav = torch.from_numpy(np.concatenate([w for w, _ in mb])).to(device)
         out.append(dict(wav=wav, lens=lens, alis=[a for _, a in mb], seconds=sum(lens) / 16000.0, host=mb))
@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--length-bucketed", action="store_true", help="N > 1: every rank draws the same utterance lengths "
+                    "(different audio / alignments), i.e. length-bucketed data parallelism without stragglers")
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
     ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
     ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
@@ -458,7 +460,10 @@ def main():
         return
     rng = np.random.default_rng(1234 + rank)
     n_unique = min(args.steps + args.warmup, 8)
-    batches = make_batches(rng, n_unique, args.batch, dev)
+    # default: SURVEY 8(d) protocol, everything seeded per rank (ranks draw different utterance lengths, so a step
+    # waits for the rank with the longest minibatch); --length-bucketed gives every rank the same lengths
+    batches = make_batches(rng, n_unique, args.batch, dev,
+                           np.random.default_rng(1234) if args.length_bucketed else None)
     log("%d minibatches ready" % n_unique)
     tr = Trainer(dev, den, arch="transformer" if args.transformer else "blstm")
 
@@ -508,7 +513,8 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
         "transition-id alignments over a synthetic left-biphone tree, 30k-state/1M-arc denominator graph; "
-        "random-init 3x512 BLSTM; supervisions built from the alignments inside the step)",
+        "random-init 3x512 BLSTM; supervisions built from the alignments inside the step%s)"
+        % ("; utterance lengths bucketed across ranks" if args.length_bucketed else ""),
         "config": {"workload": ("SECONDARY configs[4]: 12-layer TransformerAM LF-MMI; " if args.transformer else "") +
                                "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
                                "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"

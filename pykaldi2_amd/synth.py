@@ -170,11 +170,13 @@ def numerator_fst_from_alignment(ali, subsample=3, tolerance=5):
                 final_weights=np.zeros(1, dtype=np.float32))
 
 
-def minibatch(rng, batch, num_pdfs, sr=16000, ali_model=None):
+def minibatch(rng, batch, num_pdfs, sr=16000, ali_model=None, duration_rng=None):
     """One LibriSpeech-shaped minibatch: list of (wav f32[N], alignment i64[T]); the alignment holds pdf-ids,
-    or transition-ids of `ali_model` (a TransitionModel: the label files of chain training)."""
+    or transition-ids of `ali_model` (a TransitionModel: the label files of chain training).  `duration_rng`
+    draws the utterance lengths from a separate generator (length-bucketed data parallelism: every rank passes
+    the same one and gets utterances of the same lengths with different content)."""
     out = []
-    for d in utterance_durations(rng, batch):
+    for d in utterance_durations(duration_rng if duration_rng is not None else rng, batch):
         wav = waveform(rng, float(d), sr)
         T = num_fbank_frames(wav.shape[0])
         out.append((wav, phone_tid_alignment(rng, T, ali_model)[0] if ali_model is not None else pdf_alignment(rng, T, num_pdfs)))
