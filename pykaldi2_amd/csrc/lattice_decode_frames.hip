@@ -81,6 +81,21 @@ __device__ __forceinline__ int wave_alloc(int32_t* counter, bool want) {
   return base + __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Same for a run of `count` slots per lane; every lane of the wave must be active.  Returns the lane's first slot.
+__device__ __forceinline__ int wave_alloc_n(int32_t* counter, int count) {
+  const int lane = threadIdx.x & 63;
+  int incl = count;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += y;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 63 && total > 0) base = atomicAdd(counter, total);
+  return __shfl(base, 63, 64) + incl - count;
+}
+
 // Called by every lane that created the token of state d (old == kEmpty); others pass create = false.
 __device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int fb, int d,
                                                     bool create = true) {
@@ -267,14 +282,18 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
   for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
   float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
   float nmin = INFINITY;
-  for (int base = f0 + c.wg * 4 * kLatThreads; base < f1; base += c.G * 4 * kLatThreads) {
+  // the frame's tokens are cut into G equal slices (a frame has a few thousand tokens: dealing them in chunks of
+  // 4096 would leave most of the team without work and put several dependent passes of the cost loop on the rest)
+  const int per = (f1 - f0 + c.G - 1) / c.G;
+  const int s0 = f0 + c.wg * per, s1 = min(s0 + per, f1);
+  for (int base = s0; base < s1; base += 4 * kLatThreads) {
     int2 ar[4];
     int mine = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = base + tid * 4 + q;
       ar[q] = make_int2(0, 0);
-      if (i < f1) {
+      if (i < s1) {
         if (tc[i] <= cur_cutoff) ar[q] = V.tarc[i];
         // sparse reset of the state table: every token of the old frame passes here once, and nothing reads the
         // table between the launch that closed the frame and the next expand
@@ -302,13 +321,18 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
       total = 0;
     }
     __syncthreads();
-    for (int j = b0 + tid; j < b0 + total; j += kLatThreads) {
-      const int2 wk = V.work[j];
-      const int4 er = V.erec[wk.y];
-      const float ac = -__fmul_rn(p.ac_scale, sh.ll[er.w]);
-      const float tot = __fadd_rn(__fadd_rn(tc[wk.x], ac), __int_as_float(er.z));
-      wcost[j] = make_float2(tot, ac);
-      nmin = fminf(nmin, tot);
+    for (int j0 = b0 + tid; j0 < b0 + total; j0 += 2 * kLatThreads) {     // two independent arcs in flight per thread
+      const int j1 = j0 + kLatThreads;
+      const bool two = j1 < b0 + total;
+      const int2 wk0 = V.work[j0], wk1 = two ? V.work[j1] : wk0;
+      const int4 er0 = V.erec[wk0.y], er1 = V.erec[wk1.y];
+      const float c0 = tc[wk0.x], c1 = tc[wk1.x];
+      const float ac0 = -__fmul_rn(p.ac_scale, sh.ll[er0.w]), ac1 = -__fmul_rn(p.ac_scale, sh.ll[er1.w]);
+      const float tot0 = __fadd_rn(__fadd_rn(c0, ac0), __int_as_float(er0.z));
+      const float tot1 = __fadd_rn(__fadd_rn(c1, ac1), __int_as_float(er1.z));
+      wcost[j0] = make_float2(tot0, ac0);
+      nmin = fminf(nmin, tot0);
+      if (two) { wcost[j1] = make_float2(tot1, ac1); nmin = fminf(nmin, tot1); }
     }
     __syncthreads();
   }
@@ -333,32 +357,65 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodePar
   const int n_arcs = F->n_arcs, l0 = F->link_end, fb = F->f1;
   const float2* wcost = reinterpret_cast<const float2*>(V.work_tot);
   const int stride = c.G * kLatThreads;
-  for (int j0 = c.wg * kLatThreads + tid; j0 < n_arcs; j0 += 4 * stride) {
-    float2 tc2[4]; int2 wk[4]; int4 er[4]; uint32_t old[4]; bool acc[4];
+  // Waves stay whole (the loop bound is the wave's first lane) so that slots can be reserved with one atomic per
+  // wave and counter, and the independent requests of a pass are all in flight together: costs + work items ->
+  // arc records -> atomicMin on the table and the link slots -> token slots and the epsilon test -> epsilon slots.
+  for (int jw = c.wg * kLatThreads + (tid & ~63); jw < n_arcs; jw += 4 * stride) {
+    const int j0 = jw + (tid & 63);
+    float2 tc2[4]; int2 wk[4]; int4 er[4]; uint32_t old[4]; bool acc[4], made[4], eps[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int j = j0 + q * stride;
-      acc[q] = false;
-      if (j < n_arcs) { tc2[q] = wcost[j]; acc[q] = tc2[q].x < next_cutoff; }
-      if (acc[q]) wk[q] = V.work[j];
+      acc[q] = j < n_arcs;
+      if (acc[q]) { tc2[q] = wcost[j]; wk[q] = V.work[j]; }
+    }
+    int n_acc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = acc[q] && tc2[q].x < next_cutoff;
+      n_acc += acc[q];
+      if (acc[q]) er[q] = V.erec[wk[q].y];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (acc[q]) er[q] = V.erec[wk[q].y];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
       if (acc[q]) old[q] = atomicMin(&V.stc[er[q].x], enc_cost(tc2[q].x));
+    int li = l0 + wave_alloc_n(&F->n_link, n_acc);
+    int n_made = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      team_register_token(p, V, F, fb, acc[q] ? er[q].x : 0, acc[q] && old[q] == kEmpty);
-      const int li = l0 + wave_alloc(&F->n_link, acc[q]);
+      made[q] = acc[q] && old[q] == kEmpty;
+      n_made += made[q];
+      eps[q] = made[q] && p.g.n_off[er[q].x + 1] > p.g.n_off[er[q].x];
+    }
+    int ti = wave_alloc_n(&F->n_new, n_made);
+    int n_eps = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) n_eps += eps[q];
+    int ei = wave_alloc_n(&F->n_elist, n_eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
       if (!acc[q]) continue;
+      if (made[q]) {
+        if (fb + ti < V.tok_cap) {
+          V.ts[fb + ti] = er[q].x;
+          V.tc[fb + ti] = INFINITY;
+          st_coherent(&V.stt[er[q].x], ti);
+          if (eps[q]) {
+            if (ei < V.tok_cap) V.elist[ei] = fb + ti; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+            ++ei;
+          }
+        } else {
+          st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+        }
+        ++ti;
+      }
       if (li < V.link_cap) {
         V.lrec[li] = make_int4(wk[q].x, er[q].x /* state for now */, er[q].y, er[q].z);
         V.lac[li] = tc2[q].y;
       } else {
         st_coherent(&F->status, (int32_t)kLatLinkOverflow);
       }
+      ++li;
     }
   }
   if (team_last(F, c.G, &s_flag) && tid == 0) {
