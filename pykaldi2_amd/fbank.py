@@ -71,7 +71,9 @@ class FbankExtractor:
         frames = [num_frames(l) for l in wav_lengths]
         row_off_h = np.zeros(n + 1, dtype=np.int64)
         row_off_h[1:] = np.cumsum(frames)
-        row_off = torch.from_numpy(row_off_h).to(wav.device, non_blocking=False)
+        # pinned + non_blocking: a pageable copy would block the host until the stream has drained the previous
+        # training step (the host then never runs ahead of the GPU)
+        row_off = torch.from_numpy(row_off_h).pin_memory().to(wav.device, non_blocking=True)
         feats = torch.empty(int(row_off_h[-1]), 80, dtype=torch.float32, device=wav.device)
         _lib.check(_lib.lib().pk2_fbank_compute(self._h, _lib.ptr(wav), _lib.ptr(wav_off), n, _lib.ptr(feats),
                                                 _lib.ptr(row_off), 1 if apply_cmn else 0,

@@ -1,0 +1,25 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from pykaldi2_amd import chain, synth
+dev = torch.device('cuda', 0)
+g = synth.den_graph_arcs(bench.S_DEN, bench.A_DEN, bench.P, seed=0)
+den = chain.DenominatorGraph(g, bench.P)
+rng = np.random.default_rng(1234)
+batches = bench.make_batches(rng, 8, 4, dev)
+tr = bench.Trainer(dev, den)
+for i in range(4): tr.step(batches[i])
+torch.cuda.synchronize()
+host = []
+t0 = time.perf_counter()
+for i in range(16):
+    a = time.perf_counter(); tr.step(batches[i % 8]); host.append(time.perf_counter() - a)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue per step ms: mean %.2f max %.2f | loop %.1f ms, drain %.1f ms, total per step %.2f" % (1e3*np.mean(host), 1e3*max(host), 1e3*(t1-t0), 1e3*(t2-t1), 1e3*(t2-t0)/16))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for i in range(8): tr.step(batches[i % 8])
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
