@@ -59,6 +59,7 @@ def main():
     parser.add_argument("-sweep_size", default=200, type=float, help="process n hours of data per sweep (default:200)")
     parser.add_argument("-num_epochs", default=1, type=int, help="number of training epochs (default:1)")
     parser.add_argument("-global_mvn", default=False, type=bool, help="if apply global mean and variance normalization")
+    parser.add_argument("-mvn_utterances", default=2000, type=int, help="utterances used to estimate the global mean and variance")
     parser.add_argument("-resume_from_model", type=str, help="the model from which you want to resume training")
     parser.add_argument("-dropout", type=float, help="set the dropout ratio")
     parser.add_argument("-anneal_lr_epoch", default=2, type=int, help="start to anneal the learning rate from this epoch")
@@ -106,20 +107,28 @@ def main():
     criterion = ops.CrossEntropyLoss(ignore_index=-100)
     source = data.make_source(config, mc["label_size"], hvd.rank(), hvd.size())
     fb = fbank.FbankExtractor()
+    transform = None
+    if args.global_mvn:      # reference bin/train_ce.py:110-121
+        print("Estimating global mean and variance of feature vectors...")
+        transform = fbank.GlobalMeanVarianceNormalization.estimate(source, fb, dev, n_sample_to_use=args.mvn_utterances,
+                                                                   apply_cmn=config["data_config"].get("use_cmn", True))
+        print("Global mean and variance transform trained successfully!")
+        if args.exp_dir and (not args.hvd or hvd.rank() == 0):
+            transform.save(args.exp_dir + "/transform.pkl")
 
     model.train()
     for epoch in range(start_epoch, args.num_epochs):
         if epoch > args.anneal_lr_epoch:
             for param_group in optimizer.param_groups:
                 param_group['lr'] *= args.anneal_lr_ratio
-        run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev)
+        run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev, transform)
         if (not args.hvd or hvd.rank() == 0) and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.' + str(epoch) + '.tar')
     hvd.shutdown()
 
 
-def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev):
+def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev, transform):
     batch_time = utils.AverageMeter('Time', ':6.3f')
     losses = utils.AverageMeter('Loss', ':.4e')
     grad_norm = utils.AverageMeter('grad_norm', ':.4e')
@@ -148,6 +157,8 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
 
     for batch in data.sequence_batches(source, 8, args.sweep_size, dev):
         feats, frames, row_off = fb(batch["wav"], batch["lens"], apply_cmn=dc.get("use_cmn", True))
+        if transform is not None:
+            feats = transform(feats)
         off = np.concatenate([[0], np.cumsum(frames)])
         for n, y in enumerate(batch["y"]):
             f = feats[off[n]:off[n + 1]]

@@ -111,19 +111,22 @@ def main():
     supervision_opts = chain.SupervisionOptions()
     chain_opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=args.xent_regularize)
     source = data.make_source(config, P, hvd.rank(), hvd.size(), ali_model=aligner.transition_model)
+    transform = None
+    if args.transform is not None and os.path.isfile(args.transform):
+        transform = fbank.GlobalMeanVarianceNormalization.load(args.transform)
     sup_model = (aligner, chain_tree, chain_trans_model)
     fb = fbank.FbankExtractor()
 
     model.train()
     for epoch in range(args.num_epochs):
-        run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model)
+        run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model, transform)
         if hvd.rank() == 0 and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/chain.model.' + str(epoch) + '.tar')
     hvd.shutdown()
 
 
-def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model):
+def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model, transform):
     batch_time = utils.AverageMeter('Time', ':6.3f')
     losses = utils.AverageMeter('Loss', ':.4e')
     grad_norm = utils.AverageMeter('grad_norm', ':.4e')
@@ -134,6 +137,8 @@ def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, 
     for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
         frame_shift = (epoch % sub) * -1
         feats, frames, row_off = fb(batch["wav"], batch["lens"])
+        if transform is not None:     # dataset.transform of the reference (bin/train_chain.py:118-122)
+            feats = transform(feats)
         x = fb.pad_roll_subsample(feats, row_off, frames, shift=frame_shift, subsample=sub, time_major=True)
         aligner, tree, trans_model = sup_model
         sups = [chain.supervision_from_alignment(aligner, tree, trans_model, supervision_opts, np.asarray(y)[:T])

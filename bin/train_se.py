@@ -137,12 +137,15 @@ def main(arch="blstm"):
         trans_model = asr_decoder.trans_model
         log_prior = se.log_prior_from_counts(se.read_kaldi_vector(args.prior_path))
     source = data.make_source(config, P, hvd.rank(), hvd.size(), with_tids=True)
+    transform = None
+    if args.transform is not None and os.path.isfile(args.transform):
+        transform = fbank.GlobalMeanVarianceNormalization.load(args.transform)
     fb = fbank.FbankExtractor()
 
     model.train()
     for epoch in range(args.num_epochs):
         run_train_epoch(model, optimizer, log_prior.to(dev), source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev,
-                        forward)
+                        forward, transform)
         if hvd.rank() == 0 and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.se.' + str(epoch) + '.tar')
@@ -150,7 +153,7 @@ def main(arch="blstm"):
 
 
 def run_train_epoch(model, optimizer, log_prior, source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev,
-                    forward=None):
+                    forward=None, transform=None):
     batch_time = utils.AverageMeter('Time', ':6.3f')
     losses = utils.AverageMeter('Loss', ':.4e')
     grad_norm = utils.AverageMeter('grad_norm', ':.4e')
@@ -160,7 +163,7 @@ def run_train_epoch(model, optimizer, log_prior, source, fb, epoch, asr_decoder,
     end = time.time()
     for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
         loss, se_val, ce_loss, frames = se.sequence_loss(model, fb, batch, asr_decoder, trans_model, log_prior, args.criterion,
-                                                         silence_ids, args.ce_ratio, ce_criterion, forward)
+                                                         silence_ids, args.ce_ratio, ce_criterion, forward, transform)
         optimizer.zero_grad()
         loss.backward()
         norm = optim.clip_grad_norm_(optimizer, args.max_grad_norm)

@@ -36,6 +36,7 @@ def main():
     parser.add_argument("-sweep_size", default=200, type=float, help="process n hours of data per sweep (default:200)")
     parser.add_argument("-num_epochs", default=1, type=int, help="number of training epochs (default:1)")
     parser.add_argument("-global_mvn", default=False, type=bool, help="if apply global mean and variance normalization")
+    parser.add_argument("-mvn_utterances", default=2000, type=int, help="utterances used to estimate the global mean and variance")
     parser.add_argument("-resume_from_model", type=str, help="the model from which you want to resume training")
     parser.add_argument("-dropout", default=0, type=float, help="set the dropout ratio")
     parser.add_argument("-warmup_step", default=4000, type=int, help="the number of warmup steps to adjust the learning rate")
@@ -87,17 +88,25 @@ def main():
     criterion = ops.CrossEntropyLoss(ignore_index=-100)
     source = data.make_source(config, mc["label_size"], hvd.rank(), hvd.size())
     fb = fbank.FbankExtractor()
+    transform = None
+    if args.global_mvn:      # reference bin/train_ce.py:110-121
+        print("Estimating global mean and variance of feature vectors...")
+        transform = fbank.GlobalMeanVarianceNormalization.estimate(source, fb, dev, n_sample_to_use=args.mvn_utterances,
+                                                                   apply_cmn=config["data_config"].get("use_cmn", True))
+        print("Global mean and variance transform trained successfully!")
+        if args.exp_dir and (not args.hvd or hvd.rank() == 0):
+            transform.save(args.exp_dir + "/transform.pkl")
 
     model.train()
     for epoch in range(start_epoch, args.num_epochs):
-        run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev)
+        run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev, transform)
         if (not args.hvd or hvd.rank() == 0) and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.' + str(epoch) + '.tar')
     hvd.shutdown()
 
 
-def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev):
+def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev, transform):
     batch_time = utils.AverageMeter('Time', ':6.3f')
     losses = utils.AverageMeter('Loss', ':.4e')
     grad_norm = utils.AverageMeter('grad_norm', ':.4e')
@@ -107,6 +116,8 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
     end = time.time()
     for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
         feats, frames, row_off = fb(batch["wav"], batch["lens"], apply_cmn=use_cmn)
+        if transform is not None:
+            feats = transform(feats)
         x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=True)     # [Tmax, N, 80]
         prediction = transformer.padded_forward(model, x, frames, args.look_ahead)                    # [N, Tmax, P]
         N, Tmax = prediction.shape[0], prediction.shape[1]

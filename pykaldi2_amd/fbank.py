@@ -110,6 +110,13 @@ def utt2seg(feats, seg_len, seg_shift):
     return view.contiguous()
 
 
+class _MvnState:
+    """What GlobalMeanVarianceNormalization.save pickles (attribute names of the reference's class)."""
+
+    def __init__(self, mean_vec, std_vec):
+        self.mean_vec, self.std_vec, self.mean_norm, self.var_norm = mean_vec, std_vec, True, True
+
+
 class GlobalMeanVarianceNormalization:
     """Apply side of reader/preprocess.py:89-229: (x - mean_vec) / std_vec with the pickled [1, D] vectors
     (std floored at 1e-2 when it was estimated, :141-149).  Estimation stays a host-side, one-off step."""
@@ -155,6 +162,33 @@ class GlobalMeanVarianceNormalization:
         if not getattr(o, "var_norm", True):
             std = np.ones_like(std)
         return cls(mean, std)
+
+    def save(self, path):
+        """Pickles the transform with the attribute names of the reference's class (mean_vec, std_vec [1, D],
+        mean_norm, var_norm: reader/preprocess.py:89-112), so that `load` reads files from either side."""
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(_MvnState(self.mean_vec, self.std_vec), f, pickle.HIGHEST_PROTOCOL)
+
+    @classmethod
+    def estimate(cls, source, extractor, device, n_sample_to_use=2000, apply_cmn=True, batch=8):
+        """learn_mean_and_variance_from_train_loader (reference bin/train_ce.py:112-118, reader/preprocess.py:114-151):
+        sum and sum of squares of the features of `n_sample_to_use` utterances drawn from the source (accumulated on
+        the device in float64), then the floored standard deviation."""
+        s1 = torch.zeros(80, dtype=torch.float64, device=device)
+        s2 = torch.zeros(80, dtype=torch.float64, device=device)
+        n_frame, seen = 0, 0
+        while seen < n_sample_to_use:
+            utts = [source.draw() for _ in range(min(batch, n_sample_to_use - seen))]
+            seen += len(utts)
+            lens = [u[0].shape[0] for u in utts]
+            wav = torch.from_numpy(np.concatenate([u[0] for u in utts])).to(device)
+            feats, frames, _ = extractor(wav, lens, apply_cmn=apply_cmn)
+            f64 = feats.double()
+            s1 += f64.sum(0)
+            s2 += (f64 * f64).sum(0)
+            n_frame += int(sum(frames))
+        return cls.from_stats(s1.cpu().numpy(), s2.cpu().numpy(), n_frame)
 
     def __call__(self, x):
         return self.apply_on_tensor(x)

@@ -45,11 +45,13 @@ def log_prior_from_counts(counts):
 
 
 def sequence_loss(model, fb, batch, asr_decoder, trans_model, log_prior, criterion, silence_ids, ce_ratio, ce_criterion,
-                  forward=None):
+                  forward=None, transform=None):
     """Forward of one minibatch: batch = dict(wav, lens, y = pdf alignments, aux = transition-id alignments)
     from pykaldi2_amd.data.  `forward(model, x[Tmax, N, 80], frames) -> [N, Tmax, P]` replaces the BLSTM call
     (TransformerAM with its masks: bin/train_transformer_se.py).  Returns (loss, se_value, ce_loss, frames)."""
     feats, frames, row_off = fb(batch["wav"], batch["lens"])
+    if transform is not None:      # the `-transform` MVN statistics (reference bin/train_se.py:104-108)
+        feats = transform(feats)
     x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=True)      # [Tmax, N, 80]
     if forward is not None:
         prediction = forward(model, x, frames)

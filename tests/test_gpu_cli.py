@@ -37,12 +37,24 @@ def test_train_chain_cli_synthetic(tmp_path):
 def test_train_ce_cli_synthetic(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_ce.py"), "-train_config",
                           _cfg(tmp_path, "ce.yaml", 120, False), "-exp_dir", str(tmp_path / "exp"), "-lr", "1e-3",
-                          "-batch_size", "16", "-sweep_size", "0.05", "-print_freq", "1", "-synthetic"],
+                          "-batch_size", "16", "-sweep_size", "0.05", "-print_freq", "1", "-synthetic",
+                          "-global_mvn", "1", "-mvn_utterances", "6"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "Epoch: [0]" in out.stdout and "Loss" in out.stdout
     ck = torch.load(tmp_path / "exp" / "model.0.tar", map_location="cpu", weights_only=False)
     assert ck["epoch"] == 0 and "output_layer.bias" in ck["model"]
+    # -global_mvn wrote the transform; the sequence CLIs take it back through -transform
+    from pykaldi2_amd import fbank
+    t = fbank.GlobalMeanVarianceNormalization.load(str(tmp_path / "exp" / "transform.pkl"))
+    assert t.mean_vec.shape == (1, 80) and np.isfinite(t.mean_vec).all() and (t.std_vec >= 1e-2).all()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "train_chain.py"), "-config",
+                          _cfg(tmp_path, "mmi.yaml", 120, True), "-exp_dir", str(tmp_path / "exp2"), "-lr", "1e-3",
+                          "-batch_size", "2", "-sweep_size", "0.01", "-print_freq", "1", "-synthetic", "-den_states", "400",
+                          "-den_arcs", "6000", "-transform", str(tmp_path / "exp" / "transform.pkl")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Epoch: [0]" in out.stdout
 
 
 @pytest.mark.parametrize("criterion", ["mmi", "smbr"])

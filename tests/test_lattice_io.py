@@ -204,3 +204,13 @@ def test_mvn_transform_pickle_of_the_reference_class(tmp_path):
         del sys.modules["reader"], sys.modules["reader.preprocess"]
     t = fbank.GlobalMeanVarianceNormalization.load(str(tmp_path / "mvn.pkl"))
     assert np.array_equal(t.mean_vec, o.mean_vec) and np.array_equal(t.std_vec, o.std_vec)
+
+
+def test_mvn_transform_save_load_round_trip(tmp_path):
+    from pykaldi2_amd import fbank
+    rng = np.random.default_rng(3)
+    t = fbank.GlobalMeanVarianceNormalization.from_stats(rng.normal(5, 1, 80) * 1000, (rng.normal(5, 1, 80) ** 2 + 4) * 1000, 1000)
+    t.save(str(tmp_path / "transform.pkl"))
+    back = fbank.GlobalMeanVarianceNormalization.load(str(tmp_path / "transform.pkl"))
+    assert back.mean_vec.shape == (1, 80) and np.array_equal(back.mean_vec, t.mean_vec) and np.array_equal(back.std_vec, t.std_vec)
+    assert np.all(t.std_vec >= 1e-2)
