@@ -209,7 +209,9 @@ def test_mvn_transform_pickle_of_the_reference_class(tmp_path):
 def test_mvn_transform_save_load_round_trip(tmp_path):
     from pykaldi2_amd import fbank
     rng = np.random.default_rng(3)
-    t = fbank.GlobalMeanVarianceNormalization.from_stats(rng.normal(5, 1, 80) * 1000, (rng.normal(5, 1, 80) ** 2 + 4) * 1000, 1000)
+    x = rng.normal(5, 2, size=(1000, 80))
+    t = fbank.GlobalMeanVarianceNormalization.from_stats(x.sum(0), (x * x).sum(0), 1000)
+    assert np.abs(t.mean_vec - x.mean(0)).max() < 1e-3 and np.abs(t.std_vec - x.std(0)).max() < 1e-2
     t.save(str(tmp_path / "transform.pkl"))
     back = fbank.GlobalMeanVarianceNormalization.load(str(tmp_path / "transform.pkl"))
     assert back.mean_vec.shape == (1, 80) and np.array_equal(back.mean_vec, t.mean_vec) and np.array_equal(back.std_vec, t.std_vec)
