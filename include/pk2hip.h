@@ -187,6 +187,27 @@ int pk2_supervision_copy(const pk2_supervision* s, int32_t* arc_src, int32_t* ar
                          float* final_weight, int32_t* allowed_off, int32_t* allowed_phones);
 
 /* ------------------------------------------------------------------ *
+ * Reverberation + additive noise of one utterance (single channel), device arrays throughout.
+ * Replaces the numpy arithmetic of the reference's dynamic data simulation: Distorter.apply_rir /
+ * Distorter.add_noise (reference simulation/_distorter.py:86-154) as _Simulator.simulate uses them for one
+ * speech source (simulation/simulation.py:55-178, called from data/sr_dataset.py:321-345).  The random draws
+ * (SNR, noise position) are made by the host and passed in.
+ * ------------------------------------------------------------------ */
+/* out[i] = (rir * wav)[delay - 1 + i], i in [0, n): apply_rir with sync = True (:147-148); delay = argmax(rir)
+ * (delay = 0 keeps the direct path at sample 0).  out must not alias wav. */
+int pk2_sim_apply_rir(const float* wav, int64_t n, const float* rir, int32_t k, int32_t delay, float* out,
+                      void* stream);
+/* stats (device f64[2], zeroed by the caller): stats[0] += sum x^2, stats[1] = max(stats[1], max |x|). */
+int pk2_sim_power(const float* x, int64_t n, double* stats, void* stream);
+/* mixed[i] += scale * noise_placed[i], scale = sqrt(Px / Pn * 10^(-snr_db / 10)) with Px = sig_stats[0] / n and
+ * Pn = noise_stats[0] / m (_comp_noise_scale_given_snr :28-32); 'sample_noise' placement (:36-58): a noise not
+ * longer than the signal sits at [start, start + m), a longer one is cropped from `start`. */
+int pk2_sim_add_noise(float* mixed, int64_t n, const float* noise, int64_t m, int64_t start, float snr_db,
+                      const double* sig_stats, const double* noise_stats, void* stream);
+/* x *= 0.5 / stats[1]  (gain normalisation, simulation/simulation.py:170-172). */
+int pk2_sim_gain_norm(float* x, int64_t n, const double* stats, void* stream);
+
+/* ------------------------------------------------------------------ *
  * 80-dim log-mel filterbank + CMN + frame subsampling.
  * Replaces DataGeneratorTrain._logfbank_extractor (reference
  * data/sr_dataset.py:279-296 over simulation/freq_analysis.py:113-150),

@@ -74,6 +74,10 @@ SIGNATURES = {
                                   _vp, _vp]),
     "pk2_lattice_export": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp]),
+    "pk2_sim_apply_rir": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp, _vp]),
+    "pk2_sim_power": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "pk2_sim_add_noise": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),
+    "pk2_sim_gain_norm": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pk2_fbank_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pk2_fbank_destroy": (C.c_int, [_vp]),
     "pk2_fbank_num_frames": (_i32, [_i64]),
