@@ -76,6 +76,10 @@ def main():
         with open(args.data_config) as f:
             d = yaml.safe_load(f)
             config["source_paths"] = [j for i, j in d['clean_source'].items()]
+            if 'dir_noise' in d:      # reference bin/train_ce.py:73-76
+                config["dir_noise_paths"] = [j for i, j in d['dir_noise'].items()]
+            if 'rir' in d:
+                config["rir_paths"] = [j for i, j in d['rir'].items()]
     config["synthetic"] = args.synthetic
     config['data_path'] = args.dataPath
     print("Experiment starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))

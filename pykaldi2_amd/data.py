@@ -116,18 +116,98 @@ class SyntheticSource:
 
 def make_source(config, num_pdfs, rank=0, world=1, with_tids=False, ali_model=None):
     if config.get("synthetic") or not config.get("source_paths"):
-        return SyntheticSource(num_pdfs, rank=rank, world=world, with_tids=with_tids, ali_model=ali_model)
-    return ZipWavSource(config["source_paths"], config.get("data_path", ""), rank=rank, world=world)
+        source = SyntheticSource(num_pdfs, rank=rank, world=world, with_tids=with_tids, ali_model=ali_model)
+    else:
+        source = ZipWavSource(config["source_paths"], config.get("data_path", ""), rank=rank, world=world)
+    source.simulation = SimulationPool.from_config(config, seed=rank)     # None unless data_config switches it on
+    return source
 
 
-def sequence_batches(source, batch_size, hours, device):
+class SimulationPool:
+    """Noises and room impulse responses for the dynamic simulation (reference data/sr_dataset.py:94-126,321-345):
+    with probability `simulation_prob` an utterance is reverberated by a sampled RIR and mixed with one sampled
+    directional noise (reverberated by a second RIR of the pool) at an SNR drawn by pykaldi2_amd.simulation --
+    on the device.  Sources: zips of 16 kHz wav files (`dir_noise` / `rir` entries of the data yaml, first channel,
+    one impulse response per file), or the synthetic generator."""
+
+    def __init__(self, noises, rirs, use_reverb=True, use_noise=True, simulation_prob=0.5, gain_norm=False, snr_range=(0, 30)):
+        from . import simulation
+        self.noises = noises if use_noise else []
+        self.rirs = rirs if use_reverb else []
+        self.prob, self.gain_norm = float(simulation_prob), bool(gain_norm)
+        self.sim = simulation.SimpleSimulator(use_rir=bool(self.rirs), use_noise=bool(self.noises), snr_range=snr_range)
+        self._dev = {}
+
+    @classmethod
+    def from_config(cls, config, seed=0):
+        """data_config keys of the reference YAMLs (use_dir_noise, use_reverb, snr_range, simulation_prob, gain_norm)
+        plus `dir_noise_paths` / `rir_paths` (bin/train_ce.py:73-76); None when the simulation is off."""
+        dc = config.get("data_config", {})
+        prob = dc.get("simulation_prob", 0)
+        if not prob or not (dc.get("use_dir_noise") or dc.get("use_reverb")):
+            return None
+        if config.get("synthetic") or not (config.get("dir_noise_paths") or config.get("rir_paths")):
+            rng = np.random.default_rng(4321 + seed)
+            noises = [synth.waveform(rng, float(d)) for d in rng.uniform(2.0, 12.0, size=8)]
+            rirs = [synth.room_impulse_response(rng) for _ in range(16)]
+        else:
+            noises = cls._read_zips(config.get("dir_noise_paths") or [], config.get("data_path", ""))
+            rirs = cls._read_zips(config.get("rir_paths") or [], config.get("data_path", ""))
+        return cls(noises, rirs, dc.get("use_reverb", False), dc.get("use_dir_noise", False), prob, dc.get("gain_norm", False),
+                   dc.get("snr_range", (0, 30)))
+
+    @staticmethod
+    def _read_zips(sources, data_path):
+        out = []
+        for src in sources:
+            zpath = os.path.join(data_path, src["wav"]) if data_path else src["wav"]
+            with zipfile.ZipFile(zpath) as z:
+                for m in sorted(m for m in z.namelist() if m.lower().endswith(".wav")):
+                    out.append(decode_wav(z.read(m))[0])
+        return out
+
+    def _on_device(self, kind, idx, device):
+        key = (kind, idx, str(device))
+        if key not in self._dev:
+            arr = (self.noises if kind == "n" else self.rirs)[idx]
+            self._dev[key] = (torch.from_numpy(np.ascontiguousarray(arr, np.float32)).to(device), int(np.argmax(arr)))
+        return self._dev[key]
+
+    def maybe_simulate(self, wav, device):
+        """wav: host float32 -> device tensor, simulated with probability simulation_prob (the draws use numpy's
+        global generator like the reference: data/sr_dataset.py:321-336)."""
+        x = torch.from_numpy(wav).to(device, non_blocking=True)
+        if np.random.random() > self.prob:
+            return x
+        noise = noise_rir = src_rir = None
+        delays = []
+        if self.noises:
+            noise = self._on_device("n", int(np.random.choice(len(self.noises))), device)[0]
+        if self.rirs:
+            picks = np.random.choice(len(self.rirs), 2 if noise is not None else 1, replace=len(self.rirs) < 2)
+            src_rir, d0 = self._on_device("r", int(picks[0]), device)
+            delays.append(d0)
+            if noise is not None:
+                noise_rir, d1 = self._on_device("r", int(picks[1]), device)
+                delays.append(d1)
+        y, _ = self.sim(x, [noise] if noise is not None else None, src_rir, [noise_rir] if noise_rir is not None else None,
+                        normalize_gain=self.gain_norm, rir_delays=delays or None)
+        return y
+
+
+def sequence_batches(source, batch_size, hours, device, simulation=None):
     """Whole-utterance minibatches until `hours` of audio have been drawn (the reference's sweep_size,
-    data/sr_dataset.py:226)."""
+    data/sr_dataset.py:226).  `simulation`: a SimulationPool, or None."""
     budget = hours * 3600.0
+    if simulation is None:
+        simulation = getattr(source, "simulation", None)
     while budget > 0:
         utts = [source.draw() for _ in range(batch_size)]
         lens = [u[0].shape[0] for u in utts]
-        wav = torch.from_numpy(np.concatenate([u[0] for u in utts])).to(device, non_blocking=True)
+        if simulation is not None:
+            wav = torch.cat([simulation.maybe_simulate(u[0], device) for u in utts])
+        else:
+            wav = torch.from_numpy(np.concatenate([u[0] for u in utts])).to(device, non_blocking=True)
         seconds = sum(lens) / 16000.0
         budget -= seconds
         yield dict(wav=wav, lens=lens, y=[u[1] for u in utts], aux=[u[2] for u in utts],

@@ -30,6 +30,20 @@ def waveform(rng, seconds, sr=16000):
     return y.astype(np.float32)
 
 
+def room_impulse_response(rng, sr=16000):
+    """A synthetic room impulse response: direct path after 2-8 ms, then Gaussian noise under an exponential
+    envelope with T60 in [0.1, 0.5] s (the range of the reference's reverb config, simulation/config.py:63-92),
+    cut where the envelope has fallen by 60 dB."""
+    t60 = float(rng.uniform(0.1, 0.5))
+    delay = int(rng.uniform(0.002, 0.008) * sr)
+    n_tail = int(t60 * sr)
+    r = np.zeros(delay + 1 + n_tail, np.float32)
+    r[delay] = 1.0
+    env = 10.0 ** (-3.0 * np.arange(n_tail) / n_tail)        # -60 dB at t60
+    r[delay + 1:] = (0.1 * rng.standard_normal(n_tail) * env).astype(np.float32)     # the direct path stays the peak
+    return r
+
+
 def num_fbank_frames(n_samples):
     """Frames produced by the reference extractor for an n_samples wav
     (reference simulation/freq_analysis.py:64-69 after data/sr_dataset.py:288

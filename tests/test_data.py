@@ -47,3 +47,18 @@ def test_synthetic_source_shapes():
     wav, lab, aux, utt = src.draw()
     assert wav.dtype == np.float32 and 1.3 * 16000 <= wav.shape[0] <= 34.9 * 16000 + 1
     assert lab.shape[0] == synth.num_fbank_frames(wav.shape[0]) and lab.max() < 6048 and aux is None
+
+
+def test_simulation_pool_from_config_switches():
+    from pykaldi2_amd import data
+    off = dict(data_config=dict(simulation_prob=0, use_dir_noise=True, use_reverb=True), synthetic=True)
+    assert data.SimulationPool.from_config(off) is None
+    assert data.SimulationPool.from_config(dict(data_config=dict(simulation_prob=0.5, use_dir_noise=False, use_reverb=False))) is None
+    assert data.make_source(off, 120).simulation is None
+    on = dict(data_config=dict(simulation_prob=0.7, use_dir_noise=True, use_reverb=True, gain_norm=True, snr_range=[5, 15]),
+              synthetic=True)
+    pool = data.SimulationPool.from_config(on, seed=1)
+    assert pool.prob == 0.7 and pool.gain_norm and len(pool.noises) == 8 and len(pool.rirs) == 16
+    assert all(r.dtype == np.float32 and np.argmax(r) >= 32 and r[np.argmax(r)] == 1.0 for r in pool.rirs)
+    only_rir = data.SimulationPool.from_config(dict(data_config=dict(simulation_prob=1, use_dir_noise=False, use_reverb=True), synthetic=True))
+    assert not only_rir.noises and only_rir.rirs and only_rir.sim.use_rir and not only_rir.sim.use_noise
