@@ -16,17 +16,18 @@
 
 namespace pk2 {
 
-constexpr int kSimThreads = 256;
+constexpr int kSimThreads = 128;
 constexpr int kSimOut = 4;                         // outputs per thread
-constexpr int kSimTile = kSimThreads * kSimOut;    // outputs per workgroup
-constexpr int kSimTaps = 256;                      // taps staged per pass
+constexpr int kSimTile = kSimThreads * kSimOut;    // outputs per workgroup: small, so that a 12 s utterance makes
+                                                   // more workgroups than the GPU has CUs and stagings overlap
+constexpr int kSimTaps = 1024;                     // taps staged per pass (4096 FMAs per thread between two barriers)
 
 // out[i] = sum_j rir[j] * wav[i + base - j]  (wav is zero outside [0, n))
 __global__ void __launch_bounds__(kSimThreads) sim_apply_rir_kernel(const float* __restrict__ wav, int64_t n,
                                                                     const float* __restrict__ rir, int k, int64_t base,
                                                                     float* __restrict__ out) {
-  __shared__ float s_rir[kSimTaps];
-  __shared__ float s_wav[kSimTile + kSimTaps];
+  __shared__ __attribute__((aligned(16))) float s_rir[kSimTaps];
+  __shared__ __attribute__((aligned(16))) float s_wav[kSimTile + kSimTaps];
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.x * kSimTile;
   float acc[kSimOut] = {0.f, 0.f, 0.f, 0.f};
@@ -35,25 +36,36 @@ __global__ void __launch_bounds__(kSimThreads) sim_apply_rir_kernel(const float*
     // taps j0 .. j0+nt-1 need wav[i0 + base - j0 - (nt-1) .. i0 + kSimTile - 1 + base - j0]
     const int64_t w0 = i0 + base - j0 - (kSimTaps - 1);
     __syncthreads();
-    s_rir[tid] = tid < nt ? rir[j0 + tid] : 0.f;
+    for (int q = tid; q < kSimTaps; q += kSimThreads) s_rir[q] = q < nt ? rir[j0 + q] : 0.f;
     for (int q = tid; q < kSimTile + kSimTaps; q += kSimThreads) {
       const int64_t w = w0 + q;
       s_wav[q] = (w >= 0 && w < n) ? wav[w] : 0.f;
     }
     __syncthreads();
-    // output o = tid + 256 r uses s_wav[o + (kSimTaps - 1) - jj] for tap j0 + jj
-#pragma unroll 8
-    for (int jj = 0; jj < kSimTaps; ++jj) {
-      const float h = s_rir[jj];
-      const int b = tid + (kSimTaps - 1) - jj;
+    // thread `tid` owns the 4 consecutive outputs o = 4 tid + r.  Tap j0 + jj of output o reads
+    // s_wav[o + (kSimTaps - 1) - jj]; for 4 taps jj0 .. jj0+3 the 4 outputs need the 7 samples
+    // e[0..6] = s_wav[4 tid + 252 - jj0 ...]: two aligned 16-byte LDS reads (conflict-free across lanes) plus one
+    // broadcast read of the taps feed 16 FMAs.
+#pragma unroll 4
+    for (int jj0 = 0; jj0 < kSimTaps; jj0 += 4) {
+      const float4 h = *reinterpret_cast<const float4*>(&s_rir[jj0]);
+      const float4 lo = *reinterpret_cast<const float4*>(&s_wav[4 * tid + (kSimTaps - 4) - jj0]);
+      const float4 hi = *reinterpret_cast<const float4*>(&s_wav[4 * tid + kSimTaps - jj0]);
+      const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const float ht[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
-      for (int r = 0; r < kSimOut; ++r) acc[r] = fmaf(h, s_wav[b + r * kSimThreads], acc[r]);
+      for (int r = 0; r < kSimOut; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[r] = fmaf(ht[t], e[r + 3 - t], acc[r]);
     }
   }
+  const int64_t i = i0 + 4 * tid;
+  if (i + 3 < n) {
+    *reinterpret_cast<float4*>(out + i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
 #pragma unroll
-  for (int r = 0; r < kSimOut; ++r) {
-    const int64_t i = i0 + tid + r * kSimThreads;
-    if (i < n) out[i] = acc[r];
+    for (int r = 0; r < kSimOut; ++r)
+      if (i + r < n) out[i + r] = acc[r];
   }
 }
 
