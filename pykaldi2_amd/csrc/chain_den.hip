@@ -97,6 +97,19 @@ struct DenParams {
   int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop, 4 = load half of the arc records
 };
 
+// Arc records are streamed once per launch; PK2_DEN_NT_ARCS loads them with the non-temporal hint so that they do
+// not displace the state vectors the gathers want in L2.
+#ifdef PK2_DEN_NT_ARCS
+__device__ __forceinline__ int4 pk2_nt_load(const int4* p) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+#define PK2_ARC_LD(p) pk2_nt_load(p)
+#else
+#define PK2_ARC_LD(p) (*(p))
+#endif
+
 #ifdef PK2_DEN_PROFILE
 // Phase timers of the state-x frame kernel (10 ns ticks of the constant-rate counter), workgroup 0 of each direction.
 __device__ unsigned long long g_den_prof[2][8];
@@ -666,7 +679,7 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   if (wb < wb1) {
     meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) rec[j] = p.fwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane];
+    for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.fwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)((p.debug & 1) ? 0 : rec[j].x) * NG, a[j]);
   }
@@ -766,7 +779,7 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   if (wb < wb1) {
     meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane];
+    for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.bwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
       const size_t gi = (p.debug & 1) ? 0 : rec[j].x;
