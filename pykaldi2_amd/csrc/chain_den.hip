@@ -100,10 +100,10 @@ struct DenParams {
 // Arc records are streamed once per launch; PK2_DEN_NT_ARCS loads them with the non-temporal hint so that they do
 // not displace the state vectors the gathers want in L2.
 #ifdef PK2_DEN_NT_ARCS
-__device__ __forceinline__ int4 pk2_nt_load(const int4* p) {
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
-  return make_int4(v.x, v.y, v.z, v.w);
+__device__ __forceinline__ int2 pk2_nt_load(const int2* p) {
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  const v2i v = __builtin_nontemporal_load(reinterpret_cast<const v2i*>(p));
+  return make_int2(v.x, v.y);
 }
 #define PK2_ARC_LD(p) pk2_nt_load(p)
 #else
@@ -673,13 +673,13 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
     for (int n = 0; n < NG; ++n) as[n] += v[n];
   }
   int wb = wb0 + w;
-  int4 rec[kK];
+  int2 rec[kK];      // {gathered state, arc probability}
   float a[kK][NG];
   uint32_t meta = 0;
   if (wb < wb1) {
     meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.fwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane]);
+    for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.fwd.arcs2[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)((p.debug & 1) ? 0 : rec[j].x) * NG, a[j]);
   }
@@ -700,9 +700,9 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
     for (int n = 0; n < NG; ++n) sum[n] = 0.f;
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
-      const float prob = __int_as_float(rec[j].z), pr = __int_as_float(rec[j].w);
+      const float prob = __int_as_float(rec[j].y);
 #pragma unroll
-      for (int n = 0; n < NG; ++n) sum[n] += a[j][n] * prob + lk[n] * pr;
+      for (int n = 0; n < NG; ++n) sum[n] += a[j][n] * prob;
       if ((mask >> j) & 1u) {
 #pragma unroll
         for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
@@ -713,7 +713,7 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
     if (wb < wb1) {
       meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-      for (int j = 0; j < kK; ++j) rec[j] = p.fwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+      for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.fwd.arcs2[((size_t)wb * kK + j) * 64 + lane]);
 #pragma unroll
       for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)rec[j].x * NG, a[j]);
     }
@@ -725,14 +725,16 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   const float* xd = p.beta + (frame + 1) * (size_t)p.S * (2 * NG) + NG;   // x[t, pdf(d)]
   const int row0 = p.fwd.row0[chunk];
   const bool atomic = p.fwd.atomic[chunk] != 0;
+  const float* leak = p.fwd.row_leak + p.fwd.slot0[chunk];     // sum of pi[src]*prob over this piece of the row
   float loc[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) loc[n] = 0.f;
   for (int r = tid; r < nrows; r += kDenThreads) {
     float v[NG], xv[NG];
     ldv<NG>(xd + (size_t)(row0 + r) * (2 * NG), xv);
+    const float lr = leak[r];
 #pragma unroll
-    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n] * xv[n] * inv_as[n]; loc[n] += v[n]; }
+    for (int n = 0; n < NG; ++n) { v[n] = (acc[r * NG + n] + lk[n] * lr) * xv[n] * inv_as[n]; loc[n] += v[n]; }
     float* o = alpha_n + (size_t)(row0 + r) * NG;
     if (atomic) {
 #pragma unroll
@@ -773,13 +775,13 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     for (int n = 0; n < NG; ++n) lB[n] += v[n];
   }
   int wb = wb0 + w;
-  int4 rec[kK];
+  int2 rec[kK];      // {gathered state, arc probability}
   float b[kK][NG], xv[kK][NG];
   uint32_t meta = 0;
   if (wb < wb1) {
     meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.bwd.arcs[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane]);
+    for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.bwd.arcs2[((size_t)wb * kK + ((p.debug & 4) ? (j & 3) : j)) * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
       const size_t gi = (p.debug & 1) ? 0 : rec[j].x;
@@ -810,7 +812,7 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     for (int n = 0; n < NG; ++n) sum[n] = 0.f;
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
-      const float prob = __int_as_float(rec[j].z);
+      const float prob = __int_as_float(rec[j].y);
 #pragma unroll
       for (int n = 0; n < NG; ++n) sum[n] += prob * xv[j][n] * (gat[n] ? b[j][n] * inv_c[n] + p.leaky : cst[n]);
       if ((mask >> j) & 1u) {
@@ -823,7 +825,7 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     if (wb < wb1) {
       meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
-      for (int j = 0; j < kK; ++j) rec[j] = p.bwd.arcs[((size_t)wb * kK + j) * 64 + lane];
+      for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.bwd.arcs2[((size_t)wb * kK + j) * 64 + lane]);
 #pragma unroll
       for (int j = 0; j < kK; ++j) {
         ldv<NG>(bx_n + (size_t)rec[j].x * (2 * NG), b[j]);

@@ -30,6 +30,7 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
     for (int64_t i = 0; i < A; ++i) perm[cur[key[i]]++] = i;
   }
   out->arcs.clear(); out->meta.clear(); out->wb_off.assign(1, 0);
+  out->arcs2.clear(); out->row_leak.clear(); out->slot0.clear();
   out->row0.clear(); out->nrows.clear(); out->atomic.clear();
 
   struct Piece { int row; int64_t lo, hi; };  // arcs [lo,hi) of sorted list belong to `row`
@@ -48,6 +49,17 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
     int nwb = (int)(padded / per_wb);
     size_t base_arc = out->arcs.size(), base_meta = out->meta.size();
     out->arcs.resize(base_arc + padded);
+    out->arcs2.resize(base_arc + padded);
+    // leaky-HMM term of a row: sum over its arcs of pi[src]*prob does not depend on the frame, so the state-x forward
+    // kernel adds it per row instead of carrying pi*prob in every arc record
+    const size_t base_slot = out->row_leak.size();
+    out->slot0.push_back((int32_t)base_slot);
+    {
+      std::vector<double> leak(nrows, 0.0);
+      for (size_t q = 0; q < idx.size(); ++q)
+        if (idx[q] >= 0) leak[lrow[q]] += (double)piprob[idx[q]];
+      for (int r = 0; r < nrows; ++r) out->row_leak.push_back((float)leak[r]);
+    }
     out->meta.resize(base_meta + (size_t)nwb * 64);
     for (int wb = 0; wb < nwb; ++wb) {
       for (int lane = 0; lane < 64; ++lane) {
@@ -72,6 +84,7 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
           if (j == 0) c0 = row_here;
           if (j == kK - 1 || row_next != row_here) mask |= (1u << j);
           out->arcs[base_arc + ((size_t)wb * kK + j) * 64 + lane] = rec;
+          out->arcs2[base_arc + ((size_t)wb * kK + j) * 64 + lane] = make_int2(rec.x, rec.z);
         }
         out->meta[base_meta + (size_t)wb * 64 + lane] = (uint32_t)c0 | (mask << 16);
       }
@@ -177,6 +190,9 @@ static int upload_vec(pk2_den_graph* g, const std::vector<T>& v, const T** dptr)
 static int upload_ordering(pk2_den_graph* g, const HostOrdering& h, DevOrdering* d) {
   int rc;
   if ((rc = upload_vec(g, h.arcs, &d->arcs))) return rc;
+  if ((rc = upload_vec(g, h.arcs2, &d->arcs2))) return rc;
+  if ((rc = upload_vec(g, h.row_leak, &d->row_leak))) return rc;
+  if ((rc = upload_vec(g, h.slot0, &d->slot0))) return rc;
   if ((rc = upload_vec(g, h.meta, &d->meta))) return rc;
   if ((rc = upload_vec(g, h.wb_off, &d->wb_off))) return rc;
   if ((rc = upload_vec(g, h.row0, &d->row0))) return rc;

@@ -34,6 +34,9 @@ constexpr int kDenBwdThreads = 2 * kDenThreads;    // backward: a beta chunk and
 
 struct HostOrdering {
   std::vector<int4> arcs;        // {a, b, prob bits, pi*prob bits}
+  std::vector<int2> arcs2;       // {a, prob bits}: the 8-byte records of the state-x kernels, same positions as `arcs`
+  std::vector<float> row_leak;   // [sum of nrows]: sum of pi[src]*prob over the arcs of a (chunk, row) piece
+  std::vector<int32_t> slot0;    // [n_chunks]: first row_leak slot of the chunk
   std::vector<uint32_t> meta;    // per lane of each wave block
   std::vector<int32_t> wb_off;   // [n_chunks+1]
   std::vector<int32_t> row0;     // [n_chunks]
@@ -44,6 +47,9 @@ struct HostOrdering {
 
 struct DevOrdering {
   const int4* arcs = nullptr;
+  const int2* arcs2 = nullptr;
+  const float* row_leak = nullptr;
+  const int32_t* slot0 = nullptr;
   const uint32_t* meta = nullptr;
   const int32_t* wb_off = nullptr;
   const int32_t* row0 = nullptr;
