@@ -82,7 +82,8 @@ class DenominatorGraph:
         _lib.check(L.pk2_den_graph_debug_ordering(self._h, which, C.byref(na), C.byref(nc), None, None,
                                                   None, None, None, None))
         arcs = np.empty((na.value, 4), dtype=np.int32)
-        meta = np.empty(na.value // 8, dtype=np.uint32)
+        k = int(L.pk2_den_graph_arcs_per_lane())
+        meta = np.empty((na.value // k, 2), dtype=np.uint32)      # per lane {first chunk-local row, flush mask}
         wb_off = np.empty(nc.value + 1, dtype=np.int32)
         row0 = np.empty(nc.value, dtype=np.int32)
         nrows = np.empty(nc.value, dtype=np.int32)
@@ -90,7 +91,7 @@ class DenominatorGraph:
         _lib.check(L.pk2_den_graph_debug_ordering(self._h, which, None, None, _lib.ptr(arcs), _lib.ptr(meta),
                                                   _lib.ptr(wb_off), _lib.ptr(row0), _lib.ptr(nrows),
                                                   _lib.ptr(atomic)))
-        return dict(arcs=arcs, meta=meta, wb_off=wb_off, row0=row0, nrows=nrows, atomic=atomic)
+        return dict(arcs=arcs, meta=meta, wb_off=wb_off, row0=row0, nrows=nrows, atomic=atomic, arcs_per_lane=k)
 
     def __del__(self):
         try:

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(kDenThreads) den_fwd_step(const DenParams* __r
   int wb = wb0 + w;
   int4 rec[kK];
   float a[kK][NG];
-  uint32_t meta = 0;
+  uint2 meta = make_uint2(0u, 0u);
   if (wb < wb1) {
     meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
@@ -253,8 +253,8 @@ __global__ void __launch_bounds__(kDenThreads) den_fwd_step(const DenParams* __r
 
   // ---- arcs: acc[dst-row] += (alpha[src]*prob + leaky*asum*pi[src]*prob) * x[pdf] ---------
   while (wb < wb1) {
-    int c = meta & 0xffffu;
-    const uint32_t mask = meta >> 16;
+    int c = (int)meta.x;
+    const uint32_t mask = meta.y;
     float sum[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) sum[n] = 0.f;
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   int wb = wb0 + wh;
   int4 rec[KG];
   float av[KG][NG], bv[KG][NG];
-  uint32_t meta = 0;
+  uint2 meta = make_uint2(0u, 0u);
   auto fetch = [&](int jg) {
 #pragma unroll
     for (int j = 0; j < KG; ++j) rec[j] = ord.arcs[((size_t)wb * kK + jg * KG + j) * 64 + lane];
@@ -420,8 +420,8 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
 
   // ---- arcs ---------------------------------------------------------------------------------
   while (wb < wb1) {
-    int c = meta & 0xffffu;
-    const uint32_t mask = meta >> 16;
+    int c = (int)meta.x;
+    const uint32_t mask = meta.y;
     float sum[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) sum[n] = 0.f;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   int wb = wb0 + w;
   int2 rec[kK];      // {gathered state, arc probability}
   float a[kK][NG];
-  uint32_t meta = 0;
+  uint2 meta = make_uint2(0u, 0u);
   if (wb < wb1) {
     meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
@@ -693,8 +693,8 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   for (int n = 0; n < NG; ++n) { lk[n] = p.leaky * as[n]; inv_as[n] = 1.0f / as[n]; }
   if (p.debug & 2) wb = wb1;
   while (wb < wb1) {
-    int c = meta & 0xffffu;
-    const uint32_t mask = meta >> 16;
+    int c = (int)meta.x;
+    const uint32_t mask = meta.y;
     float sum[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) sum[n] = 0.f;
@@ -777,7 +777,7 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   int wb = wb0 + w;
   int2 rec[kK];      // {gathered state, arc probability}
   float b[kK][NG], xv[kK][NG];
-  uint32_t meta = 0;
+  uint2 meta = make_uint2(0u, 0u);
   if (wb < wb1) {
     meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
@@ -805,8 +805,8 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
   while (wb < wb1) {
-    int c = meta & 0xffffu;
-    const uint32_t mask = meta >> 16;
+    int c = (int)meta.x;
+    const uint32_t mask = meta.y;
     float sum[NG];
 #pragma unroll
     for (int n = 0; n < NG; ++n) sum[n] = 0.f;

@@ -86,7 +86,7 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
           out->arcs[base_arc + ((size_t)wb * kK + j) * 64 + lane] = rec;
           out->arcs2[base_arc + ((size_t)wb * kK + j) * 64 + lane] = make_int2(rec.x, rec.z);
         }
-        out->meta[base_meta + (size_t)wb * 64 + lane] = (uint32_t)c0 | (mask << 16);
+        out->meta[base_meta + (size_t)wb * 64 + lane] = make_uint2((uint32_t)c0, mask);
       }
     }
     out->wb_off.push_back(out->wb_off.back() + nwb);
@@ -276,8 +276,11 @@ extern "C" int pk2_den_graph_initial_probs(const pk2_den_graph* g, float* host_o
   return PK2_OK;
 }
 
+// Test hook: arcs per lane of a wave block (kK), needed to decode the orderings below.
+extern "C" int32_t pk2_den_graph_arcs_per_lane(void) { return kK; }
+
 // Test hook: copies one host-side ordering out (which: 0 = by dst, 1 = by src, 2 = by pdf).
-// Sizes are queried by passing null buffers.
+// Sizes are queried by passing null buffers.  meta_out receives two uint32 per lane: {first row, flush mask}.
 extern "C" int pk2_den_graph_debug_ordering(const pk2_den_graph* g, int which, int64_t* n_arcs_padded,
                                             int32_t* n_chunks, int32_t* arcs_out /* int4 */,
                                             uint32_t* meta_out, int32_t* wb_off_out,
@@ -288,7 +291,7 @@ extern "C" int pk2_den_graph_debug_ordering(const pk2_den_graph* g, int which, i
   if (n_arcs_padded) *n_arcs_padded = (int64_t)h.arcs.size();
   if (n_chunks) *n_chunks = h.n_chunks;
   if (arcs_out) memcpy(arcs_out, h.arcs.data(), h.arcs.size() * sizeof(int4));
-  if (meta_out) memcpy(meta_out, h.meta.data(), h.meta.size() * sizeof(uint32_t));
+  if (meta_out) memcpy(meta_out, h.meta.data(), h.meta.size() * sizeof(uint2));
   if (wb_off_out) memcpy(wb_off_out, h.wb_off.data(), h.wb_off.size() * sizeof(int32_t));
   if (row0_out) memcpy(row0_out, h.row0.data(), h.row0.size() * sizeof(int32_t));
   if (nrows_out) memcpy(nrows_out, h.nrows.data(), h.nrows.size() * sizeof(int32_t));

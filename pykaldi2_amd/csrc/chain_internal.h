@@ -15,17 +15,18 @@ namespace pk2 {
 //    wave block owns kK consecutive sorted arcs, stored interleaved so that
 //    iteration j of all 64 lanes is one coalesced 1 KiB load:
 //        arcs[(wb*kK + j)*64 + lane]  <->  sorted arc  wb*64*kK + lane*kK + j
-//  * meta[wb*64+lane] = c0 | (mask << 16): c0 = chunk-local row of the lane's
+//  * meta[wb*64+lane] = {c0, mask}: c0 = chunk-local row of the lane's
 //    first arc, bit j of mask = "flush the running sum into row c after arc j,
-//    then c++" (set where a row ends and at j = kK-1).
+//    then c++" (set where a row ends and at j = kK-1); kK <= 32.
 // (the three tuning constants can be overridden at build time: -DPK2_DEN_K=.. -DPK2_DEN_CHUNK=.. for experiments)
 #ifndef PK2_DEN_K
-#define PK2_DEN_K 8
+#define PK2_DEN_K 16     // 8-byte arc records leave the registers for 16 gathers in flight per lane
 #endif
 #ifndef PK2_DEN_CHUNK
 #define PK2_DEN_CHUNK 4096
 #endif
 constexpr int kK = PK2_DEN_K;
+static_assert(kK >= 1 && kK <= 32, "the flush mask of a lane has 32 bits");
 constexpr int kChunkArcs = PK2_DEN_CHUNK;
 constexpr int kMaxRows = 1024;
 constexpr int kDenWaves = kChunkArcs / (64 * kK);  // wavefronts working on one chunk (one wave block each)
@@ -37,7 +38,7 @@ struct HostOrdering {
   std::vector<int2> arcs2;       // {a, prob bits}: the 8-byte records of the state-x kernels, same positions as `arcs`
   std::vector<float> row_leak;   // [sum of nrows]: sum of pi[src]*prob over the arcs of a (chunk, row) piece
   std::vector<int32_t> slot0;    // [n_chunks]: first row_leak slot of the chunk
-  std::vector<uint32_t> meta;    // per lane of each wave block
+  std::vector<uint2> meta;       // per lane of each wave block
   std::vector<int32_t> wb_off;   // [n_chunks+1]
   std::vector<int32_t> row0;     // [n_chunks]
   std::vector<int32_t> nrows;    // [n_chunks]
@@ -50,7 +51,7 @@ struct DevOrdering {
   const int2* arcs2 = nullptr;
   const float* row_leak = nullptr;
   const int32_t* slot0 = nullptr;
-  const uint32_t* meta = nullptr;
+  const uint2* meta = nullptr;
   const int32_t* wb_off = nullptr;
   const int32_t* row0 = nullptr;
   const int32_t* nrows = nullptr;

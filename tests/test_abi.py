@@ -39,20 +39,17 @@ def test_bad_arguments_fail_loudly():
         _lib.check(rc)
 
 
-K = 8
-
-
 def _emulate(o, nrows_total, val):
     """numpy model of the kernels' lane-run segmented reduction over one ordering."""
     out = np.zeros(nrows_total)
-    arcs, meta = o["arcs"], o["meta"]
+    arcs, meta, K = o["arcs"], o["meta"], o["arcs_per_lane"]
     f32 = lambda col: arcs[:, col].copy().view(np.float32).astype(np.float64)
     v = val(arcs[:, 0], arcs[:, 1], f32(2), f32(3))
     for ch in range(len(o["row0"])):
         acc = np.zeros(o["nrows"][ch])
         for wb in range(o["wb_off"][ch], o["wb_off"][ch + 1]):
             for lane in range(64):
-                m = int(meta[wb * 64 + lane]); c = m & 0xffff; mask = m >> 16
+                c, mask = int(meta[wb * 64 + lane, 0]), int(meta[wb * 64 + lane, 1])
                 s = 0.0
                 for j in range(K):
                     s += v[(wb * K + j) * 64 + lane]
