@@ -613,7 +613,8 @@ __global__ void __launch_bounds__(256) den_gamma_states_num(DenParams p, const f
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < p.Tmax) { den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y); return; }
   const int n = (int)blockIdx.x - p.Tmax;
-  if (blockIdx.y == 0 && n < n_seq) num_fwd_bwd_body(np, n, smem);
+  if (threadIdx.x >= 64) return;      // one wave per supervision (chain_num.h)
+  if (blockIdx.y == 0 && n < n_seq) num_fwd_bwd_body<64>(np, n, smem);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -8,19 +8,26 @@ namespace pk2 {
 
 constexpr int kNumThreads = 256;
 
+template <int THREADS>
 __device__ __forceinline__ float block_sum_f(float v, float* red) {
   v = wave_sum(v);
-  __syncthreads();
+  __syncthreads();      // (with one wave this also orders the frame's LDS atomics before the next frame's reads)
+  if (THREADS == 64) return v;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < kNumThreads / 64; ++k) s += red[k];
+  for (int k = 0; k < THREADS / 64; ++k) s += red[k];
   return s;
 }
 
-// Numerator forward-backward of sequence n by the calling workgroup (kNumThreads threads); smem: 2 * states + 8 floats.
+// Numerator forward-backward of sequence n by the first THREADS threads of the calling workgroup (the others must
+// have left the kernel); smem: 2 * states + 8 floats.  A chain supervision has only a few arcs per frame, so the
+// recursion is a chain of ~2T tiny dependent steps: with THREADS = 64 (one wave) a frame costs a wave reduction and
+// a barrier that no other wave has to reach, instead of two 4-wave barriers.
+template <int THREADS = kNumThreads>
 __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, float* smem) {
+  constexpr int kNumThreads = THREADS;
   const int tid = threadIdx.x;
   const int32_t* info = p.seqinfo + n * 8;
   const int fbase = info[0], T = info[1], ns = info[2], flo = info[3], fhi = info[4];
@@ -44,7 +51,7 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
       atomicAdd(&al[p.arc_dst[a]], v);
       z += v;
     }
-    z = block_sum_f(z, red);  // (also orders the LDS atomics before the next frame's reads)
+    z = block_sum_f<THREADS>(z, red);  // (also orders the LDS atomics before the next frame's reads)
     logp += (double)m + log((double)z);
     inv_prev = 1.f / z;
   }
@@ -56,7 +63,7 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
     zf += al[s] * inv_prev * e;
     be[s] = e;
   }
-  zf = block_sum_f(zf, red);
+  zf = block_sum_f<THREADS>(zf, red);
   logp += log((double)zf);
   if (tid == 0) p.num_lp[n] = (float)logp;
 
@@ -78,8 +85,8 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
       ++na;
       zq += qq; zb += u;
     }
-    zq = block_sum_f(zq, red);
-    zb = block_sum_f(zb, red);
+    zq = block_sum_f<THREADS>(zq, red);
+    zb = block_sum_f<THREADS>(zb, red);
     const float inv_q = p.scale / zq;
     int k = 0;
     for (int a = lo + tid; a < hi; a += kNumThreads, ++k) {
