@@ -599,22 +599,84 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
   }
 }
 
+// The same sums with the states walked IN ORDER (coalesced alpha / beta rows at streaming speed instead of two
+// dependent gathers per state through the pdf -> states lists) and one row of P x NG occupancies accumulated in LDS
+// with ds_add_f32 (97 KB for P = 6048, NG = 4); used whenever that row fits.
+constexpr int kGammaThreads = 512;
+constexpr size_t kGammaMaxLds = 144 * 1024;
+template <int NG>
+__device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, const float* csum, const float* Kf, int t, int g,
+                                                          float* acc) {
+  const int tid = threadIdx.x;
+  const size_t frame = (size_t)g * (p.Tmax + 1) + t;
+  float cv[NG], kv[NG], inv_c[NG], cst[NG];
+  bool gat[NG];
+  ldv<NG>(csum + (frame + 1) * NG, cv);
+  ldv<NG>(Kf + (frame + 1) * NG, kv);
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int T = p.lengths[g * NG + n];
+    gat[n] = (t + 1) < T;
+    inv_c[n] = (gat[n] && cv[n] > 0.f) ? 1.0f / cv[n] : 0.f;
+    cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
+  }
+  for (int i = tid; i < p.P * NG; i += kGammaThreads) acc[i] = 0.f;
+  __syncthreads();
+  const float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * (2 * NG);   // {btilde'[NG], xd[NG]} per state
+  for (int s0 = tid; s0 < p.S; s0 += 4 * kGammaThreads) {
+    float a[4][NG], b[4][NG]; int pdf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s = s0 + q * kGammaThreads;
+      pdf[q] = -1;
+      if (s < p.S) {
+        pdf[q] = p.state_pdf[s];
+        ldv<NG>(alpha_n + (size_t)s * NG, a[q]);
+        ldv<NG>(beta_n + (size_t)s * (2 * NG), b[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (pdf[q] < 0) continue;
+#pragma unroll
+      for (int n = 0; n < NG; ++n) atomicAdd(&acc[pdf[q] * NG + n], a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + p.leaky : cst[n]));
+    }
+  }
+  __syncthreads();
+  float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
+  for (int i = tid; i < p.P * NG; i += kGammaThreads) gam_t[i] = acc[i] * kv[i % NG];
+}
+
 template <int NG>
 __global__ void __launch_bounds__(256) den_gamma_states(DenParams p, const float* csum, const float* Kf) {
   den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y);
 }
 
+template <int NG>
+__global__ void __launch_bounds__(kGammaThreads) den_gamma_states_lds(DenParams p, const float* csum, const float* Kf) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  den_gamma_states_lds_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y, smem);
+}
+
 // The same launch also carries the numerator: workgroups x >= Tmax of group 0 run the forward-backward of one
 // supervision FST each (chain_num.h).  The numerator is a ~1 ms latency-bound job of one workgroup per sequence;
-// here it overlaps the occupancy pass instead of holding the stream alone.
-template <int NG>
-__global__ void __launch_bounds__(256) den_gamma_states_num(DenParams p, const float* csum, const float* Kf, NumParams np,
-                                                            int n_seq) {
+// here it overlaps the occupancy pass instead of holding the stream alone.  LDS: the occupancy row, or (numerator
+// workgroups) 2 * states + 8 floats.
+template <int NG, bool LDS_ROW>
+__global__ void __launch_bounds__(LDS_ROW ? kGammaThreads : 256) den_gamma_states_num(DenParams p, const float* csum, const float* Kf,
+                                                                                     NumParams np, int n_seq, int stage) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < p.Tmax) { den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y); return; }
+  if ((int)blockIdx.x < p.Tmax) {
+    if (LDS_ROW) den_gamma_states_lds_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y, smem);
+    else den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y);
+    return;
+  }
   const int n = (int)blockIdx.x - p.Tmax;
   if (threadIdx.x >= 64) return;      // one wave per supervision (chain_num.h)
-  if (blockIdx.y == 0 && n < n_seq) num_fwd_bwd_body<64>(np, n, smem);
+  if (blockIdx.y != 0 || n >= n_seq) return;
+  if (stage) num_fwd_bwd_body<64, true>(np, n, smem);
+  else num_fwd_bwd_body<64, false>(np, n, smem);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1067,15 +1129,27 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
     hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
     hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
+    const size_t row_lds = (size_t)g->P * NG * sizeof(float);
+    const bool lds_row = row_lds <= kGammaMaxLds && !getenv("PK2_DEN_GAMMA_GATHER");
+    static bool attr_n[8] = {false};
+    if (!attr_n[NG]) {
+      PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_gamma_states_num<NG, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_gamma_states_num<NG, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_gamma_states_lds<NG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_n[NG] = true;
+    }
     if (tail && tail->valid) {
-      static bool attr_n[8] = {false};
-      if (!attr_n[NG]) {
-        PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_gamma_states_num<NG>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_n[NG] = true;
-      }
-      hipLaunchKernelGGL(den_gamma_states_num<NG>, dim3(Tmax + tail->N, G), dim3(256), tail->lds, stream, p, b.csum,
-                         b.kscale, tail->p, tail->N);
+      if (lds_row && std::max(row_lds, (size_t)tail->lds) <= kGammaMaxLds)
+        hipLaunchKernelGGL((den_gamma_states_num<NG, true>), dim3(Tmax + tail->N, G), dim3(kGammaThreads),
+                           std::max(row_lds, (size_t)tail->lds), stream, p, b.csum, b.kscale, tail->p, tail->N, tail->stage ? 1 : 0);
+      else
+        hipLaunchKernelGGL((den_gamma_states_num<NG, false>), dim3(Tmax + tail->N, G), dim3(256), tail->lds, stream, p, b.csum,
+                           b.kscale, tail->p, tail->N, tail->stage ? 1 : 0);
+    } else if (lds_row) {
+      hipLaunchKernelGGL(den_gamma_states_lds<NG>, dim3(Tmax, G), dim3(kGammaThreads), row_lds, stream, p, b.csum, b.kscale);
     } else {
       hipLaunchKernelGGL(den_gamma_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, p, b.csum, b.kscale);
     }

@@ -138,7 +138,7 @@ struct NumParams {
 };
 
 // A numerator whose forward-backward launch has been handed to the denominator (see chain_num.h).
-struct NumDeferred { NumParams p; size_t lds = 0; int N = 0; bool valid = false; };
+struct NumDeferred { NumParams p; size_t lds = 0; int N = 0; bool valid = false; bool stage = false; };
 int num_launch_deferred(const NumDeferred& d, hipStream_t stream);
 
 struct NumBuffers {

@@ -25,7 +25,7 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {
 // have left the kernel); smem: 2 * states + 8 floats.  A chain supervision has only a few arcs per frame, so the
 // recursion is a chain of ~2T tiny dependent steps: with THREADS = 64 (one wave) a frame costs a wave reduction and
 // a barrier that no other wave has to reach, instead of two 4-wave barriers.
-template <int THREADS = kNumThreads>
+template <int THREADS = kNumThreads, bool STAGE = false>
 __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, float* smem) {
   constexpr int kNumThreads = THREADS;
   const int tid = threadIdx.x;
@@ -33,22 +33,45 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
   const int fbase = info[0], T = info[1], ns = info[2], flo = info[3], fhi = info[4];
   float* al = smem;        // [ns] alpha, each frame's states carry that frame's (unknown) scale
   float* be = smem + ns;   // [ns]
-  float* red = be + ns;    // [4]
+  float* red = be + ns;    // [8]
   for (int i = tid; i < 2 * ns; i += kNumThreads) smem[i] = 0.f;
+  // STAGE: the sequence's frame table and arc arrays are copied into LDS first (one coalesced burst): inside the
+  // recursion every global load would put ~1 us of latency into each of the 2T dependent frame steps.
+  const int a0 = p.frame_off[fbase];
+  int32_t* s_foff = reinterpret_cast<int32_t*>(red + 8);          // [T+1] relative to a0
+  float* s_fmax = reinterpret_cast<float*>(s_foff + T + 1);       // [T]
+  const int na = STAGE ? p.frame_off[fbase + T] - a0 : 0;
+  int32_t* s_src = reinterpret_cast<int32_t*>(s_fmax + T);        // [na]
+  int32_t* s_dst = s_src + na;
+  int32_t* s_pdf = s_dst + na;
+  float* s_score = reinterpret_cast<float*>(s_pdf + na);
+  const float* fmax_g = p.frame_max + (fbase - n);
+  if (STAGE) {
+    for (int t = tid; t <= T; t += kNumThreads) s_foff[t] = p.frame_off[fbase + t] - a0;
+    for (int t = tid; t < T; t += kNumThreads) s_fmax[t] = fmax_g[t];
+    for (int a = tid; a < na; a += kNumThreads) {
+      s_src[a] = p.arc_src[a0 + a]; s_dst[a] = p.arc_dst[a0 + a]; s_pdf[a] = p.arc_pdf[a0 + a]; s_score[a] = p.score[a0 + a];
+    }
+  }
+  auto FOFF = [&](int t) { return STAGE ? s_foff[t] : p.frame_off[fbase + t]; };
+  auto FMAX = [&](int t) { return STAGE ? s_fmax[t] : fmax_g[t]; };
+  auto SRC = [&](int a) { return STAGE ? s_src[a] : p.arc_src[a]; };
+  auto DST = [&](int a) { return STAGE ? s_dst[a] : p.arc_dst[a]; };
+  auto PDF = [&](int a) { return STAGE ? s_pdf[a] : p.arc_pdf[a]; };
+  auto SCORE = [&](int a) { return STAGE ? s_score[a] : p.score[a]; };
   __syncthreads();
   if (tid == 0) al[0] = 1.f;
   __syncthreads();
 
-  const float* fmax = p.frame_max + (fbase - n);
   double logp = 0.0;
   float inv_prev = 1.f;
   for (int t = 0; t < T; ++t) {
-    const int lo = p.frame_off[fbase + t], hi = p.frame_off[fbase + t + 1];
-    const float m = fmax[t];
+    const int lo = FOFF(t), hi = FOFF(t + 1);
+    const float m = FMAX(t);
     float z = 0.f;
     for (int a = lo + tid; a < hi; a += kNumThreads) {
-      const float v = al[p.arc_src[a]] * inv_prev * expf(p.score[a] - m);
-      atomicAdd(&al[p.arc_dst[a]], v);
+      const float v = al[SRC(a)] * inv_prev * expf(SCORE(a) - m);
+      atomicAdd(&al[DST(a)], v);
       z += v;
     }
     z = block_sum_f<THREADS>(z, red);  // (also orders the LDS atomics before the next frame's reads)
@@ -71,18 +94,18 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
   float* grow = p.grad + (int64_t)n * p.gseq_stride;
   inv_prev = 1.f;
   for (int t = T - 1; t >= 0; --t) {
-    const int lo = p.frame_off[fbase + t], hi = p.frame_off[fbase + t + 1];
-    const float m = fmax[t];
+    const int lo = FOFF(t), hi = FOFF(t + 1);
+    const float m = FMAX(t);
     float zq = 0.f, zb = 0.f;
     // a frame holds at most a few arcs per thread; keep the products in registers
-    float q[4]; int na = 0;
+    float q[4]; int na_t = 0;
     for (int a = lo + tid; a < hi; a += kNumThreads) {
-      const int s = p.arc_src[a];
-      const float u = expf(p.score[a] - m) * be[p.arc_dst[a]] * inv_prev;
+      const int s = SRC(a);
+      const float u = expf(SCORE(a) - m) * be[DST(a)] * inv_prev;
       atomicAdd(&be[s], u);
       const float qq = al[s] * u;
-      if (na < 4) q[na] = qq;
-      ++na;
+      if (na_t < 4) q[na_t] = qq;
+      ++na_t;
       zq += qq; zb += u;
     }
     zq = block_sum_f<THREADS>(zq, red);
@@ -93,11 +116,11 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
       float qq;
       if (k < 4) {
         qq = q[k];
-      } else {  // > 1024 arcs in one frame: recompute (beta of the source is final by now,
+      } else {  // > 4 * THREADS arcs in one frame: recompute (beta of the source is final by now,
                 // so rebuild u from the destination side)
-        qq = al[p.arc_src[a]] * expf(p.score[a] - m) * be[p.arc_dst[a]] * inv_prev;
+        qq = al[SRC(a)] * expf(SCORE(a) - m) * be[DST(a)] * inv_prev;
       }
-      atomicAdd(grow + (int64_t)t * p.gframe_stride + p.arc_pdf[a], qq * inv_q);
+      atomicAdd(grow + (int64_t)t * p.gframe_stride + PDF(a), qq * inv_q);
     }
     inv_prev = 1.f / zb;
   }

@@ -44,9 +44,10 @@ __global__ void __launch_bounds__(kNumThreads) num_scores(NumParams p, int64_t f
   }
 }
 
-__global__ void __launch_bounds__(kNumThreads) num_fwd_bwd(NumParams p) {
+__global__ void __launch_bounds__(kNumThreads) num_fwd_bwd(NumParams p, int stage) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  num_fwd_bwd_body(p, blockIdx.x, smem);
+  if (stage) num_fwd_bwd_body<kNumThreads, true>(p, blockIdx.x, smem);
+  else num_fwd_bwd_body<kNumThreads, false>(p, blockIdx.x, smem);
 }
 
 size_t num_workspace(int N, int64_t total_arcs, int64_t total_frames, NumBuffers* buf, void* base) {
@@ -102,7 +103,12 @@ int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride
   p.score = buf.score; p.frame_max = buf.frame_max; p.num_lp = buf.num_lp;
   p.grad = grad; p.gseq_stride = gseq_stride; p.gframe_stride = gframe_stride;
   p.scale = scale;
-  const size_t lds = ((size_t)2 * max_states + 8) * sizeof(float);
+  // LDS: alpha, beta, reduction scratch; plus, when it fits, the sequence's frame table and arc arrays (bounded here
+  // by the batch totals: the per-sequence counts live on the device)
+  size_t lds = ((size_t)2 * max_states + 8) * sizeof(float);
+  const size_t staged = lds + ((size_t)2 * Tmax + 2 + 4 * (size_t)nb->total_arcs) * sizeof(float);
+  const bool stage = staged <= 128 * 1024;
+  if (stage) lds = staged;
   static bool attr_set = false;
   if (!attr_set) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&num_fwd_bwd),
@@ -112,17 +118,17 @@ int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride
   const int blocks_x = std::max(1, std::min(64, (Tmax + 3) / 4));
   hipLaunchKernelGGL(num_scores, dim3(blocks_x, N), dim3(kNumThreads), 0, stream, p, (int64_t)0);
   if (defer) {   // the caller launches the forward-backward together with the denominator's occupancy kernel
-    defer->p = p; defer->lds = lds; defer->N = N; defer->valid = true;
+    defer->p = p; defer->lds = lds; defer->N = N; defer->valid = true; defer->stage = stage;
     PK2_LAUNCH_CHECK();
     return PK2_OK;
   }
-  hipLaunchKernelGGL(num_fwd_bwd, dim3(N), dim3(kNumThreads), lds, stream, p);
+  hipLaunchKernelGGL(num_fwd_bwd, dim3(N), dim3(kNumThreads), lds, stream, p, stage ? 1 : 0);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
 
 int num_launch_deferred(const NumDeferred& d, hipStream_t stream) {
-  hipLaunchKernelGGL(num_fwd_bwd, dim3(d.N), dim3(kNumThreads), d.lds, stream, d.p);
+  hipLaunchKernelGGL(num_fwd_bwd, dim3(d.N), dim3(kNumThreads), d.lds, stream, d.p, d.stage ? 1 : 0);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
