@@ -702,17 +702,33 @@ __global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ 
     live[n] = t < lengths[seq];
     rows[n] = logits + (int64_t)seq * seq_stride + (int64_t)t * frame_stride;
   }
-  float* out = bx + ((size_t)g * (Tmax + 1) + t + 1) * (size_t)S * (2 * NG) + NG;
-  for (int d = threadIdx.x; d < S; d += 256) {
-    const int pdf = state_pdf[d];
-    float v[NG];
+  // The whole {btilde', x} record of a state is written (btilde' = 0 until the backward frame fills it): full 32-byte
+  // records coalesce into whole lines, the x halves alone are partial-line writes.  Four states per thread and pass
+  // keep the 4 x NG row gathers of each in flight together.
+  float* out = bx + ((size_t)g * (Tmax + 1) + t + 1) * (size_t)S * (2 * NG);
+  for (int d0 = threadIdx.x; d0 < S; d0 += 4 * 256) {
+    int pdf[4]; float x[4][NG];
 #pragma unroll
-    for (int n = 0; n < NG; ++n) {
-      float x = (live[n] && pdf >= 0) ? rows[n][pdf] : 0.f;
-      x = x < -30.f ? -30.f : (x > 30.f ? 30.f : x);   // keeps NaN (see den_exp_transpose)
-      v[n] = (live[n] && pdf >= 0) ? expf(x) : 1.0f;
+    for (int q = 0; q < 4; ++q) pdf[q] = d0 + q * 256 < S ? state_pdf[d0 + q * 256] : -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < NG; ++n) x[q][n] = (live[n] && pdf[q] >= 0) ? rows[n][pdf[q]] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = d0 + q * 256;
+      if (d >= S) continue;
+      float v[NG], zero[NG];
+#pragma unroll
+      for (int n = 0; n < NG; ++n) {
+        float xx = x[q][n];
+        xx = xx < -30.f ? -30.f : (xx > 30.f ? 30.f : xx);   // keeps NaN (see den_exp_transpose)
+        v[n] = (live[n] && pdf[q] >= 0) ? expf(xx) : 1.0f;
+        zero[n] = 0.f;
+      }
+      stv<NG>(out + (size_t)d * (2 * NG), zero);
+      stv<NG>(out + (size_t)d * (2 * NG) + NG, v);
     }
-    stv<NG>(out + (size_t)d * (2 * NG), v);
   }
 }
 
