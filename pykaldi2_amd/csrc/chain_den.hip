@@ -673,10 +673,14 @@ __global__ void __launch_bounds__(LDS_ROW ? kGammaThreads : 256) den_gamma_state
     return;
   }
   const int n = (int)blockIdx.x - p.Tmax;
-  if (threadIdx.x >= 64) return;      // one wave per supervision (chain_num.h)
   if (blockIdx.y != 0 || n >= n_seq) return;
-  if (stage) num_fwd_bwd_body<64, true>(np, n, smem);
-  else num_fwd_bwd_body<64, false>(np, n, smem);
+  if (stage) {                         // alpha and beta chains on one wave each (chain_num.h)
+    if (threadIdx.x >= 128) return;
+    num_fwd_bwd_two_waves(np, n, smem);
+  } else {
+    if (threadIdx.x >= 64) return;     // one wave per supervision
+    num_fwd_bwd_body<64, false>(np, n, smem);
+  }
 }
 
 // ----------------------------------------------------------------------------------------

@@ -126,4 +126,88 @@ __device__ __forceinline__ void num_fwd_bwd_body(const NumParams& p, int n, floa
   }
 }
 
+// Two-wave variant of the staged recursion (threads 0..127 of the calling workgroup; the others must have left):
+// the alpha chain (wave 0) and the beta chain (wave 1) do not depend on each other -- only the posteriors need
+// both -- so they run side by side, each ordered by the in-order LDS pipeline of its own wave (no workgroup barrier
+// inside the 2T frame steps), and the posteriors are formed afterwards, a frame per thread, from alpha and the
+// per-arc backward factors kept in LDS.  smem: 2 * states + 8 + (2T + 1) + 5 * arcs floats.
+__device__ __forceinline__ void num_fwd_bwd_two_waves(const NumParams& p, int n, float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* info = p.seqinfo + n * 8;
+  const int fbase = info[0], T = info[1], ns = info[2], flo = info[3], fhi = info[4];
+  float* al = smem;
+  float* be = smem + ns;
+  float* red = be + ns;
+  const int a0 = p.frame_off[fbase];
+  const int na = p.frame_off[fbase + T] - a0;
+  int32_t* s_foff = reinterpret_cast<int32_t*>(red + 8);
+  float* s_fmax = reinterpret_cast<float*>(s_foff + T + 1);
+  int32_t* s_src = reinterpret_cast<int32_t*>(s_fmax + T);
+  int32_t* s_dst = s_src + na;
+  int32_t* s_pdf = s_dst + na;
+  float* s_score = reinterpret_cast<float*>(s_pdf + na);
+  float* s_u = s_score + na;                    // backward factor of every arc (any per-frame scale)
+  const float* fmax_g = p.frame_max + (fbase - n);
+  for (int i = tid; i < 2 * ns; i += 128) smem[i] = 0.f;
+  for (int t = tid; t <= T; t += 128) s_foff[t] = p.frame_off[fbase + t] - a0;
+  for (int t = tid; t < T; t += 128) s_fmax[t] = fmax_g[t];
+  for (int a = tid; a < na; a += 128) {
+    s_src[a] = p.arc_src[a0 + a]; s_dst[a] = p.arc_dst[a0 + a]; s_pdf[a] = p.arc_pdf[a0 + a]; s_score[a] = p.score[a0 + a];
+  }
+  __syncthreads();
+  if (tid == 0) al[0] = 1.f;
+  for (int k = flo + tid; k < fhi; k += 128) be[p.final_state[k]] = expf(-p.final_w[k]);
+  __syncthreads();
+  auto wave_order = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  if (wave == 0) {
+    double logp = 0.0;
+    float inv_prev = 1.f;
+    for (int t = 0; t < T; ++t) {
+      const int lo = s_foff[t], hi = s_foff[t + 1];
+      const float m = s_fmax[t];
+      float z = 0.f;
+      for (int a = lo + lane; a < hi; a += 64) {
+        const float v = al[s_src[a]] * inv_prev * expf(s_score[a] - m);
+        atomicAdd(&al[s_dst[a]], v);
+        z += v;
+      }
+      z = wave_sum(z);
+      wave_order();
+      logp += (double)m + log((double)z);
+      inv_prev = 1.f / z;
+    }
+    float zf = 0.f;
+    for (int k = flo + lane; k < fhi; k += 64) zf += al[p.final_state[k]] * inv_prev * expf(-p.final_w[k]);
+    zf = wave_sum(zf);
+    logp += log((double)zf);
+    if (lane == 0) p.num_lp[n] = (float)logp;
+  } else {
+    float inv_prev = 1.f;
+    for (int t = T - 1; t >= 0; --t) {
+      const int lo = s_foff[t], hi = s_foff[t + 1];
+      const float m = s_fmax[t];
+      float zb = 0.f;
+      for (int a = lo + lane; a < hi; a += 64) {
+        const float u = expf(s_score[a] - m) * be[s_dst[a]] * inv_prev;
+        atomicAdd(&be[s_src[a]], u);
+        s_u[a] = u;
+        zb += u;
+      }
+      zb = wave_sum(zb);
+      wave_order();
+      inv_prev = 1.f / zb;
+    }
+  }
+  __syncthreads();
+  // posteriors: normalised inside each frame, so the frames' unknown scales cancel
+  float* grow = p.grad + (int64_t)n * p.gseq_stride;
+  for (int t = tid; t < T; t += 128) {
+    const int lo = s_foff[t], hi = s_foff[t + 1];
+    float zq = 0.f;
+    for (int a = lo; a < hi; ++a) zq += al[s_src[a]] * s_u[a];
+    const float inv_q = p.scale / zq;
+    for (int a = lo; a < hi; ++a) atomicAdd(grow + (int64_t)t * p.gframe_stride + s_pdf[a], al[s_src[a]] * s_u[a] * inv_q);
+  }
+}
+
 }  // namespace pk2

@@ -106,7 +106,7 @@ int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride
   // LDS: alpha, beta, reduction scratch; plus, when it fits, the sequence's frame table and arc arrays (bounded here
   // by the batch totals: the per-sequence counts live on the device)
   size_t lds = ((size_t)2 * max_states + 8) * sizeof(float);
-  const size_t staged = lds + ((size_t)2 * Tmax + 2 + 4 * (size_t)nb->total_arcs) * sizeof(float);
+  const size_t staged = lds + ((size_t)2 * Tmax + 2 + 5 * (size_t)nb->total_arcs) * sizeof(float);
   const bool stage = staged <= 128 * 1024;
   if (stage) lds = staged;
   static bool attr_set = false;
