@@ -400,7 +400,7 @@ def main():
     hvd.init()
     rank, world = hvd.rank(), hvd.size()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    dev = torch.device("cuda", hvd.local_rank())
+    dev = torch.device("cuda", hvd.local_device())
     torch.cuda.set_device(dev)
 
     if args.ce:
@@ -492,14 +492,14 @@ def main():
         dt, audio = float(tmax.item()), float(asum.item())
     loss_val = float(tr.last["loss"].item())
 
-    if rank != 0:
-        hvd.shutdown()
-        return
-    # per-phase breakdown of one extra (untimed) step
+    # per-phase breakdown of one extra (untimed) step -- on EVERY rank: the step contains the gradient all-reduce
     events = []
     mb = batches[0]
     tr.step(mb, events=events)
     torch.cuda.synchronize()
+    if rank != 0:
+        hvd.shutdown()
+        return
     breakdown = {events[i][0]: round(events[i - 1][1].elapsed_time(events[i][1]), 3) for i in range(1, len(events))}
     # roofline of the denominator forward-backward on this minibatch's logits
     lens = [s.frames_per_sequence for s in tr.last["sups"]]

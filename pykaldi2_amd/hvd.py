@@ -34,13 +34,13 @@ def init(backend=None):
     # rank, so the RCCL + side-stream path can be exercised on a one-GPU box.
     forced = os.environ.get("PK2_HVD_SINGLE_RANK_GROUP") == "1" and "RANK" in os.environ
     if world > 1 or forced:
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:    # PK2_HVD_BACKEND=gloo: tests that put several ranks on one GPU (RCCL refuses that)
+            backend = os.environ.get("PK2_HVD_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
         _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local, group=True)
@@ -63,6 +63,12 @@ def rank():
 
 def local_rank():
     return _state["local_rank"]
+
+
+def local_device():
+    """Index of this rank's GPU: the local rank (modulo the GPU count, which only matters when a test puts several
+    ranks on one GPU)."""
+    return _state["local_rank"] % max(1, torch.cuda.device_count())
 
 
 def _collective():

@@ -146,3 +146,22 @@ def test_bench_rccl_path_single_rank_group():
     assert a["n_gpus"] == 1 and a["config"]["parallelism"] == "dp1"
     # split-K GEMMs accumulate with float atomics: equal up to summation order
     assert abs(a["last_objf_per_frame"] - b["last_objf_per_frame"]) <= 2e-3 * abs(b["last_objf_per_frame"]) + 1e-4
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """Two bench.py ranks (the driver's torch.distributed.run line with N = 2) sharing this GPU over gloo -- RCCL refuses
+    two ranks on one device, the collective pattern is the same: parameter broadcast, bucketed gradient all-reduce on the
+    side stream, barrier-bracketed timing, MAX / SUM of the timings, and every rank reaching the same collectives (a
+    rank-0-only extra step would hang here).  Rank 0 prints the one JSON line with n_gpus = 2."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, PK2_HVD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
