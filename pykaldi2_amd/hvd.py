@@ -6,10 +6,12 @@ data/dataloader.py:45-46,83-84).  This module offers the same call surface --
 ``init, size, rank, local_rank, broadcast_parameters, broadcast_optimizer_state,
 DistributedOptimizer`` -- with one process per GPU and plain ``ncclAllReduce`` (RCCL):
 
-* gradients are averaged with one all-reduce per *bucket* of the model's flat gradient buffer
-  (output layer, then LSTM layer 2, 1, 0 -- the order backward produces them), issued on a side
-  HIP stream as soon as the bucket is complete, so the 85 MB exchange overlaps the rest of the
-  backward pass (Horovod fuses tensors with a 64 MB / 5 ms heuristic instead);
+* gradients are averaged with ONE all-reduce of the model's flat gradient buffer (85 MB) on the compute stream when
+  backward is done (Horovod fuses tensors with a 64 MB / 5 ms heuristic instead).  PK2_HVD_OVERLAP=1 selects the
+  bucketed variant -- one all-reduce per bucket (output layer, then LSTM layer 2, 1, 0: the order backward produces
+  them) on a side HIP stream, overlapping the rest of backward -- which is NOT the default because on ROCm 7.2 a
+  second active stream slows the graph-replayed step chains by more than the exchange costs (measured with a
+  one-rank RCCL group: 35.4 -> 39.9 ms per step);
 * the 1/size factor is folded into the optimiser kernel (no extra pass over the gradients);
 * ``step()`` makes the compute stream wait on the side stream, so clipping acts on the averaged
   gradient (the reference clips local, possibly mid-flight gradients: SURVEY.md Appendix B#15).
@@ -128,10 +130,17 @@ class DistributedOptimizer:
         self._flat = hasattr(optimizer, "model") and hasattr(optimizer.model, "flat_parameters")
         self._handles = []
         self._side = None
+        # PK2_HVD_OVERLAP=1: all-reduce every bucket on a side stream as soon as backward has produced it.  Default:
+        # ONE all-reduce of the whole flat gradient buffer on the compute stream when backward is done -- on ROCm 7.2
+        # a second stream that is active next to the graph-replayed LSTM / denominator step chains slows them by more
+        # than the 84 MB exchange costs (one rank, RCCL, side stream: 35.4 -> 39.9 ms per step).
+        self._overlap = os.environ.get("PK2_HVD_OVERLAP") == "1"
         if self._flat and _collective():
-            optimizer.model._bucket_hook = self._on_bucket
+            if self._overlap:
+                optimizer.model._bucket_hook = self._on_bucket
             optimizer.grad_scale = 1.0 / size()
         self._pending = set()
+        self._reduced = False
 
     def __getattr__(self, name):
         return getattr(self._opt, name)
@@ -151,6 +160,9 @@ class DistributedOptimizer:
         self._pending.add(name)
 
     def synchronize(self):
+        if self._flat and _collective() and not self._overlap and not self._reduced:
+            dist.all_reduce(self._opt.model.flat_parameters()[1], op=dist.ReduceOp.SUM)    # the flat gradient buffer
+            self._reduced = True
         for h in self._handles:
             h.wait()
         self._handles = []
@@ -159,6 +171,7 @@ class DistributedOptimizer:
         self._pending.clear()
 
     def zero_grad(self, *a, **k):
+        self._reduced = False
         return self._opt.zero_grad(*a, **k)
 
     def measure_grad_norm(self, max_norm):

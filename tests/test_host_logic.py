@@ -2,6 +2,8 @@
 supervision builder, Horovod-shaped shim over gloo (world_size 2)."""
 import os
 import subprocess
+
+import pytest
 import sys
 
 import numpy as np
@@ -123,7 +125,8 @@ class PlainSGD:
 
 m = FlatModel()
 opt = hvd.DistributedOptimizer(PlainSGD(m, 0.5))
-assert m._bucket_hook is not None and abs(opt.grad_scale - 0.5) < 1e-12
+overlap = os.environ.get("PK2_HVD_OVERLAP") == "1"       # bucketed side-stream mode, else one all-reduce after backward
+assert (m._bucket_hook is not None) == overlap and abs(opt.grad_scale - 0.5) < 1e-12
 opt.zero_grad(); m.backward()
 norm = opt.measure_grad_norm(5.0)             # synchronises the buckets first
 opt.step()
@@ -136,14 +139,15 @@ hvd.shutdown()
 '''
 
 
-def test_hvd_flat_bucketed_allreduce_world_size_2_gloo(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_hvd_flat_bucketed_allreduce_world_size_2_gloo(tmp_path, overlap):
     script = tmp_path / "f.py"
     script.write_text(FLAT_WORKER % dict(root=ROOT))
-    port = str(29900 + os.getpid() % 90)
+    port = str(29900 + (os.getpid() + int(overlap) * 37) % 90)
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port)
+                   MASTER_PORT=port, PK2_HVD_OVERLAP=overlap)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
