@@ -32,6 +32,14 @@ from pykaldi2_amd import chain, fbank, hvd, lstm, ops, optim, synth, utils  # no
 P = 6048            # configs/mmi.yaml label_size
 S_DEN, A_DEN = 30000, 1000000
 HBM_PEAK_GBS = 8000.0
+# Denominator graph topology: "chain" = what Kaldi's chain topology gives a real den.fst (the arcs entering a state carry
+# its forward pdf, its self-loop a different pdf: reference bin/train_chain.py:167,202); "unique" = round 1's graph
+# whose self-loops emit the entering pdf (kept for A/B only).
+DEN_TOPOLOGY = os.environ.get("PK2_BENCH_DEN_TOPOLOGY", "chain")
+
+
+def den_graph_arrays():
+    return synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0, loop_pdf_differs=(DEN_TOPOLOGY == "chain"))
 
 
 _chain_model = None
@@ -189,7 +197,7 @@ def cpu_baseline_worker(seed, threads):
     os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import chain_c, chain_ref, frontend_ref
     torch.set_num_threads(threads)
-    g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
+    g = den_graph_arrays()
     pi = chain_ref.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
                                      g["prob"].astype(np.float64), 0)
     rng = np.random.default_rng(seed)
@@ -387,6 +395,9 @@ def main():
     ap.add_argument("--length-bucketed", action="store_true", help="N > 1: every rank draws the same utterance lengths "
                     "(different audio / alignments), i.e. length-bucketed data parallelism without stragglers")
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
+    ap.add_argument("--den-topology", choices=["chain", "unique"], default=None,
+                    help="synthetic den.fst shape: chain (default; self-loop pdf != entering pdf, as Kaldi's chain topology "
+                    "gives) or unique (round 1: one pdf per destination state)")
     ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
     ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
     ap.add_argument("--transformer", action="store_true", help="secondary workload configs[4]: 12-layer TransformerAM "
@@ -396,6 +407,10 @@ def main():
     ap.add_argument("--ce", action="store_true", help="secondary workload configs[1]: 3x512 BLSTM CE, 256 x 80-frame "
                     "chunks per step (not the headline metric)")
     args = ap.parse_args()
+    global DEN_TOPOLOGY
+    if args.den_topology:
+        DEN_TOPOLOGY = args.den_topology
+        os.environ["PK2_BENCH_DEN_TOPOLOGY"] = DEN_TOPOLOGY     # the cpu-baseline child builds the same graph
 
     hvd.init()
     rank, world = hvd.rank(), hvd.size()
@@ -450,7 +465,7 @@ def main():
         print("lstm_fwd us/step %.2f" % (1e3 * e0.elapsed_time(e1) / 5 / T), flush=True)
         return
     log("rank %d/%d: building synthetic den graph" % (rank, world))
-    g = synth.den_graph_arcs(S_DEN, A_DEN, P, seed=0)
+    g = den_graph_arrays()
     den = chain.DenominatorGraph(g, P)
     log("den graph ready")
     if args.den_only:

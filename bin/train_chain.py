@@ -94,7 +94,7 @@ def main():
     optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters())
 
     if args.synthetic:
-        den = chain.DenominatorGraph(synth.den_graph_arcs(args.den_states, args.den_arcs, P, seed=0), P)
+        den = chain.DenominatorGraph(synth.den_graph_arcs(args.den_states, args.den_arcs, P, seed=0, loop_pdf_differs=True), P)
         chain_tree, chain_trans_model = synth.chain_model(P, seed=0)
         aligner = chain.MappedAligner(chain_trans_model)
     else:

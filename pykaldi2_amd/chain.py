@@ -76,7 +76,8 @@ class DenominatorGraph:
         return out
 
     def debug_ordering(self, which):
-        """Host-side work decomposition (test hook): which = 0 by dst, 1 by src, 2 by pdf."""
+        """Host-side work decomposition (test hook): which = 0 by dst, 1 by src, 2 by pdf (general kernels);
+        3 = by virtual destination state, 4 = by src gathering virtual destination states (state-x kernels)."""
         L = _lib.lib()
         na, nc = C.c_int64(), C.c_int32()
         _lib.check(L.pk2_den_graph_debug_ordering(self._h, which, C.byref(na), C.byref(nc), None, None,
@@ -91,7 +92,20 @@ class DenominatorGraph:
         _lib.check(L.pk2_den_graph_debug_ordering(self._h, which, None, None, _lib.ptr(arcs), _lib.ptr(meta),
                                                   _lib.ptr(wb_off), _lib.ptr(row0), _lib.ptr(nrows),
                                                   _lib.ptr(atomic)))
-        return dict(arcs=arcs, meta=meta, wb_off=wb_off, row0=row0, nrows=nrows, atomic=atomic, arcs_per_lane=k)
+        out = dict(arcs=arcs, meta=meta, wb_off=wb_off, row0=row0, nrows=nrows, atomic=atomic, arcs_per_lane=k)
+        if which >= 3:
+            nv, nl = C.c_int32(), C.c_int64()
+            _lib.check(L.pk2_den_graph_debug_virtual(self._h, which, C.byref(nv), None, None, None, None, None,
+                                                     C.byref(nl), None))
+            voff = np.empty(self._num_states + 1, dtype=np.int32)
+            vpdf = np.empty(nv.value, dtype=np.int32)
+            real0, nreal, slot0 = (np.empty(nc.value, dtype=np.int32) for _ in range(3))
+            leak = np.empty(nl.value, dtype=np.float32)
+            _lib.check(L.pk2_den_graph_debug_virtual(self._h, which, None, _lib.ptr(voff), _lib.ptr(vpdf),
+                                                     _lib.ptr(real0), _lib.ptr(nreal), _lib.ptr(slot0), None,
+                                                     _lib.ptr(leak)))
+            out.update(voff=voff, vpdf=vpdf, real0=real0, nreal=nreal, slot0=slot0, row_leak=leak)
+        return out
 
     def __del__(self):
         try:

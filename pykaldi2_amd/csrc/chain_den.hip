@@ -78,10 +78,33 @@ __device__ __forceinline__ void block_sum(float (&v)[NG], float* red) {
   }
 }
 
+// Two vectors at once (one barrier pair); `red` holds 2 * NW * NG floats.
+template <int NG, int NW>
+__device__ __forceinline__ void block_sum2(float (&u)[NG], float (&v)[NG], float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int n = 0; n < NG; ++n) { u[n] = wave_sum(u[n]); v[n] = wave_sum(v[n]); }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { red[w * NG + n] = u[n]; red[(NW + w) * NG + n] = v[n]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < NW; ++k) { a += red[k * NG + n]; b += red[(NW + k) * NG + n]; }
+    u[n] = a; v[n] = b;
+  }
+}
+
 struct IntPack { static constexpr int kN = 64; int32_t v[kN]; };
 __global__ void store_ints(IntPack pack, int count, int32_t* out) {
   if ((int)threadIdx.x < count) out[threadIdx.x] = pack.v[threadIdx.x];
 }
+
+// Uniform floor of the backward normaliser's weights, relative to the mean of pi (see den_beta_frame_sx).
+constexpr double kBetaFloor = 1e-8;
 
 struct DenParams {
   DevOrdering fwd, bwd, gam;
@@ -89,11 +112,16 @@ struct DenParams {
   float* alpha; float* beta; float* xs; float* gamma;
   float* apart; float* bpart; float* asum; float* inv_tot;
   const int32_t* lengths;
-  const int32_t* ps_off;    // states grouped by pdf (only when pdf is a function of the state)
+  const int32_t* ps_off;    // virtual states grouped by pdf (CSR over P)
   const int32_t* ps_state;
-  const int32_t* state_pdf;  // [S] pdf emitted on entering the state (-1: no incoming arc)
+  // state-x path (virtual states, chain_internal.h): fwd / bwd are then the fwdv / bwdv orderings
+  const int32_t* voff;      // [S+1] first virtual state of a state
+  const int32_t* vpdf;      // [V] pdf of a virtual state (-1: nobody enters the state)
+  float* alphav;            // [G][Tmax+1][V][NG]; == alpha when V == S
+  int V;
   int S, P, Tmax;
   float leaky, pi_sum;
+  float wu;    // kBetaFloor * sum(pi)/S: uniform floor of the backward normaliser's weights (state-x path)
   int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop, 4 = load half of the arc records
 };
 
@@ -498,29 +526,38 @@ __global__ void __launch_bounds__(kDenBwdThreads) den_bwd_step(const DenParams* 
   if (tid == 0 && chunk < ncb) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
 }
 
-// c[g][t][n] = sum_k pi[k] btilde'[t,k]  (fixed-order reduction of the backward partials)
+// csum[g][t][0][n] = cu[t] = sum_k (pi[k] + kBetaFloor*sum(pi)/S) btilde'[t,k], the normaliser of the backward recursion;
+// csum[g][t][1][n] = sum_k pi[k] btilde'[t,k] / cu[t], the factor of its leaky-HMM term
+// (fixed-order reduction of the backward partials {sum pi*btilde', sum btilde'} per chunk).
 template <int NG>
 __global__ void __launch_bounds__(256) den_csum(DenParams p, float* csum) {
-  __shared__ float red[4 * NG];
+  __shared__ float red[2 * 4 * NG];
   const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const int ncb = p.bwd.n_chunks;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
-  float c[NG];
+  float c[NG], u[NG];
 #pragma unroll
-  for (int n = 0; n < NG; ++n) c[n] = 0.f;
+  for (int n = 0; n < NG; ++n) { c[n] = 0.f; u[n] = 0.f; }
   for (int i = tid; i < ncb; i += 256) {
-    float v[NG];
-    ldv<NG>(p.bpart + (frame * ncb + i) * NG, v);
+    float v[NG], w[NG];
+    ldv<NG>(p.bpart + ((frame * ncb + i) * 2) * NG, v);
+    ldv<NG>(p.bpart + ((frame * ncb + i) * 2 + 1) * NG, w);
 #pragma unroll
-    for (int n = 0; n < NG; ++n) c[n] += v[n];
+    for (int n = 0; n < NG; ++n) { c[n] += v[n]; u[n] += w[n]; }
   }
-  block_sum<NG, 4>(c, red);
-  if (tid == 0) stv<NG>(csum + frame * NG, c);
+  block_sum2<NG, 4>(c, u, red);
+  if (tid == 0) {
+    float cu[NG], ratio[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { cu[n] = c[n] + p.wu * u[n]; ratio[n] = cu[n] > 0.f ? c[n] / cu[n] : 0.f; }
+    stv<NG>(csum + (frame * 2) * NG, cu);
+    stv<NG>(csum + (frame * 2 + 1) * NG, ratio);
+  }
 }
 
-// K[g][t][n]: true beta[t] = K[t] * betahat[t].  K[T] = sum(pi)/tot, log K[t] = log K[t+1] + log c[t]
+// K[g][t][n]: true beta[t] = K[t] * betahat[t].  K[T] = sum(pi)/tot, log K[t] = log K[t+1] + log cu[t]
 // - log asum[t]: a suffix sum in double precision (block scan, one workgroup per sequence).
-// check = (1 + leaky*sum(pi)) * K[0].
+// check = sum_h alpha'[0,h] beta'[0,h] = (1 + leaky*sum(pi)) * K[0] * (sum pi*btilde'[0]) / cu[0].
 template <int NG>
 __global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum, float* Kf, float* check) {
   __shared__ double wsum[4];
@@ -537,7 +574,7 @@ __global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum
   for (int hi = T - 1; hi >= 0; hi -= 256) {
     const int t = hi - tid;
     double v = 0.0;
-    if (t >= 0) v = log((double)csum[(f0 + t) * NG + n]) - log((double)p.asum[(f0 + t) * NG + n]);
+    if (t >= 0) v = log((double)csum[((f0 + t) * 2) * NG + n]) - log((double)p.asum[(f0 + t) * NG + n]);
     // inclusive scan over the tile
     double x = v;
 #pragma unroll
@@ -552,7 +589,7 @@ __global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum
     const double lk = off + x;
     if (t >= 0) Kf[(f0 + t) * NG + n] = (float)exp(lk);
     __syncthreads();
-    if (tid == 255 || t == 0) { carry_s = lk; if (t == 0) check[g * NG + n] = (float)((1.0 + (double)p.leaky * p.pi_sum) * exp(lk)); }
+    if (tid == 255 || t == 0) { carry_s = lk; if (t == 0) check[g * NG + n] = (float)((1.0 + (double)p.leaky * p.pi_sum) * exp(lk) * (double)csum[(f0 * 2 + 1) * NG + n]); }
     __syncthreads();
   }
 }
@@ -567,19 +604,21 @@ template <int NG>
 __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const float* csum, const float* Kf, int t, int g) {
   const int tid = threadIdx.x;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
-  float cv[NG], kv[NG], inv_c[NG], cst[NG];
+  float cv[NG], rv[NG], kv[NG], inv_c[NG], lkr[NG], cst[NG];
   bool gat[NG];
-  ldv<NG>(csum + (frame + 1) * NG, cv);
+  ldv<NG>(csum + ((frame + 1) * 2) * NG, cv);
+  ldv<NG>(csum + ((frame + 1) * 2 + 1) * NG, rv);
   ldv<NG>(Kf + (frame + 1) * NG, kv);
 #pragma unroll
   for (int n = 0; n < NG; ++n) {
     const int T = p.lengths[g * NG + n];
     gat[n] = (t + 1) < T;
     inv_c[n] = (gat[n] && cv[n] > 0.f) ? 1.0f / cv[n] : 0.f;
+    lkr[n] = p.leaky * rv[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
-  const float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
-  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * (2 * NG);   // {btilde'[NG], xd[NG]} per state
+  const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.V * NG;
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
   float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
   for (int pdf = tid; pdf < p.P; pdf += 256) {
     float v[NG];
@@ -591,7 +630,7 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
       ldv<NG>(alpha_n + (size_t)s * NG, a);
       ldv<NG>(beta_n + (size_t)s * (2 * NG), b);
 #pragma unroll
-      for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] * inv_c[n] + p.leaky : cst[n]);
+      for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] * inv_c[n] + lkr[n] : cst[n]);
     }
 #pragma unroll
     for (int n = 0; n < NG; ++n) v[n] *= kv[n];
@@ -609,29 +648,31 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
                                                           float* acc) {
   const int tid = threadIdx.x;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
-  float cv[NG], kv[NG], inv_c[NG], cst[NG];
+  float cv[NG], rv[NG], kv[NG], inv_c[NG], lkr[NG], cst[NG];
   bool gat[NG];
-  ldv<NG>(csum + (frame + 1) * NG, cv);
+  ldv<NG>(csum + ((frame + 1) * 2) * NG, cv);
+  ldv<NG>(csum + ((frame + 1) * 2 + 1) * NG, rv);
   ldv<NG>(Kf + (frame + 1) * NG, kv);
 #pragma unroll
   for (int n = 0; n < NG; ++n) {
     const int T = p.lengths[g * NG + n];
     gat[n] = (t + 1) < T;
     inv_c[n] = (gat[n] && cv[n] > 0.f) ? 1.0f / cv[n] : 0.f;
+    lkr[n] = p.leaky * rv[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
   for (int i = tid; i < p.P * NG; i += kGammaThreads) acc[i] = 0.f;
   __syncthreads();
-  const float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
-  const float* beta_n = p.beta + (frame + 1) * (size_t)p.S * (2 * NG);   // {btilde'[NG], xd[NG]} per state
-  for (int s0 = tid; s0 < p.S; s0 += 4 * kGammaThreads) {
+  const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.V * NG;
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
+  for (int s0 = tid; s0 < p.V; s0 += 4 * kGammaThreads) {
     float a[4][NG], b[4][NG]; int pdf[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int s = s0 + q * kGammaThreads;
       pdf[q] = -1;
-      if (s < p.S) {
-        pdf[q] = p.state_pdf[s];
+      if (s < p.V) {
+        pdf[q] = p.vpdf[s];
         ldv<NG>(alpha_n + (size_t)s * NG, a[q]);
         ldv<NG>(beta_n + (size_t)s * (2 * NG), b[q]);
       }
@@ -640,7 +681,7 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
     for (int q = 0; q < 4; ++q) {
       if (pdf[q] < 0) continue;
 #pragma unroll
-      for (int n = 0; n < NG; ++n) atomicAdd(&acc[pdf[q] * NG + n], a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + p.leaky : cst[n]));
+      for (int n = 0; n < NG; ++n) atomicAdd(&acc[pdf[q] * NG + n], a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]));
     }
   }
   __syncthreads();
@@ -692,12 +733,12 @@ __global__ void __launch_bounds__(LDS_ROW ? kGammaThreads : 256) den_gamma_state
 // Neither kernel stages the P x NG table of exp(logits) in LDS (saves 97 KB of LDS and 24 MB of
 // L2 traffic per frame and direction); they keep only the 16 KB row accumulator.
 // ----------------------------------------------------------------------------------------
-// bx[g][t+1][d][NG + n] = exp(clamp(logit[seq(g,n)][t][pdf(d)]))   (1 for finished sequences)
+// bx[g][t+1][v][NG + n] = exp(clamp(logit[seq(g,n)][t][pdf(v)]))   (1 for finished sequences), v = virtual state
 template <int NG>
 __global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ logits, int64_t seq_stride,
                                                       int64_t frame_stride, const int32_t* __restrict__ lengths,
-                                                      const int32_t* __restrict__ state_pdf, float* __restrict__ bx,
-                                                      int S, int Tmax) {
+                                                      const int32_t* __restrict__ state_pdf /* vpdf[V] */, float* __restrict__ bx,
+                                                      int S /* = V */, int Tmax) {
   const int t = blockIdx.x, g = blockIdx.y;
   const float* rows[NG]; bool live[NG];
 #pragma unroll
@@ -804,26 +845,49 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   DEN_T(0, 2);
   __syncthreads();
   DEN_T(0, 3);
+  // Rows are VIRTUAL states (dst, pdf): alpha_v[t+1,v] = x[t,pdf(v)]/asum * (sum over the row + leaky term); the alpha
+  // of a state is the sum over its virtual states, which all sit in this chunk (chain_graph.hip), a thread per state.
   float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
-  const float* xd = p.beta + (frame + 1) * (size_t)p.S * (2 * NG) + NG;   // x[t, pdf(d)]
+  float* alphav_n = p.alphav + (frame + 1) * (size_t)p.V * NG;
+  const bool sep = p.alphav != p.alpha;
+  const float* xd = p.beta + (frame + 1) * (size_t)p.V * (2 * NG) + NG;   // x[t, pdf(v)]
   const int row0 = p.fwd.row0[chunk];
+  const int real0 = p.fwd.real0[chunk], nreal = p.fwd.nreal[chunk];
   const bool atomic = p.fwd.atomic[chunk] != 0;
   const float* leak = p.fwd.row_leak + p.fwd.slot0[chunk];     // sum of pi[src]*prob over this piece of the row
   float loc[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) loc[n] = 0.f;
-  for (int r = tid; r < nrows; r += kDenThreads) {
-    float v[NG], xv[NG];
-    ldv<NG>(xd + (size_t)(row0 + r) * (2 * NG), xv);
-    const float lr = leak[r];
+  if (atomic) {            // one (piece of a) virtual row of a state whose rows do not fit one chunk
+    if (tid == 0) {
+      float xv[NG];
+      ldv<NG>(xd + (size_t)row0 * (2 * NG), xv);
 #pragma unroll
-    for (int n = 0; n < NG; ++n) { v[n] = (acc[r * NG + n] + lk[n] * lr) * xv[n] * inv_as[n]; loc[n] += v[n]; }
-    float* o = alpha_n + (size_t)(row0 + r) * NG;
-    if (atomic) {
+      for (int n = 0; n < NG; ++n) {
+        const float v = (acc[n] + lk[n] * leak[0]) * xv[n] * inv_as[n];
+        loc[n] = v;
+        atomicAdd(alpha_n + (size_t)real0 * NG + n, v);
+        if (sep) atomicAdd(alphav_n + (size_t)row0 * NG + n, v);
+      }
+    }
+  } else {
+    for (int r = tid; r < nreal; r += kDenThreads) {
+      const int d = real0 + r;
+      const int lo = p.voff[d] - row0, hi = p.voff[d + 1] - row0;
+      float sum[NG];
 #pragma unroll
-      for (int n = 0; n < NG; ++n) atomicAdd(o + n, v[n]);
-    } else {
-      stv<NG>(o, v);
+      for (int n = 0; n < NG; ++n) sum[n] = 0.f;
+      for (int q = lo; q < hi; ++q) {
+        float v[NG], xv[NG];
+        ldv<NG>(xd + (size_t)(row0 + q) * (2 * NG), xv);
+        const float lr = leak[q];
+#pragma unroll
+        for (int n = 0; n < NG; ++n) { v[n] = (acc[q * NG + n] + lk[n] * lr) * xv[n] * inv_as[n]; sum[n] += v[n]; }
+        if (sep) stv<NG>(alphav_n + (size_t)(row0 + q) * NG, v);
+      }
+#pragma unroll
+      for (int n = 0; n < NG; ++n) loc[n] += sum[n];
+      stv<NG>(alpha_n + (size_t)d * NG, sum);
     }
   }
   DEN_T(0, 4);
@@ -845,17 +909,18 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   const int lane = tid & 63, w = tid >> 6;
   const int ncb = p.bwd.n_chunks;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
-  const float* bx_n = p.beta + (frame + 1) * (size_t)p.S * (2 * NG);
+  const float* bx_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // gathered by virtual destination state
   const int wb0 = p.bwd.wb_off[chunk], wb1 = p.bwd.wb_off[chunk + 1];
   const int nrows = p.bwd.nrows[chunk];
-  float lB[NG];
+  float lB[NG], lU[NG];
 #pragma unroll
-  for (int n = 0; n < NG; ++n) lB[n] = 0.f;
+  for (int n = 0; n < NG; ++n) { lB[n] = 0.f; lU[n] = 0.f; }
   for (int i = tid; i < ncb; i += kDenThreads) {
-    float v[NG];
-    ldv<NG>(p.bpart + ((frame + 1) * ncb + i) * NG, v);
+    float v[NG], u[NG];
+    ldv<NG>(p.bpart + (((frame + 1) * ncb + i) * 2) * NG, v);
+    ldv<NG>(p.bpart + (((frame + 1) * ncb + i) * 2 + 1) * NG, u);
 #pragma unroll
-    for (int n = 0; n < NG; ++n) lB[n] += v[n];
+    for (int n = 0; n < NG; ++n) { lB[n] += v[n]; lU[n] += u[n]; }
   }
   int wb = wb0 + w;
   int2 rec[kK];      // {gathered state, arc probability}
@@ -874,17 +939,23 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   }
   for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
   DEN_T(1, 0);
-  block_sum<NG, kDenWaves>(lB, red);
+  block_sum2<NG, kDenWaves>(lB, lU, red);
   DEN_T(1, 1);
-  // lB now holds c[t+1] = sum_k pi[k] btilde'[t+1,k]; the normalised beta-hat' has pi-weighted sum 1,
-  // so its leaky term is exactly `leaky`.  beta-hat[T_n] = 1/sum(pi) + leaky starts each sequence.
-  float cst[NG], inv_c[NG];
+  // lB = sum_k pi[k] btilde'[t+1,k], lU = sum_k btilde'[t+1,k].  The recursion normalises by
+  // cu = lB + wu * lU, i.e. with weights pi[k] + kBetaFloor * sum(pi)/S: pi is the cheap guess of which states matter
+  // (the forward pass is not available: the two chains run side by side), the uniform floor bounds every normalised
+  // value by S / (kBetaFloor * sum(pi)) whatever pi[k] is -- normalising by the pi-weighted sum alone lets a state
+  // with pi ~ 1e-38 overflow (measured on a test graph).  The leaky-HMM term of the normalised beta-hat' is
+  // leaky * lB / cu.  beta-hat[T_n] = 1/sum(pi) + leaky starts a sequence.
+  float cst[NG], inv_c[NG], lkr[NG];
   bool gat[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) {
     const int T = p.lengths[g * NG + n];
     gat[n] = (t + 1) < T;
-    inv_c[n] = (gat[n] && lB[n] > 0.f) ? 1.0f / lB[n] : 0.f;
+    const float cu = lB[n] + p.wu * lU[n];
+    inv_c[n] = (gat[n] && cu > 0.f) ? 1.0f / cu : 0.f;
+    lkr[n] = p.leaky * lB[n] * inv_c[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
   while (wb < wb1) {
@@ -897,7 +968,7 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     for (int j = 0; j < kK; ++j) {
       const float prob = __int_as_float(rec[j].y);
 #pragma unroll
-      for (int n = 0; n < NG; ++n) sum[n] += prob * xv[j][n] * (gat[n] ? b[j][n] * inv_c[n] + p.leaky : cst[n]);
+      for (int n = 0; n < NG; ++n) sum[n] += prob * xv[j][n] * (gat[n] ? b[j][n] * inv_c[n] + lkr[n] : cst[n]);
       if ((mask >> j) & 1u) {
 #pragma unroll
         for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
@@ -919,28 +990,36 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   DEN_T(1, 2);
   __syncthreads();
   DEN_T(1, 3);
-  float* bx_t = p.beta + frame * (size_t)p.S * (2 * NG);
+  // rows are source states; btilde'[t,s] goes into the record of every virtual state of s
+  float* bx_t = p.beta + frame * (size_t)p.V * (2 * NG);
   const int row0 = p.bwd.row0[chunk];
   const bool atomic = p.bwd.atomic[chunk] != 0;
-  float loc[NG];
+  float loc[NG], locu[NG];
 #pragma unroll
-  for (int n = 0; n < NG; ++n) loc[n] = 0.f;
+  for (int n = 0; n < NG; ++n) { loc[n] = 0.f; locu[n] = 0.f; }
   for (int r = tid; r < nrows; r += kDenThreads) {
     float v[NG];
-    const float pis = p.pi[row0 + r];
+    const int s = row0 + r;
+    const float pis = p.pi[s];
+    const int v0 = p.voff[s], v1 = p.voff[s + 1];
 #pragma unroll
-    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n]; loc[n] += pis * v[n]; }
-    float* o = bx_t + (size_t)(row0 + r) * (2 * NG);
-    if (atomic) {
+    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n]; loc[n] += pis * v[n]; locu[n] += v[n]; }
+    for (int q = v0; q < v1; ++q) {
+      float* o = bx_t + (size_t)q * (2 * NG);
+      if (atomic) {
 #pragma unroll
-      for (int n = 0; n < NG; ++n) atomicAdd(o + n, v[n]);
-    } else {
-      stv<NG>(o, v);
+        for (int n = 0; n < NG; ++n) atomicAdd(o + n, v[n]);
+      } else {
+        stv<NG>(o, v);
+      }
     }
   }
   DEN_T(1, 4);
-  block_sum<NG, kDenWaves>(loc, red);
-  if (tid == 0) stv<NG>(p.bpart + (frame * ncb + chunk) * NG, loc);
+  block_sum2<NG, kDenWaves>(loc, locu, red);
+  if (tid == 0) {
+    stv<NG>(p.bpart + ((frame * ncb + chunk) * 2) * NG, loc);
+    stv<NG>(p.bpart + ((frame * ncb + chunk) * 2 + 1) * NG, locu);
+  }
   DEN_T(1, 5);
 }
 
@@ -951,7 +1030,7 @@ template <int NG>
 __global__ void __launch_bounds__(kDenThreads) den_step_sx(const DenParams* __restrict__ pp,
                                                            const StepCounter* __restrict__ cnt, int local) {
   __shared__ __attribute__((aligned(16))) float acc[kMaxRows * NG];
-  __shared__ float red[kDenWaves * NG];
+  __shared__ float red[2 * kDenWaves * NG];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
   const DenParams& p = *pp;
@@ -1013,6 +1092,16 @@ static size_t den_lds_bytes(int P, int NG) {
   return ((size_t)P * NG + (size_t)2 * kMaxRows * NG + (size_t)2 * kDenWaves * NG) * sizeof(float);
 }
 
+// The state-x kernels serve every graph; the general (per-arc pdf, LDS-staged exp(logits)) family remains for graphs
+// whose virtual-state count explodes (more than 4 distinct entering pdfs per state on average) and for A/B runs:
+// PK2_DEN_MODE=general | sx overrides the choice.
+bool den_use_sx(const pk2_den_graph* g) {
+  const char* mode = getenv("PK2_DEN_MODE");
+  if (mode && strcmp(mode, "general") == 0) return false;
+  if (mode && strcmp(mode, "sx") == 0) return true;
+  return (int64_t)g->V <= 4 * (int64_t)g->S;
+}
+
 int den_choose_ng(const pk2_den_graph* g) {
   const size_t limit = 160 * 1024;
   for (int ng : {4, 2, 1})
@@ -1030,18 +1119,21 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
   Carver c(base);
   DenBuffers b;
   const size_t GN = (size_t)ge.G * ge.NG;
+  const bool sx = den_use_sx(g);
+  const size_t V = sx ? (size_t)g->V : (size_t)g->S;
   b.alpha = c.take<float>(GN * (Tmax + 1) * (size_t)g->S);
-  b.beta = c.take<float>(GN * (Tmax + 1) * (size_t)g->S * 2);   // {beta', xd} per state on the state-x path
+  b.alphav = (V == (size_t)g->S) ? b.alpha : c.take<float>(GN * (Tmax + 1) * V);
+  b.beta = c.take<float>(GN * (Tmax + 1) * V * 2);   // {beta', xd} per virtual state on the state-x path
   b.xs = c.take<float>(GN * (size_t)Tmax * g->P);
   b.gamma = c.take<float>(GN * (size_t)Tmax * g->P);
-  b.apart = c.take<float>(GN * (Tmax + 1) * (size_t)g->h_fwd.n_chunks);
-  b.bpart = c.take<float>(GN * (Tmax + 1) * (size_t)g->h_bwd.n_chunks);
+  b.apart = c.take<float>(GN * (Tmax + 1) * (size_t)(sx ? g->h_fwdv : g->h_fwd).n_chunks);
+  b.bpart = c.take<float>(GN * (Tmax + 1) * (size_t)(sx ? 2 * g->h_bwdv.n_chunks : g->h_bwd.n_chunks));   // state-x: two sums per chunk
   b.asum = c.take<float>(GN * (Tmax + 1));
   b.inv_tot = c.take<float>(GN);
   b.den_lp = c.take<float>(GN);
   b.check = c.take<float>(GN);
   b.lengths = c.take<int32_t>(GN);
-  b.csum = c.take<float>(GN * (Tmax + 1));
+  b.csum = c.take<float>(GN * (Tmax + 1) * 2);   // {cu, sum pi*btilde' / cu}
   b.kscale = c.take<float>(GN * (Tmax + 1));
   if (geom) *geom = ge;
   if (buf) *buf = b;
@@ -1087,26 +1179,29 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   // (on the state-x path every alpha / beta' row and every occupancy is written by a plain store unless a row is
   // split over several chunks, and values of frames beyond a sequence's end are only ever selected away, never used
   // in arithmetic: the 0.9 GB of fills per call are skipped then)
-  const char* mode0 = getenv("PK2_DEN_MODE");
-  const bool sx0 = g->state_pdf_unique && !(mode0 && strcmp(mode0, "general") == 0);
+  const bool sx = den_use_sx(g);
+  const HostOrdering& hf = sx ? g->h_fwdv : g->h_fwd;
+  const HostOrdering& hb = sx ? g->h_bwdv : g->h_bwd;
   auto any_atomic = [](const HostOrdering& h) { for (int32_t a : h.atomic) if (a) return true; return false; };
-  const bool need_fill = !sx0 || any_atomic(g->h_fwd) || any_atomic(g->h_bwd);
+  const bool need_fill = !sx || any_atomic(hf) || any_atomic(hb);
   if (need_fill) {
     PK2_HIP(hipMemsetAsync(b.alpha, 0, GN * (Tmax + 1) * (size_t)g->S * sizeof(float), stream));
-    PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)g->S * 2 * sizeof(float), stream));
+    if (b.alphav != b.alpha) PK2_HIP(hipMemsetAsync(b.alphav, 0, GN * (Tmax + 1) * (size_t)g->V * sizeof(float), stream));
+    PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)(sx ? g->V : g->S) * 2 * sizeof(float), stream));
     PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
   }
-  PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * (size_t)g->h_bwd.n_chunks * sizeof(float), stream));
+  PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * (size_t)hb.n_chunks * (sx ? 2 : 1) * sizeof(float), stream));
 
   DenParams p;
-  p.fwd = g->fwd; p.bwd = g->bwd; p.gam = g->gam;
+  p.fwd = sx ? g->fwdv : g->fwd; p.bwd = sx ? g->bwdv : g->bwd; p.gam = g->gam;
   p.pi = g->d_pi;
   p.alpha = b.alpha; p.beta = b.beta; p.xs = b.xs; p.gamma = b.gamma;
   p.apart = b.apart; p.bpart = b.bpart; p.asum = b.asum; p.inv_tot = b.inv_tot;
   p.lengths = b.lengths;
-  p.ps_off = g->d_ps_off; p.ps_state = g->d_ps_state; p.state_pdf = g->d_state_pdf;
+  p.ps_off = g->d_pv_off; p.ps_state = g->d_pv_virt;
+  p.voff = g->d_voff; p.vpdf = g->d_vpdf; p.alphav = b.alphav; p.V = sx ? g->V : g->S;
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
-  p.leaky = leaky; p.pi_sum = (float)g->pi_sum;
+  p.leaky = leaky; p.pi_sum = (float)g->pi_sum; p.wu = (float)(kBetaFloor * g->pi_sum / g->S);
   p.debug = getenv("PK2_DEN_DEBUG") ? atoi(getenv("PK2_DEN_DEBUG")) : 0;
 
   const size_t lds = den_lds_bytes(g->P, NG);
@@ -1125,19 +1220,17 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   const DenParams* pb = slot->params;
   const StepCounter* cnt = slot->counter;
 
-  // Two kernel families: the "state-x" fast path when every state's incoming arcs share one pdf
-  // (PK2_DEN_MODE=general forces the general one), else LDS-staged exp(logits) + arc-based occupancies.
-  const char* mode = getenv("PK2_DEN_MODE");
-  const bool sx = g->state_pdf_unique && !(mode && strcmp(mode, "general") == 0);
+  // Two kernel families: the "state-x" path (exp(logit) as a per-virtual-state factor; den_use_sx), else LDS-staged
+  // exp(logits) + arc-based occupancies.
   char key[96];
   hipLaunchKernelGGL(den_init<NG>, dim3(std::min(256, (g->S + 255) / 256), G), dim3(256), 0, stream, p);
   if (sx) {
     hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride,
-                       b.lengths, g->d_state_pdf, b.beta, g->S, Tmax);
+                       b.lengths, g->d_vpdf, b.beta, g->V, Tmax);
     PK2_LAUNCH_CHECK();
     // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
     // share one launch
-    const dim3 gridS(g->fwd.n_chunks + g->bwd.n_chunks, G);
+    const dim3 gridS(g->fwdv.n_chunks + g->bwdv.n_chunks, G);
     snprintf(key, sizeof(key), "den_sx_%d_%u_%d_%p", NG, gridS.x, G, (void*)stream);
     rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
       hipLaunchKernelGGL(den_step_sx<NG>, gridS, dim3(kDenThreads), 0, s, pb, cnt, j);

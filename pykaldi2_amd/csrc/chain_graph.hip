@@ -17,9 +17,14 @@ namespace pk2 {
 // ----------------------------------------------------------------------------------------
 // host: graph construction
 // ----------------------------------------------------------------------------------------
+// `group_of_row` (optional, monotone): rows of one group (the virtual states of one real state) are kept in ONE chunk so
+// that the forward epilogue can sum them without atomics; a group that cannot fit a chunk is emitted row by row as
+// single-row `atomic` chunks.  Without it every row is its own group (a row longer than a chunk is split, as before).
+// `want4` / `want2`: which record formats to lay out (16-byte {a, b, prob, pi*prob} / 8-byte {a, prob}).
 static void build_ordering(int64_t A, int num_rows, const int32_t* key, const int32_t* a,
                            const int32_t* b, const float* prob, const float* piprob,
-                           HostOrdering* out) {
+                           HostOrdering* out, const int32_t* group_of_row = nullptr,
+                           bool want4 = true, bool want2 = true) {
   // counting sort by key (stable)
   std::vector<int64_t> ptr(num_rows + 1, 0);
   for (int64_t i = 0; i < A; ++i) ptr[key[i] + 1]++;
@@ -32,11 +37,14 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
   out->arcs.clear(); out->meta.clear(); out->wb_off.assign(1, 0);
   out->arcs2.clear(); out->row_leak.clear(); out->slot0.clear();
   out->row0.clear(); out->nrows.clear(); out->atomic.clear();
+  out->real0.clear(); out->nreal.clear();
+  auto group = [&](int r) { return group_of_row ? group_of_row[r] : r; };
 
   struct Piece { int row; int64_t lo, hi; };  // arcs [lo,hi) of sorted list belong to `row`
+  std::vector<int64_t> idx; std::vector<int> lrow;
   auto emit_chunk = [&](const std::vector<Piece>& pieces, int row0, int nrows, int atomic) {
     // sorted arcs of this chunk, each tagged with its chunk-local row
-    std::vector<int64_t> idx; std::vector<int> lrow;
+    idx.clear(); lrow.clear();
     for (const Piece& p : pieces) {
       for (int64_t k = p.lo; k < p.hi; ++k) { idx.push_back(perm[k]); lrow.push_back(p.row - row0); }
       // a row without arcs gets one null arc so that chunk-local rows stay consecutive
@@ -47,9 +55,9 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
     int64_t padded = std::max<int64_t>(per_wb, (n + per_wb - 1) / per_wb * per_wb);
     int last_row = nrows - 1;
     int nwb = (int)(padded / per_wb);
-    size_t base_arc = out->arcs.size(), base_meta = out->meta.size();
-    out->arcs.resize(base_arc + padded);
-    out->arcs2.resize(base_arc + padded);
+    const size_t base_arc = (size_t)out->wb_off.back() * per_wb, base_meta = out->meta.size();
+    if (want4) out->arcs.resize(base_arc + padded);
+    if (want2) out->arcs2.resize(base_arc + padded);
     // leaky-HMM term of a row: sum over its arcs of pi[src]*prob does not depend on the frame, so the state-x forward
     // kernel adds it per row instead of carrying pi*prob in every arc record
     const size_t base_slot = out->row_leak.size();
@@ -83,8 +91,8 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
           row_next = (s + 1 < n) ? lrow[s + 1] : last_row;
           if (j == 0) c0 = row_here;
           if (j == kK - 1 || row_next != row_here) mask |= (1u << j);
-          out->arcs[base_arc + ((size_t)wb * kK + j) * 64 + lane] = rec;
-          out->arcs2[base_arc + ((size_t)wb * kK + j) * 64 + lane] = make_int2(rec.x, rec.z);
+          if (want4) out->arcs[base_arc + ((size_t)wb * kK + j) * 64 + lane] = rec;
+          if (want2) out->arcs2[base_arc + ((size_t)wb * kK + j) * 64 + lane] = make_int2(rec.x, rec.z);
         }
         out->meta[base_meta + (size_t)wb * 64 + lane] = make_uint2((uint32_t)c0, mask);
       }
@@ -93,6 +101,8 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
     out->row0.push_back(row0);
     out->nrows.push_back(nrows);
     out->atomic.push_back(atomic);
+    out->real0.push_back(group(row0));
+    out->nreal.push_back(group(row0 + nrows - 1) - group(row0) + 1);
   };
 
   std::vector<Piece> cur; int cur_row0 = 0; int64_t cur_arcs = 0;
@@ -100,21 +110,31 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
     if (!cur.empty()) emit_chunk(cur, cur_row0, (int)cur.size(), 0);
     cur.clear(); cur_arcs = 0; cur_row0 = next_row;
   };
-  for (int r = 0; r < num_rows; ++r) {
-    int64_t lo = ptr[r], hi = ptr[r + 1], len = hi - lo;
-    if (len > kChunkArcs) {
-      flush(r);
-      for (int64_t s = lo; s < hi; s += kChunkArcs) {
-        std::vector<Piece> one{{r, s, std::min(hi, s + kChunkArcs)}};
-        emit_chunk(one, r, 1, 1);
-      }
-      cur_row0 = r + 1;
-      continue;
+  for (int r = 0; r < num_rows;) {
+    int r1 = r + 1;
+    while (r1 < num_rows && group(r1) == group(r)) ++r1;
+    int64_t total = 0, longest = 0;
+    for (int q = r; q < r1; ++q) {
+      const int64_t len = ptr[q + 1] - ptr[q];
+      total += std::max<int64_t>(len, 1);  // empty rows carry one null arc
+      longest = std::max(longest, len);
     }
-    const int64_t len_eff = std::max<int64_t>(len, 1);  // empty rows carry one null arc
-    if (cur_arcs + len_eff > kChunkArcs || (int)cur.size() + 1 > kMaxRows) flush(r);
-    cur.push_back({r, lo, hi});
-    cur_arcs += len_eff;
+    const bool grouped = r1 - r > 1;
+    if (longest > kChunkArcs || (grouped && (total > kChunkArcs || r1 - r > kMaxRows))) {
+      // does not fit a chunk: every row of the group in single-row atomic chunks of <= kChunkArcs arcs
+      flush(r);
+      for (int q = r; q < r1; ++q) {
+        const int64_t lo = ptr[q], hi = ptr[q + 1];
+        if (lo == hi && grouped) { emit_chunk({{q, lo, hi}}, q, 1, 1); continue; }
+        for (int64_t s = lo; s < hi; s += kChunkArcs) emit_chunk({{q, s, std::min(hi, s + kChunkArcs)}}, q, 1, 1);
+      }
+      cur_row0 = r1;
+    } else {
+      if (cur_arcs + total > kChunkArcs || (int)cur.size() + (r1 - r) > kMaxRows) flush(r);
+      for (int q = r; q < r1; ++q) cur.push_back({q, ptr[q], ptr[q + 1]});
+      cur_arcs += total;
+    }
+    r = r1;
   }
   flush(num_rows);
   out->n_chunks = (int)out->row0.size();
@@ -151,9 +171,9 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src, cons
   }
   std::vector<float> piprob(A);
   for (int64_t i = 0; i < A; ++i) piprob[i] = g->pi[src[i]] * prob[i];
-  build_ordering(A, S, dst, src, pdf, prob, piprob.data(), &g->h_fwd);   // alpha: rows = dst
-  build_ordering(A, S, src, dst, pdf, prob, piprob.data(), &g->h_bwd);   // beta : rows = src
-  build_ordering(A, P, pdf, src, dst, prob, piprob.data(), &g->h_gam);   // gamma: rows = pdf
+  build_ordering(A, S, dst, src, pdf, prob, piprob.data(), &g->h_fwd, nullptr, true, false);   // alpha: rows = dst
+  build_ordering(A, S, src, dst, pdf, prob, piprob.data(), &g->h_bwd, nullptr, true, false);   // beta : rows = src
+  build_ordering(A, P, pdf, src, dst, prob, piprob.data(), &g->h_gam, nullptr, true, false);   // gamma: rows = pdf
   // pdf as a function of the destination state?
   {
     std::vector<int32_t> spdf(S, -1);
@@ -172,6 +192,39 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src, cons
       std::vector<int32_t> cur(g->ps_off.begin(), g->ps_off.end() - 1);
       for (int s = 0; s < S; ++s) if (spdf[s] >= 0) g->ps_state[cur[spdf[s]]++] = s;
     }
+  }
+  // Virtual states: distinct (dst, pdf) pairs in (dst, pdf) order; a state nobody enters gets one with pdf -1.
+  {
+    std::vector<int64_t> order(A);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+      return dst[x] != dst[y] ? dst[x] < dst[y] : pdf[x] < pdf[y];
+    });
+    std::vector<int32_t> arc_v(A);
+    g->voff.assign(S + 1, 0);
+    g->vpdf.clear();
+    std::vector<int32_t> vstate;
+    int64_t k = 0;
+    for (int d = 0; d < S; ++d) {
+      g->voff[d] = (int32_t)g->vpdf.size();
+      if (k == A || dst[order[k]] != d) { g->vpdf.push_back(-1); vstate.push_back(d); continue; }
+      while (k < A && dst[order[k]] == d) {
+        const int32_t q = pdf[order[k]];
+        g->vpdf.push_back(q); vstate.push_back(d);
+        while (k < A && dst[order[k]] == d && pdf[order[k]] == q) arc_v[order[k++]] = (int32_t)g->vpdf.size() - 1;
+      }
+    }
+    g->V = (int32_t)g->vpdf.size();
+    g->voff[S] = g->V;
+    // the 8-byte-record orderings of the state-x kernels
+    build_ordering(A, g->V, arc_v.data(), src, pdf, prob, piprob.data(), &g->h_fwdv, vstate.data(), false, true);
+    build_ordering(A, S, src, arc_v.data(), pdf, prob, piprob.data(), &g->h_bwdv, nullptr, false, true);
+    g->pv_off.assign(P + 1, 0);
+    for (int v = 0; v < g->V; ++v) if (g->vpdf[v] >= 0) g->pv_off[g->vpdf[v] + 1]++;
+    for (int p = 0; p < P; ++p) g->pv_off[p + 1] += g->pv_off[p];
+    g->pv_virt.assign(std::max(1, g->pv_off[P]), 0);
+    std::vector<int32_t> cur(g->pv_off.begin(), g->pv_off.end() - 1);
+    for (int v = 0; v < g->V; ++v) if (g->vpdf[v] >= 0) g->pv_virt[cur[g->vpdf[v]]++] = v;
   }
   *out = g;
   return PK2_OK;
@@ -198,6 +251,8 @@ static int upload_ordering(pk2_den_graph* g, const HostOrdering& h, DevOrdering*
   if ((rc = upload_vec(g, h.row0, &d->row0))) return rc;
   if ((rc = upload_vec(g, h.nrows, &d->nrows))) return rc;
   if ((rc = upload_vec(g, h.atomic, &d->atomic))) return rc;
+  if ((rc = upload_vec(g, h.real0, &d->real0))) return rc;
+  if ((rc = upload_vec(g, h.nreal, &d->nreal))) return rc;
   d->n_chunks = h.n_chunks;
   return PK2_OK;
 }
@@ -209,6 +264,12 @@ int den_upload(pk2_den_graph* g) {
   if ((rc = upload_ordering(g, g->h_fwd, &g->fwd))) return rc;
   if ((rc = upload_ordering(g, g->h_bwd, &g->bwd))) return rc;
   if ((rc = upload_ordering(g, g->h_gam, &g->gam))) return rc;
+  if ((rc = upload_ordering(g, g->h_fwdv, &g->fwdv))) return rc;
+  if ((rc = upload_ordering(g, g->h_bwdv, &g->bwdv))) return rc;
+  if ((rc = upload_vec(g, g->voff, &g->d_voff))) return rc;
+  if ((rc = upload_vec(g, g->vpdf, &g->d_vpdf))) return rc;
+  if ((rc = upload_vec(g, g->pv_off, &g->d_pv_off))) return rc;
+  if ((rc = upload_vec(g, g->pv_virt, &g->d_pv_virt))) return rc;
   const float* dpi = nullptr;
   if ((rc = upload_vec(g, g->pi, &dpi))) return rc;
   if (g->state_pdf_unique) {
@@ -279,22 +340,49 @@ extern "C" int pk2_den_graph_initial_probs(const pk2_den_graph* g, float* host_o
 // Test hook: arcs per lane of a wave block (kK), needed to decode the orderings below.
 extern "C" int32_t pk2_den_graph_arcs_per_lane(void) { return kK; }
 
-// Test hook: copies one host-side ordering out (which: 0 = by dst, 1 = by src, 2 = by pdf).
+// Test hook: copies one host-side ordering out (which: 0 = by dst, 1 = by src, 2 = by pdf; the state-x kernels' orderings:
+// 3 = by virtual destination state, 4 = by src gathering virtual destination states; their 8-byte records {a, prob} come
+// out as {a, 0, prob, 0}).
 // Sizes are queried by passing null buffers.  meta_out receives two uint32 per lane: {first row, flush mask}.
 extern "C" int pk2_den_graph_debug_ordering(const pk2_den_graph* g, int which, int64_t* n_arcs_padded,
                                             int32_t* n_chunks, int32_t* arcs_out /* int4 */,
                                             uint32_t* meta_out, int32_t* wb_off_out,
                                             int32_t* row0_out, int32_t* nrows_out,
                                             int32_t* atomic_out) {
-  PK2_REQUIRE(g && which >= 0 && which < 3, "debug ordering: bad args");
-  const HostOrdering& h = which == 0 ? g->h_fwd : (which == 1 ? g->h_bwd : g->h_gam);
-  if (n_arcs_padded) *n_arcs_padded = (int64_t)h.arcs.size();
+  PK2_REQUIRE(g && which >= 0 && which < 5, "debug ordering: bad args");
+  const HostOrdering* hs[5] = {&g->h_fwd, &g->h_bwd, &g->h_gam, &g->h_fwdv, &g->h_bwdv};
+  const HostOrdering& h = *hs[which];
+  const size_t n = which < 3 ? h.arcs.size() : h.arcs2.size();
+  if (n_arcs_padded) *n_arcs_padded = (int64_t)n;
   if (n_chunks) *n_chunks = h.n_chunks;
-  if (arcs_out) memcpy(arcs_out, h.arcs.data(), h.arcs.size() * sizeof(int4));
+  if (arcs_out && which < 3) memcpy(arcs_out, h.arcs.data(), n * sizeof(int4));
+  if (arcs_out && which >= 3)
+    for (size_t i = 0; i < n; ++i) {
+      arcs_out[4 * i] = h.arcs2[i].x; arcs_out[4 * i + 1] = 0; arcs_out[4 * i + 2] = h.arcs2[i].y; arcs_out[4 * i + 3] = 0;
+    }
   if (meta_out) memcpy(meta_out, h.meta.data(), h.meta.size() * sizeof(uint2));
   if (wb_off_out) memcpy(wb_off_out, h.wb_off.data(), h.wb_off.size() * sizeof(int32_t));
   if (row0_out) memcpy(row0_out, h.row0.data(), h.row0.size() * sizeof(int32_t));
   if (nrows_out) memcpy(nrows_out, h.nrows.data(), h.nrows.size() * sizeof(int32_t));
   if (atomic_out) memcpy(atomic_out, h.atomic.data(), h.atomic.size() * sizeof(int32_t));
+  return PK2_OK;
+}
+
+// Test hook: the virtual states (chain_internal.h) and the per-chunk extras of ordering `which` (3 or 4): voff_out[S+1],
+// vpdf_out[V], real0_out / nreal_out / slot0_out [n_chunks], row_leak_out [sum of nrows].  Null buffers are skipped;
+// *num_virtual and *n_row_leak return the sizes.
+extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, int32_t* num_virtual, int32_t* voff_out,
+                                           int32_t* vpdf_out, int32_t* real0_out, int32_t* nreal_out,
+                                           int32_t* slot0_out, int64_t* n_row_leak, float* row_leak_out) {
+  PK2_REQUIRE(g && (which == 3 || which == 4), "debug virtual: bad args");
+  const HostOrdering& h = which == 3 ? g->h_fwdv : g->h_bwdv;
+  if (num_virtual) *num_virtual = g->V;
+  if (voff_out) memcpy(voff_out, g->voff.data(), g->voff.size() * sizeof(int32_t));
+  if (vpdf_out) memcpy(vpdf_out, g->vpdf.data(), g->vpdf.size() * sizeof(int32_t));
+  if (real0_out) memcpy(real0_out, h.real0.data(), h.real0.size() * sizeof(int32_t));
+  if (nreal_out) memcpy(nreal_out, h.nreal.data(), h.nreal.size() * sizeof(int32_t));
+  if (slot0_out) memcpy(slot0_out, h.slot0.data(), h.slot0.size() * sizeof(int32_t));
+  if (n_row_leak) *n_row_leak = (int64_t)h.row_leak.size();
+  if (row_leak_out) memcpy(row_leak_out, h.row_leak.data(), h.row_leak.size() * sizeof(float));
   return PK2_OK;
 }

@@ -43,6 +43,8 @@ struct HostOrdering {
   std::vector<int32_t> row0;     // [n_chunks]
   std::vector<int32_t> nrows;    // [n_chunks]
   std::vector<int32_t> atomic;   // [n_chunks]
+  std::vector<int32_t> real0;    // [n_chunks]: group (real state) of the chunk's first row   (grouped orderings only)
+  std::vector<int32_t> nreal;    // [n_chunks]: number of groups the chunk's rows belong to    (grouped orderings only)
   int n_chunks = 0;
 };
 
@@ -56,6 +58,8 @@ struct DevOrdering {
   const int32_t* row0 = nullptr;
   const int32_t* nrows = nullptr;
   const int32_t* atomic = nullptr;
+  const int32_t* real0 = nullptr;
+  const int32_t* nreal = nullptr;
   int n_chunks = 0;
 };
 
@@ -74,11 +78,23 @@ struct pk2_den_graph {
   const int32_t* d_ps_off = nullptr;
   const int32_t* d_ps_state = nullptr;
   double pi_sum = 0.0;
-  pk2::HostOrdering h_fwd, h_bwd, h_gam;  // keyed by dst / src / pdf
+  pk2::HostOrdering h_fwd, h_bwd, h_gam;  // keyed by dst / src / pdf (general kernels)
+  // "Virtual states" of the state-x kernels: v = a distinct (destination state, pdf) pair over the arcs, numbered
+  // by (state, pdf), so the virtual states of state d are voff[d] .. voff[d+1]-1 (a state without incoming arcs has
+  // one with pdf -1).  exp(logit) is a per-VIRTUAL-state factor for any graph; V == S when every state's incoming
+  // arcs carry one pdf.  A Kaldi chain graph (forward pdf on the entering arcs, self-loop pdf on the loop) has V ~ 2S.
+  int32_t V = 0;
+  std::vector<int32_t> voff, vpdf;        // [S+1], [V]
+  std::vector<int32_t> pv_off, pv_virt;   // virtual states grouped by pdf (CSR over P)
+  pk2::HostOrdering h_fwdv, h_bwdv;       // rows = virtual dst gathering src | rows = src gathering virtual dst
+  const int32_t* d_voff = nullptr;
+  const int32_t* d_vpdf = nullptr;
+  const int32_t* d_pv_off = nullptr;
+  const int32_t* d_pv_virt = nullptr;
   // device copies, created lazily on the first compute call
   bool uploaded = false;
   int device = -1;
-  pk2::DevOrdering fwd, bwd, gam;
+  pk2::DevOrdering fwd, bwd, gam, fwdv, bwdv;
   float* d_pi = nullptr;
   std::vector<void*> allocs;
 };
@@ -95,7 +111,8 @@ struct DenGeom {
 
 struct DenBuffers {
   float* alpha;   // [G][Tmax+1][S][NG]  alpha (before the leaky term)
-  float* beta;    // [G][Tmax+1][S][NG]  beta' (before the leaky term)
+  float* alphav;  // [G][Tmax+1][V][NG]  alpha per virtual state (state-x path; == alpha when V == S)
+  float* beta;    // [G][Tmax+1][S][NG]  beta' (before the leaky term); state-x path: [G][Tmax+1][V][2*NG] {btilde', x}
   float* xs;      // [G][Tmax][P][NG]    exp(clamp(logits)), sequences interleaved
   float* gamma;   // [G][Tmax][P][NG]    occupancies
   float* apart;   // [G][Tmax+1][nc_fwd][NG]
@@ -105,11 +122,12 @@ struct DenBuffers {
   float* den_lp;  // [G*NG]
   float* check;   // [G*NG]
   int32_t* lengths;  // [G*NG] device copy (0 for the padding sequences)
-  float* csum;    // [G][Tmax+1][NG]  sum_k pi[k] btilde'[t,k]   (state-x path)
+  float* csum;    // [G][Tmax+1][2][NG]  {cu[t], sum_k pi[k] btilde'[t,k] / cu[t]}   (state-x path, chain_den.hip)
   float* kscale;  // [G][Tmax+1][NG]  beta[t] = kscale[t] * betahat[t] (state-x path)
 };
 
 int den_choose_ng(const pk2_den_graph* g);
+bool den_use_sx(const pk2_den_graph* g);
 size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, DenBuffers* buf,
                      void* base);
 struct NumDeferred;

@@ -72,8 +72,16 @@ def pdf_alignment(rng, num_frames, num_pdfs):
     return out
 
 
-def den_graph_arcs(num_states=30000, num_arcs=1000000, num_pdfs=6048, seed=0):
+def den_graph_arcs(num_states=30000, num_arcs=1000000, num_pdfs=6048, seed=0, loop_pdf_differs=False,
+                   multi_entry_frac=0.0):
     """Phone-structured synthetic denominator graph.
+
+    ``loop_pdf_differs=True`` gives the graph Kaldi's chain topology produces (one HMM state per phone with
+    ForwardPdfClass != SelfLoopPdfClass, self-loops added after the forward transition): the arcs ENTERING a state carry
+    its forward pdf, its self-loop carries a different (self-loop) pdf, so the pdf is no longer a function of the
+    destination state -- every looping state has two entering pdfs.  ``multi_entry_frac`` additionally gives that
+    fraction of the states a second forward pdf on half of their entering arcs (states merged by minimisation across
+    phonetic contexts).
 
     States come in pairs (a 2-state left-to-right "phone"): the entry state has
     a self loop and a forward arc to the exit state; the exit state has a self
@@ -107,6 +115,15 @@ def den_graph_arcs(num_states=30000, num_arcs=1000000, num_pdfs=6048, seed=0):
     tot = np.bincount(src, weights=w, minlength=S)
     prob = w / tot[src]
     pdf = state_pdf[dst]
+    if loop_pdf_differs:
+        loop_pdf = (state_pdf + 1 + rng.integers(0, max(1, num_pdfs - 1), size=S)) % num_pdfs   # != state_pdf for P > 1
+        is_loop = src == dst
+        pdf = np.where(is_loop, loop_pdf[dst], pdf)
+    if multi_entry_frac > 0:
+        alt_pdf = rng.integers(0, num_pdfs, size=S)
+        multi = rng.random(S) < multi_entry_frac
+        flip = multi[dst] & (src != dst) & (rng.random(src.shape[0]) < 0.5)
+        pdf = np.where(flip, alt_pdf[dst], pdf)
     order = np.lexsort((dst, src))
     return dict(num_states=S, start=0, num_pdfs=int(num_pdfs),
                 src=src[order].astype(np.int32), dst=dst[order].astype(np.int32),

@@ -88,6 +88,75 @@ def test_den_graph_orderings_reproduce_segment_sums(case):
     assert np.abs(got - np.bincount(pdf, weights=al[src] * prob * be[dst], minlength=P)).max() < 1e-9
 
 
+@pytest.mark.parametrize("case", ["unique", "chain_topology", "multi_entry", "bigstate", "arc_pdf"])
+def test_den_graph_virtual_state_orderings(case):
+    """The state-x kernels' decomposition (chain_internal.h): virtual states = distinct (dst, pdf) pairs; the forward
+    ordering's rows are virtual states with the rows of one state inside one chunk, the backward ordering gathers by
+    virtual destination.  A numpy model of the kernels' arithmetic over these tables reproduces
+    alpha[d] = sum_arcs alpha[src] prob x[pdf] and beta[s] = sum_arcs prob x[pdf] beta[dst] for ANY graph."""
+    S, A, P, seed = 300, 6000, 23, 7
+    kw = dict(unique={}, chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_pdf_differs=True, multi_entry_frac=0.3),
+              bigstate=dict(loop_pdf_differs=True), arc_pdf={})[case]
+    if case == "bigstate":
+        S, A = 200, 20000
+    g = synth.den_graph_arcs(S, A, P, seed, **kw)
+    rng = np.random.default_rng(seed)
+    if case == "bigstate":   # state 5: > 4096 entering arcs over three pdfs, one of the rows alone > 4096
+        g["dst"][:9000] = 5
+        g["pdf"][:5000] = 1; g["pdf"][5000:8000] = 2; g["pdf"][8000:9000] = 3
+    if case == "arc_pdf":
+        g["pdf"] = rng.integers(0, P, size=g["pdf"].shape[0]).astype(np.int32)
+    G = chain.DenominatorGraph(g, P)
+    S_ = g["num_states"]
+    src, dst, pdf, prob = g["src"], g["dst"], g["pdf"], g["prob"].astype(np.float64)
+    of, ob = G.debug_ordering(3), G.debug_ordering(4)
+    voff, vpdf = of["voff"], of["vpdf"]
+    V = vpdf.shape[0]
+    # virtual states are the distinct (dst, pdf) pairs in order, one pdf -1 entry for states nobody enters
+    pairs = sorted(set(zip(dst.tolist(), pdf.tolist())) | {(d, -1) for d in set(range(S_)) - set(dst.tolist())})
+    assert V == len(pairs) and voff[0] == 0 and voff[-1] == V
+    vstate = np.repeat(np.arange(S_), np.diff(voff))
+    assert [(int(a), int(b)) for a, b in zip(vstate, vpdf)] == pairs
+    if case == "unique":
+        assert V == S_
+    if case == "chain_topology":
+        assert V > 1.9 * S_ * 0.5   # every looping state has two entering pdfs
+    al, be, x = rng.random(S_), rng.random(S_), rng.random(P)
+    pi = G.initial_probs().astype(np.float64)
+    xv = np.where(vpdf >= 0, x[np.maximum(vpdf, 0)], 1.0)
+    # forward: row sums over virtual rows, then x per virtual row, then the sum over the rows of a state
+    rows = _emulate(of, V, lambda a, b, p, pp: al[a] * p)
+    want_rows = np.zeros(V)
+    key = {pr: i for i, pr in enumerate(pairs)}
+    arc_v = np.array([key[(int(d), int(q))] for d, q in zip(dst, pdf)])
+    np.add.at(want_rows, arc_v, al[src] * prob)
+    assert np.abs(rows - want_rows).max() < 1e-9
+    got = np.bincount(vstate, weights=rows * xv, minlength=S_)
+    assert np.abs(got - np.bincount(dst, weights=al[src] * prob * x[pdf], minlength=S_)).max() < 1e-9
+    # the per-(chunk, row) leaky term
+    leak = np.zeros(V)
+    for ch in range(len(of["row0"])):
+        n = of["nrows"][ch]
+        leak[of["row0"][ch]:of["row0"][ch] + n] += of["row_leak"][of["slot0"][ch]:of["slot0"][ch] + n]
+    want_leak = np.zeros(V)
+    np.add.at(want_leak, arc_v, pi[src] * prob)
+    assert np.abs(leak - want_leak).max() < 1e-6
+    # chunk invariants: the rows of a state share a chunk unless the chunk is a single-row atomic one
+    for ch in range(len(of["row0"])):
+        r0, n, at = of["row0"][ch], of["nrows"][ch], of["atomic"][ch]
+        assert of["real0"][ch] == vstate[r0] and of["nreal"][ch] == vstate[r0 + n - 1] - vstate[r0] + 1
+        if at:
+            assert n == 1
+        else:
+            assert r0 == voff[vstate[r0]] and r0 + n == voff[vstate[r0 + n - 1] + 1]
+    if case == "bigstate":
+        assert of["atomic"].sum() >= 4
+    # backward: gather index = virtual destination
+    bev = be[vstate] * xv
+    got = _emulate(ob, S_, lambda a, b, p, pp: bev[a] * p)
+    assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
+
+
 def test_openfst_den_fst_reader(tmp_path):
     """Hand-assembled OpenFst binary: vector / standard, version 2."""
     arcs = {0: [(1, 1, 0.5, 1), (2, 2, 1.5, 0)], 1: [(3, 3, 0.25, 0), (1, 1, 0.0, 1)]}
