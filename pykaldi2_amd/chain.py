@@ -94,17 +94,21 @@ class DenominatorGraph:
                                                   _lib.ptr(atomic)))
         out = dict(arcs=arcs, meta=meta, wb_off=wb_off, row0=row0, nrows=nrows, atomic=atomic, arcs_per_lane=k)
         if which >= 3:
-            nv, nl = C.c_int32(), C.c_int64()
+            nv, nl, no = C.c_int32(), C.c_int64(), C.c_int32()
             _lib.check(L.pk2_den_graph_debug_virtual(self._h, which, C.byref(nv), None, None, None, None, None,
-                                                     C.byref(nl), None))
-            voff = np.empty(self._num_states + 1, dtype=np.int32)
-            vpdf = np.empty(nv.value, dtype=np.int32)
+                                                     C.byref(nl), None, None, None, C.byref(no), None, None))
+            S = self._num_states
+            voff, ooff = np.empty(S + 1, dtype=np.int32), np.empty(S + 1, dtype=np.int32)
+            vpdf, opdf = np.empty(nv.value, dtype=np.int32), np.empty(no.value, dtype=np.int32)
             real0, nreal, slot0 = (np.empty(nc.value, dtype=np.int32) for _ in range(3))
             leak = np.empty(nl.value, dtype=np.float32)
+            loop_pdf, loop_prob = np.empty(S, dtype=np.int32), np.empty(S, dtype=np.float32)
             _lib.check(L.pk2_den_graph_debug_virtual(self._h, which, None, _lib.ptr(voff), _lib.ptr(vpdf),
                                                      _lib.ptr(real0), _lib.ptr(nreal), _lib.ptr(slot0), None,
-                                                     _lib.ptr(leak)))
-            out.update(voff=voff, vpdf=vpdf, real0=real0, nreal=nreal, slot0=slot0, row_leak=leak)
+                                                     _lib.ptr(leak), _lib.ptr(loop_pdf), _lib.ptr(loop_prob), None,
+                                                     _lib.ptr(ooff), _lib.ptr(opdf)))
+            out.update(voff=voff, vpdf=vpdf, real0=real0, nreal=nreal, slot0=slot0, row_leak=leak,
+                       loop_pdf=loop_pdf, loop_prob=loop_prob, ooff=ooff, opdf=opdf)
         return out
 
     def __del__(self):

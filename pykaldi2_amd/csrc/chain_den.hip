@@ -98,6 +98,70 @@ __device__ __forceinline__ void block_sum2(float (&u)[NG], float (&v)[NG], float
   }
 }
 
+// Atomic-free row sums of the state-x kernels.  A lane owns kK consecutive arcs of the row-sorted list; rows that end
+// inside the lane after its first row end are complete there (plain LDS store by the caller); the sum up to the first
+// row end (`head`) still lacks what earlier lanes of the wave accumulated for that row, and the sum after the last row
+// end (`tail`, the whole lane when no row ends in it) belongs to a row that ends in a later lane.  A segmented scan
+// over the lanes (segments start at lanes with a row end) delivers the carry; the wave's own carry-out goes to
+// `wcarry` and is added by the row epilogue (rows crossing a wave block).  LDS float atomics cost ~3 clocks per LANE on
+// gfx950 (measured: 1.7 us of a 19 us frame), this costs 6 x (NG + 1) cross-lane moves per wave.
+// DPP cross-lane moves (full-rate VALU, no LDS round trip): lanes whose source lies outside the 16-lane row / is masked
+// receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+
+template <int NG, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_step(float (&x)[NG], int& fl) {
+  float y[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) y[n] = dpp_f<CTRL, ROW_MASK>(x[n]);
+  const int g = dpp_i<CTRL, ROW_MASK>(fl);
+#pragma unroll
+  for (int n = 0; n < NG; ++n) x[n] += fl ? 0.f : y[n];
+  fl |= g;
+}
+
+template <int NG>
+__device__ __forceinline__ void seg_carry_store(const float (&tail)[NG], const float (&head)[NG], int first_row,
+                                                float* acc, float* wcarry) {
+  const int lane = threadIdx.x & 63;
+  float x[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) x[n] = tail[n];
+  int fl = first_row >= 0 ? 1 : 0;
+  // segmented inclusive scan: row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast15 into rows 1 and 3 and
+  // row_bcast31 into rows 2 and 3 (the gfx9 wave64 scan, with the segment flag travelling along)
+  seg_scan_step<NG, 0x111, 0xf>(x, fl);
+  seg_scan_step<NG, 0x112, 0xf>(x, fl);
+  seg_scan_step<NG, 0x114, 0xf>(x, fl);
+  seg_scan_step<NG, 0x118, 0xf>(x, fl);
+  seg_scan_step<NG, 0x142, 0xa>(x, fl);
+  seg_scan_step<NG, 0x143, 0xc>(x, fl);
+  float v[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) v[n] = head[n] + dpp_f<0x138, 0xf>(x[n]);    // wave_shr:1 -- lane 0 receives 0
+  if (first_row >= 0) stv<NG>(acc + (size_t)first_row * NG, v);
+  if (lane == 63) stv<NG>(wcarry, x);
+}
+
+// Row r of the chunk: the stored sum plus the carry-outs of the wave blocks whose last row it is.
+template <int NG>
+__device__ __forceinline__ void row_value(const float* acc, const float* wcarry, const int (&crow)[kDenWaves], int r,
+                                          float (&v)[NG]) {
+  ldv<NG>(acc + (size_t)r * NG, v);
+#pragma unroll
+  for (int k = 0; k + 1 < kDenWaves; ++k) {       // the last block's carry-out is always zero (the chunk ends with a row end)
+    if (crow[k] == r) {
+#pragma unroll
+      for (int n = 0; n < NG; ++n) v[n] += wcarry[k * NG + n];
+    }
+  }
+}
+
 struct IntPack { static constexpr int kN = 64; int32_t v[kN]; };
 __global__ void store_ints(IntPack pack, int count, int32_t* out) {
   if ((int)threadIdx.x < count) out[threadIdx.x] = pack.v[threadIdx.x];
@@ -112,13 +176,18 @@ struct DenParams {
   float* alpha; float* beta; float* xs; float* gamma;
   float* apart; float* bpart; float* asum; float* inv_tot;
   const int32_t* lengths;
-  const int32_t* ps_off;    // virtual states grouped by pdf (CSR over P)
+  // state-x path (chain_internal.h: peeled self-loops, virtual states, occupancy states); fwd / bwd are then the
+  // fwdv / bwdv orderings
+  const int32_t* ps_off;    // occupancy states grouped by pdf (CSR over P)
   const int32_t* ps_state;
-  // state-x path (virtual states, chain_internal.h): fwd / bwd are then the fwdv / bwdv orderings
   const int32_t* voff;      // [S+1] first virtual state of a state
-  const int32_t* vpdf;      // [V] pdf of a virtual state (-1: nobody enters the state)
-  float* alphav;            // [G][Tmax+1][V][NG]; == alpha when V == S
-  int V;
+  const int32_t* ooff;      // [S+1] first occupancy state of a state
+  const int32_t* opdf;      // [Vo] pdf of an occupancy state (-1: none)
+  const int32_t* ovirt;     // [Vo] first virtual state of the occupancy state's state (its record holds btilde')
+  const float* loop_prob;   // [S] probability of the peeled self-loop (0: none)
+  float* alphav;            // [G][Tmax+1][Vo][NG]; == alpha when Vo == S
+  const float* xl;          // [G][Tmax][S][NG] exp(logit) of the peeled self-loop's pdf
+  int V, Vo;
   int S, P, Tmax;
   float leaky, pi_sum;
   float wu;    // kBetaFloor * sum(pi)/S: uniform floor of the backward normaliser's weights (state-x path)
@@ -617,7 +686,7 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
     lkr[n] = p.leaky * rv[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
-  const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.V * NG;
+  const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.Vo * NG;       // per occupancy state
   const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
   float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
   for (int pdf = tid; pdf < p.P; pdf += 256) {
@@ -628,7 +697,7 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
       const int s = p.ps_state[k];
       float a[NG], b[NG];
       ldv<NG>(alpha_n + (size_t)s * NG, a);
-      ldv<NG>(beta_n + (size_t)s * (2 * NG), b);
+      ldv<NG>(beta_n + (size_t)p.ovirt[s] * (2 * NG), b);
 #pragma unroll
       for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] * inv_c[n] + lkr[n] : cst[n]);
     }
@@ -641,7 +710,10 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
 // The same sums with the states walked IN ORDER (coalesced alpha / beta rows at streaming speed instead of two
 // dependent gathers per state through the pdf -> states lists) and one row of P x NG occupancies accumulated in LDS
 // with ds_add_f32 (97 KB for P = 6048, NG = 4); used whenever that row fits.
-constexpr int kGammaThreads = 512;
+#ifndef PK2_GAMMA_ABL
+#define PK2_GAMMA_ABL 0
+#endif
+constexpr int kGammaThreads = 1024;   // one workgroup per CU (the LDS row): 16 waves keep 4 x 3 loads each in flight
 constexpr size_t kGammaMaxLds = 144 * 1024;
 template <int NG>
 __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, const float* csum, const float* Kf, int t, int g,
@@ -663,30 +735,43 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
   }
   for (int i = tid; i < p.P * NG; i += kGammaThreads) acc[i] = 0.f;
   __syncthreads();
-  const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.V * NG;
+  const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.Vo * NG;      // per occupancy state
   const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
-  for (int s0 = tid; s0 < p.V; s0 += 4 * kGammaThreads) {
-    float a[4][NG], b[4][NG]; int pdf[4];
+  for (int s0 = tid; s0 < p.Vo; s0 += 4 * kGammaThreads) {
+    float a[4][NG], b[4][NG]; int pdf[4], vi[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int s = s0 + q * kGammaThreads;
-      pdf[q] = -1;
-      if (s < p.V) {
-        pdf[q] = p.vpdf[s];
+      pdf[q] = -1; vi[q] = 0;
+      if (s < p.Vo) {
+        pdf[q] = p.opdf[s];
+        vi[q] = p.ovirt[s];
         ldv<NG>(alpha_n + (size_t)s * NG, a[q]);
-        ldv<NG>(beta_n + (size_t)s * (2 * NG), b[q]);
       }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#if PK2_GAMMA_ABL == 2
+      if (pdf[q] >= 0) ldv<NG>(beta_n + (size_t)(s0 & 1023) * (2 * NG), b[q]);
+#else
+      if (pdf[q] >= 0) ldv<NG>(beta_n + (size_t)vi[q] * (2 * NG), b[q]);
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (pdf[q] < 0) continue;
 #pragma unroll
-      for (int n = 0; n < NG; ++n) atomicAdd(&acc[pdf[q] * NG + n], a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]));
+#if PK2_GAMMA_ABL == 1
+      for (int n = 0; n < NG; ++n) acc[n * p.P + pdf[q]] = a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]);
+#else
+      for (int n = 0; n < NG; ++n) atomicAdd(&acc[n * p.P + pdf[q]], a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]));
+#endif
     }
   }
   __syncthreads();
   float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
-  for (int i = tid; i < p.P * NG; i += kGammaThreads) gam_t[i] = acc[i] * kv[i % NG];
+  // the LDS row is sequence-major (acc[n][pdf]: the lanes of one ds_add_f32 then spread over all banks instead of
+  // every fourth one); the occupancies go out pdf-major
+  for (int i = tid; i < p.P * NG; i += kGammaThreads) gam_t[i] = acc[(i % NG) * p.P + i / NG] * kv[i % NG];
 }
 
 template <int NG>
@@ -733,12 +818,16 @@ __global__ void __launch_bounds__(LDS_ROW ? kGammaThreads : 256) den_gamma_state
 // Neither kernel stages the P x NG table of exp(logits) in LDS (saves 97 KB of LDS and 24 MB of
 // L2 traffic per frame and direction); they keep only the 16 KB row accumulator.
 // ----------------------------------------------------------------------------------------
-// bx[g][t+1][v][NG + n] = exp(clamp(logit[seq(g,n)][t][pdf(v)]))   (1 for finished sequences), v = virtual state
+// exp(clamp(logit[seq(g,n)][t][pdf(i)])) for a table of pdfs (1 where pdf < 0 and for finished sequences), written as
+// records of `rec` floats per entry with the NG values at float offset `xo` (the floats before them are zeroed):
+//   bx: entry = virtual state v, record {btilde' = 0, x} of frame t+1 (rec = 2*NG, xo = NG, frame_shift = 1);
+//   xl: entry = state, x of its peeled self-loop's pdf, frame t (rec = NG, xo = 0, frame_shift = 0).
 template <int NG>
-__global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ logits, int64_t seq_stride,
-                                                      int64_t frame_stride, const int32_t* __restrict__ lengths,
-                                                      const int32_t* __restrict__ state_pdf /* vpdf[V] */, float* __restrict__ bx,
-                                                      int S /* = V */, int Tmax) {
+__device__ __forceinline__ void den_exp_table(const float* __restrict__ logits, int64_t seq_stride,
+                                              int64_t frame_stride, const int32_t* __restrict__ lengths,
+                                              const int32_t* __restrict__ entry_pdf, float* __restrict__ out_base,
+                                              int S /* entries */, int frames_per_group, int frame_shift, int rec, int xo,
+                                              int slice, int num_slices) {
   const int t = blockIdx.x, g = blockIdx.y;
   const float* rows[NG]; bool live[NG];
 #pragma unroll
@@ -747,14 +836,14 @@ __global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ 
     live[n] = t < lengths[seq];
     rows[n] = logits + (int64_t)seq * seq_stride + (int64_t)t * frame_stride;
   }
-  // The whole {btilde', x} record of a state is written (btilde' = 0 until the backward frame fills it): full 32-byte
-  // records coalesce into whole lines, the x halves alone are partial-line writes.  Four states per thread and pass
-  // keep the 4 x NG row gathers of each in flight together.
-  float* out = bx + ((size_t)g * (Tmax + 1) + t + 1) * (size_t)S * (2 * NG);
-  for (int d0 = threadIdx.x; d0 < S; d0 += 4 * 256) {
+  // The whole {btilde', x} record of a virtual state is written (btilde' = 0 until the backward frame fills it): full
+  // 32-byte records coalesce into whole lines, the x halves alone are partial-line writes.  Four entries per thread and
+  // pass keep the 4 x NG row gathers of each in flight together.
+  float* out = out_base + ((size_t)g * frames_per_group + t + frame_shift) * (size_t)S * rec;
+  for (int d0 = slice * (4 * 256) + threadIdx.x; d0 < S; d0 += num_slices * (4 * 256)) {
     int pdf[4]; float x[4][NG];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pdf[q] = d0 + q * 256 < S ? state_pdf[d0 + q * 256] : -1;
+    for (int q = 0; q < 4; ++q) pdf[q] = d0 + q * 256 < S ? entry_pdf[d0 + q * 256] : -1;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -771,14 +860,25 @@ __global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ 
         v[n] = (live[n] && pdf[q] >= 0) ? expf(xx) : 1.0f;
         zero[n] = 0.f;
       }
-      stv<NG>(out + (size_t)d * (2 * NG), zero);
-      stv<NG>(out + (size_t)d * (2 * NG) + NG, v);
+      if (xo) stv<NG>(out + (size_t)d * rec, zero);
+      stv<NG>(out + (size_t)d * rec + xo, v);
     }
   }
 }
 
+// Both tables in one launch: slices [0, zv) of grid.z write the virtual states' records, the rest the loop pdfs' x.
 template <int NG>
-__device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red) {
+__global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ logits, int64_t seq_stride, int64_t frame_stride,
+                                                      const int32_t* __restrict__ lengths, const int32_t* __restrict__ vpdf,
+                                                      float* __restrict__ bx, int V, const int32_t* __restrict__ loop_pdf,
+                                                      float* __restrict__ xl, int S, int Tmax, int zv) {
+  const int z = blockIdx.z;
+  if (z < zv) den_exp_table<NG>(logits, seq_stride, frame_stride, lengths, vpdf, bx, V, Tmax + 1, 1, 2 * NG, NG, z, zv);
+  else den_exp_table<NG>(logits, seq_stride, frame_stride, lengths, loop_pdf, xl, S, Tmax, 0, NG, 0, z - zv, (int)gridDim.z - zv);
+}
+
+template <int NG>
+__device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red, float* wcarry) {
   DEN_T0();
   const int g = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -800,6 +900,24 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   int2 rec[kK];      // {gathered state, arc probability}
   float a[kK][NG];
   uint2 meta = make_uint2(0u, 0u);
+  // what the row epilogue needs and that does not depend on this frame is fetched now, not after the arc loop
+  const int row0 = p.fwd.row0[chunk];
+  const int real0 = p.fwd.real0[chunk], nreal = p.fwd.nreal[chunk];
+  const bool atomic = p.fwd.atomic[chunk] != 0;
+  const float* leak = p.fwd.row_leak + p.fwd.slot0[chunk];     // sum of pi[src]*prob over this piece of the row
+  // first state of this thread: virtual-row range, first occupancy slot, and the peeled self-loop's inputs
+  // (alpha[t,d] was finished by the previous launch; x of the loop pdf and the probabilities are per-call constants)
+  const float* xl_t = p.xl + ((size_t)g * p.Tmax + t) * (size_t)p.S * NG;
+  int pf_lo = 0, pf_hi = 0, pf_o = 0; float pf_pl = 0.f, pf_pi = 0.f, pf_al[NG], pf_xl[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) { pf_al[n] = 0.f; pf_xl[n] = 0.f; }
+  if (tid < nreal) {
+    const int d = real0 + tid;
+    pf_lo = p.voff[d]; pf_hi = p.voff[d + 1]; pf_o = p.ooff[d];
+    pf_pl = p.loop_prob[d]; pf_pi = p.pi[d];
+    ldv<NG>(alpha_t + (size_t)d * NG, pf_al);
+    ldv<NG>(xl_t + (size_t)d * NG, pf_xl);
+  }
   if (wb < wb1) {
     meta = p.fwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
@@ -807,7 +925,11 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
 #pragma unroll
     for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)((p.debug & 1) ? 0 : rec[j].x) * NG, a[j]);
   }
-  for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
+  // carry-outs of the wave blocks (chunk-local row they belong to: crow); every row of `acc` gets exactly one store
+  int crow[kDenWaves];
+#pragma unroll
+  for (int k = 0; k < kDenWaves; ++k) crow[k] = wb0 + k < wb1 ? p.fwd.wb_crow[wb0 + k] : -1;
+  if (tid < kDenWaves * NG) wcarry[tid] = 0.f;
   DEN_T(0, 0);
   block_sum<NG, kDenWaves>(as, red);
   DEN_T(0, 1);
@@ -816,31 +938,31 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
 #pragma unroll
   for (int n = 0; n < NG; ++n) { lk[n] = p.leaky * as[n]; inv_as[n] = 1.0f / as[n]; }
   if (p.debug & 2) wb = wb1;
-  while (wb < wb1) {
-    int c = (int)meta.x;
+  if (wb < wb1) {           // one wave block per wave (a chunk has at most kDenWaves of them)
+    int c = (int)meta.x, first_row = -1;
     const uint32_t mask = meta.y;
-    float sum[NG];
+    float sum[NG], head[NG];
 #pragma unroll
-    for (int n = 0; n < NG; ++n) sum[n] = 0.f;
+    for (int n = 0; n < NG; ++n) { sum[n] = 0.f; head[n] = 0.f; }
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
       const float prob = __int_as_float(rec[j].y);
 #pragma unroll
       for (int n = 0; n < NG; ++n) sum[n] += a[j][n] * prob;
       if ((mask >> j) & 1u) {
+        if (first_row < 0) {
+          first_row = c;
 #pragma unroll
-        for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
+          for (int n = 0; n < NG; ++n) head[n] = sum[n];
+        } else {
+          stv<NG>(acc + (size_t)c * NG, sum);
+        }
+#pragma unroll
+        for (int n = 0; n < NG; ++n) sum[n] = 0.f;
         ++c;
       }
     }
-    wb += kDenWaves;
-    if (wb < wb1) {
-      meta = p.fwd.meta[(size_t)wb * 64 + lane];
-#pragma unroll
-      for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.fwd.arcs2[((size_t)wb * kK + j) * 64 + lane]);
-#pragma unroll
-      for (int j = 0; j < kK; ++j) ldv<NG>(alpha_t + (size_t)rec[j].x * NG, a[j]);
-    }
+    seg_carry_store<NG>(sum, head, first_row, acc, wcarry + (size_t)(wb - wb0) * NG);
   }
   DEN_T(0, 2);
   __syncthreads();
@@ -848,13 +970,9 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   // Rows are VIRTUAL states (dst, pdf): alpha_v[t+1,v] = x[t,pdf(v)]/asum * (sum over the row + leaky term); the alpha
   // of a state is the sum over its virtual states, which all sit in this chunk (chain_graph.hip), a thread per state.
   float* alpha_n = p.alpha + (frame + 1) * (size_t)p.S * NG;
-  float* alphav_n = p.alphav + (frame + 1) * (size_t)p.V * NG;
+  float* alphav_n = p.alphav + (frame + 1) * (size_t)p.Vo * NG;
   const bool sep = p.alphav != p.alpha;
   const float* xd = p.beta + (frame + 1) * (size_t)p.V * (2 * NG) + NG;   // x[t, pdf(v)]
-  const int row0 = p.fwd.row0[chunk];
-  const int real0 = p.fwd.real0[chunk], nreal = p.fwd.nreal[chunk];
-  const bool atomic = p.fwd.atomic[chunk] != 0;
-  const float* leak = p.fwd.row_leak + p.fwd.slot0[chunk];     // sum of pi[src]*prob over this piece of the row
   float loc[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) loc[n] = 0.f;
@@ -862,28 +980,60 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
     if (tid == 0) {
       float xv[NG];
       ldv<NG>(xd + (size_t)row0 * (2 * NG), xv);
+      const int o = pf_o + (row0 - pf_lo);
+      float a0[NG];
+      row_value<NG>(acc, wcarry, crow, 0, a0);
 #pragma unroll
       for (int n = 0; n < NG; ++n) {
-        const float v = (acc[n] + lk[n] * leak[0]) * xv[n] * inv_as[n];
+        const float v = (a0[n] + lk[n] * leak[0]) * xv[n] * inv_as[n];
         loc[n] = v;
         atomicAdd(alpha_n + (size_t)real0 * NG + n, v);
-        if (sep) atomicAdd(alphav_n + (size_t)row0 * NG + n, v);
+        if (sep) atomicAdd(alphav_n + (size_t)o * NG + n, v);
+      }
+      if (p.fwd.atomic[chunk] == 2 && pf_pl > 0.f) {   // the state's first piece also adds its peeled self-loop
+        const int ol = pf_o + (pf_hi - pf_lo);
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+          const float v = (pf_al[n] + lk[n] * pf_pi) * pf_pl * pf_xl[n] * inv_as[n];
+          loc[n] += v;
+          atomicAdd(alpha_n + (size_t)real0 * NG + n, v);
+          atomicAdd(alphav_n + (size_t)ol * NG + n, v);
+        }
       }
     }
   } else {
     for (int r = tid; r < nreal; r += kDenThreads) {
       const int d = real0 + r;
-      const int lo = p.voff[d] - row0, hi = p.voff[d + 1] - row0;
+      const bool pf = r == tid;
+      const int lo = (pf ? pf_lo : p.voff[d]) - row0, hi = (pf ? pf_hi : p.voff[d + 1]) - row0;
+      const int o0 = pf ? pf_o : p.ooff[d];
+      const float pl = pf ? pf_pl : p.loop_prob[d];
       float sum[NG];
 #pragma unroll
       for (int n = 0; n < NG; ++n) sum[n] = 0.f;
       for (int q = lo; q < hi; ++q) {
-        float v[NG], xv[NG];
+        float v[NG], xv[NG], aq[NG];
         ldv<NG>(xd + (size_t)(row0 + q) * (2 * NG), xv);
         const float lr = leak[q];
+        row_value<NG>(acc, wcarry, crow, q, aq);
 #pragma unroll
-        for (int n = 0; n < NG; ++n) { v[n] = (acc[q * NG + n] + lk[n] * lr) * xv[n] * inv_as[n]; sum[n] += v[n]; }
-        if (sep) stv<NG>(alphav_n + (size_t)(row0 + q) * NG, v);
+        for (int n = 0; n < NG; ++n) { v[n] = (aq[n] + lk[n] * lr) * xv[n] * inv_as[n]; sum[n] += v[n]; }
+        if (sep) stv<NG>(alphav_n + (size_t)(o0 + q - lo) * NG, v);
+      }
+      if (pl > 0.f) {      // peeled self-loop: alpha'[t,d] * prob * x[t, loop pdf] / asum, no gather
+        float v[NG], al[NG], xlv[NG];
+        float pis = pf_pi;
+        if (pf) {
+#pragma unroll
+          for (int n = 0; n < NG; ++n) { al[n] = pf_al[n]; xlv[n] = pf_xl[n]; }
+        } else {
+          ldv<NG>(alpha_t + (size_t)d * NG, al);
+          ldv<NG>(xl_t + (size_t)d * NG, xlv);
+          pis = p.pi[d];
+        }
+#pragma unroll
+        for (int n = 0; n < NG; ++n) { v[n] = (al[n] + lk[n] * pis) * pl * xlv[n] * inv_as[n]; sum[n] += v[n]; }
+        stv<NG>(alphav_n + (size_t)(o0 + hi - lo) * NG, v);
       }
 #pragma unroll
       for (int n = 0; n < NG; ++n) loc[n] += sum[n];
@@ -903,7 +1053,7 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
 // beta is K[t] * betahat[t] with log K[t] = log K[t+1] + log c[t] - log asum[t], K[T] = sum(pi)/tot
 // (den_scales).  Forward and backward chains therefore run concurrently on two streams.
 template <int NG>
-__device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red) {
+__device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red, float* wcarry) {
   DEN_T0();
   const int g = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -926,6 +1076,18 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
   int2 rec[kK];      // {gathered state, arc probability}
   float b[kK][NG], xv[kK][NG];
   uint2 meta = make_uint2(0u, 0u);
+  // row-epilogue inputs that do not depend on this frame
+  const int row0 = p.bwd.row0[chunk];
+  const bool atomic = p.bwd.atomic[chunk] != 0;
+  const float* xl_t = p.xl + ((size_t)g * p.Tmax + t) * (size_t)p.S * NG;
+  int pf_v0 = 0, pf_v1 = 0; float pf_pi = 0.f, pf_pl = 0.f, pf_bl[NG], pf_xl[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) { pf_bl[n] = 0.f; pf_xl[n] = 0.f; }
+  if (tid < nrows) {
+    const int s = row0 + tid;
+    pf_v0 = p.voff[s]; pf_v1 = p.voff[s + 1]; pf_pi = p.pi[s]; pf_pl = p.loop_prob[s];
+    ldv<NG>(xl_t + (size_t)s * NG, pf_xl);
+  }
   if (wb < wb1) {
     meta = p.bwd.meta[(size_t)wb * 64 + lane];
 #pragma unroll
@@ -937,7 +1099,11 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
       ldv<NG>(bx_n + gi * (2 * NG) + NG, xv[j]);
     }
   }
-  for (int i = tid; i < nrows * NG; i += kDenThreads) acc[i] = 0.f;
+  if (tid < nrows && pf_pl > 0.f) ldv<NG>(bx_n + (size_t)pf_v0 * (2 * NG), pf_bl);   // btilde'[t+1,s] for the peeled self-loop
+  int crow[kDenWaves];
+#pragma unroll
+  for (int k = 0; k < kDenWaves; ++k) crow[k] = wb0 + k < wb1 ? p.bwd.wb_crow[wb0 + k] : -1;
+  if (tid < kDenWaves * NG) wcarry[tid] = 0.f;
   DEN_T(1, 0);
   block_sum2<NG, kDenWaves>(lB, lU, red);
   DEN_T(1, 1);
@@ -958,52 +1124,62 @@ __device__ __forceinline__ void den_beta_frame_sx(const DenParams& p, int t, int
     lkr[n] = p.leaky * lB[n] * inv_c[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
-  while (wb < wb1) {
-    int c = (int)meta.x;
+  if (wb < wb1) {           // one wave block per wave
+    int c = (int)meta.x, first_row = -1;
     const uint32_t mask = meta.y;
-    float sum[NG];
+    float sum[NG], head[NG];
 #pragma unroll
-    for (int n = 0; n < NG; ++n) sum[n] = 0.f;
+    for (int n = 0; n < NG; ++n) { sum[n] = 0.f; head[n] = 0.f; }
 #pragma unroll
     for (int j = 0; j < kK; ++j) {
       const float prob = __int_as_float(rec[j].y);
 #pragma unroll
       for (int n = 0; n < NG; ++n) sum[n] += prob * xv[j][n] * (gat[n] ? b[j][n] * inv_c[n] + lkr[n] : cst[n]);
       if ((mask >> j) & 1u) {
+        if (first_row < 0) {
+          first_row = c;
 #pragma unroll
-        for (int n = 0; n < NG; ++n) { atomicAdd(&acc[c * NG + n], sum[n]); sum[n] = 0.f; }
+          for (int n = 0; n < NG; ++n) head[n] = sum[n];
+        } else {
+          stv<NG>(acc + (size_t)c * NG, sum);
+        }
+#pragma unroll
+        for (int n = 0; n < NG; ++n) sum[n] = 0.f;
         ++c;
       }
     }
-    wb += kDenWaves;
-    if (wb < wb1) {
-      meta = p.bwd.meta[(size_t)wb * 64 + lane];
-#pragma unroll
-      for (int j = 0; j < kK; ++j) rec[j] = PK2_ARC_LD(&p.bwd.arcs2[((size_t)wb * kK + j) * 64 + lane]);
-#pragma unroll
-      for (int j = 0; j < kK; ++j) {
-        ldv<NG>(bx_n + (size_t)rec[j].x * (2 * NG), b[j]);
-        ldv<NG>(bx_n + (size_t)rec[j].x * (2 * NG) + NG, xv[j]);
-      }
-    }
+    seg_carry_store<NG>(sum, head, first_row, acc, wcarry + (size_t)(wb - wb0) * NG);
   }
   DEN_T(1, 2);
   __syncthreads();
   DEN_T(1, 3);
   // rows are source states; btilde'[t,s] goes into the record of every virtual state of s
   float* bx_t = p.beta + frame * (size_t)p.V * (2 * NG);
-  const int row0 = p.bwd.row0[chunk];
-  const bool atomic = p.bwd.atomic[chunk] != 0;
   float loc[NG], locu[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) { loc[n] = 0.f; locu[n] = 0.f; }
   for (int r = tid; r < nrows; r += kDenThreads) {
     float v[NG];
     const int s = row0 + r;
-    const float pis = p.pi[s];
-    const int v0 = p.voff[s], v1 = p.voff[s + 1];
+    const bool pf = r == tid;
+    const float pis = pf ? pf_pi : p.pi[s];
+    const int v0 = pf ? pf_v0 : p.voff[s], v1 = pf ? pf_v1 : p.voff[s + 1];
+    const float pl = pf ? pf_pl : p.loop_prob[s];
+    row_value<NG>(acc, wcarry, crow, r, v);
+    if (pl > 0.f && p.bwd.atomic[chunk] != 1) {   // peeled self-loop (a split row adds it in its first piece only)
+      float bl[NG], xlv[NG];
+      if (pf) {
 #pragma unroll
-    for (int n = 0; n < NG; ++n) { v[n] = acc[r * NG + n]; loc[n] += pis * v[n]; locu[n] += v[n]; }
+        for (int n = 0; n < NG; ++n) { bl[n] = pf_bl[n]; xlv[n] = pf_xl[n]; }
+      } else {
+        ldv<NG>(bx_n + (size_t)v0 * (2 * NG), bl);
+        ldv<NG>(xl_t + (size_t)s * NG, xlv);
+      }
+#pragma unroll
+      for (int n = 0; n < NG; ++n) v[n] += pl * xlv[n] * (gat[n] ? bl[n] * inv_c[n] + lkr[n] : cst[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NG; ++n) { loc[n] += pis * v[n]; locu[n] += v[n]; }
     for (int q = v0; q < v1; ++q) {
       float* o = bx_t + (size_t)q * (2 * NG);
       if (atomic) {
@@ -1031,12 +1207,13 @@ __global__ void __launch_bounds__(kDenThreads) den_step_sx(const DenParams* __re
                                                            const StepCounter* __restrict__ cnt, int local) {
   __shared__ __attribute__((aligned(16))) float acc[kMaxRows * NG];
   __shared__ float red[2 * kDenWaves * NG];
+  __shared__ __attribute__((aligned(16))) float wcarry[kDenWaves * NG];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
   const DenParams& p = *pp;
   const int ncf = p.fwd.n_chunks;
-  if ((int)blockIdx.x < ncf) den_fwd_frame_sx<NG>(p, step, blockIdx.x, acc, red);
-  else den_beta_frame_sx<NG>(p, p.Tmax - 1 - step, blockIdx.x - ncf, acc, red);
+  if ((int)blockIdx.x < ncf) den_fwd_frame_sx<NG>(p, step, blockIdx.x, acc, red, wcarry);
+  else den_beta_frame_sx<NG>(p, p.Tmax - 1 - step, blockIdx.x - ncf, acc, red, wcarry);
 }
 
 // Kaldi's consistency check: sum_h alpha'[0,h] beta'[0,h] (should be 1 per sequence).
@@ -1120,10 +1297,11 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
   DenBuffers b;
   const size_t GN = (size_t)ge.G * ge.NG;
   const bool sx = den_use_sx(g);
-  const size_t V = sx ? (size_t)g->V : (size_t)g->S;
+  const size_t V = sx ? (size_t)g->V : (size_t)g->S, Vo = sx ? (size_t)g->Vo : (size_t)g->S;
   b.alpha = c.take<float>(GN * (Tmax + 1) * (size_t)g->S);
-  b.alphav = (V == (size_t)g->S) ? b.alpha : c.take<float>(GN * (Tmax + 1) * V);
+  b.alphav = (Vo == (size_t)g->S) ? b.alpha : c.take<float>(GN * (Tmax + 1) * Vo);
   b.beta = c.take<float>(GN * (Tmax + 1) * V * 2);   // {beta', xd} per virtual state on the state-x path
+  b.xl = sx ? c.take<float>(GN * (size_t)Tmax * g->S) : nullptr;
   b.xs = c.take<float>(GN * (size_t)Tmax * g->P);
   b.gamma = c.take<float>(GN * (size_t)Tmax * g->P);
   b.apart = c.take<float>(GN * (Tmax + 1) * (size_t)(sx ? g->h_fwdv : g->h_fwd).n_chunks);
@@ -1186,7 +1364,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   const bool need_fill = !sx || any_atomic(hf) || any_atomic(hb);
   if (need_fill) {
     PK2_HIP(hipMemsetAsync(b.alpha, 0, GN * (Tmax + 1) * (size_t)g->S * sizeof(float), stream));
-    if (b.alphav != b.alpha) PK2_HIP(hipMemsetAsync(b.alphav, 0, GN * (Tmax + 1) * (size_t)g->V * sizeof(float), stream));
+    if (b.alphav != b.alpha) PK2_HIP(hipMemsetAsync(b.alphav, 0, GN * (Tmax + 1) * (size_t)g->Vo * sizeof(float), stream));
     PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)(sx ? g->V : g->S) * 2 * sizeof(float), stream));
     PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
   }
@@ -1198,8 +1376,9 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   p.alpha = b.alpha; p.beta = b.beta; p.xs = b.xs; p.gamma = b.gamma;
   p.apart = b.apart; p.bpart = b.bpart; p.asum = b.asum; p.inv_tot = b.inv_tot;
   p.lengths = b.lengths;
-  p.ps_off = g->d_pv_off; p.ps_state = g->d_pv_virt;
-  p.voff = g->d_voff; p.vpdf = g->d_vpdf; p.alphav = b.alphav; p.V = sx ? g->V : g->S;
+  p.ps_off = g->d_po_off; p.ps_state = g->d_po_occ;
+  p.voff = g->d_voff; p.ooff = g->d_ooff; p.opdf = g->d_opdf; p.ovirt = g->d_ovirt; p.loop_prob = g->d_loop_prob;
+  p.alphav = b.alphav; p.xl = b.xl; p.V = sx ? g->V : g->S; p.Vo = sx ? g->Vo : g->S;
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
   p.leaky = leaky; p.pi_sum = (float)g->pi_sum; p.wu = (float)(kBetaFloor * g->pi_sum / g->S);
   p.debug = getenv("PK2_DEN_DEBUG") ? atoi(getenv("PK2_DEN_DEBUG")) : 0;
@@ -1225,8 +1404,11 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   char key[96];
   hipLaunchKernelGGL(den_init<NG>, dim3(std::min(256, (g->S + 255) / 256), G), dim3(256), 0, stream, p);
   if (sx) {
-    hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride,
-                       b.lengths, g->d_vpdf, b.beta, g->V, Tmax);
+    // a frame's entries are cut into slices on grid.z so that short minibatches still fill the chip
+    auto slices = [&](int n) { return std::max(1, std::min((n + 1023) / 1024, (4096 + Tmax * G - 1) / (Tmax * G))); };
+    const int zv = slices(g->V), zl = slices(g->S);
+    hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G, zv + zl), dim3(256), 0, stream, logits, seq_stride, frame_stride,
+                       b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, Tmax, zv);
     PK2_LAUNCH_CHECK();
     // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
     // share one launch

@@ -7,6 +7,7 @@
 // workgroup chunks of whole rows and stored lane-interleaved (chain_internal.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 
 #include "chain_internal.h"
@@ -21,10 +22,13 @@ namespace pk2 {
 // that the forward epilogue can sum them without atomics; a group that cannot fit a chunk is emitted row by row as
 // single-row `atomic` chunks.  Without it every row is its own group (a row longer than a chunk is split, as before).
 // `want4` / `want2`: which record formats to lay out (16-byte {a, b, prob, pi*prob} / 8-byte {a, prob}).
+// `true_ends`: bit j of a lane's mask is set only where a row really ends after arc j (and at the chunk's last slot), not
+// at every lane end: the state-x kernels carry the open tail of a lane to the next lanes with a wave scan instead of
+// flushing it with an LDS atomic; wb_crow[wb] = chunk-local row that is open at the end of wave block wb.
 static void build_ordering(int64_t A, int num_rows, const int32_t* key, const int32_t* a,
                            const int32_t* b, const float* prob, const float* piprob,
                            HostOrdering* out, const int32_t* group_of_row = nullptr,
-                           bool want4 = true, bool want2 = true) {
+                           bool want4 = true, bool want2 = true, bool true_ends = false) {
   // counting sort by key (stable)
   std::vector<int64_t> ptr(num_rows + 1, 0);
   for (int64_t i = 0; i < A; ++i) ptr[key[i] + 1]++;
@@ -37,7 +41,7 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
   out->arcs.clear(); out->meta.clear(); out->wb_off.assign(1, 0);
   out->arcs2.clear(); out->row_leak.clear(); out->slot0.clear();
   out->row0.clear(); out->nrows.clear(); out->atomic.clear();
-  out->real0.clear(); out->nreal.clear();
+  out->real0.clear(); out->nreal.clear(); out->wb_crow.clear();
   auto group = [&](int r) { return group_of_row ? group_of_row[r] : r; };
 
   struct Piece { int row; int64_t lo, hi; };  // arcs [lo,hi) of sorted list belong to `row`
@@ -90,7 +94,9 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
           }
           row_next = (s + 1 < n) ? lrow[s + 1] : last_row;
           if (j == 0) c0 = row_here;
-          if (j == kK - 1 || row_next != row_here) mask |= (1u << j);
+          const bool last_slot = s == padded - 1;
+          if (true_ends ? (row_next != row_here || last_slot) : (j == kK - 1 || row_next != row_here)) mask |= (1u << j);
+          if (lane == 63 && j == kK - 1) out->wb_crow.push_back(row_here);
           if (want4) out->arcs[base_arc + ((size_t)wb * kK + j) * 64 + lane] = rec;
           if (want2) out->arcs2[base_arc + ((size_t)wb * kK + j) * 64 + lane] = make_int2(rec.x, rec.z);
         }
@@ -123,10 +129,14 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
     if (longest > kChunkArcs || (grouped && (total > kChunkArcs || r1 - r > kMaxRows))) {
       // does not fit a chunk: every row of the group in single-row atomic chunks of <= kChunkArcs arcs
       flush(r);
+      bool first = true;   // the first piece of the row / group is flagged 2: per-state terms are added there, once
       for (int q = r; q < r1; ++q) {
         const int64_t lo = ptr[q], hi = ptr[q + 1];
-        if (lo == hi && grouped) { emit_chunk({{q, lo, hi}}, q, 1, 1); continue; }
-        for (int64_t s = lo; s < hi; s += kChunkArcs) emit_chunk({{q, s, std::min(hi, s + kChunkArcs)}}, q, 1, 1);
+        if (lo == hi && grouped) { emit_chunk({{q, lo, hi}}, q, 1, first ? 2 : 1); first = false; continue; }
+        for (int64_t s = lo; s < hi; s += kChunkArcs) {
+          emit_chunk({{q, s, std::min(hi, s + kChunkArcs)}}, q, 1, first ? 2 : 1);
+          first = false;
+        }
       }
       cur_row0 = r1;
     } else {
@@ -174,57 +184,72 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src, cons
   build_ordering(A, S, dst, src, pdf, prob, piprob.data(), &g->h_fwd, nullptr, true, false);   // alpha: rows = dst
   build_ordering(A, S, src, dst, pdf, prob, piprob.data(), &g->h_bwd, nullptr, true, false);   // beta : rows = src
   build_ordering(A, P, pdf, src, dst, prob, piprob.data(), &g->h_gam, nullptr, true, false);   // gamma: rows = pdf
-  // pdf as a function of the destination state?
+  // State-x layouts (chain_internal.h): peel one self-loop per state, then virtual states = distinct (dst, pdf) pairs
+  // of the remaining arcs in (dst, pdf) order; a state nobody else enters gets one with pdf -1.
   {
-    std::vector<int32_t> spdf(S, -1);
-    bool unique = true;
-    for (int64_t i = 0; i < A && unique; ++i) {
-      if (spdf[dst[i]] < 0) spdf[dst[i]] = pdf[i];
-      else if (spdf[dst[i]] != pdf[i]) unique = false;
+    const char* peel_env = getenv("PK2_DEN_PEEL");
+    const bool peel = !(peel_env && atoi(peel_env) == 0);
+    g->loop_pdf.assign(S, -1);
+    g->loop_prob.assign(S, 0.f);
+    std::vector<int64_t> keep;
+    keep.reserve(A);
+    for (int64_t i = 0; i < A; ++i) {
+      if (peel && src[i] == dst[i] && g->loop_pdf[src[i]] < 0 && prob[i] > 0.f) {
+        g->loop_pdf[src[i]] = pdf[i];
+        g->loop_prob[src[i]] = prob[i];
+      } else {
+        keep.push_back(i);
+      }
     }
-    g->state_pdf_unique = unique;
-    if (unique) g->state_pdf = spdf;
-    if (unique) {
-      g->ps_off.assign(P + 1, 0);
-      for (int s = 0; s < S; ++s) if (spdf[s] >= 0) g->ps_off[spdf[s] + 1]++;
-      for (int p = 0; p < P; ++p) g->ps_off[p + 1] += g->ps_off[p];
-      g->ps_state.assign(std::max(1, g->ps_off[P]), 0);
-      std::vector<int32_t> cur(g->ps_off.begin(), g->ps_off.end() - 1);
-      for (int s = 0; s < S; ++s) if (spdf[s] >= 0) g->ps_state[cur[spdf[s]]++] = s;
+    const int64_t A2 = (int64_t)keep.size();
+    std::vector<int32_t> src2(A2), dst2(A2), pdf2(A2);
+    std::vector<float> prob2(A2), piprob2(A2);
+    for (int64_t k = 0; k < A2; ++k) {
+      const int64_t i = keep[k];
+      src2[k] = src[i]; dst2[k] = dst[i]; pdf2[k] = pdf[i]; prob2[k] = prob[i]; piprob2[k] = piprob[i];
     }
-  }
-  // Virtual states: distinct (dst, pdf) pairs in (dst, pdf) order; a state nobody enters gets one with pdf -1.
-  {
-    std::vector<int64_t> order(A);
+    std::vector<int64_t> order(A2);
     std::iota(order.begin(), order.end(), (int64_t)0);
     std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
-      return dst[x] != dst[y] ? dst[x] < dst[y] : pdf[x] < pdf[y];
+      return dst2[x] != dst2[y] ? dst2[x] < dst2[y] : pdf2[x] < pdf2[y];
     });
-    std::vector<int32_t> arc_v(A);
+    std::vector<int32_t> arc_v(A2);
     g->voff.assign(S + 1, 0);
     g->vpdf.clear();
     std::vector<int32_t> vstate;
     int64_t k = 0;
     for (int d = 0; d < S; ++d) {
       g->voff[d] = (int32_t)g->vpdf.size();
-      if (k == A || dst[order[k]] != d) { g->vpdf.push_back(-1); vstate.push_back(d); continue; }
-      while (k < A && dst[order[k]] == d) {
-        const int32_t q = pdf[order[k]];
+      if (k == A2 || dst2[order[k]] != d) { g->vpdf.push_back(-1); vstate.push_back(d); continue; }
+      while (k < A2 && dst2[order[k]] == d) {
+        const int32_t q = pdf2[order[k]];
         g->vpdf.push_back(q); vstate.push_back(d);
-        while (k < A && dst[order[k]] == d && pdf[order[k]] == q) arc_v[order[k++]] = (int32_t)g->vpdf.size() - 1;
+        while (k < A2 && dst2[order[k]] == d && pdf2[order[k]] == q) arc_v[order[k++]] = (int32_t)g->vpdf.size() - 1;
       }
     }
     g->V = (int32_t)g->vpdf.size();
     g->voff[S] = g->V;
+    // occupancy states: the virtual states of d, then its peeled loop
+    g->ooff.assign(S + 1, 0);
+    g->opdf.clear(); g->ovirt.clear();
+    for (int d = 0; d < S; ++d) {
+      g->ooff[d] = (int32_t)g->opdf.size();
+      for (int v = g->voff[d]; v < g->voff[d + 1]; ++v) { g->opdf.push_back(g->vpdf[v]); g->ovirt.push_back(g->voff[d]); }
+      if (g->loop_pdf[d] >= 0) { g->opdf.push_back(g->loop_pdf[d]); g->ovirt.push_back(g->voff[d]); }
+    }
+    g->Vo = (int32_t)g->opdf.size();
+    g->ooff[S] = g->Vo;
     // the 8-byte-record orderings of the state-x kernels
-    build_ordering(A, g->V, arc_v.data(), src, pdf, prob, piprob.data(), &g->h_fwdv, vstate.data(), false, true);
-    build_ordering(A, S, src, arc_v.data(), pdf, prob, piprob.data(), &g->h_bwdv, nullptr, false, true);
-    g->pv_off.assign(P + 1, 0);
-    for (int v = 0; v < g->V; ++v) if (g->vpdf[v] >= 0) g->pv_off[g->vpdf[v] + 1]++;
-    for (int p = 0; p < P; ++p) g->pv_off[p + 1] += g->pv_off[p];
-    g->pv_virt.assign(std::max(1, g->pv_off[P]), 0);
-    std::vector<int32_t> cur(g->pv_off.begin(), g->pv_off.end() - 1);
-    for (int v = 0; v < g->V; ++v) if (g->vpdf[v] >= 0) g->pv_virt[cur[g->vpdf[v]]++] = v;
+    build_ordering(A2, g->V, arc_v.data(), src2.data(), pdf2.data(), prob2.data(), piprob2.data(), &g->h_fwdv, vstate.data(),
+                   false, true, true);
+    build_ordering(A2, S, src2.data(), arc_v.data(), pdf2.data(), prob2.data(), piprob2.data(), &g->h_bwdv, nullptr, false,
+                   true, true);
+    g->po_off.assign(P + 1, 0);
+    for (int o = 0; o < g->Vo; ++o) if (g->opdf[o] >= 0) g->po_off[g->opdf[o] + 1]++;
+    for (int p = 0; p < P; ++p) g->po_off[p + 1] += g->po_off[p];
+    g->po_occ.assign(std::max(1, g->po_off[P]), 0);
+    std::vector<int32_t> cur(g->po_off.begin(), g->po_off.end() - 1);
+    for (int o = 0; o < g->Vo; ++o) if (g->opdf[o] >= 0) g->po_occ[cur[g->opdf[o]]++] = o;
   }
   *out = g;
   return PK2_OK;
@@ -253,6 +278,7 @@ static int upload_ordering(pk2_den_graph* g, const HostOrdering& h, DevOrdering*
   if ((rc = upload_vec(g, h.atomic, &d->atomic))) return rc;
   if ((rc = upload_vec(g, h.real0, &d->real0))) return rc;
   if ((rc = upload_vec(g, h.nreal, &d->nreal))) return rc;
+  if ((rc = upload_vec(g, h.wb_crow, &d->wb_crow))) return rc;
   d->n_chunks = h.n_chunks;
   return PK2_OK;
 }
@@ -268,15 +294,15 @@ int den_upload(pk2_den_graph* g) {
   if ((rc = upload_ordering(g, g->h_bwdv, &g->bwdv))) return rc;
   if ((rc = upload_vec(g, g->voff, &g->d_voff))) return rc;
   if ((rc = upload_vec(g, g->vpdf, &g->d_vpdf))) return rc;
-  if ((rc = upload_vec(g, g->pv_off, &g->d_pv_off))) return rc;
-  if ((rc = upload_vec(g, g->pv_virt, &g->d_pv_virt))) return rc;
+  if ((rc = upload_vec(g, g->loop_pdf, &g->d_loop_pdf))) return rc;
+  if ((rc = upload_vec(g, g->loop_prob, &g->d_loop_prob))) return rc;
+  if ((rc = upload_vec(g, g->ooff, &g->d_ooff))) return rc;
+  if ((rc = upload_vec(g, g->opdf, &g->d_opdf))) return rc;
+  if ((rc = upload_vec(g, g->ovirt, &g->d_ovirt))) return rc;
+  if ((rc = upload_vec(g, g->po_off, &g->d_po_off))) return rc;
+  if ((rc = upload_vec(g, g->po_occ, &g->d_po_occ))) return rc;
   const float* dpi = nullptr;
   if ((rc = upload_vec(g, g->pi, &dpi))) return rc;
-  if (g->state_pdf_unique) {
-    if ((rc = upload_vec(g, g->ps_off, &g->d_ps_off))) return rc;
-    if ((rc = upload_vec(g, g->ps_state, &g->d_ps_state))) return rc;
-    if ((rc = upload_vec(g, g->state_pdf, &g->d_state_pdf))) return rc;
-  }
   g->d_pi = const_cast<float*>(dpi);
   g->uploaded = true;
   return PK2_OK;
@@ -369,14 +395,18 @@ extern "C" int pk2_den_graph_debug_ordering(const pk2_den_graph* g, int which, i
 }
 
 // Test hook: the virtual states (chain_internal.h) and the per-chunk extras of ordering `which` (3 or 4): voff_out[S+1],
-// vpdf_out[V], real0_out / nreal_out / slot0_out [n_chunks], row_leak_out [sum of nrows].  Null buffers are skipped;
-// *num_virtual and *n_row_leak return the sizes.
+// vpdf_out[V], real0_out / nreal_out / slot0_out [n_chunks], row_leak_out [sum of nrows], the peeled self-loops
+// loop_pdf_out[S] / loop_prob_out[S], ooff_out[S+1], opdf_out[Vo].  Null buffers are skipped; *num_virtual, *num_occ and
+// *n_row_leak return the sizes.
 extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, int32_t* num_virtual, int32_t* voff_out,
                                            int32_t* vpdf_out, int32_t* real0_out, int32_t* nreal_out,
-                                           int32_t* slot0_out, int64_t* n_row_leak, float* row_leak_out) {
+                                           int32_t* slot0_out, int64_t* n_row_leak, float* row_leak_out,
+                                           int32_t* loop_pdf_out, float* loop_prob_out, int32_t* num_occ,
+                                           int32_t* ooff_out, int32_t* opdf_out) {
   PK2_REQUIRE(g && (which == 3 || which == 4), "debug virtual: bad args");
   const HostOrdering& h = which == 3 ? g->h_fwdv : g->h_bwdv;
   if (num_virtual) *num_virtual = g->V;
+  if (num_occ) *num_occ = g->Vo;
   if (voff_out) memcpy(voff_out, g->voff.data(), g->voff.size() * sizeof(int32_t));
   if (vpdf_out) memcpy(vpdf_out, g->vpdf.data(), g->vpdf.size() * sizeof(int32_t));
   if (real0_out) memcpy(real0_out, h.real0.data(), h.real0.size() * sizeof(int32_t));
@@ -384,5 +414,9 @@ extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, in
   if (slot0_out) memcpy(slot0_out, h.slot0.data(), h.slot0.size() * sizeof(int32_t));
   if (n_row_leak) *n_row_leak = (int64_t)h.row_leak.size();
   if (row_leak_out) memcpy(row_leak_out, h.row_leak.data(), h.row_leak.size() * sizeof(float));
+  if (loop_pdf_out) memcpy(loop_pdf_out, g->loop_pdf.data(), g->loop_pdf.size() * sizeof(int32_t));
+  if (loop_prob_out) memcpy(loop_prob_out, g->loop_prob.data(), g->loop_prob.size() * sizeof(float));
+  if (ooff_out) memcpy(ooff_out, g->ooff.data(), g->ooff.size() * sizeof(int32_t));
+  if (opdf_out) memcpy(opdf_out, g->opdf.data(), g->opdf.size() * sizeof(int32_t));
   return PK2_OK;
 }

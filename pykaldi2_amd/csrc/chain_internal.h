@@ -42,9 +42,10 @@ struct HostOrdering {
   std::vector<int32_t> wb_off;   // [n_chunks+1]
   std::vector<int32_t> row0;     // [n_chunks]
   std::vector<int32_t> nrows;    // [n_chunks]
-  std::vector<int32_t> atomic;   // [n_chunks]
+  std::vector<int32_t> atomic;   // [n_chunks]: 0 = whole rows; else a single-row chunk combined by atomics (2 = the row's / group's first piece)
   std::vector<int32_t> real0;    // [n_chunks]: group (real state) of the chunk's first row   (grouped orderings only)
   std::vector<int32_t> nreal;    // [n_chunks]: number of groups the chunk's rows belong to    (grouped orderings only)
+  std::vector<int32_t> wb_crow;  // [wave blocks]: chunk-local row of the block's last slot (the row its carry-out belongs to)
   int n_chunks = 0;
 };
 
@@ -60,6 +61,7 @@ struct DevOrdering {
   const int32_t* atomic = nullptr;
   const int32_t* real0 = nullptr;
   const int32_t* nreal = nullptr;
+  const int32_t* wb_crow = nullptr;
   int n_chunks = 0;
 };
 
@@ -69,28 +71,31 @@ struct pk2_den_graph {
   int32_t S = 0, P = 0, start = 0;
   int64_t A = 0;
   std::vector<float> pi;
-  // When every state's incoming arcs carry one pdf ("pdf is a function of the destination
-  // state"), the occupancy of pdf p at frame t is sum_{d in states(p)} alpha[t+1,d]*beta[t+1,d]
-  // and needs no arc traversal: states grouped by pdf (CSR).  Otherwise the arc-based pass runs.
-  bool state_pdf_unique = false;
-  std::vector<int32_t> ps_off, ps_state, state_pdf;
-  const int32_t* d_state_pdf = nullptr;
-  const int32_t* d_ps_off = nullptr;
-  const int32_t* d_ps_state = nullptr;
   double pi_sum = 0.0;
   pk2::HostOrdering h_fwd, h_bwd, h_gam;  // keyed by dst / src / pdf (general kernels)
-  // "Virtual states" of the state-x kernels: v = a distinct (destination state, pdf) pair over the arcs, numbered
-  // by (state, pdf), so the virtual states of state d are voff[d] .. voff[d+1]-1 (a state without incoming arcs has
-  // one with pdf -1).  exp(logit) is a per-VIRTUAL-state factor for any graph; V == S when every state's incoming
-  // arcs carry one pdf.  A Kaldi chain graph (forward pdf on the entering arcs, self-loop pdf on the loop) has V ~ 2S.
-  int32_t V = 0;
+  // State-x kernels (chain_den.hip).  One self-loop per state is PEELED off the arc lists: its contribution is a
+  // per-state term of the row epilogues (loop_pdf / loop_prob; -1 / 0 = none) -- every state of a Kaldi chain graph
+  // has one, carrying the self-loop pdf.  Over the remaining arcs, "virtual states" v = distinct (destination state,
+  // pdf) pairs numbered by (state, pdf): the virtual states of state d are voff[d] .. voff[d+1]-1 (a state nobody
+  // enters has one with pdf -1).  exp(logit) is a per-VIRTUAL-state factor for any graph; V == S when the arcs
+  // entering a state from elsewhere carry one pdf (the forward pdf of a chain graph).  Occupancies are kept per
+  // "occupancy state" o: the virtual states of d followed by its peeled loop, ooff[d] .. ooff[d+1]-1, Vo = V + loops.
+  int32_t V = 0, Vo = 0;
   std::vector<int32_t> voff, vpdf;        // [S+1], [V]
-  std::vector<int32_t> pv_off, pv_virt;   // virtual states grouped by pdf (CSR over P)
+  std::vector<int32_t> loop_pdf;          // [S]
+  std::vector<float> loop_prob;           // [S]
+  std::vector<int32_t> ooff, opdf, ovirt; // [S+1], [Vo] pdf, [Vo] first virtual state of the occupancy state's state
+  std::vector<int32_t> po_off, po_occ;    // occupancy states grouped by pdf (CSR over P)
   pk2::HostOrdering h_fwdv, h_bwdv;       // rows = virtual dst gathering src | rows = src gathering virtual dst
   const int32_t* d_voff = nullptr;
   const int32_t* d_vpdf = nullptr;
-  const int32_t* d_pv_off = nullptr;
-  const int32_t* d_pv_virt = nullptr;
+  const int32_t* d_loop_pdf = nullptr;
+  const float* d_loop_prob = nullptr;
+  const int32_t* d_ooff = nullptr;
+  const int32_t* d_opdf = nullptr;
+  const int32_t* d_ovirt = nullptr;
+  const int32_t* d_po_off = nullptr;
+  const int32_t* d_po_occ = nullptr;
   // device copies, created lazily on the first compute call
   bool uploaded = false;
   int device = -1;
@@ -111,7 +116,8 @@ struct DenGeom {
 
 struct DenBuffers {
   float* alpha;   // [G][Tmax+1][S][NG]  alpha (before the leaky term)
-  float* alphav;  // [G][Tmax+1][V][NG]  alpha per virtual state (state-x path; == alpha when V == S)
+  float* alphav;  // [G][Tmax+1][Vo][NG] alpha per occupancy state (state-x path; == alpha when Vo == S)
+  float* xl;      // [G][Tmax][S][NG]    exp(logit) of the peeled self-loop's pdf (state-x path)
   float* beta;    // [G][Tmax+1][S][NG]  beta' (before the leaky term); state-x path: [G][Tmax+1][V][2*NG] {btilde', x}
   float* xs;      // [G][Tmax][P][NG]    exp(clamp(logits)), sequences interleaved
   float* gamma;   // [G][Tmax][P][NG]    occupancies

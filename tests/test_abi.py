@@ -55,7 +55,8 @@ def _emulate(o, nrows_total, val):
                     s += v[(wb * K + j) * 64 + lane]
                     if (mask >> j) & 1:
                         acc[c] += s; s = 0.0; c += 1
-                assert s == 0.0
+                if s != 0.0:      # state-x orderings: the open tail of a lane belongs to the row that ends in a later lane
+                    acc[c] += s
         out[o["row0"][ch]:o["row0"][ch] + len(acc)] += acc
     return out
 
@@ -88,15 +89,18 @@ def test_den_graph_orderings_reproduce_segment_sums(case):
     assert np.abs(got - np.bincount(pdf, weights=al[src] * prob * be[dst], minlength=P)).max() < 1e-9
 
 
-@pytest.mark.parametrize("case", ["unique", "chain_topology", "multi_entry", "bigstate", "arc_pdf"])
-def test_den_graph_virtual_state_orderings(case):
-    """The state-x kernels' decomposition (chain_internal.h): virtual states = distinct (dst, pdf) pairs; the forward
-    ordering's rows are virtual states with the rows of one state inside one chunk, the backward ordering gathers by
-    virtual destination.  A numpy model of the kernels' arithmetic over these tables reproduces
-    alpha[d] = sum_arcs alpha[src] prob x[pdf] and beta[s] = sum_arcs prob x[pdf] beta[dst] for ANY graph."""
+@pytest.mark.parametrize("case", ["unique", "chain_topology", "multi_entry", "bigstate", "arc_pdf", "no_peel"])
+def test_den_graph_virtual_state_orderings(case, monkeypatch):
+    """The state-x kernels' decomposition (chain_internal.h): one self-loop per state is peeled into a per-state term;
+    virtual states = distinct (dst, pdf) pairs of the remaining arcs; the forward ordering's rows are virtual states
+    with the rows of one state inside one chunk, the backward ordering gathers by virtual destination.  A numpy model
+    of the kernels' arithmetic over these tables reproduces alpha[d] = sum_arcs alpha[src] prob x[pdf] and
+    beta[s] = sum_arcs prob x[pdf] beta[dst] for ANY graph."""
     S, A, P, seed = 300, 6000, 23, 7
     kw = dict(unique={}, chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_pdf_differs=True, multi_entry_frac=0.3),
-              bigstate=dict(loop_pdf_differs=True), arc_pdf={})[case]
+              bigstate=dict(loop_pdf_differs=True), arc_pdf={}, no_peel=dict(loop_pdf_differs=True))[case]
+    if case == "no_peel":
+        monkeypatch.setenv("PK2_DEN_PEEL", "0")
     if case == "bigstate":
         S, A = 200, 20000
     g = synth.den_graph_arcs(S, A, P, seed, **kw)
@@ -110,28 +114,48 @@ def test_den_graph_virtual_state_orderings(case):
     S_ = g["num_states"]
     src, dst, pdf, prob = g["src"], g["dst"], g["pdf"], g["prob"].astype(np.float64)
     of, ob = G.debug_ordering(3), G.debug_ordering(4)
-    voff, vpdf = of["voff"], of["vpdf"]
+    voff, vpdf, lpdf, lprob = of["voff"], of["vpdf"], of["loop_pdf"], of["loop_prob"].astype(np.float64)
     V = vpdf.shape[0]
-    # virtual states are the distinct (dst, pdf) pairs in order, one pdf -1 entry for states nobody enters
-    pairs = sorted(set(zip(dst.tolist(), pdf.tolist())) | {(d, -1) for d in set(range(S_)) - set(dst.tolist())})
+    # the peeled arcs: the first self-loop of each state
+    peeled = np.zeros(src.shape[0], bool)
+    seen = set()
+    if case != "no_peel":
+        for i in np.flatnonzero(src == dst):
+            if int(src[i]) not in seen:
+                seen.add(int(src[i])); peeled[i] = True
+                assert lpdf[src[i]] == pdf[i] and abs(lprob[src[i]] - prob[i]) < 1e-7
+    assert (lpdf >= 0).sum() == len(seen) and not lprob[lpdf < 0].any()
+    if case in ("chain_topology", "unique"):
+        assert len(seen) == S_          # every state of the synthetic graph loops
+    keep = ~peeled
+    # virtual states are the distinct (dst, pdf) pairs of the kept arcs in order, one pdf -1 entry for states nobody enters
+    ks, kd, kp, kprob = src[keep], dst[keep], pdf[keep], prob[keep]
+    pairs = sorted(set(zip(kd.tolist(), kp.tolist())) | {(d, -1) for d in set(range(S_)) - set(kd.tolist())})
     assert V == len(pairs) and voff[0] == 0 and voff[-1] == V
     vstate = np.repeat(np.arange(S_), np.diff(voff))
     assert [(int(a), int(b)) for a, b in zip(vstate, vpdf)] == pairs
-    if case == "unique":
-        assert V == S_
-    if case == "chain_topology":
-        assert V > 1.9 * S_ * 0.5   # every looping state has two entering pdfs
+    if case in ("unique", "chain_topology"):
+        assert V == S_                  # the arcs entering a state from elsewhere carry one (forward) pdf
+    if case == "no_peel":
+        assert V > 1.9 * S_
+    # occupancy states: the virtual states of a state, then its peeled loop
+    want_opdf = []
+    for d in range(S_):
+        want_opdf += vpdf[voff[d]:voff[d + 1]].tolist() + ([int(lpdf[d])] if lpdf[d] >= 0 else [])
+        assert of["ooff"][d + 1] == len(want_opdf)
+    assert of["opdf"].tolist() == want_opdf
     al, be, x = rng.random(S_), rng.random(S_), rng.random(P)
     pi = G.initial_probs().astype(np.float64)
     xv = np.where(vpdf >= 0, x[np.maximum(vpdf, 0)], 1.0)
-    # forward: row sums over virtual rows, then x per virtual row, then the sum over the rows of a state
+    xl = np.where(lpdf >= 0, x[np.maximum(lpdf, 0)], 1.0)
+    # forward: row sums over virtual rows, then x per virtual row, the sum over the rows of a state, the loop term
     rows = _emulate(of, V, lambda a, b, p, pp: al[a] * p)
     want_rows = np.zeros(V)
     key = {pr: i for i, pr in enumerate(pairs)}
-    arc_v = np.array([key[(int(d), int(q))] for d, q in zip(dst, pdf)])
-    np.add.at(want_rows, arc_v, al[src] * prob)
+    arc_v = np.array([key[(int(d), int(q))] for d, q in zip(kd, kp)])
+    np.add.at(want_rows, arc_v, al[ks] * kprob)
     assert np.abs(rows - want_rows).max() < 1e-9
-    got = np.bincount(vstate, weights=rows * xv, minlength=S_)
+    got = np.bincount(vstate, weights=rows * xv, minlength=S_) + al * lprob * xl
     assert np.abs(got - np.bincount(dst, weights=al[src] * prob * x[pdf], minlength=S_)).max() < 1e-9
     # the per-(chunk, row) leaky term
     leak = np.zeros(V)
@@ -139,21 +163,25 @@ def test_den_graph_virtual_state_orderings(case):
         n = of["nrows"][ch]
         leak[of["row0"][ch]:of["row0"][ch] + n] += of["row_leak"][of["slot0"][ch]:of["slot0"][ch] + n]
     want_leak = np.zeros(V)
-    np.add.at(want_leak, arc_v, pi[src] * prob)
+    np.add.at(want_leak, arc_v, pi[ks] * kprob)
     assert np.abs(leak - want_leak).max() < 1e-6
-    # chunk invariants: the rows of a state share a chunk unless the chunk is a single-row atomic one
+    # chunk invariants: the rows of a state share a chunk unless the chunk is a single-row atomic one; exactly one
+    # piece of a state / row that is split carries the flag 2 (it adds the per-state loop term)
+    first = {}
     for ch in range(len(of["row0"])):
         r0, n, at = of["row0"][ch], of["nrows"][ch], of["atomic"][ch]
         assert of["real0"][ch] == vstate[r0] and of["nreal"][ch] == vstate[r0 + n - 1] - vstate[r0] + 1
         if at:
             assert n == 1
+            first[int(vstate[r0])] = first.get(int(vstate[r0]), 0) + (at == 2)
         else:
             assert r0 == voff[vstate[r0]] and r0 + n == voff[vstate[r0 + n - 1] + 1]
+    assert all(c == 1 for c in first.values())
     if case == "bigstate":
-        assert of["atomic"].sum() >= 4
+        assert of["atomic"].astype(bool).sum() >= 4 and 5 in first
     # backward: gather index = virtual destination
     bev = be[vstate] * xv
-    got = _emulate(ob, S_, lambda a, b, p, pp: bev[a] * p)
+    got = _emulate(ob, S_, lambda a, b, p, pp: bev[a] * p) + lprob * xl * be
     assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
 
 
