@@ -709,15 +709,17 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
 
 // The same sums with the states walked IN ORDER (coalesced alpha / beta rows at streaming speed instead of two
 // dependent gathers per state through the pdf -> states lists) and one row of P x NG occupancies accumulated in LDS
-// with ds_add_f32 (97 KB for P = 6048, NG = 4); used whenever that row fits.
-#ifndef PK2_GAMMA_ABL
-#define PK2_GAMMA_ABL 0
-#endif
+// (97 KB for P = 6048, NG = 4); used whenever that row fits.  The row is FIXED POINT: a frame's occupancies are
+// posteriors (each <= 1, summing to 1), so a term is scaled by the frame's K and 2^30 and added with ds_add_u32.
+// LDS float atomics run at ~1 lane per 3 clocks on gfx950 (this pass: 0.92 ms with ds_add_f32, 0.23 ms with integer
+// adds or with no atomics at all); the quantisation is 5e-10 per term against a 1e-4 tolerance, and the sums no longer
+// depend on the order of the atomics.
 constexpr int kGammaThreads = 1024;   // one workgroup per CU (the LDS row): 16 waves keep 4 x 3 loads each in flight
 constexpr size_t kGammaMaxLds = 144 * 1024;
+constexpr float kGammaFix = 1073741824.f;   // 2^30
 template <int NG>
 __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, const float* csum, const float* Kf, int t, int g,
-                                                          float* acc) {
+                                                          unsigned* acc) {
   const int tid = threadIdx.x;
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
   float cv[NG], rv[NG], kv[NG], inv_c[NG], lkr[NG], cst[NG];
@@ -733,7 +735,8 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
     lkr[n] = p.leaky * rv[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
-  for (int i = tid; i < p.P * NG; i += kGammaThreads) acc[i] = 0.f;
+  for (int i = tid; i < p.P * NG; i += kGammaThreads) acc[i] = 0u;
+
   __syncthreads();
   const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.Vo * NG;      // per occupancy state
   const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
@@ -751,27 +754,23 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-#if PK2_GAMMA_ABL == 2
-      if (pdf[q] >= 0) ldv<NG>(beta_n + (size_t)(s0 & 1023) * (2 * NG), b[q]);
-#else
       if (pdf[q] >= 0) ldv<NG>(beta_n + (size_t)vi[q] * (2 * NG), b[q]);
-#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (pdf[q] < 0) continue;
 #pragma unroll
-#if PK2_GAMMA_ABL == 1
-      for (int n = 0; n < NG; ++n) acc[n * p.P + pdf[q]] = a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]);
-#else
-      for (int n = 0; n < NG; ++n) atomicAdd(&acc[n * p.P + pdf[q]], a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]));
-#endif
+      for (int n = 0; n < NG; ++n) {
+        // (alpha * beta-hat) * K <= 1 first, the fixed-point scale last: K alone can be near the float range
+        const float w = a[q][n] * (gat[n] ? b[q][n] * inv_c[n] + lkr[n] : cst[n]) * kv[n] * kGammaFix;
+        atomicAdd(&acc[n * p.P + pdf[q]], (unsigned)(w + 0.5f));
+      }
     }
   }
   __syncthreads();
   float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
   // the LDS row is sequence-major (acc[n][pdf]: the lanes of one ds_add_f32 then spread over all banks instead of
   // every fourth one); the occupancies go out pdf-major
-  for (int i = tid; i < p.P * NG; i += kGammaThreads) gam_t[i] = acc[(i % NG) * p.P + i / NG] * kv[i % NG];
+  for (int i = tid; i < p.P * NG; i += kGammaThreads) gam_t[i] = (float)acc[(i % NG) * p.P + i / NG] * (1.0f / kGammaFix);
 }
 
 template <int NG>
@@ -782,7 +781,7 @@ __global__ void __launch_bounds__(256) den_gamma_states(DenParams p, const float
 template <int NG>
 __global__ void __launch_bounds__(kGammaThreads) den_gamma_states_lds(DenParams p, const float* csum, const float* Kf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  den_gamma_states_lds_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y, smem);
+  den_gamma_states_lds_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y, reinterpret_cast<unsigned*>(smem));
 }
 
 // The same launch also carries the numerator: workgroups x >= Tmax of group 0 run the forward-backward of one
@@ -794,7 +793,7 @@ __global__ void __launch_bounds__(LDS_ROW ? kGammaThreads : 256) den_gamma_state
                                                                                      NumParams np, int n_seq, int stage) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((int)blockIdx.x < p.Tmax) {
-    if (LDS_ROW) den_gamma_states_lds_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y, smem);
+    if (LDS_ROW) den_gamma_states_lds_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y, reinterpret_cast<unsigned*>(smem));
     else den_gamma_states_body<NG>(p, csum, Kf, blockIdx.x, blockIdx.y);
     return;
   }
@@ -877,6 +876,57 @@ __global__ void __launch_bounds__(256) den_exp_states(const float* __restrict__ 
   else den_exp_table<NG>(logits, seq_stride, frame_stride, lengths, loop_pdf, xl, S, Tmax, 0, NG, 0, z - zv, (int)gridDim.z - zv);
 }
 
+// The same two tables through LDS: a workgroup first stages exp(clamp(logits)) of its frame for all pdfs (coalesced row
+// reads, P x NG values, one expf per (pdf, sequence) instead of one per table entry), then every entry is an index load,
+// one 16-byte LDS read and a store.  The direct version above is bound by its 4-byte row gathers (4 per entry: 212 M
+// per call at ~0.5 lines/clk/CU = 0.75 ms); used whenever the staged row fits LDS.
+constexpr int kExpThreads = 1024;
+template <int NG>
+__global__ void __launch_bounds__(kExpThreads) den_exp_states_lds(const float* __restrict__ logits, int64_t seq_stride,
+                                                                  int64_t frame_stride, const int32_t* __restrict__ lengths,
+                                                                  const int32_t* __restrict__ vpdf, float* __restrict__ bx, int V,
+                                                                  const int32_t* __restrict__ loop_pdf, float* __restrict__ xl,
+                                                                  int S, int P, int Tmax) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [P][NG]
+  const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const float* rows[NG]; bool live[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) {
+    const int seq = g * NG + n;
+    live[n] = t < lengths[seq];
+    rows[n] = logits + (int64_t)seq * seq_stride + (int64_t)t * frame_stride;
+  }
+  for (int p = tid; p < P; p += kExpThreads) {
+    float v[NG];
+#pragma unroll
+    for (int n = 0; n < NG; ++n) {
+      float xx = live[n] ? rows[n][p] : 0.f;
+      xx = xx < -30.f ? -30.f : (xx > 30.f ? 30.f : xx);   // keeps NaN (see den_exp_transpose)
+      v[n] = live[n] ? expf(xx) : 1.0f;
+    }
+    stv<NG>(xs + (size_t)p * NG, v);
+  }
+  __syncthreads();
+  float one[NG], zero[NG];
+#pragma unroll
+  for (int n = 0; n < NG; ++n) { one[n] = 1.f; zero[n] = 0.f; }
+  float* out = bx + ((size_t)g * (Tmax + 1) + t + 1) * (size_t)V * (2 * NG);
+  for (int d = blockIdx.z * kExpThreads + tid; d < V; d += gridDim.z * kExpThreads) {
+    const int pdf = vpdf[d];
+    float v[NG];
+    if (pdf >= 0) ldv<NG>(xs + (size_t)pdf * NG, v);
+    stv<NG>(out + (size_t)d * (2 * NG), zero);
+    stv<NG>(out + (size_t)d * (2 * NG) + NG, pdf >= 0 ? v : one);
+  }
+  float* outl = xl + ((size_t)g * Tmax + t) * (size_t)S * NG;
+  for (int d = blockIdx.z * kExpThreads + tid; d < S; d += gridDim.z * kExpThreads) {
+    const int pdf = loop_pdf[d];
+    float v[NG];
+    if (pdf >= 0) ldv<NG>(xs + (size_t)pdf * NG, v);
+    stv<NG>(outl + (size_t)d * NG, pdf >= 0 ? v : one);
+  }
+}
+
 template <int NG>
 __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red, float* wcarry) {
   DEN_T0();
@@ -886,7 +936,6 @@ __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int 
   const size_t frame = (size_t)g * (p.Tmax + 1) + t;
   const float* alpha_t = p.alpha + frame * (size_t)p.S * NG;
   const int wb0 = p.fwd.wb_off[chunk], wb1 = p.fwd.wb_off[chunk + 1];
-  const int nrows = p.fwd.nrows[chunk];
   float as[NG];
 #pragma unroll
   for (int n = 0; n < NG; ++n) as[n] = 0.f;
@@ -1406,9 +1455,22 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   if (sx) {
     // a frame's entries are cut into slices on grid.z so that short minibatches still fill the chip
     auto slices = [&](int n) { return std::max(1, std::min((n + 1023) / 1024, (4096 + Tmax * G - 1) / (Tmax * G))); };
-    const int zv = slices(g->V), zl = slices(g->S);
-    hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G, zv + zl), dim3(256), 0, stream, logits, seq_stride, frame_stride,
-                       b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, Tmax, zv);
+    const size_t exp_lds = (size_t)g->P * NG * sizeof(float);
+    if (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER")) {
+      static bool attr_e[8] = {false};
+      if (!attr_e[NG]) {
+        PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_exp_states_lds<NG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_e[NG] = true;
+      }
+      const int z = std::max(1, std::min((g->V + kExpThreads - 1) / kExpThreads, (2048 + Tmax * G - 1) / (Tmax * G)));
+      hipLaunchKernelGGL(den_exp_states_lds<NG>, dim3(Tmax, G, z), dim3(kExpThreads), exp_lds, stream, logits, seq_stride,
+                         frame_stride, b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, g->P, Tmax);
+    } else {
+      const int zv = slices(g->V), zl = slices(g->S);
+      hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G, zv + zl), dim3(256), 0, stream, logits, seq_stride, frame_stride,
+                         b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, Tmax, zv);
+    }
     PK2_LAUNCH_CHECK();
     // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
     // share one launch
