@@ -126,34 +126,65 @@ class Trainer:
         return loss
 
 
-def den_roofline(den, logits_bf, lens, reps=5):
-    """Times the denominator forward-backward (one C-ABI call = T forward + T backward frame kernels)
-    with events on the stream it is launched on.  Algorithmic bytes: SURVEY.md 8(d)."""
+DEN_ROOF_LENS = [589, 410, 377, 502]     # the fixed denominator workload of `--den-only`, the PMC passes and `roofline`
+
+
+def den_roofline(den, dev, reps=5):
+    """Times the denominator forward-backward (one C-ABI call = Tmax frame launches + the parallel passes around them)
+    with events on the stream it is launched on, on the FIXED workload the committed PMC passes were taken on
+    (4 sequences of DEN_ROOF_LENS frames, random logits): `algorithmic_bytes`, `traffic` and the timing all describe the
+    same call.  Algorithmic bytes: SURVEY.md 8(d)."""
+    lens = DEN_ROOF_LENS
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    x = torch.randn(len(lens), max(lens), P, device=dev, generator=gen)
     for _ in range(2):
-        chain.den_forward_backward(den, logits_bf, lens, 1e-4)
+        chain.den_forward_backward(den, x, lens, 1e-4)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        chain.den_forward_backward(den, logits_bf, lens, 1e-4)
+        chain.den_forward_backward(den, x, lens, 1e-4)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     Tsum, Tmax = int(sum(lens)), int(max(lens))
-    byts = Tsum * 4 * (3 * P + 2 * (S_DEN + 1)) + 24 * A_DEN * Tmax
+    S, A = den.num_states(), den.num_arcs()
+    rows = Tsum * 4 * (3 * P + 2 * (S + 1))
+    byts = rows + 24 * A * Tmax                  # SURVEY 8(d): both arc lists streamed once per frame
+    resident = rows + 24 * A                     # its lower bound: arc lists read once per call (cache-resident)
     ach = byts / (ms * 1e-3) / 1e9
-    # HBM bytes per call from the committed PMC passes of this same command (`bench.py --den-only`);
-    # counters cannot be read live, so this is the profile's number for the fixed --den-only workload.
-    traffic = None
+    # HBM bytes per call from the committed PMC passes (tools/gpu_profile.sh) of this same workload: counters cannot be
+    # read live.  Only reported when the profile was taken on the same lengths and graph shape.
+    traffic, traffic_note = None, "no PMC profile of this workload committed"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_den_traffic.json")) as f:
-            traffic = int(json.load(f)["traffic_bytes_raw"])
+        with open(os.path.join(ROOT, "profiles", "r02_den_traffic.json")) as f:
+            prof = json.load(f)
+        if prof.get("lengths") == lens and prof.get("topology") == DEN_TOPOLOGY and prof.get("arcs") == A:
+            traffic = int(prof["traffic_bytes_raw"])
+            traffic_note = ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), raw; with FETCH_SIZE doubled "
+                            "(gfx950 wide-read correction, an upper bound here): %d" % int(prof["traffic_bytes_fetch_x2"]))
     except Exception:
         pass
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=traffic, kernel="pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; "
-                "forward frame t and backward frame Tmax-1-t share a launch)",
-                ms_per_launch=round(ms, 3), algorithmic_bytes=byts)
+                traffic=traffic, traffic_note=traffic_note,
+                kernel="pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; forward frame t and "
+                "backward frame Tmax-1-t share a launch)",
+                workload="4 sequences of %s frames, %s den graph (%d states, %d arcs, %d pdfs)" % (lens, DEN_TOPOLOGY, S, A, P),
+                ms_per_launch=round(ms, 3), algorithmic_bytes=byts,
+                us_per_frame=round(1e3 * ms / Tmax, 2),
+                frac_cache_resident=round(resident / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                cache_resident_bytes=resident)
+
+
+def lstm_flops_per_frame(feat=80, hidden=512, layers=3, pdfs=P):
+    """Forward FLOPs of the BLSTM + output layer per network frame: input and recurrent products of both
+    directions of every layer plus the affine output; forward + backward = 3x."""
+    f, d_in = 0, feat
+    for _ in range(layers):
+        f += 2 * (2 * d_in * 4 * hidden + 2 * hidden * 4 * hidden)
+        d_in = 2 * hidden
+    return f + 2 * d_in * pdfs
 
 
 def gemm_mfma_roofline(dev, rows, reps=10):
@@ -227,10 +258,43 @@ def cpu_baseline_worker(seed, threads):
                                  "%.1f s wall on %d threads" % (seconds, dt, threads))), flush=True)
 
 
-def cpu_baseline(seed, timeout=240):
+def cpu_ce_worker(threads):
+    """SURVEY 8(d) config 1 in a child process: the reference's torch CPU CE path (nn.LSTM + nn.Linear = models/lstm.py:45-54,
+    nn.CrossEntropyLoss, clip 5, Adam(amsgrad, lr 1e-4)) on x[64,80,80], P=5768, dropout 0.2, on the node's host cores."""
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    B, T, PC = 64, 80, 5768
+    rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, dropout=0.2, bidirectional=True)
+    lin = torch.nn.Linear(1024, PC)
+    params = list(rnn.parameters()) + list(lin.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, amsgrad=True)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100)
+    x = torch.randn(B, T, 80)
+    y = torch.randint(0, PC, (B, T))
+
+    def step():
+        opt.zero_grad()
+        loss = crit(lin(rnn(x)[0]).reshape(-1, PC), y.reshape(-1))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+    step()
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 12.0 and n < 12):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    print(json.dumps(dict(value=round(B * T * 0.01 / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
+                          kind="reference",
+                          sample="%d steps of the reference's torch CPU CE path (nn.LSTM 3x512 bidirectional + Linear, "
+                                 "CrossEntropyLoss, clip 5, Adam amsgrad) on x[64,80,80], P=5768: %.2f s per step on %d threads"
+                                 % (n, dt, threads))), flush=True)
+
+
+def cpu_baseline(seed, timeout=240, worker="--cpu-baseline-worker"):
     import subprocess
     threads = usable_cores()
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(seed), str(threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), worker, str(seed), str(threads)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -289,6 +353,7 @@ def ce_workload(args, dev, rank, world):
         print(json.dumps({"metric": "iRTF (hrs audio/hr) 3x512 BLSTM CE, 256x80 chunks (secondary workload, configs[1])",
                           "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
                           "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "loss": round(float(loss.item()), 4),
+                          "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(0, worker="--cpu-ce-worker"),
                           "reference_published": "README.md:43-45: 190 iRTF (64x80, 1 V100), 520 iRTF (256x80, 4 V100)"}),
               flush=True)
     hvd.shutdown()
@@ -386,6 +451,8 @@ T_START = time.time()
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-ce-worker":
+        return cpu_ce_worker(int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -469,9 +536,7 @@ def main():
     den = chain.DenominatorGraph(g, P)
     log("den graph ready")
     if args.den_only:
-        lens = [589, 410, 377, 502]
-        x = torch.randn(4, max(lens), P, device=dev)
-        print(json.dumps(den_roofline(den, x, lens)), flush=True)
+        print(json.dumps(den_roofline(den, dev)), flush=True)
         return
     rng = np.random.default_rng(1234 + rank)
     n_unique = min(args.steps + args.warmup, 8)
@@ -516,27 +581,35 @@ def main():
         hvd.shutdown()
         return
     breakdown = {events[i][0]: round(events[i - 1][1].elapsed_time(events[i][1]), 3) for i in range(1, len(events))}
-    # roofline of the denominator forward-backward on this minibatch's logits
     lens = [s.frames_per_sequence for s in tr.last["sups"]]
-    logits_bf = tr.last["logits"].detach().transpose(0, 1)
-    roof = den_roofline(den, logits_bf, lens)
+    roof = den_roofline(den, dev)
     log("roofline done")
+    # whole-model MFMA utilisation of the breakdown step: all BLSTM + output-layer FLOPs (forward + backward) of the real
+    # (unpadded) frames over the time of the two model phases, against the f32 MFMA peak
+    lstm_ms = breakdown["lstm_fwd"] + breakdown["lstm_bwd"]
+    lstm_tf = 3.0 * lstm_flops_per_frame() * sum(lens) / (lstm_ms * 1e-3) / 1e12
+    roof_lstm = dict(bound="mfma", achieved=round(lstm_tf, 2), peak=157.3, unit="TFLOP/s", frac=round(lstm_tf / 157.3, 4),
+                     kernel="3x512 BLSTM + output layer, forward + backward of the breakdown minibatch (recurrence "
+                     "step kernels + f32 MFMA GEMMs)", frames=int(sum(lens)), padded_rows=len(lens) * max(lens),
+                     ms=round(lstm_ms, 3), flops_per_frame_fwd_bwd=3 * lstm_flops_per_frame(),
+                     input_projection_gemm=gemm_mfma_roofline(dev, len(lens) * max(lens)))
     result = {
         "metric": "iRTF (hrs audio/hr) 3x512 BLSTM LF-MMI, LibriSpeech-shaped synthetic utterances",
         "value": round(audio / dt, 2), "unit": "hours of audio per wall-clock hour",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
-        "transition-id alignments over a synthetic left-biphone tree, 30k-state/1M-arc denominator graph; "
+        "transition-id alignments over a synthetic left-biphone tree, 30k-state/1M-arc denominator graph (%s); "
         "random-init 3x512 BLSTM; supervisions built from the alignments inside the step%s)"
-        % ("; utterance lengths bucketed across ranks" if args.length_bucketed else ""),
+        % ("Kaldi chain topology: self-loop pdf != entering pdf" if DEN_TOPOLOGY == "chain" else "one pdf per destination state",
+           "; utterance lengths bucketed across ranks" if args.length_bucketed else ""),
         "config": {"workload": ("SECONDARY configs[4]: 12-layer TransformerAM LF-MMI; " if args.transformer else "") +
                                "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
                                "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"
                                % args.batch,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P}},
-        "roofline": roof, "roofline_lstm_gemm": gemm_mfma_roofline(dev, len(lens) * max(lens)), "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
+                   "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY}},
+        "roofline": roof, "roofline_lstm": roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
     }
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline (child process, %d cores)" % usable_cores())

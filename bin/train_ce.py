@@ -159,7 +159,17 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
         end = time.time()
         i += 1
 
-    for batch in data.sequence_batches(source, 8, args.sweep_size, dev):
+    # Every rank runs exactly n_batches steps (one gradient all-reduce each): utterances are drawn until the chunk pool
+    # has produced them, whatever lengths this rank happened to get (the reference's chunk mode has a fixed number of
+    # minibatches per sweep too, data/sr_dataset.py:226-232).
+    def utterance_stream():
+        k = 0
+        while True:
+            yield from data.sequence_batches(source, 8, args.sweep_size, dev, epoch=epoch * 1000 + k)
+            k += 1
+    stream = utterance_stream()
+    while i < n_batches:
+        batch = next(stream)
         feats, frames, row_off = fb(batch["wav"], batch["lens"], apply_cmn=dc.get("use_cmn", True))
         if transform is not None:
             feats = transform(feats)
@@ -169,9 +179,9 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
             lab = th.from_numpy(np.asarray(y)[:frames[n]]).to(dev).unsqueeze(1)
             pool.add(fbank.utt2seg(f, seg_len, seg_shift), fbank.utt2seg(lab, seg_len, seg_shift))
         for x, y in pool.batches(args.batch_size):
+            if i >= n_batches:
+                break
             train_on(x, y)
-    for x, y in pool.batches(args.batch_size, flush=True):
-        train_on(x, y)
 
 
 if __name__ == '__main__':

@@ -49,6 +49,8 @@ def main():
     parser.add_argument("-data_loader_threads", default=0, type=int, help="number of workers for data loading")
     parser.add_argument("-max_grad_norm", default=5, type=float, help="max_grad_norm for gradient clipping")
     parser.add_argument("-sweep_size", default=100, type=float, help="process n hours of data per sweep (default:100)")
+    parser.add_argument("-length_bucketed", action="store_true", help="data parallel: the ranks of one step get utterances "
+                        "of similar length (a step waits at the gradient all-reduce for its longest minibatch)")
     parser.add_argument("-num_epochs", default=1, type=int, help="number of training epochs (default:1)")
     parser.add_argument("-anneal_lr_epoch", default=2, type=int, help="start to anneal the learning rate from this epoch")
     parser.add_argument("-anneal_lr_ratio", default=0.5, type=float, help="the ratio to anneal the learning rate ratio")
@@ -138,7 +140,8 @@ def run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, 
     progress = utils.ProgressMeter(n_batches, batch_time, losses, grad_norm, prefix="Epoch: [{}]".format(epoch))
     sub = supervision_opts.frame_subsampling_factor
     end = time.time()
-    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
+    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev, epoch=epoch,
+                                                         length_bucketed=args.length_bucketed)):
         frame_shift = (epoch % sub) * -1
         feats, frames, row_off = fb(batch["wav"], batch["lens"])
         if transform is not None:     # dataset.transform of the reference (bin/train_chain.py:118-122)

@@ -58,6 +58,8 @@ def main(arch="blstm"):
     parser.add_argument("-data_loader_threads", default=0, type=int, help="number of workers for data loading")
     parser.add_argument("-max_grad_norm", default=5, type=float, help="max_grad_norm for gradient clipping")
     parser.add_argument("-sweep_size", default=100, type=float, help="process n hours of data per sweep (default:60)")
+    parser.add_argument("-length_bucketed", action="store_true", help="data parallel: the ranks of one step get utterances "
+                        "of similar length (a step waits at the gradient all-reduce for its longest minibatch)")
     parser.add_argument("-num_epochs", default=1, type=int, help="number of training epochs (default:1)")
     parser.add_argument('-print_freq', default=10, type=int, metavar='N', help='print frequency (default: 10)')
     parser.add_argument('-save_freq', default=1000, type=int, metavar='N', help='save model frequency (default: 1000)')
@@ -165,7 +167,8 @@ def run_train_epoch(model, optimizer, log_prior, source, fb, epoch, asr_decoder,
     progress = utils.ProgressMeter(n_batches, batch_time, losses, grad_norm, prefix="Epoch: [{}]".format(epoch))
     ce_criterion = ops.CrossEntropyLoss(ignore_index=-100, reduction='sum')
     end = time.time()
-    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
+    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev, epoch=epoch,
+                                                         length_bucketed=args.length_bucketed)):
         loss, se_val, ce_loss, frames = se.sequence_loss(model, fb, batch, asr_decoder, trans_model, log_prior, args.criterion,
                                                          silence_ids, args.ce_ratio, ce_criterion, forward, transform)
         optimizer.zero_grad()

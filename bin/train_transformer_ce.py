@@ -118,7 +118,7 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
     progress = utils.ProgressMeter(n_batches, batch_time, losses, grad_norm, prefix="Epoch: [{}]".format(epoch))
     use_cmn = config["data_config"].get("use_cmn", True)
     end = time.time()
-    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev)):
+    for i, batch in enumerate(data.sequence_batches(source, args.batch_size, args.sweep_size, dev, epoch=epoch)):
         feats, frames, row_off = fb(batch["wav"], batch["lens"], apply_cmn=use_cmn)
         if transform is not None:
             feats = transform(feats)

@@ -443,6 +443,29 @@ int pk2_lattice_export(const pk2_lattice_batch* b, const void* workspace, int32_
                        float* tok_final, int32_t* link_src, int32_t* link_dst, int32_t* link_tid,
                        float* link_graph, float* link_ac, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Gradient exchange: RCCL all-reduce over xGMI, one communicator per process (= per GPU).
+ * Replaces horovod.torch's NCCL all-reduce hidden in hvd.DistributedOptimizer.step()
+ * (reference bin/train_chain.py:141-145, bin/train_ce.py:127-131, bin/train_se.py:130-134).
+ * librccl is bound at run time (dlopen; a copy already mapped into the process is reused; PK2_RCCL_LIB
+ * overrides).  Only the unique id travels through the launcher's own channel (torch.distributed store /
+ * broadcast in pykaldi2_amd/hvd.py, MPI in the reference).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pk2_comm pk2_comm;
+/* Size of a unique id in bytes (NCCL_UNIQUE_ID_BYTES = 128). */
+int32_t pk2_comm_unique_id_bytes(void);
+/* Rank 0: generates the id every rank must pass to pk2_comm_init (host buffer of pk2_comm_unique_id_bytes()). */
+int pk2_comm_unique_id(void* id_out);
+/* Collective over all ranks (ncclCommInitRank on the calling thread's current device). */
+int pk2_comm_init(int32_t rank, int32_t world, const void* unique_id, pk2_comm** out);
+/* In-place SUM all-reduce of buf[0..count) (device f32: a bucket of the flat gradient buffer) enqueued on `stream`
+ * (hipStream_t): the compute stream, or a side stream the caller fences with events.  Averaging (1/world) is folded
+ * into the optimiser kernel (pk2_adam_step / pk2_sgd_step grad_scale), not done here. */
+int pk2_allreduce_bucket(pk2_comm* comm, float* buf, int64_t count, void* stream);
+/* rank / world of the communicator and the path of the RCCL library in use (any output may be NULL). */
+int pk2_comm_info(const pk2_comm* comm, int32_t* rank, int32_t* world, char* lib_path, int32_t lib_path_bytes);
+int pk2_comm_destroy(pk2_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,12 @@ SIGNATURES = {
                                   _vp, _vp]),
     "pk2_lattice_export": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp]),
+    "pk2_comm_unique_id_bytes": (_i32, []),
+    "pk2_comm_unique_id": (C.c_int, [_vp]),
+    "pk2_comm_init": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "pk2_allreduce_bucket": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "pk2_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32]),
+    "pk2_comm_destroy": (C.c_int, [_vp]),
     "pk2_sim_apply_rir": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp, _vp]),
     "pk2_sim_power": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pk2_sim_add_noise": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _f32, _vp, _vp, _vp]),

@@ -80,7 +80,21 @@ class ZipWavSource:
         return wav
 
     def draw(self):
-        zpath, member, utt, lab, aux = self.items[int(self.rng.integers(len(self.items)))]
+        return self.get(int(self.rng.integers(len(self.items))))
+
+    def durations(self):
+        """Seconds per utterance from the archive directory (16-bit mono PCM payload size), without decoding."""
+        if not hasattr(self, "_dur"):
+            sizes = {}
+            for zpath in sorted({it[0] for it in self.items}):
+                with zipfile.ZipFile(zpath) as z:
+                    for info in z.infolist():
+                        sizes[(zpath, info.filename)] = info.file_size
+            self._dur = np.array([max(0, sizes[(it[0], it[1])] - 44) / 2.0 / 16000.0 for it in self.items])
+        return self._dur
+
+    def get(self, index):
+        zpath, member, utt, lab, aux = self.items[index]
         wav = self._read(zpath, member)
         T = synth.num_fbank_frames(wav.shape[0])
         if lab is not None:   # truncate to min(n_label, n_fbank) like data/sr_dataset.py:349-363
@@ -97,12 +111,15 @@ class SyntheticSource:
         self.ali_model = ali_model     # chain training: `label` holds transition-ids of this TransitionModel
         self.rng = np.random.default_rng(1234 + seed + rank)
         self.count = 0
+        self.rank, self.world = rank, world
 
     def __len__(self):
         return 1 << 30
 
-    def draw(self):
-        d = float(synth.utterance_durations(self.rng, 1)[0])
+    MEAN_SECONDS = 12.3     # of synth.utterance_durations
+
+    def draw(self, seconds=None):
+        d = float(synth.utterance_durations(self.rng, 1)[0]) if seconds is None else float(seconds)
         wav = synth.waveform(self.rng, d)
         T = synth.num_fbank_frames(wav.shape[0])
         self.count += 1
@@ -195,20 +212,69 @@ class SimulationPool:
         return y
 
 
-def sequence_batches(source, batch_size, hours, device, simulation=None):
-    """Whole-utterance minibatches until `hours` of audio have been drawn (the reference's sweep_size,
-    data/sr_dataset.py:226).  `simulation`: a SimulationPool, or None."""
-    budget = hours * 3600.0
+def epoch_plan(source, batch_size, hours, rank=0, world=1, epoch=0, length_bucketed=False, seed=0):
+    """What every rank does in one epoch, computed from rank-independent quantities only, so that ALL ranks run the same
+    number of steps (each step ends in a gradient all-reduce: a rank that stops early would leave the others
+    blocked in the collective).  Returns a list of steps; a step is a list of `batch_size` items, an item being an
+    utterance index (finite sources) or a duration in seconds / None (the synthetic generator).
+
+    * Finite source (ZipWavSource): the reference's DistributedSampler (data/dataloader.py:83-84): a permutation of the
+      utterance list seeded by (seed, epoch) identically on every rank, padded by wrapping to a multiple of
+      world * batch_size, rank r taking every world-th group -- each utterance once per epoch, same count everywhere.
+      `hours` caps the epoch (sweep_size) through the mean duration of the list.
+    * Synthetic source: n = ceil(hours * 3600 / (12.3 s * batch_size)) steps on every rank.
+    * length_bucketed: the ranks of one step get utterances of similar length (a step waits at the all-reduce for its
+      longest minibatch): super-blocks of 16 steps are sorted by duration and dealt group by group to the ranks, the
+      steps of a super-block are then shuffled.  Synthetic: the durations come from a generator shared by the ranks."""
+    finite = hasattr(source, "items")
+    rng = np.random.default_rng([int(seed), int(epoch), 7919])          # the same stream on every rank
+    if not finite:
+        n_steps = max(1, int(np.ceil(hours * 3600.0 / (source.MEAN_SECONDS * batch_size))))
+        if not length_bucketed:
+            return [[None] * batch_size for _ in range(n_steps)]
+        durs = synth.utterance_durations(rng, n_steps * batch_size).reshape(n_steps, batch_size)
+        return [list(map(float, row)) for row in durs]
+    n = len(source.items)
+    group = world * batch_size
+    perm = rng.permutation(n)
+    total = -(-n // group) * group
+    perm = np.concatenate([perm, perm[:total - n]]) if total > n else perm     # wrap-around padding (DistributedSampler)
+    if total > perm.shape[0]:
+        perm = np.resize(perm, total)
+    n_steps = total // group
+    if hours and hours > 0:
+        mean = float(np.mean(source.durations())) if n else 1.0
+        n_steps = max(1, min(n_steps, int(np.ceil(hours * 3600.0 / (max(mean, 1e-3) * batch_size * world)))))
+    perm = perm[:n_steps * group]
+    if length_bucketed:
+        dur = source.durations()
+        out = []
+        for b0 in range(0, n_steps, 16):
+            blk = perm[b0 * group:(b0 + 16) * group]
+            blk = blk[np.argsort(dur[blk], kind="stable")]
+            steps = blk.reshape(-1, world, batch_size)            # consecutive (similar-length) groups -> the ranks of a step
+            steps = steps[rng.permutation(steps.shape[0])]
+            out.extend(steps[:, rank].tolist())
+        return out
+    return perm.reshape(n_steps, world, batch_size)[:, rank].tolist()
+
+
+def sequence_batches(source, batch_size, hours, device, simulation=None, rank=None, world=None, epoch=0,
+                     length_bucketed=False):
+    """Whole-utterance minibatches of one epoch: `hours` of audio per rank (the reference's sweep_size,
+    data/sr_dataset.py:226) on the synthetic generator, one sharded pass over the utterance list on a finite source
+    (see epoch_plan: the number of steps is the same on every rank).  `simulation`: a SimulationPool, or None."""
+    rank = getattr(source, "rank", 0) if rank is None else rank
+    world = getattr(source, "world", 1) if world is None else world
     if simulation is None:
         simulation = getattr(source, "simulation", None)
-    while budget > 0:
-        utts = [source.draw() for _ in range(batch_size)]
+    finite = hasattr(source, "items")
+    for step in epoch_plan(source, batch_size, hours, rank, world, epoch, length_bucketed):
+        utts = [source.get(int(it)) if finite else source.draw(it) for it in step]
         lens = [u[0].shape[0] for u in utts]
         if simulation is not None:
             wav = torch.cat([simulation.maybe_simulate(u[0], device) for u in utts])
         else:
             wav = torch.from_numpy(np.concatenate([u[0] for u in utts])).to(device, non_blocking=True)
-        seconds = sum(lens) / 16000.0
-        budget -= seconds
         yield dict(wav=wav, lens=lens, y=[u[1] for u in utts], aux=[u[2] for u in utts],
-                   utt_ids=[u[3] for u in utts], seconds=seconds)
+                   utt_ids=[u[3] for u in utts], seconds=sum(lens) / 16000.0)

@@ -1,17 +1,22 @@
-"""Horovod-shaped collective shim over torch.distributed (RCCL over xGMI on MI355X).
+"""Horovod-shaped collective shim: RCCL over xGMI through the C ABI, torch.distributed for the rendezvous.
 
 The reference drives data parallelism through ``horovod.torch`` (reference
 bin/train_ce.py:83-131, bin/train_chain.py:106-145, bin/train_se.py:95-134,
 data/dataloader.py:45-46,83-84).  This module offers the same call surface --
 ``init, size, rank, local_rank, broadcast_parameters, broadcast_optimizer_state,
-DistributedOptimizer`` -- with one process per GPU and plain ``ncclAllReduce`` (RCCL):
+DistributedOptimizer`` -- with one process per GPU:
 
-* gradients are averaged with ONE all-reduce of the model's flat gradient buffer (85 MB) on the compute stream when
-  backward is done (Horovod fuses tensors with a 64 MB / 5 ms heuristic instead).  PK2_HVD_OVERLAP=1 selects the
-  bucketed variant -- one all-reduce per bucket (output layer, then LSTM layer 2, 1, 0: the order backward produces
-  them) on a side HIP stream, overlapping the rest of backward -- which is NOT the default because on ROCm 7.2 a
-  second active stream slows the graph-replayed step chains by more than the exchange costs (measured with a
-  one-rank RCCL group: 35.4 -> 39.9 ms per step);
+* the gradient all-reduce is ``pk2_allreduce_bucket`` of libpk2hip.so (include/pk2hip.h: ``ncclAllReduce`` of RCCL
+  on a communicator created by ``pk2_comm_init``); torch.distributed only carries the 128-byte unique id (through
+  its store) and the one-time parameter broadcast.  Without a GPU / with the gloo backend (CPU tests, several
+  ranks on one GPU) the same calls fall back to ``torch.distributed.all_reduce``;
+* two schedules for the 85 MB flat gradient buffer: ONE all-reduce on the compute stream when backward is done, or
+  one all-reduce per bucket (output layer, then LSTM layer 2, 1, 0: the order backward produces them) on a side HIP
+  stream, overlapping the rest of backward.  Which is faster depends on the node (on ROCm 7.2 a second active stream
+  slows the graph-replayed step chains: one rank, 35.4 -> 39.9 ms per step), so with more than one rank the choice is
+  MEASURED at start-up: the two schedules alternate for a few steps, each step's (zero_grad -> gradients exchanged)
+  GPU time is normalised by the GPU time of the same minibatch's forward pass, the ranks pool their means and all
+  switch to the cheaper schedule.  PK2_HVD_OVERLAP=0/1 pins the schedule;
 * the 1/size factor is folded into the optimiser kernel (no extra pass over the gradients);
 * ``step()`` makes the compute stream wait on the side stream, so clipping acts on the averaged
   gradient (the reference clips local, possibly mid-flight gradients: SURVEY.md Appendix B#15).
@@ -20,12 +25,14 @@ Launch with ``python -m torch.distributed.run --nproc-per-node N ...`` (RANK / L
 WORLD_SIZE / MASTER_* from the environment).  Without those variables everything degrades to a
 single process (size() == 1) and no process group is created.
 """
+import ctypes as C
 import os
+import sys
 
 import torch
 import torch.distributed as dist
 
-_state = dict(initialized=False, rank=0, size=1, local_rank=0, group=False)
+_state = dict(initialized=False, rank=0, size=1, local_rank=0, group=False, comm=None)
 
 
 def init(backend=None):
@@ -46,13 +53,61 @@ def init(backend=None):
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
         _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local, group=True)
+        if backend == "nccl" and torch.cuda.is_available() and os.environ.get("PK2_HVD_COMM", "pk2") == "pk2":
+            _state["comm"] = _create_comm()
     _state["initialized"] = True
 
 
+def _create_comm():
+    """The library's own RCCL communicator (pk2_comm_init); the unique id travels through torch.distributed's store."""
+    from . import _lib
+    L = _lib.lib()
+    n = int(L.pk2_comm_unique_id_bytes())
+    store = dist.distributed_c10d._get_default_store()
+    if dist.get_rank() == 0:
+        buf = C.create_string_buffer(n)
+        _lib.check(L.pk2_comm_unique_id(buf))
+        store.set("pk2_comm_unique_id", buf.raw)
+        uid = buf.raw
+    else:
+        uid = bytes(store.get("pk2_comm_unique_id"))
+    h = C.c_void_p()
+    _lib.check(L.pk2_comm_init(dist.get_rank(), dist.get_world_size(), uid, C.byref(h)))
+    return h
+
+
+def comm_library():
+    """Path of the RCCL library behind the communicator ('' when gradients go through torch.distributed)."""
+    if _state["comm"] is None:
+        return ""
+    from . import _lib
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.lib().pk2_comm_info(_state["comm"], None, None, buf, 256))
+    return buf.value.decode()
+
+
+def _allreduce_sum(t, stream=None):
+    """In-place sum of a contiguous f32 tensor over the ranks, enqueued on `stream` (default: the current stream)."""
+    if _state["comm"] is not None and t.is_cuda:
+        from . import _lib
+        st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        _lib.check(_lib.lib().pk2_allreduce_bucket(_state["comm"], C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st.cuda_stream)))
+    elif stream is not None and t.is_cuda:
+        with torch.cuda.stream(stream):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def shutdown():
+    if _state["comm"] is not None:
+        from . import _lib
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        _lib.lib().pk2_comm_destroy(_state["comm"])
     if dist.is_initialized():
         dist.destroy_process_group()
-    _state.update(initialized=False, rank=0, size=1, local_rank=0, group=False)
+    _state.update(initialized=False, rank=0, size=1, local_rank=0, group=False, comm=None)
 
 
 def size():
@@ -109,7 +164,7 @@ def broadcast_optimizer_state(optimizer, root_rank=0):
 
 def allreduce_(tensor, average=True):
     if _collective():
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        _allreduce_sum(tensor) if tensor.dtype == torch.float32 and tensor.is_contiguous() else dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         if average:
             tensor.div_(size())
     return tensor
@@ -119,27 +174,37 @@ class DistributedOptimizer:
     """hvd.DistributedOptimizer(optimizer, named_parameters=...) (reference bin/train_ce.py:131).
 
     Two kinds of wrapped optimiser:
-    * a pykaldi2_amd.optim optimiser over a model with flat buffers: bucketed, stream-overlapped
-      all-reduce driven by the model's bucket hook, averaging folded into the update kernel;
+    * a pykaldi2_amd.optim optimiser over a model with flat buffers: one all-reduce of the flat gradient buffer, or
+      bucketed, stream-overlapped all-reduces driven by the model's bucket hook (see the module docstring for how the
+      schedule is chosen); averaging folded into the update kernel;
     * any torch.optim optimiser: gradients are all-reduced (averaged) per parameter inside step().
     """
+
+    TRIAL_STEPS = 6      # per schedule, after 2 warm-up steps
 
     def __init__(self, optimizer, named_parameters=None):
         self._opt = optimizer
         self._named = list(named_parameters) if named_parameters is not None else None
         self._flat = hasattr(optimizer, "model") and hasattr(optimizer.model, "flat_parameters")
-        self._handles = []
         self._side = None
-        # PK2_HVD_OVERLAP=1: all-reduce every bucket on a side stream as soon as backward has produced it.  Default:
-        # ONE all-reduce of the whole flat gradient buffer on the compute stream when backward is done -- on ROCm 7.2
-        # a second stream that is active next to the graph-replayed LSTM / denominator step chains slows them by more
-        # than the 84 MB exchange costs (one rank, RCCL, side stream: 35.4 -> 39.9 ms per step; DESIGN.md section 6).
-        self._overlap = os.environ.get("PK2_HVD_OVERLAP") == "1"
+        model = getattr(optimizer, "model", None)
+        # the bucketed schedule needs a model that reports finished buckets during backward (LSTMAM does, TransformerAM
+        # does not: its gradients are exchanged in one piece)
+        self._can_overlap = self._flat and callable(getattr(model, "_bucket_ready", None)) and hasattr(model, "_buckets")
+        env = os.environ.get("PK2_HVD_OVERLAP", "auto")
+        self._mode = "single"
+        self._trial = None
         if self._flat and _collective():
-            if self._overlap:
-                optimizer.model._bucket_hook = self._on_bucket
             optimizer.grad_scale = 1.0 / size()
-        self._pending = set()
+            if self._can_overlap:
+                model._bucket_hook = self._on_bucket
+                if env == "1":
+                    self._mode = "overlap"
+                elif env != "0" and size() > 1:
+                    self._trial = dict(step=0, sums={"single": 0.0, "overlap": 0.0}, n={"single": 0, "overlap": 0},
+                                       ev_prev=None, ev_zero=None)
+        self._overlap = self._mode == "overlap"     # (kept for introspection by tests)
+        self._done = []          # [lo, hi) ranges of the flat gradient already exchanged in this step
         self._reduced = False
 
     def __getattr__(self, name):
@@ -147,36 +212,89 @@ class DistributedOptimizer:
 
     # bucket finished on the compute stream -> all-reduce it on the side stream
     def _on_bucket(self, name, grad_slice):
+        if self._mode != "overlap":
+            return
         if grad_slice.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=grad_slice.device)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(grad_slice.device))
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                self._handles.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, async_op=True))
+            self._side.wait_event(ev)
+            _allreduce_sum(grad_slice, self._side)
         else:
-            self._handles.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, async_op=True))
-        self._pending.add(name)
+            _allreduce_sum(grad_slice)
+        lo, hi = self._opt.model._buckets[name]
+        self._done.append((lo, hi))
 
     def synchronize(self):
-        if self._flat and _collective() and not self._overlap and not self._reduced:
-            dist.all_reduce(self._opt.model.flat_parameters()[1], op=dist.ReduceOp.SUM)    # the flat gradient buffer
+        if self._flat and _collective() and not self._reduced:
+            gflat = self._opt.model.flat_parameters()[1]        # the flat gradient buffer
+            if self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
+            # whatever no bucket hook has covered (everything, in the single schedule; nothing, normally, in the
+            # bucketed one; the whole buffer for a model without hooks) goes out now on the compute stream
+            pos = 0
+            for lo, hi in sorted(self._done) + [(gflat.numel(), gflat.numel())]:
+                if lo > pos:
+                    _allreduce_sum(gflat[pos:lo])
+                pos = max(pos, hi)
+            self._done = []
             self._reduced = True
-        for h in self._handles:
-            h.wait()
-        self._handles = []
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-        self._pending.clear()
+            self._trial_mark_exchanged()
 
     def zero_grad(self, *a, **k):
         self._reduced = False
+        self._done = []
+        if self._trial is not None and torch.cuda.is_available():
+            self._trial["ev_zero"] = torch.cuda.Event(enable_timing=True)
+            self._trial["ev_zero"].record()
         return self._opt.zero_grad(*a, **k)
 
     def measure_grad_norm(self, max_norm):
         self.synchronize()  # the norm is taken over the summed gradient
         return self._opt.measure_grad_norm(max_norm)
+
+    # ---- start-up trial: which schedule is cheaper on this node? --------------------------------------------------
+    def _trial_mark_exchanged(self):
+        tr = self._trial
+        if tr is None or not torch.cuda.is_available():
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        tr["ev_sync"] = ev
+
+    def _trial_step_done(self):
+        tr = self._trial
+        if tr is None:
+            return
+        if not torch.cuda.is_available():
+            self._trial = None
+            return
+        ev_end = torch.cuda.Event(enable_timing=True)
+        ev_end.record()
+        if tr["step"] >= 2 and tr.get("ev_prev") is not None and tr.get("ev_zero") is not None and tr.get("ev_sync") is not None:
+            tr["ev_sync"].synchronize()
+            fwd = tr["ev_prev"].elapsed_time(tr["ev_zero"])       # forward pass + loss of this minibatch
+            bwd = tr["ev_zero"].elapsed_time(tr["ev_sync"])       # backward until the gradients are exchanged
+            if fwd > 0:
+                tr["sums"][self._mode] += bwd / fwd
+                tr["n"][self._mode] += 1
+        tr["ev_prev"], tr["ev_zero"], tr["ev_sync"] = ev_end, None, None
+        tr["step"] += 1
+        if tr["step"] >= 2:
+            self._mode = "overlap" if (tr["step"] - 2) % 2 else "single"
+        if tr["step"] >= 2 + 2 * self.TRIAL_STEPS:
+            means = torch.tensor([tr["sums"]["single"] / max(1, tr["n"]["single"]),
+                                  tr["sums"]["overlap"] / max(1, tr["n"]["overlap"])], dtype=torch.float64,
+                                 device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(means, op=dist.ReduceOp.SUM)           # every rank takes the same decision
+            self._mode = "overlap" if float(means[1]) < float(means[0]) else "single"
+            if rank() == 0:
+                sys.stderr.write("[hvd] gradient exchange schedule: %s (backward+exchange / forward GPU time, mean over ranks: "
+                                 "single %.3f, bucketed on a side stream %.3f)\n"
+                                 % (self._mode, float(means[0]) / size(), float(means[1]) / size()))
+            self._trial = None
+        self._overlap = self._mode == "overlap"
 
     def step(self, *a, **k):
         if _collective():
@@ -187,4 +305,10 @@ class DistributedOptimizer:
                 for p in params:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                     p.grad.div_(size())
-        return self._opt.step(*a, **k)
+        out = self._opt.step(*a, **k)
+        # the exchange guard never depends on the caller invoking zero_grad(): gradients are overwritten by the next
+        # backward, which must be followed by a fresh exchange
+        self._reduced = False
+        self._done = []
+        self._trial_step_done()
+        return out

@@ -62,3 +62,60 @@ def test_simulation_pool_from_config_switches():
     assert all(r.dtype == np.float32 and np.argmax(r) >= 32 and r[np.argmax(r)] == 1.0 for r in pool.rirs)
     only_rir = data.SimulationPool.from_config(dict(data_config=dict(simulation_prob=1, use_dir_noise=False, use_reverb=True), synthetic=True))
     assert not only_rir.noises and only_rir.rirs and only_rir.sim.use_rir and not only_rir.sim.use_noise
+
+
+def _zip_source(tmp_path, n_utts, rank, world, seed=3):
+    rng = np.random.default_rng(seed)
+    zpath = tmp_path / "many.zip"
+    if not zpath.exists():
+        with zipfile.ZipFile(zpath, "w") as z:
+            for k in range(n_utts):
+                z.writestr("u%03d.wav" % k, _wav_bytes(rng.uniform(-0.1, 0.1, int(rng.integers(2000, 30000)))))
+    return data.ZipWavSource([dict(wav=str(zpath))], rank=rank, world=world)
+
+
+def test_every_rank_runs_the_same_number_of_steps(tmp_path):
+    """each step ends in a gradient all-reduce, so the number of minibatches of an epoch must not
+    depend on the utterance lengths a rank happens to draw.  Finite source = the reference's DistributedSampler
+    (data/dataloader.py:83-84): every utterance once per epoch across the ranks, equal counts, padding by wrap-around;
+    synthetic source: a count computed from the sweep size alone."""
+    import torch
+    world, batch = 3, 2
+    plans = [data.epoch_plan(_zip_source(tmp_path, 23, r, world), batch, 0, r, world, epoch=1) for r in range(world)]
+    assert len({len(p) for p in plans}) == 1 and len(plans[0]) == 4          # ceil(23 / 6) steps on every rank
+    flat = [i for p in plans for step in p for i in step]
+    assert len(flat) == 24 and set(flat) == set(range(23))                   # one wrapped duplicate
+    assert plans != [data.epoch_plan(_zip_source(tmp_path, 23, r, world), batch, 0, r, world, epoch=2) for r in range(world)]
+    # the generator itself: same number of minibatches on every rank, utterances really read
+    counts = []
+    for r in range(world):
+        bs = list(data.sequence_batches(_zip_source(tmp_path, 23, r, world), batch, 0, torch.device("cpu"), epoch=0))
+        counts.append(len(bs))
+        assert all(len(b["lens"]) == batch and b["wav"].shape[0] == sum(b["lens"]) for b in bs)
+    assert counts == [4, 4, 4]
+    # sweep_size caps the epoch identically on all ranks
+    short = [len(data.epoch_plan(_zip_source(tmp_path, 23, r, world), batch, 1e-4, r, world)) for r in range(world)]
+    assert short == [1, 1, 1]
+    # synthetic generator: ranks draw different lengths, yet the same number of steps
+    n = [len(list(data.sequence_batches(data.SyntheticSource(50, rank=r, world=4), 2, 0.02, torch.device("cpu"))))
+         for r in range(4)]
+    assert n == [3, 3, 3, 3]       # ceil(72 s / (12.3 s * 2))
+
+
+def test_length_bucketed_plan_gives_the_ranks_of_a_step_similar_lengths(tmp_path):
+    world, batch = 4, 2
+    srcs = [_zip_source(tmp_path, 200, r, world, seed=5) for r in range(world)]
+    dur = srcs[0].durations()
+    assert abs(dur[0] - srcs[0].get(0)[0].shape[0] / 16000.0) < 1e-6        # from the archive directory, no decoding
+    def spread(bucketed):
+        plans = [data.epoch_plan(srcs[r], batch, 0, r, world, epoch=0, length_bucketed=bucketed) for r in range(world)]
+        assert len({len(p) for p in plans}) == 1
+        flat = sorted(i for p in plans for st in p for i in st)
+        assert flat == list(range(200))
+        longest = np.array([[max(dur[i] for i in plans[r][k]) for r in range(world)] for k in range(len(plans[0]))])
+        return float(np.mean(longest.max(1) - longest.min(1)))
+    assert spread(True) < 0.35 * spread(False)
+    # synthetic: durations shared by the ranks, content per rank
+    a = data.epoch_plan(data.SyntheticSource(50, rank=0, world=2), 2, 0.05, 0, 2, length_bucketed=True)
+    b = data.epoch_plan(data.SyntheticSource(50, rank=1, world=2), 2, 0.05, 1, 2, length_bucketed=True)
+    assert a == b and all(isinstance(x, float) for st in a for x in st)

@@ -102,15 +102,27 @@ class FlatModel:
         self.p = torch.arange(8, dtype=torch.float32)
         self.g = torch.zeros(8)
         self._bucket_hook = None
+        self._buckets = {"output_layer": (4, 8), "lstm.l0": (0, 4)}
     def flat_parameters(self):
         return self.p, self.g
     def parameters(self):
         return [self.p]
-    def backward(self):
-        self.g[4:] = float(rank + 1)            # "output layer" bucket is produced first
-        if self._bucket_hook: self._bucket_hook("output_layer", self.g[4:])
-        self.g[:4] = 10.0 * (rank + 1)
-        if self._bucket_hook: self._bucket_hook("lstm.l0", self.g[:4])
+    def _bucket_ready(self, name):
+        if self._bucket_hook is not None:
+            lo, hi = self._buckets[name]
+            self._bucket_hook(name, self.g[lo:hi])
+    def backward(self, scale=1.0):
+        self.g[4:] = scale * float(rank + 1)    # "output layer" bucket is produced first
+        self._bucket_ready("output_layer")
+        self.g[:4] = scale * 10.0 * (rank + 1)
+        self._bucket_ready("lstm.l0")
+
+class HooklessModel(FlatModel):
+    """Stands in for TransformerAM: flat buffers but no bucket reports during backward."""
+    _bucket_ready = None
+    def backward(self, scale=1.0):
+        self.g[4:] = scale * float(rank + 1)
+        self.g[:4] = scale * 10.0 * (rank + 1)
 
 class PlainSGD:
     def __init__(self, model, lr):
@@ -123,27 +135,35 @@ class PlainSGD:
         p, g = self.model.flat_parameters()
         p -= self.lr * self.grad_scale * g
 
-m = FlatModel()
-opt = hvd.DistributedOptimizer(PlainSGD(m, 0.5))
-overlap = os.environ.get("PK2_HVD_OVERLAP") == "1"       # bucketed side-stream mode, else one all-reduce after backward
-assert (m._bucket_hook is not None) == overlap and abs(opt.grad_scale - 0.5) < 1e-12
-opt.zero_grad(); m.backward()
-norm = opt.measure_grad_norm(5.0)             # synchronises the buckets first
-opt.step()
-# summed gradient: [30]*4 + [3]*4, averaged -> [15]*4 + [1.5]*4
-expect = torch.arange(8, dtype=torch.float32) - 0.5 * torch.tensor([15.0] * 4 + [1.5] * 4)
-assert torch.allclose(m.p, expect), (m.p, expect)
-assert abs(norm.item() - torch.tensor([15.0] * 4 + [1.5] * 4).norm().item()) < 1e-5
+mode = os.environ.get("PK2_HVD_OVERLAP")          # "1": bucketed side-stream schedule, "0": one all-reduce after backward
+for Model in (FlatModel, HooklessModel):
+    m = Model()
+    opt = hvd.DistributedOptimizer(PlainSGD(m, 0.5))
+    hooked = Model is FlatModel
+    # ADVICE r1 (medium): the bucketed schedule is only ever selected for a model that reports its buckets
+    assert opt._mode == ("overlap" if (mode == "1" and hooked) else "single") and abs(opt.grad_scale - 0.5) < 1e-12
+    opt.zero_grad(); m.backward()
+    norm = opt.measure_grad_norm(5.0)             # synchronises the buckets first
+    opt.step()
+    # summed gradient: [30]*4 + [3]*4, averaged -> [15]*4 + [1.5]*4
+    expect = torch.arange(8, dtype=torch.float32) - 0.5 * torch.tensor([15.0] * 4 + [1.5] * 4)
+    assert torch.allclose(m.p, expect), (m.p, expect)
+    assert abs(norm.item() - torch.tensor([15.0] * 4 + [1.5] * 4).norm().item()) < 1e-5
+    # ADVICE r1 (low): a second step WITHOUT zero_grad() still exchanges the new gradients
+    m.backward(scale=2.0)
+    opt.step()
+    expect = expect - 0.5 * torch.tensor([30.0] * 4 + [3.0] * 4)
+    assert torch.allclose(m.p, expect), (m.p, expect)
 print("OK", rank)
 hvd.shutdown()
 '''
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("overlap", ["0", "1", "auto"])
 def test_hvd_flat_bucketed_allreduce_world_size_2_gloo(tmp_path, overlap):
     script = tmp_path / "f.py"
     script.write_text(FLAT_WORKER % dict(root=ROOT))
-    port = str(29900 + (os.getpid() + int(overlap) * 37) % 90)
+    port = str(29900 + (os.getpid() + ["0", "1", "auto"].index(overlap) * 37) % 90)
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
