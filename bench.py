@@ -609,6 +609,9 @@ def main():
                                % args.batch,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY}},
+        "exchange": {"library": hvd.comm_library() or ("torch.distributed/" + (torch.distributed.get_backend()
+                     if torch.distributed.is_initialized() else "none")),
+                     "schedule": getattr(tr.opt, "_mode", "single"), "api": "pk2_allreduce_bucket" if hvd.comm_library() else "torch.distributed.all_reduce"},
         "roofline": roof, "roofline_lstm": roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
     }
     if world == 1 and not args.no_cpu_baseline:

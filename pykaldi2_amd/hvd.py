@@ -190,7 +190,7 @@ class DistributedOptimizer:
         model = getattr(optimizer, "model", None)
         # the bucketed schedule needs a model that reports finished buckets during backward (LSTMAM does, TransformerAM
         # does not: its gradients are exchanged in one piece)
-        self._can_overlap = self._flat and callable(getattr(model, "_bucket_ready", None)) and hasattr(model, "_buckets")
+        self._can_overlap = self._flat and callable(getattr(model, "_bucket_ready", None))
         env = os.environ.get("PK2_HVD_OVERLAP", "auto")
         self._mode = "single"
         self._trial = None

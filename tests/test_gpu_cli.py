@@ -134,7 +134,7 @@ def test_bench_rccl_path_single_rank_group():
     identity, so the objective after the same steps must equal the run without a process group."""
     import json
     base = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    env = dict(os.environ, PK2_HVD_SINGLE_RANK_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PK2_HVD_SINGLE_RANK_GROUP="1", PK2_HVD_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                            "--master-addr", "127.0.0.1", "--master-port", "29541"] + base,
                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -144,6 +144,9 @@ def test_bench_rccl_path_single_rank_group():
     a = json.loads(dist.stdout.strip().splitlines()[-1])
     b = json.loads(solo.stdout.strip().splitlines()[-1])
     assert a["n_gpus"] == 1 and a["config"]["parallelism"] == "dp1"
+    # the gradients went through the library's own RCCL communicator (pk2_comm_init / pk2_allreduce_bucket), bucketed
+    assert a["exchange"]["api"] == "pk2_allreduce_bucket" and "rccl" in a["exchange"]["library"]
+    assert a["exchange"]["schedule"] == "overlap" and b["exchange"]["api"] == "torch.distributed.all_reduce"
     # split-K GEMMs accumulate with float atomics: equal up to summation order
     assert abs(a["last_objf_per_frame"] - b["last_objf_per_frame"]) <= 2e-3 * abs(b["last_objf_per_frame"]) + 1e-4
 
@@ -155,7 +158,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     rank-0-only extra step would hang here).  Rank 0 prints the one JSON line with n_gpus = 2."""
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
            "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env=dict(os.environ, PK2_HVD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"))
@@ -165,3 +168,6 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8
     assert d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
+    # with more than one rank the exchange schedule is measured at start-up (the two schedules alternate for 12 steps)
+    # and every rank switches to the same one
+    assert "[hvd] gradient exchange schedule: " in out.stderr and d["exchange"]["schedule"] in ("single", "overlap")
