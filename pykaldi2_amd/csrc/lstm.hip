@@ -38,7 +38,14 @@ constexpr int kBwdUnits = 4;        // hidden units per workgroup (4 of the 16 M
                                     // the matrix work is negligible at these batch sizes, and 4x more
                                     // workgroups spread the W_hh^T read over the whole chip)
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate nonlinearities on v_exp_f32 / v_rcp_f32 (about 1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)),
+// tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); absolute error ~1e-7 (libm's expf / tanhf cost 0.27 us of a 4.2 us step, measured).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 struct LstmFwdParams {
   const float* gx;    // [T][B][D*4H]
@@ -56,13 +63,32 @@ struct LstmFwdParams {
 // group, ONE barrier, then the gate math of the group's 64 x 4 (row, unit) pairs on all 256 threads.
 constexpr int kFwdTileGroup = 4;
 
+#ifdef PK2_LSTM_PROFILE
+// Phase timers of the forward step kernel (shader clock cycles), thread 0 of workgroup (0,0,0), summed over the steps.
+__device__ unsigned long long g_lstm_prof[8];
+#define LSTM_T(k, wait) do { wait; if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { const long long now_ = clock64(); atomicAdd(&g_lstm_prof[k], (unsigned long long)(now_ - prof_last_)); prof_last_ = now_; } } while (0)
+#define LSTM_WAIT_ALL asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define LSTM_WAIT_NONE asm volatile("" ::: "memory")
+__global__ void lstm_prof_print(int steps) {
+  printf("lstm_fwd_step wg0 avg shader cycles per step over %d steps: params+counter %llu | global loads returned %llu | mfma + partial tiles in LDS %llu | barrier %llu | gate math, stores issued %llu | stores drained %llu\n",
+         steps, g_lstm_prof[0] / steps, g_lstm_prof[1] / steps, g_lstm_prof[2] / steps, g_lstm_prof[3] / steps, g_lstm_prof[4] / steps, g_lstm_prof[5] / steps);
+  for (int k = 0; k < 8; ++k) g_lstm_prof[k] = 0;
+}
+#else
+#define LSTM_T(k, wait) do { } while (0)
+#endif
+
 template <int KS>
 __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams* __restrict__ pp,
                                                              const StepCounter* __restrict__ cnt, int local) {
   __shared__ float part[kFwdTileGroup][4][16][17];   // [tile][wave] partial 16x16 tiles (padded)
+#ifdef PK2_LSTM_PROFILE
+  long long prof_last_ = clock64();
+#endif
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
   const LstmFwdParams p = *pp;
+  LSTM_T(0, LSTM_WAIT_ALL);
   const int d = blockIdx.y;
   const int u0 = blockIdx.x * kFwdUnits;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -113,6 +139,7 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
 #pragma unroll
           for (int q = 0; q < KS / 4; ++q) af[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        LSTM_T(1, LSTM_WAIT_ALL);
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][0], wf[q][0], acc0, 0, 0, 0);
@@ -125,7 +152,9 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
         for (int r = 0; r < 4; ++r) part[g2][w][kq * 4 + r][li] = acc0[r] + acc1[r];
       }
     }
+    LSTM_T(2, LSTM_WAIT_ALL);
     __syncthreads();
+    LSTM_T(3, LSTM_WAIT_NONE);
     if (pw_active) {
       if (!first) {
 #pragma unroll
@@ -133,14 +162,16 @@ __global__ void __launch_bounds__(kFwdThreads) lstm_fwd_step(const LstmFwdParams
           pre[g] += (part[tg][0][pi_][g * 4 + pu] + part[tg][1][pi_][g * 4 + pu]) +
                     (part[tg][2][pi_][g * 4 + pu] + part[tg][3][pi_][g * 4 + pu]);
       }
-      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]), gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
       const float c = fg * cprev + ig * gg;
-      const float h = og * tanhf(c);
+      const float h = og * fast_tanh(c);
       p.cells[(((size_t)d * T + t) * B + pb) * H + u0 + pu] = c;
       p.y[((size_t)t * B + pb) * yrow + (size_t)d * H + u0 + pu] = h;
       float* gr = p.gates + (((size_t)d * T + t) * B + pb) * 4 * H + u0 + pu;
       gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
     }
+    LSTM_T(4, LSTM_WAIT_NONE);
+    LSTM_T(5, LSTM_WAIT_ALL);
   }
 }
 
@@ -238,7 +269,7 @@ __global__ void __launch_bounds__(WAVES * 64) lstm_bwd_step(const LstmBwdParams*
         for (int ww = 0; ww < WAVES; ++ww) s += part[tg][ww][pi_][pj];
         dh += s;
       }
-      const float tc = tanhf(c);
+      const float tc = fast_tanh(c);
       const float dcv = dcin + dh * og * (1.f - tc * tc);
       p.dc[((size_t)d * B + pb) * H + pk] = dcv * fg;
       float* o = p.dgx + ((size_t)t * B + pb) * ((size_t)D * G4) + (size_t)d * G4 + pk;
@@ -335,7 +366,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_step_x4(const LstmBwdParams* __r
   __syncthreads();
   if (pw_active) {
     if (!last_fwd) dh += (part[pg][0][pi_][pj] + part[pg][1][pi_][pj]) + (part[pg][2][pi_][pj] + part[pg][3][pi_][pj]);
-    const float tc = tanhf(c);
+    const float tc = fast_tanh(c);
     const float dcv = dcin + dh * og * (1.f - tc * tc);
     p.dc[((size_t)d * B + pb) * H + pk] = dcv * fg;
     float* o = p.dgx + ((size_t)t * B + pb) * ((size_t)D * G4) + (size_t)d * G4 + pk;
@@ -447,9 +478,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
       float v[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) v[g] = pre[j][g] + (first ? 0.f : Cs[i][u * 4 + g]);
-      const float ig = sigmoidf_(v[0]), fg = sigmoidf_(v[1]), gg = tanhf(v[2]), og = sigmoidf_(v[3]);
+      const float ig = fast_sigmoid(v[0]), fg = fast_sigmoid(v[1]), gg = fast_tanh(v[2]), og = fast_sigmoid(v[3]);
       const float c = fg * cprev[j] + ig * gg;
-      const float h = og * tanhf(c);
+      const float h = og * fast_tanh(c);
       p.cells[(((size_t)d * T + t) * B + b) * H + u0 + u] = c;
       p.y[((size_t)t * B + b) * yrow + (size_t)d * H + u0 + u] = h;
       float* gr = p.gates + (((size_t)d * T + t) * B + b) * 4 * H + u0 + u;
@@ -543,7 +574,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_pointwise_big(const LstmBwdParam
   const float c = p.cells[(((size_t)d * T + t) * B + b) * H + k];
   const float cprev = first_fwd ? 0.f : p.cells[(((size_t)d * T + tp) * B + b) * H + k];
   float* dcp = p.dc + ((size_t)d * B + b) * H + k;
-  const float tc = tanhf(c);
+  const float tc = fast_tanh(c);
   const float dcv = (last_fwd ? 0.f : *dcp) + dh * og * (1.f - tc * tc);
   *dcp = dcv * fg;
   float* o = p.dgx + ((size_t)t * B + b) * ((size_t)D * G4) + (size_t)d * G4 + k;
@@ -629,6 +660,9 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
     }
   });
   if (rc) return rc;
+#ifdef PK2_LSTM_PROFILE
+  hipLaunchKernelGGL(lstm_prof_print, dim3(1), dim3(1), 0, stream, T - 1);
+#endif
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
