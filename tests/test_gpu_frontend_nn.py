@@ -19,14 +19,51 @@ def test_fbank_cmn_match_reference_golden(golden):
     feats_c, _, _ = fb(wav, lens, apply_cmn=True)
     feats, feats_c = feats.cpu().numpy(), feats_c.cpu().numpy()
     off = np.concatenate([[0], np.cumsum(frames)])
+    worst = 0.0
     for i in range(len(lens)):
         want = g["fbank%d" % i]
         got = feats[off[i]:off[i + 1]]
         assert got.shape == want.shape
-        # log-mel values are O(10); f32 FFT vs the reference's f64 FFT rounded to complex64
-        assert np.abs(got - want).max() < 2e-3, (i, np.abs(got - want).max())
-        assert np.abs(feats_c[off[i]:off[i + 1]] - g["cmn%d" % i]).max() < 2e-3
+        # log-mel values are O(10); f32 FFT vs the reference's f64 FFT rounded to complex64: measured 2e-5 on the
+        # GPU box (round 2), so 2e-4 leaves one decade (round 1 allowed 2e-3 without having measured)
+        worst = max(worst, np.abs(got - want).max(), np.abs(feats_c[off[i]:off[i + 1]] - g["cmn%d" % i]).max())
+        assert np.abs(got - want).max() < 2e-4, (i, np.abs(got - want).max())
+        assert np.abs(feats_c[off[i]:off[i + 1]] - g["cmn%d" % i]).max() < 2e-4
     assert not feats[off[4]:off[5]].any()
+    print("fbank / CMN max abs error vs the reference: %.3g" % worst)
+
+
+def test_wav_to_ce_posteriors_end_to_end_matches_reference_cpu_path(golden):
+    """north_star: "outputs match the reference PyTorch CPU path on the same minibatch -- CE frame posteriors within
+    1e-4 rel".  The whole chain at once, raw waveforms in: on-device fbank + CMN + zero padding + 3x512 BLSTM (P = 5768,
+    default initialisation after manual_seed(0), eval) against the reference's own stft / cmn / collate_fn / LSTMAM
+    run on the CPU by tools/gen_golden.py (tests/golden/e2e_ce.npz).  A relative error of a posterior is an absolute
+    error of its logarithm."""
+    g = golden("e2e_ce")
+    lens = [int(n) for n in g["lens"]]
+    frames = [int(n) for n in g["frames"]]
+    fb = fbank.FbankExtractor()
+    wav = torch.from_numpy(np.concatenate([g["wav%d" % i] for i in range(len(lens))])).cuda()
+    feats, fr, row_off = fb(wav, lens, apply_cmn=True)
+    assert list(fr) == frames
+    off = np.concatenate([[0], np.cumsum(frames)])
+    fbank_err = max(np.abs(feats[off[i]:off[i + 1]].cpu().numpy() - g["feats%d" % i]).max() for i in range(len(lens)))
+    x = fb.pad_roll_subsample(feats, row_off, fr, shift=0, subsample=1, time_major=True)
+    torch.manual_seed(0)
+    m = lstm.LSTMAM(80, 5768, 512, 3, 0.2, True).cuda().eval()
+    with torch.no_grad():
+        logits = m.forward_time_major(x).transpose(0, 1)            # [B, T, P]
+        logp = torch.log_softmax(logits.double(), dim=-1).cpu().numpy()
+        lse = torch.logsumexp(logits.double(), dim=-1).cpu().numpy()
+        am = logits.argmax(-1).cpu().numpy()
+    worst = 0.0
+    for i, T in enumerate(frames):
+        err = np.abs(logp[i, :T, ::16] - g["logp_sub"][i, :T]).max()
+        worst = max(worst, err, np.abs(lse[i, :T] - g["lse"][i, :T]).max())
+        assert (am[i, :T] == g["argmax"][i, :T]).mean() > 0.99
+    print("end-to-end: fbank+CMN max abs error %.3g, log-posterior max abs error %.3g" % (fbank_err, worst))
+    assert fbank_err < 5e-4, fbank_err
+    assert worst < 1e-4, worst
 
 
 def test_pad_roll_subsample_matches_reference_golden(golden):

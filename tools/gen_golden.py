@@ -208,9 +208,62 @@ def gen_chunk_mvn():
     print("chunk_mvn keys", len(out))
 
 
+def gen_e2e():
+    """north_star's "same minibatch" clause end to end: raw wav -> the reference's stft-based log-mel fbank
+    (data/sr_dataset.py:279-296) -> cmn (reader/preprocess.py:34-41) -> SeqDataloader.collate_fn zero padding
+    (data/dataloader.py:94-136) -> the reference's LSTMAM (models/lstm.py, 3x512 bidirectional, P = 5768, default
+    initialisation after torch.manual_seed(0), eval mode) -> frame log-posteriors on the CPU.  The fixture holds the
+    waveforms and a slice of the log-posteriors (every 16th pdf, all frames) plus each frame's logsumexp and argmax; the
+    21 M weights are not stored: the test re-creates them with the same seed (tests/golden/lstm_init.npz pins that the
+    default initialisation is bit-identical)."""
+    sys.path.insert(0, REF)
+    from simulation.freq_analysis import stft
+    pre = load_by_path("ref_preprocess3", "reader/preprocess.py")
+    dl = load_by_path("ref_dataloader3", "data/dataloader.py")
+    lstm_mod = load_by_path("ref_lstm3", "models/lstm.py")
+    with open(os.path.join(REF, "data/mel80_window.txt")) as f:
+        window = np.vstack([np.asarray([np.float32(j) for j in line.rstrip("\n").split(",")]) for line in f])
+
+    def logfbank(wav):
+        t1 = np.sum(window, 0)
+        t1[t1 == 0] = -1
+        mel = window.dot(np.diag(1 / t1)).T
+        wav = wav[1:] - 0.96 * wav[:-1]
+        S = stft(wav, n_fft=512, hop_length=160, win_length=400, window=np.hamming(400), center=False).T
+        return np.log((np.abs(S) ** 2).T.dot(mel * 32768 ** 2) + 1)
+
+    rng = np.random.default_rng(21)
+    lens = [20801, 14400]                                   # 1.3 s and 0.9 s -> 129 and 89 frames
+    wavs = [synth_wav(rng, n) for n in lens]
+    feats = [np.asarray(pre.cmn(logfbank(w), axis=0)).astype(np.float32) for w in wavs]
+
+    class Dummy:
+        test_only = False
+    batch = [(f, "utt%d" % i, np.zeros((f.shape[0], 1), dtype=np.int64), np.zeros((1, 3), dtype=np.int64))
+             for i, f in enumerate(feats)]
+    data = dl.SeqDataloader.collate_fn(Dummy(), batch)
+    torch.manual_seed(0)
+    m = lstm_mod.LSTMAM(80, 5768, 512, 3, 0.2, True).eval()
+    with torch.no_grad():
+        x = data["x"].to(torch.float32)
+        logits = m.output_layer(m.lstm(x)[0])               # models/lstm.py:59 with the typo fixed
+        logp = torch.log_softmax(logits.double(), dim=-1)
+    out = dict(lens=np.asarray(lens), frames=np.asarray([f.shape[0] for f in feats]))
+    for i, w in enumerate(wavs):
+        out["wav%d" % i] = w
+        out["feats%d" % i] = feats[i]
+    out["logp_sub"] = logp[:, :, ::16].numpy().astype(np.float32)
+    out["lse"] = torch.logsumexp(logits.double(), dim=-1).numpy()
+    out["argmax"] = logits.argmax(-1).numpy()
+    out["logits_sub"] = logits[:, :, ::16].numpy()
+    np.savez_compressed(os.path.join(OUT, "e2e_ce.npz"), **out)
+    print("e2e", out["logp_sub"].shape, out["frames"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_chunk_mvn()
     gen_fbank()
     gen_lstm()
     gen_ce_optim_misc()
+    gen_e2e()
