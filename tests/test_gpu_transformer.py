@@ -72,3 +72,86 @@ def test_transformer_state_dict_keys_and_init_follow_torch():
     # all layers start as copies of one initialised layer (nn.TransformerEncoder deep copies)
     a, b = m.transformer.layers[0], m.transformer.layers[1]
     assert torch.equal(a.conv1d.weight, b.conv1d.weight)
+
+
+def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle():
+    """BASELINE configs[4]: the 12-layer TransformerAM (dim 512, 8 heads, FFN 2048, conv k=3; reference
+    bin/train_transformer_se.py:128,243-258 model call with a key-padding mask) feeding ChainObjtiveBatch
+    (ops/ops.py:243-280).  Three links, each against its own reference: logits vs the torch CPU forward of the same
+    modules; objective and d objf / d logits vs the LF-MMI oracle on those logits; parameter gradients of the
+    composition vs torch CPU autograd fed with the oracle's gradient.  T = 60 subsampled frames."""
+    from oracle import chain_ref as R
+    from pykaldi2_amd import chain, ops, synth
+    torch.manual_seed(0)
+    P, T, B, L = 600, 60, 2, 12
+    m = transformer.TransformerAM(80, 512, 8, 2048, L, 0.0, P)
+    for lp in m.transformer.layers:
+        for p in lp.parameters():
+            p.data.add_(0.02 * torch.randn_like(p))
+    ref = copy.deepcopy(m).eval()
+    rng = np.random.default_rng(5)
+    sups = [chain.Supervision(synth.numerator_fst_from_alignment(synth.pdf_alignment(rng, n, P)), label_dim=P) for n in (180, 133)]
+    lens = [s.frames_per_sequence for s in sups]
+    assert lens == [60, 45]
+    x = torch.randn(T, B, 80)
+    kpm = torch.ones(B, T, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        kpm[i, :n] = False
+    g = synth.den_graph_arcs(2000, 60000, P, seed=3, loop_pdf_differs=True)
+    den = chain.DenominatorGraph(g, P)
+    dref = R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, P)
+    opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=0.1)
+    # device: model -> LF-MMI -> backward
+    md = m.cuda().train()
+    logits = md(x.cuda(), None, kpm.cuda())                             # [T, B, P]
+    logits.retain_grad()
+    loss = ops.ChainObjtiveBatch.apply(logits.transpose(0, 1), den, sups, opts)
+    loss.backward()
+    dlogits = logits.grad.detach().cpu()                                # = -d objf / d logits (ops/ops.py:276-280)
+    # (1) logits vs torch CPU
+    want = _reference_forward(ref, x, None, kpm)
+    got = logits.detach().cpu()
+    for i, n in enumerate(lens):
+        err = (got[:n, i] - want.detach()[:n, i]).abs().max().item()
+        assert err < 2e-4 * max(1.0, want.detach()[:n, i].abs().max().item()), (i, err)
+    # (2) objective / derivative vs the oracle, on the device's own logits
+    total, grad_o = 0.0, torch.zeros(T, B, P, dtype=torch.float64)
+    for i, n in enumerate(lens):
+        s = sups[i]
+        fst = R.NumFstRef(s.num_states, s.src, s.dst, s.pdf, s.arc_weight, s.final_states, s.final_weights, s.state_time)
+        objf, dg, _ = R.chain_objf_and_deriv(got[:n, i].double().numpy(), dref, fst, leaky=1e-4, xent_regularize=0.1)
+        total += objf
+        grad_o[:n, i] = torch.from_numpy(dg)
+    assert abs(loss.item() - total) <= 1e-3 * abs(total), (loss.item(), total)
+    assert (dlogits.double() + grad_o).abs().max().item() < 1e-4
+    # (3) parameter gradients of the composition: torch CPU autograd fed with the gradient the device put at the logits
+    # (checked against the oracle above), with the same modules in float64 as the truth and the reference's float32 CPU
+    # run beside it.  In float32 a ReLU input that is ~0 can land on the other side of the kink than in float64 (FFN and
+    # conv ReLUs of 12 layers x 120 rows x 2560 units); one such flip moves the gradients of everything upstream of it by
+    # ~1e-3 of their size -- in the device run AND in the reference's float32 run, at different layers (measured:
+    # device 1e-6 for layers 1..11 and 5e-3 at layer 0; torch float32 CPU 1e-3 from layer 5 down).  So: every tensor
+    # within 3e-2 of the truth in relative Frobenius norm, and the tensors no flip can reach (output layer, final norm:
+    # behind the last ReLU) within 1e-5.
+    (want * dlogits).sum().backward()
+    ref64 = copy.deepcopy(ref).double()
+    for p_ in ref64.parameters():
+        p_.grad = None
+    want64 = _reference_forward(ref64, x.double(), None, kpm)
+    (want64 * dlogits.double()).sum().backward()
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    e_dev, e_cpu = [], []
+    names = [n for n, _ in md.named_parameters()]
+    for name, p in md.named_parameters():
+        truth = g64[name].grad
+        scale = max(1e-12, truth.norm().item())
+        e_dev.append((p.grad.cpu().double() - truth).norm().item() / scale)
+        e_cpu.append((g32[name].grad.double() - truth).norm().item() / scale)
+        assert e_dev[-1] < 3e-2, (name, e_dev[-1], e_cpu[-1])
+    e_dev, e_cpu = np.array(e_dev), np.array(e_cpu)
+    print("12-layer transformer + LF-MMI: objective %.4f (oracle %.4f); parameter gradients vs float64 (relative Frobenius "
+          "error per tensor): device median %.1e max %.1e, %d of %d tensors < 1e-4; reference float32 CPU median %.1e max "
+          "%.1e, %d < 1e-4" % (loss.item(), total, np.median(e_dev), e_dev.max(), (e_dev < 1e-4).sum(), len(e_dev),
+                               np.median(e_cpu), e_cpu.max(), (e_cpu < 1e-4).sum()))
+    for n_, e_ in zip(names, e_dev):
+        if n_.startswith("output_layer.") or n_.startswith("transformer.norm."):
+            assert e_ < 1e-5, (n_, e_)
