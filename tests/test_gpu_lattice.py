@@ -282,3 +282,108 @@ def test_one_workgroup_decoder_variant():
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+FULL_SIZE_WORKER = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from pykaldi2_amd import lattice, synth
+P = 5768
+g = synth.decoding_graph_arcs(20000, P, seed=0)
+tm = synth.transition_model_arrays(P)
+o = lattice.LatticeFasterDecoderOptions(beam=13.0, lattice_beam=7.0, max_active=7000, min_active=200)
+rec = lattice.MappedLatticeFasterRecognizer(lattice.TransitionModel.from_arrays(tm), g, 0.1, o)
+ll = torch.from_numpy(np.load(%(ll)r)).cuda()
+lat = rec.decode_batch(ll, [150, 97])
+out = {}
+for n in range(2):
+    for k, v in lat.export(n).items():
+        out["%%s%%d" %% (k, n)] = v
+np.savez(%(out)r, status=lat.status, best=lat.best_cost, **out)
+'''
+
+
+def test_full_size_lattice_properties(tmp_path):
+    """The configuration bench.py --se times (BASELINE configs[3]; reference bin/train_se.py:173-181 decoder options):
+    P = 5768, 230k-state / 460k-arc word-loop HCLG, beam 13, lattice-beam 7, max_active 7000 (binding: random-init
+    scores are flat at acoustic scale 0.1), two utterances.  No oracle at this size -- properties instead:
+    (1) the launch-per-frame decoder (default) and the one-workgroup decoder (PK2_LAT_DECODER=wg, own process) keep
+        bit-identical token costs and link sets;
+    (2) token costs are the best forward costs of the kept links, and EVERY kept link lies on a complete path within
+        lattice_beam of the best one (Kaldi's PruneForwardLinks guarantee);
+    (3) MMI posteriors: numerator - denominator sums to 0 on every frame (drop_frames off), the denominator mass of a
+        frame is <= 1, padding frames stay 0."""
+    import os
+    import subprocess
+    import sys
+    P, lens, ac_scale, lat_beam = 5768, [150, 97], 0.1, 7.0
+    rng = np.random.default_rng(11)
+    ll = (2.0 * rng.standard_normal((2, 150, P))).astype(np.float32)
+    g = synth.decoding_graph_arcs(20000, P, seed=0)
+    assert g["num_states"] >= 200000
+    tm = synth.transition_model_arrays(P)
+    rec = _recognizer(g, tm, 13.0, lat_beam, ac_scale, 7000, 200)
+    lat = rec.decode_batch(torch.from_numpy(ll).cuda(), lens)
+    assert (lat.status == 0).all()
+    exp = [lat.export(n) for n in range(2)]
+    # (1) the other decoder, in its own process
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    np.save(tmp_path / "ll.npy", ll)
+    script = tmp_path / "w.py"
+    script.write_text(FULL_SIZE_WORKER % dict(root=root, ll=str(tmp_path / "ll.npy"), out=str(tmp_path / "wg.npz")))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PK2_LAT_DECODER="wg"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    wg = np.load(tmp_path / "wg.npz")
+    assert (wg["status"] == 0).all() and np.array_equal(wg["best"], lat.best_cost)
+    for n in range(2):
+        other = {k: wg["%s%d" % (k, n)] for k in exp[n]}
+        a, b = _canon(exp[n]), _canon(other)
+        assert a[0] == b[0] and a[1] == b[1], n
+    # (2) forward costs and the lattice-beam property, on the exported arrays
+    for n, T in enumerate(lens):
+        A = exp[n]
+        fr, src, dst = A["tok_frame"], A["link_src"], A["link_dst"]
+        cost = A["link_graph"].astype(np.float64) + ac_scale * A["link_ac"].astype(np.float64)
+        eps = A["link_tid"] == 0
+        assert fr.max() == T and (fr[dst] - fr[src] == np.where(eps, 0, 1)).all()
+        ntok = fr.shape[0]
+        alpha = np.full(ntok, np.inf); alpha[(fr == 0) & (A["tok_cost"] == 0)] = 0.0
+        beta = np.full(ntok, np.inf)
+        last = fr == T
+        fin = A["tok_final"].astype(np.float64)
+        beta[last] = fin[last] if np.isfinite(fin[last]).any() else 0.0
+        by_src = [np.flatnonzero(fr[src] == t) for t in range(T + 1)]
+        for t in range(T + 1):                   # forward: epsilon closure of frame t, then the emitting links t -> t+1
+            e, m = by_src[t][eps[by_src[t]]], by_src[t][~eps[by_src[t]]]
+            for _ in range(64):
+                new = alpha.copy(); np.minimum.at(new, dst[e], alpha[src[e]] + cost[e])
+                if np.array_equal(new, alpha):
+                    break
+                alpha = new
+            np.minimum.at(alpha, dst[m], alpha[src[m]] + cost[m])
+        for t in range(T, -1, -1):               # backward
+            e, m = by_src[t][eps[by_src[t]]], by_src[t][~eps[by_src[t]]]
+            np.minimum.at(beta, src[m], beta[dst[m]] + cost[m])
+            for _ in range(64):
+                new = beta.copy(); np.minimum.at(new, src[e], beta[dst[e]] + cost[e])
+                if np.array_equal(new, beta):
+                    break
+                beta = new
+        assert np.abs(alpha - A["tok_cost"]).max() < 2e-2 * (1 + T / 100), np.abs(alpha - A["tok_cost"]).max()
+        best = (alpha[last] + beta[last]).min()
+        assert abs(best - float(lat.best_cost[n])) < 2e-2
+        through = alpha[src] + cost + beta[dst]
+        assert through.min() <= best + 1e-6 and through.max() <= best + lat_beam + 5e-2, (through.max() - best)
+        assert np.isfinite(alpha).all() and np.isfinite(beta).all()      # every kept token lies on a complete path
+        assert len(src) / T > 1000                                        # a real lattice, not a single path
+    # (3) MMI posteriors
+    ref = [synth.tid_alignment(rng, T, P) for T in lens]
+    like, post = lat.mmi(ref, 1.0, 0.2, drop_frames=False)
+    post = post.cpu().numpy()
+    assert np.isfinite(like.cpu().numpy()).all()
+    for n, T in enumerate(lens):
+        assert np.abs(post[n, :T].sum(1)).max() < 1e-4
+        den = -np.minimum(post[n, :T], 0).sum(1)
+        assert den.max() <= 1 + 1e-4 and den.min() > 0.5
+        assert not post[n, T:].any()
