@@ -39,7 +39,12 @@ __global__ void __launch_bounds__(kCeThreads) softmax_ce_kernel(
   const int tid = threadIdx.x;
   const float* x = logits + row * row_stride;
   const int64_t tgt = targets[row];
-  const bool ignored = tgt == ignore_index;
+  // A label outside [0, P) that is not ignore_index (an alignment with pdf-ids beyond the config's label_size) must not
+  // index the row: nn.CrossEntropyLoss asserts on it; here the row contributes nothing and the loss becomes NaN -- loud,
+  // without a device-to-host round trip on the hot path.
+  const bool out_of_range = tgt != ignore_index && (tgt < 0 || tgt >= P);
+  if (out_of_range && tid == 0) atomicAdd(loss_sum, __int_as_float(0x7fc00000));
+  const bool ignored = tgt == ignore_index || out_of_range;
   float* g = grad ? grad + row * grad_row_stride : nullptr;
   if (ignored && !logprob) {
     if (g) for (int p = tid; p < P; p += kCeThreads) g[p] = 0.f;

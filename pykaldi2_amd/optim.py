@@ -34,6 +34,47 @@ class _FlatOptimizer:
     def _flat(self):
         return self.model.flat_parameters()
 
+    # ---- torch.optim-format state dicts ---------------------------------------------------------------------------
+    # The reference's checkpoints hold torch.optim state dicts (bin/train_ce.py:160-165: {'model', 'optimizer',
+    # 'epoch'}): per-parameter state keyed by the index of the parameter in model.parameters() order plus
+    # param_groups.  The flat buffers here are views of the same parameters, so both directions are a slicing job.
+    def _segments(self):
+        """[(offset, count, shape)] of every parameter inside the flat buffers, in model.parameters() order."""
+        self._flat()
+        layout = self.model._layout
+        return [(layout[n][0], layout[n][1], tuple(p.shape)) for n, p in self.model.named_parameters()]
+
+    def _to_torch_state(self, tensors, step):
+        """tensors: {key: flat tensor or None} -> {index: {key: per-parameter copy, 'step': tensor}}"""
+        out = {}
+        for i, (o, c, shape) in enumerate(self._segments()):
+            st = {k: v[o:o + c].view(shape).clone() for k, v in tensors.items() if v is not None}
+            if step is not None:
+                st["step"] = torch.tensor(float(step))
+            out[i] = st
+        return out
+
+    def _from_torch_state(self, state, keys):
+        """Inverse: gathers per-parameter state tensors into flat buffers; returns ({key: flat}, step)."""
+        p, _ = self._flat()
+        flat = {k: torch.zeros_like(p) for k in keys}
+        step = 0
+        for i, (o, c, shape) in enumerate(self._segments()):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            for k in keys:
+                if k in st and st[k] is not None:
+                    flat[k][o:o + c].copy_(torch.as_tensor(st[k]).reshape(-1).to(p.device))
+            if "step" in st:
+                step = max(step, int(float(st["step"])))
+        return flat, step
+
+    @staticmethod
+    def _is_torch_format(sd):
+        st = sd.get("state")
+        return isinstance(st, dict) and "param_groups" in sd and all(isinstance(k, int) or str(k).isdigit() for k in st)
+
     def measure_grad_norm(self, max_norm):
         p, g = self._flat()
         L = _lib.lib()
@@ -79,12 +120,32 @@ class Adam(_FlatOptimizer):
                                             float(self.grad_scale), _lib.stream_ptr(p.device)))
 
     def state_dict(self):
-        return dict(state=self.state, step=self.step_count,
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        """torch.optim.Adam's format (what the reference's checkpoints hold and torch.optim.Adam.load_state_dict takes)."""
+        grp = self.param_groups[0]
+        n = len(self._segments())
+        state = {} if self.state is None else self._to_torch_state(
+            dict(exp_avg=self.state["exp_avg"], exp_avg_sq=self.state["exp_avg_sq"],
+                 max_exp_avg_sq=self.state["max_exp_avg_sq"]), self.step_count)
+        return dict(state=state, param_groups=[dict(lr=grp["lr"], betas=tuple(self.betas), eps=self.eps,
+                                                    weight_decay=grp["weight_decay"], amsgrad=self.amsgrad,
+                                                    maximize=False, foreach=None, capturable=False, differentiable=False,
+                                                    fused=None, params=list(range(n)))])
 
     def load_state_dict(self, sd):
-        self.state, self.step_count = sd["state"], sd["step"]
-        self.param_groups[0].update(sd["param_groups"][0])
+        if not self._is_torch_format(sd):      # round-1 checkpoints of this repo: flat tensors
+            self.state, self.step_count = sd["state"], sd["step"]
+            self.param_groups[0].update(sd["param_groups"][0])
+            return
+        g = sd["param_groups"][0]
+        self.param_groups[0].update(lr=g["lr"], weight_decay=g.get("weight_decay", 0.0))
+        self.betas, self.eps = tuple(g.get("betas", self.betas)), g.get("eps", self.eps)
+        self.amsgrad = bool(g.get("amsgrad", self.amsgrad))
+        if not sd["state"]:
+            self.state, self.step_count = None, 0
+            return
+        keys = ["exp_avg", "exp_avg_sq"] + (["max_exp_avg_sq"] if self.amsgrad else [])
+        flat, self.step_count = self._from_torch_state(sd["state"], keys)
+        self.state = dict(exp_avg=flat["exp_avg"], exp_avg_sq=flat["exp_avg_sq"], max_exp_avg_sq=flat.get("max_exp_avg_sq"))
 
 
 class SGD(_FlatOptimizer):
@@ -108,9 +169,25 @@ class SGD(_FlatOptimizer):
                                            float(self.grad_scale), _lib.stream_ptr(p.device)))
 
     def state_dict(self):
-        return dict(buf=self.buf, step=self.step_count,
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+        """torch.optim.SGD's format (momentum_buffer per parameter)."""
+        grp = self.param_groups[0]
+        n = len(self._segments())
+        state = {} if self.buf is None else self._to_torch_state(dict(momentum_buffer=self.buf), None)
+        return dict(state=state, param_groups=[dict(lr=grp["lr"], momentum=self.momentum, dampening=0,
+                                                    weight_decay=grp["weight_decay"], nesterov=False, maximize=False,
+                                                    foreach=None, differentiable=False, fused=None,
+                                                    params=list(range(n)))])
 
     def load_state_dict(self, sd):
-        self.buf, self.step_count = sd["buf"], sd["step"]
-        self.param_groups[0].update(sd["param_groups"][0])
+        if not self._is_torch_format(sd):
+            self.buf, self.step_count = sd["buf"], sd["step"]
+            self.param_groups[0].update(sd["param_groups"][0])
+            return
+        g = sd["param_groups"][0]
+        self.param_groups[0].update(lr=g["lr"], weight_decay=g.get("weight_decay", 0.0))
+        self.momentum = g.get("momentum", self.momentum)
+        if not sd["state"]:
+            self.buf, self.step_count = None, 0
+            return
+        flat, _ = self._from_torch_state(sd["state"], ["momentum_buffer"])
+        self.buf, self.step_count = flat["momentum_buffer"], 1      # the buffer exists: not the first step

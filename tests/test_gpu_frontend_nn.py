@@ -189,6 +189,13 @@ def test_cross_entropy_matches_reference_golden(golden):
         loss.backward()
         assert abs(loss.item() - float(g["ce_loss_" + red])) < 1e-5 * abs(float(g["ce_loss_" + red]))
         assert np.abs(x.grad.cpu().numpy() - g["ce_grad_" + red]).max() < 1e-6
+    # a label outside [0, P) (not ignore_index) never indexes the row: the loss turns NaN, that row's gradient is zero
+    tg = torch.from_numpy(g["ce_targets"]).clone()
+    tg[0] = g["ce_logits"].shape[1] + 5
+    x = torch.from_numpy(g["ce_logits"]).cuda().requires_grad_()
+    loss = ops.CrossEntropyLoss(ignore_index=-100, reduction="sum")(x, tg.cuda())
+    loss.backward()
+    assert torch.isnan(loss).item() and not x.grad[0].any().item() and torch.isfinite(x.grad).all().item()
 
 
 class _Flat:

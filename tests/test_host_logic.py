@@ -173,3 +173,42 @@ def test_hvd_flat_bucketed_allreduce_world_size_2_gloo(tmp_path, overlap):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs)
+
+
+def test_optimizer_state_dicts_are_torch_optim_format():
+    """the checkpoints of the reference hold torch.optim state dicts (bin/train_ce.py:160-165); the flat
+    fused optimisers read and write that format, so `-resume_from_model` works across the two code bases."""
+    import torch
+    from pykaldi2_amd import lstm, optim
+    torch.manual_seed(0)
+    m = lstm.LSTMAM(8, 11, 16, 2, 0.0, True)
+    # the reference side: the same architecture as torch modules, trained two steps with torch.optim
+    lin = torch.nn.Linear(32, 11)                  # reference models/lstm.py:45-54 creates the output layer first
+    rnn = torch.nn.LSTM(8, 16, 2, batch_first=True, bidirectional=True)
+    ref_params = list(lin.parameters()) + list(rnn.parameters())
+    assert [tuple(p.shape) for p in m.parameters()] == [tuple(p.shape) for p in ref_params]
+    for name, cls, kw in (("adam", torch.optim.Adam, dict(lr=1e-3, amsgrad=True)), ("sgd", torch.optim.SGD, dict(lr=1e-2, momentum=0.9))):
+        topt = cls(ref_params, **kw)
+        for _ in range(2):
+            for p in ref_params:
+                p.grad = torch.randn_like(p)
+            topt.step()
+        tsd = topt.state_dict()
+        ours = optim.Adam(m, lr=5.0, amsgrad=True) if name == "adam" else optim.SGD(m, lr=5.0, momentum=0.1)
+        ours.load_state_dict(tsd)                                   # a reference-written optimiser state
+        assert ours.param_groups[0]["lr"] == kw["lr"]
+        back = ours.state_dict()                                    # ... and what this repo writes
+        assert sorted(back["state"].keys()) == list(range(len(ref_params))) and back["param_groups"][0]["params"] == list(range(len(ref_params)))
+        for i in range(len(ref_params)):
+            for k, v in tsd["state"][i].items():
+                if k == "step":
+                    assert float(back["state"][i]["step"]) == float(v)
+                elif v is not None:
+                    assert torch.equal(back["state"][i][k], v), (name, i, k)
+        cls(list(m.parameters()), **kw).load_state_dict(back)       # torch.optim accepts it
+        if name == "adam":
+            assert ours.step_count == 2 and ours.amsgrad
+    # an optimiser that has not stepped yet
+    fresh = optim.Adam(m, lr=1e-3, amsgrad=True)
+    assert fresh.state_dict()["state"] == {}
+    fresh.load_state_dict(fresh.state_dict())
