@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "gemm_tile.h"
+#include "lstm_persist.h"
 #include "step_graph.h"
 
 namespace pk2 {
@@ -623,6 +624,12 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
   PK2_REQUIRE(gx && whh && y && gates && cells && B > 0 && T > 0 && (D == 1 || D == 2), "lstm_fwd: bad args");
   PK2_REQUIRE(lstm_h_ok(H), "lstm_fwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (lstm_persist_wanted(B, H, D)) {       // one launch for the whole sequence (lstm_persist.hip)
+    bool ran = false;
+    int prc = lstm_fwd_persist_launch(gx, whh, bhh, B, T, H, D, y, gates, cells, stream, &ran);
+    if (prc) return prc;
+    if (ran) return PK2_OK;
+  }
   ParamSlot<LstmFwdParams>* slot;
   int rc = get_param_slot(g_fwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;

@@ -1,0 +1,20 @@
+// Persistent small-batch LSTM recurrence (lstm_persist.hip): internal interface used by lstm.hip.
+#pragma once
+#include "common.h"
+
+namespace pk2 {
+
+struct PersistCtl {
+  unsigned reg[8];     // workgroups registered per XCD (arrival order = role)
+  unsigned abort;      // set when a poll timed out: every workgroup leaves, outputs keep their NaN sentinels
+  unsigned pad[7];
+};
+
+bool lstm_persist_wanted(int B, int H, int D);
+// Runs the whole forward recurrence of a layer in one launch.  *ran = false when the persistent path is unusable on this
+// device (checked once): the caller then uses the step kernels.
+int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
+                            float* gates, float* cells, hipStream_t stream, bool* ran);
+int lstm_persist_status(unsigned* abort_flag);
+
+}  // namespace pk2

@@ -115,6 +115,74 @@ __global__ void __launch_bounds__(256) ks(unsigned* buf, int steps, unsigned* fa
   if (acc == 1.2345f) sink[0] = acc;
 }
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u load16_sc0(const unsigned* p) {
+  v4u v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// same exchange through the XCD's L2 only: plain stores (L1 is write-through) and L1-bypassing sc0 loads
+template <int VALS>
+__global__ void __launch_bounds__(256) ks0(unsigned* buf, int steps, unsigned* fail, float* sink, int use_xcd, unsigned* reg) {
+  extern __shared__ float lds[];
+  __shared__ int s_slot, s_group;
+  const int tid = threadIdx.x;
+  const unsigned xcd = xcc_id();
+  if (tid == 0) {
+    s_slot = (int)__hip_atomic_fetch_add(&reg[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&reg[8], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(&reg[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+      if (++spins > 20000000u) { atomicAdd(fail, 1000000u); break; }
+    s_group = (int)__hip_atomic_load(&reg[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if ((int)xcd != use_xcd) return;
+  const int me = s_slot, group = s_group, total4 = group * VALS / 4;
+  float acc = 0.f;
+  for (int s = 0; s < steps; ++s) {
+    unsigned* slot = buf + (size_t)s * 32 * VALS;
+    if (tid < VALS) slot[(size_t)me * VALS + tid] = __float_as_uint(0.001f * (me + tid + s));
+    unsigned spins = 0;
+    for (int i = tid; i < total4; i += 256) {
+      v4u v;
+      do {
+        v = load16_sc0(slot + 4 * i);
+        if (++spins > 2000000u) { atomicAdd(fail, 1u); break; }
+      } while (v.x == kSentinel || v.y == kSentinel || v.z == kSentinel || v.w == kSentinel);
+      *reinterpret_cast<float4*>(&lds[(i * 4) & 8191]) = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    __syncthreads();
+    acc += lds[(tid * 7) & 8191];
+    __syncthreads();
+  }
+  if (acc == 1.2345f) sink[0] = acc;
+}
+
+template <int VALS>
+int run_sentinel0(int steps) {
+  const int nwg = 256;
+  unsigned *buf, *fail, *reg; float* sink;
+  const size_t words = (size_t)steps * 32 * VALS;
+  CK(hipMalloc(&buf, 4 * words)); CK(hipMalloc(&reg, 36)); CK(hipMalloc(&fail, 4)); CK(hipMemset(fail, 0, 4)); CK(hipMalloc(&sink, 4));
+  std::vector<unsigned> fill(words, kSentinel);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ks0<VALS>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipMemcpy(buf, fill.data(), 4 * words, hipMemcpyHostToDevice));
+    CK(hipMemset(reg, 0, 36));
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((ks0<VALS>), dim3(nwg), dim3(256), 100 * 1024, 0, buf, steps, fail, sink, 0, reg);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+  }
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned f; CK(hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost));
+  printf("one XCD, 32 workgroups, %3d floats/wg (%5d B gathered/step), sentinel slots, plain stores + sc0 16-byte polls: %6.2f us/step (timeouts %u)\n",
+         VALS, 32 * VALS * 4, 1e3 * ms / steps, f);
+  return 0;
+}
+
 template <int VALS>
 int run_sentinel(int steps) {
   const int nwg = 256;
@@ -173,6 +241,11 @@ int main() {
   const int steps = 2000;
   run<32, 0>(steps);     // 16 units x 4 batch rows per workgroup, 2 values per granule
   run<64, 0>(steps);
+  run<32, 1>(steps);
+  run<64, 1>(steps);
+  run_sentinel0<64>(steps);
+  run_sentinel0<128>(steps);
+  run_sentinel0<256>(steps);
   run_sentinel<64>(steps);     // forward: 16 units x 4 batch rows per workgroup -> 8 KB gathered
   run_sentinel<128>(steps);    // batch 8
   run_sentinel<256>(steps);    // backward: 4 gates x 16 units x 4 batch rows -> 32 KB gathered
