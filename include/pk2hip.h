@@ -305,6 +305,10 @@ int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float* bhh, int3
 /* dy: device f32 [T][B][D*H] gradient wrt y.  dgx: device f32 [T][B][D*4H]
  * receives the gradient wrt the pre-activations (= gradient wrt gx).
  * scratch: device f32, at least pk2_lstm_bwd_scratch_floats(B,H,D). */
+/* Batches of <= 4 rows at H = 512 run the whole recurrence of a layer in ONE persistent launch (csrc/lstm_persist.hip;
+ * PK2_LSTM_PERSIST=0 keeps the launch-per-step kernels).  A poll of that kernel that times out leaves NaNs in the
+ * outputs and raises this flag (the call synchronises the device). */
+int pk2_lstm_persist_status(uint32_t* abort_flag);
 size_t pk2_lstm_bwd_scratch_floats(int32_t B, int32_t H, int32_t num_dirs);
 int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, const float* cells,
                        int32_t B, int32_t T, int32_t H, int32_t num_dirs, float* dgx,

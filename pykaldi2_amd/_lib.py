@@ -109,6 +109,7 @@ SIGNATURES = {
     "pk2_colsum_f32": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _vp, _vp]),
     "pk2_lstm_fwd_workspace_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pk2_lstm_persist_status": (C.c_int, [C.POINTER(C.c_uint32)]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pk2_dropout_f32": (C.c_int, [_vp, _vp, _i64, _f32, C.c_uint64, _vp]),

@@ -674,6 +674,16 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
   return PK2_OK;
 }
 
+// Test / monitoring hook: 1 in *abort_flag when a poll of the persistent recurrence (lstm_persist.hip) has timed out
+// (synchronises the device).
+extern "C" int pk2_lstm_persist_status(uint32_t* abort_flag) {
+  PK2_REQUIRE(abort_flag, "lstm_persist_status: null pointer");
+  unsigned f = 0;
+  int rc = lstm_persist_status(&f);
+  *abort_flag = f;
+  return rc;
+}
+
 extern "C" size_t pk2_lstm_bwd_scratch_floats(int32_t B, int32_t H, int32_t D) {
   return (size_t)D * H * 4 * H + (size_t)D * B * H + 64 + (B >= kBigBatch ? (size_t)kBigSplitK * D * B * H : 0);
 }
@@ -685,6 +695,12 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
               "lstm_bwd: bad args");
   PK2_REQUIRE(lstm_h_ok(H), "lstm_bwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (lstm_persist_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {   // one launch for the whole sequence (lstm_persist.hip)
+    bool ran = false;      // the mailboxes (1 MB) live where the step kernels keep W_hh^T
+    int prc = lstm_bwd_persist_launch(dy, whh, gates, cells, B, T, H, D, dgx, scratch, stream, &ran);
+    if (prc) return prc;
+    if (ran) return PK2_OK;
+  }
   float* whhT = scratch;
   float* dc = scratch + (size_t)D * H * 4 * H;
   hipLaunchKernelGGL(transpose_whh, dim3(H / 32, 4 * H / 32, D), dim3(256), 0, stream, whh, whhT, H);

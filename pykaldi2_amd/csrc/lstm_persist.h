@@ -15,6 +15,10 @@ bool lstm_persist_wanted(int B, int H, int D);
 // device (checked once): the caller then uses the step kernels.
 int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
                             float* gates, float* cells, hipStream_t stream, bool* ran);
+// Backward recurrence; `mailboxes`: device scratch of lstm_bwd_persist_mailbox_floats(D) floats.
+size_t lstm_bwd_persist_mailbox_floats(int D);
+int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
+                            int D, float* dgx, float* mailboxes, hipStream_t stream, bool* ran);
 int lstm_persist_status(unsigned* abort_flag);
 
 }  // namespace pk2

@@ -236,6 +236,188 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
   }
 }
 
+// ---- backward through time ----------------------------------------------------------------------------------------------
+// Same residency (direction on one XCD, workgroup r owns units 16r..16r+15, its 64 gate rows of W_hh in VGPRs), other
+// dataflow: d h[b][k] = dy[b][k] + sum over ALL 2048 gate rows of dgates[b][row] * W_hh[row][k].  Gathering all of
+// dgates would be 32 KB per workgroup and step; instead every workgroup multiplies ITS OWN 64 rows of dgates (which it has
+// just produced, in LDS) with its W_hh rows into a partial [4][512] (again v_mfma_f32_4x4x1: the four batch rows x four
+// k's x one row per block, no cross-lane reduction at all), stores the 64 values each peer needs into that peer's mailbox
+// and gathers its own mailbox, 32 x 64 floats = 8 KB, summing the 32 partials.  Mailboxes are double buffered and reset to
+// the sentinel by their reader: a peer can only write step s+2 after it has read what this workgroup produced in step s+1,
+// which this workgroup stored after its resets of step s were acknowledged (release fence + barrier).
+struct PersistBwdParams {
+  const float* dy;     // [T][B][D*H]
+  const float* whh;    // [D][4H][H]
+  const float* gates;  // [D][T][B][4H]
+  const float* cells;  // [D][T][B][H]
+  float* dgx;          // [T][B][D*4H]
+  float* px;           // [D][2][32 reader][32 writer][4][16] mailboxes, pre-filled with the sentinel
+  int B, T, D;
+};
+
+__device__ __forceinline__ void store16_agent(float* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+__global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, PersistCtl* ctl) {
+  constexpr int H = kPH;
+  __shared__ __attribute__((aligned(16))) float pl[kPWgs][64 + 4];   // gathered partials [writer][batch row * 16 + unit]
+  __shared__ __attribute__((aligned(16))) float dgl[4][64 + 4];      // this workgroup's dgates [batch row][gate * 16 + unit]
+  __shared__ int s_rank, s_dir, s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    s_abort = 0;
+    const unsigned xcd = xcc_id();
+    int r = -1;
+    if ((int)xcd < p.D) {
+      const unsigned slot = __hip_atomic_fetch_add(&ctl->reg[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot < (unsigned)kPWgs) r = (int)slot;
+    }
+    s_rank = r; s_dir = (int)xcd;
+  }
+  __syncthreads();
+  if (s_rank < 0) return;
+  const int d = s_dir, rank = s_rank, B = p.B, T = p.T, D = p.D;
+  constexpr int G4 = 4 * H;
+  // B operand of the MFMAs: W_hh[d][(r/16)*H + 16*rank + r%16][128*w + 64*cg + lane] for the 64 own rows r, cg = 0, 1
+  float wb[128];
+  {
+    const float* wbase = p.whh + (size_t)d * G4 * H + 128 * w + lane;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const float* row = wbase + ((size_t)(r >> 4) * H + 16 * rank + (r & 15)) * H;
+      wb[2 * r] = row[0];
+      wb[2 * r + 1] = row[64];
+    }
+  }
+  // pointwise role (threads 0..63): batch row tid/16, unit 16*rank + tid%16
+  const int pb = tid >> 4, pu = tid & 15, unit = 16 * rank + pu;
+  const bool pw = tid < 64 && pb < B;
+  float dcarry = 0.f;
+  bool timed_out = false;
+  float* mail[2];
+  mail[0] = p.px + ((size_t)(d * 2 + 0) * kPWgs + rank) * (kPWgs * 64);
+  mail[1] = p.px + ((size_t)(d * 2 + 1) * kPWgs + rank) * (kPWgs * 64);
+  const u32x4 sent = {kSentinelBits, kSentinelBits, kSentinelBits, kSentinelBits};
+  // operands of the pointwise stage, one step ahead
+  float n_dy = 0.f, n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_cp = 0.f;
+  auto load_pw = [&](int step_) {
+    if (pw && step_ < T) {
+      const int fs = T - 1 - step_;
+      const int t_ = d == 0 ? fs : T - 1 - fs;
+      const int tp_ = d == 0 ? t_ - 1 : t_ + 1;
+      n_dy = p.dy[((size_t)t_ * B + pb) * ((size_t)D * H) + (size_t)d * H + unit];
+      const float* gr = p.gates + (((size_t)d * T + t_) * B + pb) * G4 + unit;
+      n_i = gr[0]; n_f = gr[(size_t)H]; n_g = gr[(size_t)2 * H]; n_o = gr[(size_t)3 * H];
+      n_c = p.cells[(((size_t)d * T + t_) * B + pb) * H + unit];
+      n_cp = fs == 0 ? 0.f : p.cells[(((size_t)d * T + tp_) * B + pb) * H + unit];
+    }
+  };
+  load_pw(0);
+  for (int step = 0; step < T; ++step) {
+    const int fstep = T - 1 - step;
+    const int t = d == 0 ? fstep : T - 1 - fstep;
+    const float c_dy = n_dy, c_i = n_i, c_f = n_f, c_g = n_g, c_o = n_o, c_c = n_c, c_cp = n_cp;
+    load_pw(step + 1);
+    // ---- gather the 32 partials of d h for the own 16 units (written by the peers during the previous step) ------------
+    float rec = 0.f;
+    if (step > 0) {
+      float* box = mail[step & 1];
+      {
+        float* src0 = box + (size_t)tid * 4;
+        float* src1 = src0 + 1024;
+        u32x4 v0, v1;
+        long long t0 = 0;
+        unsigned spins = 0;
+        bool bad;
+        do {
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(v0), "=&v"(v1) : "v"(src0), "v"(src1) : "memory");
+          bad = has_sentinel(v0) || has_sentinel(v1);
+          ++spins;
+          if (bad && (spins & 255u) == 0u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > kSpinTicks || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              timed_out = true;
+              break;
+            }
+          }
+        } while (bad);
+        store16_agent(src0, sent);               // the mailbox is free again (ordered before this step's own stores below)
+        store16_agent(src1, sent);
+        const int g0 = tid, g1 = tid + 256;      // granule = writer * 16 + (batch row * 16 + unit) / 4
+        *reinterpret_cast<u32x4*>(&pl[g0 >> 4][(g0 & 15) * 4]) = v0;
+        *reinterpret_cast<u32x4*>(&pl[g1 >> 4][(g1 & 15) * 4]) = v1;
+      }
+      if (timed_out) s_abort = 1;
+      __syncthreads();
+      if (s_abort) {       // loud failure: the gradient of this layer turns NaN (nobody waits on a flag on the hot path)
+        if (tid == 0) p.dgx[(size_t)d * G4 + 16 * rank] = __int_as_float(0x7fc00000);
+        return;
+      }
+      if (tid < 64) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < kPWgs; q += 4) { s0 += pl[q][tid]; s1 += pl[q + 1][tid]; s2 += pl[q + 2][tid]; s3 += pl[q + 3][tid]; }
+        rec = (s0 + s1) + (s2 + s3);
+      }
+    }
+    // ---- gate derivatives of (batch row, unit) ---------------------------------------------------------------------------
+    if (tid < 64) {
+      float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f;
+      if (pw) {
+        const float dh = c_dy + rec;
+        const float tc = ftanh(c_c);
+        const float dcv = dcarry + dh * c_o * (1.f - tc * tc);
+        dcarry = dcv * c_f;
+        dgi = dcv * c_g * c_i * (1.f - c_i);
+        dgf = dcv * c_cp * c_f * (1.f - c_f);
+        dgg = dcv * c_i * (1.f - c_g * c_g);
+        dgo = dh * tc * c_o * (1.f - c_o);
+        float* o = p.dgx + ((size_t)t * B + pb) * ((size_t)D * G4) + (size_t)d * G4 + unit;
+        o[0] = dgi; o[(size_t)H] = dgf; o[(size_t)2 * H] = dgg; o[(size_t)3 * H] = dgo;
+      }
+      dgl[pb][pu] = dgi; dgl[pb][16 + pu] = dgf; dgl[pb][32 + pu] = dgg; dgl[pb][48 + pu] = dgo;
+    }
+    if (step == T - 1) break;
+    // this thread's mailbox resets have been acknowledged by the L2 ... (a plain wait for the outstanding stores: an
+    // agent-scope release FENCE would write the whole L2 back to memory on this multi-XCD part -- measured 12 us per step)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // ... and so have everybody's, before any partial goes out
+    // ---- own 64 rows of dgates x own W_hh rows: partial[batch row][k] for k = 128 w + 64 cg + lane ---------------------
+    {
+      const float* arow = &dgl[lane & 3][0];
+      f32x4 av[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) av[q] = *reinterpret_cast<const f32x4*>(arow + q * 4);
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][0], wb[8 * q], a0, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][0], wb[8 * q + 1], b0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][1], wb[8 * q + 2], a1, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][1], wb[8 * q + 3], b1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][2], wb[8 * q + 4], a0, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][2], wb[8 * q + 5], b0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][3], wb[8 * q + 6], a1, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][3], wb[8 * q + 7], b1, 0, 0, 0);
+      }
+      const f32x4 r0 = a0 + a1, r1 = b0 + b1;     // register i = batch row i; column k = 128 w + 64 cg + lane
+      // peer k/16 reads [writer = rank][batch row][k%16] from its mailbox of the next step
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const int k = 128 * w + 64 * cg + lane;
+        float* dst = p.px + (((size_t)(d * 2 + ((step + 1) & 1)) * kPWgs + (k >> 4)) * kPWgs + rank) * 64 + (k & 15);
+        const f32x4 rv = cg == 0 ? r0 : r1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_agent(dst + i * 16, rv[i]);
+      }
+    }
+  }
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------
 static PersistCtl* g_ctl = nullptr;      // device
 static int g_persist_state = -1;         // -1 untested, 0 unusable, 1 verified on this device
@@ -274,6 +456,24 @@ int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh,
   *ran = true;
   return PK2_OK;
 }
+
+int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
+                            int D, float* dgx, float* mailboxes, hipStream_t stream, bool* ran) {
+  *ran = false;
+  if (g_persist_state != 1) return PK2_OK;   // the forward pass verifies the device first
+  int dev = 0, cus = 256;
+  PK2_HIP(hipGetDevice(&dev));
+  PK2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  PK2_HIP(hipMemsetAsync(g_ctl, 0, sizeof(PersistCtl), stream));
+  PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mailboxes), (int)kSentinelBits, lstm_bwd_persist_mailbox_floats(D), stream));
+  PersistBwdParams p{dy, whh, gates, cells, dgx, mailboxes, B, T, D};
+  hipLaunchKernelGGL(lstm_bwd_persist, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
+  PK2_LAUNCH_CHECK();
+  *ran = true;
+  return PK2_OK;
+}
+
+size_t lstm_bwd_persist_mailbox_floats(int D) { return (size_t)D * 2 * kPWgs * kPWgs * 64; }
 
 int lstm_persist_status(unsigned* abort_flag) {
   PersistCtl h{};

@@ -152,6 +152,37 @@ def test_blstm_3x512_posteriors_match_torch_cpu():
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
 
 
+@pytest.mark.parametrize("B,T,bi,layers", [(3, 301, True, 1), (4, 150, False, 2), (1, 64, True, 1)])
+def test_persistent_recurrence_long_sequences_match_torch_cpu(B, T, bi, layers):
+    """The persistent small-batch recurrence (csrc/lstm_persist.hip: H = 512, B <= 4; one direction per XCD, h and the
+    d h partials exchanged through the XCD's L2 with double-buffered sentinel mailboxes) over hundreds of steps, partial
+    batches and one direction, against the reference's torch CPU nn.LSTM: outputs and every gradient."""
+    torch.manual_seed(B * 1000 + T)
+    H, Din, P = 512, 80, 40
+    m = lstm.LSTMAM(Din, P, H, layers, 0.0, bi)
+    ref_lstm = torch.nn.LSTM(Din, H, layers, batch_first=True, bidirectional=bi)
+    ref_out = torch.nn.Linear(H * (2 if bi else 1), P)
+    ref_lstm.load_state_dict({k[5:]: v for k, v in m.state_dict().items() if k.startswith("lstm.")})
+    ref_out.load_state_dict({k[13:]: v for k, v in m.state_dict().items() if k.startswith("output_layer.")})
+    x = torch.randn(B, T, Din)
+    wgt = torch.randn(B, T, P)
+    ref_logits = ref_out(ref_lstm(x)[0])
+    (ref_logits * wgt).sum().backward()
+    m = m.cuda()
+    logits = m(x.cuda())
+    err = (logits.cpu() - ref_logits.detach()).abs().max().item()
+    assert err < 2e-4, err
+    (logits * wgt.cuda()).sum().backward()
+    refg = dict(list(("lstm." + k, v.grad) for k, v in ref_lstm.named_parameters()) +
+                list(("output_layer." + k, v.grad) for k, v in ref_out.named_parameters()))
+    for name, p in m.named_parameters():
+        e = (p.grad.cpu() - refg[name]).abs().max().item()
+        assert e < 2e-4 * max(1.0, refg[name].abs().max().item()), (name, e)
+    from pykaldi2_amd import _lib
+    flag = __import__("ctypes").c_uint32(7)
+    assert _lib.lib().pk2_lstm_persist_status(__import__("ctypes").byref(flag)) == 0 and flag.value == 0   # no poll timed out
+
+
 @pytest.mark.parametrize("B,T,H,bi", [(70, 9, 128, True), (256, 5, 512, True), (33, 6, 64, False),
                                       (7, 9, 128, True), (20, 6, 256, True), (3, 11, 64, False), (31, 4, 512, True)])
 def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
