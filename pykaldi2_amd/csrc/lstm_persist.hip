@@ -66,9 +66,9 @@ struct PersistFwdParams {
 
 #ifdef PK2_PERSIST_PROFILE
 __device__ unsigned long long g_pp[8];
-#define PP_T(k) do { if (tid == 0 && s_rank == 0 && d == 0) { const long long n_ = clock64(); g_pp[k] += (unsigned long long)(n_ - pp_last); pp_last = n_; } } while (0)
+#define PP_T(k) do { const long long n_ = clock64(); pp_acc[k] += (unsigned long long)(n_ - pp_last); pp_last = n_; } while (0)
 __global__ void pp_print(int steps) {
-  printf("lstm_fwd_persist rank 0, shader cycles per step over %d steps: gx prefetch issue %llu | h gathered into LDS %llu | barrier %llu | 128 MFMA + reduce %llu | transpose + gates + stores %llu\n",
+  printf("lstm_fwd_persist rank 0 thread 0, shader cycles per step over %d steps: loop top %llu | h polled and written to LDS %llu | barrier %llu | LDS reads + 128 MFMA + reduce %llu | transpose + gates + stores %llu\n",
          steps, g_pp[0] / steps, g_pp[1] / steps, g_pp[2] / steps, g_pp[3] / steps, g_pp[4] / steps);
   for (int k = 0; k < 8; ++k) g_pp[k] = 0;
 }
@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
   };
   load_gx(0);
 #ifdef PK2_PERSIST_PROFILE
+  unsigned long long pp_acc[5] = {0, 0, 0, 0, 0};
   long long pp_last = clock64();
 #endif
   for (int step = 0; step < T; ++step) {
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
     if (timed_out) s_abort = 1;
     __syncthreads();
     if (s_abort) return;
+    PP_T(2);
     load_gx(step + 1);
     // ---- recurrent product: D_blk[r][c] += W[g][u0+r][k] * h[c][k] over the lane block's 128 k's ---------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -234,6 +236,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
     }
     PP_T(4);
   }
+#ifdef PK2_PERSIST_PROFILE
+  if (tid == 0 && s_rank == 0 && d == 0) for (int k = 0; k < 5; ++k) g_pp[k] = pp_acc[k];
+#endif
 }
 
 // ---- backward through time ----------------------------------------------------------------------------------------------
