@@ -33,6 +33,8 @@ def main():
     parser.add_argument("-batch_size", default=32, type=int, help="Override the batch size in the config")
     parser.add_argument("-sweep_size", default=200, type=float, help="process n hours of data per sweep (default:60)")
     parser.add_argument("-data_loader_threads", default=4, type=int, help="number of workers for data loading")
+    parser.add_argument("-frame_subsampling_factor", default=1, type=int, help="the factor to subsample the features (decode.py)")
+    parser.add_argument("-gpuid", default=0, type=int, help="GPU ID (decode.py)")
     parser.add_argument("-synthetic", type=int, default=0, help="dump this many seeded synthetic utterances instead")
     args = parser.parse_args()
 
@@ -40,7 +42,8 @@ def main():
         config = yaml.safe_load(f)
     config["sweep_size"] = args.sweep_size
     print("job starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
-    dev = th.device("cuda", 0)
+    dev = th.device("cuda", args.gpuid)
+    th.cuda.set_device(dev)
     mc = config["model_config"]
     P = mc["label_size"]
     model = lstm.LSTMAM(mc["feat_dim"], P, mc["hidden_size"], mc["num_layers"], mc["dropout"], True).to(dev)
@@ -75,7 +78,10 @@ def main():
             feats, frames, row_off = fb(wav, lens)
             if transform is not None:
                 feats = transform(feats)
-            x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=1, time_major=True)
+            sub = max(1, args.frame_subsampling_factor)          # reference decode.py:108-110: every sub-th frame, T // sub frames
+            x = fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=sub, time_major=True)
+            if sub > 1:
+                frames = [int(t) // sub for t in frames]
             prediction = model.forward_time_major(x).transpose(0, 1)
             # save only the unpadded part of each utterance in the batch
             for j in range(len(chunk)):

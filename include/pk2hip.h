@@ -386,6 +386,16 @@ int pk2_decode_graph_create(int32_t num_states, int32_t start_state, int64_t num
 /* HCLG.fst in OpenFst binary form ("vector" or "const" container, "standard" arcs;
  * reference bin/train_se.py:145,180). */
 int pk2_decode_graph_from_openfst(const char* path, pk2_decode_graph** out);
+/* The same with output labels (word ids; pk2_decode_graph_from_openfst keeps the olabels of the file), and the word of
+ * the HCLG arc behind each link of an exported lattice (host arrays; -1 = no such arc): what the lattice-dumping command
+ * line needs for `decoder_out["text"]` and the word labels of the compact lattice (reference bin/latgen.py:170-181). */
+int pk2_decode_graph_create_words(int32_t num_states, int32_t start_state, int64_t num_arcs,
+                                  const int32_t* arc_src, const int32_t* arc_dst, const int32_t* arc_ilabel,
+                                  const int32_t* arc_olabel, const float* arc_weight, const float* final_cost,
+                                  pk2_decode_graph** out);
+int pk2_decode_graph_link_words(const pk2_decode_graph* g, int64_t num_links, const int32_t* src_state,
+                                const int32_t* dst_state, const int32_t* tid, const float* graph_cost,
+                                int32_t* word_out);
 int pk2_decode_graph_destroy(pk2_decode_graph* g);
 int pk2_decode_graph_info(const pk2_decode_graph* g, int32_t* num_states, int64_t* num_arcs,
                           int32_t* max_ilabel);

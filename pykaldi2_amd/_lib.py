@@ -64,6 +64,8 @@ SIGNATURES = {
                                      C.POINTER(_i32)]),
     "pk2_supervision_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pk2_decode_graph_create": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pk2_decode_graph_create_words": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "pk2_decode_graph_link_words": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pk2_decode_graph_from_openfst": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "pk2_decode_graph_destroy": (C.c_int, [_vp]),
     "pk2_decode_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),

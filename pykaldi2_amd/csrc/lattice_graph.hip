@@ -12,7 +12,7 @@ using namespace pk2;
 
 static int build_decode_graph(int32_t S, int32_t start, int64_t A, const int32_t* src, const int32_t* dst,
                               const int32_t* ilabel, const float* weight, const float* final_cost,
-                              pk2_decode_graph** out) {
+                              pk2_decode_graph** out, const int32_t* olabel = nullptr) {
   PK2_REQUIRE(S > 0 && start >= 0 && start < S && A >= 0, "decode graph: bad sizes");
   auto* g = new pk2_decode_graph;
   g->S = S; g->start = start; g->A = A;
@@ -30,14 +30,17 @@ static int build_decode_graph(int32_t S, int32_t start, int64_t A, const int32_t
   for (int32_t s = 0; s < S; ++s) { g->e_off[s + 1] += g->e_off[s]; g->n_off[s + 1] += g->n_off[s]; }
   g->e_dst.resize(g->e_off[S]); g->e_tid.resize(g->e_off[S]); g->e_w.resize(g->e_off[S]);
   g->n_dst.resize(g->n_off[S]); g->n_w.resize(g->n_off[S]);
+  g->e_ol.assign(g->e_off[S], 0); g->n_ol.assign(g->n_off[S], 0);
   std::vector<int32_t> ep(g->e_off.begin(), g->e_off.end() - 1), np(g->n_off.begin(), g->n_off.end() - 1);
   for (int64_t a = 0; a < A; ++a) {
     if (ilabel[a] > 0) {
       const int32_t k = ep[src[a]]++;
       g->e_dst[k] = dst[a]; g->e_tid[k] = ilabel[a]; g->e_w[k] = weight[a];
+      if (olabel) g->e_ol[k] = olabel[a];
     } else {
       const int32_t k = np[src[a]]++;
       g->n_dst[k] = dst[a]; g->n_w[k] = weight[a];
+      if (olabel) g->n_ol[k] = olabel[a];
     }
   }
   g->final_cost.assign(final_cost, final_cost + S);
@@ -58,7 +61,45 @@ extern "C" int pk2_decode_graph_from_openfst(const char* path, pk2_decode_graph*
   const std::string why = read_openfst(path, &fst);
   if (!why.empty()) { set_error("%s: %s", path, why.c_str()); return PK2_ERR_IO; }
   return build_decode_graph((int32_t)fst.num_states, (int32_t)fst.start, (int64_t)fst.src.size(), fst.src.data(),
-                            fst.dst.data(), fst.ilabel.data(), fst.weight.data(), fst.final_cost.data(), out);
+                            fst.dst.data(), fst.ilabel.data(), fst.weight.data(), fst.final_cost.data(), out, fst.olabel.data());
+}
+
+extern "C" int pk2_decode_graph_create_words(int32_t num_states, int32_t start_state, int64_t num_arcs,
+                                             const int32_t* arc_src, const int32_t* arc_dst, const int32_t* arc_ilabel,
+                                             const int32_t* arc_olabel, const float* arc_weight, const float* final_cost,
+                                             pk2_decode_graph** out) {
+  PK2_REQUIRE(arc_src && arc_dst && arc_ilabel && arc_olabel && arc_weight && final_cost && out, "decode graph: null pointer");
+  return build_decode_graph(num_states, start_state, num_arcs, arc_src, arc_dst, arc_ilabel, arc_weight, final_cost, out,
+                            arc_olabel);
+}
+
+// Output label (word id) of the HCLG arc behind each lattice link (host arrays, e.g. from pk2_lattice_export): the arc
+// src -> dst with that transition-id (0 = epsilon arc) whose weight is closest to the link's graph cost.  -1 when the
+// graph has no such arc.
+extern "C" int pk2_decode_graph_link_words(const pk2_decode_graph* g, int64_t num_links, const int32_t* src_state,
+                                           const int32_t* dst_state, const int32_t* tid, const float* graph_cost,
+                                           int32_t* word_out) {
+  PK2_REQUIRE(g && src_state && dst_state && tid && graph_cost && word_out && num_links >= 0, "link_words: bad args");
+  for (int64_t l = 0; l < num_links; ++l) {
+    const int32_t s = src_state[l];
+    PK2_REQUIRE(s >= 0 && s < g->S, "link_words: state %d out of range", s);
+    int32_t best = -1; float bd = std::numeric_limits<float>::infinity();
+    if (tid[l] > 0) {
+      for (int32_t k = g->e_off[s]; k < g->e_off[s + 1]; ++k)
+        if (g->e_dst[k] == dst_state[l] && g->e_tid[k] == tid[l]) {
+          const float dd = std::fabs(g->e_w[k] - graph_cost[l]);
+          if (dd < bd) { bd = dd; best = g->e_ol[k]; }
+        }
+    } else {
+      for (int32_t k = g->n_off[s]; k < g->n_off[s + 1]; ++k)
+        if (g->n_dst[k] == dst_state[l]) {
+          const float dd = std::fabs(g->n_w[k] - graph_cost[l]);
+          if (dd < bd) { bd = dd; best = g->n_ol[k]; }
+        }
+    }
+    word_out[l] = best;
+  }
+  return PK2_OK;
 }
 
 extern "C" int pk2_decode_graph_destroy(pk2_decode_graph* g) {

@@ -92,6 +92,7 @@ struct pk2_decode_graph {
   int32_t S = 0, start = 0, max_ilabel = 0;
   int64_t A = 0;
   std::vector<int32_t> e_off, e_dst, e_tid, n_off, n_dst;
+  std::vector<int32_t> e_ol, n_ol;   // output labels (word ids) of the emitting / epsilon arcs, host only (0 when not given)
   std::vector<float> e_w, n_w, final_cost;
   bool uploaded = false;
   int device = -1;

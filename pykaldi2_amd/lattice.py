@@ -232,13 +232,28 @@ class DecodeGraph:
             il = np.ascontiguousarray(graph["ilabel"], np.int32); w = np.ascontiguousarray(graph["weight"], np.float32)
             fin = np.ascontiguousarray(graph["final"], np.float32)
             assert fin.shape[0] == int(graph["num_states"])
-            _lib.check(L.pk2_decode_graph_create(int(graph["num_states"]), int(graph["start"]), src.shape[0],
-                                                 src.ctypes.data, dst.ctypes.data, il.ctypes.data, w.ctypes.data,
-                                                 fin.ctypes.data, C.byref(h)))
+            if graph.get("olabel") is not None:     # word ids: only the lattice-dumping tools need them
+                ol = np.ascontiguousarray(graph["olabel"], np.int32)
+                _lib.check(L.pk2_decode_graph_create_words(int(graph["num_states"]), int(graph["start"]), src.shape[0],
+                                                           src.ctypes.data, dst.ctypes.data, il.ctypes.data, ol.ctypes.data,
+                                                           w.ctypes.data, fin.ctypes.data, C.byref(h)))
+            else:
+                _lib.check(L.pk2_decode_graph_create(int(graph["num_states"]), int(graph["start"]), src.shape[0],
+                                                     src.ctypes.data, dst.ctypes.data, il.ctypes.data, w.ctypes.data,
+                                                     fin.ctypes.data, C.byref(h)))
         self._h = h
         ns, na, mi = C.c_int32(), C.c_int64(), C.c_int32()
         _lib.check(L.pk2_decode_graph_info(h, C.byref(ns), C.byref(na), C.byref(mi)))
         self.num_states, self.num_arcs, self.max_ilabel = ns.value, na.value, mi.value
+
+    def link_words(self, src_state, dst_state, tid, graph_cost):
+        """Word id (HCLG output label) of the arc behind each lattice link (host arrays of LatticeBatch.export)."""
+        src_state = np.ascontiguousarray(src_state, np.int32); dst_state = np.ascontiguousarray(dst_state, np.int32)
+        tid = np.ascontiguousarray(tid, np.int32); graph_cost = np.ascontiguousarray(graph_cost, np.float32)
+        out = np.empty(src_state.shape[0], np.int32)
+        _lib.check(_lib.lib().pk2_decode_graph_link_words(self._h, src_state.shape[0], src_state.ctypes.data, dst_state.ctypes.data,
+                                                          tid.ctypes.data, graph_cost.ctypes.data, out.ctypes.data))
+        return out
 
     def __del__(self):
         try:
@@ -258,6 +273,7 @@ class LatticeBatch:
         self.device, self.trans_model, self.num_pdfs = device, trans_model, num_pdfs
         self.status = self.num_tokens = self.num_links = self.best_cost = None
         self.time_major = False
+        self._acoustic_scale = 1.0
 
     def __del__(self):
         try:
@@ -331,6 +347,55 @@ class LatticeBatch:
         return a
 
 
+    def compact_lattice(self, n, acoustic_scale=None):
+        """Utterance n as a Kaldi CompactLattice (what `decoder_out["lattice"]` holds at reference bin/latgen.py:181): state =
+        lattice token, arc = lattice link with ilabel = olabel = word id of the HCLG arc, weight (graph cost, acoustic
+        cost with the acoustic scale removed) and the transition-id string ([tid], empty for epsilon links) -- Kaldi's
+        ConvertLattice(Lattice -> CompactLattice) of the raw state-level lattice.  NOT determinised: the reference asks
+        PyKaldi for `determinize_lattice = True` (DeterminizeLatticePhonePrunedWrapper); every Kaldi lattice tool reads
+        this form too (lattice-determinize-pruned produces the reference's).  Returns a dict of host arrays for
+        kaldi_io.CompactLatticeWriter, plus the best path: words, transition-ids and its total cost."""
+        A = self.export(n)
+        fr, st = A["tok_frame"], A["tok_state"]
+        T = self.lengths[n]
+        words = self._graph.link_words(st[A["link_src"]], st[A["link_dst"]], A["link_tid"], A["link_graph"]) \
+            if self._graph is not None else np.zeros(A["link_src"].shape[0], np.int32)
+        if (words < 0).any():
+            raise _lib.Pk2Error("lattice link without a matching HCLG arc")
+        last = fr == T
+        fin = A["tok_final"].astype(np.float32).copy()
+        if not np.isfinite(fin[last]).any():
+            fin[last] = 0.0             # no final state reached: every surviving token is final (Kaldi's convention)
+        fin[~last] = np.inf
+        # token 0..: the start token is the frame-0 token with cost 0 reached by no link
+        indeg = np.bincount(A["link_dst"], minlength=fr.shape[0])
+        starts = np.flatnonzero((fr == 0) & (indeg == 0))
+        start = int(starts[0]) if starts.size else 0
+        # best path (for decoder_out["text"] / ["likelihood"]): tok_cost is the best forward cost of each token
+        sc = self._acoustic_scale if acoustic_scale is None else acoustic_scale
+        total = A["tok_cost"].astype(np.float64) + np.where(np.isfinite(fin), fin, np.inf)
+        end = int(np.argmin(np.where(last, total, np.inf)))
+        cost = A["link_graph"].astype(np.float64) + sc * A["link_ac"].astype(np.float64)
+        order = np.argsort(A["link_dst"], kind="stable")
+        lo = np.searchsorted(A["link_dst"][order], np.arange(fr.shape[0] + 1))
+        path, tok, guard = [], end, 0
+        while tok != start and guard < 4 * (T + 1) + 64:
+            cand = order[lo[tok]:lo[tok + 1]]
+            if cand.size == 0:
+                break
+            through = A["tok_cost"][A["link_src"][cand]].astype(np.float64) + cost[cand]
+            l = int(cand[int(np.argmin(through))])
+            path.append(l)
+            tok = int(A["link_src"][l])
+            guard += 1
+        path.reverse()
+        return dict(num_states=int(fr.shape[0]), start=start, src=A["link_src"], dst=A["link_dst"], word=words,
+                    graph=A["link_graph"], acoustic=A["link_ac"], tid=A["link_tid"], final=fin,
+                    best_words=[int(words[l]) for l in path if words[l] > 0],
+                    best_tids=[int(A["link_tid"][l]) for l in path if A["link_tid"][l] > 0],
+                    best_cost=float(total[end]))
+
+
 class MappedLatticeFasterRecognizer:
     """On-the-fly lattice generator with the reference's construction signature
     (bin/train_se.py:180-183: `MappedLatticeFasterRecognizer.from_files(trans_model, HCLG, words_txt,
@@ -375,6 +440,7 @@ class MappedLatticeFasterRecognizer:
             _lib.check(L.pk2_lattice_batch_create(self.graph._h, lens.ctypes.data, N, C.byref(opts), C.byref(h)))
             ws = torch.empty(L.pk2_lattice_batch_bytes(h), dtype=torch.uint8, device=dev)
             batch = LatticeBatch(h, ws, lens.tolist(), dev, self.trans_model, P, self.graph)
+            batch._acoustic_scale = self.acoustic_scale
             _lib.check(L.pk2_lattice_decode(h, _lib.ptr(loglikes), loglikes.stride(0), loglikes.stride(1), P, _lib.ptr(t2p),
                                             self.trans_model.num_transition_ids(), _lib.ptr(ws), _lib.stream_ptr(dev)))
             status = np.zeros(N, np.int32); ntok = np.zeros(N, np.int32); nlink = np.zeros(N, np.int32)

@@ -233,13 +233,13 @@ def decoding_graph_arcs(num_words=2000, num_pdfs=5768, seed=0, max_phones=5):
     """Synthetic HCLG-shaped decoding graph: a word loop over `num_words` pronunciations of 2..max_phones
     phones, every phone 3 HMM states with a self-loop and a forward arc (ilabels = transition-ids of
     transition_model_arrays), word entry = epsilon arc carrying a Zipf unigram cost, word exit = epsilon arc
-    back to the loop state (so tokens cross two epsilon arcs between words).  Returns dict(num_states, start,
-    src, dst, ilabel, weight, final)."""
+    back to the loop state (so tokens cross two epsilon arcs between words); the word-entry arc carries the word id
+    (1-based) as its output label.  Returns dict(num_states, start, src, dst, ilabel, olabel, weight, final)."""
     rng = np.random.default_rng(seed)
     num_phones = num_pdfs // 3
     p = 1.0 / np.arange(1, num_words + 1)
     p /= p.sum()
-    src, dst, ilab, w = [], [], [], []
+    src, dst, ilab, w, olab = [], [], [], [], []
     loop = 0
     n_states = 1
     lp_self, lp_fwd = -np.log(0.6), -np.log(0.4)
@@ -249,21 +249,22 @@ def decoding_graph_arcs(num_words=2000, num_pdfs=5768, seed=0, max_phones=5):
         if wd == 0:
             phones = np.array([1, 1])      # a silence "word"
         first = n_states
-        src.append(loop); dst.append(first); ilab.append(0); w.append(-np.log(p[wd]))
+        src.append(loop); dst.append(first); ilab.append(0); w.append(-np.log(p[wd])); olab.append(wd + 1)   # the word label
         for ph in phones:
             for hs in range(3):
                 s = n_states
                 n_states += 1
                 base = 1 + 2 * (3 * (int(ph) - 1) + hs)
-                src.append(s); dst.append(s); ilab.append(base); w.append(lp_self)
-                src.append(s); dst.append(s + 1); ilab.append(base + 1); w.append(lp_fwd)
+                src.append(s); dst.append(s); ilab.append(base); w.append(lp_self); olab.append(0)
+                src.append(s); dst.append(s + 1); ilab.append(base + 1); w.append(lp_fwd); olab.append(0)
         end = n_states        # word-end state reached by the last forward arc
         n_states += 1
-        src.append(end); dst.append(loop); ilab.append(0); w.append(0.0)
+        src.append(end); dst.append(loop); ilab.append(0); w.append(0.0); olab.append(0)
     final = np.full(n_states, np.inf, np.float32)
     final[loop] = 0.0
     return dict(num_states=n_states, start=loop, src=np.asarray(src, np.int32), dst=np.asarray(dst, np.int32),
-                ilabel=np.asarray(ilab, np.int32), weight=np.asarray(w, np.float32), final=final)
+                ilabel=np.asarray(ilab, np.int32), olabel=np.asarray(olab, np.int32), weight=np.asarray(w, np.float32),
+                final=final)
 
 
 def tid_alignment(rng, num_frames, num_pdfs):

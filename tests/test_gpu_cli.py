@@ -128,6 +128,67 @@ def test_dump_loglikes_cli_synthetic(tmp_path):
     assert len(mats) == 3 and all(m.shape[1] == 120 and m.shape[0] > 100 and np.isfinite(m).all() for _, m in mats)
 
 
+def test_latgen_cli_synthetic_writes_compact_lattices(tmp_path):
+    """bin/latgen.py (reference bin/latgen.py:143-181): model forward -> on-device lattice generation -> Kaldi compact-lattice
+    archive, best word sequence and per-frame log-likelihood printed per utterance."""
+    from pykaldi2_amd import kaldi_io
+    import yaml as _yaml
+    cfg = _yaml.safe_load(open(_cfg(tmp_path, "se.yaml", 120, True)))
+    cfg["decoder_config"] = dict(beam=13, lattice_beam=7, max_active=7000, acoustic_scale=0.1)
+    (tmp_path / "se.yaml").write_text(_yaml.safe_dump(cfg))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "latgen.py"), "-config", str(tmp_path / "se.yaml"),
+                          "-out_file", str(tmp_path / "lat.ark"), "-synthetic", "3", "-synthetic_words", "300", "-batch_size", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lats = list(kaldi_io.read_compact_lattice_ark(str(tmp_path / "lat.ark")))
+    assert [k for k, _ in lats] == ["synth-1", "synth-2", "synth-3"]
+    for key, lat in lats:
+        assert lat["start"] == 0 and len(lat["arcs"]) > 500 and any(np.isfinite(f[0]) for f in lat["finals"])
+        assert all(0 <= a[1] < lat["num_states"] and a[2] == a[3] for a in lat["arcs"])
+        assert any(a[2] > 0 for a in lat["arcs"]) and all(len(a[4][2]) <= 1 for a in lat["arcs"])
+        assert "Log-like per-frame for utterance %s is " % key in out.stdout
+    # the best word sequence of every utterance is printed (ids: the synthetic graph has no words.txt)
+    texts = [l for l in out.stdout.splitlines() if l.startswith("synth-")]
+    assert len(texts) == 3 and all(len(t.split()) >= 2 and all(w.isdigit() for w in t.split()[1:]) for t in texts)
+
+
+def test_best_path_of_the_compact_lattice_is_the_decoders():
+    """LatticeBatch.compact_lattice: the back-traced best path costs what the decoder reported, consumes one transition-id
+    per frame, and its words are the output labels of the HCLG arcs it crossed."""
+    import torch
+    from pykaldi2_amd import lattice, synth
+    P, T = 90, 57
+    g = synth.decoding_graph_arcs(80, P, seed=5)
+    tm = synth.transition_model_arrays(P)
+    rec = lattice.MappedLatticeFasterRecognizer(lattice.TransitionModel.from_arrays(tm), g, 0.3,
+                                                lattice.LatticeFasterDecoderOptions(beam=12.0, lattice_beam=5.0))
+    ll = torch.from_numpy((2.0 * np.random.default_rng(2).standard_normal((T, P))).astype(np.float32)).cuda()
+    lat = rec.decode(ll)
+    cl = lat.compact_lattice(0)
+    assert abs(cl["best_cost"] - float(lat.best_cost[0])) < 1e-3 * max(1.0, abs(float(lat.best_cost[0])))
+    assert len(cl["best_tids"]) == T and len(cl["best_words"]) >= 1
+    assert set(cl["best_words"]) <= set(g["olabel"][g["olabel"] > 0].tolist())
+    # every word arc of the lattice carries the label of a word-entry arc of the graph; emitting links carry none
+    assert (cl["word"][cl["tid"] > 0] == 0).all() and (cl["word"] >= 0).all()
+
+
+def test_decode_py_dumps_subsampled_loglikes(tmp_path):
+    """decode.py (reference decode.py:102-122): log-likelihood matrices, every third frame with -frame_subsampling_factor 3."""
+    from pykaldi2_amd import kaldi_io
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "decode.py"), "-config", _cfg(tmp_path, "ce.yaml", 120, True),
+                          "-out_file", str(tmp_path / "ll.ark"), "-synthetic", "2", "-frame_subsampling_factor", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    full = subprocess.run([sys.executable, os.path.join(ROOT, "decode.py"), "-config", _cfg(tmp_path, "ce.yaml", 120, True),
+                           "-out_file", str(tmp_path / "ll1.ark"), "-synthetic", "2"], capture_output=True, text=True, timeout=600)
+    assert full.returncode == 0
+    a = dict(kaldi_io.read_matrix_ark(str(tmp_path / "ll.ark")))
+    b = dict(kaldi_io.read_matrix_ark(str(tmp_path / "ll1.ark")))
+    assert set(a) == set(b) and len(a) == 2
+    for k in a:
+        assert a[k].shape == (b[k].shape[0] // 3, b[k].shape[1]) and np.isfinite(a[k]).all()
+
+
 def test_bench_rccl_path_single_rank_group():
     """The driver's N>1 launch line with one rank: process group over RCCL, bucketed gradient all-reduce on the
     side stream while the step graphs replay, barrier-bracketed timing.  With one rank the exchange is the

@@ -216,3 +216,41 @@ def test_mvn_transform_save_load_round_trip(tmp_path):
     back = fbank.GlobalMeanVarianceNormalization.load(str(tmp_path / "transform.pkl"))
     assert back.mean_vec.shape == (1, 80) and np.array_equal(back.mean_vec, t.mean_vec) and np.array_equal(back.std_vec, t.std_vec)
     assert np.all(t.std_vec >= 1e-2)
+
+
+def test_compact_lattice_archives_and_link_words(tmp_path):
+    """kaldi_io.CompactLatticeWriter (reference bin/latgen.py:156-181 writes `decoder_out["lattice"]` through PyKaldi's
+    CompactLatticeWriter): binary OpenFst "vector" / "compactlattice44" entries and the text form, start state renumbered
+    to 0; and the word lookup of lattice links on the host side of the decode graph."""
+    import numpy as np
+    from pykaldi2_amd import kaldi_io, lattice, synth
+    lat = dict(num_states=4, start=2, src=np.array([2, 2, 0, 1, 0]), dst=np.array([0, 1, 3, 3, 1]),
+               word=np.array([7, 0, 0, 9, 0], np.int32), graph=np.array([0.5, 1.5, 0.0, 2.25, 0.125], np.float32),
+               acoustic=np.array([-3.0, -4.0, -5.5, 0.0, -1.0], np.float32), tid=np.array([11, 12, 13, 0, 14], np.int32),
+               final=np.array([np.inf, np.inf, np.inf, 0.75], np.float32))
+    with kaldi_io.CompactLatticeWriter("ark:" + str(tmp_path / "l.ark")) as w:
+        w["utt-a"] = lat
+        w["utt-b"] = lat
+    got = list(kaldi_io.read_compact_lattice_ark(str(tmp_path / "l.ark")))
+    assert [k for k, _ in got] == ["utt-a", "utt-b"]
+    g = got[0][1]
+    assert g["start"] == 0 and g["num_states"] == 4
+    ren = {2: 0, 0: 2, 1: 1, 3: 3}                                   # start state swapped into position 0
+    want = sorted((ren[s], ren[d], int(wd), int(wd), (float(gr), float(ac), [int(t)] if t else []))
+                  for s, d, wd, gr, ac, t in zip(lat["src"], lat["dst"], lat["word"], lat["graph"], lat["acoustic"], lat["tid"]))
+    assert sorted(g["arcs"]) == want
+    assert g["finals"][3] == (0.75, 0.0, []) and all(np.isinf(g["finals"][s][0]) for s in (0, 1, 2))
+    raw = (tmp_path / "l.ark").read_bytes()
+    assert raw.startswith(b"utt-a \0B" + b"\xd6\xfd\xb2\x7e") and b"compactlattice44" in raw[:64]
+    with kaldi_io.CompactLatticeWriter("ark,t:" + str(tmp_path / "l.txt")) as w:
+        w["utt-a"] = lat
+    lines = (tmp_path / "l.txt").read_text().split("\n")
+    assert lines[0] == "utt-a" and "0\t2\t7\t0.5,-3.0,11" in lines and "1\t3\t9\t2.25,0.0," in lines and "3\t0.75,0," in lines
+    assert lines[-2:] == ["", ""]
+    # words of lattice links from the decode graph (no GPU involved)
+    gr = synth.decoding_graph_arcs(30, 60, seed=2)
+    dg = lattice.DecodeGraph(gr)
+    idx = np.flatnonzero(gr["olabel"] > 0)[:5].tolist() + [3, 4, 5]
+    words = dg.link_words(gr["src"][idx], gr["dst"][idx], gr["ilabel"][idx], gr["weight"][idx])
+    assert words.tolist() == gr["olabel"][idx].tolist()
+    assert dg.link_words([0], [0], [5], [0.0]).tolist() == [-1]      # no such arc
