@@ -67,6 +67,11 @@ struct PersistFwdParams {
 #ifdef PK2_PERSIST_PROFILE
 __device__ unsigned long long g_pp[8];
 #define PP_T(k) do { const long long n_ = clock64(); pp_acc[k] += (unsigned long long)(n_ - pp_last); pp_last = n_; } while (0)
+__device__ unsigned long long g_ppb[8];
+__global__ void ppb_print(int steps) {
+  printf("lstm_bwd_persist rank 0 thread 0, shader cycles per step over %d steps: loop top %llu | mailbox polled, reset, written to LDS %llu | barrier %llu | reduce 32 partials + gate derivatives %llu | store wait + barrier %llu | LDS reads + 128 MFMA + partial stores %llu\n",
+         steps, g_ppb[0] / steps, g_ppb[1] / steps, g_ppb[2] / steps, g_ppb[3] / steps, g_ppb[4] / steps, g_ppb[5] / steps);
+}
 __global__ void pp_print(int steps) {
   printf("lstm_fwd_persist rank 0 thread 0, shader cycles per step over %d steps: loop top %llu | h polled and written to LDS %llu | barrier %llu | LDS reads + 128 MFMA + reduce %llu | transpose + gates + stores %llu\n",
          steps, g_pp[0] / steps, g_pp[1] / steps, g_pp[2] / steps, g_pp[3] / steps, g_pp[4] / steps);
@@ -319,11 +324,16 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
     }
   };
   load_pw(0);
+#ifdef PK2_PERSIST_PROFILE
+  unsigned long long pp_acc[6] = {0, 0, 0, 0, 0, 0};
+  long long pp_last = clock64();
+#endif
   for (int step = 0; step < T; ++step) {
     const int fstep = T - 1 - step;
     const int t = d == 0 ? fstep : T - 1 - fstep;
     const float c_dy = n_dy, c_i = n_i, c_f = n_f, c_g = n_g, c_o = n_o, c_c = n_c, c_cp = n_cp;
     load_pw(step + 1);
+    PP_T(0);
     // ---- gather the 32 partials of d h for the own 16 units (written by the peers during the previous step) ------------
     float rec = 0.f;
     if (step > 0) {
@@ -356,8 +366,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
         *reinterpret_cast<u32x4*>(&pl[g0 >> 4][(g0 & 15) * 4]) = v0;
         *reinterpret_cast<u32x4*>(&pl[g1 >> 4][(g1 & 15) * 4]) = v1;
       }
+      PP_T(1);
       if (timed_out) s_abort = 1;
       __syncthreads();
+      PP_T(2);
       if (s_abort) {       // loud failure: the gradient of this layer turns NaN (nobody waits on a flag on the hot path)
         if (tid == 0) p.dgx[(size_t)d * G4 + 16 * rank] = __int_as_float(0x7fc00000);
         return;
@@ -386,11 +398,13 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
       }
       dgl[pb][pu] = dgi; dgl[pb][16 + pu] = dgf; dgl[pb][32 + pu] = dgg; dgl[pb][48 + pu] = dgo;
     }
+    PP_T(3);
     if (step == T - 1) break;
     // this thread's mailbox resets have been acknowledged by the L2 ... (a plain wait for the outstanding stores: an
     // agent-scope release FENCE would write the whole L2 back to memory on this multi-XCD part -- measured 12 us per step)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // ... and so have everybody's, before any partial goes out
+    PP_T(4);
     // ---- own 64 rows of dgates x own W_hh rows: partial[batch row][k] for k = 128 w + 64 cg + lane ---------------------
     {
       const float* arow = &dgl[lane & 3][0];
@@ -420,7 +434,11 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
         for (int i = 0; i < 4; ++i) store_agent(dst + i * 16, rv[i]);
       }
     }
+    PP_T(5);
   }
+#ifdef PK2_PERSIST_PROFILE
+  if (tid == 0 && s_rank == 0 && d == 0) for (int k = 0; k < 6; ++k) g_ppb[k] = pp_acc[k];
+#endif
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
@@ -473,6 +491,9 @@ int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gate
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mailboxes), (int)kSentinelBits, lstm_bwd_persist_mailbox_floats(D), stream));
   PersistBwdParams p{dy, whh, gates, cells, dgx, mailboxes, B, T, D};
   hipLaunchKernelGGL(lstm_bwd_persist, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
+#ifdef PK2_PERSIST_PROFILE
+  hipLaunchKernelGGL(ppb_print, dim3(1), dim3(1), 0, stream, T);
+#endif
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;
