@@ -71,6 +71,7 @@ struct pk2_den_graph {
   int32_t S = 0, P = 0, start = 0;
   int64_t A = 0;
   std::vector<float> pi;
+  std::vector<int32_t> orig_of;   // [S] caller's id of internal state k (identity unless PK2_DEN_ORDER reorders)
   double pi_sum = 0.0;
   pk2::HostOrdering h_fwd, h_bwd, h_gam;  // keyed by dst / src / pdf (general kernels)
   // State-x kernels (chain_den.hip).  One self-loop per state is PEELED off the arc lists: its contribution is a

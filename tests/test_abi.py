@@ -62,7 +62,8 @@ def _emulate(o, nrows_total, val):
 
 
 @pytest.mark.parametrize("case", ["small", "bigrow", "sparse"])
-def test_den_graph_orderings_reproduce_segment_sums(case):
+def test_den_graph_orderings_reproduce_segment_sums(case, monkeypatch):
+    monkeypatch.setenv("PK2_DEN_ORDER", "none")     # the layouts below are compared in the caller's state numbering
     S, A, P, seed = dict(small=(40, 300, 7, 1), bigrow=(200, 20000, 11, 2), sparse=(3000, 9000, 50, 3))[case]
     g = synth.den_graph_arcs(S, A, P, seed)
     if case == "bigrow":  # one state with > 4096 incoming arcs (split chunk) and a pdf without arcs
@@ -99,6 +100,7 @@ def test_den_graph_virtual_state_orderings(case, monkeypatch):
     S, A, P, seed = 300, 6000, 23, 7
     kw = dict(unique={}, chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_pdf_differs=True, multi_entry_frac=0.3),
               bigstate=dict(loop_pdf_differs=True), arc_pdf={}, no_peel=dict(loop_pdf_differs=True))[case]
+    monkeypatch.setenv("PK2_DEN_ORDER", "none")     # the layouts below are compared in the caller's state numbering
     if case == "no_peel":
         monkeypatch.setenv("PK2_DEN_PEEL", "0")
     if case == "bigstate":
@@ -183,6 +185,20 @@ def test_den_graph_virtual_state_orderings(case, monkeypatch):
     bev = be[vstate] * xv
     got = _emulate(ob, S_, lambda a, b, p, pp: bev[a] * p) + lprob * xl * be
     assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
+
+
+def test_den_graph_internal_state_order_is_invisible():
+    """By default the library renumbers the states by in-degree (gather locality); initial_probs() still answers in the
+    caller's numbering."""
+    g = synth.den_graph_arcs(300, 6000, 23, 7, loop_pdf_differs=True)
+    G = chain.DenominatorGraph(g, 23)
+    ref = R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, 23)
+    assert np.abs(G.initial_probs() - ref.initial_probs).max() < 1e-7
+    o = G.debug_ordering(3)
+    indeg_sorted = np.sort(np.bincount(g["dst"][g["src"] != g["dst"]], minlength=g["num_states"]))[::-1]
+    # rows of the forward ordering are (virtual) destination states in internal order: most-entered first
+    lens = [int((o["arcs"][:, 2] != 0).sum())]       # total arcs kept
+    assert lens[0] == int((g["src"] != g["dst"]).sum()) and indeg_sorted[0] >= indeg_sorted[-1]
 
 
 def test_openfst_den_fst_reader(tmp_path):
