@@ -12,6 +12,7 @@
 // prefetched into registers while the current one is multiplied.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_tile.h"
@@ -45,14 +46,9 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
     B += i0 * bt.sB0 + i1 * bt.sB1;
     C += i0 * bt.sC0 + i1 * bt.sC1;
   }
-  // kSlabs slabs of BK = 16 k are staged per barrier pair.  Two slabs (32 k per iteration) were measured in the
-  // same job against one: equal or slower on every shape of the model (bench.py --gemm-only), so one it is.
-#ifndef PK2_GEMM_SLABS
-#define PK2_GEMM_SLABS 1
+#ifndef PK2_GEMM_PIPE
+#define PK2_GEMM_PIPE 1
 #endif
-  constexpr int kSlabs = PK2_GEMM_SLABS;
-  __shared__ __attribute__((aligned(16))) float As[kSlabs][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[kSlabs][BK * LDB];
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
@@ -64,6 +60,73 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
     for (int j = 0; j < TILES; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int kq = lane >> 5, li = lane & 31;
+#if PK2_GEMM_PIPE
+  // Two k-slabs of BK = 16 in flight in registers, two LDS buffers, ONE barrier per slab: while slab kt is multiplied out
+  // of LDS[kt & 1], slab kt+1 (loaded two iterations ago) is written into the other buffer and slabs kt+2 / kt+3 are on
+  // their way from memory.  (Round 1: one LDS buffer, one slab in flight, two barriers per slab -- the global-load
+  // latency of a slab was exposed at every barrier: 38 % MFMA-busy on the model's shapes.)
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  float4 ra[2][TILES], rb[2][TILES];
+  const int nk = (K - kbeg + BK - 1) / BK;
+  // interior tile: every slab but possibly the last is loaded through precomputed pointers (gemm_tile.h)
+  const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N;
+  const int nk_fast = interior ? (K - kbeg) / BK : 0;        // slabs that lie wholly inside K
+  const float* pa[TILES]; const float* pb[TILES];
+  int64_t stepA = 0, stepB = 0;
+  slab_pointers<!TA, TILES>(A, lda, m0, kbeg, pa, &stepA);
+  slab_pointers<TB, TILES>(B, ldb, n0, kbeg, pb, &stepB);
+  auto fetch = [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
+    if (ks < nk_fast) {
+      load_slab_fast<TILES>(pa, ks * stepA, xa);
+      load_slab_fast<TILES>(pb, ks * stepB, xb);
+    } else {
+      load_slab<!TA, TILES>(A, lda, m0, kbeg + ks * BK, M, K, vecA, xa);
+      load_slab<TB, TILES>(B, ldb, n0, kbeg + ks * BK, N, K, vecB, xb);
+    }
+  };
+  fetch(0, ra[0], rb[0]);
+  if (nk > 1) fetch(1, ra[1], rb[1]);
+  store_slab<!TA, TILES>(As[0], ra[0]);
+  store_slab<TB, TILES>(Bs[0], rb[0]);
+  __syncthreads();
+  if (nk > 2) fetch(2, ra[0], rb[0]);
+  auto slab_step = [&](int kt, auto P) {
+    constexpr int cur = decltype(P)::value, nxt = 1 - cur;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TILES], b[TILES];
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) a[i] = As[cur][(kk + kq) * LDA + wm + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TILES; ++j) b[j] = Bs[cur][(kk + kq) * LDB + wn + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < TILES; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_slab<!TA, TILES>(As[nxt], ra[nxt]);
+      store_slab<TB, TILES>(Bs[nxt], rb[nxt]);
+    }
+    __syncthreads();
+    if (kt + 3 < nk) fetch(kt + 3, ra[nxt], rb[nxt]);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    slab_step(kt, std::integral_constant<int, 0>());
+    if (kt + 1 < nk) slab_step(kt + 1, std::integral_constant<int, 1>());
+  }
+#else
+  // kSlabs slabs of BK = 16 k are staged per barrier pair.  Two slabs (32 k per iteration) were measured in the
+  // same job against one: equal or slower on every shape of the model (bench.py --gemm-only), so one it is.
+#ifndef PK2_GEMM_SLABS
+#define PK2_GEMM_SLABS 1
+#endif
+  constexpr int kSlabs = PK2_GEMM_SLABS;
+  __shared__ __attribute__((aligned(16))) float As[kSlabs][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[kSlabs][BK * LDB];
 
   float4 ra[kSlabs][TILES], rb[kSlabs][TILES];
   // A is "k-contiguous" when not transposed ([M,K]); B is k-contiguous when transposed ([N,K]).
@@ -94,7 +157,6 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
         load_slab<TB, TILES>(B, ldb, n0, kbeg + ((kt + 1) * kSlabs + q) * BK, N, K, vecB, rb[q]);
       }
     }
-    const int kq = lane >> 5, li = lane & 31;
 #pragma unroll
     for (int q = 0; q < kSlabs; ++q) {
 #pragma unroll
@@ -116,6 +178,7 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
       }
     }
   }
+#endif
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
