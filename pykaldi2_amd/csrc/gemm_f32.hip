@@ -249,6 +249,9 @@ __global__ void scale_vec_kernel(float* v, int n, float beta) {
 
 using namespace pk2;
 
+#ifndef PK2_GEMM_MIN_KSLICE
+#define PK2_GEMM_MIN_KSLICE 256   // (measured on the layer-0 weight gradient 4096 x 80 x 2276: 101 -> 64 us)
+#endif
 static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha, const float* A, int64_t lda,
                        const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
                        int n0, const GemmBatch& bt_in, bool aligned_strides, hipStream_t stream) {
@@ -263,7 +266,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   bt.klen = K;
   const char* fsplit = getenv("PK2_GEMM_SPLITK");
   if (big_tiles <= 256 && K >= 2048 && (!fsplit || atoi(fsplit) != 1)) {   // (measured: no gain above one tile per CU)
-    int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / 512);
+    int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / PK2_GEMM_MIN_KSLICE);
     if (fsplit && atoi(fsplit) > 1) ks = atoi(fsplit);
     if (ks > 1 && (int64_t)n0 * bt.n1 * ks <= 65535) {
       tiles = 2;
@@ -274,22 +277,51 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
                            stream, M, N, beta, C, ldc, bias, bt);
     }
   }
-  const int edge = 64 * tiles;
-  dim3 grid((N + edge - 1) / edge, (M + edge - 1) / edge, n0 * bt.n1 * bt.ksplit), block(kGemmThreads);
-#define PK2_GEMM(TA, TB)                                                                                   \
-  do {                                                                                                     \
-    if (tiles == 2)                                                                                        \
-      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, block, 0, stream, M, N, K, alpha, A, lda, B,  \
-                         ldb, beta, C, ldc, bias, vecA, vecB, bt);                                         \
-    else                                                                                                   \
-      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, block, 0, stream, M, N, K, alpha, A, lda, B,  \
-                         ldb, beta, C, ldc, bias, vecA, vecB, bt);                                         \
+  // One launch of `t`-tiles (1 = 64x64, 2 = 128x128) over rows [m_off, m_off + m_rows) of C.
+  auto launch = [&](int t, int m_off, int m_rows) {
+    const int edge = 64 * t;
+    const float* Ap = transa ? A + m_off : A + (int64_t)m_off * lda;
+    float* Cp = C + (int64_t)m_off * ldc;
+    dim3 grid((N + edge - 1) / edge, (m_rows + edge - 1) / edge, n0 * bt.n1 * bt.ksplit), block(kGemmThreads);
+#define PK2_GEMM(TA, TB)                                                                                          \
+  do {                                                                                                            \
+    if (t == 2)                                                                                                   \
+      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B,   \
+                         ldb, beta, Cp, ldc, bias, vecA, vecB, bt);                                               \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B,   \
+                         ldb, beta, Cp, ldc, bias, vecA, vecB, bt);                                               \
   } while (0)
-  if (!transa && !transb) PK2_GEMM(false, false);
-  else if (!transa && transb) PK2_GEMM(false, true);
-  else if (transa && !transb) PK2_GEMM(true, false);
-  else PK2_GEMM(true, true);
+    if (!transa && !transb) PK2_GEMM(false, false);
+    else if (!transa && transb) PK2_GEMM(false, true);
+    else if (transa && !transb) PK2_GEMM(true, false);
+    else PK2_GEMM(true, true);
 #undef PK2_GEMM
+  };
+  // Tile quantisation: 128x128 tiles are dealt to 256 CUs, so e.g. the 18 x 32 = 576 tiles of the BLSTM input projection
+  // (M = 2276 rows) take three tile-times on some CUs for 2.25 tile-times of work.  A plain 2-D product is therefore cut
+  // along M: as many 128-row bands as fill the chip a whole number of times get 128x128 tiles, the remaining rows get
+  // 64x64 tiles in a second launch (here: 16 bands = 512 tiles = 2 per CU, then 228 rows x 64 columns-tiles = 256 small
+  // tiles = 1 per CU).  Estimated cost of a small tile = 0.3 of a big one (a quarter of the flops at lower intensity).
+  static const bool no_band = [] { const char* e = getenv("PK2_GEMM_BANDS"); return e && atoi(e) == 0; }();
+  int cus = 256;
+  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && (transa ? (lda & 3) == 0 : true)) {
+    const int Cn = (N + 127) / 128, R = (M + 127) / 128, Cs = (N + 63) / 64;
+    auto rounds = [&](int64_t n) { return (double)((n + cus - 1) / cus); };
+    int best_r = R; double best = rounds((int64_t)R * Cn);
+    for (int r = 0; r < R; ++r) {
+      const int rest = M - r * 128;
+      const double c = rounds((int64_t)r * Cn) + 0.3 * rounds((int64_t)((rest + 63) / 64) * Cs);
+      if (c < best - 1e-9) { best = c; best_r = r; }
+    }
+    if (best_r < R) {
+      if (best_r > 0) launch(2, 0, best_r * 128);
+      launch(1, best_r * 128, M - best_r * 128);
+      PK2_LAUNCH_CHECK();
+      return PK2_OK;
+    }
+  }
+  launch(tiles, 0, M);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
