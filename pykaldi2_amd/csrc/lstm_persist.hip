@@ -32,7 +32,8 @@ constexpr unsigned kSentinelBits = 0x7fc0dead;     // a NaN payload no LSTM outp
 constexpr int kPH = 512;                           // hidden size served
 constexpr int kPUnits = 16;                        // hidden units per workgroup
 constexpr int kPWgs = kPH / kPUnits;               // workgroups per direction = CUs of an XCD
-constexpr long long kSpinTicks = 20 * 1000 * 100;  // 20 ms of the 100 MHz wall clock before a poll gives up
+constexpr long long kSpinTicks = 1000LL * 1000 * 100;  // 1 s of the 100 MHz wall clock before a poll gives up (peers whose
+                                                       // dispatch is delayed by other kernels on the chip are simply waited for)
 
 __device__ __forceinline__ unsigned xcc_id() {
   unsigned v;

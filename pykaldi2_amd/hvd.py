@@ -54,7 +54,21 @@ def init(backend=None):
             dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
         _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local, group=True)
         if backend == "nccl" and torch.cuda.is_available() and os.environ.get("PK2_HVD_COMM", "pk2") == "pk2":
-            _state["comm"] = _create_comm()
+            # every rank must end up on the same path: a rank whose communicator could not be created tells the others
+            try:
+                comm, err = _create_comm(), ""
+            except Exception as e:      # e.g. librccl not found: gradients then go through torch.distributed
+                comm, err = None, str(e)
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                _state["comm"] = comm
+            else:
+                if comm is not None:
+                    from . import _lib
+                    _lib.lib().pk2_comm_destroy(comm)
+                if _state["rank"] == 0:
+                    sys.stderr.write("[hvd] library communicator unavailable (%s): gradients go through torch.distributed\n" % err)
     _state["initialized"] = True
 
 
