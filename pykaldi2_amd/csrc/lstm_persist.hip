@@ -1,4 +1,4 @@
-// Persistent recurrence of one (bi)directional LSTM layer for small batches (B <= 4, H = 512) on gfx950.
+// Persistent recurrence of one (bi)directional LSTM layer for small batches (B <= 8, H = 512) on gfx950.
 //
 // The launch-per-step kernels of lstm.hip pay, every time step, a dependent kernel launch and -- because the L2s of
 // the 8 XCDs are not coherent with each other and are invalidated at kernel boundaries -- a COLD round trip to memory
@@ -16,6 +16,7 @@
 //    the dispatcher deals workgroup ids to XCDs; a timeout raises an abort flag instead of hanging.
 // Replaces the same cuDNN RNN as lstm.hip (reference models/lstm.py:49-58); the step kernels remain for other shapes.
 #include <cstdlib>
+#include <map>
 
 #include "common.h"
 #include "lstm_persist.h"
@@ -25,6 +26,9 @@ namespace pk2 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PK2_PERSIST_SCALAR_STORES
+#define PK2_PERSIST_SCALAR_STORES 0
+#endif
 #ifndef PK2_PERSIST_DUAL
 #define PK2_PERSIST_DUAL 1
 #endif
@@ -82,14 +86,16 @@ __global__ void pp_print(int steps) {
 #define PP_T(k) do { } while (0)
 #endif
 
+// NBG = groups of 4 batch rows (1: B <= 4, 2: B <= 8): W_hh is read from the registers once per group.
+template <int NBG>
 __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, PersistCtl* ctl) {
-  constexpr int H = kPH;
+  constexpr int H = kPH, NB = 4 * NBG;
   // h_{t-1} of the direction, double buffered, as [batch row][k-phase][128 + 4]: the 16 (batch row, k-phase) streams the
   // MFMA lanes read side by side start 16 bytes apart modulo the 64 banks (unpadded they all start on bank 0: measured
   // 1.9 us per step in 16-way conflicts)
   constexpr int kPhasePitch = 132, kRowPitch = 4 * kPhasePitch;
-  __shared__ __attribute__((aligned(16))) float hs[2][4 * kRowPitch];
-  __shared__ __attribute__((aligned(16))) float tr[4][16][4];     // per-wave transposition of the 16 (gate, batch) sums
+  __shared__ __attribute__((aligned(16))) float hs[2][NB * kRowPitch];
+  __shared__ __attribute__((aligned(16))) float tr[4][NBG][16][4];   // per-wave transposition of the (gate, batch row) sums
   __shared__ int s_rank, s_dir, s_abort;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
@@ -117,9 +123,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
       wa[i * 4] = v[0]; wa[i * 4 + 1] = v[1]; wa[i * 4 + 2] = v[2]; wa[i * 4 + 3] = v[3];
     }
   }
-  // gate-math role (lanes 0..15 of every wave): unit u0 + lane/4, batch row lane%4
-  const int gu = u0 + (lane >> 2), gc = lane & 3;
-  const bool gate_lane = lane < 16 && gc < B;
+  // gate-math role (lanes 0 .. 16*NBG-1 of every wave): batch group lane/16, unit u0 + (lane%16)/4, row 4*group + lane%4
+  const int gg_ = lane >> 4, gu = u0 + ((lane & 15) >> 2), gc = 4 * gg_ + (lane & 3);
+  const bool gate_lane = lane < 16 * NBG && gc < B;
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
   if (gate_lane && p.bhh) {
 #pragma unroll
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
   float cstate = 0.f;
   bool timed_out = false;
   const size_t yrow = (size_t)D * H;
-  float gxn[4] = {0.f, 0.f, 0.f, 0.f};             // input projection (+ bias) of the step about to run
+  float gxn[4] = {0.f, 0.f, 0.f, 0.f};             // input projection of the step about to run
   auto load_gx = [&](int step_) {
     if (gate_lane && step_ < T) {
       const int t_ = d == 0 ? step_ : T - 1 - step_;
@@ -150,11 +156,11 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
 #pragma unroll
     for (int k = 0; k < 4; ++k) pre[k] = gxn[k] + bias[k];       // loaded one step ahead (does not depend on h)
     PP_T(0);
-    // ---- gather h_{t-1} of this direction: [4][H] floats = 512 granules of 16 bytes, two per thread -------------------
-    {
-      const int c0 = tid >> 7, c1 = c0 + 2, k4 = (tid & 127) * 4;          // granules tid and tid + 256
+    // ---- gather h_{t-1} of this direction: [NB][H] floats = NB * 128 granules of 16 bytes, two per thread and group ---
+#pragma unroll
+    for (int grp = 0; grp < NBG; ++grp) {
+      const int c0 = 4 * grp + (tid >> 7), c1 = c0 + 2, k4 = (tid & 127) * 4;
       u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0;
-      bool timed_out_local = false;
       const bool need0 = step > 0 && c0 < B, need1 = step > 0 && c1 < B;
       const float* src0 = p.y + ((size_t)tp * B + c0) * yrow + (size_t)d * H + k4;
       const float* src1 = p.y + ((size_t)tp * B + c1) * yrow + (size_t)d * H + k4;
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
         bool bad;
         do {
           // both loads in flight, one wait
-          if (need0 && need1 && PK2_PERSIST_DUAL) {
+          if (need0 && need1) {
             asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(v0), "=&v"(v1) : "v"(src0), "v"(src1) : "memory");
           } else {
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
             if (t0 == 0) t0 = now;
             if (now - t0 > kSpinTicks || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
               __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              timed_out = true; (void)timed_out_local;
+              timed_out = true;
               break;
             }
           }
@@ -196,42 +202,50 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
     PP_T(2);
     load_gx(step + 1);
     // ---- recurrent product: D_blk[r][c] += W[g][u0+r][k] * h[c][k] over the lane block's 128 k's ---------------------
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NBG];
+#pragma unroll
+    for (int grp = 0; grp < NBG; ++grp) acc[grp] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (step > 0) {
-      // all of the lane's h values first (32 LDS reads in flight), then four independent accumulator chains: a
-      // dependent 4x4x1 MFMA waits ~4x its issue time for its predecessor (measured: 128 chained = 1.9 us)
-      const float* hrow = &hs[buf][q4 * kRowPitch + kp * kPhasePitch];
-      f32x4 hv[32];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) hv[i] = *reinterpret_cast<const f32x4*>(hrow + i * 4);
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      for (int grp = 0; grp < NBG; ++grp) {
+        // all of the lane's h values first (32 LDS reads in flight), then four independent accumulator chains
+        const float* hrow = &hs[buf][(4 * grp + q4) * kRowPitch + kp * kPhasePitch];
+        f32x4 hv[32];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4], hv[i][0], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4 + 1], hv[i][1], a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4 + 2], hv[i][2], a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4 + 3], hv[i][3], a3, 0, 0, 0);
-      }
-      acc = (a0 + a1) + (a2 + a3);
-      // the four k-phases of a (gate, batch row) sit 16 lanes apart
+        for (int i = 0; i < 32; ++i) hv[i] = *reinterpret_cast<const f32x4*>(hrow + i * 4);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[r];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[r] = v;
+        for (int i = 0; i < 32; ++i) {
+          a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4], hv[i][0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4 + 1], hv[i][1], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4 + 2], hv[i][2], a2, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i * 4 + 3], hv[i][3], a3, 0, 0, 0);
+        }
+        f32x4 sum = (a0 + a1) + (a2 + a3);
+        // the four k-phases of a (gate, batch row) sit 16 lanes apart
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = sum[r];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          sum[r] = v;
+        }
+        acc[grp] = sum;
       }
     }
     PP_T(3);
     // lane 4g + c (< 16) holds the sums of gate g, batch row c for units u0..u0+3: transpose to (unit, batch row) lanes
-    if (lane < 16) *reinterpret_cast<f32x4*>(&tr[w][lane][0]) = acc;
+    if (lane < 16) {
+#pragma unroll
+      for (int grp = 0; grp < NBG; ++grp) *reinterpret_cast<f32x4*>(&tr[w][grp][lane][0]) = acc[grp];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (gate_lane) {
-      const int ul = lane >> 2;
+      const int ul = (lane & 15) >> 2, cl = lane & 3;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pre[k] += tr[w][4 * k + gc][ul];
+      for (int k = 0; k < 4; ++k) pre[k] += tr[w][gg_][4 * k + cl][ul];
       const float ig = fsig(pre[0]), fg = fsig(pre[1]), gg = ftanh(pre[2]), og = fsig(pre[3]);
       cstate = fg * cstate + ig * gg;
       const float h = og * ftanh(cstate);
@@ -251,29 +265,34 @@ __global__ void __launch_bounds__(256) lstm_fwd_persist(PersistFwdParams p, Pers
 // Same residency (direction on one XCD, workgroup r owns units 16r..16r+15, its 64 gate rows of W_hh in VGPRs), other
 // dataflow: d h[b][k] = dy[b][k] + sum over ALL 2048 gate rows of dgates[b][row] * W_hh[row][k].  Gathering all of
 // dgates would be 32 KB per workgroup and step; instead every workgroup multiplies ITS OWN 64 rows of dgates (which it has
-// just produced, in LDS) with its W_hh rows into a partial [4][512] (again v_mfma_f32_4x4x1: the four batch rows x four
-// k's x one row per block, no cross-lane reduction at all), stores the 64 values each peer needs into that peer's mailbox
-// and gathers its own mailbox, 32 x 64 floats = 8 KB, summing the 32 partials.  Mailboxes are double buffered and reset to
-// the sentinel by their reader: a peer can only write step s+2 after it has read what this workgroup produced in step s+1,
-// which this workgroup stored after its resets of step s were acknowledged (release fence + barrier).
+// just produced, in LDS) with its W_hh rows into a partial [B][512] (again v_mfma_f32_4x4x1: four batch rows x four
+// k's x one row per block, no cross-lane reduction at all), stores the 16 x B values each peer needs into that peer's
+// mailbox (one 16-byte store per column and batch group: layout [writer][unit][batch row]) and gathers its own mailbox,
+// 32 x 16 x B floats, summing the 32 partials.  Mailboxes are double buffered and reset to the sentinel by their reader: a
+// peer can only write step s+2 after it has read what this workgroup produced in step s+1, which this workgroup stored
+// after its resets of step s were acknowledged (wait for the outstanding stores + barrier).
 struct PersistBwdParams {
   const float* dy;     // [T][B][D*H]
   const float* whh;    // [D][4H][H]
   const float* gates;  // [D][T][B][4H]
   const float* cells;  // [D][T][B][H]
   float* dgx;          // [T][B][D*4H]
-  float* px;           // [D][2][32 reader][32 writer][4][16] mailboxes, pre-filled with the sentinel
+  float* px;           // [D][2][32 reader][32 writer][16 units][4*NBG batch rows] mailboxes, pre-filled with the sentinel
   int B, T, D;
 };
 
+// The s_nop covers the ">8-byte VMEM store data followed by a VALU write of the same VGPRs" hazard: the compiler
+// inserts that wait state for its own stores but does not see one inside an asm statement (without it the first
+// two dwords were overwritten by the next VALU instruction before the store had read them).
 __device__ __forceinline__ void store16_agent(float* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
+template <int NBG>
 __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, PersistCtl* ctl) {
-  constexpr int H = kPH;
-  __shared__ __attribute__((aligned(16))) float pl[kPWgs][64 + 4];   // gathered partials [writer][batch row * 16 + unit]
-  __shared__ __attribute__((aligned(16))) float dgl[4][64 + 4];      // this workgroup's dgates [batch row][gate * 16 + unit]
+  constexpr int H = kPH, NB = 4 * NBG, BOX = 16 * NB;       // floats a writer leaves in a reader's mailbox
+  __shared__ __attribute__((aligned(16))) float pl[kPWgs][BOX + 4];  // gathered partials [writer][unit * NB + batch row]
+  __shared__ __attribute__((aligned(16))) float dgl[NB][64 + 4];     // this workgroup's dgates [batch row][gate * 16 + unit]
   __shared__ int s_rank, s_dir, s_abort;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
@@ -301,14 +320,14 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
       wb[2 * r + 1] = row[64];
     }
   }
-  // pointwise role (threads 0..63): batch row tid/16, unit 16*rank + tid%16
+  // pointwise role (threads 0 .. 16*NB-1): batch row tid/16, unit 16*rank + tid%16
   const int pb = tid >> 4, pu = tid & 15, unit = 16 * rank + pu;
-  const bool pw = tid < 64 && pb < B;
+  const bool pw_thread = tid < 16 * NB, pw = pw_thread && pb < B;
   float dcarry = 0.f;
   bool timed_out = false;
   float* mail[2];
-  mail[0] = p.px + ((size_t)(d * 2 + 0) * kPWgs + rank) * (kPWgs * 64);
-  mail[1] = p.px + ((size_t)(d * 2 + 1) * kPWgs + rank) * (kPWgs * 64);
+  mail[0] = p.px + ((size_t)(d * 2 + 0) * kPWgs + rank) * (kPWgs * BOX);
+  mail[1] = p.px + ((size_t)(d * 2 + 1) * kPWgs + rank) * (kPWgs * BOX);
   const u32x4 sent = {kSentinelBits, kSentinelBits, kSentinelBits, kSentinelBits};
   // operands of the pointwise stage, one step ahead
   float n_dy = 0.f, n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_cp = 0.f;
@@ -339,8 +358,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
     float rec = 0.f;
     if (step > 0) {
       float* box = mail[step & 1];
-      {
-        float* src0 = box + (size_t)tid * 4;
+#pragma unroll
+      for (int grp = 0; grp < NBG; ++grp) {
+        // granule = writer * (4 * NBG * 4... ) : the mailbox is 32 * BOX floats = 512 * NBG granules, two per thread and group
+        float* src0 = box + (size_t)(grp * 512 + tid) * 4;
         float* src1 = src0 + 1024;
         u32x4 v0, v1;
         long long t0 = 0;
@@ -363,9 +384,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
         } while (bad);
         store16_agent(src0, sent);               // the mailbox is free again (ordered before this step's own stores below)
         store16_agent(src1, sent);
-        const int g0 = tid, g1 = tid + 256;      // granule = writer * 16 + (batch row * 16 + unit) / 4
-        *reinterpret_cast<u32x4*>(&pl[g0 >> 4][(g0 & 15) * 4]) = v0;
-        *reinterpret_cast<u32x4*>(&pl[g1 >> 4][(g1 & 15) * 4]) = v1;
+        const int g0 = grp * 512 + tid, g1 = g0 + 256;      // float offset 4 * granule = writer * BOX + (unit * NB + row)
+        *reinterpret_cast<u32x4*>(&pl[(g0 * 4) / BOX][(g0 * 4) % BOX]) = v0;
+        *reinterpret_cast<u32x4*>(&pl[(g1 * 4) / BOX][(g1 * 4) % BOX]) = v1;
       }
       PP_T(1);
       if (timed_out) s_abort = 1;
@@ -375,15 +396,16 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
         if (tid == 0) p.dgx[(size_t)d * G4 + 16 * rank] = __int_as_float(0x7fc00000);
         return;
       }
-      if (tid < 64) {
+      if (pw_thread) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const int col = pu * NB + pb;
 #pragma unroll
-        for (int q = 0; q < kPWgs; q += 4) { s0 += pl[q][tid]; s1 += pl[q + 1][tid]; s2 += pl[q + 2][tid]; s3 += pl[q + 3][tid]; }
+        for (int q = 0; q < kPWgs; q += 4) { s0 += pl[q][col]; s1 += pl[q + 1][col]; s2 += pl[q + 2][col]; s3 += pl[q + 3][col]; }
         rec = (s0 + s1) + (s2 + s3);
       }
     }
     // ---- gate derivatives of (batch row, unit) ---------------------------------------------------------------------------
-    if (tid < 64) {
+    if (pw_thread) {
       float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f;
       if (pw) {
         const float dh = c_dy + rec;
@@ -407,8 +429,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
     __syncthreads();                                       // ... and so have everybody's, before any partial goes out
     PP_T(4);
     // ---- own 64 rows of dgates x own W_hh rows: partial[batch row][k] for k = 128 w + 64 cg + lane ---------------------
-    {
-      const float* arow = &dgl[lane & 3][0];
+#pragma unroll
+    for (int grp = 0; grp < NBG; ++grp) {
+      const float* arow = &dgl[4 * grp + (lane & 3)][0];
       f32x4 av[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) av[q] = *reinterpret_cast<const f32x4*>(arow + q * 4);
@@ -424,15 +447,21 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
         a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][3], wb[8 * q + 6], a1, 0, 0, 0);
         b1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q][3], wb[8 * q + 7], b1, 0, 0, 0);
       }
-      const f32x4 r0 = a0 + a1, r1 = b0 + b1;     // register i = batch row i; column k = 128 w + 64 cg + lane
-      // peer k/16 reads [writer = rank][batch row][k%16] from its mailbox of the next step
+      const f32x4 r0 = a0 + a1, r1 = b0 + b1;     // register i = batch row 4*grp + i; column k = 128 w + 64 cg + lane
+      // peer k/16 reads [writer = rank][unit k%16][batch row] from its mailbox of the next step: one 16-byte store
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
         const int k = 128 * w + 64 * cg + lane;
-        float* dst = p.px + (((size_t)(d * 2 + ((step + 1) & 1)) * kPWgs + (k >> 4)) * kPWgs + rank) * 64 + (k & 15);
+        float* dst = p.px + (((size_t)(d * 2 + ((step + 1) & 1)) * kPWgs + (k >> 4)) * kPWgs + rank) * BOX + (k & 15) * NB + 4 * grp;
         const f32x4 rv = cg == 0 ? r0 : r1;
+#if PK2_PERSIST_SCALAR_STORES
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store_agent(dst + i * 16, rv[i]);
+        for (int i = 0; i < 4; ++i) store_agent(dst + i, rv[i]);
+#else
+        u32x4 bits;
+        bits.x = __float_as_uint(rv[0]); bits.y = __float_as_uint(rv[1]); bits.z = __float_as_uint(rv[2]); bits.w = __float_as_uint(rv[3]);
+        store16_agent(dst, bits);
+#endif
       }
     }
     PP_T(5);
@@ -443,19 +472,34 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
-static PersistCtl* g_ctl = nullptr;      // device
+static std::map<hipStream_t, PersistCtl*> g_ctls;   // device control blocks, one per caller stream (launches on different
+                                                    // streams may overlap; each needs its own role counters)
+static PersistCtl* g_ctl_last = nullptr;
 static int g_persist_state = -1;         // -1 untested, 0 unusable, 1 verified on this device
+
+static int get_ctl(hipStream_t stream, PersistCtl** out) {
+  auto it = g_ctls.find(stream);
+  if (it == g_ctls.end()) {
+    PersistCtl* c = nullptr;
+    PK2_HIP(hipMalloc(reinterpret_cast<void**>(&c), sizeof(PersistCtl)));
+    it = g_ctls.emplace(stream, c).first;
+  }
+  *out = g_ctl_last = it->second;
+  return PK2_OK;
+}
 
 bool lstm_persist_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_PERSIST");
   if (env && atoi(env) == 0) return false;
-  return g_persist_state != 0 && H == kPH && B >= 1 && B <= 4 && (D == 1 || D == 2);
+  return g_persist_state != 0 && H == kPH && B >= 1 && B <= 8 && (D == 1 || D == 2);
 }
 
 int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
                             float* gates, float* cells, hipStream_t stream, bool* ran) {
   *ran = false;
-  if (!g_ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&g_ctl), sizeof(PersistCtl)));
+  PersistCtl* g_ctl = nullptr;
+  int crc = get_ctl(stream, &g_ctl);
+  if (crc) return crc;
   int dev = 0, cus = 256;
   PK2_HIP(hipGetDevice(&dev));
   PK2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -463,7 +507,8 @@ int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh,
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(y), (int)kSentinelBits, (size_t)T * B * D * H, stream));
   PersistFwdParams p{gx, whh, bhh, y, gates, cells, B, T, D};
   // one workgroup per CU: every XCD receives its 32, the ones on XCD 0 (and 1) take the roles, the rest return at once
-  hipLaunchKernelGGL(lstm_fwd_persist, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
+  if (B <= 4) hipLaunchKernelGGL(lstm_fwd_persist<1>, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
+  else hipLaunchKernelGGL(lstm_fwd_persist<2>, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
 #ifdef PK2_PERSIST_PROFILE
   hipLaunchKernelGGL(pp_print, dim3(1), dim3(1), 0, stream, T);
 #endif
@@ -485,13 +530,17 @@ int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gate
                             int D, float* dgx, float* mailboxes, hipStream_t stream, bool* ran) {
   *ran = false;
   if (g_persist_state != 1) return PK2_OK;   // the forward pass verifies the device first
+  PersistCtl* g_ctl = nullptr;
+  int crc = get_ctl(stream, &g_ctl);
+  if (crc) return crc;
   int dev = 0, cus = 256;
   PK2_HIP(hipGetDevice(&dev));
   PK2_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   PK2_HIP(hipMemsetAsync(g_ctl, 0, sizeof(PersistCtl), stream));
-  PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mailboxes), (int)kSentinelBits, lstm_bwd_persist_mailbox_floats(D), stream));
+  PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mailboxes), (int)kSentinelBits, lstm_bwd_persist_mailbox_floats(D), stream));   // (sized for 8 batch rows)
   PersistBwdParams p{dy, whh, gates, cells, dgx, mailboxes, B, T, D};
-  hipLaunchKernelGGL(lstm_bwd_persist, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
+  if (B <= 4) hipLaunchKernelGGL(lstm_bwd_persist<1>, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
+  else hipLaunchKernelGGL(lstm_bwd_persist<2>, dim3(std::max(cus, 8 * kPWgs)), dim3(256), 0, stream, p, g_ctl);
 #ifdef PK2_PERSIST_PROFILE
   hipLaunchKernelGGL(ppb_print, dim3(1), dim3(1), 0, stream, T);
 #endif
@@ -500,12 +549,16 @@ int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gate
   return PK2_OK;
 }
 
-size_t lstm_bwd_persist_mailbox_floats(int D) { return (size_t)D * 2 * kPWgs * kPWgs * 64; }
+size_t lstm_bwd_persist_mailbox_floats(int D) { return (size_t)D * 2 * kPWgs * kPWgs * 128; }   // 16 units x 8 batch rows per writer
 
 int lstm_persist_status(unsigned* abort_flag) {
-  PersistCtl h{};
-  if (g_ctl) PK2_HIP(hipMemcpy(&h, g_ctl, sizeof(h), hipMemcpyDeviceToHost));
-  *abort_flag = h.abort;
+  unsigned any = 0;
+  for (auto& kv : g_ctls) {
+    PersistCtl h{};
+    PK2_HIP(hipMemcpy(&h, kv.second, sizeof(h), hipMemcpyDeviceToHost));
+    any |= h.abort;
+  }
+  *abort_flag = any;
   return PK2_OK;
 }
 

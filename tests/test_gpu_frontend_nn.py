@@ -152,9 +152,9 @@ def test_blstm_3x512_posteriors_match_torch_cpu():
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
 
 
-@pytest.mark.parametrize("B,T,bi,layers", [(3, 301, True, 1), (4, 150, False, 2), (1, 64, True, 1)])
+@pytest.mark.parametrize("B,T,bi,layers", [(3, 301, True, 1), (4, 150, False, 2), (1, 64, True, 1), (8, 120, True, 1), (6, 77, True, 2)])
 def test_persistent_recurrence_long_sequences_match_torch_cpu(B, T, bi, layers):
-    """The persistent small-batch recurrence (csrc/lstm_persist.hip: H = 512, B <= 4; one direction per XCD, h and the
+    """The persistent small-batch recurrence (csrc/lstm_persist.hip: H = 512, B <= 8 in groups of 4 batch rows; one direction per XCD, h and the
     d h partials exchanged through the XCD's L2 with double-buffered sentinel mailboxes) over hundreds of steps, partial
     batches and one direction, against the reference's torch CPU nn.LSTM: outputs and every gradient."""
     torch.manual_seed(B * 1000 + T)
