@@ -75,6 +75,24 @@ class DenominatorGraph:
         _lib.check(_lib.lib().pk2_den_graph_initial_probs(self._h, _lib.ptr(out)))
         return out
 
+    def debug_persist(self, which):
+        """Layout of an ordering for the persistent kernel (test hook): which = 0 forward, 1 backward; None when the
+        graph does not fit it."""
+        L = _lib.lib()
+        info = np.zeros(8, dtype=np.int32)
+        _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), None, None, None, None, None, None, None))
+        if not info[0]:
+            return None
+        R, T, K, W, rows = (int(v) for v in info[3:8])
+        out = dict(arcs=np.empty((R, K, T, 2), dtype=np.int32), ends=np.empty((R, T), dtype=np.uint64),
+                   first_row=np.empty((R, T), dtype=np.int32), wcrow=np.empty((R, W), dtype=np.int32),
+                   row_begin=np.empty(R + 1, dtype=np.int32), grp_begin=np.empty(R + 1, dtype=np.int32),
+                   row_leak=np.empty(rows, dtype=np.float32))
+        _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), *[_lib.ptr(out[k]) for k in
+                   ("arcs", "ends", "first_row", "wcrow", "row_begin", "grp_begin", "row_leak")]))
+        out.update(max_rows=int(info[1]), max_groups=int(info[2]))
+        return out
+
     def debug_ordering(self, which):
         """Host-side work decomposition (test hook): which = 0 by dst, 1 by src, 2 by pdf (general kernels);
         3 = by virtual destination state, 4 = by src gathering virtual destination states (state-x kernels)."""

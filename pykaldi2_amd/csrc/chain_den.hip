@@ -28,6 +28,8 @@
 
 #include "chain_internal.h"
 #include "chain_num.h"
+#include "den_kernels.h"
+#include "den_persist.h"
 #include "step_graph.h"
 
 namespace pk2 {
@@ -105,26 +107,6 @@ __device__ __forceinline__ void block_sum2(float (&u)[NG], float (&v)[NG], float
 // over the lanes (segments start at lanes with a row end) delivers the carry; the wave's own carry-out goes to
 // `wcarry` and is added by the row epilogue (rows crossing a wave block).  LDS float atomics cost ~3 clocks per LANE on
 // gfx950 (measured: 1.7 us of a 19 us frame), this costs 6 x (NG + 1) cross-lane moves per wave.
-// DPP cross-lane moves (full-rate VALU, no LDS round trip): lanes whose source lies outside the 16-lane row / is masked
-// receive 0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
-
-template <int NG, int CTRL, int ROW_MASK>
-__device__ __forceinline__ void seg_scan_step(float (&x)[NG], int& fl) {
-  float y[NG];
-#pragma unroll
-  for (int n = 0; n < NG; ++n) y[n] = dpp_f<CTRL, ROW_MASK>(x[n]);
-  const int g = dpp_i<CTRL, ROW_MASK>(fl);
-#pragma unroll
-  for (int n = 0; n < NG; ++n) x[n] += fl ? 0.f : y[n];
-  fl |= g;
-}
-
 template <int NG>
 __device__ __forceinline__ void seg_carry_store(const float (&tail)[NG], const float (&head)[NG], int first_row,
                                                 float* acc, float* wcarry) {
@@ -166,33 +148,6 @@ struct IntPack { static constexpr int kN = 64; int32_t v[kN]; };
 __global__ void store_ints(IntPack pack, int count, int32_t* out) {
   if ((int)threadIdx.x < count) out[threadIdx.x] = pack.v[threadIdx.x];
 }
-
-// Uniform floor of the backward normaliser's weights, relative to the mean of pi (see den_beta_frame_sx).
-constexpr double kBetaFloor = 1e-8;
-
-struct DenParams {
-  DevOrdering fwd, bwd, gam;
-  const float* pi;
-  float* alpha; float* beta; float* xs; float* gamma;
-  float* apart; float* bpart; float* asum; float* inv_tot;
-  const int32_t* lengths;
-  // state-x path (chain_internal.h: peeled self-loops, virtual states, occupancy states); fwd / bwd are then the
-  // fwdv / bwdv orderings
-  const int32_t* ps_off;    // occupancy states grouped by pdf (CSR over P)
-  const int32_t* ps_state;
-  const int32_t* voff;      // [S+1] first virtual state of a state
-  const int32_t* ooff;      // [S+1] first occupancy state of a state
-  const int32_t* opdf;      // [Vo] pdf of an occupancy state (-1: none)
-  const int32_t* ovirt;     // [Vo] first virtual state of the occupancy state's state (its record holds btilde')
-  const float* loop_prob;   // [S] probability of the peeled self-loop (0: none)
-  float* alphav;            // [G][Tmax+1][Vo][NG]; == alpha when Vo == S
-  const float* xl;          // [G][Tmax][S][NG] exp(logit) of the peeled self-loop's pdf
-  int V, Vo;
-  int S, P, Tmax;
-  float leaky, pi_sum;
-  float wu;    // kBetaFloor * sum(pi)/S: uniform floor of the backward normaliser's weights (state-x path)
-  int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop, 4 = load half of the arc records
-};
 
 // Arc records are streamed once per launch; PK2_DEN_NT_ARCS loads them with the non-temporal hint so that they do
 // not displace the state vectors the gathers want in L2.
@@ -735,6 +690,11 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
     lkr[n] = p.leaky * rv[n];
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
+  bool any = false;
+#pragma unroll
+  for (int n = 0; n < NG; ++n) any = any || t < p.lengths[g * NG + n];
+  if (!any) return;      // nothing reads the occupancies of a frame past every sequence of the group (and the persistent
+                         // kernel leaves alpha / beta of such frames unwritten)
   for (int i = tid; i < p.P * NG; i += kGammaThreads) acc[i] = 0u;
 
   __syncthreads();
@@ -886,7 +846,7 @@ __global__ void __launch_bounds__(kExpThreads) den_exp_states_lds(const float* _
                                                                   int64_t frame_stride, const int32_t* __restrict__ lengths,
                                                                   const int32_t* __restrict__ vpdf, float* __restrict__ bx, int V,
                                                                   const int32_t* __restrict__ loop_pdf, float* __restrict__ xl,
-                                                                  int S, int P, int Tmax) {
+                                                                  int S, int P, int Tmax, float* __restrict__ xv) {
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [P][NG]
   const int t = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const float* rows[NG]; bool live[NG];
@@ -917,6 +877,7 @@ __global__ void __launch_bounds__(kExpThreads) den_exp_states_lds(const float* _
     if (pdf >= 0) ldv<NG>(xs + (size_t)pdf * NG, v);
     stv<NG>(out + (size_t)d * (2 * NG), zero);
     stv<NG>(out + (size_t)d * (2 * NG) + NG, pdf >= 0 ? v : one);
+    if (NG == 1 && xv) xv[((size_t)g * Tmax + t) * (size_t)V + d] = pdf >= 0 ? v[0] : 1.f;   // the persistent kernel's compact copy
   }
   float* outl = xl + ((size_t)g * Tmax + t) * (size_t)S * NG;
   for (int d = blockIdx.z * kExpThreads + tid; d < S; d += gridDim.z * kExpThreads) {
@@ -1335,13 +1296,14 @@ int den_choose_ng(const pk2_den_graph* g) {
   return 0;
 }
 
-size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, DenBuffers* buf,
-                     void* base) {
+static size_t den_workspace_as(const pk2_den_graph* g, int N, int Tmax, bool persist, DenGeom* geom, DenBuffers* buf,
+                               void* base) {
   DenGeom ge;
-  ge.NG = den_choose_ng(g);
+  ge.NG = persist ? 1 : den_choose_ng(g);
   if (ge.NG == 0) ge.NG = 1;
   ge.N = N; ge.Tmax = Tmax;
   ge.G = (N + ge.NG - 1) / ge.NG;
+  ge.persist = persist;
   Carver c(base);
   DenBuffers b;
   const size_t GN = (size_t)ge.G * ge.NG;
@@ -1353,8 +1315,11 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
   b.xl = sx ? c.take<float>(GN * (size_t)Tmax * g->S) : nullptr;
   b.xs = c.take<float>(GN * (size_t)Tmax * g->P);
   b.gamma = c.take<float>(GN * (size_t)Tmax * g->P);
-  b.apart = c.take<float>(GN * (Tmax + 1) * (size_t)(sx ? g->h_fwdv : g->h_fwd).n_chunks);
-  b.bpart = c.take<float>(GN * (Tmax + 1) * (size_t)(sx ? 2 * g->h_bwdv.n_chunks : g->h_bwd.n_chunks));   // state-x: two sums per chunk
+  // (the persistent kernel leaves kPR partial sums per frame; its fallback the chunk counts of the frame kernels)
+  const size_t ncf = std::max<size_t>((sx ? g->h_fwdv : g->h_fwd).n_chunks, persist ? kPR : 0);
+  const size_t ncb = std::max<size_t>((sx ? g->h_bwdv : g->h_bwd).n_chunks, persist ? kPR : 0);
+  b.apart = c.take<float>(GN * (Tmax + 1) * ncf);
+  b.bpart = c.take<float>(GN * (Tmax + 1) * (sx ? 2 * ncb : ncb));   // state-x: two sums per chunk
   b.asum = c.take<float>(GN * (Tmax + 1));
   b.inv_tot = c.take<float>(GN);
   b.den_lp = c.take<float>(GN);
@@ -1362,9 +1327,22 @@ size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, Den
   b.lengths = c.take<int32_t>(GN);
   b.csum = c.take<float>(GN * (Tmax + 1) * 2);   // {cu, sum pi*btilde' / cu}
   b.kscale = c.take<float>(GN * (Tmax + 1));
+  b.xv = persist ? c.take<float>(GN * (size_t)Tmax * V + 64) : nullptr;   // (read in whole 64-entry rows: up to 63 floats past the end)
   if (geom) *geom = ge;
   if (buf) *buf = b;
   return c.bytes();
+}
+
+// The persistent kernel works on one-sequence groups (NG = 1).  A sizing call (no base) answers for both geometries:
+// the choice can still change before the compute call (the first launch on a device is verified).
+size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, DenBuffers* buf,
+                     void* base) {
+  const bool persist = den_persist_wanted(g, N);
+  if (base) return den_workspace_as(g, N, Tmax, persist, geom, buf, base);
+  const size_t a = den_workspace_as(g, N, Tmax, false, nullptr, nullptr, nullptr);
+  const size_t b = den_workspace_as(g, N, Tmax, true, nullptr, nullptr, nullptr);
+  den_workspace_as(g, N, Tmax, persist, geom, buf, nullptr);
+  return std::max(a, b);
 }
 
 static StepGraphs g_den_graphs;
@@ -1417,7 +1395,8 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     PK2_HIP(hipMemsetAsync(b.beta, 0, GN * (Tmax + 1) * (size_t)(sx ? g->V : g->S) * 2 * sizeof(float), stream));
     PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
   }
-  PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * (size_t)hb.n_chunks * (sx ? 2 : 1) * sizeof(float), stream));
+  const bool persist = ge.persist && NG == 1 && sx;
+  PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * std::max<size_t>(hb.n_chunks, persist ? kPR : 0) * (sx ? 2 : 1) * sizeof(float), stream));
 
   DenParams p;
   p.fwd = sx ? g->fwdv : g->fwd; p.bwd = sx ? g->bwdv : g->bwd; p.gam = g->gam;
@@ -1431,6 +1410,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
   p.leaky = leaky; p.pi_sum = (float)g->pi_sum; p.wu = (float)(kBetaFloor * g->pi_sum / g->S);
   p.debug = getenv("PK2_DEN_DEBUG") ? atoi(getenv("PK2_DEN_DEBUG")) : 0;
+  if (persist) { p.fwd.n_chunks = kPR; p.bwd.n_chunks = kPR; }     // partial sums per frame: one per workgroup of a team
 
   const size_t lds = den_lds_bytes(g->P, NG);
   static bool attr_set[8] = {false};
@@ -1456,7 +1436,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     // a frame's entries are cut into slices on grid.z so that short minibatches still fill the chip
     auto slices = [&](int n) { return std::max(1, std::min((n + 1023) / 1024, (4096 + Tmax * G - 1) / (Tmax * G))); };
     const size_t exp_lds = (size_t)g->P * NG * sizeof(float);
-    if (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER")) {
+    if (persist || (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER"))) {
       static bool attr_e[8] = {false};
       if (!attr_e[NG]) {
         PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_exp_states_lds<NG>),
@@ -1465,26 +1445,39 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
       }
       const int z = std::max(1, std::min((g->V + kExpThreads - 1) / kExpThreads, (2048 + Tmax * G - 1) / (Tmax * G)));
       hipLaunchKernelGGL(den_exp_states_lds<NG>, dim3(Tmax, G, z), dim3(kExpThreads), exp_lds, stream, logits, seq_stride,
-                         frame_stride, b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, g->P, Tmax);
+                         frame_stride, b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, g->P, Tmax,
+                         persist ? b.xv : nullptr);
     } else {
       const int zv = slices(g->V), zl = slices(g->S);
       hipLaunchKernelGGL(den_exp_states<NG>, dim3(Tmax, G, zv + zl), dim3(256), 0, stream, logits, seq_stride, frame_stride,
                          b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, Tmax, zv);
     }
     PK2_LAUNCH_CHECK();
-    // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
-    // share one launch
-    const dim3 gridS(g->fwdv.n_chunks + g->bwdv.n_chunks, G);
-    snprintf(key, sizeof(key), "den_sx_%d_%u_%d_%p", NG, gridS.x, G, (void*)stream);
-    rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
-      hipLaunchKernelGGL(den_step_sx<NG>, gridS, dim3(kDenThreads), 0, s, pb, cnt, j);
-    });
-    if (rc) return rc;
+    bool ran = false;
+    if (persist) {      // both recursions of every sequence in one launch (chain_den_persist.hip)
+      rc = den_persist_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran);
+      if (rc) return rc;
+      if (!ran) {       // the device failed the first-use verification: the frame kernels, with their own chunk counts
+        DenGeom ge2 = ge;
+        ge2.persist = false;
+        return den_compute_t<NG>(g, logits, seq_stride, frame_stride, lengths_host, ge2, b, leaky, stream, tail);
+      }
+    } else {
+      // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
+      // share one launch
+      const dim3 gridS(g->fwdv.n_chunks + g->bwdv.n_chunks, G);
+      snprintf(key, sizeof(key), "den_sx_%d_%u_%d_%p", NG, gridS.x, G, (void*)stream);
+      rc = g_den_graphs.run(key, Tmax, slot->counter, stream, [&](hipStream_t s, int j) {
+        hipLaunchKernelGGL(den_step_sx<NG>, gridS, dim3(kDenThreads), 0, s, pb, cnt, j);
+      });
+      if (rc) return rc;
+    }
 #ifdef PK2_DEN_PROFILE
     hipLaunchKernelGGL(den_prof_print, dim3(1), dim3(1), 0, stream, Tmax);
 #endif
     hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
     hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
+    if (ran) den_persist_check_launch(b.den_lp, ge.N, stream);
     hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
     const size_t row_lds = (size_t)g->P * NG * sizeof(float);
     const bool lds_row = row_lds <= kGammaMaxLds && !getenv("PK2_DEN_GAMMA_GATHER");

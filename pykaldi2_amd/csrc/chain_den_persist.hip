@@ -1,0 +1,774 @@
+// Persistent denominator recursion: the alpha and beta chains of a whole minibatch in ONE launch (gfx950).
+//
+// The launch-per-frame kernels of chain_den.hip spend a frame's 18 us on a dependent launch, a cold re-stream of the
+// 1 M arc records (the L2s are invalidated at kernel boundaries) and ~1 M random gathers from L2.  Here a recursion
+// (one sequence, one direction) lives on ONE XCD for all of its frames:
+//  * the 32 workgroups of a team (one per CU, 1024 threads) own contiguous row ranges of the arc ordering; a thread keeps
+//    its 32 arc slots {gathered index, probability} in VGPRs for the whole call -- the arcs are read from memory once;
+//  * the frame's state vector (alpha[t, .], or x[t, v] * beta-hat[t+1, .] per virtual state) sits in LDS (4 bytes per
+//    state: 120 KB for the 30 k states of the BASELINE graph), so an arc costs one ds_read_b32 and one FMA;
+//  * row sums are the atomic-free lane-private / wave-scan / wave-carry scheme of den_step_sx with 32 slots per lane;
+//  * a frame's results are exchanged through the XCD's own L2: a ring of three state vectors guarded by a NaN sentinel
+//    (the owner of an entry resets the slot after next before publishing), polled with agent-scope loads -- no flags, no
+//    grid barrier, nothing crosses to another XCD.  The per-frame history (alpha, per-occupancy-state alpha, btilde',
+//    partial sums) goes out with plain stores in the NG = 1 layouts of chain_den.hip, whose parallel passes (exp tables,
+//    scales, occupancies) run unchanged around this kernel;
+//  * 2 N recursions are handed to the teams from a queue, longest first (8 XCDs = 4 sequences x 2 directions at once).
+// Teams form by arrival order per XCD (XCC_ID register); polls time out after 1 s and raise an abort flag.
+// Replaces the same DenominatorComputation as chain_den.hip (reference ops/ops.py:265, bin/train_chain.py:202).
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "den_persist.h"
+#include "step_graph.h"
+
+namespace pk2 {
+
+constexpr unsigned kRingSentinel = 0x7fc0dead;       // a NaN payload no arithmetic produces
+constexpr int kMaxTeams = 8;                         // teams per XCD the control block has room for
+constexpr int kMaxTasks = 64;
+constexpr long long kDenSpinTicks = 1000LL * 1000 * 100;   // 1 s of the 100 MHz wall clock
+
+#ifdef PK2_DP_PROFILE
+__device__ unsigned long long g_dp_prof[2][8];
+#define DP_T0() long long dp_last_ = clock64(); unsigned long long dp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DP_T(k) do { const long long n_ = clock64(); dp_acc_[k] += (unsigned long long)(n_ - dp_last_); dp_last_ = n_; } while (0)
+#define DP_FLUSH(dir) do { if (rank == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_dp_prof[dir][k_], dp_acc_[k_]); } while (0)
+__device__ long long g_dp_tl[2][kPR][8];     // wall-clock (10 ns) timeline of frame 100 of the first sequence, per rank
+#define DP_TL(dir, k) do { if (g == 0 && t == 100 && threadIdx.x == 0) g_dp_tl[dir][rank][k] = wall_clock64(); } while (0)
+__global__ void dp_prof_print(int frames) {
+  for (int dir = 0; dir < 2; ++dir) {
+    long long t0 = g_dp_tl[dir][0][0];
+    for (int r = 0; r < kPR; ++r) t0 = g_dp_tl[dir][r][0] < t0 ? g_dp_tl[dir][r][0] : t0;
+    printf("timeline %s frame 100 (10 ns ticks after the first rank entered the frame): rank: enter, partials valid, table ready, after barrier, arcs done, epilogue done, published\n", dir ? "bwd" : "fwd");
+    for (int r = 0; r < kPR; ++r)
+      printf("  %2d: %lld %lld %lld %lld %lld %lld %lld\n", r, g_dp_tl[dir][r][0] - t0, g_dp_tl[dir][r][1] - t0, g_dp_tl[dir][r][2] - t0,
+             g_dp_tl[dir][r][3] - t0, g_dp_tl[dir][r][4] - t0, g_dp_tl[dir][r][5] - t0, g_dp_tl[dir][r][6] - t0);
+  }
+  for (int dir = 0; dir < 2; ++dir) {
+    printf("den_persist %s rank 0 thread 0, shader clocks per frame over %d frames: exchange (poll + table) %llu | barrier %llu | arcs %llu | barrier+fixup+barrier %llu | epilogue %llu | wait stores + block sum + publish %llu | prefetch %llu\n",
+           dir ? "bwd" : "fwd", frames, g_dp_prof[dir][0] / frames, g_dp_prof[dir][1] / frames, g_dp_prof[dir][2] / frames,
+           g_dp_prof[dir][3] / frames, g_dp_prof[dir][4] / frames, g_dp_prof[dir][5] / frames, g_dp_prof[dir][6] / frames);
+    for (int k = 0; k < 8; ++k) g_dp_prof[dir][k] = 0;
+  }
+}
+#else
+#define DP_T0() do { } while (0)
+#define DP_T(k) do { } while (0)
+#define DP_FLUSH(dir) do { } while (0)
+#define DP_TL(dir, k) do { } while (0)
+#endif
+
+struct DenPersistCtl {
+  unsigned arrive[8];     // workgroups arrived per XCD: team = slot / kPR, rank = slot % kPR
+  unsigned next_task;     // queue head
+  unsigned abort;
+  unsigned done;          // recursions completed
+  unsigned pad[5];
+  struct Team {
+    unsigned task[kMaxTasks + 1];   // task[i] = 1 + index of the i-th recursion of this team (written by its rank 0)
+    unsigned bar;                   // team barrier: arrivals
+    unsigned pad[62];
+  } team[8][kMaxTeams];
+};
+
+struct DenPersistParams {
+  DenParams d;
+  DevPersist fwd, bwd;
+  const float* xv;        // [G][Tmax][V]
+  float* ring;            // [8 * kMaxTeams][2][rpad]
+  float* pring;           // [8 * kMaxTeams][3][kPR][2]
+  int rpad;               // floats per ring slot and of the LDS table
+  int cap;                // LDS row buffers
+  int ntasks;
+  short task_seq[kMaxTasks];
+  unsigned char task_dir[kMaxTasks];
+};
+
+// The parameter block is read through the constant address space: uniform fields become scalar loads (SGPRs), and no
+// store of the kernel can be assumed to clobber them.
+typedef __attribute__((address_space(4))) const DenPersistParams CParams;
+typedef __attribute__((address_space(4))) const DenParams CDenParams;
+
+// Arguments of a (non-inlined) device function arrive in VGPRs: the compiler must treat them -- and everything loaded
+// through them -- as divergent.  Passing the wave-uniform ones through readfirstlane turns the parameter block's fields
+// into scalar loads and their pointer arithmetic into SALU work (dozens of VGPRs next to the 96 of the arcs).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ CParams* uni(CParams* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (CParams*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ unsigned den_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0x7;
+}
+// Pointers that arrive through memory (the parameter block) or as function arguments are generic: their accesses would be
+// FLAT instructions, which count on lgkmcnt as well as vmcnt -- every LDS read of the arc loop would then wait for the
+// global prefetches in flight.  The hot pointers are therefore cast to the global address space once.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) const float cgfloat;
+typedef __attribute__((address_space(1))) unsigned gunsigned;
+__device__ __forceinline__ gfloat* G(float* p) { return (gfloat*)p; }
+__device__ __forceinline__ cgfloat* G(const float* p) { return (cgfloat*)p; }
+__device__ __forceinline__ gunsigned* G(unsigned* p) { return (gunsigned*)p; }
+__device__ __forceinline__ float ld_agent(cgfloat* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(gfloat* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent_u(gunsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool is_sentinel(float v) { return __float_as_uint(v) == kRingSentinel; }
+__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// How the state vectors travel (build-time switches for A/B runs).  Default: agent-scope (sc1) stores and loads, as in
+// lstm_persist.hip.  Plain stores + s_waitcnt are NOT enough -- the partial sum that announces a slice overtook the slice
+// on small graphs (wrong results) -- and plain loads behind `buffer_inv sc0` were no faster (11.77 vs 11.75 ms per call).
+#ifndef PK2_DP_LOADMODE
+#define PK2_DP_LOADMODE 0      // 0: agent-scope loads; 1: buffer_inv sc0 + plain loads; 2: buffer_inv sc1 + plain loads
+#endif
+#ifndef PK2_DP_STOREMODE
+#define PK2_DP_STOREMODE 1     // 0: plain stores; 1: agent-scope stores
+#endif
+__device__ __forceinline__ void invalidate_l1() {
+#if PK2_DP_LOADMODE == 1
+  asm volatile("buffer_inv sc0" ::: "memory");
+#elif PK2_DP_LOADMODE == 2
+  asm volatile("buffer_inv sc1" ::: "memory");
+#endif
+}
+__device__ __forceinline__ float ring_load(cgfloat* p) {
+#if PK2_DP_LOADMODE == 0
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void ring_store(gfloat* p, float v) {
+#if PK2_DP_STOREMODE == 1
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+
+// A poll that keeps failing reads the wall clock every 256 rounds; after 1 s (or when somebody else gave up) it raises
+// the abort flag.
+struct Spin {
+  DenPersistCtl* ctl;
+  long long t0;
+  unsigned n;
+  __device__ __forceinline__ explicit Spin(DenPersistCtl* c) : ctl(c), t0(0), n(0) {}
+  __device__ __forceinline__ bool expired() {
+    if ((++n & 255u) != 0u) return false;
+    const long long now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    if (now - t0 > kDenSpinTicks || ld_agent_u(G(&ctl->abort))) {
+      __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    return false;
+  }
+};
+
+// All kPR workgroups of the team have made their earlier stores visible and arrived `nbar` times.
+__device__ __forceinline__ bool team_barrier(DenPersistCtl* ctl, DenPersistCtl::Team* team, unsigned* nbar, int* s_abort) {
+  wait_stores();
+  __syncthreads();
+  const unsigned target = (unsigned)kPR * ++*nbar;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&team->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Spin spin(ctl);
+    while (ld_agent_u(G(&team->bar)) < target) {
+      if (spin.expired()) { *s_abort = 1; break; }
+    }
+  }
+  __syncthreads();
+  return *s_abort == 0;
+}
+
+// LDS-DMA (gfx950 global_load_lds_dwordx4): 256 consecutive floats of global memory -> 256 consecutive floats of LDS per
+// wave instruction, no VGPR round trip; asynchronous (vmcnt).  Both addresses 16-byte aligned.
+__device__ __forceinline__ void dma256(cgfloat* gsrc_lane, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, PK2_DP_LOADMODE == 0 ? 16 : 0);
+}
+
+// The workgroup's LDS, carved out of the dynamic allocation (the recursions are separate functions: everything they
+// share with the kernel lives here, and every pointer is derived from the LDS symbol so that the accesses stay ds_*).
+extern __shared__ __attribute__((aligned(16))) float den_persist_smem[];
+struct Lds {
+  float* table;    // [rpad]  the frame's gather table
+  float* acc;      // [cap]   row sums
+  float* xown;     // [cap]   forward: x[t, own rows]
+  float* leak;     // [cap]   forward: leaky-HMM constant of own rows
+  float* red;      // [2 * kPW]
+  float* tot;      // [4]     a frame's partial sums added up (written by the polling wave)
+  float* wcarry;   // [kPW]
+  int* wcrow;      // [kPW]
+  int* rb;         // [kPR+1] ring entries of a rank: [rb[r], rb[r+1])
+  int* abort;      // + rank, team, xcd, task
+};
+constexpr int kLdsTailInts = kPW + (kPR + 1) + 8;
+__device__ __forceinline__ Lds carve_lds(int rpad, int cap) {
+  Lds L;
+  L.table = den_persist_smem; L.acc = L.table + rpad; L.xown = L.acc + cap; L.leak = L.xown + cap;
+  L.red = L.leak + cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
+  L.wcrow = reinterpret_cast<int*>(L.wcarry + kPW); L.rb = L.wcrow + kPW; L.abort = L.rb + (kPR + 1);
+  return L;
+}
+
+// Exchange.  A rank publishes its partial sums of a frame AFTER its slice of the state vector has reached L2, so "all
+// kPR partial sums valid" means the ring slot is complete.  ONE wave per workgroup polls (lane l: rank l % 32, sum l / 32;
+// 256 waves polling the same two cache lines made a frame wait ~9 us for a value that was already there), the others wait
+// at the barrier that follows; the totals travel through LDS (tot[0], tot[1]: the same bits in every thread).
+__device__ __forceinline__ void poll_partials(cgfloat* ps, bool two, Spin& spin, const Lds& L) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    const bool mine = two || lane < kPR;
+    cgfloat* src = ps + (lane & (kPR - 1)) * 2 + (lane >> 5);
+    float pv = mine ? ld_agent(src) : 0.f;
+    bool ok = true;
+    while (__ballot(mine && is_sentinel(pv)) != 0ull) {
+      if (spin.expired()) { ok = false; break; }
+      if (mine && is_sentinel(pv)) pv = ld_agent(src);
+    }
+    if (!ok) pv = 0.f;
+    const float a = wave_sum(lane < kPR ? pv : 0.f), b = wave_sum(lane < kPR ? 0.f : pv);
+    if (lane == 0) { L.tot[0] = a; L.tot[1] = b; if (!ok) *L.abort = 1; }
+  }
+}
+
+// Vector in global memory -> LDS table by LDS-DMA, 1 KB rows dealt to the waves round robin (complete vector; the
+// reader's L1 may hold lines of the buffer's previous use).  R is rounded up to whole 16-byte granules: source and table
+// are padded accordingly.
+__device__ __forceinline__ void dma_table(cgfloat* src, int R, float* table) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  invalidate_l1();
+  for (int off = w * 256; off < R; off += kPW * 256)
+    if (off + lane * 4 < R) dma256(src + off + lane * 4, table + off);
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Backward: entries of the table a thread transforms in place, (wave * kXN + i) * 64 + lane for i < kXN -- a wave owns
+// kXN consecutive 256-byte rows, entry i of a lane sits at the fixed byte offset i * 256 (immediate offsets: one address
+// register per 16 entries instead of one per entry); its x[t, .] values wait in registers (loaded at the end of the
+// previous frame).
+constexpr int kXN = 64;                 // table entries <= kXN * kPT
+
+// Row sums of the thread's kPK register-resident arcs over the LDS table: complete rows are stored by the lane, the
+// piece before the first row end gets the carry of the earlier lanes (segmented wave scan), the open tail of a wave goes
+// to wcarry and is added to its row by carry_fixup.
+__device__ __forceinline__ void arc_rows(const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint64_t ends, int frow,
+                                         const Lds& L) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float sum = 0.f;
+  int c = frow;
+#pragma unroll
+  for (int j0 = 0; j0 < kPK; j0 += 8) {
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t pk = idx2[(j0 + j) >> 1];
+      const uint32_t byte_off = (j & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
+      a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.table) + byte_off);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sum = fmaf(a[j], prob[j0 + j], sum);
+      if ((ends >> (j0 + j)) & 1ull) { L.acc[c] = sum; ++c; sum = 0.f; }
+    }
+  }
+  float x[1] = {sum};
+  int fl = ends != 0ull ? 1 : 0;
+  seg_scan_step<1, 0x111, 0xf>(x, fl);
+  seg_scan_step<1, 0x112, 0xf>(x, fl);
+  seg_scan_step<1, 0x114, 0xf>(x, fl);
+  seg_scan_step<1, 0x118, 0xf>(x, fl);
+  seg_scan_step<1, 0x142, 0xa>(x, fl);
+  seg_scan_step<1, 0x143, 0xc>(x, fl);
+  const float cin = dpp_f<0x138, 0xf>(x[0]);     // wave_shr:1 -- lane 0 receives 0
+  if (ends != 0ull) L.acc[frow] += cin;            // the lane's own first row end (stored above by this lane)
+  if (lane == 63) L.wcarry[w] = x[0];
+}
+
+// The carry-outs of consecutive waves that belong to one row are added to it by the lane of the last of them.
+__device__ __forceinline__ void carry_fixup(const Lds& L) {
+  const int k = threadIdx.x;
+  if (k < kPW) {
+    const int row = L.wcrow[k];
+    if (row >= 0 && (k == kPW - 1 || L.wcrow[k + 1] != row)) {
+      int k0 = k;
+      while (k0 > 0 && L.wcrow[k0 - 1] == row) --k0;
+      float s = 0.f;
+      for (int q = k0; q <= k; ++q) s += L.wcarry[q];
+      L.acc[row] += s;
+    }
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void block_sum2_1(float& u, float& v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u = wave_sum(u); v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) { red[w] = u; red[NW + w] = v; }
+  __syncthreads();
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < NW; ++k) { a += red[k]; b += red[NW + k]; }
+  u = a; v = b;
+}
+
+// alpha recursion of sequence g (T frames): den_fwd_frame_sx<1> frame by frame.
+__device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
+                                     unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
+  CParams* pp = uni(pp_);
+  DenPersistCtl* ctl = uni(ctl_); DenPersistCtl::Team* team = uni(team_);
+  const int g = uni(g_), T = uni(T_), rank = uni(rank_);
+  ring_ = uni(ring_); pring_ = uni(pring_);
+  CParams& p = *pp;
+  CDenParams& d = p.d;
+  const Lds L = carve_lds(p.rpad, p.cap);
+  gfloat* ring = G(ring_); gfloat* pring = G(pring_);
+  const int tid = threadIdx.x;
+  const int S = d.S, V = d.V, Vo = d.Vo;
+  const bool sep = d.alphav != d.alpha;
+  float prob[kPK]; uint32_t idx2[kPK / 2];
+#pragma unroll
+  for (int j = 0; j < kPK; ++j) prob[j] = p.fwd.prob[((size_t)rank * kPK + j) * kPT + tid];
+#pragma unroll
+  for (int j = 0; j < kPK / 2; ++j) idx2[j] = p.fwd.idx2[((size_t)rank * (kPK / 2) + j) * kPT + tid];
+  const uint64_t ends = p.fwd.ends[(size_t)rank * kPT + tid];
+  const int frow = p.fwd.first_row[(size_t)rank * kPT + tid];
+  const int row0 = p.fwd.row_begin[rank], nrows = p.fwd.row_begin[rank + 1] - row0;
+  const int g0 = p.fwd.grp_begin[rank], ngrp = p.fwd.grp_begin[rank + 1] - g0;
+  for (int r = tid; r < nrows; r += kPT) L.leak[r] = p.fwd.row_leak[row0 + r];
+  if (tid < kPW) L.wcrow[tid] = p.fwd.wcrow[rank * kPW + tid];
+  if (tid <= kPR) L.rb[tid] = p.fwd.grp_begin[tid];            // the ring holds alpha per real state
+  int st_lo[kPSPT], st_hi[kPSPT], st_o[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) {
+    const int r = tid + i * kPT;
+    st_ok[i] = r < ngrp;
+    st_lo[i] = st_hi[i] = st_o[i] = 0; st_pl[i] = st_pi[i] = 0.f;
+    if (st_ok[i]) {
+      const int dd = g0 + r;
+      st_lo[i] = d.voff[dd] - row0; st_hi[i] = d.voff[dd + 1] - row0; st_o[i] = d.ooff[dd];
+      st_pl[i] = d.loop_prob[dd]; st_pi[i] = d.pi[dd];
+    }
+  }
+  // own partial-sum entries start as "not yet written"
+  if (tid < 3) st_agent(pring + (tid * kPR + rank) * 2, __uint_as_float(kRingSentinel));
+  if (!team_barrier(ctl, team, nbar, L.abort)) return;
+
+  const size_t f0 = (size_t)g * (d.Tmax + 1);
+  cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
+  cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
+  float xr[kPSPT], xlr[kPSPT];
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      xr[i] = r < nrows ? xv_g[(size_t)t * V + row0 + r] : 0.f;
+      xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + g0 + r] : 0.f;
+    }
+  };
+  prefetch(0);
+  Spin spin(ctl);
+  DP_T0();
+  for (int t = 0; t < T; ++t) {
+    float as;
+    DP_TL(0, 0);
+    if (t == 0) {
+      for (int idx = tid; idx < S; idx += kPT) L.table[idx] = G(d.pi)[idx];
+      as = d.pi_sum;
+    } else {
+      poll_partials(pring + (size_t)(t % 3) * kPR * 2, false, spin, L);
+      __syncthreads();
+      DP_TL(0, 1);
+      if (*L.abort) return;
+      as = L.tot[0];
+      dma_table(ring + (size_t)(t & 1) * p.rpad, S, L.table);
+    }
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      if (r < nrows) L.xown[r] = xr[i];
+    }
+    dma_wait();
+    DP_T(0);
+    DP_TL(0, 2);
+    __syncthreads();
+    DP_T(1);
+    DP_TL(0, 3);
+    if (rank == 0 && tid == 0) G(d.asum)[f0 + t] = as;
+    const float lk = d.leaky * as, inv_as = 1.0f / as;
+    float own_a[kPSPT];
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) own_a[i] = st_ok[i] ? L.table[g0 + tid + i * kPT] : 0.f;
+    arc_rows(prob, idx2, ends, frow, L);
+    DP_T(2);
+    DP_TL(0, 4);
+    __syncthreads();
+    carry_fixup(L);
+    __syncthreads();
+    DP_T(3);
+    // rows are virtual states (dst, pdf); a thread per real state sums its rows and adds the peeled self-loop.  First
+    // only what the other workgroups wait for: the ring entries, then (once they are in L2) the partial sum.
+    gfloat* ring_n = ring + (size_t)((t + 1) & 1) * p.rpad;
+    const bool publish = t + 1 < T;
+    float outv[kPSPT], loopv[kPSPT], loc = 0.f, unused = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      outv[i] = 0.f; loopv[i] = 0.f;
+      if (!st_ok[i]) continue;
+      float sum = 0.f;
+      for (int q = st_lo[i]; q < st_hi[i]; ++q) sum += (L.acc[q] + lk * L.leak[q]) * L.xown[q] * inv_as;
+      if (st_pl[i] > 0.f) { loopv[i] = (own_a[i] + lk * st_pi[i]) * st_pl[i] * xlr[i] * inv_as; sum += loopv[i]; }
+      if (publish) ring_store(ring_n + g0 + tid + i * kPT, sum);
+      outv[i] = sum;
+      loc += sum;
+    }
+    DP_T(4);
+    DP_TL(0, 5);
+    wait_stores();        // this rank's slice of frame t+1 is in L2 before its partial sum says so
+    block_sum2_1<kPW>(loc, unused, L.red);
+    if (tid == 0 && publish) {
+      st_agent(pring + (((t + 2) % 3) * kPR + rank) * 2, __uint_as_float(kRingSentinel));
+      wait_stores();      // the reset of the entry after next is in L2 before anybody can see this frame complete
+      st_agent(pring + (((t + 1) % 3) * kPR + rank) * 2, loc);
+    }
+    DP_T(5);
+    DP_TL(0, 6);
+    // the history the parallel passes read (nobody waits for these stores)
+    gfloat* alpha_n = G(d.alpha) + (f0 + t + 1) * (size_t)S;
+    gfloat* alphav_n = G(d.alphav) + (f0 + t + 1) * (size_t)Vo;
+    if (tid == 0) G(d.apart)[(f0 + t + 1) * kPR + rank] = loc;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      if (!st_ok[i]) continue;
+      alpha_n[g0 + tid + i * kPT] = outv[i];
+      if (sep) {
+        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = (L.acc[q] + lk * L.leak[q]) * L.xown[q] * inv_as;
+        if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
+      }
+    }
+    if (publish) prefetch(t + 1);
+    DP_T(6);
+  }
+  DP_FLUSH(0);
+}
+
+// btilde' recursion of sequence g: den_beta_frame_sx<1> frame by frame, T-1 down to 0.
+__device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
+                                     unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
+  CParams* pp = uni(pp_);
+  DenPersistCtl* ctl = uni(ctl_); DenPersistCtl::Team* team = uni(team_);
+  const int g = uni(g_), T = uni(T_), rank = uni(rank_);
+  ring_ = uni(ring_); pring_ = uni(pring_);
+  CParams& p = *pp;
+  CDenParams& d = p.d;
+  const Lds L = carve_lds(p.rpad, p.cap);
+  gfloat* ring = G(ring_); gfloat* pring = G(pring_);
+  const int tid = threadIdx.x;
+  const int S = d.S, V = d.V;
+  float prob[kPK]; uint32_t idx2[kPK / 2];
+#pragma unroll
+  for (int j = 0; j < kPK; ++j) prob[j] = p.bwd.prob[((size_t)rank * kPK + j) * kPT + tid];
+#pragma unroll
+  for (int j = 0; j < kPK / 2; ++j) idx2[j] = p.bwd.idx2[((size_t)rank * (kPK / 2) + j) * kPT + tid];
+  const uint64_t ends = p.bwd.ends[(size_t)rank * kPT + tid];
+  const int frow = p.bwd.first_row[(size_t)rank * kPT + tid];
+  const int row0 = p.bwd.row_begin[rank], nrows = p.bwd.row_begin[rank + 1] - row0;
+  if (tid < kPW) L.wcrow[tid] = p.bwd.wcrow[rank * kPW + tid];
+  int st_v0[kPSPT], st_v1[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) {
+    const int r = tid + i * kPT;
+    st_ok[i] = r < nrows;
+    st_v0[i] = st_v1[i] = 0; st_pl[i] = st_pi[i] = 0.f;
+    if (st_ok[i]) {
+      const int s = row0 + r;
+      st_v0[i] = d.voff[s]; st_v1[i] = d.voff[s + 1]; st_pl[i] = d.loop_prob[s]; st_pi[i] = d.pi[s];
+    }
+  }
+  if (tid < 6) st_agent(pring + ((tid >> 1) * kPR + rank) * 2 + (tid & 1), __uint_as_float(kRingSentinel));
+  if (!team_barrier(ctl, team, nbar, L.abort)) return;
+
+  const size_t f0 = (size_t)g * (d.Tmax + 1);
+  cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
+  cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
+  float xlr[kPSPT], prevb[kPSPT];
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) prevb[i] = 0.f;
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + tid + i * kPT] : 0.f;
+  };
+  prefetch(T - 1);
+  Spin spin(ctl);
+  const float cst_last = 1.0f / d.pi_sum + d.leaky;
+  // x[t, .] of the frame about to run waits in registers (loaded at the end of the previous frame, behind the partial sums
+  // and the history stores); the table itself receives btilde'[t+1, .] by DMA and is transformed in place.
+  // (whole 64-entry rows: the table, the ring slots and the x plane are padded to them, so a row is valid or not for the
+  // whole wave -- a scalar test -- and nothing per entry has to be kept in, or spilled from, registers)
+  float xq[kXN];
+  const int xrows = (V + 63) >> 6;
+  const int xrow0 = (tid >> 6) * kXN, xlane = tid & 63;
+  auto load_x = [&](int t) {
+    cgfloat* xsrc = xv_g + (size_t)t * V + (size_t)xrow0 * 64 + xlane;
+#pragma unroll
+    for (int i = 0; i < kXN; ++i)
+      if (xrow0 + i < xrows) xq[i] = xsrc[i * 64];
+  };
+  load_x(T - 1);
+  DP_T0();
+  for (int t = T - 1; t >= 0; --t) {
+    const bool gat = t + 1 < T;
+    float inv_c = 0.f, lkr = 0.f;
+    DP_TL(1, 0);
+    if (!gat) {
+      float* tl = L.table + xrow0 * 64 + xlane;
+#pragma unroll
+      for (int i = 0; i < kXN; ++i)
+        if (xrow0 + i < xrows) tl[i * 64] = xq[i] * cst_last;
+    } else {
+      poll_partials(pring + (size_t)((t + 1) % 3) * kPR * 2, true, spin, L);
+      __syncthreads();
+      DP_TL(1, 1);
+      if (*L.abort) return;
+      const float lB = L.tot[0], lU = L.tot[1];
+      const float cu = lB + d.wu * lU;
+      inv_c = cu > 0.f ? 1.0f / cu : 0.f;
+      lkr = d.leaky * lB * inv_c;
+      dma_table(ring + (size_t)((t + 1) & 1) * p.rpad, V, L.table);
+      dma_wait();
+      __syncthreads();
+      float* tl = L.table + xrow0 * 64 + xlane;
+#pragma unroll
+      for (int i = 0; i < kXN; ++i)
+        if (xrow0 + i < xrows) tl[i * 64] = xq[i] * (tl[i * 64] * inv_c + lkr);
+    }
+    DP_T(0);
+    DP_TL(1, 2);
+    __syncthreads();
+    DP_T(1);
+    DP_TL(1, 3);
+    arc_rows(prob, idx2, ends, frow, L);
+    DP_T(2);
+    DP_TL(1, 4);
+    __syncthreads();
+    carry_fixup(L);
+    __syncthreads();
+    DP_T(3);
+    // rows are source states; btilde'[t, s] goes into the ring entry and the record of every virtual state of s
+    gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad;
+    const bool publish = t > 0;
+    float loc = 0.f, locu = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      if (!st_ok[i]) continue;
+      float v = L.acc[tid + i * kPT];
+      if (st_pl[i] > 0.f) v += st_pl[i] * xlr[i] * (gat ? prevb[i] * inv_c + lkr : cst_last);
+      loc += st_pi[i] * v; locu += v;
+      if (publish)
+        for (int q = st_v0[i]; q < st_v1[i]; ++q) ring_store(ring_n + q, v);
+      prevb[i] = v;
+    }
+    DP_T(4);
+    DP_TL(1, 5);
+    wait_stores();
+    block_sum2_1<kPW>(loc, locu, L.red);
+    if (tid == 0 && publish) {
+      st_agent(pring + (((t + 2) % 3) * kPR + rank) * 2, __uint_as_float(kRingSentinel));
+      st_agent(pring + (((t + 2) % 3) * kPR + rank) * 2 + 1, __uint_as_float(kRingSentinel));
+      wait_stores();
+      st_agent(pring + ((t % 3) * kPR + rank) * 2, loc);
+      st_agent(pring + ((t % 3) * kPR + rank) * 2 + 1, locu);
+    }
+    DP_T(5);
+    DP_TL(1, 6);
+    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
+    if (tid == 0) {
+      G(d.bpart)[((f0 + t) * kPR + rank) * 2] = loc;
+      G(d.bpart)[((f0 + t) * kPR + rank) * 2 + 1] = locu;
+    }
+    // (the occupancy pass reads btilde' of a state from the record of its FIRST virtual state: ovirt)
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i)
+      if (st_ok[i]) bx_t[(size_t)st_v0[i] * 2] = prevb[i];
+    if (publish) { prefetch(t - 1); load_x(t - 1); }
+    DP_T(6);
+  }
+  DP_FLUSH(1);
+}
+
+// (the parameter block lives in device memory: the two recursions are separate functions -- separate register
+// allocations around their 128 arc registers -- and read it through scalar loads)
+__global__ void __launch_bounds__(kPT) den_persist_kernel(const DenPersistParams* __restrict__ pp_, DenPersistCtl* ctl) {
+  CParams* pp = (CParams*)pp_;
+  CParams& p = *pp;
+  const Lds L = carve_lds(p.rpad, p.cap);
+  int& s_abort = L.abort[0];
+  int& s_rank = L.abort[1]; int& s_team = L.abort[2]; int& s_xcd = L.abort[3]; int& s_task = L.abort[4];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_abort = 0;
+    const unsigned xcd = den_xcc_id();
+    const unsigned slot = __hip_atomic_fetch_add(&ctl->arrive[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_rank = (int)(slot % kPR); s_team = (int)(slot / kPR); s_xcd = (int)xcd;
+  }
+  __syncthreads();
+  if (s_team >= kMaxTeams) return;
+  const int rank = s_rank;
+  DenPersistCtl::Team* team = &ctl->team[s_xcd][s_team];
+  const size_t ti = (size_t)s_xcd * kMaxTeams + s_team;
+  float* ring = p.ring + ti * 2 * p.rpad;
+  float* pring = p.pring + ti * 3 * kPR * 2;
+  unsigned nbar = 0;
+  for (int iter = 0; iter <= kMaxTasks; ++iter) {
+    if (tid == 0) {
+      unsigned k;
+      if (rank == 0) {
+        k = __hip_atomic_fetch_add(&ctl->next_task, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->task[iter], k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        Spin spin(ctl);
+        unsigned k1;
+        while ((k1 = ld_agent_u(G(&team->task[iter]))) == 0u) {
+          if (spin.expired()) { s_abort = 1; k1 = 1u << 30; break; }
+        }
+        k = k1 - 1u;
+      }
+      s_task = (int)k;
+    }
+    __syncthreads();
+    const int k = s_task;
+    if (s_abort || k >= p.ntasks) return;
+    const int g = p.task_seq[k], T = p.d.lengths[g];
+    if (!team_barrier(ctl, team, &nbar, &s_abort)) return;      // everybody has left the previous recursion
+#ifndef PK2_DP_NOFWD
+    if (p.task_dir[k] == 0) run_fwd(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+#endif
+#ifndef PK2_DP_NOBWD
+    if (p.task_dir[k] != 0) run_bwd(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+#endif
+    __syncthreads();
+    if (s_abort) return;
+    if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// A launch that did not complete every recursion (a poll timed out) must not look like a result.
+__global__ void den_persist_check(const DenPersistCtl* ctl, int ntasks, float* den_lp, int n) {
+  if (ctl->abort != 0u || ctl->done != (unsigned)ntasks)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) den_lp[i] = __uint_as_float(0x7fc00000u);
+}
+
+// ----------------------------------------------------------------------------------------
+// host
+// ----------------------------------------------------------------------------------------
+static int g_den_persist_state = -1;     // -1: not verified yet, 0: unusable on this device, 1: verified
+struct DenPersistParams;
+struct DenPersistScratch { DenPersistParams* params = nullptr; DenPersistCtl* ctl = nullptr; float* ring = nullptr; float* pring = nullptr; int rpad = 0; int ntasks = 0; };
+static std::map<hipStream_t, DenPersistScratch> g_den_scratch;
+
+static int den_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 63) / 64 * 64; }
+static int den_cap(const pk2_den_graph* g) {
+  return (std::max({g->h_pfwd.max_rows, g->h_pfwd.max_groups, g->h_pbwd.max_rows, 1}) + 3) / 4 * 4;
+}
+size_t den_persist_lds_bytes(const pk2_den_graph* g) {
+  return ((size_t)den_rpad(g) + 3 * (size_t)den_cap(g) + 3 * kPW + 4 + kLdsTailInts) * sizeof(float);
+}
+
+bool den_persist_fits(const pk2_den_graph* g) {
+  return g->h_pfwd.ok && g->h_pbwd.ok && den_persist_lds_bytes(g) <= kDenPersistMaxLds && den_rpad(g) <= kXN * kPT;
+}
+
+bool den_persist_wanted(const pk2_den_graph* g, int N) {
+  const char* env = getenv("PK2_DEN_PERSIST");
+  if (env && atoi(env) == 0) return false;
+  if (g_den_persist_state == 0 || !den_persist_fits(g) || !den_use_sx(g)) return false;
+  if (N < 1 || 2 * N > kMaxTasks) return false;
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  return cus == 8 * kPR;
+}
+
+int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, const int32_t* lengths_host, int N,
+                       hipStream_t stream, bool* ran) {
+  *ran = false;
+  DenPersistScratch& sc = g_den_scratch[stream];
+  const int rpad = den_rpad(g);
+  if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(DenPersistCtl)));
+  if (!sc.params) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.params), sizeof(DenPersistParams)));
+  if (!sc.pring) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.pring), (size_t)8 * kMaxTeams * 3 * kPR * 2 * sizeof(float)));
+  if (sc.rpad < rpad) {
+    if (sc.ring) PK2_HIP(hipFree(sc.ring));
+    sc.ring = nullptr; sc.rpad = 0;
+    PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ring), (size_t)8 * kMaxTeams * 2 * rpad * sizeof(float)));
+    sc.rpad = rpad;
+  }
+  DenPersistParams p;
+  p.d = dp;
+  p.fwd = g->pfwd; p.bwd = g->pbwd;
+  p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
+  p.rpad = rpad; p.cap = den_cap(g);
+  // recursions, longest first
+  std::vector<std::pair<int, int>> order;    // (-T, task id = 2 n + dir)
+  for (int n = 0; n < N; ++n)
+    if (lengths_host[n] > 0) { order.push_back({-lengths_host[n], 2 * n}); order.push_back({-lengths_host[n], 2 * n + 1}); }
+  std::sort(order.begin(), order.end());
+  p.ntasks = (int)order.size();
+  for (int k = 0; k < kMaxTasks; ++k) { p.task_seq[k] = 0; p.task_dir[k] = 0; }
+  for (int k = 0; k < p.ntasks; ++k) { p.task_seq[k] = (short)(order[k].second >> 1); p.task_dir[k] = (unsigned char)(order[k].second & 1); }
+  sc.ntasks = 0;
+  if (p.ntasks == 0) { *ran = true; return PK2_OK; }
+  const size_t lds = den_persist_lds_bytes(g);
+  static bool attr = false;
+  if (!attr) {
+    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr = true;
+  }
+  PK2_HIP(hipMemsetAsync(sc.ctl, 0, sizeof(DenPersistCtl), stream));
+  hipLaunchKernelGGL(param_block_store<DenPersistParams>, dim3(1), dim3(1), 0, stream, p, sc.params);
+  hipLaunchKernelGGL(den_persist_kernel, dim3(8 * kPR), dim3(kPT), lds, stream, sc.params, sc.ctl);
+#ifdef PK2_DP_PROFILE
+  { int tot = 0; for (int n = 0; n < N; ++n) tot += lengths_host[n];
+    hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4)); }   // (rank 0 of every team adds up)
+#endif
+  PK2_LAUNCH_CHECK();
+  if (g_den_persist_state < 0) {     // first use on this device: every recursion done, nobody timed out?
+    DenPersistCtl* h = new DenPersistCtl;
+    hipError_t e = hipMemcpyAsync(h, sc.ctl, sizeof(DenPersistCtl), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)p.ntasks;
+    delete h;
+    if (e != hipSuccess) { set_error("den_persist: %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
+    g_den_persist_state = ok ? 1 : 0;
+    if (!ok) return PK2_OK;
+  }
+  sc.ntasks = p.ntasks;
+  *ran = true;
+  return PK2_OK;
+}
+
+void den_persist_check_launch(float* den_lp, int N, hipStream_t stream) {
+  const DenPersistScratch& sc = g_den_scratch[stream];
+  if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N);
+}
+
+}  // namespace pk2

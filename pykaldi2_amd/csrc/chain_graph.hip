@@ -12,6 +12,7 @@
 #include <numeric>
 
 #include "chain_internal.h"
+#include "den_persist.h"
 #include "openfst_io.h"
 
 namespace pk2 {
@@ -151,8 +152,108 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
   out->n_chunks = (int)out->row0.size();
 }
 
-static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src_in, const int32_t* dst_in,
-                       const int32_t* pdf, const float* prob, int32_t start, pk2_den_graph** out) {
+// Persistent-kernel layout of one ordering (chain_internal.h: HostPersist).  `key` = row of an arc, `idx` = what it
+// gathers, `group_of_row` (monotone, may be null: every row its own group) = the real state a row belongs to.
+static void build_persist(int64_t A, int num_rows, const int32_t* key, const int32_t* idx, const float* prob,
+                          const float* piprob, const int32_t* group_of_row, int num_groups, HostPersist* out) {
+  *out = HostPersist();
+  std::vector<int64_t> ptr(num_rows + 1, 0);
+  for (int64_t i = 0; i < A; ++i) ptr[key[i] + 1]++;
+  for (int r = 0; r < num_rows; ++r) ptr[r + 1] += ptr[r];
+  std::vector<int64_t> perm(A);
+  {
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < A; ++i) perm[cur[key[i]]++] = i;
+  }
+  auto slots_of = [&](int r) { return std::max<int64_t>(1, ptr[r + 1] - ptr[r]); };
+  // rows of each group
+  std::vector<int32_t> grow(num_groups + 1, 0);
+  if (group_of_row) {
+    for (int r = 0; r < num_rows; ++r) grow[group_of_row[r] + 1]++;
+    for (int g = 0; g < num_groups; ++g) grow[g + 1] += grow[g];
+  } else {
+    for (int g = 0; g <= num_groups; ++g) grow[g] = g;
+  }
+  if (grow[num_groups] != num_rows) return;
+  std::vector<int64_t> gslots(num_groups, 0);
+  int64_t total = 0;
+  for (int g = 0; g < num_groups; ++g) {
+    for (int r = grow[g]; r < grow[g + 1]; ++r) gslots[g] += slots_of(r);
+    total += gslots[g];
+  }
+  // contiguous ranges of whole groups, balanced by slots
+  out->row_begin.assign(kPR + 1, num_rows);
+  out->grp_begin.assign(kPR + 1, num_groups);
+  int g = 0;
+  int64_t left = total;
+  for (int r = 0; r < kPR; ++r) {
+    out->grp_begin[r] = g; out->row_begin[r] = grow[g];
+    const int64_t target = (left + (kPR - r) - 1) / (kPR - r);
+    int64_t have = 0; int rows = 0, groups = 0;
+    while (g < num_groups) {
+      const int gr = grow[g + 1] - grow[g];
+      if (have + gslots[g] > kPSlots || rows + gr > kPMaxRows || groups + 1 > kPMaxRows) break;
+      if (have >= target) break;
+      have += gslots[g]; rows += gr; ++groups; ++g;
+    }
+    left -= have;
+    out->max_rows = std::max(out->max_rows, rows);
+    out->max_groups = std::max(out->max_groups, groups);
+  }
+  if (g < num_groups) return;             // does not fit: the launch-per-frame kernels serve this graph
+  out->arcs.assign((size_t)kPR * kPSlots, make_int2(0, 0));
+  out->ends.assign((size_t)kPR * kPT, 0ull);
+  out->first_row.assign((size_t)kPR * kPT, 0);
+  out->wcrow.assign((size_t)kPR * kPW, -1);
+  out->row_leak.assign(num_rows, 0.f);
+  std::vector<int32_t> srow; std::vector<int64_t> sarc; std::vector<char> send;
+  for (int r = 0; r < kPR; ++r) {
+    const int row0 = out->row_begin[r], row1 = out->row_begin[r + 1];
+    srow.clear(); sarc.clear(); send.clear();
+    for (int q = row0; q < row1; ++q) {
+      double leak = 0.0;
+      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) { srow.push_back(q - row0); sarc.push_back(perm[k]); send.push_back(0); leak += (double)piprob[perm[k]]; }
+      if (ptr[q] == ptr[q + 1]) { srow.push_back(q - row0); sarc.push_back(-1); send.push_back(0); }
+      send.back() = 1;
+      out->row_leak[q] = (float)leak;
+    }
+    const int64_t n = (int64_t)srow.size();
+    for (int tid = 0; tid < kPT; ++tid) {
+      uint64_t e = 0;
+      for (int j = 0; j < kPK; ++j) {
+        const int64_t s = (int64_t)tid * kPK + j;
+        if (s >= n) break;
+        if (sarc[s] >= 0) out->arcs[((size_t)r * kPK + j) * kPT + tid] = make_int2(idx[sarc[s]], __builtin_bit_cast(int, prob[sarc[s]]));
+        if (send[s]) e |= 1ull << j;
+      }
+      out->ends[(size_t)r * kPT + tid] = e;
+      const int64_t s0 = (int64_t)tid * kPK;
+      out->first_row[(size_t)r * kPT + tid] = s0 < n ? srow[s0] : 0;
+    }
+    for (int w = 0; w < kPW; ++w) {
+      const int64_t last = (int64_t)(w + 1) * 64 * kPK - 1;
+      if (last < n && !send[last]) out->wcrow[(size_t)r * kPW + w] = srow[last];
+    }
+  }
+  // device form: probabilities and 16-bit indices apart
+  int max_idx = 0;
+  for (const int2& a : out->arcs) max_idx = std::max(max_idx, a.x);
+  if (max_idx >= 65536) return;
+  out->prob.resize(out->arcs.size());
+  out->idx2.assign(out->arcs.size() / 2, 0u);
+  for (int r = 0; r < kPR; ++r)
+    for (int j = 0; j < kPK; ++j)
+      for (int tid = 0; tid < kPT; ++tid) {
+        const int2 a = out->arcs[((size_t)r * kPK + j) * kPT + tid];
+        out->prob[((size_t)r * kPK + j) * kPT + tid] = __builtin_bit_cast(float, a.y);
+        out->idx2[((size_t)r * (kPK / 2) + j / 2) * kPT + tid] |= (uint32_t)a.x << (16 * (j & 1));
+      }
+  out->ok = true;
+}
+
+static int build_graph_ordered(int32_t S, int32_t P, int64_t A, const int32_t* src_in, const int32_t* dst_in,
+                               const int32_t* pdf, const float* prob, int32_t start, const char* order_mode,
+                               pk2_den_graph** out) {
   PK2_REQUIRE(S > 0 && P > 0 && A > 0 && start >= 0 && start < S, "den graph: bad sizes");
   PK2_REQUIRE(P <= 65536, "den graph: num_pdfs %d > 65536 unsupported", P);
   for (int64_t i = 0; i < A; ++i) {
@@ -169,7 +270,7 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src_in, c
   {
     std::vector<int32_t> order(S);
     std::iota(order.begin(), order.end(), 0);
-    const char* env = getenv("PK2_DEN_ORDER");
+    const char* env = order_mode;
     if (!(env && strcmp(env, "none") == 0)) {
       std::vector<int64_t> deg(S, 0);
       const bool both = env && strcmp(env, "degree") == 0;
@@ -268,6 +369,8 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src_in, c
                    false, true, true);
     build_ordering(A2, S, src2.data(), arc_v.data(), pdf2.data(), prob2.data(), piprob2.data(), &g->h_bwdv, nullptr, false,
                    true, true);
+    build_persist(A2, g->V, arc_v.data(), src2.data(), prob2.data(), piprob2.data(), vstate.data(), S, &g->h_pfwd);
+    build_persist(A2, S, src2.data(), arc_v.data(), prob2.data(), piprob2.data(), nullptr, S, &g->h_pbwd);
     g->po_off.assign(P + 1, 0);
     for (int o = 0; o < g->Vo; ++o) if (g->opdf[o] >= 0) g->po_off[g->opdf[o] + 1]++;
     for (int p = 0; p < P; ++p) g->po_off[p + 1] += g->po_off[p];
@@ -279,6 +382,22 @@ static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src_in, c
   return PK2_OK;
 }
 
+// State numbering: the persistent kernel (chain_den_persist.hip) gathers from LDS and only needs the rows of its 32
+// workgroups balanced, which the caller's numbering gives for any graph without a degree trend along the state ids; the
+// launch-per-frame kernels gather from L2 and gain from the in-degree order.  So: the caller's numbering when the
+// persistent layouts fit with it, else the in-degree order.  PK2_DEN_ORDER = none | indegree | degree forces one.
+static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src_in, const int32_t* dst_in,
+                       const int32_t* pdf, const float* prob, int32_t start, pk2_den_graph** out) {
+  const char* env = getenv("PK2_DEN_ORDER");
+  if (env) return build_graph_ordered(S, P, A, src_in, dst_in, pdf, prob, start, env, out);
+  int rc = build_graph_ordered(S, P, A, src_in, dst_in, pdf, prob, start, "none", out);
+  if (rc) return rc;
+  if (den_persist_fits(*out)) return PK2_OK;
+  delete *out;
+  *out = nullptr;
+  return build_graph_ordered(S, P, A, src_in, dst_in, pdf, prob, start, "indegree", out);
+}
+
 template <typename T>
 static int upload_vec(pk2_den_graph* g, const std::vector<T>& v, const T** dptr) {
   void* d = nullptr;
@@ -286,6 +405,21 @@ static int upload_vec(pk2_den_graph* g, const std::vector<T>& v, const T** dptr)
   g->allocs.push_back(d);
   if (!v.empty()) PK2_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   *dptr = static_cast<const T*>(d);
+  return PK2_OK;
+}
+
+static int upload_persist(pk2_den_graph* g, const HostPersist& h, DevPersist* d) {
+  if (!h.ok) return PK2_OK;
+  int rc;
+  if ((rc = upload_vec(g, h.prob, &d->prob))) return rc;
+  if ((rc = upload_vec(g, h.idx2, &d->idx2))) return rc;
+  if ((rc = upload_vec(g, h.ends, &d->ends))) return rc;
+  if ((rc = upload_vec(g, h.first_row, &d->first_row))) return rc;
+  if ((rc = upload_vec(g, h.wcrow, &d->wcrow))) return rc;
+  if ((rc = upload_vec(g, h.row_begin, &d->row_begin))) return rc;
+  if ((rc = upload_vec(g, h.grp_begin, &d->grp_begin))) return rc;
+  if ((rc = upload_vec(g, h.row_leak, &d->row_leak))) return rc;
+  d->max_rows = h.max_rows; d->max_groups = h.max_groups;
   return PK2_OK;
 }
 
@@ -316,6 +450,8 @@ int den_upload(pk2_den_graph* g) {
   if ((rc = upload_ordering(g, g->h_gam, &g->gam))) return rc;
   if ((rc = upload_ordering(g, g->h_fwdv, &g->fwdv))) return rc;
   if ((rc = upload_ordering(g, g->h_bwdv, &g->bwdv))) return rc;
+  if ((rc = upload_persist(g, g->h_pfwd, &g->pfwd))) return rc;
+  if ((rc = upload_persist(g, g->h_pbwd, &g->pbwd))) return rc;
   if ((rc = upload_vec(g, g->voff, &g->d_voff))) return rc;
   if ((rc = upload_vec(g, g->vpdf, &g->d_vpdf))) return rc;
   if ((rc = upload_vec(g, g->loop_pdf, &g->d_loop_pdf))) return rc;
@@ -442,5 +578,27 @@ extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, in
   if (loop_prob_out) memcpy(loop_prob_out, g->loop_prob.data(), g->loop_prob.size() * sizeof(float));
   if (ooff_out) memcpy(ooff_out, g->ooff.data(), g->ooff.size() * sizeof(int32_t));
   if (opdf_out) memcpy(opdf_out, g->opdf.data(), g->opdf.size() * sizeof(int32_t));
+  return PK2_OK;
+}
+
+// Test hook: the persistent kernel's layout of an ordering (which: 0 = forward, rows = virtual destination states;
+// 1 = backward, rows = source states).  info = {ok, max_rows, max_groups, workgroups, threads, slots per thread, waves,
+// rows}; the arrays (may be null) are sized from it: arcs [workgroups * slots * threads][2], ends / first_row
+// [workgroups * threads], wcrow [workgroups * waves], row_begin / grp_begin [workgroups + 1], row_leak [rows].
+extern "C" int pk2_den_graph_debug_persist(const pk2_den_graph* g, int which, int32_t* info, int32_t* arcs_out,
+                                           uint64_t* ends_out, int32_t* first_row_out, int32_t* wcrow_out,
+                                           int32_t* row_begin_out, int32_t* grp_begin_out, float* row_leak_out) {
+  PK2_REQUIRE(g && (which == 0 || which == 1) && info, "den graph debug: bad arguments");
+  const HostPersist& h = which == 0 ? g->h_pfwd : g->h_pbwd;
+  info[0] = h.ok ? 1 : 0; info[1] = h.max_rows; info[2] = h.max_groups;
+  info[3] = kPR; info[4] = kPT; info[5] = kPK; info[6] = kPW; info[7] = (int32_t)h.row_leak.size();
+  if (!h.ok) return PK2_OK;
+  if (arcs_out) memcpy(arcs_out, h.arcs.data(), h.arcs.size() * sizeof(int2));
+  if (ends_out) memcpy(ends_out, h.ends.data(), h.ends.size() * sizeof(uint64_t));
+  if (first_row_out) memcpy(first_row_out, h.first_row.data(), h.first_row.size() * sizeof(int32_t));
+  if (wcrow_out) memcpy(wcrow_out, h.wcrow.data(), h.wcrow.size() * sizeof(int32_t));
+  if (row_begin_out) memcpy(row_begin_out, h.row_begin.data(), h.row_begin.size() * sizeof(int32_t));
+  if (grp_begin_out) memcpy(grp_begin_out, h.grp_begin.data(), h.grp_begin.size() * sizeof(int32_t));
+  if (row_leak_out) memcpy(row_leak_out, h.row_leak.data(), h.row_leak.size() * sizeof(float));
   return PK2_OK;
 }

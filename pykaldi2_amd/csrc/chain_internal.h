@@ -65,6 +65,47 @@ struct DevOrdering {
   int n_chunks = 0;
 };
 
+// Layout of one arc ordering for the persistent denominator kernel (chain_den_persist.hip): the rows are dealt to the
+// kPR workgroups of a team (one per CU of an XCD) in contiguous ranges of whole groups (a group = the rows of one real
+// state), every workgroup keeps its <= kPSlots arc slots in registers for the whole call:
+//   thread `tid` of rank r owns the consecutive sorted slots tid*kPK .. tid*kPK + kPK-1 of the rank's list,
+//   arcs[(r*kPK + j)*kPT + tid] = {gathered index, probability bits}; a row without arcs has one null slot; on the device
+//   the probabilities are prob[(r*kPK + j)*kPT + tid] and the indices (< 32768: the LDS table) are packed two to a word,
+//   idx2[(r*kPK/2 + j/2)*kPT + tid] = idx(j even) | idx(j odd) << 16 -- 96 registers per thread instead of 128;
+//   bit j of ends[r*kPT + tid]: a row ends after the thread's slot j; first_row = rank-local row of its slot 0;
+//   wcrow[r*kPW + w]: rank-local row still open after the last slot of wave w (-1: none) -- the wave's carry-out is its.
+constexpr int kPR = 32;                 // workgroups of a team = CUs of an XCD
+constexpr int kPT = 512;                // threads of a workgroup: 2 waves per SIMD, 256 VGPRs each (the arcs take 128)
+constexpr int kPW = kPT / 64;
+constexpr int kPK = 64;                 // arc slots per thread
+constexpr int kPSlots = kPT * kPK;      // arc slots per workgroup
+constexpr int kPSPT = 4;                // states per thread in the row epilogues
+constexpr int kPMaxRows = kPSPT * kPT;  // rows, and groups, per workgroup
+struct HostPersist {
+  bool ok = false;                 // the graph fits (slots, rows per rank)
+  int max_rows = 0, max_groups = 0;
+  std::vector<int2> arcs;
+  std::vector<float> prob;         // device form of `arcs`
+  std::vector<uint32_t> idx2;
+  std::vector<uint64_t> ends;
+  std::vector<int32_t> first_row;
+  std::vector<int32_t> wcrow;
+  std::vector<int32_t> row_begin;  // [kPR+1] first row of a rank
+  std::vector<int32_t> grp_begin;  // [kPR+1] first group (real state) of a rank
+  std::vector<float> row_leak;     // [rows]   sum of pi[src]*prob over the arcs of a row
+};
+struct DevPersist {
+  const float* prob = nullptr;
+  const uint32_t* idx2 = nullptr;
+  const uint64_t* ends = nullptr;
+  const int32_t* first_row = nullptr;
+  const int32_t* wcrow = nullptr;
+  const int32_t* row_begin = nullptr;
+  const int32_t* grp_begin = nullptr;
+  const float* row_leak = nullptr;
+  int max_rows = 0, max_groups = 0;
+};
+
 }  // namespace pk2
 
 struct pk2_den_graph {
@@ -88,6 +129,8 @@ struct pk2_den_graph {
   std::vector<int32_t> ooff, opdf, ovirt; // [S+1], [Vo] pdf, [Vo] first virtual state of the occupancy state's state
   std::vector<int32_t> po_off, po_occ;    // occupancy states grouped by pdf (CSR over P)
   pk2::HostOrdering h_fwdv, h_bwdv;       // rows = virtual dst gathering src | rows = src gathering virtual dst
+  pk2::HostPersist h_pfwd, h_pbwd;        // the same two orderings for the persistent kernel
+  pk2::DevPersist pfwd, pbwd;
   const int32_t* d_voff = nullptr;
   const int32_t* d_vpdf = nullptr;
   const int32_t* d_loop_pdf = nullptr;
@@ -113,6 +156,7 @@ struct DenGeom {
   int G;       // number of groups
   int N;       // sequences
   int Tmax;
+  bool persist = false;   // NG = 1, one group per sequence, recursions by the persistent kernel (chain_den_persist.hip)
 };
 
 struct DenBuffers {
@@ -131,6 +175,7 @@ struct DenBuffers {
   int32_t* lengths;  // [G*NG] device copy (0 for the padding sequences)
   float* csum;    // [G][Tmax+1][2][NG]  {cu[t], sum_k pi[k] btilde'[t,k] / cu[t]}   (state-x path, chain_den.hip)
   float* kscale;  // [G][Tmax+1][NG]  beta[t] = kscale[t] * betahat[t] (state-x path)
+  float* xv;      // [G][Tmax][V]     exp(logit) per virtual state, compact (persistent kernel only)
 };
 
 int den_choose_ng(const pk2_den_graph* g);
