@@ -79,7 +79,7 @@ struct DenPersistParams {
   DevPersist fwd, bwd;
   const float* xv;        // [G][Tmax][V]
   float* ring;            // [8 * kMaxTeams][2][rpad]
-  float* pring;           // [8 * kMaxTeams][3][kPR][2]
+  float* pring;           // [8 * kMaxTeams][3][kPR][kPWords]
   int rpad;               // floats per ring slot and of the LDS table
   int cap;                // LDS row buffers
   int ntasks;
@@ -226,15 +226,17 @@ __device__ __forceinline__ Lds carve_lds(int rpad, int cap) {
   return L;
 }
 
-// Exchange.  A rank publishes its partial sums of a frame AFTER its slice of the state vector has reached L2, so "all
-// kPR partial sums valid" means the ring slot is complete.  ONE wave per workgroup polls (lane l: rank l % 32, sum l / 32;
-// 256 waves polling the same two cache lines made a frame wait ~9 us for a value that was already there), the others wait
-// at the barrier that follows; the totals travel through LDS (tot[0], tot[1]: the same bits in every thread).
-__device__ __forceinline__ void poll_partials(cgfloat* ps, bool two, Spin& spin, const Lds& L) {
+// Exchange.  Every rank owns four words per frame slot: {partial sum 0, partial sum 1, "slice ready", -}.  A rank
+// publishes a word AFTER the stores it announces have reached L2, so "the word of all kPR ranks is valid" means the data
+// is complete.  ONE wave per workgroup polls (lane l: rank l % 32, word first + l / 32; 256 waves polling the same cache
+// lines made a frame wait ~9 us for a value that was already there), the others wait at the barrier that follows; the
+// sums over the ranks travel through LDS (tot[0], tot[1]: the same bits in every thread).
+constexpr int kPWords = 4;
+__device__ __forceinline__ void poll_words(cgfloat* ps, int first, int nwords, Spin& spin, const Lds& L) {
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
-    const bool mine = two || lane < kPR;
-    cgfloat* src = ps + (lane & (kPR - 1)) * 2 + (lane >> 5);
+    const bool mine = (lane >> 5) < nwords;
+    cgfloat* src = ps + (lane & (kPR - 1)) * kPWords + first + (lane >> 5);
     float pv = mine ? ld_agent(src) : 0.f;
     bool ok = true;
     while (__ballot(mine && is_sentinel(pv)) != 0ull) {
@@ -245,6 +247,9 @@ __device__ __forceinline__ void poll_partials(cgfloat* ps, bool two, Spin& spin,
     const float a = wave_sum(lane < kPR ? pv : 0.f), b = wave_sum(lane < kPR ? 0.f : pv);
     if (lane == 0) { L.tot[0] = a; L.tot[1] = b; if (!ok) *L.abort = 1; }
   }
+}
+__device__ __forceinline__ gfloat* word_of(gfloat* pring, int frame, int rank, int word) {
+  return pring + (((frame % 3) * kPR + rank) * kPWords + word);
 }
 
 // Vector in global memory -> LDS table by LDS-DMA, 1 KB rows dealt to the waves round robin (complete vector; the
@@ -258,12 +263,6 @@ __device__ __forceinline__ void dma_table(cgfloat* src, int R, float* table) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Backward: entries of the table a thread transforms in place, (wave * kXN + i) * 64 + lane for i < kXN -- a wave owns
-// kXN consecutive 256-byte rows, entry i of a lane sits at the fixed byte offset i * 256 (immediate offsets: one address
-// register per 16 entries instead of one per entry); its x[t, .] values wait in registers (loaded at the end of the
-// previous frame).
-constexpr int kXN = 64;                 // table entries <= kXN * kPT
-
 // Row sums of the thread's kPK register-resident arcs over the LDS table: complete rows are stored by the lane, the
 // piece before the first row end gets the carry of the earlier lanes (segmented wave scan), the open tail of a wave goes
 // to wcarry and is added to its row by carry_fixup.
@@ -272,6 +271,9 @@ __device__ __forceinline__ void arc_rows(const float (&prob)[kPK], const uint32_
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float sum = 0.f;
   int c = frow;
+  // row-end bits, most significant first: `m + m` shifts the next one into the carry (one v_add_co per arc instead of a
+  // 64-bit shift, a mask and a compare)
+  unsigned m[2] = {__builtin_bitreverse32((unsigned)ends), __builtin_bitreverse32((unsigned)(ends >> 32))};
 #pragma unroll
   for (int j0 = 0; j0 < kPK; j0 += 8) {
     float a[8];
@@ -284,7 +286,8 @@ __device__ __forceinline__ void arc_rows(const float (&prob)[kPK], const uint32_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       sum = fmaf(a[j], prob[j0 + j], sum);
-      if ((ends >> (j0 + j)) & 1ull) { L.acc[c] = sum; ++c; sum = 0.f; }
+      unsigned& mm = m[(j0 + j) >> 5];
+      if (__builtin_add_overflow(mm, mm, &mm)) { L.acc[c] = sum; ++c; sum = 0.f; }
     }
   }
   float x[1] = {sum};
@@ -300,19 +303,14 @@ __device__ __forceinline__ void arc_rows(const float (&prob)[kPK], const uint32_
   if (lane == 63) L.wcarry[w] = x[0];
 }
 
-// The carry-outs of consecutive waves that belong to one row are added to it by the lane of the last of them.
-__device__ __forceinline__ void carry_fixup(const Lds& L) {
-  const int k = threadIdx.x;
-  if (k < kPW) {
-    const int row = L.wcrow[k];
-    if (row >= 0 && (k == kPW - 1 || L.wcrow[k + 1] != row)) {
-      int k0 = k;
-      while (k0 > 0 && L.wcrow[k0 - 1] == row) --k0;
-      float s = 0.f;
-      for (int q = k0; q <= k; ++q) s += L.wcarry[q];
-      L.acc[row] += s;
-    }
-  }
+// Value of rank-local row r after the arcs: the stored sum plus the carry-outs of the waves whose open tail belongs to
+// it (a row longer than a wave's 4096 slots collects several).
+__device__ __forceinline__ float row_sum(const Lds& L, int r) {
+  float v = L.acc[r];
+#pragma unroll
+  for (int k = 0; k < kPW; ++k)
+    if (L.wcrow[k] == r) v += L.wcarry[k];
+  return v;
 }
 
 template <int NW>
@@ -352,7 +350,6 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
   const int g0 = p.fwd.grp_begin[rank], ngrp = p.fwd.grp_begin[rank + 1] - g0;
   for (int r = tid; r < nrows; r += kPT) L.leak[r] = p.fwd.row_leak[row0 + r];
   if (tid < kPW) L.wcrow[tid] = p.fwd.wcrow[rank * kPW + tid];
-  if (tid <= kPR) L.rb[tid] = p.fwd.grp_begin[tid];            // the ring holds alpha per real state
   int st_lo[kPSPT], st_hi[kPSPT], st_o[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
 #pragma unroll
   for (int i = 0; i < kPSPT; ++i) {
@@ -365,8 +362,8 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       st_pl[i] = d.loop_prob[dd]; st_pi[i] = d.pi[dd];
     }
   }
-  // own partial-sum entries start as "not yet written"
-  if (tid < 3) st_agent(pring + (tid * kPR + rank) * 2, __uint_as_float(kRingSentinel));
+  // own words of the three frame slots start as "not yet written"
+  if (tid < 3 * kPWords) st_agent(pring + ((tid / kPWords) * kPR + rank) * kPWords + tid % kPWords, __uint_as_float(kRingSentinel));
   if (!team_barrier(ctl, team, nbar, L.abort)) return;
 
   const size_t f0 = (size_t)g * (d.Tmax + 1);
@@ -391,7 +388,7 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       for (int idx = tid; idx < S; idx += kPT) L.table[idx] = G(d.pi)[idx];
       as = d.pi_sum;
     } else {
-      poll_partials(pring + (size_t)(t % 3) * kPR * 2, false, spin, L);
+      poll_words(pring + (size_t)(t % 3) * kPR * kPWords, 0, 1, spin, L);
       __syncthreads();
       DP_TL(0, 1);
       if (*L.abort) return;
@@ -403,6 +400,10 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       const int r = tid + i * kPT;
       if (r < nrows) L.xown[r] = xr[i];
     }
+    // the word this rank will publish two frames from now must read "not yet written" by then: reset here, long before
+    // the stores it has to precede (the waits of the epilogue cover it)
+    const bool publish = t + 1 < T;
+    if (tid == 0 && publish) st_agent(word_of(pring, t + 2, rank, 0), __uint_as_float(kRingSentinel));
     dma_wait();
     DP_T(0);
     DP_TL(0, 2);
@@ -418,20 +419,17 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     DP_T(2);
     DP_TL(0, 4);
     __syncthreads();
-    carry_fixup(L);
-    __syncthreads();
     DP_T(3);
     // rows are virtual states (dst, pdf); a thread per real state sums its rows and adds the peeled self-loop.  First
     // only what the other workgroups wait for: the ring entries, then (once they are in L2) the partial sum.
     gfloat* ring_n = ring + (size_t)((t + 1) & 1) * p.rpad;
-    const bool publish = t + 1 < T;
     float outv[kPSPT], loopv[kPSPT], loc = 0.f, unused = 0.f;
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i) {
       outv[i] = 0.f; loopv[i] = 0.f;
       if (!st_ok[i]) continue;
       float sum = 0.f;
-      for (int q = st_lo[i]; q < st_hi[i]; ++q) sum += (L.acc[q] + lk * L.leak[q]) * L.xown[q] * inv_as;
+      for (int q = st_lo[i]; q < st_hi[i]; ++q) sum += (row_sum(L, q) + lk * L.leak[q]) * L.xown[q] * inv_as;
       if (st_pl[i] > 0.f) { loopv[i] = (own_a[i] + lk * st_pi[i]) * st_pl[i] * xlr[i] * inv_as; sum += loopv[i]; }
       if (publish) ring_store(ring_n + g0 + tid + i * kPT, sum);
       outv[i] = sum;
@@ -439,13 +437,9 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     }
     DP_T(4);
     DP_TL(0, 5);
-    wait_stores();        // this rank's slice of frame t+1 is in L2 before its partial sum says so
+    wait_stores();        // this rank's slice of frame t+1 (and the reset above) is in L2 before its partial sum says so
     block_sum2_1<kPW>(loc, unused, L.red);
-    if (tid == 0 && publish) {
-      st_agent(pring + (((t + 2) % 3) * kPR + rank) * 2, __uint_as_float(kRingSentinel));
-      wait_stores();      // the reset of the entry after next is in L2 before anybody can see this frame complete
-      st_agent(pring + (((t + 1) % 3) * kPR + rank) * 2, loc);
-    }
+    if (tid == 0 && publish) st_agent(word_of(pring, t + 1, rank, 0), loc);
     DP_T(5);
     DP_TL(0, 6);
     // the history the parallel passes read (nobody waits for these stores)
@@ -457,7 +451,7 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       if (!st_ok[i]) continue;
       alpha_n[g0 + tid + i * kPT] = outv[i];
       if (sep) {
-        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = (L.acc[q] + lk * L.leak[q]) * L.xown[q] * inv_as;
+        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = (row_sum(L, q) + lk * L.leak[q]) * L.xown[q] * inv_as;
         if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
       }
     }
@@ -467,7 +461,12 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
   DP_FLUSH(0);
 }
 
-// btilde' recursion of sequence g: den_beta_frame_sx<1> frame by frame, T-1 down to 0.
+// btilde' recursion of sequence g: den_beta_frame_sx<1> frame by frame, T-1 down to 0.  What a frame gathers is
+//   w[t+1][v] = x[t, pdf(v)] * (btilde'[t+1, state(v)] / c[t+1] + leaky term of frame t+1)   per virtual state v,
+// and it is the PRODUCER of btilde'[t+1, .] that scales its slice (it needs x only for its own ~V/32 virtual states; a
+// consumer-side transform would have every workgroup read all of x[t, .]: 120 KB more per frame and CU, and 64 more live
+// registers per thread).  The scaling needs the frame's sums over all states, so a frame has two exchanges: the partial
+// sums (words 0, 1), then the slice of w (word 2 = ready).
 __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
                                      unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
   CParams* pp = uni(pp_);
@@ -488,6 +487,7 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
   const uint64_t ends = p.bwd.ends[(size_t)rank * kPT + tid];
   const int frow = p.bwd.first_row[(size_t)rank * kPT + tid];
   const int row0 = p.bwd.row_begin[rank], nrows = p.bwd.row_begin[rank + 1] - row0;
+  const int vfirst = d.voff[row0], nvirt = d.voff[row0 + nrows] - vfirst;     // own virtual states: a contiguous range
   if (tid < kPW) L.wcrow[tid] = p.bwd.wcrow[rank * kPW + tid];
   int st_v0[kPSPT], st_v1[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
 #pragma unroll
@@ -497,66 +497,50 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     st_v0[i] = st_v1[i] = 0; st_pl[i] = st_pi[i] = 0.f;
     if (st_ok[i]) {
       const int s = row0 + r;
-      st_v0[i] = d.voff[s]; st_v1[i] = d.voff[s + 1]; st_pl[i] = d.loop_prob[s]; st_pi[i] = d.pi[s];
+      st_v0[i] = d.voff[s] - vfirst; st_v1[i] = d.voff[s + 1] - vfirst; st_pl[i] = d.loop_prob[s]; st_pi[i] = d.pi[s];
     }
   }
-  if (tid < 6) st_agent(pring + ((tid >> 1) * kPR + rank) * 2 + (tid & 1), __uint_as_float(kRingSentinel));
+  if (tid < 3 * kPWords) st_agent(pring + ((tid / kPWords) * kPR + rank) * kPWords + tid % kPWords, __uint_as_float(kRingSentinel));
   if (!team_barrier(ctl, team, nbar, L.abort)) return;
 
   const size_t f0 = (size_t)g * (d.Tmax + 1);
   cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
   cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
-  float xlr[kPSPT], prevb[kPSPT];
+  float xlr[kPSPT], xw[kPSPT], bh[kPSPT];        // x of own loops (frame t), x of own virtual states (frame t-1), beta-hat[t+1]
+  const float cst_last = 1.0f / d.pi_sum + d.leaky;
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) prevb[i] = 0.f;
+  for (int i = 0; i < kPSPT; ++i) bh[i] = cst_last;
   auto prefetch = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + tid + i * kPT] : 0.f;
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
+      xw[i] = (t > 0 && r < nvirt) ? xv_g[(size_t)(t - 1) * V + vfirst + r] : 0.f;
+    }
   };
   prefetch(T - 1);
   Spin spin(ctl);
-  const float cst_last = 1.0f / d.pi_sum + d.leaky;
-  // x[t, .] of the frame about to run waits in registers (loaded at the end of the previous frame, behind the partial sums
-  // and the history stores); the table itself receives btilde'[t+1, .] by DMA and is transformed in place.
-  // (whole 64-entry rows: the table, the ring slots and the x plane are padded to them, so a row is valid or not for the
-  // whole wave -- a scalar test -- and nothing per entry has to be kept in, or spilled from, registers)
-  float xq[kXN];
-  const int xrows = (V + 63) >> 6;
-  const int xrow0 = (tid >> 6) * kXN, xlane = tid & 63;
-  auto load_x = [&](int t) {
-    cgfloat* xsrc = xv_g + (size_t)t * V + (size_t)xrow0 * 64 + xlane;
-#pragma unroll
-    for (int i = 0; i < kXN; ++i)
-      if (xrow0 + i < xrows) xq[i] = xsrc[i * 64];
-  };
-  load_x(T - 1);
   DP_T0();
   for (int t = T - 1; t >= 0; --t) {
     const bool gat = t + 1 < T;
-    float inv_c = 0.f, lkr = 0.f;
     DP_TL(1, 0);
-    if (!gat) {
-      float* tl = L.table + xrow0 * 64 + xlane;
-#pragma unroll
-      for (int i = 0; i < kXN; ++i)
-        if (xrow0 + i < xrows) tl[i * 64] = xq[i] * cst_last;
+    if (!gat) {          // w[T] = x[T-1, .] * (1 / sum(pi) + leaky): straight from the exp table
+      for (int idx = tid; idx < V; idx += kPT) L.table[idx] = xv_g[(size_t)t * V + idx] * cst_last;
     } else {
-      poll_partials(pring + (size_t)((t + 1) % 3) * kPR * 2, true, spin, L);
+      poll_words(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 2, 1, spin, L);
       __syncthreads();
       DP_TL(1, 1);
       if (*L.abort) return;
-      const float lB = L.tot[0], lU = L.tot[1];
-      const float cu = lB + d.wu * lU;
-      inv_c = cu > 0.f ? 1.0f / cu : 0.f;
-      lkr = d.leaky * lB * inv_c;
       dma_table(ring + (size_t)((t + 1) & 1) * p.rpad, V, L.table);
-      dma_wait();
-      __syncthreads();
-      float* tl = L.table + xrow0 * 64 + xlane;
-#pragma unroll
-      for (int i = 0; i < kXN; ++i)
-        if (xrow0 + i < xrows) tl[i * 64] = xq[i] * (tl[i * 64] * inv_c + lkr);
     }
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      if (r < nvirt) L.xown[r] = xw[i];
+    }
+    const bool publish = t > 0;
+    if (tid < 3 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
+    dma_wait();
     DP_T(0);
     DP_TL(1, 2);
     __syncthreads();
@@ -566,46 +550,57 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     DP_T(2);
     DP_TL(1, 4);
     __syncthreads();
-    carry_fixup(L);
-    __syncthreads();
     DP_T(3);
-    // rows are source states; btilde'[t, s] goes into the ring entry and the record of every virtual state of s
-    gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad;
-    const bool publish = t > 0;
-    float loc = 0.f, locu = 0.f;
+    // rows are source states: btilde'[t, s] = row + peeled loop; its sums over the states go out first
+    float vs[kPSPT], loc = 0.f, locu = 0.f;
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i) {
+      vs[i] = 0.f;
       if (!st_ok[i]) continue;
-      float v = L.acc[tid + i * kPT];
-      if (st_pl[i] > 0.f) v += st_pl[i] * xlr[i] * (gat ? prevb[i] * inv_c + lkr : cst_last);
+      float v = row_sum(L, tid + i * kPT);
+      if (st_pl[i] > 0.f) v += st_pl[i] * xlr[i] * bh[i];
       loc += st_pi[i] * v; locu += v;
-      if (publish)
-        for (int q = st_v0[i]; q < st_v1[i]; ++q) ring_store(ring_n + q, v);
-      prevb[i] = v;
+      vs[i] = v;
+    }
+    block_sum2_1<kPW>(loc, locu, L.red);
+    if (tid < 2 && publish) {
+      wait_stores();      // (the reset above)
+      st_agent(word_of(pring, t, rank, tid), tid == 0 ? loc : locu);
     }
     DP_T(4);
     DP_TL(1, 5);
-    wait_stores();
-    block_sum2_1<kPW>(loc, locu, L.red);
-    if (tid == 0 && publish) {
-      st_agent(pring + (((t + 2) % 3) * kPR + rank) * 2, __uint_as_float(kRingSentinel));
-      st_agent(pring + (((t + 2) % 3) * kPR + rank) * 2 + 1, __uint_as_float(kRingSentinel));
-      wait_stores();
-      st_agent(pring + ((t % 3) * kPR + rank) * 2, loc);
-      st_agent(pring + ((t % 3) * kPR + rank) * 2 + 1, locu);
-    }
-    DP_T(5);
-    DP_TL(1, 6);
+    // history for the parallel passes (the occupancy pass reads btilde' of a state from its first virtual state: ovirt)
     gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
     if (tid == 0) {
       G(d.bpart)[((f0 + t) * kPR + rank) * 2] = loc;
       G(d.bpart)[((f0 + t) * kPR + rank) * 2 + 1] = locu;
     }
-    // (the occupancy pass reads btilde' of a state from the record of its FIRST virtual state: ovirt)
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i)
-      if (st_ok[i]) bx_t[(size_t)st_v0[i] * 2] = prevb[i];
-    if (publish) { prefetch(t - 1); load_x(t - 1); }
+      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
+    if (publish) {
+      // second exchange: with the sums of frame t, this rank's slice of w[t] for frame t-1
+      poll_words(pring + (size_t)(t % 3) * kPR * kPWords, 0, 2, spin, L);
+      __syncthreads();
+      if (*L.abort) return;
+      const float lB = L.tot[0], lU = L.tot[1];
+      const float cu = lB + d.wu * lU;
+      const float inv_c = cu > 0.f ? 1.0f / cu : 0.f;
+      const float lkr = d.leaky * lB * inv_c;
+      gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad + vfirst;
+#pragma unroll
+      for (int i = 0; i < kPSPT; ++i) {
+        if (!st_ok[i]) continue;
+        bh[i] = vs[i] * inv_c + lkr;
+        for (int q = st_v0[i]; q < st_v1[i]; ++q) ring_store(ring_n + q, L.xown[q] * bh[i]);
+      }
+      wait_stores();
+      __syncthreads();
+      if (tid == 0) st_agent(word_of(pring, t, rank, 2), 1.0f);
+      DP_T(5);
+      DP_TL(1, 6);
+      prefetch(t - 1);
+    }
     DP_T(6);
   }
   DP_FLUSH(1);
@@ -632,7 +627,7 @@ __global__ void __launch_bounds__(kPT) den_persist_kernel(const DenPersistParams
   DenPersistCtl::Team* team = &ctl->team[s_xcd][s_team];
   const size_t ti = (size_t)s_xcd * kMaxTeams + s_team;
   float* ring = p.ring + ti * 2 * p.rpad;
-  float* pring = p.pring + ti * 3 * kPR * 2;
+  float* pring = p.pring + ti * 3 * kPR * kPWords;
   unsigned nbar = 0;
   for (int iter = 0; iter <= kMaxTasks; ++iter) {
     if (tid == 0) {
@@ -683,14 +678,14 @@ static std::map<hipStream_t, DenPersistScratch> g_den_scratch;
 
 static int den_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 63) / 64 * 64; }
 static int den_cap(const pk2_den_graph* g) {
-  return (std::max({g->h_pfwd.max_rows, g->h_pfwd.max_groups, g->h_pbwd.max_rows, 1}) + 3) / 4 * 4;
+  return (std::max({g->h_pfwd.max_rows, g->h_pfwd.max_groups, g->h_pbwd.max_rows, g->h_pbwd.max_groups, 1}) + 3) / 4 * 4;
 }
 size_t den_persist_lds_bytes(const pk2_den_graph* g) {
   return ((size_t)den_rpad(g) + 3 * (size_t)den_cap(g) + 3 * kPW + 4 + kLdsTailInts) * sizeof(float);
 }
 
 bool den_persist_fits(const pk2_den_graph* g) {
-  return g->h_pfwd.ok && g->h_pbwd.ok && den_persist_lds_bytes(g) <= kDenPersistMaxLds && den_rpad(g) <= kXN * kPT;
+  return g->h_pfwd.ok && g->h_pbwd.ok && den_persist_lds_bytes(g) <= kDenPersistMaxLds;
 }
 
 bool den_persist_wanted(const pk2_den_graph* g, int N) {
@@ -714,7 +709,7 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, c
   const int rpad = den_rpad(g);
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(DenPersistCtl)));
   if (!sc.params) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.params), sizeof(DenPersistParams)));
-  if (!sc.pring) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.pring), (size_t)8 * kMaxTeams * 3 * kPR * 2 * sizeof(float)));
+  if (!sc.pring) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.pring), (size_t)8 * kMaxTeams * 3 * kPR * kPWords * sizeof(float)));
   if (sc.rpad < rpad) {
     if (sc.ring) PK2_HIP(hipFree(sc.ring));
     sc.ring = nullptr; sc.rpad = 0;

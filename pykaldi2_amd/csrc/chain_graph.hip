@@ -371,6 +371,12 @@ static int build_graph_ordered(int32_t S, int32_t P, int64_t A, const int32_t* s
                    true, true);
     build_persist(A2, g->V, arc_v.data(), src2.data(), prob2.data(), piprob2.data(), vstate.data(), S, &g->h_pfwd);
     build_persist(A2, S, src2.data(), arc_v.data(), prob2.data(), piprob2.data(), nullptr, S, &g->h_pbwd);
+    if (g->h_pbwd.ok) {     // the backward workgroups also stage x for their own virtual states: max_groups = how many
+      g->h_pbwd.max_groups = 0;
+      for (int r = 0; r < kPR; ++r)
+        g->h_pbwd.max_groups = std::max(g->h_pbwd.max_groups, g->voff[g->h_pbwd.row_begin[r + 1]] - g->voff[g->h_pbwd.row_begin[r]]);
+      if (g->h_pbwd.max_groups > kPMaxRows) g->h_pbwd.ok = false;
+    }
     g->po_off.assign(P + 1, 0);
     for (int o = 0; o < g->Vo; ++o) if (g->opdf[o] >= 0) g->po_off[g->opdf[o] + 1]++;
     for (int p = 0; p < P; ++p) g->po_off[p + 1] += g->po_off[p];
