@@ -79,7 +79,7 @@ class DenominatorGraph:
         """Layout of an ordering for the persistent kernel (test hook): which = 0 forward, 1 backward; None when the
         graph does not fit it."""
         L = _lib.lib()
-        info = np.zeros(8, dtype=np.int32)
+        info = np.zeros(9, dtype=np.int32)
         _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), None, None, None, None, None, None, None))
         if not info[0]:
             return None
@@ -90,7 +90,7 @@ class DenominatorGraph:
                    row_leak=np.empty(rows, dtype=np.float32))
         _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), *[_lib.ptr(out[k]) for k in
                    ("arcs", "ends", "first_row", "wcrow", "row_begin", "grp_begin", "row_leak")]))
-        out.update(max_rows=int(info[1]), max_groups=int(info[2]))
+        out.update(max_rows=int(info[1]), max_groups=int(info[2]), estep=int(info[8]))
         return out
 
     def debug_ordering(self, which):

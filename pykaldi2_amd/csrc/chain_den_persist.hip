@@ -265,29 +265,42 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 
 // Row sums of the thread's kPK register-resident arcs over the LDS table: complete rows are stored by the lane, the
 // piece before the first row end gets the carry of the earlier lanes (segmented wave scan), the open tail of a wave goes
-// to wcarry and is added to its row by carry_fixup.
+// to wcarry and is added to its row by row_sum.  ESTEP (chain_internal.h: HostPersist::estep): rows end only after slots
+// ESTEP-1 (mod ESTEP), so the row-end code exists at 64/ESTEP places.  The gathers of the next 8 slots are in flight while
+// 8 slots are accumulated.
+template <int ESTEP>
 __device__ __forceinline__ void arc_rows(const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint64_t ends, int frow,
                                          const Lds& L) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float sum = 0.f;
   int c = frow;
-  // row-end bits, most significant first: `m + m` shifts the next one into the carry (one v_add_co per arc instead of a
-  // 64-bit shift, a mask and a compare)
-  unsigned m[2] = {__builtin_bitreverse32((unsigned)ends), __builtin_bitreverse32((unsigned)(ends >> 32))};
+  // the row-end bits of the possible places, most significant first: `m + m` shifts the next one into the carry (one
+  // v_add_co per place instead of a 64-bit shift, a mask and a compare)
+  uint64_t packed = 0;
 #pragma unroll
-  for (int j0 = 0; j0 < kPK; j0 += 8) {
-    float a[8];
+  for (int k = 0; k < kPK / ESTEP; ++k) packed |= ((ends >> (k * ESTEP + ESTEP - 1)) & 1ull) << k;
+  unsigned m[2] = {__builtin_bitreverse32((unsigned)packed), __builtin_bitreverse32((unsigned)(packed >> 32))};
+  auto gather = [&](int j0, float (&a)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t pk = idx2[(j0 + j) >> 1];
       const uint32_t byte_off = (j & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
       a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L.table) + byte_off);
     }
+  };
+  float a[2][8];
+  gather(0, a[0]);
+#pragma unroll
+  for (int g = 0; g < kPK / 8; ++g) {
+    if (g + 1 < kPK / 8) gather(8 * (g + 1), a[(g + 1) & 1]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      sum = fmaf(a[j], prob[j0 + j], sum);
-      unsigned& mm = m[(j0 + j) >> 5];
-      if (__builtin_add_overflow(mm, mm, &mm)) { L.acc[c] = sum; ++c; sum = 0.f; }
+      const int jj = 8 * g + j;
+      sum = fmaf(a[g & 1][j], prob[jj], sum);
+      if ((jj + 1) % ESTEP == 0) {
+        unsigned& mm = m[(jj / ESTEP) >> 5];
+        if (__builtin_add_overflow(mm, mm, &mm)) { L.acc[c] = sum; ++c; sum = 0.f; }
+      }
     }
   }
   float x[1] = {sum};
@@ -301,6 +314,15 @@ __device__ __forceinline__ void arc_rows(const float (&prob)[kPK], const uint32_
   const float cin = dpp_f<0x138, 0xf>(x[0]);     // wave_shr:1 -- lane 0 receives 0
   if (ends != 0ull) L.acc[frow] += cin;            // the lane's own first row end (stored above by this lane)
   if (lane == 63) L.wcarry[w] = x[0];
+}
+__device__ __forceinline__ void arc_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint64_t ends,
+                                             int frow, const Lds& L) {
+  switch (estep) {
+    case 8: arc_rows<8>(prob, idx2, ends, frow, L); break;
+    case 4: arc_rows<4>(prob, idx2, ends, frow, L); break;
+    case 2: arc_rows<2>(prob, idx2, ends, frow, L); break;
+    default: arc_rows<1>(prob, idx2, ends, frow, L); break;
+  }
 }
 
 // Value of rank-local row r after the arcs: the stored sum plus the carry-outs of the waves whose open tail belongs to
@@ -415,7 +437,7 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     float own_a[kPSPT];
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i) own_a[i] = st_ok[i] ? L.table[g0 + tid + i * kPT] : 0.f;
-    arc_rows(prob, idx2, ends, frow, L);
+    arc_rows_any(p.fwd.estep, prob, idx2, ends, frow, L);
     DP_T(2);
     DP_TL(0, 4);
     __syncthreads();
@@ -546,7 +568,7 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     __syncthreads();
     DP_T(1);
     DP_TL(1, 3);
-    arc_rows(prob, idx2, ends, frow, L);
+    arc_rows_any(p.bwd.estep, prob, idx2, ends, frow, L);
     DP_T(2);
     DP_TL(1, 4);
     __syncthreads();

@@ -154,9 +154,16 @@ static void build_ordering(int64_t A, int num_rows, const int32_t* key, const in
 
 // Persistent-kernel layout of one ordering (chain_internal.h: HostPersist).  `key` = row of an arc, `idx` = what it
 // gathers, `group_of_row` (monotone, may be null: every row its own group) = the real state a row belongs to.
-static void build_persist(int64_t A, int num_rows, const int32_t* key, const int32_t* idx, const float* prob,
-                          const float* piprob, const int32_t* group_of_row, int num_groups, HostPersist* out) {
+//  * `estep`: every row is padded with null slots to a multiple of estep slots, so a row can only end at the slots
+//    j = estep-1 (mod estep) of a thread: the kernel runs its row-end code (an exec-masked LDS store and three VALU
+//    operations) at 64/estep places per thread instead of 64.  Costs slots: the caller takes the largest step that fits.
+//  * the arcs of a row that sit in one thread are dealt to its slots so that, for every slot index j, the 32 lanes of a
+//    half wave gather from as many different LDS banks as possible (ds_read_b32: a half wave per cycle, bank = index
+//    mod 32; random indices cost ~3.5 cycles per half wave).
+static bool build_persist_step(int64_t A, int num_rows, const int32_t* key, const int32_t* idx, const float* prob,
+                               const float* piprob, const int32_t* group_of_row, int num_groups, int estep, HostPersist* out) {
   *out = HostPersist();
+  out->estep = estep;
   std::vector<int64_t> ptr(num_rows + 1, 0);
   for (int64_t i = 0; i < A; ++i) ptr[key[i] + 1]++;
   for (int r = 0; r < num_rows; ++r) ptr[r + 1] += ptr[r];
@@ -165,7 +172,7 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
     std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
     for (int64_t i = 0; i < A; ++i) perm[cur[key[i]]++] = i;
   }
-  auto slots_of = [&](int r) { return std::max<int64_t>(1, ptr[r + 1] - ptr[r]); };
+  auto slots_of = [&](int r) { return (std::max<int64_t>(1, ptr[r + 1] - ptr[r]) + estep - 1) / estep * estep; };
   // rows of each group
   std::vector<int32_t> grow(num_groups + 1, 0);
   if (group_of_row) {
@@ -174,7 +181,7 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
   } else {
     for (int g = 0; g <= num_groups; ++g) grow[g] = g;
   }
-  if (grow[num_groups] != num_rows) return;
+  if (grow[num_groups] != num_rows) return false;
   std::vector<int64_t> gslots(num_groups, 0);
   int64_t total = 0;
   for (int g = 0; g < num_groups; ++g) {
@@ -200,13 +207,16 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
     out->max_rows = std::max(out->max_rows, rows);
     out->max_groups = std::max(out->max_groups, groups);
   }
-  if (g < num_groups) return;             // does not fit: the launch-per-frame kernels serve this graph
+  if (g < num_groups) return false;       // does not fit
   out->arcs.assign((size_t)kPR * kPSlots, make_int2(0, 0));
   out->ends.assign((size_t)kPR * kPT, 0ull);
   out->first_row.assign((size_t)kPR * kPT, 0);
   out->wcrow.assign((size_t)kPR * kPW, -1);
   out->row_leak.assign(num_rows, 0.f);
   std::vector<int32_t> srow; std::vector<int64_t> sarc; std::vector<char> send;
+  std::vector<int32_t> sidx;              // gathered index of a slot after the bank-aware deal (nulls get one too)
+  std::vector<int32_t> load((size_t)2 * kPK * 32);
+  std::vector<int64_t> cand;
   for (int r = 0; r < kPR; ++r) {
     const int row0 = out->row_begin[r], row1 = out->row_begin[r + 1];
     srow.clear(); sarc.clear(); send.clear();
@@ -214,16 +224,53 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
       double leak = 0.0;
       for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) { srow.push_back(q - row0); sarc.push_back(perm[k]); send.push_back(0); leak += (double)piprob[perm[k]]; }
       if (ptr[q] == ptr[q + 1]) { srow.push_back(q - row0); sarc.push_back(-1); send.push_back(0); }
+      while (srow.size() % estep) { srow.push_back(q - row0); sarc.push_back(-1); send.push_back(0); }
       send.back() = 1;
       out->row_leak[q] = (float)leak;
     }
     const int64_t n = (int64_t)srow.size();
+    // bank-aware deal: inside a thread, the slots of one row are interchangeable
+    sidx.assign(n, 0);
+    for (int64_t wbase = 0; wbase < n; wbase += (int64_t)64 * kPK) {
+      std::fill(load.begin(), load.end(), 0);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int half = lane >> 5;
+        int64_t s = wbase + (int64_t)lane * kPK;
+        const int64_t lane_end = std::min<int64_t>(n, s + kPK);
+        while (s < lane_end) {
+          int64_t e = s;
+          while (e < lane_end && srow[e] == srow[s]) ++e;
+          cand.assign(sarc.begin() + s, sarc.begin() + e);      // arcs (and nulls, -1) of this segment
+          for (int64_t pos = s; pos < e; ++pos) {
+            const int j = (int)(pos % kPK);
+            int32_t* ld = &load[((size_t)half * kPK + j) * 32];
+            size_t best = 0; int best_load = 1 << 30;
+            for (size_t c = 0; c < cand.size(); ++c) {
+              const int l = cand[c] < 0 ? -1 : ld[idx[cand[c]] & 31];     // a null slot goes wherever it is free
+              if (l < best_load) { best_load = l; best = c; }
+            }
+            const int64_t a = cand[best];
+            cand[best] = cand.back(); cand.pop_back();
+            sarc[pos] = a;
+            if (a >= 0) {
+              sidx[pos] = idx[a];
+            } else {
+              int bank = 0;
+              for (int b2 = 1; b2 < 32; ++b2) if (ld[b2] < ld[bank]) bank = b2;
+              sidx[pos] = bank;               // any valid entry: its probability is 0
+            }
+            ld[sidx[pos] & 31]++;
+          }
+          s = e;
+        }
+      }
+    }
     for (int tid = 0; tid < kPT; ++tid) {
       uint64_t e = 0;
       for (int j = 0; j < kPK; ++j) {
         const int64_t s = (int64_t)tid * kPK + j;
         if (s >= n) break;
-        if (sarc[s] >= 0) out->arcs[((size_t)r * kPK + j) * kPT + tid] = make_int2(idx[sarc[s]], __builtin_bit_cast(int, prob[sarc[s]]));
+        out->arcs[((size_t)r * kPK + j) * kPT + tid] = make_int2(sidx[s], sarc[s] >= 0 ? __builtin_bit_cast(int, prob[sarc[s]]) : 0);
         if (send[s]) e |= 1ull << j;
       }
       out->ends[(size_t)r * kPT + tid] = e;
@@ -238,7 +285,7 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
   // device form: probabilities and 16-bit indices apart
   int max_idx = 0;
   for (const int2& a : out->arcs) max_idx = std::max(max_idx, a.x);
-  if (max_idx >= 65536) return;
+  if (max_idx >= 65536) return false;
   out->prob.resize(out->arcs.size());
   out->idx2.assign(out->arcs.size() / 2, 0u);
   for (int r = 0; r < kPR; ++r)
@@ -249,6 +296,18 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
         out->idx2[((size_t)r * (kPK / 2) + j / 2) * kPT + tid] |= (uint32_t)a.x << (16 * (j & 1));
       }
   out->ok = true;
+  return true;
+}
+
+static void build_persist(int64_t A, int num_rows, const int32_t* key, const int32_t* idx, const float* prob,
+                          const float* piprob, const int32_t* group_of_row, int num_groups, HostPersist* out) {
+  const char* env = getenv("PK2_DEN_ESTEP");
+  const int forced = env ? atoi(env) : 0;
+  for (int estep : {8, 4, 2, 1}) {
+    if (forced > 0 && estep != forced) continue;
+    if (build_persist_step(A, num_rows, key, idx, prob, piprob, group_of_row, num_groups, estep, out)) return;
+  }
+  *out = HostPersist();
 }
 
 static int build_graph_ordered(int32_t S, int32_t P, int64_t A, const int32_t* src_in, const int32_t* dst_in,
@@ -425,7 +484,7 @@ static int upload_persist(pk2_den_graph* g, const HostPersist& h, DevPersist* d)
   if ((rc = upload_vec(g, h.row_begin, &d->row_begin))) return rc;
   if ((rc = upload_vec(g, h.grp_begin, &d->grp_begin))) return rc;
   if ((rc = upload_vec(g, h.row_leak, &d->row_leak))) return rc;
-  d->max_rows = h.max_rows; d->max_groups = h.max_groups;
+  d->max_rows = h.max_rows; d->max_groups = h.max_groups; d->estep = h.estep;
   return PK2_OK;
 }
 
@@ -589,7 +648,7 @@ extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, in
 
 // Test hook: the persistent kernel's layout of an ordering (which: 0 = forward, rows = virtual destination states;
 // 1 = backward, rows = source states).  info = {ok, max_rows, max_groups, workgroups, threads, slots per thread, waves,
-// rows}; the arrays (may be null) are sized from it: arcs [workgroups * slots * threads][2], ends / first_row
+// rows, estep}; the arrays (may be null) are sized from it: arcs [workgroups * slots * threads][2], ends / first_row
 // [workgroups * threads], wcrow [workgroups * waves], row_begin / grp_begin [workgroups + 1], row_leak [rows].
 extern "C" int pk2_den_graph_debug_persist(const pk2_den_graph* g, int which, int32_t* info, int32_t* arcs_out,
                                            uint64_t* ends_out, int32_t* first_row_out, int32_t* wcrow_out,
@@ -597,7 +656,7 @@ extern "C" int pk2_den_graph_debug_persist(const pk2_den_graph* g, int which, in
   PK2_REQUIRE(g && (which == 0 || which == 1) && info, "den graph debug: bad arguments");
   const HostPersist& h = which == 0 ? g->h_pfwd : g->h_pbwd;
   info[0] = h.ok ? 1 : 0; info[1] = h.max_rows; info[2] = h.max_groups;
-  info[3] = kPR; info[4] = kPT; info[5] = kPK; info[6] = kPW; info[7] = (int32_t)h.row_leak.size();
+  info[3] = kPR; info[4] = kPT; info[5] = kPK; info[6] = kPW; info[7] = (int32_t)h.row_leak.size(); info[8] = h.estep;
   if (!h.ok) return PK2_OK;
   if (arcs_out) memcpy(arcs_out, h.arcs.data(), h.arcs.size() * sizeof(int2));
   if (ends_out) memcpy(ends_out, h.ends.data(), h.ends.size() * sizeof(uint64_t));

@@ -84,6 +84,7 @@ constexpr int kPMaxRows = kPSPT * kPT;  // rows, and groups, per workgroup
 struct HostPersist {
   bool ok = false;                 // the graph fits (slots, rows per rank)
   int max_rows = 0, max_groups = 0;
+  int estep = 1;                   // rows end only at slots j = estep-1 (mod estep) of a thread
   std::vector<int2> arcs;
   std::vector<float> prob;         // device form of `arcs`
   std::vector<uint32_t> idx2;
@@ -104,6 +105,7 @@ struct DevPersist {
   const int32_t* grp_begin = nullptr;
   const float* row_leak = nullptr;
   int max_rows = 0, max_groups = 0;
+  int estep = 1;
 };
 
 }  // namespace pk2
