@@ -326,12 +326,18 @@ __device__ __forceinline__ void arc_rows_any(int estep, const float (&prob)[kPK]
 }
 
 // Value of rank-local row r after the arcs: the stored sum plus the carry-outs of the waves whose open tail belongs to
-// it (a row longer than a wave's 4096 slots collects several).
-__device__ __forceinline__ float row_sum(const Lds& L, int r) {
+// it (a row longer than a wave's 4096 slots collects several).  The targets (wcr, at most kPW rows of the workgroup) are
+// per-task constants in scalar registers; a frame's carries are read from LDS once per thread.
+struct Carries { int row[kPW]; float val[kPW]; };
+__device__ __forceinline__ void load_carries(const Lds& L, Carries& c) {
+#pragma unroll
+  for (int k = 0; k < kPW; ++k) c.val[k] = c.row[k] >= 0 ? L.wcarry[k] : 0.f;
+}
+__device__ __forceinline__ float row_sum(const Lds& L, const Carries& c, int r) {
   float v = L.acc[r];
 #pragma unroll
   for (int k = 0; k < kPW; ++k)
-    if (L.wcrow[k] == r) v += L.wcarry[k];
+    if (c.row[k] >= 0 && c.row[k] == r) v += c.val[k];
   return v;
 }
 
@@ -371,7 +377,9 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
   const int row0 = p.fwd.row_begin[rank], nrows = p.fwd.row_begin[rank + 1] - row0;
   const int g0 = p.fwd.grp_begin[rank], ngrp = p.fwd.grp_begin[rank + 1] - g0;
   for (int r = tid; r < nrows; r += kPT) L.leak[r] = p.fwd.row_leak[row0 + r];
-  if (tid < kPW) L.wcrow[tid] = p.fwd.wcrow[rank * kPW + tid];
+  Carries cr;
+#pragma unroll
+  for (int k = 0; k < kPW; ++k) cr.row[k] = p.fwd.wcrow[rank * kPW + k];
   int st_lo[kPSPT], st_hi[kPSPT], st_o[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
 #pragma unroll
   for (int i = 0; i < kPSPT; ++i) {
@@ -441,6 +449,7 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     DP_T(2);
     DP_TL(0, 4);
     __syncthreads();
+    load_carries(L, cr);
     DP_T(3);
     // rows are virtual states (dst, pdf); a thread per real state sums its rows and adds the peeled self-loop.  First
     // only what the other workgroups wait for: the ring entries, then (once they are in L2) the partial sum.
@@ -451,7 +460,11 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       outv[i] = 0.f; loopv[i] = 0.f;
       if (!st_ok[i]) continue;
       float sum = 0.f;
-      for (int q = st_lo[i]; q < st_hi[i]; ++q) sum += (row_sum(L, q) + lk * L.leak[q]) * L.xown[q] * inv_as;
+      for (int q = st_lo[i]; q < st_hi[i]; ++q) {
+        const float v = (row_sum(L, cr, q) + lk * L.leak[q]) * L.xown[q] * inv_as;
+        L.acc[q] = v;          // (the row belongs to this thread alone: kept for the history stores below)
+        sum += v;
+      }
       if (st_pl[i] > 0.f) { loopv[i] = (own_a[i] + lk * st_pi[i]) * st_pl[i] * xlr[i] * inv_as; sum += loopv[i]; }
       if (publish) ring_store(ring_n + g0 + tid + i * kPT, sum);
       outv[i] = sum;
@@ -473,7 +486,7 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       if (!st_ok[i]) continue;
       alpha_n[g0 + tid + i * kPT] = outv[i];
       if (sep) {
-        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = (row_sum(L, q) + lk * L.leak[q]) * L.xown[q] * inv_as;
+        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = L.acc[q];
         if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
       }
     }
@@ -510,7 +523,9 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
   const int frow = p.bwd.first_row[(size_t)rank * kPT + tid];
   const int row0 = p.bwd.row_begin[rank], nrows = p.bwd.row_begin[rank + 1] - row0;
   const int vfirst = d.voff[row0], nvirt = d.voff[row0 + nrows] - vfirst;     // own virtual states: a contiguous range
-  if (tid < kPW) L.wcrow[tid] = p.bwd.wcrow[rank * kPW + tid];
+  Carries cr;
+#pragma unroll
+  for (int k = 0; k < kPW; ++k) cr.row[k] = p.bwd.wcrow[rank * kPW + k];
   int st_v0[kPSPT], st_v1[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
 #pragma unroll
   for (int i = 0; i < kPSPT; ++i) {
@@ -572,6 +587,7 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     DP_T(2);
     DP_TL(1, 4);
     __syncthreads();
+    load_carries(L, cr);
     DP_T(3);
     // rows are source states: btilde'[t, s] = row + peeled loop; its sums over the states go out first
     float vs[kPSPT], loc = 0.f, locu = 0.f;
@@ -579,7 +595,7 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     for (int i = 0; i < kPSPT; ++i) {
       vs[i] = 0.f;
       if (!st_ok[i]) continue;
-      float v = row_sum(L, tid + i * kPT);
+      float v = row_sum(L, cr, tid + i * kPT);
       if (st_pl[i] > 0.f) v += st_pl[i] * xlr[i] * bh[i];
       loc += st_pi[i] * v; locu += v;
       vs[i] = v;
@@ -591,15 +607,6 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     }
     DP_T(4);
     DP_TL(1, 5);
-    // history for the parallel passes (the occupancy pass reads btilde' of a state from its first virtual state: ovirt)
-    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
-    if (tid == 0) {
-      G(d.bpart)[((f0 + t) * kPR + rank) * 2] = loc;
-      G(d.bpart)[((f0 + t) * kPR + rank) * 2 + 1] = locu;
-    }
-#pragma unroll
-    for (int i = 0; i < kPSPT; ++i)
-      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
     if (publish) {
       // second exchange: with the sums of frame t, this rank's slice of w[t] for frame t-1
       poll_words(pring + (size_t)(t % 3) * kPR * kPWords, 0, 2, spin, L);
@@ -623,6 +630,16 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       DP_TL(1, 6);
       prefetch(t - 1);
     }
+    // history for the parallel passes, after everything another workgroup waits for (the occupancy pass reads btilde' of
+    // a state from its first virtual state: ovirt)
+    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
+    if (tid == 0) {
+      G(d.bpart)[((f0 + t) * kPR + rank) * 2] = loc;
+      G(d.bpart)[((f0 + t) * kPR + rank) * 2 + 1] = locu;
+    }
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i)
+      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
     DP_T(6);
   }
   DP_FLUSH(1);
