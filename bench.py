@@ -168,8 +168,10 @@ def den_roofline(den, dev, reps=5):
         pass
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                 traffic=traffic, traffic_note=traffic_note,
-                kernel="pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; forward frame t and "
-                "backward frame Tmax-1-t share a launch)",
+                kernel={2: "pk2::den_persist_kernel (one launch per denominator call: the alpha and beta recursions of the 4 "
+                           "sequences, one per XCD, arcs in registers, state vector in LDS) + the parallel exp / occupancy passes",
+                        1: "pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; forward frame t and "
+                           "backward frame Tmax-1-t share a launch)"}.get(den.kernel_path(len(lens)), "pk2::den_fwd_step / den_bwd_step x Tmax"),
                 workload="4 sequences of %s frames, %s den graph (%d states, %d arcs, %d pdfs)" % (lens, DEN_TOPOLOGY, S, A, P),
                 ms_per_launch=round(ms, 3), algorithmic_bytes=byts,
                 us_per_frame=round(1e3 * ms / Tmax, 2),

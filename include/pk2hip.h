@@ -57,6 +57,11 @@ int pk2_den_graph_info(const pk2_den_graph* g, int32_t* num_states, int32_t* num
 /* Copies initial_probs (num_states floats) to a host buffer. */
 int pk2_den_graph_initial_probs(const pk2_den_graph* g, float* host_out);
 
+/* Which kernels a denominator call on num_seqs sequences takes on the current device: 0 = per-arc-pdf kernels,
+ * 1 = state-x kernels, one launch per frame, 2 = state-x, persistent recursion kernel (one launch per call).  Reporting
+ * only; the choice is the library's (reference: kaldi.chain.DenominatorComputation behind ops/ops.py:265). */
+int32_t pk2_den_graph_path(const pk2_den_graph* g, int32_t num_seqs);
+
 /* ------------------------------------------------------------------ *
  * LF-MMI objective and derivative for a minibatch of N sequences.
  * Replaces kaldi.chain.compute_chain_objf_and_deriv (reference ops/ops.py:265)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pk2_den_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "pk2_den_graph_initial_probs": (C.c_int, [_vp, _vp]),
     "pk2_den_graph_arcs_per_lane": (_i32, []),
+    "pk2_den_graph_path": (_i32, [_vp, _i32]),
     "pk2_den_graph_debug_ordering": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i32), _vp, _vp,
                                                _vp, _vp, _vp, _vp]),
     "pk2_den_graph_debug_virtual": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp,

@@ -75,6 +75,10 @@ class DenominatorGraph:
         _lib.check(_lib.lib().pk2_den_graph_initial_probs(self._h, _lib.ptr(out)))
         return out
 
+    def kernel_path(self, num_seqs):
+        """0 = per-arc-pdf kernels, 1 = state-x kernels (a launch per frame), 2 = persistent recursion kernel."""
+        return int(_lib.lib().pk2_den_graph_path(self._h, int(num_seqs)))
+
     def debug_persist(self, which):
         """Layout of an ordering for the persistent kernel (test hook): which = 0 forward, 1 backward; None when the
         graph does not fit it."""

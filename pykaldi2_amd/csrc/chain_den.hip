@@ -1589,3 +1589,11 @@ extern "C" int pk2_chain_den_fwd_bwd(const pk2_den_graph* gc, const float* logit
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
+
+// Which kernels a denominator call on `num_seqs` sequences takes: 0 = general (per-arc pdf), 1 = state-x, a launch per
+// frame, 2 = state-x, persistent recursion kernel (chain_den_persist.hip).  Reporting hook (bench.py).
+extern "C" int32_t pk2_den_graph_path(const pk2_den_graph* g, int32_t num_seqs) {
+  if (!g) return -1;
+  if (!pk2::den_use_sx(g)) return 0;
+  return pk2::den_persist_wanted(g, num_seqs) ? 2 : 1;
+}

@@ -187,6 +187,99 @@ def test_den_graph_virtual_state_orderings(case, monkeypatch):
     assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
 
 
+def _emulate_persist(lay, table):
+    """numpy model of arc_rows + row_sum of chain_den_persist.hip: the value of every row of an ordering."""
+    R_, K, T, _ = lay["arcs"].shape
+    W = T // 64
+    out = np.zeros(lay["row_begin"][-1])
+    for r in range(R_):
+        row0, row1 = lay["row_begin"][r], lay["row_begin"][r + 1]
+        acc = np.full(max(row1 - row0, 1), np.nan)
+        idx = lay["arcs"][r, :, :, 0]
+        prob = lay["arcs"][r, :, :, 1].copy().view(np.float32).astype(np.float64)
+        tails, has_end = np.zeros(T), np.zeros(T, bool)
+        for tid in range(T):
+            e, c, s = int(lay["ends"][r, tid]), int(lay["first_row"][r, tid]), 0.0
+            assert all((j + 1) % lay["estep"] == 0 for j in range(K) if (e >> j) & 1)     # rows end only at the aligned slots
+            for j in range(K):
+                s += table[idx[j, tid]] * prob[j, tid]
+                if (e >> j) & 1:
+                    acc[c] = s; c += 1; s = 0.0
+            tails[tid], has_end[tid] = s, e != 0
+        wcarry = np.zeros(W)
+        for w in range(W):          # segmented scan over the lanes of a wave: the open tails reach the next row end
+            x = 0.0
+            for lane in range(64):
+                tid = w * 64 + lane
+                if has_end[tid]:
+                    acc[lay["first_row"][r, tid]] += x
+                    x = tails[tid]
+                else:
+                    x += tails[tid]
+            wcarry[w] = x
+        for k in range(W):          # what is still open at the end of a wave belongs to row wcrow
+            if lay["wcrow"][r, k] >= 0:
+                acc[lay["wcrow"][r, k]] += wcarry[k]
+        out[row0:row1] = acc[:row1 - row0]
+    return out
+
+
+@pytest.mark.parametrize("case", ["chain_topology", "multi_entry", "bigstate", "no_peel"])
+@pytest.mark.parametrize("estep", [0, 1, 4])
+def test_den_graph_persistent_layouts(case, estep, monkeypatch):
+    """The persistent kernel's layouts (chain_internal.h: HostPersist): 32 workgroups x 512 threads x 64 register-resident
+    arc slots, rows ending only at aligned slots, wave carries.  A numpy model of the kernel's row sums over these tables
+    reproduces alpha[d] = sum_arcs alpha[src] prob x[pdf] and beta[s] = sum_arcs prob x[pdf] beta[dst] -- including a state
+    whose 30000 entering arcs span several waves."""
+    S, A, P, seed = 300, 6000, 23, 7
+    kw = dict(chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_pdf_differs=True, multi_entry_frac=0.3),
+              bigstate=dict(loop_pdf_differs=True), no_peel=dict(loop_pdf_differs=True))[case]
+    monkeypatch.setenv("PK2_DEN_ORDER", "none")
+    if estep:
+        monkeypatch.setenv("PK2_DEN_ESTEP", str(estep))
+    if case == "no_peel":
+        monkeypatch.setenv("PK2_DEN_PEEL", "0")
+    if case == "bigstate":
+        S, A = 200, 40000
+    g = synth.den_graph_arcs(S, A, P, seed, **kw)
+    if case == "bigstate":
+        g["dst"][:30000] = 5
+        g["pdf"][:20000] = 1; g["pdf"][20000:28000] = 2; g["pdf"][28000:30000] = 3
+    G = chain.DenominatorGraph(g, P)
+    of = G.debug_ordering(3)
+    voff, vpdf, lpdf, lprob = of["voff"], of["vpdf"], of["loop_pdf"], of["loop_prob"].astype(np.float64)
+    S_, V = g["num_states"], len(of["vpdf"])
+    vstate = np.repeat(np.arange(S_), np.diff(voff))
+    rng = np.random.default_rng(1)
+    al, be, x = rng.random(S_), rng.random(S_), rng.random(P)
+    xv = np.where(vpdf >= 0, x[np.maximum(vpdf, 0)], 1.0)
+    xl = np.where(lpdf >= 0, x[np.maximum(lpdf, 0)], 1.0)
+    src, dst, pdf, prob = g["src"], g["dst"], g["pdf"], g["prob"].astype(np.float64)
+    pf, pb = G.debug_persist(0), G.debug_persist(1)
+    assert pf is not None and pb is not None
+    if estep:
+        assert pf["estep"] == estep and pb["estep"] == estep
+    else:
+        assert pf["estep"] == 8       # small graphs leave room for the widest alignment
+    assert pf["grp_begin"][-1] == S_ and pf["row_begin"][-1] == V and pb["row_begin"][-1] == S_
+    assert (np.diff(pf["grp_begin"]) >= 0).all() and (voff[pf["grp_begin"]] == pf["row_begin"]).all()   # whole states per workgroup
+    rows = _emulate_persist(pf, al)
+    got = np.bincount(vstate, weights=rows * xv, minlength=S_) + al * lprob * xl
+    assert np.abs(got - np.bincount(dst, weights=al[src] * prob * x[pdf], minlength=S_)).max() < 1e-9
+    pi = G.initial_probs().astype(np.float64)
+    keep = np.ones(len(src), bool)
+    if case != "no_peel":
+        seen = set()
+        for i in np.flatnonzero(src == dst):
+            if int(src[i]) not in seen:
+                seen.add(int(src[i])); keep[i] = False
+    want_leak = np.zeros(S_)
+    np.add.at(want_leak, dst[keep], pi[src[keep]] * prob[keep])
+    assert np.abs(np.bincount(vstate, weights=pf["row_leak"], minlength=S_) - want_leak).max() < 1e-6
+    got = _emulate_persist(pb, be[vstate] * xv) + lprob * xl * be
+    assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
+
+
 def test_den_graph_internal_state_order_is_invisible():
     """By default the library renumbers the states by in-degree (gather locality); initial_probs() still answers in the
     caller's numbering."""

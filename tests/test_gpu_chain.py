@@ -1,5 +1,7 @@
 """HIP LF-MMI kernels against the CPU oracle (through the C ABI).  Tolerances: objective 1e-3 rel
 (north star), occupancies / gradient 1e-4 abs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,7 +23,7 @@ _KIND = dict(chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_p
 
 
 @pytest.mark.parametrize("path", ["state_x", "general_forced", "arc_pdf", "chain_topology", "multi_entry", "arc_pdf_sx_forced",
-                                  "chain_topology_general"])
+                                  "chain_topology_general", "state_x_frames", "chain_topology_frames", "multi_entry_frames"])
 @pytest.mark.parametrize("S,A,P,lens,leaky", [
     (8, 30, 5, [6], 1e-2),
     (200, 3000, 40, [51, 17, 33], 1e-4),
@@ -42,14 +44,20 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
         monkeypatch.setenv("PK2_DEN_MODE", "general")
     if path == "arc_pdf_sx_forced":
         monkeypatch.setenv("PK2_DEN_MODE", "sx")
+    frames = path.endswith("_frames")       # the launch-per-frame state-x kernels (the default is the persistent kernel)
+    if frames:
+        monkeypatch.setenv("PK2_DEN_PERSIST", "0")
     arc_pdf = path.startswith("arc_pdf")
-    g, G, ref = _mk(S, A, P, seed=S, arc_pdf=arc_pdf, **_KIND.get(path.replace("_general", ""), {}))
+    g, G, ref = _mk(S, A, P, seed=S, arc_pdf=arc_pdf, **_KIND.get(path.replace("_general", "").replace("_frames", ""), {}))
     if A == 20000:
         g["dst"][:6000] = 5
         if not arc_pdf:
             g["pdf"][:6000] = g["pdf"][0]
         G = chain.DenominatorGraph(g, P)
         ref = R.DenGraphRef(g["num_states"], g["src"], g["dst"], g["pdf"], g["prob"], 0, P)
+    if not arc_pdf:             # (a random pdf per arc: the library decides by the number of virtual states)
+        want_path = 0 if path in ("general_forced", "chain_topology_general") else (1 if frames else 2)
+        assert G.kernel_path(len(lens)) == want_path, (path, G.kernel_path(len(lens)))
     rng = np.random.default_rng(1)
     T = max(lens)
     lg = rng.normal(0, 3, size=(len(lens), T, P)).astype(np.float32)
@@ -151,6 +159,34 @@ def test_reference_operator_convention_and_nan_guard():
     bad = lg.copy(); bad[3, 5] = np.nan
     out, grad = chain.compute_chain_objf_and_deriv(opts, G, [sup], torch.from_numpy(bad).cuda().unsqueeze(0))
     assert out[0, 0].item() == -10.0 * T and not grad.any().item()
+
+
+def test_persistent_kernel_more_recursions_than_teams():
+    """9 ragged sequences (18 recursions for the 8 teams of the persistent kernel: every team takes several from the
+    queue, the ring buffers are reused), lengths down to 1, against the oracle and against the launch-per-frame kernels."""
+    S, A, P = 500, 12000, 50
+    g, G, ref = _mk(S, A, P, seed=4, **_KIND["multi_entry"])
+    lens = [37, 1, 22, 60, 2, 45, 13, 60, 30]
+    assert G.kernel_path(len(lens)) == 2
+    rng = np.random.default_rng(3)
+    lg = rng.normal(0, 2, size=(len(lens), max(lens), P)).astype(np.float32)
+    x = torch.from_numpy(lg).cuda()
+    lp, gamma = chain.den_forward_backward(G, x, lens, 1e-3)
+    lp2, gamma2 = chain.den_forward_backward(G, x, lens, 1e-3)
+    assert torch.equal(lp, lp2) and torch.equal(gamma, gamma2)          # no order-dependent arithmetic
+    lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, _ = R.den_forward_backward(lg[n, :Tn].astype(np.float64), ref, 1e-3)
+        assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp) + 1e-4, (n, lp[n], want_lp)
+        assert np.abs(gamma[n, :Tn] - want_g).max() < 1e-4
+        assert not gamma[n, Tn:].any()
+    os.environ["PK2_DEN_PERSIST"] = "0"
+    try:
+        lp_f, gamma_f = chain.den_forward_backward(G, x, lens, 1e-3)
+    finally:
+        del os.environ["PK2_DEN_PERSIST"]
+    assert np.abs(lp_f.cpu().numpy() - lp).max() <= 1e-4 * np.abs(lp).max()
+    assert np.abs(gamma_f.cpu().numpy() - gamma).max() < 1e-5
 
 
 @pytest.mark.parametrize("kind", ["unique", "chain_topology"])
