@@ -234,30 +234,35 @@ def cpu_baseline_worker(seed, threads):
     pi = chain_ref.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
                                      g["prob"].astype(np.float64), 0)
     rng = np.random.default_rng(seed)
-    host = synth.minibatch(rng, 4, P, ali_model=chain_model()[2])
-    seconds = sum(w.shape[0] for w, _ in host) / 16000.0
+    ali_model = chain_model()[2]
     torch.manual_seed(0)
     rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
     lin = torch.nn.Linear(1024, P)
     params = list(rnn.parameters()) + list(lin.parameters())
     opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True)
     mel = fbank.mel_filterbank()
-    t0 = time.time()
-    feats = [frontend_ref.cmn(frontend_ref.logfbank(w, mel)).astype(np.float32) for w, _ in host]
-    x = torch.from_numpy(frontend_ref.pad_roll_subsample(feats, 0, 3).copy())
-    logits = lin(rnn(x)[0])
-    sups = build_supervisions([a for _, a in host])
-    out, grad = chain_c.chain_batch(g, pi, logits.detach().numpy(), sups, 1e-4, 0.1)
-    opt.zero_grad()
-    logits.backward(torch.from_numpy(-grad))
-    torch.nn.utils.clip_grad_norm_(params, 5.0)
-    opt.step()
-    dt = time.time() - t0
+    # a bounded sample of the same workload: whole training steps until ~12 s of host work are done (at most 8 minibatches)
+    seconds, dt, steps = 0.0, 0.0, 0
+    while steps < 8 and dt < 12.0:
+        host = synth.minibatch(rng, 4, P, ali_model=ali_model)
+        t0 = time.time()
+        feats = [frontend_ref.cmn(frontend_ref.logfbank(w, mel)).astype(np.float32) for w, _ in host]
+        x = torch.from_numpy(frontend_ref.pad_roll_subsample(feats, 0, 3).copy())
+        logits = lin(rnn(x)[0])
+        sups = build_supervisions([a for _, a in host])
+        out, grad = chain_c.chain_batch(g, pi, logits.detach().numpy(), sups, 1e-4, 0.1)
+        opt.zero_grad()
+        logits.backward(torch.from_numpy(-grad))
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        dt += time.time() - t0
+        seconds += sum(w.shape[0] for w, _ in host) / 16000.0
+        steps += 1
     print(json.dumps(dict(value=round(seconds / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
                           kind="port",
-                          sample="1 minibatch of 4 utterances (%.1f s audio): numpy fbank oracle + torch CPU 3x512 "
+                          sample="%d minibatches of 4 utterances (%.1f s audio): numpy fbank oracle + torch CPU 3x512 "
                                  "BLSTM fwd/bwd + C port of the LF-MMI objective (OpenMP over sequences) + Adam; "
-                                 "%.1f s wall on %d threads" % (seconds, dt, threads))), flush=True)
+                                 "%.1f s wall on %d threads" % (steps, seconds, dt, threads))), flush=True)
 
 
 def cpu_ce_worker(threads):
