@@ -339,6 +339,21 @@ int pk2_softmax_mask_fwd(float* scores, const float* src_mask, const uint8_t* ke
                          int32_t T, void* stream);
 /* dP <- P * (dP - rowsum(dP * P)), in place. */
 int pk2_softmax_bwd(const float* P, float* dP, int32_t BH, int32_t T, void* stream);
+
+/* Fused multi-head self-attention (head size 64): ctx = softmax(Q K^T * scale + src_mask, padded keys -> -inf) V, read
+ * from / written to the packed time-major projections qkv[T*B][3*H*64] (row = t*B + b; Q | K | V) and ctx[T*B][H*64];
+ * lse[B*H][T] = log-sum-exp of every score row, kept for the backward pass; dropout on the probabilities with the
+ * counter-based mask of pk2_dropout_f32 indexed as a [B*H][T][T] matrix.  The scores never reach HBM.  Replaces the
+ * scaled-dot-product core of nn.MultiheadAttention under nn.TransformerEncoderLayer (reference
+ * models/transformer.py:52-67); PK2_ERR_INVALID for other head sizes (callers keep the batched-GEMM form for those). */
+int pk2_attention_fwd(const float* qkv, int32_t T, int32_t B, int32_t H, int32_t head_dim, float scale,
+                      const float* src_mask, const uint8_t* key_padding, float dropout_p, uint64_t seed, float* ctx,
+                      float* lse, void* stream);
+/* Gradient of the above by recomputation: dqkv[T*B][3*H*64] (every element written) from qkv, ctx, d ctx and lse;
+ * dsum[B*H][T] is scratch (rowsum(dctx * ctx)). */
+int pk2_attention_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int32_t T, int32_t B,
+                      int32_t H, int32_t head_dim, float scale, const float* src_mask, const uint8_t* key_padding,
+                      float dropout_p, uint64_t seed, float* dqkv, float* dsum, void* stream);
 int pk2_relu_fwd(float* x, int64_t n, void* stream);                 /* in place */
 int pk2_relu_bwd(const float* y, float* dy, int64_t n, void* stream); /* dy <- dy * (y > 0) */
 int pk2_add_inplace(float* a, const float* b, int64_t n, void* stream);

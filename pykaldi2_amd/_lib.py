@@ -107,6 +107,9 @@ SIGNATURES = {
     "pk2_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "pk2_softmax_mask_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pk2_softmax_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "pk2_attention_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _f32, C.c_uint64, _vp, _vp, _vp]),
+    "pk2_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _f32, C.c_uint64, _vp,
+                                    _vp, _vp]),
     "pk2_relu_fwd": (C.c_int, [_vp, _i64, _vp]),
     "pk2_relu_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pk2_add_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),

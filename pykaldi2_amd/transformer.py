@@ -12,11 +12,13 @@ methods is used**.  ``forward(x[T,B,D], src_mask, src_key_padding_mask) -> [T,B,
     -> ReLU ] -> LayerNorm -> Linear(C->P);  positional encoding disabled (models/transformer.py:90).
 
 Arithmetic: f32 MFMA GEMMs (`pk2_gemm_f32`, batched per (utterance, head) for QK^T and PV), masked
-softmax, LayerNorm(+residual), ReLU, counter-based dropout -- all HIP kernels of libpk2hip.so.  The
-attention is the unfused form (scores materialised in HBM); a fused flash-style kernel is future work.
+softmax, LayerNorm(+residual), ReLU, counter-based dropout -- all HIP kernels of libpk2hip.so.  With head size 64
+(the reference's 512 / 8) the attention core is the fused kernel of csrc/attention.hip (scores never reach HBM, backward
+by recomputation); other head sizes, or PK2_ATTN_FUSED=0, take the batched-GEMM form with the scores in HBM.
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -72,6 +74,23 @@ def _seed():
     return int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFFFFFF
 
 
+def _attention_bwd_unfused(L, sp, new, s, qkv, dcx, dqkv, T, B, C, H, d, drop):
+    """Batched-GEMM form: dP = dctx V^T ; dV = Pd^T dctx ; dS = softmax'(P, dP) ; dQ = a dS K ; dK = a dS^T Q."""
+    dP = new(B * H, T, T)
+    _bgemm(0, 1, T, T, d, 1.0, _p(dcx), B * C, C, d, _p(qkv, 2 * C), B * 3 * C, 3 * C, d, 0.0, _p(dP), T,
+           H * T * T, T * T, B, H)
+    _bgemm(1, 0, T, d, T, 1.0, _p(s["Pd"]), T, H * T * T, T * T, _p(dcx), B * C, C, d, 0.0,
+           _p(dqkv, 2 * C), B * 3 * C, 3 * C, d, B, H)
+    if drop > 0:
+        _dropout(dP, drop, s["seed_attn"], dP)
+    _lib.check(L.pk2_softmax_bwd(_p(s["P"]), _p(dP), B * H, T, sp))
+    sc = 1.0 / math.sqrt(d)
+    _bgemm(0, 0, T, d, T, sc, _p(dP), T, H * T * T, T * T, _p(qkv, C), B * 3 * C, 3 * C, d, 0.0,
+           _p(dqkv), B * 3 * C, 3 * C, d, B, H)
+    _bgemm(1, 0, T, d, T, sc, _p(dP), T, H * T * T, T * T, _p(qkv), B * 3 * C, 3 * C, d, 0.0,
+           _p(dqkv, C), B * 3 * C, 3 * C, d, B, H)
+
+
 class _TransformerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, src_mask, key_pad, *params):
@@ -85,6 +104,8 @@ class _TransformerFunction(torch.autograd.Function):
         dev = x.device
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         drop = m.dropout if m.training else 0.0
+        fused = d == 64 and os.environ.get("PK2_ATTN_FUSED", "1") != "0"
+        ctx.fused, ctx.masks = fused, (src_mask, key_pad)
         x = x.contiguous()
         h = new(R, C)
         _gemm(0, 1, R, C, Din, _p(x), Din, _p(m.input_layer.weight), Din, _p(h), C, bias=_p(m.input_layer.bias))
@@ -95,16 +116,24 @@ class _TransformerFunction(torch.autograd.Function):
             s = dict(h_in=h)
             qkv = new(R, 3 * C)
             _gemm(0, 1, R, 3 * C, C, _p(h), C, _p(a.in_proj_weight), C, _p(qkv), 3 * C, bias=_p(a.in_proj_bias))
-            Pm = new(B * H, T, T)
-            _bgemm(0, 1, T, T, d, 1.0 / math.sqrt(d), _p(qkv), B * 3 * C, 3 * C, d, _p(qkv, C), B * 3 * C, 3 * C, d,
-                   0.0, _p(Pm), T, H * T * T, T * T, B, H)
-            _lib.check(L.pk2_softmax_mask_fwd(_p(Pm), _p(src_mask) if src_mask is not None else None,
-                                              _p(key_pad) if key_pad is not None else None, B, H, T, sp))
             s["seed_attn"] = _seed() if drop > 0 else None
-            Pd = _dropout(Pm, drop, s["seed_attn"]) if drop > 0 else Pm
             cx = new(R, C)
-            _bgemm(0, 0, T, d, T, 1.0, _p(Pd), T, H * T * T, T * T, _p(qkv, 2 * C), B * 3 * C, 3 * C, d, 0.0,
-                   _p(cx), B * C, C, d, B, H)
+            Pm = Pd = lse = None
+            if fused:
+                lse = new(B * H, T)
+                _lib.check(L.pk2_attention_fwd(_p(qkv), T, B, H, d, 1.0 / math.sqrt(d),
+                                               _p(src_mask) if src_mask is not None else None,
+                                               _p(key_pad) if key_pad is not None else None, float(drop),
+                                               s["seed_attn"] or 0, _p(cx), _p(lse), sp))
+            else:
+                Pm = new(B * H, T, T)
+                _bgemm(0, 1, T, T, d, 1.0 / math.sqrt(d), _p(qkv), B * 3 * C, 3 * C, d, _p(qkv, C), B * 3 * C, 3 * C, d,
+                       0.0, _p(Pm), T, H * T * T, T * T, B, H)
+                _lib.check(L.pk2_softmax_mask_fwd(_p(Pm), _p(src_mask) if src_mask is not None else None,
+                                                  _p(key_pad) if key_pad is not None else None, B, H, T, sp))
+                Pd = _dropout(Pm, drop, s["seed_attn"]) if drop > 0 else Pm
+                _bgemm(0, 0, T, d, T, 1.0, _p(Pd), T, H * T * T, T * T, _p(qkv, 2 * C), B * 3 * C, 3 * C, d, 0.0,
+                       _p(cx), B * C, C, d, B, H)
             ao = new(R, C)
             _gemm(0, 1, R, C, C, _p(cx), C, _p(a.out_proj.weight), C, _p(ao), C, bias=_p(a.out_proj.bias))
             s["seed1"] = _seed() if drop > 0 else None
@@ -134,7 +163,7 @@ class _TransformerFunction(torch.autograd.Function):
                 _gemm(0, 1, R - B, C, C, _p(x2), C, _p(Wp, 0), C, _p(y, B * C), C, beta=1.0)
                 _gemm(0, 1, R - B, C, C, _p(x2, B * C), C, _p(Wp, 2 * C * C), C, _p(y), C, beta=1.0)
             _lib.check(L.pk2_relu_fwd(_p(y), y.numel(), sp))
-            s.update(qkv=qkv, P=Pm, Pd=Pd, cx=cx, s1=s1, x1=x1, mu1=mu1, rs1=rs1, f1=f1, f1d=f1d, s2=s2, x2=x2,
+            s.update(qkv=qkv, P=Pm, Pd=Pd, lse=lse, cx=cx, s1=s1, x1=x1, mu1=mu1, rs1=rs1, f1=f1, f1d=f1d, s2=s2, x2=x2,
                      mu2=mu2, rs2=rs2, Wp=Wp, y=y)
             saved.append(s)
             h = y
@@ -229,19 +258,14 @@ class _TransformerFunction(torch.autograd.Function):
             # attention: dP = dctx V^T ; dV = Pd^T dctx ; dS = softmax'(P, dP) ; dQ = a dS K ; dK = a dS^T Q
             qkv = s["qkv"]
             dqkv = new(R, 3 * C)
-            dP = new(B * H, T, T)
-            _bgemm(0, 1, T, T, d, 1.0, _p(dcx), B * C, C, d, _p(qkv, 2 * C), B * 3 * C, 3 * C, d, 0.0, _p(dP), T,
-                   H * T * T, T * T, B, H)
-            _bgemm(1, 0, T, d, T, 1.0, _p(s["Pd"]), T, H * T * T, T * T, _p(dcx), B * C, C, d, 0.0,
-                   _p(dqkv, 2 * C), B * 3 * C, 3 * C, d, B, H)
-            if drop > 0:
-                _dropout(dP, drop, s["seed_attn"], dP)
-            _lib.check(L.pk2_softmax_bwd(_p(s["P"]), _p(dP), B * H, T, sp))
-            sc = 1.0 / math.sqrt(d)
-            _bgemm(0, 0, T, d, T, sc, _p(dP), T, H * T * T, T * T, _p(qkv, C), B * 3 * C, 3 * C, d, 0.0,
-                   _p(dqkv), B * 3 * C, 3 * C, d, B, H)
-            _bgemm(1, 0, T, d, T, sc, _p(dP), T, H * T * T, T * T, _p(qkv), B * 3 * C, 3 * C, d, 0.0,
-                   _p(dqkv, C), B * 3 * C, 3 * C, d, B, H)
+            if ctx.fused:
+                src_mask, key_pad = ctx.masks
+                _lib.check(L.pk2_attention_bwd(_p(qkv), _p(s["cx"]), _p(dcx), _p(s["lse"]), T, B, H, d, 1.0 / math.sqrt(d),
+                                               _p(src_mask) if src_mask is not None else None,
+                                               _p(key_pad) if key_pad is not None else None, float(drop),
+                                               s["seed_attn"] or 0, _p(dqkv), _p(new(B * H, T)), sp))
+            else:
+                _attention_bwd_unfused(L, sp, new, s, qkv, dcx, dqkv, T, B, C, H, d, drop)
             lin_grads(dqkv, s["h_in"], C, 3 * C, pre + "encoder_layer.self_attn.in_proj_weight",
                       pre + "encoder_layer.self_attn.in_proj_bias")
             dh = ds1 if drop == 0 else ds1     # residual branch of the attention block

@@ -61,6 +61,40 @@ def test_transformer_matches_torch_cpu(cfg):
         assert e < 5e-4 * max(1e-2, rg.abs().max().item()), (name, e, rg.abs().max().item())
 
 
+@pytest.mark.parametrize("T,B,look,drop", [(77, 3, 5, 0.0), (77, 3, 5, 0.1), (32, 1, -1, 0.0), (130, 2, -1, 0.2)])
+def test_fused_attention_equals_the_batched_gemm_form(T, B, look, drop, monkeypatch):
+    """Head size 64: csrc/attention.hip (scores in registers, backward by recomputation, probabilities dropped with the
+    counter-based mask indexed like the [B*H][T][T] matrix) against the unfused form with the same seeds: outputs and
+    every parameter gradient; T not a multiple of the 32-wide tiles, look-ahead mask, padded keys."""
+    C, H = 128, 2
+
+    def run(fused):
+        monkeypatch.setenv("PK2_ATTN_FUSED", "1" if fused else "0")
+        torch.manual_seed(3)
+        m = transformer.TransformerAM(24, C, H, 256, 2, drop, 19).cuda().train()
+        x = torch.randn(T, B, 24, device="cuda")
+        kpm = torch.zeros(B, T, dtype=torch.bool, device="cuda")
+        for i in range(1, B):
+            kpm[i, T - 3 * i:] = True
+        src_mask = None
+        if look > -1:
+            tri = torch.tril(torch.ones(T, T), diagonal=look)
+            src_mask = tri.float().masked_fill(tri == 0, float("-inf")).masked_fill(tri == 1, 0.0).cuda()
+        torch.manual_seed(11)            # the dropout seeds are drawn from torch's generator
+        y = m(x, src_mask, kpm)
+        w = torch.randn(T, B, 19, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        (y * w).sum().backward()
+        return y.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.isfinite(y1).all()
+    assert (y1 - y0).abs().max().item() < 2e-5 * max(1.0, y0.abs().max().item())
+    for n in g0:
+        e = (g1[n] - g0[n]).abs().max().item()
+        assert e < 1e-4 * max(1e-2, g0[n].abs().max().item()), (n, e, g0[n].abs().max().item())
+
+
 def test_transformer_state_dict_keys_and_init_follow_torch():
     torch.manual_seed(3)
     m = transformer.TransformerAM(80, 512, 8, 2048, 2, 0.1, 5768)
