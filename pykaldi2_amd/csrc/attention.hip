@@ -73,6 +73,25 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ base, int64
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
   }
 }
+// The same in two halves, so that the global loads of the NEXT tile are in flight while a tile is multiplied.
+struct TileRegs { float4 v[8]; };
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ base, int64_t rs, int r0, int T, TileRegs& t) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4), col = (lane & 15) * 4;
+    t.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < T) t.v[it] = *reinterpret_cast<const float4*>(base + (int64_t)(r0 + row) * rs + col);
+  }
+}
+__device__ __forceinline__ void put_tile(const TileRegs& t, float* tile) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    float* o = tile + (it * 4 + (lane >> 4)) * kALd + (lane & 15) * 4;
+    o[0] = t.v[it].x; o[1] = t.v[it].y; o[2] = t.v[it].z; o[3] = t.v[it].w;
+  }
+}
 // "row operand" of a staged tile: lane (row = lane % 32, hi = lane / 32) -> tile[row][32 hi + i], i < 32
 __device__ __forceinline__ void load_rows(const float* tile, float (&r)[32]) {
   const int lane = threadIdx.x & 63;
@@ -127,7 +146,7 @@ __device__ __forceinline__ void store_t(float* out_row, int hi, const f32x16& ac
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64 * kAWaves) attn_fwd_kernel(AttnParams p) {
+__global__ void __launch_bounds__(64 * kAWaves, 2) attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kAWaves][2 * kATileFloats];
   __shared__ float stat[kAWaves][2][kAT];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, qi = lane & 31;
@@ -151,11 +170,14 @@ __global__ void __launch_bounds__(64 * kAWaves) attn_fwd_kernel(AttnParams p) {
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   const int q = q0 + qi;
   const int nkt = (T + kAT - 1) / kAT;
+  TileRegs kr, vr;
+  if (w < nkt) { fetch_tile(K, rs, w * kAT, T, kr); fetch_tile(V, rs, w * kAT, T, vr); }
   for (int kt = w; kt < nkt; kt += kAWaves) {
     const int k0 = kt * kAT;
-    stage_tile(K, rs, k0, T, Ks);
-    stage_tile(V, rs, k0, T, Vs);
+    put_tile(kr, Ks);
+    put_tile(vr, Vs);
     wave_lds_sync();
+    if (kt + kAWaves < nkt) { fetch_tile(K, rs, k0 + kAWaves * kAT, T, kr); fetch_tile(V, rs, k0 + kAWaves * kAT, T, vr); }
     f32x16 s = mfma_rows(Ks, qreg);                              // S^T: register r <-> key k0 + row_of(r, hi), this lane's query
     float mt = -INFINITY;
 #pragma unroll
@@ -219,7 +241,7 @@ __global__ void __launch_bounds__(64 * kAWaves) attn_fwd_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // backward 1: dQ (and D = rowsum(dO * O)), owner = query tile, the key tiles dealt to the waves
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64 * kAWaves) attn_bwd_dq_kernel(AttnParams p) {
+__global__ void __launch_bounds__(64 * kAWaves, 2) attn_bwd_dq_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kAWaves][2 * kATileFloats];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hi = lane >> 5, qi = lane & 31;
   const int z = blockIdx.y, b = z / p.H, h = z % p.H, q0 = blockIdx.x * kAT, T = p.T;
@@ -258,11 +280,14 @@ __global__ void __launch_bounds__(64 * kAWaves) attn_bwd_dq_kernel(AttnParams p)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
   const int nkt = (T + kAT - 1) / kAT;
+  TileRegs kr, vr;
+  if (w < nkt) { fetch_tile(K, rs, w * kAT, T, kr); fetch_tile(V, rs, w * kAT, T, vr); }
   for (int kt = w; kt < nkt; kt += kAWaves) {
     const int k0 = kt * kAT;
-    stage_tile(K, rs, k0, T, Ks);
-    stage_tile(V, rs, k0, T, Vs);
+    put_tile(kr, Ks);
+    put_tile(vr, Vs);
     wave_lds_sync();
+    if (kt + kAWaves < nkt) { fetch_tile(K, rs, k0 + kAWaves * kAT, T, kr); fetch_tile(V, rs, k0 + kAWaves * kAT, T, vr); }
     f32x16 s = mfma_rows(Ks, qreg);
     f32x16 dp = mfma_rows(Vs, doreg);                            // dP^T[key][query] = V dO^T
 #pragma unroll
@@ -320,10 +345,15 @@ __global__ void __launch_bounds__(64 * kAWaves) attn_bwd_dkv_kernel(AttnParams p
 #pragma unroll
   for (int r = 0; r < 16; ++r) { gk0[r] = 0.f; gk1[r] = 0.f; gv0[r] = 0.f; gv1[r] = 0.f; }
   const int nqt = (T + kAT - 1) / kAT;
+  // (the key side holds 64 registers here, the prefetched tiles 64 more: one workgroup per CU.  Measured: 135 us per layer
+  // against 195 us without the prefetch at two workgroups per CU)
+  TileRegs qr, dr;
+  if (w < nqt) { fetch_tile(Q, rs, w * kAT, T, qr); fetch_tile(dO, rc, w * kAT, T, dr); }
   for (int qt = w; qt < nqt; qt += kAWaves) {
     const int q0 = qt * kAT;
-    stage_tile(Q, rs, q0, T, Qs);
-    stage_tile(dO, rc, q0, T, Ds);
+    put_tile(qr, Qs);
+    put_tile(dr, Ds);
+    if (qt + kAWaves < nqt) { fetch_tile(Q, rs, q0 + kAWaves * kAT, T, qr); fetch_tile(dO, rc, q0 + kAWaves * kAT, T, dr); }
     if (lane < kAT) {
       const int q = q0 + lane;
       qstat[w][0][lane] = q < T ? p.lse_in[(int64_t)z * T + q] : -INFINITY;
