@@ -624,6 +624,12 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
   PK2_REQUIRE(gx && whh && y && gates && cells && B > 0 && T > 0 && (D == 1 || D == 2), "lstm_fwd: bad args");
   PK2_REQUIRE(lstm_h_ok(H), "lstm_fwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (lstm_seq_wanted(B, H, D)) {           // one launch, a (sequence, direction) pair per XCD (lstm_persist_seq.hip)
+    bool ran = false;
+    int prc = lstm_fwd_seq_launch(gx, whh, bhh, B, T, H, D, y, gates, cells, stream, &ran);
+    if (prc) return prc;
+    if (ran) return PK2_OK;
+  }
   if (lstm_persist_wanted(B, H, D)) {       // one launch for the whole sequence (lstm_persist.hip)
     bool ran = false;
     int prc = lstm_fwd_persist_launch(gx, whh, bhh, B, T, H, D, y, gates, cells, stream, &ran);
@@ -680,6 +686,9 @@ extern "C" int pk2_lstm_persist_status(uint32_t* abort_flag) {
   PK2_REQUIRE(abort_flag, "lstm_persist_status: null pointer");
   unsigned f = 0;
   int rc = lstm_persist_status(&f);
+  unsigned f2 = 0;
+  if (!rc) rc = lstm_seq_status(&f2);
+  f |= f2;
   *abort_flag = f;
   return rc;
 }
@@ -695,6 +704,12 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
               "lstm_bwd: bad args");
   PK2_REQUIRE(lstm_h_ok(H), "lstm_bwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (lstm_seq_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {
+    bool ran = false;
+    int prc = lstm_bwd_seq_launch(dy, whh, gates, cells, B, T, H, D, dgx, stream, &ran);
+    if (prc) return prc;
+    if (ran) return PK2_OK;
+  }
   if (lstm_persist_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {   // one launch for the whole sequence (lstm_persist.hip)
     bool ran = false;      // the mailboxes (1 MB) live where the step kernels keep W_hh^T
     int prc = lstm_bwd_persist_launch(dy, whh, gates, cells, B, T, H, D, dgx, scratch, stream, &ran);

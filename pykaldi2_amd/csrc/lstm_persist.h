@@ -21,4 +21,12 @@ int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gate
                             int D, float* dgx, float* mailboxes, hipStream_t stream, bool* ran);
 int lstm_persist_status(unsigned* abort_flag);
 
+// One (sequence, direction) per XCD (lstm_persist_seq.hip): same tensors, same layouts; preferred when available.
+bool lstm_seq_wanted(int B, int H, int D);
+int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
+                        float* gates, float* cells, hipStream_t stream, bool* ran);
+int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
+                        int D, float* dgx, hipStream_t stream, bool* ran);
+int lstm_seq_status(unsigned* abort_flag);
+
 }  // namespace pk2
