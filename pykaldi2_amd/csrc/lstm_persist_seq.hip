@@ -391,7 +391,8 @@ static int seq_scratch(hipStream_t stream, SeqScratch** out) {
 bool lstm_seq_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_SEQ");
   if (env && atoi(env) == 0) return false;
-  if (g_seq_state == 0 || H != kSH || B < 1 || B * D > kSeqMaxTasks || (D != 1 && D != 2)) return false;
+  // (up to 4 pairs per XCD one after the other; larger batches are better served by the batched step kernels)
+  if (g_seq_state == 0 || H != kSH || B < 1 || B * D > 32 || (D != 1 && D != 2)) return false;
   static int cus = -1;
   if (cus < 0) {
     int dev = 0, n = 0;

@@ -152,11 +152,16 @@ def test_blstm_3x512_posteriors_match_torch_cpu():
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
 
 
+@pytest.mark.parametrize("impl", ["pair_per_xcd", "direction_per_xcd"])
 @pytest.mark.parametrize("B,T,bi,layers", [(3, 301, True, 1), (4, 150, False, 2), (1, 64, True, 1), (8, 120, True, 1), (6, 77, True, 2)])
-def test_persistent_recurrence_long_sequences_match_torch_cpu(B, T, bi, layers):
-    """The persistent small-batch recurrence (csrc/lstm_persist.hip: H = 512, B <= 8 in groups of 4 batch rows; one direction per XCD, h and the
-    d h partials exchanged through the XCD's L2 with double-buffered sentinel mailboxes) over hundreds of steps, partial
-    batches and one direction, against the reference's torch CPU nn.LSTM: outputs and every gradient."""
+def test_persistent_recurrence_long_sequences_match_torch_cpu(B, T, bi, layers, impl, monkeypatch):
+    """The persistent small-batch recurrences (H = 512): csrc/lstm_persist_seq.hip, a (sequence, direction) pair per XCD
+    (the default; more pairs than XCDs queue up: B = 6 / 8 bidirectional), and csrc/lstm_persist.hip (PK2_LSTM_SEQ=0), a
+    direction per XCD with B <= 8 in groups of 4 batch rows; h and the d h partials exchanged through the XCD's L2 with
+    double-buffered sentinel mailboxes, over hundreds of steps, partial batches and one direction, against the reference's
+    torch CPU nn.LSTM: outputs and every gradient."""
+    if impl == "direction_per_xcd":
+        monkeypatch.setenv("PK2_LSTM_SEQ", "0")
     torch.manual_seed(B * 1000 + T)
     H, Din, P = 512, 80, 40
     m = lstm.LSTMAM(Din, P, H, layers, 0.0, bi)
