@@ -69,6 +69,10 @@ __device__ __forceinline__ float seq_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
+// Workgroup barrier that waits for the LDS traffic only: __syncthreads() also waits for every outstanding global store
+// and load of the thread (s_waitcnt vmcnt(0)), i.e. for the HBM traffic of the previous step.
+__device__ __forceinline__ void seq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // A poll that keeps failing reads the wall clock every 256 rounds; after 1 s (or when somebody else gave up) it raises
 // the abort flag.
 struct SeqSpin {
@@ -160,6 +164,8 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
   const int ul = lane >> 4, g = (lane >> 2) & 3, q = lane & 3;
   const int gu = 16 * rank + 4 * w + ul;                 // hidden unit of this lane's row
   const bool unit_lane = (lane & 15) == 0;
+  const bool poll_lane = (lane & 15) >= 1 && (lane & 15) <= 8;
+  const int gran = w * 32 + (lane >> 4) * 8 + ((lane & 15) - 1);      // granule of h this lane polls (128 per step)
   const size_t yrow = (size_t)D * H;
   unsigned nbar = 0;
   for (int iter = 0; iter <= kSeqMaxTasks; ++iter) {
@@ -201,17 +207,19 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
 #pragma unroll
       for (int k = 0; k < 4; ++k) pre[k] = gxn[k] + bias[k];
       // ---- gather h_{t-1} of this (sequence, direction): 512 floats = 128 granules of 16 bytes -----------------------
-      if (step > 0 && tid < 128) {
-        const float* src = p.y + ((size_t)tp * B + b) * yrow + (size_t)d * H + 4 * tid;
+      // (by lanes 1..8 of every 16-lane row: a poll waits for ALL of the thread's outstanding memory operations, and the
+      // unit lanes -- lane % 16 == 0 -- still have the previous step's gate / cell stores and the gx prefetch in flight)
+      if (step > 0 && poll_lane) {
+        const float* src = p.y + ((size_t)tp * B + b) * yrow + (size_t)d * H + 4 * gran;
         u32x4 v = seq_load16(src);
         while (seq_has_sentinel(v)) {
           if (spin.expired()) { timed_out = true; break; }
           v = seq_load16(src);
         }
-        *reinterpret_cast<u32x4*>(&hs[buf][(tid >> 5) * kPhasePitch + 4 * (tid & 31)]) = v;
+        *reinterpret_cast<u32x4*>(&hs[buf][(gran >> 5) * kPhasePitch + 4 * (gran & 31)]) = v;
       }
       if (timed_out) s_i[3] = 1;
-      __syncthreads();
+      seq_lds_barrier();
       if (s_i[3]) return;
       load_gx(step + 1);
       // ---- recurrent product: this lane's quarter of its gate row ------------------------------------------------------
@@ -308,19 +316,21 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
       const int fstep = T - 1 - step;
       const int t = d == 0 ? fstep : T - 1 - fstep;
       const float c_dy = n_dy, c_i = n_i, c_f = n_f, c_g = n_g, c_o = n_o, c_c = n_c, c_cp = n_cp;
-      load_pw(step + 1);
       // ---- gather the 32 partials of d h for the own 16 units (written by the peers during the previous step) ----------
       float rec = 0.f;
       if (step > 0) {
-        if (tid < 128) {
-          float* src = mail0 + ((size_t)(step & 1) * kSWgs + rank) * (kSWgs * 16) + 4 * tid;     // [writer = tid/4][4 units]
+        // (threads 128..255 poll: the pointwise threads 0..15 have prefetches and gradient stores in flight, which a poll
+        // -- it waits for all of a thread's outstanding memory operations -- would wait for)
+        if (tid >= 128) {
+          const int gt = tid - 128;
+          float* src = mail0 + ((size_t)(step & 1) * kSWgs + rank) * (kSWgs * 16) + 4 * gt;      // [writer = gt/4][4 units]
           u32x4 v = seq_load16(src);
           while (seq_has_sentinel(v)) {
             if (spin.expired()) { timed_out = true; break; }
             v = seq_load16(src);
           }
           seq_store16(src, sent);               // free again (ordered before this step's own stores by the wait below)
-          *reinterpret_cast<u32x4*>(&pl[tid >> 2][4 * (tid & 3)]) = v;
+          *reinterpret_cast<u32x4*>(&pl[gt >> 2][4 * (gt & 3)]) = v;
         }
         if (timed_out) s_i[3] = 1;
         __syncthreads();
@@ -336,24 +346,31 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
         }
       }
       // ---- gate derivatives of the own units ------------------------------------------------------------------------------
+      float dgi = 0.f, dgf = 0.f, dgg = 0.f, dgo = 0.f;
       if (pw) {
         const float dh = c_dy + rec;
         const float tc = seq_tanh(c_c);
         const float dcv = dcarry + dh * c_o * (1.f - tc * tc);
         dcarry = dcv * c_f;
-        const float dgi = dcv * c_g * c_i * (1.f - c_i);
-        const float dgf = dcv * c_cp * c_f * (1.f - c_f);
-        const float dgg = dcv * c_i * (1.f - c_g * c_g);
-        const float dgo = dh * tc * c_o * (1.f - c_o);
-        float* o = p.dgx + ((size_t)t * B + b) * ((size_t)D * G4) + (size_t)d * G4 + unit;
-        o[0] = dgi; o[(size_t)H] = dgf; o[(size_t)2 * H] = dgg; o[(size_t)3 * H] = dgo;
+        dgi = dcv * c_g * c_i * (1.f - c_i);
+        dgf = dcv * c_cp * c_f * (1.f - c_f);
+        dgg = dcv * c_i * (1.f - c_g * c_g);
+        dgo = dh * tc * c_o * (1.f - c_o);
         dgl[tid] = dgi; dgl[16 + tid] = dgf; dgl[32 + tid] = dgg; dgl[48 + tid] = dgo;
       }
-      if (step == T - 1) break;
+      auto store_dgx = [&]() {        // (to HBM; nothing waits for these)
+        if (pw) {
+          float* o = p.dgx + ((size_t)t * B + b) * ((size_t)D * G4) + (size_t)d * G4 + unit;
+          o[0] = dgi; o[(size_t)H] = dgf; o[(size_t)2 * H] = dgg; o[(size_t)3 * H] = dgo;
+        }
+      };
+      if (step == T - 1) { store_dgx(); break; }
       // the mailbox resets have been acknowledged by the L2 (a plain wait: an agent-scope release FENCE writes the whole L2
       // back on this multi-XCD part), everybody's, before any partial goes out
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      store_dgx();
+      load_pw(step + 1);             // the next step's pointwise operands: a whole step to arrive
       // ---- own 64 rows of dgates x own W_hh rows: the lane's two columns ---------------------------------------------------
       float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
