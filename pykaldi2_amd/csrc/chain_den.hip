@@ -875,9 +875,13 @@ __global__ void __launch_bounds__(kExpThreads) den_exp_states_lds(const float* _
     const int pdf = vpdf[d];
     float v[NG];
     if (pdf >= 0) ldv<NG>(xs + (size_t)pdf * NG, v);
+    if (NG == 1 && xv) {      // the persistent kernel reads a compact copy and fills the btilde' halves itself: the records' x
+                              // halves have no reader then (566 MB of stores per call on the bench graph)
+      xv[((size_t)g * Tmax + t) * (size_t)V + d] = pdf >= 0 ? v[0] : 1.f;
+      continue;
+    }
     stv<NG>(out + (size_t)d * (2 * NG), zero);
     stv<NG>(out + (size_t)d * (2 * NG) + NG, pdf >= 0 ? v : one);
-    if (NG == 1 && xv) xv[((size_t)g * Tmax + t) * (size_t)V + d] = pdf >= 0 ? v[0] : 1.f;   // the persistent kernel's compact copy
   }
   float* outl = xl + ((size_t)g * Tmax + t) * (size_t)S * NG;
   for (int d = blockIdx.z * kExpThreads + tid; d < S; d += gridDim.z * kExpThreads) {

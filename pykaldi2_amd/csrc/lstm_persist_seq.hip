@@ -31,7 +31,7 @@ constexpr int kSWgs = 32;                   // workgroups of a team = CUs of an 
 constexpr int kSeqTeams = 8;                // teams per XCD the control block has room for
 constexpr int kSeqMaxTasks = 64;
 constexpr long long kSeqSpinTicks = 1000LL * 1000 * 100;     // 1 s of the 100 MHz wall clock
-constexpr int kSeqMailFloats = 2 * kSWgs * kSWgs * 16;       // per team: [parity][reader][writer][16 units]
+constexpr int kSeqMailFloats = 3 * kSWgs * kSWgs * 16;       // per team: [step % 3][reader][writer][16 units]
 
 struct SeqCtl {
   unsigned arrive[8];
@@ -198,6 +198,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
       }
     };
     load_gx(0);
+    float gxm[4];                      // the input projections of step s+1; gxn: those of step s+2, in flight
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gxm[k] = gxn[k];
+    load_gx(1);
     SeqSpin spin(ctl);
     for (int step = 0; step < T; ++step) {
       const int t = d == 0 ? step : T - 1 - step;
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
       const int buf = step & 1;
       float pre[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pre[k] = gxn[k] + bias[k];
+      for (int k = 0; k < 4; ++k) { pre[k] = gxm[k] + bias[k]; gxm[k] = gxn[k]; }
       // ---- gather h_{t-1} of this (sequence, direction): 512 floats = 128 granules of 16 bytes -----------------------
       // (by lanes 1..8 of every 16-lane row: a poll waits for ALL of the thread's outstanding memory operations, and the
       // unit lanes -- lane % 16 == 0 -- still have the previous step's gate / cell stores and the gx prefetch in flight)
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
       if (timed_out) s_i[3] = 1;
       seq_lds_barrier();
       if (s_i[3]) return;
-      load_gx(step + 1);
+      load_gx(step + 2);
       // ---- recurrent product: this lane's quarter of its gate row ------------------------------------------------------
       float s = 0.f;
       if (step > 0) {
@@ -262,7 +266,7 @@ struct SeqBwdParams {
   const float* gates;  // [D][T][B][4H]
   const float* cells;  // [D][T][B][H]
   float* dgx;          // [T][B][D*4H]
-  float* mail;         // [teams][2][32 readers][32 writers][16 units], all sentinel
+  float* mail;         // [teams][3][32 readers][32 writers][16 units], all sentinel
   int B, T, D;
 };
 
@@ -297,7 +301,8 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
     }
     float dcarry = 0.f;
     bool timed_out = false;
-    float n_dy = 0.f, n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_cp = 0.f;
+    float n_dy = 0.f, n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_cp = 0.f;          // operands of step s+2 (in flight)
+    float m_dy = 0.f, m_i = 0.f, m_f = 0.f, m_g = 0.f, m_o = 0.f, m_c = 0.f, m_cp = 0.f;          // operands of step s+1
     auto load_pw = [&](int step_) {
       if (pw && step_ < T) {
         const int fs = T - 1 - step_;
@@ -311,11 +316,16 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
       }
     };
     load_pw(0);
+    m_dy = n_dy; m_i = n_i; m_f = n_f; m_g = n_g; m_o = n_o; m_c = n_c; m_cp = n_cp;
+    load_pw(1);
     SeqSpin spin(ctl);
     for (int step = 0; step < T; ++step) {
       const int fstep = T - 1 - step;
       const int t = d == 0 ? fstep : T - 1 - fstep;
-      const float c_dy = n_dy, c_i = n_i, c_f = n_f, c_g = n_g, c_o = n_o, c_c = n_c, c_cp = n_cp;
+      // (loaded two steps ahead: a step is shorter than a round trip to memory; the rotation below only touches values whose
+      // loads were issued a whole step ago)
+      const float c_dy = m_dy, c_i = m_i, c_f = m_f, c_g = m_g, c_o = m_o, c_c = m_c, c_cp = m_cp;
+      m_dy = n_dy; m_i = n_i; m_f = n_f; m_g = n_g; m_o = n_o; m_c = n_c; m_cp = n_cp;
       // ---- gather the 32 partials of d h for the own 16 units (written by the peers during the previous step) ----------
       float rec = 0.f;
       if (step > 0) {
@@ -323,7 +333,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
         // -- it waits for all of a thread's outstanding memory operations -- would wait for)
         if (tid >= 128) {
           const int gt = tid - 128;
-          float* src = mail0 + ((size_t)(step & 1) * kSWgs + rank) * (kSWgs * 16) + 4 * gt;      // [writer = gt/4][4 units]
+          float* src = mail0 + ((size_t)(step % 3) * kSWgs + rank) * (kSWgs * 16) + 4 * gt;      // [writer = gt/4][4 units]
           u32x4 v = seq_load16(src);
           while (seq_has_sentinel(v)) {
             if (spin.expired()) { timed_out = true; break; }
@@ -365,12 +375,13 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
         }
       };
       if (step == T - 1) { store_dgx(); break; }
-      // the mailbox resets have been acknowledged by the L2 (a plain wait: an agent-scope release FENCE writes the whole L2
-      // back on this multi-XCD part), everybody's, before any partial goes out
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // Three mailbox buffers: the one read (and reset) in step s is written again by the peers in their step s+2, after they
+      // have read this workgroup's partials of step s+2 -- which go out behind the barrier of step s+1, and the polling
+      // threads reach that barrier only after their reset stores have been acknowledged (a poll waits for the thread's
+      // outstanding stores).  So no wait for the resets here (with two buffers it cost an L2 round trip per step).
+      seq_lds_barrier();
       store_dgx();
-      load_pw(step + 1);             // the next step's pointwise operands: a whole step to arrive
+      load_pw(step + 2);             // the pointwise operands of the step after next
       // ---- own 64 rows of dgates x own W_hh rows: the lane's two columns ---------------------------------------------------
       float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
@@ -382,7 +393,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
         a1 = fmaf(dv[3], wb[8 * r4 + 6], a1); b1 = fmaf(dv[3], wb[8 * r4 + 7], b1);
       }
       // peer k/16 reads [writer = rank][unit k%16] from its mailbox of the next step
-      float* box = mail0 + (size_t)((step + 1) & 1) * kSWgs * (kSWgs * 16);
+      float* box = mail0 + (size_t)((step + 1) % 3) * kSWgs * (kSWgs * 16);
       const int k0 = 128 * w + lane, k1 = k0 + 64;
       seq_store(box + ((size_t)(k0 >> 4) * kSWgs + rank) * 16 + (k0 & 15), a0 + a1);
       seq_store(box + ((size_t)(k1 >> 4) * kSWgs + rank) * 16 + (k1 & 15), b0 + b1);
