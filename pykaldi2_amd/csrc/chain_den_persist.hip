@@ -170,6 +170,18 @@ __device__ __forceinline__ void ring_store(gfloat* p, float v) {
 #endif
 }
 
+// Sum over the 64 lanes with DPP moves (full-rate VALU; __shfl_xor is a ds_bpermute round trip per step), the total
+// broadcast from lane 63: the same bits in every lane.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f<0x111, 0xf>(v);      // row_shr:1
+  v += dpp_f<0x112, 0xf>(v);      // row_shr:2
+  v += dpp_f<0x114, 0xf>(v);      // row_shr:4
+  v += dpp_f<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row's sum
+  v += dpp_f<0x142, 0xa>(v);      // row_bcast15 -> rows 1 and 3 add the sum of the row before
+  v += dpp_f<0x143, 0xc>(v);      // row_bcast31 -> rows 2 and 3 add the sum of rows 0..1
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // A poll that keeps failing reads the wall clock every 256 rounds; after 1 s (or when somebody else gave up) it raises
 // the abort flag.
 struct Spin {
@@ -254,7 +266,7 @@ __device__ __forceinline__ void poll_words(cgfloat* ps, int first, int nwords, S
       if (mine && is_sentinel(pv)) pv = ld_agent(src);
     }
     if (!ok) pv = 0.f;
-    const float a = wave_sum(lane < kPR ? pv : 0.f), b = wave_sum(lane < kPR ? 0.f : pv);
+    const float a = wave_sum_dpp(lane < kPR ? pv : 0.f), b = wave_sum_dpp(lane < kPR ? 0.f : pv);
     if (lane == 0) { L.tot[0] = a; L.tot[1] = b; if (!ok) *L.abort = 1; }
   }
 }
@@ -354,7 +366,7 @@ __device__ __forceinline__ float row_sum(const Lds& L, const Carries& c, int r) 
 template <int NW>
 __device__ __forceinline__ void block_sum2_1(float& u, float& v, float* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  u = wave_sum(u); v = wave_sum(v);
+  u = wave_sum_dpp(u); v = wave_sum_dpp(v);
   __syncthreads();
   if (lane == 0) { red[w] = u; red[NW + w] = v; }
   __syncthreads();
