@@ -49,7 +49,7 @@ SIGNATURES = {
                                                _vp, _vp, _vp, _vp]),
     "pk2_den_graph_debug_virtual": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp,
                                               C.POINTER(_i64), _vp, _vp, _vp, C.POINTER(_i32), _vp, _vp]),
-    "pk2_den_graph_debug_persist": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pk2_den_graph_debug_persist": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pk2_chain_workspace_bytes": (_sz, [_vp, _i32, _i32, _i64]),
     "pk2_chain_objf_and_deriv": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(NumBatch), _f32,
                                            _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),

@@ -84,16 +84,16 @@ class DenominatorGraph:
         graph does not fit it."""
         L = _lib.lib()
         info = np.zeros(9, dtype=np.int32)
-        _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), None, None, None, None, None, None, None))
+        _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), None, None, None, None, None, None, None, None))
         if not info[0]:
             return None
         R, T, K, W, rows = (int(v) for v in info[3:8])
         out = dict(arcs=np.empty((R, K, T, 2), dtype=np.int32), ends=np.empty((R, T), dtype=np.uint64),
                    first_row=np.empty((R, T), dtype=np.int32), wcrow=np.empty((R, W), dtype=np.int32),
                    row_begin=np.empty(R + 1, dtype=np.int32), grp_begin=np.empty(R + 1, dtype=np.int32),
-                   row_leak=np.empty(rows, dtype=np.float32))
+                   row_leak=np.empty(rows, dtype=np.float32), row_psum=np.empty(rows, dtype=np.float32))
         _lib.check(L.pk2_den_graph_debug_persist(self._h, which, _lib.ptr(info), *[_lib.ptr(out[k]) for k in
-                   ("arcs", "ends", "first_row", "wcrow", "row_begin", "grp_begin", "row_leak")]))
+                   ("arcs", "ends", "first_row", "wcrow", "row_begin", "grp_begin", "row_leak", "row_psum")]))
         out.update(max_rows=int(info[1]), max_groups=int(info[2]), estep=int(info[8]))
         return out
 

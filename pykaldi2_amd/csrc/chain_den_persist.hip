@@ -15,16 +15,17 @@
 //  * a frame's results are exchanged through the XCD's own L2: two state-vector buffers written with agent-scope stores,
 //    and four words per rank and frame (partial sums, "slice ready") that a rank publishes AFTER its slice has reached
 //    L2 -- one wave per workgroup polls them, NaN-sentinel guarded, reset by their owner two frames ahead.  No grid
-//    barrier, nothing crosses to another XCD.  The forward recursion needs one exchange per frame; the backward one two
-//    (the sums over all states, then the scaled slices: see run_bwd).  The per-frame history (alpha, per-occupancy-state
-//    alpha, btilde', partial sums) goes out with plain stores, after everything another workgroup waits for, in the
-//    NG = 1 layouts of chain_den.hip, whose parallel passes (exp tables, scales, occupancies) run unchanged around this
-//    kernel;
+//    barrier, nothing crosses to another XCD.  Both recursions need ONE exchange per frame: the backward one's scaling
+//    needs the frame's sums over all states before it can publish anything, but those sums are linear in the vector the
+//    frame gathers, so the producers of that vector deliver them with it (see run_bwd).  The per-frame history (alpha,
+//    per-occupancy-state alpha, btilde', partial sums) goes out with plain stores, after everything another workgroup
+//    waits for, in the NG = 1 layouts of chain_den.hip, whose parallel passes (exp tables, scales, occupancies) run
+//    unchanged around this kernel;
 //  * 2 N recursions are handed to the teams from a queue, longest first (8 XCDs = 4 sequences x 2 directions at once).
 // Teams form by arrival order per XCD (XCC_ID register); polls time out after 1 s and raise an abort flag (the first
 // launch on a device is verified, a later failure poisons the objective with NaN instead of passing for a result).
-// Measured on the bench graph (S = 30 k, A = 1.01 M, 4 sequences, Tmax = 589): 6.1 ms per denominator call against
-// 11.0 ms for the frame kernels; a frame takes ~8.6 us forward / ~9.6 us backward.
+// Measured on the bench graph (S = 30 k, A = 1.01 M, 4 sequences, Tmax = 589): 5.0 ms per denominator call against
+// 11.0 ms for the frame kernels; a frame takes ~8 us in either direction.
 // Replaces the same DenominatorComputation as chain_den.hip (reference ops/ops.py:265, bin/train_chain.py:202).
 #include <algorithm>
 #include <cstdlib>
@@ -231,7 +232,8 @@ struct Lds {
   float* table;    // [rpad]  the frame's gather table
   float* acc;      // [cap]   row sums
   float* xown;     // [cap]   forward: x[t, own rows]
-  float* leak;     // [cap]   forward: leaky-HMM constant of own rows
+  float* leak;     // [cap]   forward: leaky-HMM constant of own rows; backward: weight of an own virtual state in lB
+  float* aux;      // [cap]   backward: its weight in lU
   float* red;      // [2 * kPW]
   float* tot;      // [4]     a frame's partial sums added up (written by the polling wave)
   float* wcarry;   // [kPW]
@@ -242,8 +244,8 @@ struct Lds {
 constexpr int kLdsTailInts = kPW + (kPR + 1) + 8;
 __device__ __forceinline__ Lds carve_lds(int rpad, int cap) {
   Lds L;
-  L.table = den_persist_smem; L.acc = L.table + rpad; L.xown = L.acc + cap; L.leak = L.xown + cap;
-  L.red = L.leak + cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
+  L.table = den_persist_smem; L.acc = L.table + rpad; L.xown = L.acc + cap; L.leak = L.xown + cap; L.aux = L.leak + cap;
+  L.red = L.aux + cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
   L.wcrow = reinterpret_cast<int*>(L.wcarry + kPW); L.rb = L.wcrow + kPW; L.abort = L.rb + (kPR + 1);
   return L;
 }
@@ -519,11 +521,16 @@ __device__ __noinline__ void run_fwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
 }
 
 // btilde' recursion of sequence g: den_beta_frame_sx<1> frame by frame, T-1 down to 0.  What a frame gathers is
-//   w[t+1][v] = x[t, pdf(v)] * (btilde'[t+1, state(v)] / c[t+1] + leaky term of frame t+1)   per virtual state v,
+//   w[t+1][v] = x[t, pdf(v)] * betahat[t+1, state(v)],  betahat[t+1, s] = btilde'[t+1, s] / c[t+1] + leaky term of t+1,
 // and it is the PRODUCER of btilde'[t+1, .] that scales its slice (it needs x only for its own ~V/32 virtual states; a
 // consumer-side transform would have every workgroup read all of x[t, .]: 120 KB more per frame and CU, and 64 more live
-// registers per thread).  The scaling needs the frame's sums over all states, so a frame has two exchanges: the partial
-// sums (words 0, 1), then the slice of w (word 2 = ready).
+// registers per thread).  The scaling needs the frame's sums over ALL states, lB[t] = sum_s pi[s] btilde'[t, s] and
+// lU[t] = sum_s btilde'[t, s] -- which would cost a second exchange per frame (partial sums out, totals back, only then
+// the slices).  But btilde'[t, .] is linear in the vector the frame gathers:
+//   lB[t] = sum_v w[t+1][v] * (sum of pi[src] * prob over the arcs entering v)  +  sum_s pi[s] loop_s x_loop[t, s] betahat[t+1, s]
+// (lU alike without pi), and the per-virtual-state weights are constants of the graph (the forward layout's row_leak /
+// row_psum).  So the producer of w[t+1] publishes, WITH its slice, its share of the sums frame t is going to compute: a
+// frame knows c[t] before its first arc, scales its rows as soon as they are summed, and one exchange per frame is left.
 __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
                                      unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
   CParams* pp = uni(pp_);
@@ -559,46 +566,81 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
       st_v0[i] = d.voff[s] - vfirst; st_v1[i] = d.voff[s + 1] - vfirst; st_pl[i] = d.loop_prob[s]; st_pi[i] = d.pi[s];
     }
   }
+  // what an own virtual state contributes to the next frame's sums (virtual states are the forward layout's rows)
+  for (int r = tid; r < nvirt; r += kPT) { L.leak[r] = p.fwd.row_leak[vfirst + r]; L.aux[r] = p.fwd.row_psum[vfirst + r]; }
   if (tid < 3 * kPWords) st_agent(pring + ((tid / kPWords) * kPR + rank) * kPWords + tid % kPWords, __uint_as_float(kRingSentinel));
   if (!team_barrier(ctl, team, nbar, L.abort)) return;
 
   const size_t f0 = (size_t)g * (d.Tmax + 1);
   cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
   cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
-  float xlr[kPSPT], xw[kPSPT], bh[kPSPT];        // x of own loops (frame t), x of own virtual states (frame t-1), beta-hat[t+1]
+  // x of own loops at the frame being computed (xl_cur) and at the one after it (xl_prev), x of own virtual states at the
+  // latter (xw), beta-hat of own states at the frame computed last (bh)
+  float xl_cur[kPSPT], xl_prev[kPSPT], xw[kPSPT], bh[kPSPT];
   const float cst_last = 1.0f / d.pi_sum + d.leaky;
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) bh[i] = cst_last;
+  for (int i = 0; i < kPSPT; ++i) { bh[i] = cst_last; xl_cur[i] = 0.f; }
   auto prefetch = [&](int t) {
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i) {
       const int r = tid + i * kPT;
-      xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
-      xw[i] = (t > 0 && r < nvirt) ? xv_g[(size_t)(t - 1) * V + vfirst + r] : 0.f;
+      xl_prev[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
+      xw[i] = r < nvirt ? xv_g[(size_t)t * V + vfirst + r] : 0.f;
     }
   };
-  prefetch(T - 1);
-  Spin spin(ctl);
-  DP_T0();
-  for (int t = T - 1; t >= 0; --t) {
-    const bool gat = t + 1 < T;
-    DP_TL(1, 0);
-    if (!gat) {          // w[T] = x[T-1, .] * (1 / sum(pi) + leaky): straight from the exp table
-      for (int idx = tid; idx < V; idx += kPT) L.table[idx] = xv_g[(size_t)t * V + idx] * cst_last;
-    } else {
-      poll_words(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 2, 1, spin, L);
-      __syncthreads();
-      DP_TL(1, 1);
-      if (*L.abort) return;
-      dma_table(ring + (size_t)((t + 1) & 1) * p.rpad, V, L.table);
-    }
+  auto stage_x = [&]() {
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i) {
       const int r = tid + i * kPT;
       if (r < nvirt) L.xown[r] = xw[i];
     }
+  };
+  // Publishes this rank's slice of w[t] = x[t-1, .] * bh (xown = x[t-1, own virtual states], xl_prev = x_loop[t-1, own
+  // states]) and, once it is in L2, its share of lB[t-1] / lU[t-1]: words 0 and 1 of frame slot t.
+  auto emit = [&](int t) {
+    gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad + vfirst;
+    float pB = 0.f, pU = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      if (!st_ok[i]) continue;
+      for (int q = st_v0[i]; q < st_v1[i]; ++q) {
+        const float w = L.xown[q] * bh[i];
+        ring_store(ring_n + q, w);
+        pB = fmaf(w, L.leak[q], pB); pU = fmaf(w, L.aux[q], pU);
+      }
+      if (st_pl[i] > 0.f) { const float lp = st_pl[i] * xl_prev[i] * bh[i]; pB = fmaf(st_pi[i], lp, pB); pU += lp; }
+    }
+    wait_stores();        // the slice (and the reset of the words two frames on) is in L2 before the sums say so
+    block_sum2_1<kPW>(pB, pU, L.red);
+    if (tid < 2) st_agent(word_of(pring, t, rank, tid), tid == 0 ? pB : pU);
+    if (tid == 0) {       // the parallel passes recompute c[t-1] from the same shares
+      G(d.bpart)[((f0 + t - 1) * kPR + rank) * 2] = pB;
+      G(d.bpart)[((f0 + t - 1) * kPR + rank) * 2 + 1] = pU;
+    }
+  };
+  // w[T] = x[T-1, .] * (1 / sum(pi) + leaky)
+  prefetch(T - 1);
+  stage_x();
+  __syncthreads();
+  emit(T);
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) xl_cur[i] = xl_prev[i];
+  if (T >= 2) prefetch(T - 2);
+  Spin spin(ctl);
+  DP_T0();
+  for (int t = T - 1; t >= 0; --t) {
+    DP_TL(1, 0);
+    poll_words(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 0, 2, spin, L);
+    __syncthreads();
+    DP_TL(1, 1);
+    if (*L.abort) return;
+    const float lB = L.tot[0], lU = L.tot[1];        // sums of btilde'[t, .], known before it is computed
+    dma_table(ring + (size_t)((t + 1) & 1) * p.rpad, V, L.table);
     const bool publish = t > 0;
-    if (tid < 3 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
+    if (publish) stage_x();
+    // the words this rank will publish two frames from now must read "not yet written" by then: reset here, long before
+    // the stores they have to precede (the waits of emit cover it)
+    if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
     dma_wait();
     DP_T(0);
     DP_TL(1, 2);
@@ -611,57 +653,34 @@ __device__ __noinline__ void run_bwd(CParams* pp_, DenPersistCtl* ctl_, DenPersi
     __syncthreads();
     load_carries(L, cr);
     DP_T(3);
-    // rows are source states: btilde'[t, s] = row + peeled loop; its sums over the states go out first
-    float vs[kPSPT], loc = 0.f, locu = 0.f;
+    // rows are source states: btilde'[t, s] = row + peeled loop, then beta-hat[t, s] with the sums received above
+    const float cu = lB + d.wu * lU;
+    const float inv_c = cu > 0.f ? 1.0f / cu : 0.f;
+    const float lkr = d.leaky * lB * inv_c;
+    float vs[kPSPT];
 #pragma unroll
     for (int i = 0; i < kPSPT; ++i) {
       vs[i] = 0.f;
       if (!st_ok[i]) continue;
       float v = row_sum(L, cr, tid + i * kPT);
-      if (st_pl[i] > 0.f) v += st_pl[i] * xlr[i] * bh[i];
-      loc += st_pi[i] * v; locu += v;
+      if (st_pl[i] > 0.f) v += st_pl[i] * xl_cur[i] * bh[i];
       vs[i] = v;
-    }
-    block_sum2_1<kPW>(loc, locu, L.red);
-    if (tid < 2 && publish) {
-      wait_stores();      // (the reset above)
-      st_agent(word_of(pring, t, rank, tid), tid == 0 ? loc : locu);
+      bh[i] = v * inv_c + lkr;
     }
     DP_T(4);
     DP_TL(1, 5);
-    if (publish) {
-      // second exchange: with the sums of frame t, this rank's slice of w[t] for frame t-1
-      poll_words(pring + (size_t)(t % 3) * kPR * kPWords, 0, 2, spin, L);
-      __syncthreads();
-      if (*L.abort) return;
-      const float lB = L.tot[0], lU = L.tot[1];
-      const float cu = lB + d.wu * lU;
-      const float inv_c = cu > 0.f ? 1.0f / cu : 0.f;
-      const float lkr = d.leaky * lB * inv_c;
-      gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad + vfirst;
-#pragma unroll
-      for (int i = 0; i < kPSPT; ++i) {
-        if (!st_ok[i]) continue;
-        bh[i] = vs[i] * inv_c + lkr;
-        for (int q = st_v0[i]; q < st_v1[i]; ++q) ring_store(ring_n + q, L.xown[q] * bh[i]);
-      }
-      wait_stores();
-      __syncthreads();
-      if (tid == 0) st_agent(word_of(pring, t, rank, 2), 1.0f);
-      DP_T(5);
-      DP_TL(1, 6);
-      prefetch(t - 1);
-    }
+    if (publish) emit(t);
+    DP_T(5);
+    DP_TL(1, 6);
     // history for the parallel passes, after everything another workgroup waits for (the occupancy pass reads btilde' of
     // a state from its first virtual state: ovirt)
     gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
-    if (tid == 0) {
-      G(d.bpart)[((f0 + t) * kPR + rank) * 2] = loc;
-      G(d.bpart)[((f0 + t) * kPR + rank) * 2 + 1] = locu;
-    }
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i)
+    for (int i = 0; i < kPSPT; ++i) {
       if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
+      xl_cur[i] = xl_prev[i];
+    }
+    if (t >= 2) prefetch(t - 2);
     DP_T(6);
   }
   DP_FLUSH(1);
@@ -742,7 +761,7 @@ static int den_cap(const pk2_den_graph* g) {
   return (std::max({g->h_pfwd.max_rows, g->h_pfwd.max_groups, g->h_pbwd.max_rows, g->h_pbwd.max_groups, 1}) + 3) / 4 * 4;
 }
 size_t den_persist_lds_bytes(const pk2_den_graph* g) {
-  return ((size_t)den_rpad(g) + 3 * (size_t)den_cap(g) + 3 * kPW + 4 + kLdsTailInts) * sizeof(float);
+  return ((size_t)den_rpad(g) + 4 * (size_t)den_cap(g) + 3 * kPW + 4 + kLdsTailInts) * sizeof(float);
 }
 
 bool den_persist_fits(const pk2_den_graph* g) {

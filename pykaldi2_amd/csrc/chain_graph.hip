@@ -213,6 +213,7 @@ static bool build_persist_step(int64_t A, int num_rows, const int32_t* key, cons
   out->first_row.assign((size_t)kPR * kPT, 0);
   out->wcrow.assign((size_t)kPR * kPW, -1);
   out->row_leak.assign(num_rows, 0.f);
+  out->row_psum.assign(num_rows, 0.f);
   std::vector<int32_t> srow; std::vector<int64_t> sarc; std::vector<char> send;
   std::vector<int32_t> sidx;              // gathered index of a slot after the bank-aware deal (nulls get one too)
   std::vector<int32_t> load((size_t)2 * kPK * 32);
@@ -221,12 +222,16 @@ static bool build_persist_step(int64_t A, int num_rows, const int32_t* key, cons
     const int row0 = out->row_begin[r], row1 = out->row_begin[r + 1];
     srow.clear(); sarc.clear(); send.clear();
     for (int q = row0; q < row1; ++q) {
-      double leak = 0.0;
-      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) { srow.push_back(q - row0); sarc.push_back(perm[k]); send.push_back(0); leak += (double)piprob[perm[k]]; }
+      double leak = 0.0, psum = 0.0;
+      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) {
+        srow.push_back(q - row0); sarc.push_back(perm[k]); send.push_back(0);
+        leak += (double)piprob[perm[k]]; psum += (double)prob[perm[k]];
+      }
       if (ptr[q] == ptr[q + 1]) { srow.push_back(q - row0); sarc.push_back(-1); send.push_back(0); }
       while (srow.size() % estep) { srow.push_back(q - row0); sarc.push_back(-1); send.push_back(0); }
       send.back() = 1;
       out->row_leak[q] = (float)leak;
+      out->row_psum[q] = (float)psum;
     }
     const int64_t n = (int64_t)srow.size();
     // bank-aware deal: inside a thread, the slots of one row are interchangeable
@@ -484,6 +489,7 @@ static int upload_persist(pk2_den_graph* g, const HostPersist& h, DevPersist* d)
   if ((rc = upload_vec(g, h.row_begin, &d->row_begin))) return rc;
   if ((rc = upload_vec(g, h.grp_begin, &d->grp_begin))) return rc;
   if ((rc = upload_vec(g, h.row_leak, &d->row_leak))) return rc;
+  if ((rc = upload_vec(g, h.row_psum, &d->row_psum))) return rc;
   d->max_rows = h.max_rows; d->max_groups = h.max_groups; d->estep = h.estep;
   return PK2_OK;
 }
@@ -649,10 +655,11 @@ extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, in
 // Test hook: the persistent kernel's layout of an ordering (which: 0 = forward, rows = virtual destination states;
 // 1 = backward, rows = source states).  info = {ok, max_rows, max_groups, workgroups, threads, slots per thread, waves,
 // rows, estep}; the arrays (may be null) are sized from it: arcs [workgroups * slots * threads][2], ends / first_row
-// [workgroups * threads], wcrow [workgroups * waves], row_begin / grp_begin [workgroups + 1], row_leak [rows].
+// [workgroups * threads], wcrow [workgroups * waves], row_begin / grp_begin [workgroups + 1], row_leak / row_psum [rows].
 extern "C" int pk2_den_graph_debug_persist(const pk2_den_graph* g, int which, int32_t* info, int32_t* arcs_out,
                                            uint64_t* ends_out, int32_t* first_row_out, int32_t* wcrow_out,
-                                           int32_t* row_begin_out, int32_t* grp_begin_out, float* row_leak_out) {
+                                           int32_t* row_begin_out, int32_t* grp_begin_out, float* row_leak_out,
+                                           float* row_psum_out) {
   PK2_REQUIRE(g && (which == 0 || which == 1) && info, "den graph debug: bad arguments");
   const HostPersist& h = which == 0 ? g->h_pfwd : g->h_pbwd;
   info[0] = h.ok ? 1 : 0; info[1] = h.max_rows; info[2] = h.max_groups;
@@ -665,5 +672,6 @@ extern "C" int pk2_den_graph_debug_persist(const pk2_den_graph* g, int which, in
   if (row_begin_out) memcpy(row_begin_out, h.row_begin.data(), h.row_begin.size() * sizeof(int32_t));
   if (grp_begin_out) memcpy(grp_begin_out, h.grp_begin.data(), h.grp_begin.size() * sizeof(int32_t));
   if (row_leak_out) memcpy(row_leak_out, h.row_leak.data(), h.row_leak.size() * sizeof(float));
+  if (row_psum_out) memcpy(row_psum_out, h.row_psum.data(), h.row_psum.size() * sizeof(float));
   return PK2_OK;
 }

@@ -94,6 +94,7 @@ struct HostPersist {
   std::vector<int32_t> row_begin;  // [kPR+1] first row of a rank
   std::vector<int32_t> grp_begin;  // [kPR+1] first group (real state) of a rank
   std::vector<float> row_leak;     // [rows]   sum of pi[src]*prob over the arcs of a row
+  std::vector<float> row_psum;     // [rows]   sum of prob over the arcs of a row
 };
 struct DevPersist {
   const float* prob = nullptr;
@@ -104,6 +105,7 @@ struct DevPersist {
   const int32_t* row_begin = nullptr;
   const int32_t* grp_begin = nullptr;
   const float* row_leak = nullptr;
+  const float* row_psum = nullptr;
   int max_rows = 0, max_groups = 0;
   int estep = 1;
 };

@@ -15,8 +15,8 @@ constexpr size_t kDenPersistMaxLds = 160 * 1024 - 256;
 
 // Runs the forward and backward recursions of all N sequences (NG = 1 layouts: one group per sequence; `p` as the
 // launch-per-frame kernels would receive it, `xv` = [G][Tmax][V] exp(logit) per virtual state).  Leaves alpha, alphav,
-// apart, asum, the btilde' slots of `beta` and bpart exactly where den_step_sx<1> leaves them, with kPR partial sums per
-// frame.  *ran = false when the device failed the first-use verification (the caller then replays the frame launches).
+// apart, asum, the btilde' slots of `beta` and bpart where den_step_sx<1> leaves them, with kPR partial sums per frame
+// (bpart: shares whose sum over the ranks is the frame's sum, not sums over a rank's own states).  *ran = false when the device failed the first-use verification (the caller then replays the frame launches).
 int den_persist_launch(pk2_den_graph* g, const DenParams& p, const float* xv, const int32_t* lengths_host, int N,
                        hipStream_t stream, bool* ran);
 // After den_finalize: a launch in which a poll timed out turns den_lp into NaN instead of passing for a result.

@@ -276,6 +276,15 @@ def test_den_graph_persistent_layouts(case, estep, monkeypatch):
     want_leak = np.zeros(S_)
     np.add.at(want_leak, dst[keep], pi[src[keep]] * prob[keep])
     assert np.abs(np.bincount(vstate, weights=pf["row_leak"], minlength=S_) - want_leak).max() < 1e-6
+    want_psum = np.zeros(S_)
+    np.add.at(want_psum, dst[keep], prob[keep])
+    assert np.abs(np.bincount(vstate, weights=pf["row_psum"], minlength=S_) - want_psum).max() < 1e-5
+    # the backward kernel predicts a frame's sums over the states from the vector it gathers (one exchange per frame):
+    # sum_s pi[s] b'[s] = sum_v w[v] row_leak[v] + the peeled loops, sum_s b'[s] = sum_v w[v] row_psum[v] + loops
+    w = be[vstate] * xv
+    b_new = _emulate_persist(pb, w) + lprob * xl * be
+    assert abs((pi * b_new).sum() - ((w * pf["row_leak"]).sum() + (pi * lprob * xl * be).sum())) < 1e-6 * max(1.0, (pi * b_new).sum())
+    assert abs(b_new.sum() - ((w * pf["row_psum"]).sum() + (lprob * xl * be).sum())) < 1e-5 * max(1.0, b_new.sum())
     got = _emulate_persist(pb, be[vstate] * xv) + lprob * xl * be
     assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
 
