@@ -182,10 +182,14 @@ class _LstmAmFunction(torch.autograd.Function):
                 # dW_hh[d] = sum_t dg_d[t]^T h_d[t-1] (reverse direction: h_d[t+1]); time-major => row shift by B
                 if T > 1:
                     k = (T - 1) * B
-                    _gemm(1, 0, 4 * H, H, k, _p(dgx, B * G), G, _p(y), D * H, _p(gw_hh), H)
                     if D == 2:
-                        _gemm(1, 0, 4 * H, H, k, _p(dgx, 4 * H), G, _p(y, B * D * H + H), D * H,
-                              _p(gw_hh, 4 * H * H), H)
+                        # both directions in one batched launch (matrix 1 = matrix 0 + these strides: the reverse
+                        # direction pairs dg[t] with h[t+1])
+                        _lib.check(L.pk2_gemm_f32_batched(1, 0, 4 * H, H, k, 1.0, _p(dgx, B * G), G, 4 * H - B * G, 0,
+                                                          _p(y), D * H, B * D * H + H, 0, 0.0, _p(gw_hh), H,
+                                                          4 * H * H, 0, 2, 1, _lib.stream_ptr()))
+                    else:
+                        _gemm(1, 0, 4 * H, H, k, _p(dgx, B * G), G, _p(y), D * H, _p(gw_hh), H)
                 else:
                     gw_hh.zero_()
                 m._bucket_ready("lstm.l%d" % l)
