@@ -14,6 +14,7 @@
 // Tensors and their layouts are those of lstm_persist.hip (y pre-filled with the sentinel, gates / cells kept for the
 // backward pass), so the two implementations are interchangeable behind pk2_lstm_layer_fwd / _bwd.
 // Replaces the same cuDNN RNN (reference models/lstm.py:49-58).
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 
@@ -416,6 +417,14 @@ static int seq_scratch(hipStream_t stream, SeqScratch** out) {
   return PK2_OK;
 }
 
+// Teams per XCD of a launch: with more than 8 pairs a second team per XCD takes its own pairs from the queue at the same
+// time (two workgroups per CU; a recurrence is latency-bound, two of them interleave almost for free).
+static int seq_teams(int pairs) {
+  const char* env = getenv("PK2_LSTM_SEQ_TEAMS");
+  const int most = env ? std::max(1, std::min(atoi(env), kSeqTeams)) : 2;
+  return std::max(1, std::min(most, (pairs + 7) / 8));
+}
+
 bool lstm_seq_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_SEQ");
   if (env && atoi(env) == 0) return false;
@@ -439,7 +448,7 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(y), (int)kSeqSentinel, (size_t)T * B * D * H, stream));
   SeqFwdParams p{gx, whh, bhh, y, gates, cells, B, T, D};
-  hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs), dim3(256), 0, stream, p, sc->ctl);
+  hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   PK2_LAUNCH_CHECK();
   if (g_seq_state < 0) {                 // first use on this device: every pair done, nobody timed out?
     SeqCtl* h = new SeqCtl;
@@ -465,7 +474,7 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * kSeqTeams * kSeqMailFloats, stream));
   SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D};
-  hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs), dim3(256), 0, stream, p, sc->ctl);
+  hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;
