@@ -443,14 +443,24 @@ __device__ int compact_links(const UttView& V, Shared& sh, int l0, int l1, float
 // workgroup.  This is the only serial part of the pruning: whether a link survives is a function of the final extra
 // costs alone, so the links are dropped, and the epsilon-DAG depths computed, afterwards by prune_segments, segment
 // by segment in parallel.
-__device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared& sh, int n, int T, int s_tok_end,
-                                 int s_link_end) {
+__device__ __forceinline__ float block_min(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int k = 1; k < kLatWaves; ++k) r = fminf(r, red[k]);
+  return r;
+}
+
+// ---- final costs (ComputeFinalCosts): extra costs of the last frame's tokens; `red` = kLatWaves floats of LDS ----
+__device__ void final_costs(const DecodeParams& p, const UttView& V, float* red, int T, int s_tok_end, int* any_final,
+                            float* best) {
   const int tid = threadIdx.x;
   int32_t* ts = V.ts; float* tc = V.tc; float* te = V.te; float* tf = V.tf;
-  int32_t* ftok = V.ftok; int32_t* seg = V.seg;
-  int4* lrec = V.lrec;
-  // ---- final costs (ComputeFinalCosts) ----
-  const int fT0 = ftok[T], fT1 = s_tok_end;
+  const int fT0 = V.ftok[T], fT1 = s_tok_end;
   int anyf = 0;
   for (int i = fT0 + tid; i < fT1; i += kLatThreads) anyf |= (p.g.final_cost[ts[i]] < INFINITY);
   anyf = __syncthreads_or(anyf);
@@ -460,16 +470,23 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
     tf[i] = fc;
     if (fc < INFINITY) bmin = fminf(bmin, tc[i] + fc);
   }
-  const float best_final = block_min(bmin, sh);
+  const float best_final = block_min(bmin, red);
   for (int i = fT0 + tid; i < fT1; i += kLatThreads) {
     const float fc = tf[i];
     te[i] = fc < INFINITY ? (tc[i] + fc) - best_final : INFINITY;
   }
   for (int i = tid; i < s_tok_end; i += kLatThreads) V.tl[i] = 0;
   __syncthreads();
+  *any_final = anyf; *best = best_final;
+}
 
-  // ---- lattice-beam pruning, last frame first (PruneForwardLinksFinal / PruneForwardLinks) ----
-  uint32_t* teu = reinterpret_cast<uint32_t*>(te);   // extra costs are >= 0: their bit patterns order like the floats
+// ---- lattice-beam pruning, last frame first (PruneForwardLinksFinal / PruneForwardLinks), everything in global memory ----
+__device__ void extra_costs_global(const DecodeParams& p, const UttView& V, int T) {
+  const int tid = threadIdx.x;
+  float* tc = V.tc;
+  int32_t* seg = V.seg;
+  int4* lrec = V.lrec;
+  uint32_t* teu = reinterpret_cast<uint32_t*>(V.te);   // extra costs are >= 0: their bit patterns order like the floats
   const float lbeam = p.lattice_beam;
   for (int t = T; t >= 0; --t) {
     // epsilon links inside frame t, to the fixed point
@@ -491,7 +508,6 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
       }
       if (!__syncthreads_or(changed)) break;
     }
-    LAT_T(8);
     // emitting links t-1 -> t: the extra costs of frame t are final; they give the extra costs of their sources
     if (t > 0) {
       const int m0 = seg[2 * t - 1], m1 = seg[2 * t];
@@ -512,9 +528,15 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
       }
     }
     __syncthreads();
-    LAT_T(10);
   }
-  if (tid == 0) {
+}
+
+__device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared& sh, int n, int T, int s_tok_end,
+                                 int s_link_end) {
+  int anyf; float best_final;
+  final_costs(p, V, sh.redf, T, s_tok_end, &anyf, &best_final);
+  extra_costs_global(p, V, T);
+  if (threadIdx.x == 0) {
     LatUtt* o = p.L.utt + n;
     o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
   }

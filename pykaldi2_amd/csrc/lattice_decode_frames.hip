@@ -22,7 +22,7 @@
 // stores of the same launch; everything that crosses workgroups inside a launch is an agent-scope atomic (state
 // table, counters).  Token costs and the kept link SET are those of the one-workgroup decoder and of the oracle
 // (minima and sets do not depend on the order of the atomics); token and link numbering differ.
-// Final costs and lattice pruning run in finish_and_prune (one workgroup per utterance), unchanged.
+// Final costs and lattice pruning: one workgroup per utterance (lat_frames_finish below, extra costs in LDS).
 #include <map>
 
 #include "lattice_decode_common.h"
@@ -551,25 +551,155 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodePara
 }
 
 // ---- after the last frame: final costs + lattice-beam pruning, or the failure report ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodeParams p) {
-  __shared__ Shared sh;
+// The pruning pass is a min-plus recursion over the frames, last frame first: extra[s] = min over the links s -> d of
+// extra[d] + (cost[s] + link cost - cost[d]), with an epsilon fixed point inside every frame.  One workgroup per utterance
+// walks it; with everything in global memory a frame cost ~150 us (every epsilon round = three dependent round trips to
+// L2 plus returning atomics).  Here the bracketed part of every link is computed beforehand by a parallel pass
+// (lat_link_delta: it depends on the token costs only), and the extra costs of the frame being finished and of the frame
+// before it live in LDS (order-preserving bit patterns, ds_min): a round is LDS traffic and a barrier.  The arithmetic and
+// its order are those of finish_and_prune (lattice_decode_common.h: the one-workgroup decoder's pass).  A frame with more
+// tokens than the LDS arrays hold (frame 0 has one per word of the vocabulary) is worked on in global memory.
+constexpr int kFinEps = 8;          // epsilon links per thread kept in registers over the rounds of a frame
+extern __shared__ __attribute__((aligned(16))) uint32_t lat_fin_smem[];
+
+__global__ void __launch_bounds__(256) lat_link_delta(const DecodeParams p) {
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const LatUtt U = p.L.utt[n];
+  if (p.L.frame[n].status != kLatOk) return;
+  const UttView V = make_view(p, n, U);
+  float* delta = p.L.link_delta + U.link_base;
+  for (int k = blockIdx.x; k <= 2 * U.T; k += gridDim.x) {      // segment k: epsilon links of frame k/2 (even), k/2 -> k/2+1 (odd)
+    const int l0 = V.seg[k], l1 = V.seg[k + 1];
+    if (k & 1) {
+      for (int l = l0 + tid; l < l1; l += 256) {
+        const int4 r = V.lrec[l];
+        delta[l] = __fadd_rn(__fadd_rn(V.tc[r.x], V.lac[l]), __int_as_float(r.w)) - V.tc[r.y];
+      }
+    } else {
+      for (int l = l0 + tid; l < l1; l += 256) {
+        const int4 r = V.lrec[l];
+        delta[l] = (V.tc[r.x] + __int_as_float(r.w)) - V.tc[r.y];
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodeParams p, int cap) {
+  __shared__ float s_redf[kLatWaves];
   const int n = blockIdx.x, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
   const UttView V = make_view(p, n, U);
   const LatFrame* F = p.L.frame + n;
-  if (tid == 0) {
-    sh.n_heavy = 0;
-#ifdef PK2_LAT_PROFILE
-    for (int k = 0; k < 16; ++k) sh.prof[k] = 0;
-    sh.prof_last = wall_clock64();
-#endif
-  }
-  __syncthreads();
   if (F->status != kLatOk) {
     if (tid == 0) { p.L.utt[n].status = F->status; p.L.utt[n].n_tok = F->f1; p.L.utt[n].n_link = F->link_end; }
     return;
   }
-  finish_and_prune(p, V, sh, n, U.T, F->f1, F->link_end);
+  const int T = U.T, s_tok_end = F->f1, s_link_end = F->link_end;
+  int anyf; float best_final;
+  final_costs(p, V, s_redf, T, s_tok_end, &anyf, &best_final);
+  uint32_t* A = lat_fin_smem;            // extra costs of frame t (when it fits: at most `cap` tokens)
+  uint32_t* B = lat_fin_smem + cap;      // ... of frame t-1, being collected
+  uint32_t* teu = reinterpret_cast<uint32_t*>(V.te);
+  const float* delta = p.L.link_delta + U.link_base;
+  const float lbeam = p.lattice_beam;
+  int base = V.ftok[T], cnt = s_tok_end - base;
+  bool a_lds = cnt <= cap;               // a frame with more tokens (frame 0: one per word) is worked on in global memory
+  if (a_lds)
+    for (int i = tid; i < cnt; i += kLatThreads) A[i] = teu[base + i];
+  __syncthreads();
+  for (int t = T; t >= 0; --t) {
+    // epsilon links inside frame t, to the fixed point
+    const int e0 = V.seg[2 * t], e1 = V.seg[2 * t + 1];
+    if (e1 > e0 && a_lds) {
+      int es[kFinEps], ed[kFinEps]; float el[kFinEps];
+#pragma unroll
+      for (int q = 0; q < kFinEps; ++q) {
+        const int l = e0 + tid + q * kLatThreads;
+        es[q] = -1; ed[q] = 0; el[q] = 0.f;
+        if (l < e1) { const int4 r = V.lrec[l]; es[q] = r.x - base; ed[q] = r.y - base; el[q] = delta[l]; }
+      }
+      auto relax = [&](int s, int d, float dl) -> int {
+        const float x = __uint_as_float(A[d]);
+        if (x < INFINITY) {
+          float le = x + dl;
+          if (le <= lbeam) {
+            le = fmaxf(le, 0.f);
+            const uint32_t k = __float_as_uint(le);
+            if (k < atomicMin(&A[s], k)) return 1;
+          }
+        }
+        return 0;
+      };
+      for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
+        int changed = 0;
+#pragma unroll
+        for (int q = 0; q < kFinEps; ++q)
+          if (es[q] >= 0) changed |= relax(es[q], ed[q], el[q]);
+        for (int l = e0 + tid + kFinEps * kLatThreads; l < e1; l += kLatThreads) {
+          const int4 r = V.lrec[l];
+          changed |= relax(r.x - base, r.y - base, delta[l]);
+        }
+        if (!__syncthreads_or(changed)) break;
+      }
+    } else if (e1 > e0) {
+      for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
+        int changed = 0;
+        for (int l = e0 + tid; l < e1; l += kLatThreads) {
+          const int4 r = V.lrec[l];
+          const float x = __uint_as_float(ld_coherent(&teu[r.y]));
+          if (x < INFINITY) {
+            float le = x + delta[l];
+            if (le <= lbeam) {
+              le = fmaxf(le, 0.f);
+              const uint32_t k = __float_as_uint(le);
+              if (k < atomicMin(&teu[r.x], k)) changed = 1;
+            }
+          }
+        }
+        if (!__syncthreads_or(changed)) break;
+      }
+    }
+    // the extra costs of frame t are final
+    if (a_lds)
+      for (int i = tid; i < cnt; i += kLatThreads) teu[base + i] = A[i];
+    if (t > 0) {
+      const int pbase = V.ftok[t - 1], pcnt = base - pbase;
+      const bool b_lds = pcnt <= cap;
+      if (b_lds)
+        for (int i = tid; i < pcnt; i += kLatThreads) B[i] = 0x7f800000u;
+      __syncthreads();
+      // emitting links t-1 -> t
+      const int m0 = V.seg[2 * t - 1], m1 = V.seg[2 * t];
+      for (int l0 = m0 + tid; l0 < m1; l0 += 4 * kLatThreads) {
+        int2 r[4]; float dl[4]; float x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (l0 + q * kLatThreads < m1) {
+            r[q] = *reinterpret_cast<const int2*>(&V.lrec[l0 + q * kLatThreads]);
+            dl[q] = delta[l0 + q * kLatThreads];
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (l0 + q * kLatThreads < m1) x[q] = __uint_as_float(a_lds ? A[r[q].y - base] : ld_coherent(&teu[r[q].y]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (l0 + q * kLatThreads >= m1 || !(x[q] < INFINITY)) continue;
+          const float le = x[q] + dl[q];
+          if (le <= lbeam) {
+            const uint32_t k = __float_as_uint(fmaxf(le, 0.f));
+            if (b_lds) atomicMin(&B[r[q].x - pbase], k); else atomicMin(&teu[r[q].x], k);
+          }
+        }
+      }
+      __syncthreads();
+      uint32_t* tmp = A; A = B; B = tmp;
+      base = pbase; cnt = pcnt; a_lds = b_lds;
+    }
+  }
+  if (tid == 0) {
+    LatUtt* o = p.L.utt + n;
+    o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
+  }
 }
 
 static StepGraphs g_lat_graphs;
@@ -627,7 +757,18 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
     hipLaunchKernelGGL(lat_frames_close, all, thr, 0, s, pk, cnt, j);
   });
   if (rc) return rc;
-  hipLaunchKernelGGL(lat_frames_finish, dim3(N), thr, 0, stream, p);
+  // lattice-beam pruning: the per-link constants in parallel, then the serial pass with two frames' extra costs in LDS
+  constexpr int kFinCap = 19456;                   // tokens of a frame the LDS arrays hold (2 x 76 KB)
+  static bool attr = false;
+  if (!attr) {
+    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_frames_finish), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * kFinCap * (int)sizeof(uint32_t)));
+    attr = true;
+  }
+  hipLaunchKernelGGL(lat_link_delta, dim3(256, N), dim3(256), 0, stream, p);
+  const char* cap_env = getenv("PK2_LAT_FIN_CAP");       // (test hook: 0 sends every utterance down the global-memory pass)
+  const int cap = cap_env ? std::max(0, std::min(kFinCap, atoi(cap_env))) : kFinCap;
+  hipLaunchKernelGGL(lat_frames_finish, dim3(N), thr, 2 * kFinCap * sizeof(uint32_t), stream, p, cap);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -13,7 +13,9 @@
 // the pruning pass), workgroup barriers in between.  The alpha and the beta recursion of an utterance do not depend
 // on each other: they run side by side in two workgroups (so do the two expected-accuracy recursions of sMBR / MPFE),
 // and the posteriors, which are local to a frame, are computed by 64 workgroups per utterance.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "lattice_internal.h"
 
@@ -123,37 +125,92 @@ __device__ __forceinline__ double final_like(const FbParams& p, const FbView& v,
 
 // alpha (workgroup x = 0) and beta (x = 1) are independent recursions: they run side by side.  x = 0 also leaves the
 // total log-likelihood in the utterance's frame state.
-__global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p) {
+// The values of the frame being ACCUMULATED live in LDS (one array of doubles; the log-adds are 64-bit LDS
+// compare-and-swaps, the epsilon levels of the frame never leave the CU); a finished frame is written back, and the
+// next frame reads its sources from there.  A frame with more than `cap` tokens (frame 0: a token per word) is
+// accumulated in global memory as before.  (With everything in global memory a frame cost ~14 us of dependent round
+// trips and CAS loops through L2.)
+constexpr int kFbEps = 4;       // epsilon links per thread kept in registers over the levels of a frame
+extern __shared__ __attribute__((aligned(16))) double lat_fb_smem[];
+
+__device__ __forceinline__ void lds_log_add(double* addr, double v) {
+  if (v == -INFINITY) return;
+  unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *a, assumed;
+  do {
+    assumed = old;
+    const double nv = log_add(__longlong_as_double((long long)assumed), v);
+    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(nv));
+  } while (old != assumed);
+}
+
+__global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int cap) {
   __shared__ double red[kFbWaves];
+  double* cur = lat_fb_smem;
   const int n = blockIdx.y, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
   if (U.status != kLatOk) { if (tid == 0 && blockIdx.x == 0) p.out[n] = NAN; return; }
   const FbView v = fb_view(p, n, U);
   const int T = v.T;
   const int fT0 = v.ftok[T], fT1 = v.ftok[T + 1];
-  if (blockIdx.x == 0) {
-    for (int i = tid; i < v.nt; i += kFbThreads) { v.alpha[i] = -INFINITY; v.af[i] = 0.0; }
+  const bool fwd = blockIdx.x == 0;
+  double* val = fwd ? v.alpha : v.beta;          // the recursion's values in global memory
+  for (int i = tid; i < v.nt; i += kFbThreads) { val[i] = -INFINITY; (fwd ? v.af : v.ab)[i] = 0.0; }
+  if (fwd)
     for (int t = tid; t < T; t += kFbThreads) v.ref_post[t] = 0.0;
-    __syncthreads();
-    if (tid == 0) v.alpha[0] = 0.0;
-    __syncthreads();
+  __syncthreads();
+  // Epsilon links of frame t inside the LDS array (or global memory), level by level; dir = +1: source level ascending
+  // and values flow src -> dst (alpha), -1: descending and dst -> src (beta).
+  auto eps_levels = [&](int t, int base, bool lds) {
+    const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
+    const int nlev = v.maxlev[t];
+    if (nlev <= 0 || e1 <= e0) return;
+    int es[kFbEps], ed[kFbEps], el[kFbEps]; double ek[kFbEps];
+#pragma unroll
+    for (int q = 0; q < kFbEps; ++q) {
+      const int l = e0 + tid + q * kFbThreads;
+      es[q] = -1; ed[q] = 0; el[q] = -1; ek[q] = 0.0;
+      if (l < e1) { const int4 r = v.lrec[l]; es[q] = r.x; ed[q] = r.y; el[q] = v.tl[r.x]; ek[q] = link_like(p, v, r, l); }
+    }
+    auto one = [&](int s, int d, double like) {
+      const int from = fwd ? s : d, to = fwd ? d : s;
+      if (lds) lds_log_add(&cur[to - base], cur[from - base] + like);
+      else atomic_log_add(&val[to], ldc(&val[from]) + like);
+    };
+    for (int k = 0; k < nlev; ++k) {
+      const int lev = fwd ? k : nlev - 1 - k;
+#pragma unroll
+      for (int q = 0; q < kFbEps; ++q)
+        if (es[q] >= 0 && el[q] == lev) one(es[q], ed[q], ek[q]);
+      for (int l = e0 + tid + kFbEps * kFbThreads; l < e1; l += kFbThreads) {
+        const int4 r = v.lrec[l];
+        if (v.tl[r.x] == lev) one(r.x, r.y, link_like(p, v, r, l));
+      }
+      __syncthreads();
+    }
+  };
+  if (fwd) {
     for (int t = 0; t <= T; ++t) {
+      const int base = v.ftok[t], cnt = v.ftok[t + 1] - base;
+      const bool lds = cnt <= cap;
+      if (lds)
+        for (int i = tid; i < cnt; i += kFbThreads) cur[i] = (t == 0 && i == 0) ? 0.0 : -INFINITY;
+      else if (t == 0 && tid == 0)
+        val[0] = 0.0;
+      __syncthreads();
       if (t > 0) {
         const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
         for (int l = m0 + tid; l < m1; l += kFbThreads) {
           const int4 r = v.lrec[l];
-          atomic_log_add(&v.alpha[r.y], ldc(&v.alpha[r.x]) + link_like(p, v, r, l));
+          const double x = ldc(&val[r.x]) + link_like(p, v, r, l);
+          if (lds) lds_log_add(&cur[r.y - base], x); else atomic_log_add(&val[r.y], x);
         }
         __syncthreads();
       }
-      const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
-      for (int lev = 0; lev < v.maxlev[t]; ++lev) {
-        for (int l = e0 + tid; l < e1; l += kFbThreads) {
-          const int4 r = v.lrec[l];
-          if (v.tl[r.x] == lev) atomic_log_add(&v.alpha[r.y], ldc(&v.alpha[r.x]) + link_like(p, v, r, l));
-        }
-        __syncthreads();
-      }
+      eps_levels(t, base, lds);
+      if (lds)
+        for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = cur[i];
+      __syncthreads();          // (the frame's values are in memory before the next frame gathers them)
     }
     // total likelihood over the final tokens (stable log-sum-exp)
     double mx = -INFINITY;
@@ -166,27 +223,32 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p) {
     sm = block_sum_d(sm, red);
     if (tid == 0) v.F->fb_tot = mx + log(sm);
   } else {
-    for (int i = tid; i < v.nt; i += kFbThreads) { v.beta[i] = -INFINITY; v.ab[i] = 0.0; }
-    __syncthreads();
-    for (int i = fT0 + tid; i < fT1; i += kFbThreads)
-      if (v.tf[i] < INFINITY) v.beta[i] = final_like(p, v, i);
+    int base = fT0, cnt = fT1 - fT0;
+    bool lds = cnt <= cap;
+    for (int i = tid; i < cnt; i += kFbThreads) {
+      const double b0 = v.tf[base + i] < INFINITY ? final_like(p, v, base + i) : -INFINITY;
+      if (lds) cur[i] = b0; else val[base + i] = b0;
+    }
     __syncthreads();
     for (int t = T; t >= 0; --t) {
-      const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
-      for (int lev = v.maxlev[t] - 1; lev >= 0; --lev) {
-        for (int l = e0 + tid; l < e1; l += kFbThreads) {
-          const int4 r = v.lrec[l];
-          if (v.tl[r.x] == lev) atomic_log_add(&v.beta[r.x], ldc(&v.beta[r.y]) + link_like(p, v, r, l));
-        }
-        __syncthreads();
-      }
+      eps_levels(t, base, lds);
+      if (lds)
+        for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = cur[i];
+      __syncthreads();
       if (t > 0) {
+        const int pbase = v.ftok[t - 1], pcnt = base - pbase;
+        const bool plds = pcnt <= cap;
+        if (plds)
+          for (int i = tid; i < pcnt; i += kFbThreads) cur[i] = -INFINITY;
+        __syncthreads();
         const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
         for (int l = m0 + tid; l < m1; l += kFbThreads) {
           const int4 r = v.lrec[l];
-          atomic_log_add(&v.beta[r.x], ldc(&v.beta[r.y]) + link_like(p, v, r, l));
+          const double x = ldc(&val[r.y]) + link_like(p, v, r, l);
+          if (plds) lds_log_add(&cur[r.x - pbase], x); else atomic_log_add(&val[r.x], x);
         }
         __syncthreads();
+        base = pbase; cnt = pcnt; lds = plds;
       }
     }
   }
@@ -309,7 +371,16 @@ static int fb_launch(int mode, const pk2_lattice_batch* b, void* workspace, FbPa
   PK2_REQUIRE(b->decoded, "lattice forward-backward: pk2_lattice_decode has not run on this batch");
   lattice_carve(b, workspace, &p.L);
   const dim3 two(2, b->N), many(64, b->N), thr(kFbThreads);
-  hipLaunchKernelGGL(lat_fb_alpha_beta, two, thr, 0, stream, p);
+  constexpr int kFbCap = 19456;                    // tokens of a frame the LDS array holds (152 KB of doubles)
+  static bool attr = false;
+  if (!attr) {
+    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_fb_alpha_beta), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kFbCap * (int)sizeof(double)));
+    attr = true;
+  }
+  const char* cap_env = getenv("PK2_LAT_FIN_CAP");       // (test hook, shared with the pruning pass of the decoder)
+  const int cap = cap_env ? std::max(0, std::min(kFbCap, atoi(cap_env))) : kFbCap;
+  hipLaunchKernelGGL(lat_fb_alpha_beta, two, thr, kFbCap * sizeof(double), stream, p, cap);
   if (mode == 0) {
     hipLaunchKernelGGL(lat_fb_posteriors<0>, many, thr, 0, stream, p);
   } else {

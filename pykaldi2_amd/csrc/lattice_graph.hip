@@ -165,6 +165,7 @@ size_t lattice_carve(const pk2_lattice_batch* b, void* base, LatPtrs* out) {
   L.acc_f = c.take<double>(b->tok_total); L.acc_b = c.take<double>(b->tok_total);
   L.link_rec = c.take<int4>(b->link_total);
   L.link_ac = c.take<float>(b->link_total);
+  L.link_delta = c.take<float>(b->link_total);
   L.e_rec = c.take<int4>(b->graph->e_dst.size());
   L.frame_tok = c.take<int32_t>(b->frame_total); L.seg_off = c.take<int32_t>(b->frame_total);
   L.seg_kept = c.take<int32_t>(b->frame_total); L.frame_maxlev = c.take<int32_t>(b->frame_total);

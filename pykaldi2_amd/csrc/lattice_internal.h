@@ -77,6 +77,7 @@ struct LatPtrs {
   double* alpha; double* beta; double* acc_f; double* acc_b;
   int4* link_rec;        // {source token, destination token, transition-id (0 = epsilon), graph cost bits}: one 16-byte access per link
   float* link_ac;        // acoustic cost
+  float* link_delta;     // scratch of the lattice-beam pruning: the part of a link's extra cost that its ends' costs fix
   int4* e_rec;           // per call: emitting arcs of HCLG packed as {dst state, transition-id, weight bits, pdf}
   int32_t* frame_tok;    // per utterance [T+2]: first token of each frame (utterance-local), [T+1] = end
   int32_t* seg_off;      // per utterance [2(T+1)+1]: link segments: 2t = epsilon links inside frame t, 2t+1 = t -> t+1

@@ -48,8 +48,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("pruning_pass", ["lds", "mixed", "global_memory"])
 @pytest.mark.parametrize("case", CASES)
-def test_decoder_matches_oracle(case):
+def test_decoder_matches_oracle(case, pruning_pass, monkeypatch):
+    if pruning_pass != "lds":      # frames with more tokens than the LDS arrays hold are pruned in global memory
+        monkeypatch.setenv("PK2_LAT_FIN_CAP", "0" if pruning_pass == "global_memory" else "60")
     nw, P, T, seed, beam, lb, ac, maxa, mina = case
     g, tm, ll, _ = _setup(nw, P, T, seed)
     want = lr.decode(_ref_graph(g), ll, tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac))
@@ -73,8 +76,11 @@ def _ali_near_lattice(rng, lat_ref, P):
     return ali
 
 
+@pytest.mark.parametrize("frame_values", ["lds", "mixed", "global_memory"])
 @pytest.mark.parametrize("case", CASES[:3])
-def test_mmi_matches_oracle(case):
+def test_mmi_matches_oracle(case, frame_values, monkeypatch):
+    if frame_values != "lds":      # frames with more tokens than the LDS array holds are accumulated in global memory
+        monkeypatch.setenv("PK2_LAT_FIN_CAP", "0" if frame_values == "global_memory" else "60")
     nw, P, T, seed, beam, lb, ac, maxa, mina = case
     g, tm, ll, rng = _setup(nw, P, T, seed)
     want = lr.decode(_ref_graph(g), ll, tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac))
