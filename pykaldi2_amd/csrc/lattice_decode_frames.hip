@@ -559,7 +559,8 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodePara
 // before it live in LDS (order-preserving bit patterns, ds_min): a round is LDS traffic and a barrier.  The arithmetic and
 // its order are those of finish_and_prune (lattice_decode_common.h: the one-workgroup decoder's pass).  A frame with more
 // tokens than the LDS arrays hold (frame 0 has one per word of the vocabulary) is worked on in global memory.
-constexpr int kFinEps = 8;          // epsilon links per thread kept in registers over the rounds of a frame
+constexpr int kFinEps = 8;  // epsilon links per thread kept in registers over the rounds of a frame
+constexpr int kFinEmit = 12;       // emitting links per thread fetched ahead of the epsilon rounds
 extern __shared__ __attribute__((aligned(16))) uint32_t lat_fin_smem[];
 
 __global__ void __launch_bounds__(256) lat_link_delta(const DecodeParams p) {
@@ -607,7 +608,23 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
   if (a_lds)
     for (int i = tid; i < cnt; i += kLatThreads) A[i] = teu[base + i];
   __syncthreads();
+#ifdef PK2_LAT_FIN_DEBUG
+  long long ph[6] = {0, 0, 0, 0, 0, 0}, last = wall_clock64(); int nrounds = 0;
+#define FIN_T(k) do { __syncthreads(); const long long now_ = wall_clock64(); ph[k] += now_ - last; last = now_; } while (0)
+#else
+#define FIN_T(k) do { } while (0)
+#endif
   for (int t = T; t >= 0; --t) {
+    // the emitting links t-1 -> t do not depend on the epsilon rounds below: their loads are issued first and land
+    // while the rounds run (one exposed round trip to memory per frame instead of two)
+    const int m0 = t > 0 ? V.seg[2 * t - 1] : 0, m1 = t > 0 ? V.seg[2 * t] : 0;
+    int2 mr[kFinEmit]; float md[kFinEmit];
+#pragma unroll
+    for (int q = 0; q < kFinEmit; ++q) {
+      const int l = m0 + tid + q * kLatThreads;
+      mr[q] = make_int2(0, 0); md[q] = 0.f;
+      if (l < m1) { mr[q] = *reinterpret_cast<const int2*>(&V.lrec[l]); md[q] = delta[l]; }
+    }
     // epsilon links inside frame t, to the fixed point
     const int e0 = V.seg[2 * t], e1 = V.seg[2 * t + 1];
     if (e1 > e0 && a_lds) {
@@ -625,7 +642,9 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
           if (le <= lbeam) {
             le = fmaxf(le, 0.f);
             const uint32_t k = __float_as_uint(le);
-            if (k < atomicMin(&A[s], k)) return 1;
+            // (a token with thousands of links -- silence, word ends -- serialises its ds_min's: only those that would
+            // lower the value are issued; the plain read of one address by many lanes is a broadcast)
+            if (k < A[s] && k < atomicMin(&A[s], k)) return 1;
           }
         }
         return 0;
@@ -639,6 +658,9 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
           const int4 r = V.lrec[l];
           changed |= relax(r.x - base, r.y - base, delta[l]);
         }
+#ifdef PK2_LAT_FIN_DEBUG
+        ++nrounds;
+#endif
         if (!__syncthreads_or(changed)) break;
       }
     } else if (e1 > e0) {
@@ -659,43 +681,45 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
         if (!__syncthreads_or(changed)) break;
       }
     }
+    FIN_T(0);
     // the extra costs of frame t are final
     if (a_lds)
       for (int i = tid; i < cnt; i += kLatThreads) teu[base + i] = A[i];
+    FIN_T(1);
     if (t > 0) {
       const int pbase = V.ftok[t - 1], pcnt = base - pbase;
       const bool b_lds = pcnt <= cap;
       if (b_lds)
         for (int i = tid; i < pcnt; i += kLatThreads) B[i] = 0x7f800000u;
       __syncthreads();
+      FIN_T(2);
       // emitting links t-1 -> t
-      const int m0 = V.seg[2 * t - 1], m1 = V.seg[2 * t];
-      for (int l0 = m0 + tid; l0 < m1; l0 += 4 * kLatThreads) {
-        int2 r[4]; float dl[4]; float x[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (l0 + q * kLatThreads < m1) {
-            r[q] = *reinterpret_cast<const int2*>(&V.lrec[l0 + q * kLatThreads]);
-            dl[q] = delta[l0 + q * kLatThreads];
-          }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (l0 + q * kLatThreads < m1) x[q] = __uint_as_float(a_lds ? A[r[q].y - base] : ld_coherent(&teu[r[q].y]));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (l0 + q * kLatThreads >= m1 || !(x[q] < INFINITY)) continue;
-          const float le = x[q] + dl[q];
-          if (le <= lbeam) {
-            const uint32_t k = __float_as_uint(fmaxf(le, 0.f));
-            if (b_lds) atomicMin(&B[r[q].x - pbase], k); else atomicMin(&teu[r[q].x], k);
-          }
+      auto emit = [&](int s, int d, float dl) {
+        const float x = __uint_as_float(a_lds ? A[d - base] : ld_coherent(&teu[d]));
+        if (!(x < INFINITY)) return;
+        const float le = x + dl;
+        if (le <= lbeam) {
+          const uint32_t k = __float_as_uint(fmaxf(le, 0.f));
+          if (b_lds) { if (k < B[s - pbase]) atomicMin(&B[s - pbase], k); } else atomicMin(&teu[s], k);
         }
+      };
+#pragma unroll
+      for (int q = 0; q < kFinEmit; ++q)
+        if (m0 + tid + q * kLatThreads < m1) emit(mr[q].x, mr[q].y, md[q]);
+      for (int l = m0 + tid + kFinEmit * kLatThreads; l < m1; l += kLatThreads) {
+        const int2 r = *reinterpret_cast<const int2*>(&V.lrec[l]);
+        emit(r.x, r.y, delta[l]);
       }
       __syncthreads();
+      FIN_T(3);
       uint32_t* tmp = A; A = B; B = tmp;
       base = pbase; cnt = pcnt; a_lds = b_lds;
     }
   }
+#ifdef PK2_LAT_FIN_DEBUG
+  if (tid == 0) printf("finish utt %d T %d: us per frame: eps (loads + %.1f rounds) %.2f | write back %.2f | init %.2f | emitting %.2f\n", n, T,
+                       (double)nrounds / (T + 1), ph[0] * 0.01 / (T + 1), ph[1] * 0.01 / (T + 1), ph[2] * 0.01 / (T + 1), ph[3] * 0.01 / (T + 1));
+#endif
   if (tid == 0) {
     LatUtt* o = p.L.utt + n;
     o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
