@@ -272,7 +272,9 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // 2356 x 4096 x 1024 (608 tiles) 209 -> 194 us, the data gradients 2356 x 1024 x 6048 / 4096 (152 tiles) 342 -> 321 /
   // 235 -> 219 us; with 256..511 tiles or a remainder behind three or more rounds it was 3-5 % slower, so those keep the
   // split-K / row-band schedules.
-  const bool sk_shape = big_tiles < 256 || (big_tiles >= 512 && big_tiles < 768 && big_tiles % 256 != 0);
+  // (and the Transformer's products -- 76 tiles, K = 512 or 2048 -- are better off with 64x64 tiles / split-K: 27.9 vs
+  // 31.0 ms per TransformerAM step with pieces for every K, 28.5 with pieces from K = 2048)
+  const bool sk_shape = (big_tiles < 256 && K >= 4096) || (big_tiles >= 512 && big_tiles < 768 && big_tiles % 256 != 0);
   if (!no_sk && !force && n0 * bt.n1 == 1 && M > 64 && N > 64 && K >= 512 && (sk_shape || (sk_env && atoi(sk_env) == 2))) {
     const int cus = 256, slots = 3 * cus, min_slabs = 8;            // a piece is at least 128 k deep
     GemmSk sk;
