@@ -44,13 +44,16 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int kq = lane >> 5, li = lane & 31;
-  // Two k-slabs of BK = 16 in flight in registers, two LDS buffers, ONE barrier per slab: while slab kt is multiplied out
-  // of LDS[kt & 1], slab kt+1 (loaded two iterations ago) is written into the other buffer and slabs kt+2 / kt+3 are on
-  // their way from memory.  (Round 1: one LDS buffer, one slab in flight, two barriers per slab -- the global-load
-  // latency of a slab was exposed at every barrier: 38 % MFMA-busy on the model's shapes.)
+  // DEPTH k-slabs of BK = 16 in flight in registers, two LDS buffers, ONE barrier per slab: while slab kt is multiplied
+  // out of LDS[kt & 1], slab kt+1 (loaded DEPTH iterations ago) is written into the other buffer and slabs kt+2 ..
+  // kt+DEPTH+1 are on their way from memory.  (Round 1: one LDS buffer, one slab in flight, two barriers per slab -- the
+  // global-load latency of a slab was exposed at every barrier: 38 % MFMA-busy on the model's shapes.)  A 128x128 tile
+  // multiplies for ~0.85 us per slab: two slabs in flight cover a round trip to memory.  A 64x64 tile multiplies for
+  // ~0.2 us, and products small enough to get 64x64 tiles put one or two workgroups on a CU: six slabs in flight.
+  constexpr int DEPTH = TILES == 1 ? 6 : 2;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
-  float4 ra[2][TILES], rb[2][TILES];
+  float4 ra[DEPTH][TILES], rb[DEPTH][TILES];
   const int nk = (K - kbeg + BK - 1) / BK;
   // interior tile: every slab but possibly the last is loaded through precomputed pointers (gemm_tile.h)
   const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N;
@@ -68,14 +71,16 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
       load_slab<TB, TILES>(B, ldb, n0, kbeg + ks * BK, N, K, vecB, xb);
     }
   };
-  fetch(0, ra[0], rb[0]);
-  if (nk > 1) fetch(1, ra[1], rb[1]);
+  // slab i travels in register stage i % DEPTH
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < nk) fetch(i, ra[i], rb[i]);
   store_slab<!TA, TILES>(As[0], ra[0]);
   store_slab<TB, TILES>(Bs[0], rb[0]);
   __syncthreads();
-  if (nk > 2) fetch(2, ra[0], rb[0]);
+  if (nk > DEPTH) fetch(DEPTH, ra[0], rb[0]);
   auto slab_step = [&](int kt, auto P) {
-    constexpr int cur = decltype(P)::value, nxt = 1 - cur;
+    constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TILES], b[TILES];
@@ -90,15 +95,21 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_slab<!TA, TILES>(As[nxt], ra[nxt]);
-      store_slab<TB, TILES>(Bs[nxt], rb[nxt]);
+      store_slab<!TA, TILES>(As[nxt], ra[sn]);
+      store_slab<TB, TILES>(Bs[nxt], rb[sn]);
     }
     __syncthreads();
-    if (kt + 3 < nk) fetch(kt + 3, ra[nxt], rb[nxt]);
+    if (kt + 1 + DEPTH < nk) fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
   };
-  for (int kt = 0; kt < nk; kt += 2) {
+  for (int kt = 0; kt < nk; kt += DEPTH) {
     slab_step(kt, std::integral_constant<int, 0>());
     if (kt + 1 < nk) slab_step(kt + 1, std::integral_constant<int, 1>());
+    if constexpr (DEPTH > 2) {
+      if (kt + 2 < nk) slab_step(kt + 2, std::integral_constant<int, 2>());
+      if (kt + 3 < nk) slab_step(kt + 3, std::integral_constant<int, 3>());
+      if (kt + 4 < nk) slab_step(kt + 4, std::integral_constant<int, 4>());
+      if (kt + 5 < nk) slab_step(kt + 5, std::integral_constant<int, 5>());
+    }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);

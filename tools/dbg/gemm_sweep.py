@@ -22,7 +22,14 @@ def t(ta, tb, M, N, K, reps=20):
     print("ta=%d tb=%d M=%5d N=%5d K=%5d  %7.1f us  %6.1f TF/s" % (ta, tb, M, N, K, us, 2.0 * M * N * K / us / 1e6), flush=True)
 
 
-for K in (512, 1024, 2048, 4096):
-    t(0, 1, 2356, 4096, K)
-for M in (2048, 2304, 2356, 3072, 4096, 6144):
-    t(0, 1, M, 4096, 1024)
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "small":       # the TransformerAM's products (d_model 512, FFN 2048)
+        for sh in [(0, 1, 2300, 512, 512), (0, 1, 2300, 1536, 512), (0, 1, 2300, 2048, 512), (0, 1, 2300, 512, 2048),
+                   (0, 0, 2300, 512, 512), (0, 0, 2300, 512, 2048), (0, 0, 2300, 2048, 512), (1, 0, 512, 512, 2300),
+                   (1, 0, 2048, 512, 2300), (1, 0, 512, 2048, 2300), (0, 1, 2300, 512, 512)]:
+            t(*sh, reps=50)
+    else:
+        for K in (512, 1024, 2048, 4096):
+            t(0, 1, 2356, 4096, K)
+        for M in (2048, 2304, 2356, 3072, 4096, 6144):
+            t(0, 1, M, 4096, 1024)
