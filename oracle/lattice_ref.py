@@ -36,8 +36,10 @@ path.  Self-made pins (tests/test_oracle_lattice.py):
 One documented difference from Kaldi's serial decoder: ProcessEmitting tightens ``next_cutoff`` while it
 walks the token list, so which arcs above the final cutoff are kept depends on hash-list order; here (and in
 the HIP decoder) an arc is kept iff its cost is below the FINAL cutoff (best new cost + adaptive beam).
-Such arcs lead to tokens above the next frame's cutoff, which are never expanded, so they can only survive
-lattice pruning on the last frame.  Kaldi's per-frame cost offsets (numerical only) are not applied.
+Such arcs lead to tokens above the frame's next_cutoff; they are not closed over epsilon arcs, and they are expanded in
+the next frame only if that frame's own cutoff is looser (max_active binding on one frame and not on the next).
+``decode(..., serial_order=...)`` emulates the serial rule for several walking orders; tests/test_oracle_lattice.py
+measures what it changes in the pruned lattice and in the MMI posteriors.  Kaldi's per-frame cost offsets (numerical only) are not applied.
 Word labels (olabels) are not carried: no criterion of the path uses them.
 """
 import math
@@ -126,9 +128,15 @@ class LatticeRef:
                    for s, d, t in zip(self.link_src, self.link_dst, self.link_tid))
 
 
-def decode(graph, loglikes, tid2pdf, opts):
+def decode(graph, loglikes, tid2pdf, opts, serial_order=None):
     """LatticeFasterDecoder::Decode + GetRawLattice + final pruning, all arithmetic in float32 in the order
-    (cur_cost + ac_cost) + graph_cost.  loglikes [T, P] float32; tid2pdf[tid] (index 0 unused)."""
+    (cur_cost + ac_cost) + graph_cost.  loglikes [T, P] float32; tid2pdf[tid] (index 0 unused).
+
+    serial_order: None = an emitting arc is kept iff its cost is below the frame's FINAL next_cutoff (the rule of this
+    build, see the module docstring).  Otherwise Kaldi's serial ProcessEmitting is emulated: the best token's arcs first
+    bound next_cutoff, then the tokens are walked in the given order -- "ascending" / "descending" (by cost) or a
+    numpy Generator (random order; Kaldi's own order is that of its hash list) -- and an arc is kept iff its cost is
+    below the cutoff AS IT STANDS when the arc is reached, which tightens on the way."""
     loglikes = np.asarray(loglikes, np.float32)
     T = loglikes.shape[0]
     frames = []      # per frame: dict state -> cost
@@ -185,7 +193,31 @@ def decode(graph, loglikes, tid2pdf, opts):
                 cand.append((s, int(graph.dst[a]), tid, graph.weight[a], ac, tot))
         nxt = {}
         lk = []
-        if cand:
+        if cand and serial_order is not None:
+            # LatticeFasterDecoder::ProcessEmitting as written: a running cutoff
+            by_src = {}
+            for x in cand:
+                by_src.setdefault(x[0], []).append(x)
+            srcs = list(by_src.keys())
+            if isinstance(serial_order, str):
+                srcs.sort(key=lambda q: (cur[q], q), reverse=(serial_order == "descending"))
+            else:
+                srcs = [srcs[i] for i in serial_order.permutation(len(srcs))]
+            next_cutoff = INF
+            best_src = min(cur, key=lambda q: (cur[q], q))
+            for x in by_src.get(best_src, []):
+                if np.float32(x[5] + adaptive_beam) < next_cutoff:
+                    next_cutoff = np.float32(x[5] + adaptive_beam)
+            for q in srcs:
+                for s, d, tid, gw, ac, tot in by_src[q]:
+                    if tot >= next_cutoff:
+                        continue
+                    if np.float32(tot + adaptive_beam) < next_cutoff:
+                        next_cutoff = np.float32(tot + adaptive_beam)
+                    lk.append((s, d, tid, gw, ac))
+                    if tot < nxt.get(d, INF):
+                        nxt[d] = tot
+        elif cand:
             next_cutoff = np.float32(min(x[5] for x in cand) + adaptive_beam)
             for s, d, tid, gw, ac, tot in cand:
                 if tot < next_cutoff:

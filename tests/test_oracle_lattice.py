@@ -136,3 +136,48 @@ def test_beam_pruning_limits_tokens():
         assert lat.link_set() <= wide.link_set()
     # the pruned search expands at most max_active (+ ties) tokens per frame
     assert len(lat.link_src) <= len(wide.link_src) or abs(lat.best_cost - wide.best_cost) >= 1e-4
+
+
+SERIAL_CASES = [
+    # words pdfs T seed beam lattice_beam ac max_active min_active | most extra links (fraction), largest posterior change
+    ((40, 60, 40, 1, 8.0, 4.0, 0.5, 2 ** 31 - 1, 0), 0.06, 0.1),          # narrow beams, nothing binds
+    ((200, 150, 60, 2, 13.0, 7.0, 0.1, 300, 200), 0.002, 2e-4),            # the configuration's beams, max_active binds
+    ((60, 90, 30, 3, 4.0, 2.0, 1.0, 10000, 40), 0.0, 1e-12),
+    ((300, 300, 120, 4, 10.0, 5.0, 0.3, 700, 200), 0.007, 7e-3),           # max_active binds: a few links are lost as well
+]
+
+
+@pytest.mark.parametrize("case,max_extra,max_dpost", SERIAL_CASES)
+def test_final_cutoff_rule_against_kaldis_serial_process_emitting(case, max_extra, max_dpost):
+    """Kaldi's ProcessEmitting tightens next_cutoff while it walks the token list, so the arcs it keeps depend on the
+    order of its hash list; this build (oracle and HIP decoder) keeps an arc iff its cost is below the frame's FINAL
+    cutoff.  Measured here with an emulation of the serial rule (lattice_ref.decode(serial_order=...)):
+      * walking the tokens best-first, the serial rule IS the final-cutoff rule (identical lattices);
+      * any other order only ADDS links whose cost lies between the final and the running cutoff (nothing this build
+        keeps is lost while max_active does not bind), never changes the best path, and moves the MMI posteriors by
+        what the bounds above record: ~1e-4 at the configuration's beams (13 / 7), 6e-3 at 10 / 5 with max_active
+        binding (the extra tokens then also shift later frames: 0.1 % of this build's links are missing), up to 8e-2 at
+        beam 8 / lattice-beam 4 on a 40-word graph, where a few dozen links are 5 % of the lattice."""
+    nw, P, T, seed, beam, lb, ac, maxa, mina = case
+    rng = np.random.default_rng(seed)
+    g = synth.decoding_graph_arcs(nw, P, seed=seed, max_phones=3)
+    graph = lr.DecodeGraphRef(g["num_states"], g["start"], g["src"], g["dst"], g["ilabel"], g["weight"], g["final"])
+    tm = synth.transition_model_arrays(P)
+    ll = (2.0 * rng.standard_normal((T, P))).astype(np.float32)
+    opts = lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac)
+    base = lr.decode(graph, ll, tm["tid2pdf"], opts)
+    ali = synth.tid_alignment(rng, base.T, P)
+    like0, post0 = lr.lattice_mmi(base, ali, tm["tid2pdf"], P, 1.0, 0.2, False)
+    links0 = base.link_set()
+    best_first = lr.decode(graph, ll, tm["tid2pdf"], opts, serial_order="ascending")
+    assert best_first.link_set() == links0
+    assert np.abs(lr.lattice_mmi(best_first, ali, tm["tid2pdf"], P, 1.0, 0.2, False)[1] - post0).max() < 1e-12
+    for order in ("descending", np.random.default_rng(5)):
+        lat = lr.decode(graph, ll, tm["tid2pdf"], opts, serial_order=order)
+        links = lat.link_set()
+        assert lat.best_cost == base.best_cost
+        if maxa > 10 ** 6:
+            assert links0 <= links
+        assert len(links - links0) <= max_extra * len(links0)
+        like, post = lr.lattice_mmi(lat, ali, tm["tid2pdf"], P, 1.0, 0.2, False)
+        assert np.abs(post - post0).max() <= max_dpost
