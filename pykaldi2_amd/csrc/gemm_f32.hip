@@ -55,32 +55,17 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
   float4 ra[DEPTH][TILES], rb[DEPTH][TILES];
   const int nk = (K - kbeg + BK - 1) / BK;
-  // interior tile: every slab but possibly the last is loaded through precomputed pointers (gemm_tile.h)
+  // Interior tile (whole rows inside the matrix, aligned float4 loads): the slabs that lie wholly inside K are loaded
+  // through precomputed pointers (gemm_tile.h) by straight-line code -- with a branch inside the fetch the compiler can no
+  // longer count the loads in flight and waits for all of them (vmcnt(0)) before every LDS store, which exposes a round
+  // trip to memory per slab whatever DEPTH is; a last partial slab is multiplied separately behind the loop.
   const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N;
-  const int nk_fast = interior ? (K - kbeg) / BK : 0;        // slabs that lie wholly inside K
   const float* pa[TILES]; const float* pb[TILES];
   int64_t stepA = 0, stepB = 0;
   slab_pointers<!TA, TILES>(A, lda, m0, kbeg, pa, &stepA);
   slab_pointers<TB, TILES>(B, ldb, n0, kbeg, pb, &stepB);
-  auto fetch = [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
-    if (ks < nk_fast) {
-      load_slab_fast<TILES>(pa, ks * stepA, xa);
-      load_slab_fast<TILES>(pb, ks * stepB, xb);
-    } else {
-      load_slab<!TA, TILES>(A, lda, m0, kbeg + ks * BK, M, K, vecA, xa);
-      load_slab<TB, TILES>(B, ldb, n0, kbeg + ks * BK, N, K, vecB, xb);
-    }
-  };
-  // slab i travels in register stage i % DEPTH
-#pragma unroll
-  for (int i = 0; i < DEPTH; ++i)
-    if (i < nk) fetch(i, ra[i], rb[i]);
-  store_slab<!TA, TILES>(As[0], ra[0]);
-  store_slab<TB, TILES>(Bs[0], rb[0]);
-  __syncthreads();
-  if (nk > DEPTH) fetch(DEPTH, ra[0], rb[0]);
-  auto slab_step = [&](int kt, auto P) {
-    constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
+  auto multiply = [&](auto C_) {
+    constexpr int cur = decltype(C_)::value;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TILES], b[TILES];
@@ -94,22 +79,79 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
         for (int j = 0; j < TILES; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
+  };
+  // the pipelined loop over `n` slabs; slab i travels in register stage i % DEPTH
+  auto pipeline = [&](int n, auto fetch) {
+    if (n <= 0) return;
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+      if (i < n) fetch(i, ra[i], rb[i]);
+    store_slab<!TA, TILES>(As[0], ra[0]);
+    store_slab<TB, TILES>(Bs[0], rb[0]);
+    lds_barrier();
+    if (n > DEPTH) fetch(DEPTH, ra[0], rb[0]);
+    auto slab_step = [&](int kt, auto P) {
+      constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
+      multiply(std::integral_constant<int, cur>());
+      if (kt + 1 < n) {
+        store_slab<!TA, TILES>(As[nxt], ra[sn]);
+        store_slab<TB, TILES>(Bs[nxt], rb[sn]);
+      }
+      lds_barrier();        // (not __syncthreads: the slabs in flight must stay in flight)
+      if (kt + 1 + DEPTH < n) fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
+    };
+    // steady state: DEPTH steps whose store and fetch all exist -- no branch between the loads and the waits for them, so
+    // the compiler waits for exactly the slab it is about to store (vmcnt(in flight behind it)), not for everything
+    auto steady_step = [&](int kt, auto P) {
+      constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
+      multiply(std::integral_constant<int, cur>());
       store_slab<!TA, TILES>(As[nxt], ra[sn]);
       store_slab<TB, TILES>(Bs[nxt], rb[sn]);
+      lds_barrier();
+      fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
+    };
+    int kt = 0;
+    for (; kt + 2 * DEPTH < n; kt += DEPTH) {
+      steady_step(kt, std::integral_constant<int, 0>());
+      steady_step(kt + 1, std::integral_constant<int, 1>());
+      if constexpr (DEPTH > 2) {
+        steady_step(kt + 2, std::integral_constant<int, 2>());
+        steady_step(kt + 3, std::integral_constant<int, 3>());
+        steady_step(kt + 4, std::integral_constant<int, 4>());
+        steady_step(kt + 5, std::integral_constant<int, 5>());
+      }
     }
-    __syncthreads();
-    if (kt + 1 + DEPTH < nk) fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
+    for (; kt < n; kt += DEPTH) {       // the last slabs: nothing left to fetch
+      slab_step(kt, std::integral_constant<int, 0>());
+      if (kt + 1 < n) slab_step(kt + 1, std::integral_constant<int, 1>());
+      if constexpr (DEPTH > 2) {
+        if (kt + 2 < n) slab_step(kt + 2, std::integral_constant<int, 2>());
+        if (kt + 3 < n) slab_step(kt + 3, std::integral_constant<int, 3>());
+        if (kt + 4 < n) slab_step(kt + 4, std::integral_constant<int, 4>());
+        if (kt + 5 < n) slab_step(kt + 5, std::integral_constant<int, 5>());
+      }
+    }
   };
-  for (int kt = 0; kt < nk; kt += DEPTH) {
-    slab_step(kt, std::integral_constant<int, 0>());
-    if (kt + 1 < nk) slab_step(kt + 1, std::integral_constant<int, 1>());
-    if constexpr (DEPTH > 2) {
-      if (kt + 2 < nk) slab_step(kt + 2, std::integral_constant<int, 2>());
-      if (kt + 3 < nk) slab_step(kt + 3, std::integral_constant<int, 3>());
-      if (kt + 4 < nk) slab_step(kt + 4, std::integral_constant<int, 4>());
-      if (kt + 5 < nk) slab_step(kt + 5, std::integral_constant<int, 5>());
+  if (interior) {
+    const int nk_fast = (K - kbeg) / BK;        // slabs that lie wholly inside K
+    pipeline(nk_fast, [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
+      load_slab_fast<TILES>(pa, ks * stepA, xa);
+      load_slab_fast<TILES>(pb, ks * stepB, xb);
+    });
+    if (nk > nk_fast) {     // the partial last slab (its LDS buffers are free: the loop ends behind a barrier)
+      load_slab<!TA, TILES>(A, lda, m0, kbeg + nk_fast * BK, M, K, vecA, ra[0]);
+      load_slab<TB, TILES>(B, ldb, n0, kbeg + nk_fast * BK, N, K, vecB, rb[0]);
+      store_slab<!TA, TILES>(As[0], ra[0]);
+      store_slab<TB, TILES>(Bs[0], rb[0]);
+      lds_barrier();
+      multiply(std::integral_constant<int, 0>());
+      lds_barrier();        // (stream-K: the next piece of this workgroup reuses the buffers)
     }
+  } else {
+    pipeline(nk, [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
+      load_slab<!TA, TILES>(A, lda, m0, kbeg + ks * BK, M, K, vecA, xa);
+      load_slab<TB, TILES>(B, ldb, n0, kbeg + ks * BK, N, K, vecB, xb);
+    });
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);

@@ -8,6 +8,12 @@ namespace pk2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier for LDS hand-overs.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it also drains
+// every global load the thread has in flight -- i.e. the k-slabs prefetched for LATER iterations, which makes every slab
+// of the main loop wait a full round trip to memory however deep the prefetch is (measured: ~0.9 us per slab with one
+// workgroup per CU, whatever the number of slabs in flight).  The staging loops only exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int BK = 16;
 constexpr int kGemmThreads = 256;
 // TILES = MFMA tiles per wave per dimension: block tile (64*TILES)^2.  TILES = 2 (128x128) for large
