@@ -31,128 +31,14 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
                                            const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C,
                                            int64_t ldc, const float* __restrict__ bias, bool vecA, bool vecB, int m0, int n0,
                                            bool atomic) {
-  constexpr int BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
   constexpr int LDA = Geo<TILES>::template ld<!TA>(), LDB = Geo<TILES>::template ld<TB>();   // per-operand LDS row pitch
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
 
   f32x16 acc[TILES][TILES];
-#pragma unroll
-  for (int i = 0; i < TILES; ++i)
-#pragma unroll
-    for (int j = 0; j < TILES; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int kq = lane >> 5, li = lane & 31;
-  // DEPTH k-slabs of BK = 16 in flight in registers, two LDS buffers, ONE barrier per slab: while slab kt is multiplied
-  // out of LDS[kt & 1], slab kt+1 (loaded DEPTH iterations ago) is written into the other buffer and slabs kt+2 ..
-  // kt+DEPTH+1 are on their way from memory.  (Round 1: one LDS buffer, one slab in flight, two barriers per slab -- the
-  // global-load latency of a slab was exposed at every barrier: 38 % MFMA-busy on the model's shapes.)  A 128x128 tile
-  // multiplies for ~0.85 us per slab: two slabs in flight cover a round trip to memory.  A 64x64 tile multiplies for
-  // ~0.2 us, and products small enough to get 64x64 tiles put one or two workgroups on a CU: six slabs in flight.
-  constexpr int DEPTH = TILES == 1 ? 6 : 2;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
-  float4 ra[DEPTH][TILES], rb[DEPTH][TILES];
-  const int nk = (K - kbeg + BK - 1) / BK;
-  // Interior tile (whole rows inside the matrix, aligned float4 loads): the slabs that lie wholly inside K are loaded
-  // through precomputed pointers (gemm_tile.h) by straight-line code -- with a branch inside the fetch the compiler can no
-  // longer count the loads in flight and waits for all of them (vmcnt(0)) before every LDS store, which exposes a round
-  // trip to memory per slab whatever DEPTH is; a last partial slab is multiplied separately behind the loop.
-  const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N;
-  const float* pa[TILES]; const float* pb[TILES];
-  int64_t stepA = 0, stepB = 0;
-  slab_pointers<!TA, TILES>(A, lda, m0, kbeg, pa, &stepA);
-  slab_pointers<TB, TILES>(B, ldb, n0, kbeg, pb, &stepB);
-  auto multiply = [&](auto C_) {
-    constexpr int cur = decltype(C_)::value;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TILES], b[TILES];
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) a[i] = As[cur][(kk + kq) * LDA + wm + i * 32 + li];
-#pragma unroll
-      for (int j = 0; j < TILES; ++j) b[j] = Bs[cur][(kk + kq) * LDB + wn + j * 32 + li];
-#pragma unroll
-      for (int i = 0; i < TILES; ++i)
-#pragma unroll
-        for (int j = 0; j < TILES; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  // the pipelined loop over `n` slabs; slab i travels in register stage i % DEPTH
-  auto pipeline = [&](int n, auto fetch) {
-    if (n <= 0) return;
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i)
-      if (i < n) fetch(i, ra[i], rb[i]);
-    store_slab<!TA, TILES>(As[0], ra[0]);
-    store_slab<TB, TILES>(Bs[0], rb[0]);
-    lds_barrier();
-    if (n > DEPTH) fetch(DEPTH, ra[0], rb[0]);
-    auto slab_step = [&](int kt, auto P) {
-      constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
-      multiply(std::integral_constant<int, cur>());
-      if (kt + 1 < n) {
-        store_slab<!TA, TILES>(As[nxt], ra[sn]);
-        store_slab<TB, TILES>(Bs[nxt], rb[sn]);
-      }
-      lds_barrier();        // (not __syncthreads: the slabs in flight must stay in flight)
-      if (kt + 1 + DEPTH < n) fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
-    };
-    // steady state: DEPTH steps whose store and fetch all exist -- no branch between the loads and the waits for them, so
-    // the compiler waits for exactly the slab it is about to store (vmcnt(in flight behind it)), not for everything
-    auto steady_step = [&](int kt, auto P) {
-      constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
-      multiply(std::integral_constant<int, cur>());
-      store_slab<!TA, TILES>(As[nxt], ra[sn]);
-      store_slab<TB, TILES>(Bs[nxt], rb[sn]);
-      lds_barrier();
-      fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
-    };
-    int kt = 0;
-    for (; kt + 2 * DEPTH < n; kt += DEPTH) {
-      steady_step(kt, std::integral_constant<int, 0>());
-      steady_step(kt + 1, std::integral_constant<int, 1>());
-      if constexpr (DEPTH > 2) {
-        steady_step(kt + 2, std::integral_constant<int, 2>());
-        steady_step(kt + 3, std::integral_constant<int, 3>());
-        steady_step(kt + 4, std::integral_constant<int, 4>());
-        steady_step(kt + 5, std::integral_constant<int, 5>());
-      }
-    }
-    for (; kt < n; kt += DEPTH) {       // the last slabs: nothing left to fetch
-      slab_step(kt, std::integral_constant<int, 0>());
-      if (kt + 1 < n) slab_step(kt + 1, std::integral_constant<int, 1>());
-      if constexpr (DEPTH > 2) {
-        if (kt + 2 < n) slab_step(kt + 2, std::integral_constant<int, 2>());
-        if (kt + 3 < n) slab_step(kt + 3, std::integral_constant<int, 3>());
-        if (kt + 4 < n) slab_step(kt + 4, std::integral_constant<int, 4>());
-        if (kt + 5 < n) slab_step(kt + 5, std::integral_constant<int, 5>());
-      }
-    }
-  };
-  if (interior) {
-    const int nk_fast = (K - kbeg) / BK;        // slabs that lie wholly inside K
-    pipeline(nk_fast, [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
-      load_slab_fast<TILES>(pa, ks * stepA, xa);
-      load_slab_fast<TILES>(pb, ks * stepB, xb);
-    });
-    if (nk > nk_fast) {     // the partial last slab (its LDS buffers are free: the loop ends behind a barrier)
-      load_slab<!TA, TILES>(A, lda, m0, kbeg + nk_fast * BK, M, K, vecA, ra[0]);
-      load_slab<TB, TILES>(B, ldb, n0, kbeg + nk_fast * BK, N, K, vecB, rb[0]);
-      store_slab<!TA, TILES>(As[0], ra[0]);
-      store_slab<TB, TILES>(Bs[0], rb[0]);
-      lds_barrier();
-      multiply(std::integral_constant<int, 0>());
-      lds_barrier();        // (stream-K: the next piece of this workgroup reuses the buffers)
-    }
-  } else {
-    pipeline(nk, [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
-      load_slab<!TA, TILES>(A, lda, m0, kbeg + ks * BK, M, K, vecA, xa);
-      load_slab<TB, TILES>(B, ldb, n0, kbeg + ks * BK, N, K, vecB, xb);
-    });
-  }
+  tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll

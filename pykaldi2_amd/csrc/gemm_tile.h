@@ -2,6 +2,8 @@
 // operands are staged through LDS in k-major order ([k][row]) whatever their memory layout, so every MFMA
 // operand fetch is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace pk2 {
@@ -120,5 +122,134 @@ __device__ __forceinline__ void store_slab(float* __restrict__ tile, const float
   }
 }
 
+// The pipelined main loop of a block tile: acc (zeroed here) = A[m0.., kbeg..K) * B[kbeg..K), n0..] for the
+// (64 TILES) x (64 TILES) tile of 256 threads (4 waves, 2 x 2; wave w owns rows 32 TILES (w / 2).., columns 32 TILES (w % 2)..).
+// KCA / KCB: the operand is k-contiguous in memory (element (r, k) at base[r ld + k]) or row-contiguous (base[k ld + r]).
+// As / Bs: two LDS buffers of BK x Geo<TILES>::ld<KC?>() floats each.  Ends behind a barrier (the buffers are free).
+template <bool KCA, bool KCB, int TILES>
+__device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                              int m0, int n0, int kbeg, int K, int M, int N, bool vecA, bool vecB,
+                                              float (*As)[BK * Geo<TILES>::template ld<KCA>()],
+                                              float (*Bs)[BK * Geo<TILES>::template ld<KCB>()],
+                                              f32x16 (&acc)[TILES][TILES]) {
+  constexpr int BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
+  constexpr int LDA = Geo<TILES>::template ld<KCA>(), LDB = Geo<TILES>::template ld<KCB>();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
+#pragma unroll
+  for (int i = 0; i < TILES; ++i)
+#pragma unroll
+    for (int j = 0; j < TILES; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int kq = lane >> 5, li = lane & 31;
+  // DEPTH k-slabs of BK = 16 in flight in registers, two LDS buffers, ONE barrier per slab: while slab kt is multiplied
+  // out of LDS[kt & 1], slab kt+1 (loaded DEPTH iterations ago) is written into the other buffer and slabs kt+2 ..
+  // kt+DEPTH+1 are on their way from memory.  (Round 1: one LDS buffer, one slab in flight, two barriers per slab -- the
+  // global-load latency of a slab was exposed at every barrier: 38 % MFMA-busy on the model's shapes.)  A 128x128 tile
+  // multiplies for ~0.85 us per slab: two slabs in flight cover a round trip to memory.  A 64x64 tile multiplies for
+  // ~0.2 us, and products small enough to get 64x64 tiles put one or two workgroups on a CU: six slabs in flight.
+  constexpr int DEPTH = TILES == 1 ? 6 : 2;
+  float4 ra[DEPTH][TILES], rb[DEPTH][TILES];
+  const int nk = (K - kbeg + BK - 1) / BK;
+  // Interior tile (whole rows inside the matrix, aligned float4 loads): the slabs that lie wholly inside K are loaded
+  // through precomputed pointers (gemm_tile.h) by straight-line code -- with a branch inside the fetch the compiler can no
+  // longer count the loads in flight and waits for all of them (vmcnt(0)) before every LDS store, which exposes a round
+  // trip to memory per slab whatever DEPTH is; a last partial slab is multiplied separately behind the loop.
+  const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N;
+  const float* pa[TILES]; const float* pb[TILES];
+  int64_t stepA = 0, stepB = 0;
+  slab_pointers<KCA, TILES>(A, lda, m0, kbeg, pa, &stepA);
+  slab_pointers<KCB, TILES>(B, ldb, n0, kbeg, pb, &stepB);
+  auto multiply = [&](auto C_) {
+    constexpr int cur = decltype(C_)::value;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TILES], b[TILES];
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) a[i] = As[cur][(kk + kq) * LDA + wm + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TILES; ++j) b[j] = Bs[cur][(kk + kq) * LDB + wn + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < TILES; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // the pipelined loop over `n` slabs; slab i travels in register stage i % DEPTH
+  auto pipeline = [&](int n, auto fetch) {
+    if (n <= 0) return;
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+      if (i < n) fetch(i, ra[i], rb[i]);
+    store_slab<KCA, TILES>(As[0], ra[0]);
+    store_slab<KCB, TILES>(Bs[0], rb[0]);
+    lds_barrier();
+    if (n > DEPTH) fetch(DEPTH, ra[0], rb[0]);
+    auto slab_step = [&](int kt, auto P) {
+      constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
+      multiply(std::integral_constant<int, cur>());
+      if (kt + 1 < n) {
+        store_slab<KCA, TILES>(As[nxt], ra[sn]);
+        store_slab<KCB, TILES>(Bs[nxt], rb[sn]);
+      }
+      lds_barrier();        // (not __syncthreads: the slabs in flight must stay in flight)
+      if (kt + 1 + DEPTH < n) fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
+    };
+    // steady state: DEPTH steps whose store and fetch all exist -- no branch between the loads and the waits for them, so
+    // the compiler waits for exactly the slab it is about to store (vmcnt(in flight behind it)), not for everything
+    auto steady_step = [&](int kt, auto P) {
+      constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
+      multiply(std::integral_constant<int, cur>());
+      store_slab<KCA, TILES>(As[nxt], ra[sn]);
+      store_slab<KCB, TILES>(Bs[nxt], rb[sn]);
+      lds_barrier();
+      fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
+    };
+    int kt = 0;
+    for (; kt + 2 * DEPTH < n; kt += DEPTH) {
+      steady_step(kt, std::integral_constant<int, 0>());
+      steady_step(kt + 1, std::integral_constant<int, 1>());
+      if constexpr (DEPTH > 2) {
+        steady_step(kt + 2, std::integral_constant<int, 2>());
+        steady_step(kt + 3, std::integral_constant<int, 3>());
+        steady_step(kt + 4, std::integral_constant<int, 4>());
+        steady_step(kt + 5, std::integral_constant<int, 5>());
+      }
+    }
+    for (; kt < n; kt += DEPTH) {       // the last slabs: nothing left to fetch
+      slab_step(kt, std::integral_constant<int, 0>());
+      if (kt + 1 < n) slab_step(kt + 1, std::integral_constant<int, 1>());
+      if constexpr (DEPTH > 2) {
+        if (kt + 2 < n) slab_step(kt + 2, std::integral_constant<int, 2>());
+        if (kt + 3 < n) slab_step(kt + 3, std::integral_constant<int, 3>());
+        if (kt + 4 < n) slab_step(kt + 4, std::integral_constant<int, 4>());
+        if (kt + 5 < n) slab_step(kt + 5, std::integral_constant<int, 5>());
+      }
+    }
+  };
+  if (interior) {
+    const int nk_fast = (K - kbeg) / BK;        // slabs that lie wholly inside K
+    pipeline(nk_fast, [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
+      load_slab_fast<TILES>(pa, ks * stepA, xa);
+      load_slab_fast<TILES>(pb, ks * stepB, xb);
+    });
+    if (nk > nk_fast) {     // the partial last slab (its LDS buffers are free: the loop ends behind a barrier)
+      load_slab<KCA, TILES>(A, lda, m0, kbeg + nk_fast * BK, M, K, vecA, ra[0]);
+      load_slab<KCB, TILES>(B, ldb, n0, kbeg + nk_fast * BK, N, K, vecB, rb[0]);
+      store_slab<KCA, TILES>(As[0], ra[0]);
+      store_slab<KCB, TILES>(Bs[0], rb[0]);
+      lds_barrier();
+      multiply(std::integral_constant<int, 0>());
+      lds_barrier();        // (stream-K: the next piece of this workgroup reuses the buffers)
+    }
+  } else {
+    pipeline(nk, [&](int ks, float4 (&xa)[TILES], float4 (&xb)[TILES]) {
+      load_slab<KCA, TILES>(A, lda, m0, kbeg + ks * BK, M, K, vecA, xa);
+      load_slab<KCB, TILES>(B, ldb, n0, kbeg + ks * BK, N, K, vecB, xb);
+    });
+  }
+}
 
 }  // namespace pk2

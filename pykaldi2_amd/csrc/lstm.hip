@@ -386,7 +386,6 @@ __global__ void __launch_bounds__(256) lstm_bwd_step_x4(const LstmBwdParams* __r
 // ----------------------------------------------------------------------------------------
 constexpr int kBigBatch = 32;
 constexpr int kBigSplitK = 4;
-constexpr int kBigSlabs = 4;     // k-slabs of BK staged per iteration (64 k)
 
 // whh_units[d][u][g][k] = whh[d][g*H + u][k]
 __global__ void __launch_bounds__(256) regroup_whh_units(const float* __restrict__ whh, float* __restrict__ out, int H) {
@@ -399,8 +398,8 @@ __global__ void __launch_bounds__(256) regroup_whh_units(const float* __restrict
 __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __restrict__ pp,
                                                          const StepCounter* __restrict__ cnt, int local) {
   constexpr int LD = Geo<1>::LDK;     // both operands are k-contiguous in memory
-  __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LD];
-  __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LD];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LD];
   __shared__ float Cs[64][65];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
@@ -434,39 +433,12 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
     const float* A = p.y + (size_t)tp * B * yrow + (size_t)d * H;               // h_{prev}: row b, k contiguous
     const float* Bw = p.whh_units + ((size_t)d * H + u0) * 4 * H;              // 64 rows (unit, gate), k contiguous
     const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // kBigSlabs k-slabs of 16 per stage: one workgroup per CU has to keep enough bytes in flight by itself
-    float4 ra[kBigSlabs][1], rb[kBigSlabs][1];
-#pragma unroll
-    for (int q = 0; q < kBigSlabs; ++q) {
-      load_slab<true, 1>(A, (int64_t)yrow, m0, q * BK, B, H, true, ra[q]);
-      load_slab<true, 1>(Bw, H, 0, q * BK, 64, H, true, rb[q]);
-    }
-    const int nk = H / (BK * kBigSlabs);
-    for (int kt = 0; kt < nk; ++kt) {
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < kBigSlabs; ++q) {
-        store_slab<true, 1>(As[q], ra[q]);
-        store_slab<true, 1>(Bs[q], rb[q]);
-      }
-      __syncthreads();
-      if (kt + 1 < nk) {
-#pragma unroll
-        for (int q = 0; q < kBigSlabs; ++q) {
-          load_slab<true, 1>(A, (int64_t)yrow, m0, ((kt + 1) * kBigSlabs + q) * BK, B, H, true, ra[q]);
-          load_slab<true, 1>(Bw, H, 0, ((kt + 1) * kBigSlabs + q) * BK, 64, H, true, rb[q]);
-        }
-      }
-      const int kq = lane >> 5, li = lane & 31;
-#pragma unroll
-      for (int q = 0; q < kBigSlabs; ++q)
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[q][(kk + kq) * LD + wm + li], Bs[q][(kk + kq) * LD + wn + li], acc, 0, 0, 0);
-    }
+    // the step's matrix phase is one 64 x 64 x H block tile: the GEMM's pipelined loop (six k-slabs in flight, LDS-only
+    // barriers -- one workgroup per CU has to cover the round trips to memory by itself; the weights come from memory
+    // again in every launch).  (Two barriers and one 64-k stage in flight per iteration: 30 us per step.)
+    f32x16 acc1[1][1];
+    tile_mainloop<true, true, 1>(A, (int64_t)yrow, Bw, (int64_t)H, m0, 0, 0, H, B, 64, true, true, As, Bs, acc1);
+    const f32x16 acc = acc1[0][0];
     const int col = wn + (lane & 31), rh = 4 * (lane >> 5);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Cs[wm + (r & 3) + 8 * (r >> 2) + rh][col] = acc[r];
@@ -494,8 +466,8 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
 __global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __restrict__ pp,
                                                        const StepCounter* __restrict__ cnt, int local) {
   constexpr int LDA = Geo<1>::LDK, LDB = Geo<1>::LD;   // dgates rows are k-contiguous, W_hh is read [k][n]
-  __shared__ __attribute__((aligned(16))) float As[kBigSlabs][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[kBigSlabs][BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
   const int step = cnt->base + local;
   if (step >= cnt->T || step == 0) return;     // the first backward step has no recurrent gradient
   const LstmBwdParams p = *pp;
@@ -510,38 +482,9 @@ __global__ void __launch_bounds__(256) lstm_bwd_dh_big(const LstmBwdParams* __re
   const float* A = p.dgx + (size_t)tn * B * ((size_t)D * G4) + (size_t)d * G4 + kbeg;   // rows b, r contiguous
   const float* Bw = p.whh + (size_t)d * G4 * H + (size_t)kbeg * H;                      // [r][k]: (k=r, n) at r*H + n
   const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 ra[kBigSlabs][1], rb[kBigSlabs][1];
-#pragma unroll
-  for (int q = 0; q < kBigSlabs; ++q) {
-    load_slab<true, 1>(A, (int64_t)D * G4, m0, q * BK, B, klen, true, ra[q]);
-    load_slab<false, 1>(Bw, H, n0, q * BK, H, klen, true, rb[q]);
-  }
-  const int nk = klen / (BK * kBigSlabs);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kBigSlabs; ++q) {
-      store_slab<true, 1>(As[q], ra[q]);
-      store_slab<false, 1>(Bs[q], rb[q]);
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int q = 0; q < kBigSlabs; ++q) {
-        load_slab<true, 1>(A, (int64_t)D * G4, m0, ((kt + 1) * kBigSlabs + q) * BK, B, klen, true, ra[q]);
-        load_slab<false, 1>(Bw, H, n0, ((kt + 1) * kBigSlabs + q) * BK, H, klen, true, rb[q]);
-      }
-    }
-    const int kq = lane >> 5, li = lane & 31;
-#pragma unroll
-    for (int q = 0; q < kBigSlabs; ++q)
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[q][(kk + kq) * LDA + wm + li], Bs[q][(kk + kq) * LDB + wn + li], acc, 0, 0, 0);
-  }
+  f32x16 acc1[1][1];
+  tile_mainloop<true, false, 1>(A, (int64_t)D * G4, Bw, (int64_t)H, m0, n0, 0, klen, B, H, true, true, As, Bs, acc1);
+  const f32x16 acc = acc1[0][0];
   float* out = p.dh_part + (((size_t)sk * D + d) * B) * H;
   const int col = n0 + wn + (lane & 31), rh = 4 * (lane >> 5);
 #pragma unroll
