@@ -94,65 +94,6 @@ __global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, in
                             blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1);
 }
 
-// Stream-K hybrid for a single product (128x128 tiles, numbered band-major: tile t = rows 128 (t / cn), columns
-// 128 (t % cn)).  Two things cost the whole-tile grid its efficiency on the model's shapes (M = 2.3 k rows): 256 CUs take
-// whole tiles only in multiples of 256 (M = 2356 x N = 4096: 608 tiles = 2.375 per CU -> 3 tile-times), and a CU needs
-// three resident workgroups to keep its matrix pipe busy (one workgroup per CU: 80-85 TFLOP/s; three: 100-120).  So
-// n_dp workgroups multiply one whole tile each, and the k-slabs of the remaining `rem` tiles (rem x slabs of them,
-// tile-major) are dealt evenly to g_sk workgroups, which add their pieces into C with float atomics (those tiles are
-// initialised to beta * C + bias by gemm_prescale_tiles beforehand).  `mix`: the pieces are interleaved with the whole
-// tiles in launch order (everything is resident at once -- 3 per CU -- and every CU should get the same share of both);
-// otherwise they follow the whole tiles and fill the tail of the last round.
-struct GemmSk { int cn, n_dp, rem, g_sk, slabs, mix; };
-
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(kGemmThreads) gemm_f32_sk_kernel(int M, int N, int K, float alpha,
-                                                                   const float* __restrict__ A, int64_t lda,
-                                                                   const float* __restrict__ B, int64_t ldb,
-                                                                   float beta, float* __restrict__ C, int64_t ldc,
-                                                                   const float* __restrict__ bias, bool vecA,
-                                                                   bool vecB, GemmSk sk) {
-  const int L = blockIdx.x, total = sk.n_dp + sk.g_sk;
-  int piece = L - sk.n_dp;                                   // >= 0: the g-th dealer of k-slabs; < 0: whole tile L
-  int whole = L;
-  if (sk.mix) {
-    const int before = (int)((int64_t)L * sk.g_sk / total);
-    const bool is_piece = (int)((int64_t)(L + 1) * sk.g_sk / total) > before;
-    piece = is_piece ? before : -1;
-    whole = L - before;
-  }
-  int64_t it, end;
-  if (piece < 0) {
-    it = (int64_t)whole * sk.slabs; end = it + sk.slabs;
-  } else {
-    const int64_t W = (int64_t)sk.rem * sk.slabs;
-    it = (int64_t)sk.n_dp * sk.slabs + piece * W / sk.g_sk;
-    end = (int64_t)sk.n_dp * sk.slabs + (piece + 1) * W / sk.g_sk;
-  }
-  while (it < end) {
-    const int t = (int)(it / sk.slabs);
-    const int s0 = (int)(it % sk.slabs);
-    const int s1 = (int)min((int64_t)sk.slabs, s0 + (end - it));
-    gemm_block<TA, TB, 2>(M, N, min(K, s1 * BK), s0 * BK, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
-                          (t / sk.cn) * 128, (t % sk.cn) * 128, piece >= 0);
-    it += s1 - s0;
-  }
-}
-
-// C = beta * C + bias on the 128x128 tiles [t0, t0 + gridDim.x) ahead of their stream-K pieces.
-__global__ void __launch_bounds__(256) gemm_prescale_tiles(int M, int N, float beta, float* __restrict__ C, int64_t ldc,
-                                                           const float* __restrict__ bias, int cn, int t0) {
-  const int t = t0 + blockIdx.x;
-  const int m0 = (t / cn) * 128, n = (t % cn) * 128 + (threadIdx.x & 127);
-  if (n >= N) return;
-  const float bv = bias ? bias[n] : 0.f;
-  const int m1 = min(M, m0 + 128);
-  for (int m = m0 + (threadIdx.x >> 7); m < m1; m += 2) {
-    float* o = C + (int64_t)m * ldc + n;
-    *o = beta == 0.f ? bv : beta * (*o) + bv;
-  }
-}
-
 // C = beta * C + bias ahead of a split-K product (blockIdx.z = batch entry).
 __global__ void __launch_bounds__(256) gemm_prescale_kernel(int M, int N, float beta, float* __restrict__ C,
                                                             int64_t ldc, const float* __restrict__ bias, GemmBatch bt) {
@@ -203,46 +144,11 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   const bool vecB = aligned_strides && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const int64_t big_tiles = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * n0 * bt.n1;
   const char* force = getenv("PK2_GEMM_TILES");
-  // Single products of at least one 128x128 tile: whole tiles in multiples of the CU count, the rest dealt by k-slabs
-  // (gemm_f32_sk_kernel).  PK2_GEMM_SK=0 keeps the split-K / row-band schedules below, =2 uses it for every shape.
-  const char* sk_env = getenv("PK2_GEMM_SK");
-  const bool no_sk = sk_env && atoi(sk_env) == 0;
-  // Measured against the schedules below on the model's shapes (bench.py --gemm-only, M = 2356): the input projection
-  // 2356 x 4096 x 1024 (608 tiles) 209 -> 194 us, the data gradients 2356 x 1024 x 6048 / 4096 (152 tiles) 342 -> 321 /
-  // 235 -> 219 us; with 256..511 tiles or a remainder behind three or more rounds it was 3-5 % slower, so those keep the
-  // split-K / row-band schedules.
-  // (and the Transformer's products -- 76 tiles, K = 512 or 2048 -- are better off with 64x64 tiles / split-K: 27.9 vs
-  // 31.0 ms per TransformerAM step with pieces for every K, 28.5 with pieces from K = 2048)
-  const bool sk_shape = (big_tiles < 256 && K >= 4096) || (big_tiles >= 512 && big_tiles < 768 && big_tiles % 256 != 0);
-  if (!no_sk && !force && n0 * bt.n1 == 1 && M > 64 && N > 64 && K >= 512 && (sk_shape || (sk_env && atoi(sk_env) == 2))) {
-    const int cus = 256, slots = 3 * cus, min_slabs = 8;            // a piece is at least 128 k deep
-    GemmSk sk;
-    sk.cn = (N + 127) / 128;
-    sk.slabs = (K + BK - 1) / BK;
-    const int tiles = (int)big_tiles;
-    // fewer than two tiles per CU: everything by k-slabs, three pieces per CU; two tiles per CU: the rest as one piece per
-    // CU next to them; more: whole rounds of tiles, then the rest as three small pieces per CU
-    sk.n_dp = tiles < 2 * cus ? 0 : tiles / cus * cus;
-    sk.rem = tiles - sk.n_dp;
-    sk.mix = sk.n_dp == 2 * cus;
-    sk.g_sk = 0;
-    if (sk.rem > 0) {
-      const int64_t W = (int64_t)sk.rem * sk.slabs;
-      sk.g_sk = (int)std::max<int64_t>(1, std::min<int64_t>(sk.mix ? cus : slots, W / min_slabs));
-      hipLaunchKernelGGL(gemm_prescale_tiles, dim3(sk.rem), dim3(256), 0, stream, M, N, beta, C, ldc, bias, sk.cn, sk.n_dp);
-    }
-    dim3 grid(sk.n_dp + sk.g_sk), block(kGemmThreads);
-#define PK2_GEMM_SKL(TA, TB) \
-  hipLaunchKernelGGL((gemm_f32_sk_kernel<TA, TB>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, sk)
-    if (!transa && !transb) PK2_GEMM_SKL(false, false);
-    else if (!transa && transb) PK2_GEMM_SKL(false, true);
-    else if (transa && !transb) PK2_GEMM_SKL(true, false);
-    else PK2_GEMM_SKL(true, true);
-#undef PK2_GEMM_SKL
-    PK2_LAUNCH_CHECK();
-    return PK2_OK;
-  }
-  int tiles = force ? atoi(force) : (big_tiles >= 512 ? 2 : 1);
+  // (A stream-K hybrid -- whole tiles in multiples of the CU count, the k-slabs of the rest dealt evenly to further
+  // workgroups that add their pieces with atomics -- was built and measured in round 2: once the 64x64-tile kernel kept six
+  // slabs in flight behind LDS-only barriers, the row bands / split-K below were faster on every shape of the models, e.g.
+  // 2356 x 4096 x 1024: 194 us against 244; removed.)
+  int tiles = force ? atoi(force) : ((big_tiles >= 512 && K >= 256) ? 2 : 1);      // (shallow products: 64x64 tiles, 27 vs 33 us at K = 80)
   // Deep-K products with few output tiles (the weight gradients: K = frames): 128x128 tiles over K slices.
   bt.ksplit = 1;
   bt.klen = K;
