@@ -191,8 +191,11 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // along M: as many 128-row bands as fill the chip a whole number of times get 128x128 tiles, the remaining rows get
   // 64x64 tiles in a second launch (here: 16 bands = 512 tiles = 2 per CU, then 228 rows x 64 columns-tiles = 256 small
   // tiles = 1 per CU).  Estimated cost of a small tile = 0.3 of a big one (a quarter of the flops at lower intensity).
-  static const bool no_band = [] { const char* e = getenv("PK2_GEMM_BANDS"); return e && atoi(e) == 0; }();
   int cus = 256;
+  const char* band_env = getenv("PK2_GEMM_BANDS");
+  const bool no_band = band_env && atoi(band_env) == 0;
+  // (between one and two big tiles per CU -- 64x64 tiles throughout -- a band of one big tile per CU plus small ones was
+  // slower: 6048 x 1024 x 2356: 351 against 334 us, tools/dbg/gemm_modes.py)
   if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && (transa ? (lda & 3) == 0 : true)) {
     const int Cn = (N + 127) / 128, R = (M + 127) / 128, Cs = (N + 63) / 64;
     auto rounds = [&](int64_t n) { return (double)((n + cus - 1) / cus); };

@@ -149,7 +149,11 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
   // global-load latency of a slab was exposed at every barrier: 38 % MFMA-busy on the model's shapes.)  A 128x128 tile
   // multiplies for ~0.85 us per slab: two slabs in flight cover a round trip to memory.  A 64x64 tile multiplies for
   // ~0.2 us, and products small enough to get 64x64 tiles put one or two workgroups on a CU: six slabs in flight.
-  constexpr int DEPTH = TILES == 1 ? 6 : 2;
+#ifndef PK2_GEMM_DEPTH2
+#define PK2_GEMM_DEPTH2 2
+#endif
+  constexpr int DEPTH = TILES == 1 ? 6 : PK2_GEMM_DEPTH2;
+  static_assert(DEPTH == 2 || DEPTH == 4 || DEPTH == 6, "an even number of register stages (the LDS buffer is the stage's parity)");
   float4 ra[DEPTH][TILES], rb[DEPTH][TILES];
   const int nk = (K - kbeg + BK - 1) / BK;
   // Interior tile (whole rows inside the matrix, aligned float4 loads): the slabs that lie wholly inside K are loaded
@@ -214,6 +218,8 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
       if constexpr (DEPTH > 2) {
         steady_step(kt + 2, std::integral_constant<int, 2>());
         steady_step(kt + 3, std::integral_constant<int, 3>());
+      }
+      if constexpr (DEPTH > 4) {
         steady_step(kt + 4, std::integral_constant<int, 4>());
         steady_step(kt + 5, std::integral_constant<int, 5>());
       }
@@ -224,6 +230,8 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
       if constexpr (DEPTH > 2) {
         if (kt + 2 < n) slab_step(kt + 2, std::integral_constant<int, 2>());
         if (kt + 3 < n) slab_step(kt + 3, std::integral_constant<int, 3>());
+      }
+      if constexpr (DEPTH > 4) {
         if (kt + 4 < n) slab_step(kt + 4, std::integral_constant<int, 4>());
         if (kt + 5 < n) slab_step(kt + 5, std::integral_constant<int, 5>());
       }

@@ -43,6 +43,7 @@ def measure(ta, tb, M, N, K, reps=20):
 SHAPES = [(0, 1, 2356, 4096, 1024), (0, 1, 2356, 6048, 1024), (1, 0, 6048, 1024, 2356), (0, 0, 2356, 1024, 6048),
           (1, 0, 4096, 1024, 2356), (1, 0, 2048, 512, 2352), (0, 0, 2356, 1024, 4096), (0, 1, 2356, 4096, 80),
           (1, 0, 4096, 80, 2356), (0, 1, 2300, 512, 512), (0, 0, 2300, 512, 2048), (0, 1, 2300, 2048, 512), (1, 0, 512, 512, 2300),
-          (1, 0, 2048, 512, 20480), (1, 0, 4096, 1024, 20480), (0, 1, 20480, 4096, 1024)]
+          (1, 0, 2048, 512, 20480), (1, 0, 4096, 1024, 20480), (0, 1, 20480, 4096, 1024), (1, 0, 5768, 1024, 20480),
+          (0, 1, 2300, 1536, 512)]
 for sh in SHAPES:
     measure(*sh)
