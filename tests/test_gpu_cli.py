@@ -219,7 +219,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     rank-0-only extra step would hang here).  Rank 0 prints the one JSON line with n_gpus = 2."""
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env=dict(os.environ, PK2_HVD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"))
@@ -229,6 +229,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8
     assert d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
-    # with more than one rank the exchange schedule is measured at start-up (the two schedules alternate for 12 steps)
-    # and every rank switches to the same one
+    # with more than one rank the exchange schedule is measured at start-up (2 + 2 x 6 steps, the two schedules in turn)
+    # and every rank switches to the same one; bench.py runs that calibration to its end BEFORE its warm-up steps
     assert "[hvd] gradient exchange schedule: " in out.stderr and d["exchange"]["schedule"] in ("single", "overlap")
+    assert d["exchange"]["calibration_steps"] == 14 and d["steps"] == 4
