@@ -122,6 +122,14 @@ __device__ __forceinline__ void store_slab(float* __restrict__ tile, const float
   }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+
 // The pipelined main loop of a block tile: acc (zeroed here) = A[m0.., kbeg..K) * B[kbeg..K), n0..] for the
 // (64 TILES) x (64 TILES) tile of 256 threads (4 waves, 2 x 2; wave w owns rows 32 TILES (w / 2).., columns 32 TILES (w % 2)..).
 // KCA / KCB: the operand is k-contiguous in memory (element (r, k) at base[r ld + k]) or row-contiguous (base[k ld + r]).
@@ -152,8 +160,11 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
 #ifndef PK2_GEMM_DEPTH2
 #define PK2_GEMM_DEPTH2 2
 #endif
-  constexpr int DEPTH = TILES == 1 ? 6 : PK2_GEMM_DEPTH2;
-  static_assert(DEPTH == 2 || DEPTH == 4 || DEPTH == 6, "an even number of register stages (the LDS buffer is the stage's parity)");
+#ifndef PK2_GEMM_DEPTH1
+#define PK2_GEMM_DEPTH1 6
+#endif
+  constexpr int DEPTH = TILES == 1 ? PK2_GEMM_DEPTH1 : PK2_GEMM_DEPTH2;
+  static_assert(DEPTH % 2 == 0, "an even number of register stages (the LDS buffer is the stage's parity)");
   float4 ra[DEPTH][TILES], rb[DEPTH][TILES];
   const int nk = (K - kbeg + BK - 1) / BK;
   // Interior tile (whole rows inside the matrix, aligned float4 loads): the slabs that lie wholly inside K are loaded
@@ -212,30 +223,10 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
       fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
     };
     int kt = 0;
-    for (; kt + 2 * DEPTH < n; kt += DEPTH) {
-      steady_step(kt, std::integral_constant<int, 0>());
-      steady_step(kt + 1, std::integral_constant<int, 1>());
-      if constexpr (DEPTH > 2) {
-        steady_step(kt + 2, std::integral_constant<int, 2>());
-        steady_step(kt + 3, std::integral_constant<int, 3>());
-      }
-      if constexpr (DEPTH > 4) {
-        steady_step(kt + 4, std::integral_constant<int, 4>());
-        steady_step(kt + 5, std::integral_constant<int, 5>());
-      }
-    }
-    for (; kt < n; kt += DEPTH) {       // the last slabs: nothing left to fetch
-      slab_step(kt, std::integral_constant<int, 0>());
-      if (kt + 1 < n) slab_step(kt + 1, std::integral_constant<int, 1>());
-      if constexpr (DEPTH > 2) {
-        if (kt + 2 < n) slab_step(kt + 2, std::integral_constant<int, 2>());
-        if (kt + 3 < n) slab_step(kt + 3, std::integral_constant<int, 3>());
-      }
-      if constexpr (DEPTH > 4) {
-        if (kt + 4 < n) slab_step(kt + 4, std::integral_constant<int, 4>());
-        if (kt + 5 < n) slab_step(kt + 5, std::integral_constant<int, 5>());
-      }
-    }
+    for (; kt + 2 * DEPTH < n; kt += DEPTH)
+      static_for<0, DEPTH>([&](auto S) { steady_step(kt + decltype(S)::value, S); });
+    for (; kt < n; kt += DEPTH)       // the last slabs
+      static_for<0, DEPTH>([&](auto S) { if (kt + decltype(S)::value < n) slab_step(kt + decltype(S)::value, S); });
   };
   if (interior) {
     const int nk_fast = (K - kbeg) / BK;        // slabs that lie wholly inside K
