@@ -196,12 +196,11 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
   auto pipeline = [&](int n, auto fetch) {
     if (n <= 0) return;
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i)
-      if (i < n) fetch(i, ra[i], rb[i]);
+    for (int i = 0; i < DEPTH; ++i) fetch(min(i, n - 1), ra[i], rb[i]);
     store_slab<KCA, TILES>(As[0], ra[0]);
     store_slab<KCB, TILES>(Bs[0], rb[0]);
     lds_barrier();
-    if (n > DEPTH) fetch(DEPTH, ra[0], rb[0]);
+    fetch(min(DEPTH, n - 1), ra[0], rb[0]);
     auto slab_step = [&](int kt, auto P) {
       constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
       multiply(std::integral_constant<int, cur>());
@@ -212,20 +211,22 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
       lds_barrier();        // (not __syncthreads: the slabs in flight must stay in flight)
       if (kt + 1 + DEPTH < n) fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
     };
-    // steady state: DEPTH steps whose store and fetch all exist -- no branch between the loads and the waits for them, so
-    // the compiler waits for exactly the slab it is about to store (vmcnt(in flight behind it)), not for everything
+    // Whole groups of DEPTH steps run without a branch between the loads and the waits for them, so the compiler waits
+    // for exactly the slab it is about to store (vmcnt(in flight behind it)) instead of for everything: behind the last
+    // slab the fetch index is clamped (the last slab is fetched again: a few cache hits) and the store of a slab that
+    // does not exist goes into the LDS buffer nobody reads any more.
     auto steady_step = [&](int kt, auto P) {
       constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
       multiply(std::integral_constant<int, cur>());
       store_slab<KCA, TILES>(As[nxt], ra[sn]);
       store_slab<KCB, TILES>(Bs[nxt], rb[sn]);
       lds_barrier();
-      fetch(kt + 1 + DEPTH, ra[sn], rb[sn]);
+      fetch(min(kt + 1 + DEPTH, n - 1), ra[sn], rb[sn]);
     };
     int kt = 0;
-    for (; kt + 2 * DEPTH < n; kt += DEPTH)
+    for (; kt + DEPTH <= n; kt += DEPTH)
       static_for<0, DEPTH>([&](auto S) { steady_step(kt + decltype(S)::value, S); });
-    for (; kt < n; kt += DEPTH)       // the last slabs
+    if (kt < n)                         // a last, partial group
       static_for<0, DEPTH>([&](auto S) { if (kt + decltype(S)::value < n) slab_step(kt + decltype(S)::value, S); });
   };
   if (interior) {

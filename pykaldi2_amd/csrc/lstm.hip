@@ -403,6 +403,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
   __shared__ float Cs[64][65];
   const int step = cnt->base + local;
   if (step >= cnt->T) return;
+#ifdef PK2_BIGSTEP_PROFILE
+  const long long bs_t0 = wall_clock64();
+#endif
   const LstmFwdParams p = *pp;
   const int d = blockIdx.y, u0 = blockIdx.x * 16, m0 = blockIdx.z * 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -411,20 +414,22 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
   const int tp = d == 0 ? t - 1 : t + 1;
   const bool first = step == 0;
   const size_t yrow = (size_t)D * H;
-  // gate-math operands of the 4 (row, unit) items of this thread, fetched before the matrix phase
-  float pre[4][4], cprev[4];
+  // gate-math operands of the 4 (row, unit) items of this thread: ISSUED before the matrix phase, first USED behind it
+  // (adding the bias here made the kernel wait for them before it had a single k-slab in flight: in-kernel timers showed
+  // 8 us between entry and the main loop)
+  float pre[4][4], bias[4][4], cprev[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int idx = tid + j * 256, i = idx >> 4, u = idx & 15, b = m0 + i;
     cprev[j] = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pre[j][g] = 0.f;
+    for (int g = 0; g < 4; ++g) { pre[j][g] = 0.f; bias[j][g] = 0.f; }
     if (b < B) {
       const float* gxr = p.gx + ((size_t)t * B + b) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + u;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         pre[j][g] = gxr[(size_t)g * H];
-        if (p.bhh) pre[j][g] += p.bhh[(size_t)d * 4 * H + (size_t)g * H + u0 + u];
+        if (p.bhh) bias[j][g] = p.bhh[(size_t)d * 4 * H + (size_t)g * H + u0 + u];
       }
       if (!first) cprev[j] = p.cells[(((size_t)d * T + tp) * B + b) * H + u0 + u];
     }
@@ -437,7 +442,14 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
     // barriers -- one workgroup per CU has to cover the round trips to memory by itself; the weights come from memory
     // again in every launch).  (Two barriers and one 64-k stage in flight per iteration: 30 us per step.)
     f32x16 acc1[1][1];
+#ifdef PK2_BIGSTEP_PROFILE
+    const long long bs_t1 = wall_clock64();
+#endif
     tile_mainloop<true, true, 1>(A, (int64_t)yrow, Bw, (int64_t)H, m0, 0, 0, H, B, 64, true, true, As, Bs, acc1);
+#ifdef PK2_BIGSTEP_PROFILE
+    if (tid == 0 && blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 1 && step == 40)
+      printf("lstm_fwd_step_big step 40: entry -> main loop %lld, main loop %lld (10 ns ticks)\n", bs_t1 - bs_t0, wall_clock64() - bs_t1);
+#endif
     const f32x16 acc = acc1[0][0];
     const int col = wn + (lane & 31), rh = 4 * (lane >> 5);
 #pragma unroll
@@ -450,7 +462,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
     if (b < B) {
       float v[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) v[g] = pre[j][g] + (first ? 0.f : Cs[i][u * 4 + g]);
+      for (int g = 0; g < 4; ++g) v[g] = (pre[j][g] + bias[j][g]) + (first ? 0.f : Cs[i][u * 4 + g]);
       const float ig = fast_sigmoid(v[0]), fg = fast_sigmoid(v[1]), gg = fast_tanh(v[2]), og = fast_sigmoid(v[3]);
       const float c = fg * cprev[j] + ig * gg;
       const float h = og * fast_tanh(c);
@@ -460,6 +472,11 @@ __global__ void __launch_bounds__(256) lstm_fwd_step_big(const LstmFwdParams* __
       gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
     }
   }
+#ifdef PK2_BIGSTEP_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 1 && step == 40)
+    printf("lstm_fwd_step_big step 40: whole kernel %lld (10 ns ticks)\n", wall_clock64() - bs_t0);
+#endif
 }
 
 // dh_part[s][d][b][k] = sum_{r in K-slice s} dgates[tn][b][r] * W_hh[d][r][k]   (64 x 64 tiles, split-K)
