@@ -38,7 +38,13 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
   f32x16 acc[TILES][TILES];
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+#ifdef PK2_GEMM_PROFILE
+  const long long gp_t0 = wall_clock64();
+#endif
   tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
+#ifdef PK2_GEMM_PROFILE
+  const long long gp_t1 = wall_clock64();
+#endif
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
@@ -68,6 +74,12 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
       }
     }
   }
+#ifdef PK2_GEMM_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && K == 1024 && N == 4096 && (blockIdx.x + blockIdx.y * gridDim.x) % 97 == 0)
+    printf("gemm tile (%d,%d) of grid (%d,%d) tiles=%d: start %lld main loop %lld epilogue %lld (10 ns ticks)\n", blockIdx.x, blockIdx.y,
+           gridDim.x, gridDim.y, TILES, gp_t0, gp_t1 - gp_t0, wall_clock64() - gp_t1);
+#endif
 }
 
 template <bool TA, bool TB, int TILES>
