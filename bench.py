@@ -126,6 +126,17 @@ class Trainer:
         return loss
 
 
+def dump_chain_parity_inputs(tr, mb, path):
+    """The logits of the breakdown minibatch, its alignments, and what the device computes for them (objective per
+    sequence, d objf / d logits): the `parity` leg of the cpu-baseline child checks them against the C port."""
+    logits = tr.last["logits"].detach().transpose(0, 1).contiguous()          # [N, T', P]
+    out, grad = chain.compute_chain_objf_and_deriv(tr.opts, tr.den, tr.last["sups"], logits)
+    torch.cuda.synchronize()
+    arrs = {"ali%d" % n: np.asarray(a) for n, a in enumerate(mb["alis"])}
+    np.savez(path, n=len(mb["alis"]), xent=tr.opts.xent_regularize, logits=logits.cpu().numpy(),
+             gpu_out=out.cpu().numpy(), gpu_grad=grad.cpu().numpy(), **arrs)
+
+
 DEN_ROOF_LENS = [589, 410, 377, 502]     # the fixed denominator workload of `--den-only`, the PMC passes and `roofline`
 
 
@@ -223,7 +234,29 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline_worker(seed, threads):
+def chain_parity(g, pi, path):
+    """In-job parity gate (north star "LF-MMI objective within 1e-3 rel"): the objective and the logit
+    gradient the device computed for one minibatch of the run (dumped by the parent: logits, alignments, device results)
+    against the C restatement of Kaldi's chain computation (oracle/chain_oracle.c) on the same logits."""
+    from oracle import chain_c
+    d = np.load(path)
+    sups = build_supervisions([d["ali%d" % n] for n in range(int(d["n"]))])
+    want_out, want_grad = chain_c.chain_batch(g, pi, d["logits"], sups, 1e-4, float(d["xent"]))
+    got = d["gpu_out"].astype(np.float64)
+    rel = float(abs(got[0].sum() - want_out[0].sum()) / abs(want_out[0].sum()))
+    rel_seq = float((np.abs(got[0] - want_out[0]) / np.abs(want_out[0])).max())
+    gerr = float(np.abs(d["gpu_grad"] - want_grad).max())
+    return dict(objective_device=round(float(got[0].sum()), 4), objective_cpu_port=round(float(want_out[0].sum()), 4),
+                objective_rel_err=float("%.3g" % rel), objective_rel_err_worst_sequence=float("%.3g" % rel_seq),
+                den_logprob_rel_err=float("%.3g" % float((np.abs(got[2] - want_out[2]) / np.abs(want_out[2])).max())),
+                grad_max_abs_err=float("%.3g" % gerr), tolerance={"objective_rel": 1e-3, "grad_abs": 1e-4},
+                ok=bool(rel <= 1e-3 and rel_seq <= 1e-3 and gerr <= 1e-4),
+                frames=[int(s.frames_per_sequence) for s in sups],
+                against="oracle/chain_oracle.c (float32 restatement of Kaldi's DenominatorComputation / NumeratorComputation, "
+                        "SURVEY App. A; unpinned at the Kaldi boundary) on the logits of one minibatch of this run")
+
+
+def cpu_baseline_worker(seed, threads, parity_path=None):
     """Runs in a child process (no HIP context, bounded by a timeout): the same step on the host.
     numpy front end (oracle), the reference's torch CPU model path (nn.LSTM + nn.Linear,
     models/lstm.py:45-54), the C port of the chain objective, Adam(amsgrad) + clip."""
@@ -233,6 +266,12 @@ def cpu_baseline_worker(seed, threads):
     g = den_graph_arrays()
     pi = chain_ref.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
                                      g["prob"].astype(np.float64), 0)
+    parity = None
+    if parity_path:
+        try:
+            parity = chain_parity(g, pi, parity_path)
+        except Exception as e:       # the baseline is still worth reporting
+            parity = dict(ok=False, error=repr(e)[:300])
     rng = np.random.default_rng(seed)
     ali_model = chain_model()[2]
     torch.manual_seed(0)
@@ -259,16 +298,42 @@ def cpu_baseline_worker(seed, threads):
         seconds += sum(w.shape[0] for w, _ in host) / 16000.0
         steps += 1
     print(json.dumps(dict(value=round(seconds / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
-                          kind="port",
+                          kind="port", parity=parity,
                           sample="%d minibatches of 4 utterances (%.1f s audio): numpy fbank oracle + torch CPU 3x512 "
                                  "BLSTM fwd/bwd + C port of the LF-MMI objective (OpenMP over sequences) + Adam; "
                                  "%.1f s wall on %d threads" % (steps, seconds, dt, threads))), flush=True)
 
 
-def cpu_ce_worker(threads):
+def ce_parity(path):
+    """north star "CE frame posteriors within 1e-4 rel": the device's posteriors for chunks of one 256 x 80 minibatch of the
+    run (model in eval mode) against the reference's torch CPU modules (nn.LSTM + nn.Linear, models/lstm.py:45-54)
+    loaded with the same state_dict."""
+    d = torch.load(path)
+    PC = d["logits"].shape[-1]
+    rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, dropout=0.2, bidirectional=True).eval()
+    lin = torch.nn.Linear(1024, PC).eval()
+    rnn.load_state_dict({k[5:]: v for k, v in d["state_dict"].items() if k.startswith("lstm.")})
+    lin.load_state_dict({k[13:]: v for k, v in d["state_dict"].items() if k.startswith("output_layer.")})
+    with torch.no_grad():
+        want = torch.softmax(lin(rnn(d["x"])[0]).double(), -1)
+    got = torch.softmax(d["logits"].double(), -1)
+    rel = float(((got - want).abs() / want.clamp_min(1e-30)).max())
+    return dict(posterior_max_rel_err=float("%.3g" % rel), tolerance={"posterior_rel": 1e-4}, ok=bool(rel <= 1e-4),
+                chunks=int(d["x"].shape[0]), frames_per_chunk=int(d["x"].shape[1]),
+                against="torch CPU nn.LSTM(80, 512, 3, bidirectional) + nn.Linear with the run's state_dict "
+                        "(the reference's LSTMAM modules, models/lstm.py:45-54)")
+
+
+def cpu_ce_worker(threads, parity_path=None):
     """SURVEY 8(d) config 1 in a child process: the reference's torch CPU CE path (nn.LSTM + nn.Linear = models/lstm.py:45-54,
     nn.CrossEntropyLoss, clip 5, Adam(amsgrad, lr 1e-4)) on x[64,80,80], P=5768, dropout 0.2, on the node's host cores."""
     torch.set_num_threads(threads)
+    parity = None
+    if parity_path:
+        try:
+            parity = ce_parity(parity_path)
+        except Exception as e:
+            parity = dict(ok=False, error=repr(e)[:300])
     torch.manual_seed(0)
     B, T, PC = 64, 80, 5768
     rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, dropout=0.2, bidirectional=True)
@@ -292,16 +357,16 @@ def cpu_ce_worker(threads):
         n += 1
     dt = (time.time() - t0) / n
     print(json.dumps(dict(value=round(B * T * 0.01 / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
-                          kind="reference",
+                          kind="reference", parity=parity,
                           sample="%d steps of the reference's torch CPU CE path (nn.LSTM 3x512 bidirectional + Linear, "
                                  "CrossEntropyLoss, clip 5, Adam amsgrad) on x[64,80,80], P=5768: %.2f s per step on %d threads"
                                  % (n, dt, threads))), flush=True)
 
 
-def cpu_baseline(seed, timeout=240, worker="--cpu-baseline-worker"):
+def cpu_baseline(seed, timeout=240, worker="--cpu-baseline-worker", parity_path=None):
     import subprocess
     threads = usable_cores()
-    cmd = [sys.executable, os.path.abspath(__file__), worker, str(seed), str(threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), worker, str(seed), str(threads)] + ([parity_path] if parity_path else [])
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -357,10 +422,28 @@ def ce_workload(args, dev, rank, world):
     dt = time.perf_counter() - t0
     audio = args.steps * BATCH * CH * 0.01
     if rank == 0:
+        base = parity = None
+        if world == 1 and not args.no_cpu_baseline:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                # posteriors of the first 32 chunks of one minibatch, model in eval mode (dropout off), for the child
+                path = os.path.join(td, "ce_parity.pt")
+                mb = batches[0]
+                model.eval()
+                with torch.no_grad():
+                    feats, frames, row_off = fb(mb["wav"], mb["lens"])
+                    off = np.concatenate([[0], np.cumsum(frames)])
+                    x = torch.cat([fbank.utt2seg(feats[off[n]:off[n + 1]], CH, CH) for n in range(len(frames))])[:BATCH]
+                    lg = model.forward_time_major(x.transpose(0, 1).contiguous()).transpose(0, 1)[:32]
+                model.train()
+                torch.save(dict(state_dict={k: v.cpu() for k, v in model.state_dict().items()}, x=x[:32].cpu(),
+                                logits=lg.contiguous().cpu()), path)
+                base = cpu_baseline(0, worker="--cpu-ce-worker", parity_path=path)
+            parity = base.pop("parity", None)
         print(json.dumps({"metric": "iRTF (hrs audio/hr) 3x512 BLSTM CE, 256x80 chunks (secondary workload, configs[1])",
                           "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
                           "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "loss": round(float(loss.item()), 4),
-                          "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(0, worker="--cpu-ce-worker"),
+                          "cpu_baseline": base, "parity": parity,
                           "reference_published": "README.md:43-45: 190 iRTF (64x80, 1 V100), 520 iRTF (256x80, 4 V100)"}),
               flush=True)
     hvd.shutdown()
@@ -457,9 +540,9 @@ T_START = time.time()
 
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+        return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-ce-worker":
-        return cpu_ce_worker(int(sys.argv[3]))
+        return cpu_ce_worker(int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -630,10 +713,16 @@ def main():
         "roofline": roof, "roofline_lstm": roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
     }
     if world == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (child process, %d cores)" % usable_cores())
-        result["cpu_baseline"] = cpu_baseline(1234)
+        log("cpu baseline + parity (child process, %d cores)" % usable_cores())
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "parity.npz")
+            dump_chain_parity_inputs(tr, mb, path)
+            result["cpu_baseline"] = cpu_baseline(1234, parity_path=path)
+        result["parity"] = result["cpu_baseline"].pop("parity", None)
     else:
         result["cpu_baseline"] = None
+        result["parity"] = None
     print(json.dumps(result), flush=True)
     hvd.shutdown()
 

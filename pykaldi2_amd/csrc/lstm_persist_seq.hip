@@ -404,8 +404,18 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
   }
 }
 
+// A launch in which a poll timed out (or a pair was never finished) must not pass for a result: the forward
+// pass keeps its NaN sentinels in y, but the backward pass would leave dgx -- freshly allocated memory -- partly
+// unwritten.  One workgroup after every persistent launch turns the launch's output into NaN in that case and raises a
+// sticky flag (the control block itself is cleared by the next launch) that pk2_lstm_persist_status reports.
+__global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky) {
+  if (ctl->abort == 0u && ctl->done == pairs) return;
+  if (threadIdx.x == 0) *sticky = 1u;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------
-struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; };
+struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; };
 static std::map<hipStream_t, SeqScratch> g_seq_scratch;
 static int g_seq_state = -1;             // -1 untested, 0 unusable, 1 verified on this device
 
@@ -413,6 +423,10 @@ static int seq_scratch(hipStream_t stream, SeqScratch** out) {
   SeqScratch& sc = g_seq_scratch[stream];
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(SeqCtl)));
   if (!sc.mail) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.mail), (size_t)8 * kSeqTeams * kSeqMailFloats * sizeof(float)));
+  if (!sc.sticky) {
+    PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.sticky), sizeof(unsigned)));
+    PK2_HIP(hipMemsetAsync(sc.sticky, 0, sizeof(unsigned), stream));
+  }
   *out = &sc;
   return PK2_OK;
 }
@@ -460,6 +474,7 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
     g_seq_state = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
+  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky);
   *ran = true;
   return PK2_OK;
 }
@@ -475,6 +490,7 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * kSeqTeams * kSeqMailFloats, stream));
   SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D};
   hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
+  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky);
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;
@@ -488,6 +504,8 @@ int lstm_seq_status(unsigned* abort_flag) {
     hipError_t e = hipMemcpy(h, kv.second.ctl, sizeof(SeqCtl), hipMemcpyDeviceToHost);
     if (e == hipSuccess) any |= h->abort;
     delete h;
+    unsigned st = 0;
+    if (kv.second.sticky && hipMemcpy(&st, kv.second.sticky, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) any |= st;
   }
   *abort_flag = any;
   return PK2_OK;

@@ -157,23 +157,86 @@ def broadcast_parameters(params, root_rank=0):
             dist.broadcast(t, src=root_rank)
 
 
+def _bcast_device():
+    """Where a small control tensor has to live for the process group's backend (RCCL moves device memory only)."""
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _bcast_inplace(t, root_rank):
+    """Broadcast into `t` itself, whatever device the backend wants the payload on."""
+    dev = _bcast_device()
+    if t.device.type == dev.type:
+        dist.broadcast(t, src=root_rank)
+    else:
+        tmp = t.to(dev)
+        dist.broadcast(tmp, src=root_rank)
+        t.copy_(tmp)
+
+
 def broadcast_optimizer_state(optimizer, root_rank=0):
-    """Broadcasts tensors held in the optimiser state (reference bin/train_ce.py:128).  State created
-    lazily on the first step (the usual case at start-up) needs no exchange."""
+    """Makes every rank's optimiser state equal to root's (reference bin/train_ce.py:128, after -resume_from_model).
+
+    * pykaldi2_amd.optim optimisers (also behind DistributedOptimizer): the LIVE flat buffers (exp_avg, exp_avg_sq,
+      max_exp_avg_sq / the momentum buffer) and the step counter are broadcast in place; a rank that has no state yet while
+      root has one (only root read the checkpoint) allocates it first, and root having none (the usual fresh start: state is
+      created on the first step) means nothing is exchanged.  state_dict() returns per-parameter COPIES in torch.optim's
+      format, so broadcasting into those would never reach the buffers the update kernel reads.
+    * any torch.optim optimiser: every tensor of optimizer.state in place (CPU `step` scalars travel on the backend's
+      device), python numbers through broadcast_object_list."""
     if not _collective():
         return
-    sd = optimizer.state_dict()
+    opt = getattr(optimizer, "_opt", optimizer)
+    if hasattr(opt, "model") and hasattr(opt.model, "flat_parameters"):
+        p, _ = opt.model.flat_parameters()
+        adam = hasattr(opt, "betas")
+        names = ["exp_avg", "exp_avg_sq", "max_exp_avg_sq"] if adam else ["momentum_buffer"]
 
-    def walk(o):
-        if torch.is_tensor(o):
-            dist.broadcast(o, src=root_rank)
-        elif isinstance(o, dict):
-            for k in sorted(o, key=str):
-                walk(o[k])
-        elif isinstance(o, (list, tuple)):
-            for v in o:
-                walk(v)
-    walk(sd.get("state", sd))
+        def live():
+            if adam:
+                return None if opt.state is None else [opt.state[k] for k in names]
+            return None if opt.buf is None else [opt.buf]
+        cur = live()
+        hdr = torch.tensor([int(opt.step_count), 0 if cur is None else 1] + [0 if (cur is None or t is None) else 1 for t in (cur or [None] * len(names))],
+                           dtype=torch.int64, device=_bcast_device())
+        dist.broadcast(hdr, src=root_rank)
+        h = [int(v) for v in hdr.cpu()]
+        if not h[1]:                         # root has no state: every rank starts from zero moments, like root will
+            if adam:
+                opt.state = None
+            else:
+                opt.buf = None
+            opt.step_count = h[0]
+            return
+        if cur is None or any(t is None and h[2 + i] for i, t in enumerate(cur)) or (cur[0] is not None and cur[0].device != p.device):
+            if adam:
+                opt.state = {k: (torch.zeros_like(p) if h[2 + i] else None) for i, k in enumerate(names)}
+            else:
+                opt.buf = torch.zeros_like(p)
+            cur = live()
+        for t in cur:
+            if t is not None:
+                _bcast_inplace(t, root_rank)
+        opt.step_count = h[0]
+        lr = torch.tensor([float(opt.param_groups[0]["lr"])], dtype=torch.float64, device=_bcast_device())
+        dist.broadcast(lr, src=root_rank)
+        opt.param_groups[0]["lr"] = float(lr.item())
+        return
+    state = getattr(opt, "state", None)
+    if not isinstance(state, dict):
+        return
+    params = [q for grp in opt.param_groups for q in grp["params"]]
+    for q in params:
+        st = state.get(q)
+        if not isinstance(st, dict):
+            continue
+        for k in sorted(st, key=str):
+            v = st[k]
+            if torch.is_tensor(v):
+                _bcast_inplace(v, root_rank)
+            elif isinstance(v, (int, float)):
+                box = [v]
+                dist.broadcast_object_list(box, src=root_rank)
+                st[k] = box[0]
 
 
 def allreduce_(tensor, average=True):

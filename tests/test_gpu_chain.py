@@ -223,3 +223,64 @@ def test_denominator_large_pdf_counts_use_narrower_groups(P, arc_pdf):
         assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp) + 1e-4, (n, lp[n], want_lp)
         assert np.abs(gamma[n, :Tn] - want_g).max() < 1e-4
         assert not gamma[n, Tn:].any()
+
+
+def test_bench_size_denominator_matches_c_oracle(monkeypatch):
+    """The north-star kernel where it is measured (VERDICT r2 #1a): S = 30 k, A = 1 M, P = 6048, Kaldi chain topology,
+    4 ragged sequences of T' ~ 130.  The call must take the persistent kernel (path 2); den log-prob within 1e-3 rel
+    and occupancies within 1e-4 abs of the C restatement of Kaldi's DenominatorComputation (oracle/chain_oracle.c,
+    float32 state like Kaldi), and of the launch-per-frame kernels (PK2_DEN_PERSIST=0)."""
+    from oracle import chain_c
+    P = 6048
+    g = synth.den_graph_arcs(30000, 1000000, P, seed=0, loop_pdf_differs=True)
+    G = chain.DenominatorGraph(g, P)
+    lens = [130, 77, 101, 64]
+    assert G.kernel_path(len(lens)) == 2
+    pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
+                             g["prob"].astype(np.float64), 0)
+    assert np.abs(G.initial_probs() - pi).max() < 1e-6
+    rng = np.random.default_rng(9)
+    lg = rng.normal(0, 2, size=(4, 130, P)).astype(np.float32)
+    x = torch.from_numpy(lg).cuda()
+    lp, gamma = chain.den_forward_backward(G, x, lens, 1e-4)
+    lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, chk = chain_c.den_fb(g, pi, lg[n, :Tn], 1e-4)
+        assert abs(chk - 1.0) < 1e-3
+        assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp), (n, lp[n], want_lp)
+        err = np.abs(gamma[n, :Tn] - want_g).max()
+        assert err < 1e-4, (n, err)
+        assert not gamma[n, Tn:].any()
+    monkeypatch.setenv("PK2_DEN_PERSIST", "0")
+    assert G.kernel_path(len(lens)) == 1
+    lp_f, gamma_f = chain.den_forward_backward(G, x, lens, 1e-4)
+    assert np.abs(lp_f.cpu().numpy() - lp).max() <= 1e-5 * np.abs(lp).max()
+    assert np.abs(gamma_f.cpu().numpy() - gamma).max() < 1e-5
+
+
+def test_bench_size_objective_with_alignment_built_supervisions_matches_c_oracle():
+    """Full LF-MMI objective and logit gradient at the bench configuration (S = 30 k / A = 1 M / P = 6048, supervisions
+    built from transition-id alignments as bench.py and bin/train_chain.py:262-272 do, xent_regularize 0.1) against
+    oracle/chain_oracle.c on the same logits: objective 1e-3 rel (north star), gradient 1e-4 abs."""
+    from oracle import chain_c
+    P = 6048
+    g = synth.den_graph_arcs(30000, 1000000, P, seed=0, loop_pdf_differs=True)
+    G = chain.DenominatorGraph(g, P)
+    tree, tm = synth.chain_model(P, seed=0)
+    aligner, sopts = chain.MappedAligner(tm), chain.SupervisionOptions()
+    rng = np.random.default_rng(5)
+    frames = [390, 231, 303, 192]                          # network-input frames -> T' = ceil(T / 3)
+    sups = [chain.supervision_from_alignment(aligner, tree, tm, sopts, synth.phone_tid_alignment(rng, T, tm)[0])
+            for T in frames]
+    lens = [s.frames_per_sequence for s in sups]
+    assert lens == [130, 77, 101, 64] and G.kernel_path(4) == 2
+    lg = rng.normal(0, 2, size=(4, max(lens), P)).astype(np.float32)
+    opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=0.1)
+    out, grad = chain.compute_chain_objf_and_deriv(opts, G, sups, torch.from_numpy(lg).cuda())
+    pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
+                             g["prob"].astype(np.float64), 0)
+    want_out, want_grad = chain_c.chain_batch(g, pi, lg, sups, 1e-4, 0.1)
+    got = out.cpu().numpy()
+    assert np.abs(got[0] - want_out[0]).max() <= 1e-3 * np.abs(want_out[0]).max(), (got[0], want_out[0])
+    assert abs(got[0].sum() - want_out[0].sum()) <= 1e-3 * abs(want_out[0].sum())
+    assert np.abs(grad.cpu().numpy() - want_grad).max() < 1e-4

@@ -221,6 +221,44 @@ def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
 
 
+def test_full_size_ce_configuration_matches_torch_cpu():
+    """configs[1] at its full size (VERDICT r2 #1d): 256 chunks x 80 frames x 80 fbank bins, 3x512 BLSTM, P = 5768,
+    dropout 0 -- the large-batch recurrence kernels at the shape bench.py --ce times them -- against the reference's
+    torch CPU path (nn.LSTM + nn.Linear = models/lstm.py:45-54, nn.CrossEntropyLoss): frame posteriors 1e-4 rel
+    (north star), the loss, and every parameter gradient."""
+    torch.manual_seed(3)
+    B, T, P = 256, 80, 5768
+    m = lstm.LSTMAM(80, P, 512, 3, 0.0, True)
+    ref_lstm = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
+    ref_out = torch.nn.Linear(1024, P)
+    ref_lstm.load_state_dict({k[5:]: v for k, v in m.state_dict().items() if k.startswith("lstm.")})
+    ref_out.load_state_dict({k[13:]: v for k, v in m.state_dict().items() if k.startswith("output_layer.")})
+    x = torch.randn(B, T, 80)
+    tgt = torch.randint(0, P, (B, T))
+    tgt[5, 60:] = -100
+    ref_logits = ref_out(ref_lstm(x)[0])
+    ref_loss = torch.nn.CrossEntropyLoss(ignore_index=-100)(ref_logits.view(-1, P), tgt.view(-1))
+    ref_loss.backward()
+    m = m.cuda()
+    logits = m.forward_time_major(x.cuda().transpose(0, 1).contiguous()).transpose(0, 1)       # as bench.py --ce
+    # posteriors in float64 from both sets of logits, a slab of rows at a time (B*T*P doubles would be 9 GB)
+    rel = 0.0
+    for b0 in range(0, B, 32):
+        post = torch.softmax(logits[b0:b0 + 32].double().cpu(), -1)
+        ref_post = torch.softmax(ref_logits[b0:b0 + 32].double().detach(), -1)
+        rel = max(rel, ((post - ref_post).abs() / ref_post.clamp_min(1e-30)).max().item())
+    assert rel < 1e-4, rel
+    loss = ops.CrossEntropyLoss(ignore_index=-100)(logits, tgt.cuda())
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    loss.backward()
+    refg = dict(list(("lstm." + k, v.grad) for k, v in ref_lstm.named_parameters()) +
+                list(("output_layer." + k, v.grad) for k, v in ref_out.named_parameters()))
+    for name, p in m.named_parameters():
+        want = refg[name]
+        e = (p.grad.cpu() - want).abs().max().item()
+        assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
+
+
 def test_cross_entropy_matches_reference_golden(golden):
     g = golden("misc")
     for red in ("mean", "sum"):

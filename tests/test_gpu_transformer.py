@@ -189,3 +189,39 @@ def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle
     for n_, e_ in zip(names, e_dev):
         if n_.startswith("output_layer.") or n_.startswith("transformer.norm."):
             assert e_ < 1e-5, (n_, e_)
+
+
+@pytest.mark.parametrize("tag", ["small", "heads16"])
+def test_transformer_matches_reference_golden(golden, tag):
+    """tests/golden/transformer.npz is written by tools/gen_golden.py::gen_transformer, which IMPORTS the reference's
+    models/transformer.py (TransformerAM, TransformerEncoderLayerWithConv1d) and runs its layers on CPU: the reference's
+    own state_dict loads with strict=True, logits and all parameter gradients match (head size 64 = fused attention with a
+    look-ahead mask; head size 16 = the batched-GEMM attention; padded keys in both)."""
+    g = golden("transformer")
+    D, C, H, FF, L, P, T, B, look = (int(v) for v in g[tag + "_cfg"])
+    m = transformer.TransformerAM(D, C, H, FF, L, 0.0, P)
+    sd = {k[len(tag) + 7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
+    sd["pos_encoder.pe"] = m.state_dict()["pos_encoder.pe"]
+    assert np.array_equal(sd["pos_encoder.pe"][:8].numpy(), g[tag + "_pe_head"])
+    m.load_state_dict(sd, strict=True)
+    lens = [int(v) for v in g[tag + "_lens"]]
+    kpm = torch.ones(B, T)
+    for i, n in enumerate(lens):
+        kpm[i, :n] = 0
+    src_mask = None
+    if look > -1:
+        tri = torch.tril(torch.ones(T, T), diagonal=look)
+        src_mask = tri.float().masked_fill(tri == 0, float("-inf")).masked_fill(tri == 1, 0.0).cuda()
+    m = m.cuda().train()
+    got = m(torch.from_numpy(g[tag + "_x"]).cuda(), src_mask, kpm.bool().cuda())
+    want = torch.from_numpy(g[tag + "_logits"])
+    valid = torch.zeros(T, B, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        valid[:n, i] = True
+    err = (got.cpu() - want)[valid].abs().max().item()
+    assert err < 2e-4 * max(1.0, want[valid].abs().max().item()), err
+    (got * torch.from_numpy(g[tag + "_w"]).cuda()).sum().backward()
+    for name, p in m.named_parameters():
+        rg = torch.from_numpy(g[tag + "_grad_" + name])
+        e = (p.grad.cpu() - rg).abs().max().item()
+        assert e < 5e-4 * max(1e-2, rg.abs().max().item()), (name, e, rg.abs().max().item())

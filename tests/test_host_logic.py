@@ -175,6 +175,79 @@ def test_hvd_flat_bucketed_allreduce_world_size_2_gloo(tmp_path, overlap):
     assert all("OK" in o for o in outs)
 
 
+RESUME_WORKER = r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pykaldi2_amd import hvd, lstm, optim
+hvd.init(backend="gloo")
+rank = hvd.rank()
+
+def same_on_all_ranks(t):
+    lo, hi = t.detach().clone().double(), t.detach().clone().double()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return torch.equal(lo, hi)
+
+torch.manual_seed(0)
+m = lstm.LSTMAM(8, 11, 16, 2, 0.0, True)
+# a reference-written optimiser state (torch.optim format), different on every rank; rank 1 of the SGD case has none at all
+lin = torch.nn.Linear(32, 11); rnn = torch.nn.LSTM(8, 16, 2, batch_first=True, bidirectional=True)
+ref_params = list(lin.parameters()) + list(rnn.parameters())
+torch.manual_seed(100 + rank)
+for name in ("adam", "sgd"):
+    topt = torch.optim.Adam(ref_params, lr=1e-3 * (rank + 1), amsgrad=True) if name == "adam" else torch.optim.SGD(ref_params, lr=1e-2, momentum=0.9)
+    for _ in range(2 + rank):
+        for p in ref_params:
+            p.grad = torch.randn_like(p)
+        topt.step()
+    ours = optim.Adam(m, lr=5.0, amsgrad=True) if name == "adam" else optim.SGD(m, lr=5.0, momentum=0.9)
+    if name == "adam" or rank == 0:
+        ours.load_state_dict(topt.state_dict())
+    wrapped = hvd.DistributedOptimizer(ours, named_parameters=m.named_parameters())
+    hvd.broadcast_optimizer_state(wrapped, root_rank=0)
+    live = [ours.state[k] for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")] if name == "adam" else [ours.buf]
+    assert all(t is not None and same_on_all_ranks(t) for t in live), name
+    assert all(float(t.abs().sum()) > 0 for t in live)
+    if name == "adam":
+        assert ours.step_count == 2 and ours.param_groups[0]["lr"] == 1e-3      # root's
+        # the broadcast reached the buffers the update kernel reads, not copies: state_dict() shows root's moments
+        sd = ours.state_dict()["state"]
+        assert same_on_all_ranks(sd[3]["exp_avg"]) and float(sd[0]["step"]) == 2.0
+# a fresh start: root has no state, nothing to exchange, nobody hangs
+fresh = optim.Adam(m, lr=1e-3, amsgrad=True)
+hvd.broadcast_optimizer_state(fresh, root_rank=0)
+assert fresh.state is None and fresh.step_count == 0
+# torch.optim optimisers: tensors in place, including the CPU `step` scalars
+t2 = torch.optim.Adam(ref_params, lr=1e-3, amsgrad=True)
+for _ in range(1 + rank):
+    for p in ref_params:
+        p.grad = torch.randn_like(p)
+    t2.step()
+hvd.broadcast_optimizer_state(t2, root_rank=0)
+for p in ref_params:
+    st = t2.state[p]
+    assert same_on_all_ranks(st["exp_avg"]) and float(st["step"]) == 1.0
+print("OK", rank)
+hvd.shutdown()
+"""
+
+
+def test_broadcast_optimizer_state_after_resume_world_size_2_gloo(tmp_path):
+    """-resume_from_model + hvd.broadcast_optimizer_state (reference bin/train_ce.py:128) must make the
+    LIVE flat moments of every rank equal to root's (state_dict() hands out copies), also when only root has a state."""
+    script = tmp_path / "r.py"
+    script.write_text(RESUME_WORKER % dict(root=ROOT))
+    port = str(29700 + os.getpid() % 150)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)
+
+
 def test_optimizer_state_dicts_are_torch_optim_format():
     """the checkpoints of the reference hold torch.optim state dicts (bin/train_ce.py:160-165); the flat
     fused optimisers read and write that format, so `-resume_from_model` works across the two code bases."""
@@ -212,3 +285,19 @@ def test_optimizer_state_dicts_are_torch_optim_format():
     fresh = optim.Adam(m, lr=1e-3, amsgrad=True)
     assert fresh.state_dict()["state"] == {}
     fresh.load_state_dict(fresh.state_dict())
+
+
+def test_reference_transformer_state_dict_loads_strict(golden):
+    """tests/golden/transformer.npz holds the state_dict of the reference's models/transformer.py::TransformerAM
+    (tools/gen_golden.py::gen_transformer imports it): same keys and shapes as pykaldi2_amd.transformer.TransformerAM."""
+    import torch
+    from pykaldi2_amd import transformer
+    g = golden("transformer")
+    for tag in ("small", "heads16"):
+        D, C, H, FF, L, P = (int(v) for v in g[tag + "_cfg"][:6])
+        m = transformer.TransformerAM(D, C, H, FF, L, 0.0, P)
+        sd = {k[len(tag) + 7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
+        sd["pos_encoder.pe"] = m.state_dict()["pos_encoder.pe"]
+        assert np.array_equal(sd["pos_encoder.pe"][:8].numpy(), g[tag + "_pe_head"])
+        m.load_state_dict(sd, strict=True)
+        assert sorted(n for n, _ in m.named_parameters()) == sorted(k[len(tag) + 6:] for k in g.files if k.startswith(tag + "_grad_"))

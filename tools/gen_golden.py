@@ -260,6 +260,53 @@ def gen_e2e():
     print("e2e", out["logp_sub"].shape, out["frames"])
 
 
+def gen_transformer():
+    """models/transformer.py:52-94 imported as it is.  Fix-up: nn.TransformerEncoder's
+    forward reads attributes of the custom layer that torch >= 2 expects of nn.TransformerEncoderLayer, so the module's
+    own layers are called one after the other (what nn.TransformerEncoder.forward does on the pinned torch 1.2), then
+    its final norm and the output layer.  The positional encoder is commented out in the reference's forward."""
+    tr = load_by_path("ref_transformer", "models/transformer.py")
+    out = {}
+    for tag, (D, C, H, FF, L, P, T, B, look) in dict(small=(20, 128, 2, 96, 2, 37, 19, 3, 2),
+                                                     heads16=(24, 64, 4, 128, 3, 29, 40, 2, -1)).items():
+        torch.manual_seed(1)
+        m = tr.TransformerAM(D, C, H, FF, L, 0.0, P)
+        for lp in m.transformer.layers:      # nn.TransformerEncoder deep-copies one initialised layer: break the symmetry
+            for p_ in lp.parameters():
+                p_.data.add_(0.02 * torch.randn_like(p_))
+        x = torch.randn(T, B, D)
+        lens = [T] + [max(1, T - 4 - 3 * i) for i in range(B - 1)]
+        kpm = torch.ones(B, T)
+        for i, n in enumerate(lens):
+            kpm[i, :n] = 0
+        kpm = kpm.bool()
+        src_mask = None
+        if look > -1:
+            tri = torch.tril(torch.ones(T, T), diagonal=look)
+            src_mask = tri.float().masked_fill(tri == 0, float("-inf")).masked_fill(tri == 1, 0.0)
+        h = m.input_layer(x)
+        for layer in m.transformer.layers:
+            h = layer(h, src_mask, kpm)      # TransformerEncoderLayerWithConv1d.forward, models/transformer.py:62-66
+        logits = m.output_layer(m.transformer.norm(h))
+        w = torch.randn(T, B, P)
+        for i, n in enumerate(lens):
+            w[n:, i] = 0                     # padded query rows carry no loss in the reference's training scripts
+        (logits * w).sum().backward()
+        out[tag + "_cfg"] = np.asarray([D, C, H, FF, L, P, T, B, look])
+        out[tag + "_lens"] = np.asarray(lens)
+        out[tag + "_x"] = x.numpy()
+        out[tag + "_w"] = w.numpy()
+        out[tag + "_logits"] = logits.detach().numpy()
+        for k, v in m.state_dict().items():
+            if k != "pos_encoder.pe":        # a 5000 x C sine table, unused by the reference's forward: first rows only
+                out[tag + "_param_" + k] = v.numpy().copy()
+        out[tag + "_pe_head"] = m.state_dict()["pos_encoder.pe"][:8].numpy().copy()
+        for k, v in m.named_parameters():
+            out[tag + "_grad_" + k] = v.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "transformer.npz"), **out)
+    print("transformer keys", len(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_chunk_mvn()
@@ -267,3 +314,4 @@ if __name__ == "__main__":
     gen_lstm()
     gen_ce_optim_misc()
     gen_e2e()
+    gen_transformer()
