@@ -241,7 +241,7 @@ def chain_parity(g, pi, path):
     from oracle import chain_c
     d = np.load(path)
     sups = build_supervisions([d["ali%d" % n] for n in range(int(d["n"]))])
-    want_out, want_grad = chain_c.chain_batch(g, pi, d["logits"], sups, 1e-4, float(d["xent"]))
+    want_out, want_grad = chain_c.chain_batch(g, pi, d["logits"], sups, 1e-4, float(d["xent"]), double=True)
     got = d["gpu_out"].astype(np.float64)
     rel = float(abs(got[0].sum() - want_out[0].sum()) / abs(want_out[0].sum()))
     rel_seq = float((np.abs(got[0] - want_out[0]) / np.abs(want_out[0])).max())
@@ -252,7 +252,7 @@ def chain_parity(g, pi, path):
                 grad_max_abs_err=float("%.3g" % gerr), tolerance={"objective_rel": 1e-3, "grad_abs": 1e-4},
                 ok=bool(rel <= 1e-3 and rel_seq <= 1e-3 and gerr <= 1e-4),
                 frames=[int(s.frames_per_sequence) for s in sups],
-                against="oracle/chain_oracle.c (float32 restatement of Kaldi's DenominatorComputation / NumeratorComputation, "
+                against="oracle/chain_oracle.c, float64 build (restatement of Kaldi's DenominatorComputation / NumeratorComputation, "
                         "SURVEY App. A; unpinned at the Kaldi boundary) on the logits of one minibatch of this run")
 
 

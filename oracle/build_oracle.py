@@ -9,14 +9,16 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libchain_oracle.so")
+LIB64 = os.path.join(OUT, "libchain_oracle_f64.so")      # the same recursion with double state (parity at bench size)
 
 
-def build():
+def build(double=False):
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(HERE, "chain_oracle.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-fopenmp", "-shared", "-fPIC", src, "-o", LIB, "-lm"])
-    return LIB
+    for lib, extra in ((LIB, []), (LIB64, ["-DORC_REAL=double"])):
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-fopenmp", "-shared", "-fPIC"] + extra + [src, "-o", lib, "-lm"])
+    return LIB64 if double else LIB
 
 
 if __name__ == "__main__":

@@ -5,22 +5,22 @@ import numpy as np
 
 from . import build_oracle
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build_oracle.build())
-        _lib.orc_den_fb.restype = C.c_double
-    return _lib
+def lib(double=False):
+    """double=False: float32 state like Kaldi's BaseFloat (the timed cpu_baseline); True: the float64 build."""
+    if double not in _libs:
+        _libs[double] = C.CDLL(build_oracle.build(double))
+        _libs[double].orc_den_fb.restype = C.c_double
+    return _libs[double]
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def den_fb(g, pi, logits, leaky):
+def den_fb(g, pi, logits, leaky, double=False):
     """g: dict of arc arrays; returns (logprob, gamma[T,P], check)."""
     T, P = logits.shape
     lg = np.ascontiguousarray(logits, dtype=np.float32)
@@ -29,13 +29,13 @@ def den_fb(g, pi, logits, leaky):
     src, dst, pdf = (np.ascontiguousarray(g[k], dtype=np.int32) for k in ("src", "dst", "pdf"))
     prob = np.ascontiguousarray(g["prob"], dtype=np.float32)
     pi = np.ascontiguousarray(pi, dtype=np.float32)
-    lp = lib().orc_den_fb(C.c_int(g["num_states"]), C.c_int(P), C.c_int64(src.shape[0]), _p(src), _p(dst), _p(pdf),
+    lp = lib(double).orc_den_fb(C.c_int(g["num_states"]), C.c_int(P), C.c_int64(src.shape[0]), _p(src), _p(dst), _p(pdf),
                           _p(prob), _p(pi), _p(lg), C.c_int64(P), C.c_int(T), C.c_float(leaky), C.c_float(1.0),
                           _p(gamma), C.c_int64(P), C.byref(chk))
     return lp, gamma, chk.value
 
 
-def chain_batch(g, pi, logits, sups, leaky, xent, weight=1.0):
+def chain_batch(g, pi, logits, sups, leaky, xent, weight=1.0, double=False):
     """logits [N,Tmax,P] float32; sups: list of objects with the chain.Supervision fields.
     Returns (out[3,N], grad[N,Tmax,P])."""
     N, Tmax, P = logits.shape
@@ -56,7 +56,7 @@ def chain_batch(g, pi, logits, sups, leaky, xent, weight=1.0):
     n_finw = np.concatenate([s.final_weights for s in sups]).astype(np.float32)
     n_finoff = np.cumsum([0] + [s.final_states.shape[0] for s in sups]).astype(np.int32)
     out = np.zeros(3 * N, dtype=np.float64)
-    lib().orc_chain_batch(C.c_int(g["num_states"]), C.c_int(P), C.c_int64(src.shape[0]), _p(src), _p(dst), _p(pdf),
+    lib(double).orc_chain_batch(C.c_int(g["num_states"]), C.c_int(P), C.c_int64(src.shape[0]), _p(src), _p(dst), _p(pdf),
                           _p(prob), _p(pi), _p(lg), C.c_int64(Tmax * P), C.c_int64(P), _p(lengths), C.c_int(N),
                           _p(n_src), _p(n_dst), _p(n_pdf), _p(n_w), _p(n_foff), _p(arc_base), _p(n_states),
                           _p(n_fin), _p(n_finw), _p(n_finoff), C.c_float(leaky), C.c_float(xent), C.c_float(weight),

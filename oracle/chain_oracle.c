@@ -17,33 +17,42 @@
 
 /* Denominator forward-backward of ONE sequence.  Arcs: src,dst,pdf,prob.  gamma[T*P] += occupancy
  * * scale.  Returns log p_den; *check receives sum_h alpha'[0,h] beta'[0,h]. */
+/* State type of the denominator recursion: float = Kaldi's BaseFloat (the build bench.py's cpu_baseline times);
+ * -DORC_REAL=double builds libchain_oracle_f64.so, the same recursion without float32 rounding, which the parity
+ * checks at bench size compare the device with (at T ~ 600 frames the float build itself is ~1e-4 away from it). */
+#ifndef ORC_REAL
+#define ORC_REAL float
+#endif
+typedef ORC_REAL real;
+
 double orc_den_fb(int S, int P, int64_t A, const int32_t* src, const int32_t* dst, const int32_t* pdf,
                   const float* prob, const float* pi, const float* logits, int64_t row_stride, int T,
                   float leaky, float scale, float* gamma, int64_t grow_stride, double* check) {
-  float* alpha = (float*)malloc(sizeof(float) * (size_t)(T + 1) * S); /* alpha' (with leaky term) */
-  float* asum = (float*)malloc(sizeof(float) * (size_t)(T + 1));
-  float* x = (float*)malloc(sizeof(float) * (size_t)P);
-  float* bcur = (float*)malloc(sizeof(float) * (size_t)S);
-  float* bnext = (float*)malloc(sizeof(float) * (size_t)S);
-  float* a = (float*)malloc(sizeof(float) * (size_t)S);
-  memcpy(a, pi, sizeof(float) * S);
+  real* alpha = (real*)malloc(sizeof(real) * (size_t)(T + 1) * S); /* alpha' (with leaky term) */
+  real* asum = (real*)malloc(sizeof(real) * (size_t)(T + 1));
+  real* x = (real*)malloc(sizeof(real) * (size_t)P);
+  real* bcur = (real*)malloc(sizeof(real) * (size_t)S);
+  real* bnext = (real*)malloc(sizeof(real) * (size_t)S);
+  real* a = (real*)malloc(sizeof(real) * (size_t)S);
+  real* grow = (real*)malloc(sizeof(real) * (size_t)P);
+  for (int h = 0; h < S; ++h) a[h] = pi[h];
   double logp = 0.0;
   for (int t = 0; t <= T; ++t) {
     double s = 0.0;
     for (int h = 0; h < S; ++h) s += a[h];
-    asum[t] = (float)s;
-    float* ad = alpha + (size_t)t * S;
-    for (int h = 0; h < S; ++h) ad[h] = a[h] + leaky * asum[t] * pi[h];
+    asum[t] = (real)s;
+    real* ad = alpha + (size_t)t * S;
+    for (int h = 0; h < S; ++h) ad[h] = a[h] + (real)leaky * asum[t] * (real)pi[h];
     if (t == T) break;
     const float* row = logits + (int64_t)t * row_stride;
     for (int p = 0; p < P; ++p) {
       float v = row[p];
       v = v < -30.f ? -30.f : (v > 30.f ? 30.f : v);
-      x[p] = expf(v);
+      x[p] = sizeof(real) == sizeof(float) ? (real)expf(v) : (real)exp((double)v);
     }
-    memset(a, 0, sizeof(float) * S);
-    const float inv = 1.0f / asum[t];
-    for (int64_t k = 0; k < A; ++k) a[dst[k]] += ad[src[k]] * prob[k] * x[pdf[k]] * inv;
+    memset(a, 0, sizeof(real) * S);
+    const real inv = (real)1.0 / asum[t];
+    for (int64_t k = 0; k < A; ++k) a[dst[k]] += ad[src[k]] * (real)prob[k] * x[pdf[k]] * inv;
     logp += log((double)asum[t]);
   }
   double tot = 0.0;
@@ -51,24 +60,26 @@ double orc_den_fb(int S, int P, int64_t A, const int32_t* src, const int32_t* ds
   logp += log(tot);
   /* beta */
   double pb = 0.0;
-  for (int h = 0; h < S; ++h) { bnext[h] = (float)(1.0 / tot); pb += (double)pi[h] * bnext[h]; }
-  for (int h = 0; h < S; ++h) bnext[h] += leaky * (float)pb;
+  for (int h = 0; h < S; ++h) { bnext[h] = (real)(1.0 / tot); pb += (double)pi[h] * bnext[h]; }
+  for (int h = 0; h < S; ++h) bnext[h] += (real)leaky * (real)pb;
   for (int t = T - 1; t >= 0; --t) {
     const float* row = logits + (int64_t)t * row_stride;
     for (int p = 0; p < P; ++p) {
       float v = row[p];
       v = v < -30.f ? -30.f : (v > 30.f ? 30.f : v);
-      x[p] = expf(v);
+      x[p] = sizeof(real) == sizeof(float) ? (real)expf(v) : (real)exp((double)v);
     }
-    const float* ad = alpha + (size_t)t * S;
-    float* grow = gamma + (int64_t)t * grow_stride;
-    const float inv = 1.0f / asum[t];
-    memset(bcur, 0, sizeof(float) * S);
+    const real* ad = alpha + (size_t)t * S;
+    float* gout = gamma + (int64_t)t * grow_stride;
+    const real inv = (real)1.0 / asum[t];
+    memset(bcur, 0, sizeof(real) * S);
+    memset(grow, 0, sizeof(real) * P);
     for (int64_t k = 0; k < A; ++k) {
-      const float f = prob[k] * x[pdf[k]] * bnext[dst[k]] * inv;
+      const real f = (real)prob[k] * x[pdf[k]] * bnext[dst[k]] * inv;
       bcur[src[k]] += f;
-      grow[pdf[k]] += scale * ad[src[k]] * f;
+      grow[pdf[k]] += ad[src[k]] * f;
     }
+    for (int p = 0; p < P; ++p) gout[p] += scale * (float)grow[p];
     pb = 0.0;
     for (int h = 0; h < S; ++h) pb += (double)pi[h] * bcur[h];
     if (t == 0 && check) {
@@ -76,9 +87,9 @@ double orc_den_fb(int S, int P, int64_t A, const int32_t* src, const int32_t* ds
       for (int h = 0; h < S; ++h) c += (double)alpha[h] * bcur[h];
       *check = c;
     }
-    for (int h = 0; h < S; ++h) bnext[h] = bcur[h] + leaky * (float)pb;
+    for (int h = 0; h < S; ++h) bnext[h] = bcur[h] + (real)leaky * (real)pb;
   }
-  free(alpha); free(asum); free(x); free(bcur); free(bnext); free(a);
+  free(alpha); free(asum); free(x); free(bcur); free(bnext); free(a); free(grow);
   return logp;
 }
 

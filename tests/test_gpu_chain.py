@@ -229,7 +229,7 @@ def test_bench_size_denominator_matches_c_oracle(monkeypatch):
     """The north-star kernel where it is measured (VERDICT r2 #1a): S = 30 k, A = 1 M, P = 6048, Kaldi chain topology,
     4 ragged sequences of T' ~ 130.  The call must take the persistent kernel (path 2); den log-prob within 1e-3 rel
     and occupancies within 1e-4 abs of the C restatement of Kaldi's DenominatorComputation (oracle/chain_oracle.c,
-    float32 state like Kaldi), and of the launch-per-frame kernels (PK2_DEN_PERSIST=0)."""
+    its float64 build), and of the launch-per-frame kernels (PK2_DEN_PERSIST=0)."""
     from oracle import chain_c
     P = 6048
     g = synth.den_graph_arcs(30000, 1000000, P, seed=0, loop_pdf_differs=True)
@@ -245,7 +245,7 @@ def test_bench_size_denominator_matches_c_oracle(monkeypatch):
     lp, gamma = chain.den_forward_backward(G, x, lens, 1e-4)
     lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
     for n, Tn in enumerate(lens):
-        want_lp, want_g, chk = chain_c.den_fb(g, pi, lg[n, :Tn], 1e-4)
+        want_lp, want_g, chk = chain_c.den_fb(g, pi, lg[n, :Tn], 1e-4, double=True)
         assert abs(chk - 1.0) < 1e-3
         assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp), (n, lp[n], want_lp)
         err = np.abs(gamma[n, :Tn] - want_g).max()
@@ -279,7 +279,7 @@ def test_bench_size_objective_with_alignment_built_supervisions_matches_c_oracle
     out, grad = chain.compute_chain_objf_and_deriv(opts, G, sups, torch.from_numpy(lg).cuda())
     pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
                              g["prob"].astype(np.float64), 0)
-    want_out, want_grad = chain_c.chain_batch(g, pi, lg, sups, 1e-4, 0.1)
+    want_out, want_grad = chain_c.chain_batch(g, pi, lg, sups, 1e-4, 0.1, double=True)
     got = out.cpu().numpy()
     assert np.abs(got[0] - want_out[0]).max() <= 1e-3 * np.abs(want_out[0]).max(), (got[0], want_out[0])
     assert abs(got[0].sum() - want_out[0].sum()) <= 1e-3 * abs(want_out[0].sum())

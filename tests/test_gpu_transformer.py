@@ -202,7 +202,7 @@ def test_transformer_matches_reference_golden(golden, tag):
     m = transformer.TransformerAM(D, C, H, FF, L, 0.0, P)
     sd = {k[len(tag) + 7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "_param_")}
     sd["pos_encoder.pe"] = m.state_dict()["pos_encoder.pe"]
-    assert np.array_equal(sd["pos_encoder.pe"][:8].numpy(), g[tag + "_pe_head"])
+    assert np.abs(sd["pos_encoder.pe"][:8].numpy() - g[tag + "_pe_head"]).max() < 1e-6      # (libm of the box)
     m.load_state_dict(sd, strict=True)
     lens = [int(v) for v in g[tag + "_lens"]]
     kpm = torch.ones(B, T)

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import bench
 from pykaldi2_amd import chain, synth
 dev = torch.device('cuda', 0)
-g = synth.den_graph_arcs(bench.S_DEN, bench.A_DEN, bench.P, seed=0)
+g = bench.den_graph_arrays()
 den = chain.DenominatorGraph(g, bench.P)
 rng = np.random.default_rng(1234)
 batches = bench.make_batches(rng, 8, 4, dev)
