@@ -179,7 +179,9 @@ def den_roofline(den, dev, reps=5):
         pass
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                 traffic=traffic, traffic_note=traffic_note,
-                kernel={2: "pk2::den_persist_kernel (one launch per denominator call: the alpha and beta recursions of the 4 "
+                persist_form=den.persist_form(len(lens)),
+                kernel={2: ("pk2::den_persist2_kernel" if den.persist_form(len(lens)) == 2 else "pk2::den_persist_kernel") +
+                           " (one launch per denominator call: the alpha and beta recursions of the 4 "
                            "sequences, one per XCD, arcs in registers, state vector in LDS) + the parallel exp / occupancy passes",
                         1: "pk2::den_step_sx<4> x Tmax (one denominator forward-backward call; forward frame t and "
                            "backward frame Tmax-1-t share a launch)"}.get(den.kernel_path(len(lens)), "pk2::den_fwd_step / den_bwd_step x Tmax"),
@@ -552,6 +554,9 @@ def main():
     ap.add_argument("--length-bucketed", action="store_true", help="N > 1: every rank draws the same utterance lengths "
                     "(different audio / alignments), i.e. length-bucketed data parallelism without stragglers")
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
+    ap.add_argument("--den-states", type=int, default=None, help="states of the synthetic den graph (default 30000); with "
+                    "--den-only: the graph-size sweep of profiles/r03_den_sweep.txt")
+    ap.add_argument("--den-arcs", type=int, default=None, help="arcs of the synthetic den graph (default 1000000)")
     ap.add_argument("--den-topology", choices=["chain", "unique"], default=None,
                     help="synthetic den.fst shape: chain (default; self-loop pdf != entering pdf, as Kaldi's chain topology "
                     "gives) or unique (round 1: one pdf per destination state)")
@@ -564,7 +569,11 @@ def main():
     ap.add_argument("--ce", action="store_true", help="secondary workload configs[1]: 3x512 BLSTM CE, 256 x 80-frame "
                     "chunks per step (not the headline metric)")
     args = ap.parse_args()
-    global DEN_TOPOLOGY
+    global DEN_TOPOLOGY, S_DEN, A_DEN
+    if args.den_states:
+        S_DEN = args.den_states
+    if args.den_arcs:
+        A_DEN = args.den_arcs
     if args.den_topology:
         DEN_TOPOLOGY = args.den_topology
         os.environ["PK2_BENCH_DEN_TOPOLOGY"] = DEN_TOPOLOGY     # the cpu-baseline child builds the same graph

@@ -61,6 +61,10 @@ int pk2_den_graph_initial_probs(const pk2_den_graph* g, float* host_out);
  * 1 = state-x kernels, one launch per frame, 2 = state-x, persistent recursion kernel (one launch per call).  Reporting
  * only; the choice is the library's (reference: kaldi.chain.DenominatorComputation behind ops/ops.py:265). */
 int32_t pk2_den_graph_path(const pk2_den_graph* g, int32_t num_seqs);
+/* The form of the persistent recursion kernel behind path 2: 1 = every arc in registers and the whole state vector in LDS
+ * (graphs up to ~1.05 M arc slots / ~36 k states), 2 = chunked LDS table whose copy overlaps the arcs, two resident passes
+ * and streamed overflow (any graph with < 65536 states); 0 = none (paths 0 / 1).  PK2_DEN_PERSIST = 0 | 1 | 2 forces one. */
+int32_t pk2_den_graph_persist_form(const pk2_den_graph* g, int32_t num_seqs);
 
 /* ------------------------------------------------------------------ *
  * LF-MMI objective and derivative for a minibatch of N sequences.

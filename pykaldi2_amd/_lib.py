@@ -45,11 +45,13 @@ SIGNATURES = {
     "pk2_den_graph_initial_probs": (C.c_int, [_vp, _vp]),
     "pk2_den_graph_arcs_per_lane": (_i32, []),
     "pk2_den_graph_path": (_i32, [_vp, _i32]),
+    "pk2_den_graph_persist_form": (_i32, [_vp, _i32]),
     "pk2_den_graph_debug_ordering": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i32), _vp, _vp,
                                                _vp, _vp, _vp, _vp]),
     "pk2_den_graph_debug_virtual": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp,
                                               C.POINTER(_i64), _vp, _vp, _vp, C.POINTER(_i32), _vp, _vp]),
     "pk2_den_graph_debug_persist": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pk2_den_graph_debug_persist2": (C.c_int, [_vp, C.c_int] + [_vp] * 18),
     "pk2_chain_workspace_bytes": (_sz, [_vp, _i32, _i32, _i64]),
     "pk2_chain_objf_and_deriv": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(NumBatch), _f32,
                                            _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),

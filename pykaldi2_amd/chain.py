@@ -79,6 +79,37 @@ class DenominatorGraph:
         """0 = per-arc-pdf kernels, 1 = state-x kernels (a launch per frame), 2 = persistent recursion kernel."""
         return int(_lib.lib().pk2_den_graph_path(self._h, int(num_seqs)))
 
+    def persist_form(self, num_seqs):
+        """Form of the persistent kernel behind kernel_path() == 2: 1 = everything resident, 2 = chunked table + streamed
+        overflow (csrc/chain_den_persist2.hip); 0 = none."""
+        return int(_lib.lib().pk2_den_graph_persist_form(self._h, int(num_seqs)))
+
+    def debug_persist2(self, which):
+        """Second persistent layout of an ordering (test hook; csrc/chain_internal.h: HostPersist2); None if absent."""
+        L = _lib.lib()
+        info = np.zeros(32, dtype=np.int32)
+        _lib.check(L.pk2_den_graph_debug_persist2(self._h, which, _lib.ptr(info), *([None] * 17)))
+        if not info[0]:
+            return None
+        R, T, K, W, SP, SEG = (int(v) for v in info[26:32])
+        MC = SEG - 2
+        pieces, rows = int(info[7]), int(info[9])
+        out = dict(prob=np.empty((R, K, T), np.float32), idx2=np.empty((R, K // 2, T), np.uint32),
+                   ends=np.empty((R, 2, T), np.uint32), first_row=np.empty((R, 2, T), np.int32),
+                   uncovered=np.empty((R, 2), np.int32), ncomp=np.empty((R, 2), np.int32), rmap=np.empty((2, rows), np.int16),
+                   pbeg=np.empty((R, MC + 1), np.int32),
+                   sprob=np.empty((pieces, SP, T), np.float32), sidx2=np.empty((pieces, SP // 2, T), np.uint32),
+                   sends=np.empty((pieces, T), np.uint32), sfirst_row=np.empty((R, MC, T), np.int32),
+                   wcrow=np.empty((R, SEG, W), np.int32), row_begin=np.empty(R + 1, np.int32),
+                   grp_begin=np.empty(R + 1, np.int32), row_leak=np.empty(rows, np.float32), row_psum=np.empty(rows, np.float32))
+        order = ("prob", "idx2", "ends", "first_row", "uncovered", "ncomp", "rmap", "pbeg", "sprob", "sidx2", "sends", "sfirst_row", "wcrow",
+                 "row_begin", "grp_begin", "row_leak", "row_psum")
+        _lib.check(L.pk2_den_graph_debug_persist2(self._h, which, _lib.ptr(info), *[_lib.ptr(out[k]) for k in order]))
+        out.update(estep=int(info[1]), K=int(info[2]), R=int(info[3]), tfloats=int(info[4]), max_rows=int(info[5]),
+                   max_groups=int(info[6]), pieces=pieces, cap=int(info[8]), cbeg=[int(v) for v in info[10:10 + MC + 1]],
+                   lds_off=[int(v) for v in info[20:20 + MC]], SP=SP, W=W, T=T, slots=K)
+        return out
+
     def debug_persist(self, which):
         """Layout of an ordering for the persistent kernel (test hook): which = 0 forward, 1 backward; None when the
         graph does not fit it."""

@@ -1341,7 +1341,7 @@ static size_t den_workspace_as(const pk2_den_graph* g, int N, int Tmax, bool per
 // the choice can still change before the compute call (the first launch on a device is verified).
 size_t den_workspace(const pk2_den_graph* g, int N, int Tmax, DenGeom* geom, DenBuffers* buf,
                      void* base) {
-  const bool persist = den_persist_wanted(g, N);
+  const bool persist = den_persist_version(g, N) != 0;
   if (base) return den_workspace_as(g, N, Tmax, persist, geom, buf, base);
   const size_t a = den_workspace_as(g, N, Tmax, false, nullptr, nullptr, nullptr);
   const size_t b = den_workspace_as(g, N, Tmax, true, nullptr, nullptr, nullptr);
@@ -1458,9 +1458,13 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     }
     PK2_LAUNCH_CHECK();
     bool ran = false;
-    if (persist) {      // both recursions of every sequence in one launch (chain_den_persist.hip)
-      rc = den_persist_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran);
+    int persist_form = 0;
+    if (persist) {      // both recursions of every sequence in one launch (chain_den_persist.hip / chain_den_persist2.hip)
+      const int form = den_persist_version(g, ge.N);
+      rc = form == 2 ? den_persist2_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran)
+                     : den_persist_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran);
       if (rc) return rc;
+      persist_form = ran ? form : 0;
       if (!ran) {       // the device failed the first-use verification: the frame kernels, with their own chunk counts
         DenGeom ge2 = ge;
         ge2.persist = false;
@@ -1481,7 +1485,8 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
 #endif
     hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
     hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
-    if (ran) den_persist_check_launch(b.den_lp, ge.N, stream);
+    if (ran && persist_form == 2) den_persist2_check_launch(b.den_lp, ge.N, stream);
+    else if (ran) den_persist_check_launch(b.den_lp, ge.N, stream);
     hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
     const size_t row_lds = (size_t)g->P * NG * sizeof(float);
     const bool lds_row = row_lds <= kGammaMaxLds && !getenv("PK2_DEN_GAMMA_GATHER");
@@ -1599,5 +1604,13 @@ extern "C" int pk2_chain_den_fwd_bwd(const pk2_den_graph* gc, const float* logit
 extern "C" int32_t pk2_den_graph_path(const pk2_den_graph* g, int32_t num_seqs) {
   if (!g) return -1;
   if (!pk2::den_use_sx(g)) return 0;
-  return pk2::den_persist_wanted(g, num_seqs) ? 2 : 1;
+  return pk2::den_persist_version(g, num_seqs) != 0 ? 2 : 1;
+}
+
+// Which form of the persistent recursion kernel such a call takes: 0 = none (frame kernels), 1 = den_persist_kernel
+// (everything resident), 2 = den_persist2_kernel (chunked table, two resident passes, streamed overflow).
+extern "C" int32_t pk2_den_graph_persist_form(const pk2_den_graph* g, int32_t num_seqs) {
+  if (!g) return -1;
+  if (!pk2::den_use_sx(g)) return 0;
+  return pk2::den_persist_version(g, num_seqs);
 }

@@ -1,0 +1,820 @@
+// Persistent denominator recursion, second form: no capacity cliff, and the table copy overlaps the arcs (gfx950).
+//
+// chain_den_persist.hip keeps ALL arcs of a recursion in registers and the WHOLE state vector in LDS, which bounds the
+// graphs it takes (~1.05 M arc slots, ~36 k states) -- one arc more and a call fell to the launch-per-frame kernels, 2.2x
+// slower.  Same recursion per XCD, same exchange through the XCD's L2 here, but a frame's row sums are built from PASSES:
+//  * the state vector is cut into table chunks (chain_internal.h: HostPersist2).  A vector that fits LDS has two, back to
+//    back: both LDS-DMAs are started when the frame's words are valid, the arcs that gather from chunk 0 (pass A: 32 register
+//    slots per thread) run as soon as chunk 0 has landed -- s_waitcnt vmcnt(n) with n = the DMA instructions of chunk 1 still
+//    allowed in flight -- and pass B (the other 32 slots) follows when chunk 1 is there: ~half of the 2 us copy of v1's frame
+//    disappears behind pass A.  A longer vector goes through two half-size LDS buffers, chunk c+2 copied into the buffer
+//    chunk c has just left;
+//  * arcs that do not fit the 2 x 32 register slots of a thread (and all arcs gathering from chunks >= 2) are STREAMED: read
+//    again in every frame from the XCD's L2 in pieces of 16 slots per thread, the next piece on its way while one is summed.
+//    A graph a little too large costs one piece per frame (~0.5 us of ~7), not a fall to another kernel family;
+//  * every pass sums complete rows in a lane / finishes rows crossing lanes by a segmented wave scan / leaves the wave's
+//    open tail as a carry, exactly as den_persist_kernel does for its single list; pass A and pass B store into their own LDS
+//    row arrays (one plain store per row), streamed segments add into pass A's array behind a barrier, the row epilogue adds
+//    up the arrays and the carries of all segments.
+// Everything else -- teams by arrival order per XCD, the task queue, NaN-sentinel words, one exchange per frame in both
+// directions, history stores after the words other workgroups wait for, the 1 s poll timeout -- is chain_den_persist.hip's
+// (den_persist_dev.h).  Replaces the same DenominatorComputation (reference ops/ops.py:265, bin/train_chain.py:202).
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <type_traits>
+#include <vector>
+
+#include "den_persist_dev.h"
+
+namespace pk2 {
+
+struct DenPersist2Params {
+  DenParams d;
+  DevPersist2 fwd, bwd;
+  const float* xv;        // [G][Tmax][V]
+  float* ring;            // [8 * kMaxTeams][2][rpad]
+  float* pring;           // [8 * kMaxTeams][3][kPR][kPWords]
+  int rpad;               // floats per ring slot
+  int tfloats;            // LDS table floats
+  int cap;                // LDS row buffers
+  int ntasks;
+  int fwd_stream, bwd_stream;   // the ordering has streamed pieces (or more than two table chunks)
+  short task_seq[kMaxTasks];
+  unsigned char task_dir[kMaxTasks];
+};
+typedef __attribute__((address_space(4))) const DenPersist2Params CParams2;
+typedef __attribute__((address_space(4))) const DevPersist2 CDev2;
+__device__ __forceinline__ CParams2* uni(CParams2* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (CParams2*)(((unsigned long long)hi << 32) | lo);
+}
+
+extern __shared__ __attribute__((aligned(16))) float den_persist2_smem[];
+struct Lds2 {
+  float* table;    // [tfloats] the chunks of the frame's gather table
+  float* accA;     // [cap]  row sums of pass A, by compact row of list 0
+  float* accB;     // [cap]  row sums of pass B, by compact row of list 1
+  float* accS;     // [cap]  row sums of the streamed segments, by rank-local row
+  float* xown;     // [cap]  forward: x[t, own rows]; backward: x of own virtual states
+  float* leak;     // [cap]
+  float* aux;      // [cap]  backward: weight of an own virtual state in lU; forward: the finished rows (history stores)
+  short* mapA;     // [cap]  compact row of a rank-local row in list 0 / list 1 (-1: the row has no slot there)
+  short* mapB;     // [cap]
+  float* red;      // [2 * kPW]
+  float* tot;      // [4]
+  float* wcarry;   // [kSegs * kPW] open tail of wave w in segment s
+  int* wcrow;      // [kSegs * kPW] the rank-local row it belongs to (-1: none)
+  int* abort;      // + rank, team, xcd, task
+};
+__device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap) {
+  Lds2 L;
+  L.table = den_persist2_smem; L.accA = L.table + tfloats; L.accB = L.accA + cap; L.accS = L.accB + cap; L.xown = L.accS + cap;
+  L.leak = L.xown + cap; L.aux = L.leak + cap;
+  L.mapA = reinterpret_cast<short*>(L.aux + cap); L.mapB = L.mapA + cap;
+  L.red = L.aux + 2 * cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
+  L.wcrow = reinterpret_cast<int*>(L.wcarry + kSegs * kPW); L.abort = L.wcrow + kSegs * kPW;
+  return L;
+}
+
+// Workgroup barrier that orders LDS accesses only: the LDS-DMA instructions a wave has in flight stay in flight.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant).
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (__builtin_amdgcn_readfirstlane(n)) {
+#define PK2_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    PK2_VM_CASE(1) PK2_VM_CASE(2) PK2_VM_CASE(3) PK2_VM_CASE(4) PK2_VM_CASE(5) PK2_VM_CASE(6) PK2_VM_CASE(7) PK2_VM_CASE(8)
+    PK2_VM_CASE(9) PK2_VM_CASE(10) PK2_VM_CASE(11) PK2_VM_CASE(12) PK2_VM_CASE(13) PK2_VM_CASE(14) PK2_VM_CASE(15) PK2_VM_CASE(16)
+    PK2_VM_CASE(17) PK2_VM_CASE(18) PK2_VM_CASE(19) PK2_VM_CASE(20)
+#undef PK2_VM_CASE
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// LDS-DMA of table chunk c of the vector at `src` into its LDS buffer: 1 KB rows dealt to the waves round robin; every wave
+// issues the SAME number of instructions (a wave without a row of its own copies the last row again), which is returned: the
+// count a later s_waitcnt may leave in flight.
+__device__ __forceinline__ int dma_chunk(cgfloat* src, CDev2& o, int c, float* table) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = o.cbeg[c], e = o.cbeg[c + 1];
+  const int rows = (e - b + 255) >> 8;
+  const int n = (rows + kPW - 1) / kPW;
+  const int e4 = (e + 3) & ~3;
+  float* dst = table + o.lds_off[c];
+  for (int k = 0; k < n; ++k) {
+    int row = w + k * kPW;
+    row = row < rows ? row : rows - 1;
+    const int off = row << 8;
+    if (b + off + lane * 4 < e4) dma256(src + b + off + lane * 4, dst + off);
+  }
+  return n;
+}
+
+// Row sums of NS register slots (slots J0 .. J0+NS-1 of the thread's arrays) over the LDS table into `acc`: complete rows
+// are stored by the lane, the piece before the first row end gets the carry of the earlier lanes (segmented wave scan), the
+// open tail of the wave goes to wcarry[w].  Rows end only after slots ESTEP-1 (mod ESTEP).
+template <int ESTEP, int J0, int NS>
+__device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint32_t ends, int frow,
+                                          const float* table, float* acc, float* wcarry) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float sum = 0.f;
+  int c = frow;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < NS / ESTEP; ++k) packed |= ((ends >> (k * ESTEP + ESTEP - 1)) & 1u) << k;
+  unsigned m = __builtin_bitreverse32(packed);
+  auto gather = [&](int j0, float (&a)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t pk = idx2[(J0 + j0 + j) >> 1];
+      const uint32_t byte_off = ((J0 + j0 + j) & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
+      a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + byte_off);
+    }
+  };
+  float a[2][8];
+  gather(0, a[0]);
+#pragma unroll
+  for (int g = 0; g < NS / 8; ++g) {
+    if (g + 1 < NS / 8) gather(8 * (g + 1), a[(g + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int jj = 8 * g + j;
+      sum = fmaf(a[g & 1][j], prob[J0 + jj], sum);
+      if ((jj + 1) % ESTEP == 0) {
+        if (__builtin_add_overflow(m, m, &m)) { acc[c] = sum; ++c; sum = 0.f; }
+      }
+    }
+  }
+  float x[1] = {sum};
+  int fl = ends != 0u ? 1 : 0;
+  seg_scan_step<1, 0x111, 0xf>(x, fl);
+  seg_scan_step<1, 0x112, 0xf>(x, fl);
+  seg_scan_step<1, 0x114, 0xf>(x, fl);
+  seg_scan_step<1, 0x118, 0xf>(x, fl);
+  seg_scan_step<1, 0x142, 0xa>(x, fl);
+  seg_scan_step<1, 0x143, 0xc>(x, fl);
+  const float cin = dpp_f<0x138, 0xf>(x[0]);     // wave_shr:1 -- lane 0 receives 0
+  if (ends != 0u) acc[frow] += cin;               // the lane's own first row end (stored above by this lane)
+  if (lane == 63) wcarry[w] = x[0];
+}
+template <int J0>
+__device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint32_t ends,
+                                              int frow, const float* table, float* acc, float* wcarry) {
+  switch (estep) {
+    case 8: pass_rows<8, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
+    case 4: pass_rows<4, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
+    case 2: pass_rows<2, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
+    default: pass_rows<1, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
+  }
+}
+
+// A streamed piece: kSP slots per thread, read from memory in every frame.  The sums ADD to `acc` (the rows also have slots
+// in a resident pass or in another segment; a barrier separates the segments).
+struct Piece { float prob[kSP]; uint32_t idx2[kSP / 2]; uint32_t ends; };
+__device__ __forceinline__ void piece_load(CDev2& o, int piece, Piece& q) {
+  const int tid = threadIdx.x;
+  const __attribute__((address_space(1))) float* sp = (const __attribute__((address_space(1))) float*)o.sprob;
+  const __attribute__((address_space(1))) uint32_t* si = (const __attribute__((address_space(1))) uint32_t*)o.sidx2;
+  const __attribute__((address_space(1))) uint32_t* se = (const __attribute__((address_space(1))) uint32_t*)o.sends;
+#pragma unroll
+  for (int j = 0; j < kSP; ++j) q.prob[j] = sp[((size_t)piece * kSP + j) * kPT + tid];
+#pragma unroll
+  for (int j = 0; j < kSP / 2; ++j) q.idx2[j] = si[((size_t)piece * (kSP / 2) + j) * kPT + tid];
+  q.ends = se[(size_t)piece * kPT + tid];
+}
+template <int ESTEP>
+__device__ __forceinline__ void piece_rows(const Piece& q, const float* table, float* acc, float& sum, int& c) {
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < kSP / ESTEP; ++k) packed |= ((q.ends >> (k * ESTEP + ESTEP - 1)) & 1u) << k;
+  unsigned m = __builtin_bitreverse32(packed);
+  float a[kSP];
+#pragma unroll
+  for (int j = 0; j < kSP; ++j) {
+    const uint32_t pk = q.idx2[j >> 1];
+    const uint32_t byte_off = (j & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
+    a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + byte_off);
+  }
+#pragma unroll
+  for (int j = 0; j < kSP; ++j) {
+    sum = fmaf(a[j], q.prob[j], sum);
+    if ((j + 1) % ESTEP == 0) {
+      if (__builtin_add_overflow(m, m, &m)) { acc[c] += sum; ++c; sum = 0.f; }
+    }
+  }
+}
+__device__ __forceinline__ void piece_rows_any(int estep, const Piece& q, const float* table, float* acc, float& sum, int& c) {
+  switch (estep) {
+    case 8: piece_rows<8>(q, table, acc, sum, c); break;
+    case 4: piece_rows<4>(q, table, acc, sum, c); break;
+    case 2: piece_rows<2>(q, table, acc, sum, c); break;
+    default: piece_rows<1>(q, table, acc, sum, c); break;
+  }
+}
+
+// The streamed segment of chunk c: pieces [p0, p1) of this rank; `cur` holds piece p0 already (prefetched), on return it
+// holds piece p1 if that exists (p1 < pend: the first piece of the next segment, or of the next frame's first segment when
+// the caller wraps around).
+__device__ __forceinline__ void streamed_segment(CDev2& o, int rank, int c, int p0, int p1, int pnext_valid, int pwrap, Piece& cur,
+                                                 const Lds2& L) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const __attribute__((address_space(1))) int32_t* sfr = (const __attribute__((address_space(1))) int32_t*)o.sfirst_row;
+  const int frow = sfr[((size_t)rank * kMaxChunks + c) * kPT + tid];
+  float sum = 0.f;
+  int cc = frow;
+  uint32_t had = 0;
+  for (int p = p0; p < p1; ++p) {
+    Piece nxt;
+    const int pn = p + 1 < p1 ? p + 1 : (pnext_valid ? p1 : pwrap);      // what the thread will need next
+    piece_load(o, pn, nxt);
+    had |= cur.ends;
+    piece_rows_any(o.estep, cur, L.table, L.accS, sum, cc);
+    cur = nxt;
+  }
+  float x[1] = {sum};
+  int fl = had != 0u ? 1 : 0;
+  seg_scan_step<1, 0x111, 0xf>(x, fl);
+  seg_scan_step<1, 0x112, 0xf>(x, fl);
+  seg_scan_step<1, 0x114, 0xf>(x, fl);
+  seg_scan_step<1, 0x118, 0xf>(x, fl);
+  seg_scan_step<1, 0x142, 0xa>(x, fl);
+  seg_scan_step<1, 0x143, 0xc>(x, fl);
+  const float cin = dpp_f<0x138, 0xf>(x[0]);
+  if (had != 0u) L.accS[frow] += cin;
+  if (lane == 63) L.wcarry[(2 + c) * kPW + w] = x[0];
+}
+
+// The frame's row sums once its words are valid: both resident passes and every streamed segment over the vector at `src`.
+// On return a barrier has NOT been passed yet: the caller's __syncthreads() precedes the first read of the sums.
+struct FrameRegs {
+  float prob[kPK]; uint32_t idx2[kPK / 2]; uint32_t endsA, endsB; int frowA, frowB;
+};
+// STREAM = false: the rank-independent fact "this ordering has no streamed piece at all" compiled in -- no piece registers,
+// no segment barriers, chunks beyond the two resident ones cannot exist.
+struct StreamState { Piece cur; int pb[kMaxChunks + 1]; };
+struct NoStream { };
+struct RowSpan { int nrows, uncA, ncA, uncB, ncB; };
+template <bool STREAM, typename ST>
+__device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, const RowSpan& rs, const FrameRegs& r,
+                                           ST& st, const Lds2& L) {
+  const int tid = threadIdx.x;
+  if constexpr (STREAM) {
+    // the streamed segments add up in accS; compact rows past a truncated resident list get no store from their pass
+    for (int q = tid; q < rs.nrows; q += kPT) L.accS[q] = 0.f;
+    for (int q = rs.uncA + tid; q < rs.ncA; q += kPT) L.accA[q] = 0.f;
+    for (int q = rs.uncB + tid; q < rs.ncB; q += kPT) L.accB[q] = 0.f;
+  }
+  dma_chunk(src, o, 0, L.table);
+  const int n1 = dma_chunk(src, o, 1, L.table);
+  wait_vm(n1);                           // chunk 0 has landed (this wave's part); chunk 1 may still be in flight
+  lds_only_barrier();                    // (__syncthreads() would wait for chunk 1 as well: it is vmcnt(0) + s_barrier)
+  pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry);
+  if constexpr (STREAM) {
+    const int (&pb)[kMaxChunks + 1] = st.pb;
+    const int K = o.K;
+    const int pfirst = pb[0], pend = pb[K];
+    if (pb[1] > pb[0]) streamed_segment(o, rank, 0, pb[0], pb[1], pb[1] < pend, pfirst, st.cur, L);
+    wait_vm(0);
+    __syncthreads();                       // chunk 1 is complete, and buffer 0 is free
+    if (K > 2) dma_chunk(src, o, 2, L.table);
+    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW);
+    // (consecutive segments add to the same rows of accS: the barrier between two chunks separates them)
+    if (pb[2] > pb[1]) streamed_segment(o, rank, 1, pb[1], pb[2], pb[2] < pend, pfirst, st.cur, L);
+    for (int c = 2; c < K; ++c) {
+      wait_vm(0);
+      __syncthreads();                     // chunk c is complete, and the buffer of chunk c-1 is free
+      if (c + 1 < K) dma_chunk(src, o, c + 1, L.table);
+      if (pb[c + 1] > pb[c]) streamed_segment(o, rank, c, pb[c], pb[c + 1], pb[c + 1] < pend, pfirst, st.cur, L);
+    }
+  } else {
+    wait_vm(0);
+    __syncthreads();                       // chunk 1 is complete
+    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW);
+  }
+}
+
+// Value of rank-local row q after the frame's passes: its entries in the two compact row arrays (and the streamed one) plus
+// the wave carry-outs that belong to it.  `cmask` (a constant of the task): the carries whose row is one of this thread's
+// rows -- usually none.
+template <bool STREAM>
+__device__ __forceinline__ float row_val(const Lds2& L, uint64_t cmask, int q) {
+  const int a = L.mapA[q], b = L.mapB[q];
+  float v = (a >= 0 ? L.accA[a] : 0.f) + (b >= 0 ? L.accB[b] : 0.f);
+  if constexpr (STREAM) v += L.accS[q];
+  uint64_t m = cmask;
+  while (m) {
+    const int k = __builtin_ctzll(m);
+    m &= m - 1;
+    if (L.wcrow[k] == q) v += L.wcarry[k];
+  }
+  return v;
+}
+
+template <int NW>
+__device__ __forceinline__ void block_sum2(float& u, float& v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u = wave_sum_dpp(u); v = wave_sum_dpp(v);
+  __syncthreads();
+  if (lane == 0) { red[w] = u; red[NW + w] = v; }
+  __syncthreads();
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < NW; ++k) { a += red[k]; b += red[NW + k]; }
+  u = a; v = b;
+}
+
+__device__ __forceinline__ void load_frame_regs(CDev2& o, int rank, FrameRegs& r) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < kPK; ++j) r.prob[j] = o.prob[((size_t)rank * kPK + j) * kPT + tid];
+#pragma unroll
+  for (int j = 0; j < kPK / 2; ++j) r.idx2[j] = o.idx2[((size_t)rank * (kPK / 2) + j) * kPT + tid];
+  r.endsA = o.ends[((size_t)rank * 2 + 0) * kPT + tid]; r.endsB = o.ends[((size_t)rank * 2 + 1) * kPT + tid];
+  r.frowA = o.first_row[((size_t)rank * 2 + 0) * kPT + tid]; r.frowB = o.first_row[((size_t)rank * 2 + 1) * kPT + tid];
+}
+
+// alpha recursion of sequence g (T frames).
+template <bool STREAM>
+__device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
+                                      unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
+  CParams2* pp = uni(pp_);
+  DenPersistCtl* ctl = uni(ctl_); DenPersistCtl::Team* team = uni(team_);
+  const int g = uni(g_), T = uni(T_), rank = uni(rank_);
+  ring_ = uni(ring_); pring_ = uni(pring_);
+  CParams2& p = *pp;
+  CDenParams& d = p.d;
+  CDev2& o = p.fwd;
+  const Lds2 L = carve_lds2(p.tfloats, p.cap);
+  gfloat* ring = G(ring_); gfloat* pring = G(pring_);
+  const int tid = threadIdx.x;
+  const int S = d.S, V = d.V, Vo = d.Vo;
+  const bool sep = d.alphav != d.alpha;
+  FrameRegs fr;
+  load_frame_regs(o, rank, fr);
+  const int row0 = o.row_begin[rank], nrows = o.row_begin[rank + 1] - row0;
+  const int g0 = o.grp_begin[rank], ngrp = o.grp_begin[rank + 1] - g0;
+  RowSpan rs;
+  rs.nrows = nrows; rs.uncA = o.uncovered[rank * 2]; rs.uncB = o.uncovered[rank * 2 + 1];
+  rs.ncA = o.ncomp[rank * 2]; rs.ncB = o.ncomp[rank * 2 + 1];
+  for (int r = tid; r < nrows; r += kPT) { L.mapA[r] = o.rmap[row0 + r]; L.mapB[r] = o.rmap[(size_t)o.num_rows + row0 + r]; }
+  typename std::conditional<STREAM, StreamState, NoStream>::type st;
+  if constexpr (STREAM) {
+#pragma unroll
+    for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
+  }
+  for (int r = tid; r < nrows; r += kPT) L.leak[r] = o.row_leak[row0 + r];
+  if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
+  int st_lo[kPSPT], st_hi[kPSPT], st_o[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) {
+    const int r = tid + i * kPT;
+    st_ok[i] = r < ngrp;
+    st_lo[i] = st_hi[i] = st_o[i] = 0; st_pl[i] = st_pi[i] = 0.f;
+    if (st_ok[i]) {
+      const int dd = g0 + r;
+      st_lo[i] = d.voff[dd] - row0; st_hi[i] = d.voff[dd + 1] - row0; st_o[i] = d.ooff[dd];
+      st_pl[i] = d.loop_prob[dd]; st_pi[i] = d.pi[dd];
+    }
+  }
+  // own words of the three frame slots start as "not yet written"
+  if (tid < 3 * kPWords) st_agent(pring + ((tid / kPWords) * kPR + rank) * kPWords + tid % kPWords, __uint_as_float(kRingSentinel));
+  if (!team_barrier(ctl, team, nbar, L.abort)) return;
+  uint64_t cmask = 0;
+  for (int k = 0; k < kSegs * kPW; ++k) {
+    const int q = L.wcrow[k];
+    bool mine = false;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) mine = mine || (st_ok[i] && q >= st_lo[i] && q < st_hi[i]);
+    if (q >= 0 && mine) cmask |= 1ull << k;
+  }
+
+  const size_t f0 = (size_t)g * (d.Tmax + 1);
+  cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
+  cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
+  float xr[kPSPT], xlr[kPSPT];
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      xr[i] = r < nrows ? xv_g[(size_t)t * V + row0 + r] : 0.f;
+      xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + g0 + r] : 0.f;
+    }
+  };
+  prefetch(0);
+  if constexpr (STREAM) {
+    if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
+  }
+  float own_a[kPSPT];
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) own_a[i] = st_pi[i];          // alpha[0, .] = pi
+  Spin spin(ctl);
+  DP_T0();
+  for (int t = 0; t < T; ++t) {
+    float as;
+    cgfloat* src;
+    DP_TL(0, 0);
+    if (t == 0) {
+      as = d.pi_sum;
+      src = G(d.pi);
+    } else {
+      poll_words(pring + (size_t)(t % 3) * kPR * kPWords, 0, 1, spin, L);
+      __syncthreads();
+      DP_TL(0, 1);
+      if (*L.abort) return;
+      as = L.tot[0];
+      src = ring + (size_t)(t & 1) * p.rpad;
+    }
+    // the word this rank will publish two frames from now must read "not yet written" by then: reset here, before the
+    // copies (no store sits between them and their waits), long before the stores it has to precede
+    const bool publish = t + 1 < T;
+    if (tid == 0 && publish) st_agent(word_of(pring, t + 2, rank, 0), __uint_as_float(kRingSentinel));
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      if (r < nrows) L.xown[r] = xr[i];
+    }
+    DP_T(0);
+    // Every prefetched value is "used" here on all paths: the compiler then waits for those loads HERE, not -- because one of
+    // their registers gets reused behind a branch that skipped the use -- between the two table copies of frame_rows.
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) asm volatile("" :: "v"(xr[i]), "v"(xlr[i]));
+    frame_rows<STREAM>(o, src, rank, rs, fr, st, L);
+    DP_T(2);
+    DP_TL(0, 4);
+    __syncthreads();
+    DP_T(3);
+    if (rank == 0 && tid == 0) G(d.asum)[f0 + t] = as;
+    const float lk = d.leaky * as, inv_as = 1.0f / as;
+    // rows are virtual states (dst, pdf); a thread per real state sums its rows and adds the peeled self-loop.  First
+    // only what the other workgroups wait for: the ring entries, then (once they are in L2) the partial sum.
+    gfloat* ring_n = ring + (size_t)((t + 1) & 1) * p.rpad;
+    float outv[kPSPT], loopv[kPSPT], loc = 0.f, unused = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      outv[i] = 0.f; loopv[i] = 0.f;
+      if (!st_ok[i]) continue;
+      float sum = 0.f;
+      for (int q = st_lo[i]; q < st_hi[i]; ++q) {
+        const float v = (row_val<STREAM>(L, cmask, q) + lk * L.leak[q]) * L.xown[q] * inv_as;
+        L.aux[q] = v;          // (the row belongs to this thread alone: kept for the history stores below)
+        sum += v;
+      }
+      if (st_pl[i] > 0.f) { loopv[i] = (own_a[i] + lk * st_pi[i]) * st_pl[i] * xlr[i] * inv_as; sum += loopv[i]; }
+      if (publish) ring_store(ring_n + g0 + tid + i * kPT, sum);
+      outv[i] = sum;
+      own_a[i] = sum;          // alpha[t+1] of the own state: the next frame's loop term
+      loc += sum;
+    }
+    DP_T(4);
+    DP_TL(0, 5);
+    wait_stores();        // this rank's slice of frame t+1 (and the reset above) is in L2 before its partial sum says so
+    block_sum2<kPW>(loc, unused, L.red);
+    if (tid == 0 && publish) st_agent(word_of(pring, t + 1, rank, 0), loc);
+    DP_T(5);
+    DP_TL(0, 6);
+    // the history the parallel passes read (nobody waits for these stores)
+    gfloat* alpha_n = G(d.alpha) + (f0 + t + 1) * (size_t)S;
+    gfloat* alphav_n = G(d.alphav) + (f0 + t + 1) * (size_t)Vo;
+    if (tid == 0) G(d.apart)[(f0 + t + 1) * kPR + rank] = loc;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      if (!st_ok[i]) continue;
+      alpha_n[g0 + tid + i * kPT] = outv[i];
+      if (sep) {
+        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = L.aux[q];
+        if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
+      }
+    }
+    if (publish) prefetch(t + 1);
+    DP_T(6);
+  }
+  DP_FLUSH(0);
+}
+
+// btilde' recursion of sequence g, T-1 down to 0 (see chain_den_persist.hip: run_bwd for the algebra).
+template <bool STREAM>
+__device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
+                                      unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
+  CParams2* pp = uni(pp_);
+  DenPersistCtl* ctl = uni(ctl_); DenPersistCtl::Team* team = uni(team_);
+  const int g = uni(g_), T = uni(T_), rank = uni(rank_);
+  ring_ = uni(ring_); pring_ = uni(pring_);
+  CParams2& p = *pp;
+  CDenParams& d = p.d;
+  CDev2& o = p.bwd;
+  const Lds2 L = carve_lds2(p.tfloats, p.cap);
+  gfloat* ring = G(ring_); gfloat* pring = G(pring_);
+  const int tid = threadIdx.x;
+  const int S = d.S, V = d.V;
+  FrameRegs fr;
+  load_frame_regs(o, rank, fr);
+  const int row0 = o.row_begin[rank], nrows = o.row_begin[rank + 1] - row0;
+  const int vfirst = d.voff[row0], nvirt = d.voff[row0 + nrows] - vfirst;     // own virtual states: a contiguous range
+  RowSpan rs;
+  rs.nrows = nrows; rs.uncA = o.uncovered[rank * 2]; rs.uncB = o.uncovered[rank * 2 + 1];
+  rs.ncA = o.ncomp[rank * 2]; rs.ncB = o.ncomp[rank * 2 + 1];
+  for (int r = tid; r < nrows; r += kPT) { L.mapA[r] = o.rmap[row0 + r]; L.mapB[r] = o.rmap[(size_t)o.num_rows + row0 + r]; }
+  typename std::conditional<STREAM, StreamState, NoStream>::type st;
+  if constexpr (STREAM) {
+#pragma unroll
+    for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
+  }
+  if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
+  int st_v0[kPSPT], st_v1[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) {
+    const int r = tid + i * kPT;
+    st_ok[i] = r < nrows;
+    st_v0[i] = st_v1[i] = 0; st_pl[i] = st_pi[i] = 0.f;
+    if (st_ok[i]) {
+      const int s = row0 + r;
+      st_v0[i] = d.voff[s] - vfirst; st_v1[i] = d.voff[s + 1] - vfirst; st_pl[i] = d.loop_prob[s]; st_pi[i] = d.pi[s];
+    }
+  }
+  // what an own virtual state contributes to the next frame's sums (virtual states are the forward layout's rows)
+  for (int r = tid; r < nvirt; r += kPT) { L.leak[r] = p.fwd.row_leak[vfirst + r]; L.aux[r] = p.fwd.row_psum[vfirst + r]; }
+  if (tid < 3 * kPWords) st_agent(pring + ((tid / kPWords) * kPR + rank) * kPWords + tid % kPWords, __uint_as_float(kRingSentinel));
+  if (!team_barrier(ctl, team, nbar, L.abort)) return;
+  uint64_t cmask = 0;
+  for (int k = 0; k < kSegs * kPW; ++k) {
+    const int q = L.wcrow[k];
+    bool mine = false;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) mine = mine || (st_ok[i] && q == tid + i * kPT);
+    if (q >= 0 && mine) cmask |= 1ull << k;
+  }
+
+  const size_t f0 = (size_t)g * (d.Tmax + 1);
+  cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
+  cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
+  float xl_cur[kPSPT], xl_prev[kPSPT], xw[kPSPT], bh[kPSPT];
+  const float cst_last = 1.0f / d.pi_sum + d.leaky;
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) { bh[i] = cst_last; xl_cur[i] = 0.f; }
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      xl_prev[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
+      xw[i] = r < nvirt ? xv_g[(size_t)t * V + vfirst + r] : 0.f;
+    }
+  };
+  auto stage_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      const int r = tid + i * kPT;
+      if (r < nvirt) L.xown[r] = xw[i];
+    }
+  };
+  auto emit = [&](int t) {
+    gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad + vfirst;
+    float pB = 0.f, pU = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      if (!st_ok[i]) continue;
+      for (int q = st_v0[i]; q < st_v1[i]; ++q) {
+        const float w = L.xown[q] * bh[i];
+        ring_store(ring_n + q, w);
+        pB = fmaf(w, L.leak[q], pB); pU = fmaf(w, L.aux[q], pU);
+      }
+      if (st_pl[i] > 0.f) { const float lp = st_pl[i] * xl_prev[i] * bh[i]; pB = fmaf(st_pi[i], lp, pB); pU += lp; }
+    }
+    wait_stores();        // the slice (and the reset of the words two frames on) is in L2 before the sums say so
+    block_sum2<kPW>(pB, pU, L.red);
+    if (tid < 2) st_agent(word_of(pring, t, rank, tid), tid == 0 ? pB : pU);
+    if (tid == 0) {       // the parallel passes recompute c[t-1] from the same shares
+      G(d.bpart)[((f0 + t - 1) * kPR + rank) * 2] = pB;
+      G(d.bpart)[((f0 + t - 1) * kPR + rank) * 2 + 1] = pU;
+    }
+  };
+  // w[T] = x[T-1, .] * (1 / sum(pi) + leaky)
+  prefetch(T - 1);
+  stage_x();
+  __syncthreads();
+  emit(T);
+#pragma unroll
+  for (int i = 0; i < kPSPT; ++i) xl_cur[i] = xl_prev[i];
+  if (T >= 2) prefetch(T - 2);
+  if constexpr (STREAM) {
+    if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
+  }
+  Spin spin(ctl);
+  DP_T0();
+  for (int t = T - 1; t >= 0; --t) {
+    DP_TL(1, 0);
+    poll_words(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 0, 2, spin, L);
+    __syncthreads();
+    DP_TL(1, 1);
+    if (*L.abort) return;
+    const float lB = L.tot[0], lU = L.tot[1];        // sums of btilde'[t, .], known before it is computed
+    const bool publish = t > 0;
+    // the words this rank will publish two frames from now must read "not yet written" by then: reset here, before the
+    // copies, long before the stores they have to precede (the waits of emit cover it)
+    if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
+    if (publish) stage_x();
+    DP_T(0);
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) asm volatile("" :: "v"(xl_prev[i]), "v"(xw[i]));      // (see run_fwd2)
+    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, st, L);
+    DP_T(2);
+    DP_TL(1, 4);
+    __syncthreads();
+    DP_T(3);
+    // rows are source states: btilde'[t, s] = row + peeled loop, then beta-hat[t, s] with the sums received above
+    const float cu = lB + d.wu * lU;
+    const float inv_c = cu > 0.f ? 1.0f / cu : 0.f;
+    const float lkr = d.leaky * lB * inv_c;
+    float vs[kPSPT];
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      vs[i] = 0.f;
+      if (!st_ok[i]) continue;
+      float v = row_val<STREAM>(L, cmask, tid + i * kPT);
+      if (st_pl[i] > 0.f) v += st_pl[i] * xl_cur[i] * bh[i];
+      vs[i] = v;
+      bh[i] = v * inv_c + lkr;
+    }
+    DP_T(4);
+    DP_TL(1, 5);
+    if (publish) emit(t);
+    DP_T(5);
+    DP_TL(1, 6);
+    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
+#pragma unroll
+    for (int i = 0; i < kPSPT; ++i) {
+      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
+      xl_cur[i] = xl_prev[i];
+    }
+    if (t >= 2) prefetch(t - 2);
+    DP_T(6);
+  }
+  DP_FLUSH(1);
+}
+
+__global__ void __launch_bounds__(kPT) den_persist2_kernel(const DenPersist2Params* __restrict__ pp_, DenPersistCtl* ctl) {
+  CParams2* pp = (CParams2*)pp_;
+  CParams2& p = *pp;
+  const Lds2 L = carve_lds2(p.tfloats, p.cap);
+  int& s_abort = L.abort[0];
+  int& s_rank = L.abort[1]; int& s_team = L.abort[2]; int& s_xcd = L.abort[3]; int& s_task = L.abort[4];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_abort = 0;
+    const unsigned xcd = den_xcc_id();
+    const unsigned slot = __hip_atomic_fetch_add(&ctl->arrive[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_rank = (int)(slot % kPR); s_team = (int)(slot / kPR); s_xcd = (int)xcd;
+  }
+  __syncthreads();
+  if (s_team >= kMaxTeams) return;
+  const int rank = s_rank;
+  DenPersistCtl::Team* team = &ctl->team[s_xcd][s_team];
+  const size_t ti = (size_t)s_xcd * kMaxTeams + s_team;
+  float* ring = p.ring + ti * 2 * p.rpad;
+  float* pring = p.pring + ti * 3 * kPR * kPWords;
+  unsigned nbar = 0;
+  for (int iter = 0; iter <= kMaxTasks; ++iter) {
+    if (tid == 0) {
+      unsigned k;
+      if (rank == 0) {
+        k = __hip_atomic_fetch_add(&ctl->next_task, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&team->task[iter], k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        Spin spin(ctl);
+        unsigned k1;
+        while ((k1 = ld_agent_u(G(&team->task[iter]))) == 0u) {
+          if (spin.expired()) { s_abort = 1; k1 = 1u << 30; break; }
+        }
+        k = k1 - 1u;
+      }
+      s_task = (int)k;
+    }
+    __syncthreads();
+    const int k = s_task;
+    if (s_abort || k >= p.ntasks) return;
+    const int g = p.task_seq[k], T = p.d.lengths[g];
+    if (!team_barrier(ctl, team, &nbar, &s_abort)) return;      // everybody has left the previous recursion
+    if (p.task_dir[k] == 0) {
+      if (p.fwd_stream) run_fwd2<true>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+      else run_fwd2<false>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+    } else {
+      if (p.bwd_stream) run_bwd2<true>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+      else run_bwd2<false>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+    }
+    __syncthreads();
+    if (s_abort) return;
+    if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void den_persist2_check(const DenPersistCtl* ctl, int ntasks, float* den_lp, int n) {
+  if (ctl->abort != 0u || ctl->done != (unsigned)ntasks)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) den_lp[i] = __uint_as_float(0x7fc00000u);
+}
+
+// ----------------------------------------------------------------------------------------
+// host
+// ----------------------------------------------------------------------------------------
+static int g_den_persist2_state = -1;     // -1: not verified yet, 0: unusable on this device, 1: verified
+struct DenPersist2Scratch { DenPersist2Params* params = nullptr; DenPersistCtl* ctl = nullptr; float* ring = nullptr; float* pring = nullptr; int rpad = 0; int ntasks = 0; };
+static std::map<hipStream_t, DenPersist2Scratch> g_den2_scratch;
+
+static int den2_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 255) / 256 * 256 + 256; }
+static int den2_tfloats(const pk2_den_graph* g) { return std::max(g->h_p2fwd.tfloats, g->h_p2bwd.tfloats); }
+
+bool den_persist2_fits(const pk2_den_graph* g) {
+  return g->h_p2fwd.ok && g->h_p2bwd.ok && g->p2_cap > 0 && den_persist2_lds_bytes(den2_tfloats(g), g->p2_cap) <= kDenPersistMaxLds;
+}
+
+static bool den_is_8x32() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  return cus == 8 * kPR;
+}
+
+// Which form runs: the forced one if it fits; by default the second form (it takes every graph the first takes and overlaps
+// the table copy), the first only when PK2_DEN_PERSIST=1 asks for it.
+int den_persist_version(const pk2_den_graph* g, int N) {
+  const char* env = getenv("PK2_DEN_PERSIST");
+  const int want = env ? atoi(env) : -1;
+  if (want == 0 || !den_use_sx(g) || N < 1 || 2 * N > kMaxTasks || !den_is_8x32()) return 0;
+  const bool ok1 = den_persist_wanted(g, N);
+  const bool ok2 = g_den_persist2_state != 0 && den_persist2_fits(g);
+  if (want == 1) return ok1 ? 1 : 0;
+  if (want == 2) return ok2 ? 2 : 0;
+  return ok2 ? 2 : (ok1 ? 1 : 0);
+}
+
+int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, const int32_t* lengths_host, int N,
+                        hipStream_t stream, bool* ran) {
+  *ran = false;
+  DenPersist2Scratch& sc = g_den2_scratch[stream];
+  const int rpad = den2_rpad(g);
+  if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(DenPersistCtl)));
+  if (!sc.params) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.params), sizeof(DenPersist2Params)));
+  if (!sc.pring) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.pring), (size_t)8 * kMaxTeams * 3 * kPR * kPWords * sizeof(float)));
+  if (sc.rpad < rpad) {
+    if (sc.ring) PK2_HIP(hipFree(sc.ring));
+    sc.ring = nullptr; sc.rpad = 0;
+    PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ring), (size_t)8 * kMaxTeams * 2 * rpad * sizeof(float)));
+    // (entries past a vector's end are copied into LDS with the last 16-byte granule but never gathered: keep them finite)
+    PK2_HIP(hipMemsetAsync(sc.ring, 0, (size_t)8 * kMaxTeams * 2 * rpad * sizeof(float), stream));
+    sc.rpad = rpad;
+  }
+  DenPersist2Params p;
+  p.d = dp;
+  p.fwd = g->p2fwd; p.bwd = g->p2bwd;
+  p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
+  p.rpad = rpad; p.tfloats = den2_tfloats(g); p.cap = g->p2_cap;
+  p.fwd_stream = (!g->h_p2fwd.sends.empty() || g->h_p2fwd.K > 2) ? 1 : 0;
+  p.bwd_stream = (!g->h_p2bwd.sends.empty() || g->h_p2bwd.K > 2) ? 1 : 0;
+  std::vector<std::pair<int, int>> order;    // (-T, task id = 2 n + dir), longest first
+  for (int n = 0; n < N; ++n)
+    if (lengths_host[n] > 0) { order.push_back({-lengths_host[n], 2 * n}); order.push_back({-lengths_host[n], 2 * n + 1}); }
+  std::sort(order.begin(), order.end());
+  p.ntasks = (int)order.size();
+  for (int k = 0; k < kMaxTasks; ++k) { p.task_seq[k] = 0; p.task_dir[k] = 0; }
+  for (int k = 0; k < p.ntasks; ++k) { p.task_seq[k] = (short)(order[k].second >> 1); p.task_dir[k] = (unsigned char)(order[k].second & 1); }
+  sc.ntasks = 0;
+  if (p.ntasks == 0) { *ran = true; return PK2_OK; }
+  const size_t lds = den_persist2_lds_bytes(p.tfloats, p.cap);
+  static bool attr = false;
+  if (!attr) {
+    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_persist2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr = true;
+  }
+  PK2_HIP(hipMemsetAsync(sc.ctl, 0, sizeof(DenPersistCtl), stream));
+  hipLaunchKernelGGL(param_block_store<DenPersist2Params>, dim3(1), dim3(1), 0, stream, p, sc.params);
+  hipLaunchKernelGGL(den_persist2_kernel, dim3(8 * kPR), dim3(kPT), lds, stream, sc.params, sc.ctl);
+#ifdef PK2_DP_PROFILE
+  { int tot = 0; for (int n = 0; n < N; ++n) tot += lengths_host[n];
+    hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4)); }
+#endif
+  PK2_LAUNCH_CHECK();
+  if (g_den_persist2_state < 0) {     // first use on this device: every recursion done, nobody timed out?
+    DenPersistCtl* h = new DenPersistCtl;
+    hipError_t e = hipMemcpyAsync(h, sc.ctl, sizeof(DenPersistCtl), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)p.ntasks;
+    delete h;
+    if (e != hipSuccess) { set_error("den_persist2: %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
+    g_den_persist2_state = ok ? 1 : 0;
+    if (!ok) return PK2_OK;
+  }
+  sc.ntasks = p.ntasks;
+  *ran = true;
+  return PK2_OK;
+}
+
+void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream) {
+  const DenPersist2Scratch& sc = g_den2_scratch[stream];
+  if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist2_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N);
+}
+
+}  // namespace pk2

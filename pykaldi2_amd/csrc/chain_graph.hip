@@ -315,6 +315,376 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
   *out = HostPersist();
 }
 
+// ---- second persistent layout (chain_internal.h: HostPersist2; kernel: chain_den_persist2.hip) ----------------------------
+// Contiguous ranges of whole groups for the kPR ranks, balanced by arcs (+1 per row: every row costs a slot in every list).
+static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const int32_t* group_of_row, int num_groups,
+                            HostPersist2* out) {
+  std::vector<int64_t> rarcs(num_rows, 0);
+  for (int64_t i = 0; i < A; ++i) rarcs[key[i]]++;
+  std::vector<int32_t> grow(num_groups + 1, 0);
+  if (group_of_row) {
+    for (int r = 0; r < num_rows; ++r) grow[group_of_row[r] + 1]++;
+    for (int g = 0; g < num_groups; ++g) grow[g + 1] += grow[g];
+  } else {
+    for (int g = 0; g <= num_groups; ++g) grow[g] = g;
+  }
+  if (grow[num_groups] != num_rows) return false;
+  std::vector<int64_t> gcost(num_groups, 0);
+  int64_t total = 0;
+  for (int g = 0; g < num_groups; ++g) {
+    for (int r = grow[g]; r < grow[g + 1]; ++r) gcost[g] += rarcs[r] + 2;
+    total += gcost[g];
+  }
+  out->row_begin.assign(kPR + 1, num_rows);
+  out->grp_begin.assign(kPR + 1, num_groups);
+  out->max_rows = out->max_groups = 0;
+  int g = 0;
+  int64_t left = total;
+  for (int r = 0; r < kPR; ++r) {
+    out->grp_begin[r] = g; out->row_begin[r] = grow[g];
+    const int64_t target = (left + (kPR - r) - 1) / (kPR - r);
+    int64_t have = 0; int rows = 0, groups = 0;
+    while (g < num_groups) {
+      const int gr = grow[g + 1] - grow[g];
+      if (rows + gr > kPMaxRows || groups + 1 > kPMaxRows) break;
+      if (have >= target) break;
+      have += gcost[g]; rows += gr; ++groups; ++g;
+    }
+    left -= have;
+    out->max_rows = std::max(out->max_rows, rows);
+    out->max_groups = std::max(out->max_groups, groups);
+  }
+  return g == num_groups;
+}
+
+// Table chunks of an ordering whose vector has R entries, for an LDS table of `tcap` floats (a multiple of 512).
+static bool persist2_chunks(int64_t A, const int32_t* idx, int R, int tcap, HostPersist2* out) {
+  out->R = R;
+  const int rpad = (R + 255) / 256 * 256;
+  if (rpad <= tcap) {
+    // Back to back.  Pass A may only gather from chunk 0 (chunk 1 is still arriving), pass B from both, so the lists can be
+    // balanced per rank as long as a little more than half of the gathers are eligible for pass A: the boundary is where 55 %
+    // of the gathers lie below it, at least one 1 KB row, and -- when the vector has two rows -- not the whole vector
+    // unless the gathers demand it.
+    std::vector<int64_t> cnt(rpad / 256, 0);
+    for (int64_t i = 0; i < A; ++i) cnt[idx[i] / 256]++;
+    int b = 0; int64_t below = 0;
+    while (b < rpad / 256 && 100 * below < 55 * A) below += cnt[b++];
+    b = std::max(1, b);
+    out->K = 2;
+    out->cbeg[0] = 0; out->cbeg[1] = std::min(R, b * 256); out->cbeg[2] = R;
+    out->lds_off[0] = 0; out->lds_off[1] = b * 256;
+    out->tfloats = rpad;
+    out->flexible = true;
+    for (int c = 3; c <= kMaxChunks; ++c) out->cbeg[c] = R;
+    return true;
+  }
+  out->flexible = false;
+  const int H = tcap / 2 / 256 * 256;
+  if (H < 256) return false;
+  const int K = (R + H - 1) / H;
+  if (K > kMaxChunks) return false;
+  out->K = K;
+  for (int c = 0; c <= kMaxChunks; ++c) out->cbeg[c] = std::min(R, c * H);
+  for (int c = 0; c < K; ++c) out->lds_off[c] = (c & 1) * H;
+  out->tfloats = 2 * H;
+  return true;
+}
+
+// Deals the arcs of a row that sit in one thread to its slots so that, slot index by slot index, the 32 lanes of a half wave
+// gather from different LDS banks (as build_persist_step).  `spt` = consecutive sorted slots per thread.
+static void persist2_deal(int64_t n, int spt, const std::vector<int32_t>& srow, std::vector<int64_t>& sarc, const int32_t* lidx,
+                          std::vector<int32_t>& sidx, int null_base, int null_span) {
+  sidx.assign(n, null_base);
+  std::vector<int32_t> load((size_t)2 * spt * 32);
+  std::vector<int64_t> cand;
+  for (int64_t wbase = 0; wbase < n; wbase += (int64_t)64 * spt) {
+    std::fill(load.begin(), load.end(), 0);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int half = lane >> 5;
+      int64_t s = wbase + (int64_t)lane * spt;
+      const int64_t lane_end = std::min<int64_t>(n, s + spt);
+      while (s < lane_end) {
+        int64_t e = s;
+        while (e < lane_end && srow[e] == srow[s]) ++e;
+        cand.assign(sarc.begin() + s, sarc.begin() + e);
+        for (int64_t pos = s; pos < e; ++pos) {
+          const int j = (int)(pos % spt);
+          int32_t* ld = &load[((size_t)half * spt + j) * 32];
+          size_t best = 0; int best_load = 1 << 30;
+          for (size_t c = 0; c < cand.size(); ++c) {
+            const int l = cand[c] < 0 ? -1 : ld[lidx[cand[c]] & 31];
+            if (l < best_load) { best_load = l; best = c; }
+          }
+          const int64_t a = cand[best];
+          cand[best] = cand.back(); cand.pop_back();
+          sarc[pos] = a;
+          if (a >= 0) {
+            sidx[pos] = lidx[a];
+          } else {
+            int bank = null_base & 31;          // any VALID entry of the chunk's buffer (its probability is 0; what lies
+            for (int b2 = 0; b2 < null_span; ++b2)   // past the vector's end in LDS was never written and may be a NaN)
+              if (ld[(null_base + b2) & 31] < ld[bank]) bank = (null_base + b2) & 31;
+            int off = 0;
+            while (((null_base + off) & 31) != bank) ++off;
+            sidx[pos] = null_base + off;
+          }
+          ld[sidx[pos] & 31]++;
+        }
+        s = e;
+      }
+    }
+  }
+}
+
+// Which list every arc goes to (and the LDS offset of the entry it gathers): the chunk it gathers from -- except that with
+// back-to-back chunks (`flexible`) pass B sees chunk 0 as well, so arcs into chunk 0 are moved to list 1 until the two lists
+// of a rank are equally long.  Row by row, the split is taken from the few values around the proportional share that cost
+// the fewest padding slots (both parts a multiple of `estep`, or one of them empty).
+static bool persist2_arc_lists(int64_t A, const int32_t* idx, const HostPersist2& h, int estep, const std::vector<int64_t>& ptr,
+                               const std::vector<int64_t>& perm, std::vector<uint8_t>* chunk_out, std::vector<int32_t>* lidx_out) {
+  const int K = h.K;
+  std::vector<uint8_t>& chunk = *chunk_out; std::vector<int32_t>& lidx = *lidx_out;
+  chunk.assign(A, 0); lidx.assign(A, 0);
+  for (int64_t i = 0; i < A; ++i) {
+    int c = 0;
+    while (c + 1 < K && idx[i] >= h.cbeg[c + 1]) ++c;
+    chunk[i] = (uint8_t)c;
+    lidx[i] = h.lds_off[c] + (idx[i] - h.cbeg[c]);
+    if (lidx[i] >= 65536) return false;
+  }
+  if (!h.flexible) return true;
+  auto pad = [&](int64_t x) { return x == 0 ? 0 : (estep - x % estep) % estep; };
+  for (int r = 0; r < kPR; ++r) {
+    int64_t elig = 0, all = 0;
+    for (int q = h.row_begin[r]; q < h.row_begin[r + 1]; ++q)
+      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) { ++all; if (chunk[perm[k]] == 0) ++elig; }
+    if (elig == 0) continue;
+    const double keep = std::min(1.0, (double)all / 2.0 / (double)elig);   // share of the eligible arcs that stays in list 0
+    double err = 0.0;
+    for (int q = h.row_begin[r]; q < h.row_begin[r + 1]; ++q) {
+      int64_t e = 0, o = 0;
+      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) (chunk[perm[k]] == 0 ? e : o)++;
+      if (e == 0) continue;
+      const double t = keep * (double)e + err;
+      int64_t best = -1; double best_cost = 1e30;
+      const int64_t lo = std::max<int64_t>(0, (int64_t)std::floor(t) - estep), hi = std::min<int64_t>(e, (int64_t)std::ceil(t) + estep);
+      for (int64_t a = lo; a <= hi; ++a) {
+        const double cost = (double)(pad(a) + pad(e - a + o)) + 0.01 * std::fabs((double)a - t);
+        if (cost < best_cost) { best_cost = cost; best = a; }
+      }
+      err = t - (double)best;
+      int64_t kept = 0;
+      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) {
+        if (chunk[perm[k]] != 0) continue;
+        if (kept < best) ++kept; else chunk[perm[k]] = 1;
+      }
+    }
+  }
+  return true;
+}
+
+// The slot lists of an ordering whose ranks, chunks and arc lists are fixed.  `res` = register slots per thread of a resident
+// pass (kQ; smaller values exist for tests that force streaming on small graphs).
+//  * resident list c (c < 2): only the rows that have an arc in it, numbered compactly (rmap: rank-local compact index of a
+//    row in list c, -1 = absent); what exceeds res * kPT slots is cut off and streamed;
+//  * streamed segment c: the cut-off remainder of list c (from the row the cut falls into) or, for c >= 2, the whole list,
+//    with EVERY row from its first one on (a null slot where a row has nothing): it adds into a row-indexed array.
+static bool persist2_lists(int64_t A, int num_rows, const float* prob, const float* piprob, const std::vector<int64_t>& ptr,
+                           const std::vector<int64_t>& perm, const std::vector<uint8_t>& chunk, const std::vector<int32_t>& lidx,
+                           int estep, int res, HostPersist2* out) {
+  out->estep = estep;
+  const int K = out->K;
+  out->prob.assign((size_t)kPR * kPSlots, 0.f);
+  out->idx2.assign((size_t)kPR * kPSlots / 2, 0u);
+  out->ends.assign((size_t)kPR * 2 * kPT, 0u);
+  out->first_row.assign((size_t)kPR * 2 * kPT, 0);
+  out->uncovered.assign((size_t)kPR * 2, 0);
+  out->ncomp.assign((size_t)kPR * 2, 0);
+  out->rmap.assign((size_t)2 * num_rows, (int16_t)-1);
+  out->pbeg.assign((size_t)kPR * (kMaxChunks + 1), 0);
+  out->sfirst_row.assign((size_t)kPR * kMaxChunks * kPT, 0);
+  out->wcrow.assign((size_t)kPR * kSegs * kPW, -1);
+  out->row_leak.assign(num_rows, 0.f);
+  out->row_psum.assign(num_rows, 0.f);
+  out->sprob.clear(); out->sidx2.clear(); out->sends.clear();
+  out->resident_slots = out->streamed_slots = 0;
+  out->max_pieces = 0;
+  std::vector<int32_t> srow, scomp, sidx; std::vector<int64_t> sarc; std::vector<char> send;
+  int npieces = 0;
+  // where the null slots of a chunk's lists point: valid entries of the buffer the chunk occupies (an empty chunk: chunk 0's)
+  int null_base[kMaxChunks], null_span[kMaxChunks];
+  for (int c = 0; c < K; ++c) {
+    const int cc = out->cbeg[c + 1] > out->cbeg[c] ? c : 0;
+    null_base[c] = out->lds_off[cc];
+    null_span[c] = std::max(1, std::min(32, out->cbeg[cc + 1] - out->cbeg[cc]));
+  }
+  for (int r = 0; r < kPR; ++r) {
+    const int row0 = out->row_begin[r], row1 = out->row_begin[r + 1];
+    for (int q = row0; q < row1; ++q) {
+      double leak = 0.0, psum = 0.0;
+      for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k) { leak += (double)piprob[perm[k]]; psum += (double)prob[perm[k]]; }
+      out->row_leak[q] = (float)leak; out->row_psum[q] = (float)psum;
+    }
+    int rank_pieces = 0;
+    for (int c = 0; c < K; ++c) {
+      // the list of chunk c: the rows with an arc in it, padded to estep slots; scomp = compact row index
+      srow.clear(); scomp.clear(); sarc.clear(); send.clear();
+      int ncomp = 0;
+      for (int q = row0; q < row1; ++q) {
+        const size_t before = srow.size();
+        for (int64_t k = ptr[q]; k < ptr[q + 1]; ++k)
+          if (chunk[perm[k]] == c) { srow.push_back(q - row0); scomp.push_back(ncomp); sarc.push_back(perm[k]); send.push_back(0); }
+        if (srow.size() == before) continue;
+        while ((srow.size() - before) % estep) { srow.push_back(q - row0); scomp.push_back(ncomp); sarc.push_back(-1); send.push_back(0); }
+        send.back() = 1;
+        if (c < 2) out->rmap[(size_t)c * num_rows + q] = (int16_t)ncomp;
+        ++ncomp;
+      }
+      const int64_t n = (int64_t)srow.size();
+      const int64_t nres = c < 2 ? std::min<int64_t>(n, (int64_t)res * kPT) : 0;
+      // (a cut falls on a slot boundary of estep: res and kSP are multiples of it)
+      if (c < 2) {
+        // resident pass: thread tid owns the sorted slots tid*res .. tid*res + res-1
+        std::vector<int32_t> rrow(scomp.begin(), scomp.begin() + nres);
+        std::vector<int64_t> rarc(sarc.begin(), sarc.begin() + nres);
+        persist2_deal(nres, res, rrow, rarc, lidx.data(), sidx, null_base[c], null_span[c]);
+        for (int tid = 0; tid < kPT; ++tid) {
+          uint32_t e = 0;
+          for (int j = 0; j < res; ++j) {
+            const int64_t s = (int64_t)tid * res + j;
+            if (s >= nres) break;
+            const int jj = c * kQ + j;
+            out->prob[((size_t)r * kPK + jj) * kPT + tid] = rarc[s] >= 0 ? prob[rarc[s]] : 0.f;
+            out->idx2[((size_t)r * (kPK / 2) + jj / 2) * kPT + tid] |= (uint32_t)sidx[s] << (16 * (jj & 1));
+            if (send[s]) e |= 1u << j;
+          }
+          // (slots past the list, and the unused slots res..kQ-1 of a test build, keep probability 0 and LDS offset 0: the
+          // first entry of chunk 0 or of the chunk that replaced it in buffer 0, a valid number either way)
+          out->ends[((size_t)r * 2 + c) * kPT + tid] = e;
+          const int64_t s0 = (int64_t)tid * res;
+          out->first_row[((size_t)r * 2 + c) * kPT + tid] = s0 < nres ? scomp[s0] : 0;
+        }
+        for (int w = 0; w < kPW; ++w) {      // (the carries are addressed by rank-local ROW, like the streamed segments')
+          const int64_t last = (int64_t)(w + 1) * 64 * res - 1;
+          if (last < nres && !send[last]) out->wcrow[((size_t)r * kSegs + c) * kPW + w] = srow[last];
+        }
+        // compact rows whose END is not in the resident part get no store from the pass: the kernel clears them itself
+        out->uncovered[(size_t)r * 2 + c] = nres < n ? scomp[nres] : ncomp;
+        out->ncomp[(size_t)r * 2 + c] = ncomp;
+        out->resident_slots += nres;
+      }
+      // streamed segment: the remainder, every row from its first one on; thread tid owns pieces*kSP consecutive sorted slots
+      out->pbeg[(size_t)r * (kMaxChunks + 1) + c] = npieces;
+      if (nres == n) continue;
+      {
+        std::vector<int32_t> rrow; std::vector<int64_t> rarc; std::vector<char> rend;
+        int64_t s = nres;
+        for (int q = srow[nres]; q < row1 - row0; ++q) {
+          const size_t before = rrow.size();
+          while (s < n && srow[s] == q) { if (sarc[s] >= 0) { rrow.push_back(q); rarc.push_back(sarc[s]); rend.push_back(0); } ++s; }
+          if (rrow.size() == before) { rrow.push_back(q); rarc.push_back(-1); rend.push_back(0); }
+          while ((rrow.size() - before) % estep) { rrow.push_back(q); rarc.push_back(-1); rend.push_back(0); }
+          rend.back() = 1;
+        }
+        const int64_t ns = (int64_t)rrow.size();
+        const int pieces = (int)((ns + (int64_t)kPT * kSP - 1) / ((int64_t)kPT * kSP));
+        const int spt = pieces * kSP;
+        persist2_deal(ns, spt, rrow, rarc, lidx.data(), sidx, null_base[c], null_span[c]);
+        out->sprob.resize((size_t)(npieces + pieces) * kSP * kPT, 0.f);
+        out->sidx2.resize((size_t)(npieces + pieces) * (kSP / 2) * kPT, 0u);
+        out->sends.resize((size_t)(npieces + pieces) * kPT, 0u);
+        // null slots past the segment's end gather a valid entry too
+        const uint32_t null_pair = (uint32_t)null_base[c] | ((uint32_t)null_base[c] << 16);
+        for (size_t k = (size_t)npieces * (kSP / 2) * kPT; k < out->sidx2.size(); ++k) out->sidx2[k] = null_pair;
+        for (int tid = 0; tid < kPT; ++tid) {
+          for (int p = 0; p < spt; ++p) {
+            const int64_t s2 = (int64_t)tid * spt + p;
+            if (s2 >= ns) break;
+            const int piece = npieces + p / kSP, j = p % kSP;
+            out->sprob[((size_t)piece * kSP + j) * kPT + tid] = rarc[s2] >= 0 ? prob[rarc[s2]] : 0.f;
+            uint32_t& w2 = out->sidx2[((size_t)piece * (kSP / 2) + j / 2) * kPT + tid];
+            w2 = (w2 & ~(0xffffu << (16 * (j & 1)))) | ((uint32_t)sidx[s2] << (16 * (j & 1)));
+            if (rend[s2]) out->sends[(size_t)piece * kPT + tid] |= 1u << j;
+          }
+          const int64_t s0 = (int64_t)tid * spt;
+          out->sfirst_row[((size_t)r * kMaxChunks + c) * kPT + tid] = s0 < ns ? rrow[s0] : 0;
+        }
+        for (int w = 0; w < kPW; ++w) {
+          const int64_t last = (int64_t)(w + 1) * 64 * spt - 1;
+          if (last < ns && !rend[last]) out->wcrow[((size_t)r * kSegs + 2 + c) * kPW + w] = rrow[last];
+        }
+        npieces += pieces;
+        rank_pieces += pieces;
+        out->streamed_slots += ns;
+      }
+    }
+    for (int c = K; c <= kMaxChunks; ++c) out->pbeg[(size_t)r * (kMaxChunks + 1) + c] = npieces;
+    out->max_pieces = std::max(out->max_pieces, rank_pieces);
+  }
+  out->ok = true;
+  return true;
+}
+
+// Both orderings of the second persistent layout.  fkey / fidx: forward ordering (rows = virtual destination states,
+// gathering source states); bkey / bidx: backward ordering (rows = source states, gathering virtual destination states).
+static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, const int32_t* src2, const float* prob2,
+                           const float* piprob2, const int32_t* vstate) {
+  HostPersist2& f = g->h_p2fwd; HostPersist2& b = g->h_p2bwd;
+  f = HostPersist2(); b = HostPersist2();
+  g->p2_cap = 0;
+  const int S = g->S, V = g->V;
+  if (V >= 65536 || S >= 65536) return;
+  if (!persist2_assign(A2, V, arc_v, vstate, S, &f)) return;
+  if (!persist2_assign(A2, S, src2, nullptr, S, &b)) return;
+  // the backward workgroups also stage x for their own virtual states: max_groups = how many
+  b.max_groups = 0;
+  for (int r = 0; r < kPR; ++r) b.max_groups = std::max(b.max_groups, g->voff[b.row_begin[r + 1]] - g->voff[b.row_begin[r]]);
+  if (b.max_groups > kPMaxRows) return;
+  const int cap = (std::max({f.max_rows, f.max_groups, b.max_rows, b.max_groups, 1}) + 3) / 4 * 4;
+  int64_t tcap = ((int64_t)kDenPersistMaxLds / 4 - kP2RowArrays * (int64_t)cap - kP2FixedFloats) / 512 * 512;
+  if (const char* env = getenv("PK2_DP2_TCAP")) tcap = std::min<int64_t>(tcap, std::max(512, atoi(env) / 512 * 512));
+  if (tcap < 512) return;
+  int res = kQ;
+  if (const char* env = getenv("PK2_DP2_RES")) res = std::max(1, std::min(kQ, atoi(env)));     // (tests: force streaming)
+  const char* env_e = getenv("PK2_DEN_ESTEP");
+  const int forced = env_e ? atoi(env_e) : 0;
+  // per frame, in microseconds: what the arcs of the two resident passes cost with row-end code at 64 / estep places
+  // (measured for 1 and 2 on the BASELINE graph), a streamed piece, a segment's extra barrier
+  auto arcs_us = [](int e) { return e == 1 ? 3.1 : e == 2 ? 1.8 : e == 4 ? 1.55 : 1.45; };
+  for (int which = 0; which < 2; ++which) {
+    HostPersist2& h = which == 0 ? f : b;
+    const int rows = which == 0 ? V : S, R = which == 0 ? S : V;
+    const int32_t* key = which == 0 ? arc_v : src2;
+    const int32_t* idx = which == 0 ? src2 : arc_v;
+    if (!persist2_chunks(A2, idx, R, (int)tcap, &h)) { f.ok = b.ok = false; return; }
+    std::vector<int64_t> ptr(rows + 1, 0);
+    for (int64_t i = 0; i < A2; ++i) ptr[key[i] + 1]++;
+    for (int r = 0; r < rows; ++r) ptr[r + 1] += ptr[r];
+    std::vector<int64_t> perm(A2);
+    {
+      std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+      for (int64_t i = 0; i < A2; ++i) perm[cur[key[i]]++] = i;
+    }
+    // the widest row padding without a streamed piece; if every width streams, the cheapest frame
+    HostPersist2 best_h; double best_cost = 1e30;
+    std::vector<uint8_t> list_of; std::vector<int32_t> lidx;
+    for (int estep : {8, 4, 2, 1}) {
+      if ((forced > 0 && estep != forced) || res % estep != 0) continue;      // (a cut must fall between whole rows' slots)
+      HostPersist2 cand = h;
+      if (!persist2_arc_lists(A2, idx, cand, estep, ptr, perm, &list_of, &lidx) ||
+          !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, estep, res, &cand)) { f.ok = b.ok = false; return; }
+      const double cost = arcs_us(estep) + 0.6 * cand.max_pieces + (cand.max_pieces ? 0.3 : 0.0);
+      if (cost < best_cost) { best_cost = cost; best_h = std::move(cand); }
+      if (best_h.max_pieces == 0 && best_h.K == 2) break;
+    }
+    if (best_cost > 1e29) { f.ok = b.ok = false; return; }
+    h = std::move(best_h);
+  }
+  if (!(f.ok && b.ok)) { f.ok = b.ok = false; return; }
+  g->p2_cap = cap;
+}
+
 static int build_graph_ordered(int32_t S, int32_t P, int64_t A, const int32_t* src_in, const int32_t* dst_in,
                                const int32_t* pdf, const float* prob, int32_t start, const char* order_mode,
                                pk2_den_graph** out) {
@@ -435,6 +805,7 @@ static int build_graph_ordered(int32_t S, int32_t P, int64_t A, const int32_t* s
                    true, true);
     build_persist(A2, g->V, arc_v.data(), src2.data(), prob2.data(), piprob2.data(), vstate.data(), S, &g->h_pfwd);
     build_persist(A2, S, src2.data(), arc_v.data(), prob2.data(), piprob2.data(), nullptr, S, &g->h_pbwd);
+    build_persist2(g, A2, arc_v.data(), src2.data(), prob2.data(), piprob2.data(), vstate.data());
     if (g->h_pbwd.ok) {     // the backward workgroups also stage x for their own virtual states: max_groups = how many
       g->h_pbwd.max_groups = 0;
       for (int r = 0; r < kPR; ++r)
@@ -494,6 +865,33 @@ static int upload_persist(pk2_den_graph* g, const HostPersist& h, DevPersist* d)
   return PK2_OK;
 }
 
+static int upload_persist2(pk2_den_graph* g, const HostPersist2& h, DevPersist2* d) {
+  if (!h.ok) return PK2_OK;
+  int rc;
+  if ((rc = upload_vec(g, h.prob, &d->prob))) return rc;
+  if ((rc = upload_vec(g, h.idx2, &d->idx2))) return rc;
+  if ((rc = upload_vec(g, h.ends, &d->ends))) return rc;
+  if ((rc = upload_vec(g, h.first_row, &d->first_row))) return rc;
+  if ((rc = upload_vec(g, h.uncovered, &d->uncovered))) return rc;
+  if ((rc = upload_vec(g, h.ncomp, &d->ncomp))) return rc;
+  if ((rc = upload_vec(g, h.rmap, &d->rmap))) return rc;
+  d->num_rows = (int)(h.rmap.size() / 2);
+  if ((rc = upload_vec(g, h.pbeg, &d->pbeg))) return rc;
+  if ((rc = upload_vec(g, h.sprob, &d->sprob))) return rc;
+  if ((rc = upload_vec(g, h.sidx2, &d->sidx2))) return rc;
+  if ((rc = upload_vec(g, h.sends, &d->sends))) return rc;
+  if ((rc = upload_vec(g, h.sfirst_row, &d->sfirst_row))) return rc;
+  if ((rc = upload_vec(g, h.wcrow, &d->wcrow))) return rc;
+  if ((rc = upload_vec(g, h.row_begin, &d->row_begin))) return rc;
+  if ((rc = upload_vec(g, h.grp_begin, &d->grp_begin))) return rc;
+  if ((rc = upload_vec(g, h.row_leak, &d->row_leak))) return rc;
+  if ((rc = upload_vec(g, h.row_psum, &d->row_psum))) return rc;
+  d->estep = h.estep; d->K = h.K; d->R = h.R;
+  for (int c = 0; c <= kMaxChunks; ++c) d->cbeg[c] = h.cbeg[c];
+  for (int c = 0; c < kMaxChunks; ++c) d->lds_off[c] = h.lds_off[c];
+  return PK2_OK;
+}
+
 static int upload_ordering(pk2_den_graph* g, const HostOrdering& h, DevOrdering* d) {
   int rc;
   if ((rc = upload_vec(g, h.arcs, &d->arcs))) return rc;
@@ -523,6 +921,8 @@ int den_upload(pk2_den_graph* g) {
   if ((rc = upload_ordering(g, g->h_bwdv, &g->bwdv))) return rc;
   if ((rc = upload_persist(g, g->h_pfwd, &g->pfwd))) return rc;
   if ((rc = upload_persist(g, g->h_pbwd, &g->pbwd))) return rc;
+  if ((rc = upload_persist2(g, g->h_p2fwd, &g->p2fwd))) return rc;
+  if ((rc = upload_persist2(g, g->h_p2bwd, &g->p2bwd))) return rc;
   if ((rc = upload_vec(g, g->voff, &g->d_voff))) return rc;
   if ((rc = upload_vec(g, g->vpdf, &g->d_vpdf))) return rc;
   if ((rc = upload_vec(g, g->loop_pdf, &g->d_loop_pdf))) return rc;
@@ -533,7 +933,11 @@ int den_upload(pk2_den_graph* g) {
   if ((rc = upload_vec(g, g->po_off, &g->d_po_off))) return rc;
   if ((rc = upload_vec(g, g->po_occ, &g->d_po_occ))) return rc;
   const float* dpi = nullptr;
-  if ((rc = upload_vec(g, g->pi, &dpi))) return rc;
+  {   // (padded to whole 1 KB rows: the persistent kernels copy it into LDS with 16-byte LDS-DMA granules)
+    std::vector<float> pi_pad(g->pi);
+    pi_pad.resize((pi_pad.size() + 255) / 256 * 256 + 256, 0.f);
+    if ((rc = upload_vec(g, pi_pad, &dpi))) return rc;
+  }
   g->d_pi = const_cast<float*>(dpi);
   g->uploaded = true;
   return PK2_OK;
@@ -649,6 +1053,36 @@ extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, in
   if (loop_prob_out) memcpy(loop_prob_out, g->loop_prob.data(), g->loop_prob.size() * sizeof(float));
   if (ooff_out) memcpy(ooff_out, g->ooff.data(), g->ooff.size() * sizeof(int32_t));
   if (opdf_out) memcpy(opdf_out, g->opdf.data(), g->opdf.size() * sizeof(int32_t));
+  return PK2_OK;
+}
+
+// Test hook: the second persistent layout of an ordering (which: 0 forward, 1 backward).  info[32] = {ok, estep, K, R,
+// tfloats, max_rows, max_groups, pieces, cap, rows, cbeg[0..kMaxChunks] at 10.., lds_off[0..kMaxChunks-1] at 20..,
+// kPR, kPT, kPK, kPW, kSP, kSegs at 26..}; the arrays (may be null) are sized from it (chain_internal.h: HostPersist2).
+extern "C" int pk2_den_graph_debug_persist2(const pk2_den_graph* g, int which, int32_t* info, float* prob, uint32_t* idx2,
+                                            uint32_t* ends, int32_t* first_row, int32_t* uncovered, int32_t* ncomp, int16_t* rmap,
+                                            int32_t* pbeg, float* sprob,
+                                            uint32_t* sidx2, uint32_t* sends, int32_t* sfirst_row, int32_t* wcrow,
+                                            int32_t* row_begin, int32_t* grp_begin, float* row_leak, float* row_psum) {
+  PK2_REQUIRE(g && (which == 0 || which == 1) && info, "den graph debug: bad arguments");
+  const HostPersist2& h = which == 0 ? g->h_p2fwd : g->h_p2bwd;
+  for (int k = 0; k < 32; ++k) info[k] = 0;
+  info[0] = h.ok ? 1 : 0; info[1] = h.estep; info[2] = h.K; info[3] = h.R; info[4] = h.tfloats; info[5] = h.max_rows;
+  info[6] = h.max_groups; info[7] = (int32_t)(h.sends.size() / kPT); info[8] = g->p2_cap; info[9] = (int32_t)h.row_leak.size();
+  for (int c = 0; c <= kMaxChunks; ++c) info[10 + c] = h.cbeg[c];
+  for (int c = 0; c < kMaxChunks; ++c) info[20 + c] = h.lds_off[c];
+  info[26] = kPR; info[27] = kPT; info[28] = kPK; info[29] = kPW; info[30] = kSP; info[31] = kSegs;
+  if (!h.ok) return PK2_OK;
+  auto cp = [](void* dst, const void* src, size_t bytes) { if (dst && bytes) memcpy(dst, src, bytes); };
+  cp(prob, h.prob.data(), h.prob.size() * 4); cp(idx2, h.idx2.data(), h.idx2.size() * 4);
+  cp(ends, h.ends.data(), h.ends.size() * 4); cp(first_row, h.first_row.data(), h.first_row.size() * 4);
+  cp(uncovered, h.uncovered.data(), h.uncovered.size() * 4); cp(pbeg, h.pbeg.data(), h.pbeg.size() * 4);
+  cp(ncomp, h.ncomp.data(), h.ncomp.size() * 4); cp(rmap, h.rmap.data(), h.rmap.size() * 2);
+  cp(sprob, h.sprob.data(), h.sprob.size() * 4); cp(sidx2, h.sidx2.data(), h.sidx2.size() * 4);
+  cp(sends, h.sends.data(), h.sends.size() * 4); cp(sfirst_row, h.sfirst_row.data(), h.sfirst_row.size() * 4);
+  cp(wcrow, h.wcrow.data(), h.wcrow.size() * 4); cp(row_begin, h.row_begin.data(), h.row_begin.size() * 4);
+  cp(grp_begin, h.grp_begin.data(), h.grp_begin.size() * 4); cp(row_leak, h.row_leak.data(), h.row_leak.size() * 4);
+  cp(row_psum, h.row_psum.data(), h.row_psum.size() * 4);
   return PK2_OK;
 }
 

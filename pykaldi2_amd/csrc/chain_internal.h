@@ -110,6 +110,64 @@ struct DevPersist {
   int estep = 1;
 };
 
+// Second layout of the persistent kernel (chain_den_persist2.hip): no capacity limits.
+//  * The frame's state vector is cut into K table CHUNKS, contiguous index ranges [cbeg[c], cbeg[c+1]) (whole 1 KB LDS-DMA
+//    rows).  A vector that fits the LDS table has two, laid out back to back: the kernel starts both DMAs at once and runs the
+//    arcs that gather from chunk 0 while chunk 1 is still arriving.  A longer vector goes through two LDS buffers of half the
+//    table each, chunk c in buffer c % 2.
+//  * Per rank and chunk the arcs form their own row-sorted slot list (rows padded to `estep` slots).  A thread keeps kQ
+//    register slots of list 0 ("pass A") and kQ of list 1 ("pass B"); these two lists hold only the rows that have an arc in
+//    them, numbered compactly (rmap).  With back-to-back chunks pass B may gather from chunk 0 as well, so arcs move from
+//    list 0 to list 1 until the two are equally long.  What does not fit the register slots -- the rest of lists 0 / 1 and the
+//    whole lists of chunks >= 2 -- is STREAMED: read again in every frame from the XCD's L2, kSP slots per thread at a time
+//    ("piece"); a thread owns `pieces * kSP` consecutive sorted slots of a streamed segment, which holds EVERY row from its
+//    first one on (a null slot where a row has no arc).
+//  * Pass A and pass B sum into their own compact LDS row arrays (plain stores, one per row), the streamed segments add into
+//    a third, row-indexed one; the row epilogue adds them up together with the wave carry-outs of every segment.
+constexpr int kQ = kPK / 2;             // register slots per thread of one resident pass
+constexpr int kSP = 16;                 // slots per thread of a streamed piece
+constexpr int kMaxChunks = 6;
+constexpr int kSegs = 2 + kMaxChunks;   // row-sum segments of a frame: pass A, pass B, streamed segment of chunk 0 .. K-1
+struct HostPersist2 {
+  bool ok = false;
+  int estep = 1;
+  int K = 0;                             // table chunks
+  int R = 0;                             // table entries
+  int cbeg[kMaxChunks + 1] = {0};        // first table index of a chunk (multiples of 256 but the last end = R)
+  int lds_off[kMaxChunks] = {0};         // where the chunk sits in the LDS table (floats)
+  int tfloats = 0;                       // LDS table floats
+  bool flexible = false;                 // chunks back to back: list 1 (pass B and its segment) may gather from chunk 0 too
+  int max_rows = 0, max_groups = 0;
+  int64_t resident_slots = 0, streamed_slots = 0;   // (statistics)
+  int max_pieces = 0;                    // most streamed pieces of one rank
+  std::vector<float> prob;               // [(r*kPK + j)*kPT + tid]   j < kQ: pass A, else pass B
+  std::vector<uint32_t> idx2;            // [(r*kPK/2 + j/2)*kPT + tid] LDS float offsets, two to a word
+  std::vector<uint32_t> ends;            // [(r*2 + pass)*kPT + tid]  bit j: a row ends after the pass's slot j
+  std::vector<int32_t> first_row;        // [(r*2 + pass)*kPT + tid]  COMPACT row of the thread's first slot
+  std::vector<int32_t> uncovered;        // [r*2 + pass] first compact row whose end is not in the resident pass (ncomp: none)
+  std::vector<int32_t> ncomp;            // [r*2 + pass] rows of the rank that have a slot in list `pass` (its compact rows)
+  std::vector<int16_t> rmap;             // [pass*rows + row] compact index of a row in list `pass` of its rank, -1 = absent
+  std::vector<int32_t> pbeg;             // [r*(kMaxChunks+1) + c] pieces of rank r, chunk c: [pbeg[c], pbeg[c+1]) (global ids)
+  std::vector<float> sprob;              // [(piece*kSP + j)*kPT + tid]
+  std::vector<uint32_t> sidx2;           // [(piece*kSP/2 + j/2)*kPT + tid]
+  std::vector<uint32_t> sends;           // [piece*kPT + tid] bit j (< kSP): a row ends after slot j of the piece
+  std::vector<int32_t> sfirst_row;       // [(r*kMaxChunks + c)*kPT + tid]
+  std::vector<int32_t> wcrow;            // [(r*kSegs + seg)*kPW + w] rank-local row open after the last slot of wave w (-1: none)
+  std::vector<int32_t> row_begin, grp_begin;
+  std::vector<float> row_leak, row_psum;
+};
+struct DevPersist2 {
+  const float* prob = nullptr; const uint32_t* idx2 = nullptr; const uint32_t* ends = nullptr; const int32_t* first_row = nullptr;
+  const int32_t* uncovered = nullptr; const int32_t* ncomp = nullptr; const int16_t* rmap = nullptr; const int32_t* pbeg = nullptr;
+  int num_rows = 0;
+  const float* sprob = nullptr; const uint32_t* sidx2 = nullptr; const uint32_t* sends = nullptr; const int32_t* sfirst_row = nullptr;
+  const int32_t* wcrow = nullptr; const int32_t* row_begin = nullptr; const int32_t* grp_begin = nullptr;
+  const float* row_leak = nullptr; const float* row_psum = nullptr;
+  int estep = 1, K = 0, R = 0;
+  int cbeg[kMaxChunks + 1] = {0};
+  int lds_off[kMaxChunks] = {0};
+};
+
 }  // namespace pk2
 
 struct pk2_den_graph {
@@ -135,6 +193,9 @@ struct pk2_den_graph {
   pk2::HostOrdering h_fwdv, h_bwdv;       // rows = virtual dst gathering src | rows = src gathering virtual dst
   pk2::HostPersist h_pfwd, h_pbwd;        // the same two orderings for the persistent kernel
   pk2::DevPersist pfwd, pbwd;
+  pk2::HostPersist2 h_p2fwd, h_p2bwd;     // ... and for its second form (chain_den_persist2.hip: chunked table, streamed overflow)
+  pk2::DevPersist2 p2fwd, p2bwd;
+  int p2_cap = 0;                         // LDS row buffers of that kernel (rows / groups / own virtual states of a rank)
   const int32_t* d_voff = nullptr;
   const int32_t* d_vpdf = nullptr;
   const int32_t* d_loop_pdf = nullptr;

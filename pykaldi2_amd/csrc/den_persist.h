@@ -22,4 +22,21 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& p, const float* xv, co
 // After den_finalize: a launch in which a poll timed out turns den_lp into NaN instead of passing for a result.
 void den_persist_check_launch(float* den_lp, int N, hipStream_t stream);
 
+// ---- second form (chain_den_persist2.hip): chunked LDS table, two resident passes, streamed overflow -- any graph whose
+// ranks hold at most kPMaxRows rows and whose vector needs at most kMaxChunks table chunks.
+// LDS of a workgroup: the table, seven row arrays of `cap` floats (sums of pass A, of pass B, of the streamed segments, x
+// of own rows, two per-row constants, and the two 16-bit compact-row maps), and the small fixed part (reduction scratch,
+// the segments' wave carries and their rows, flags).
+constexpr int kP2RowArrays = 7;
+constexpr int kP2FixedFloats = 2 * kPW + 4 + 2 * kSegs * kPW + 16;
+inline size_t den_persist2_lds_bytes(int tfloats, int cap) { return ((size_t)tfloats + kP2RowArrays * (size_t)cap + kP2FixedFloats) * sizeof(float); }
+bool den_persist2_fits(const pk2_den_graph* g);
+int den_persist2_launch(pk2_den_graph* g, const DenParams& p, const float* xv, const int32_t* lengths_host, int N,
+                        hipStream_t stream, bool* ran);
+void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream);
+// Which recursion kernel a call of N sequences takes: 0 = the launch-per-frame kernels, 1 = den_persist_kernel (everything
+// resident: graphs up to ~1.05 M arc slots and ~36 k states), 2 = den_persist2_kernel.  PK2_DEN_PERSIST = 0 | 1 | 2 forces one
+// (a forced form that does not fit the graph falls back to the frame kernels).
+int den_persist_version(const pk2_den_graph* g, int N);
+
 }  // namespace pk2

@@ -289,6 +289,175 @@ def test_den_graph_persistent_layouts(case, estep, monkeypatch):
     assert np.abs(got - np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)).max() < 1e-9
 
 
+def _emulate_persist2(lay, table):
+    """numpy model of frame_rows + row_val of chain_den_persist2.hip over the host layout (chain_internal.h: HostPersist2):
+    chunked LDS table (entries never copied are NaN: a null slot must not touch them), pass A / pass B with plain stores,
+    streamed segments adding into pass A's array, segmented wave scans, wave carries of every segment."""
+    R_, K, T = lay["prob"].shape
+    Q, SP, W, NC = K // 2, lay["SP"], T // 64, lay["K"]
+    cbeg, off = lay["cbeg"], lay["lds_off"]
+    out = np.zeros(lay["row_begin"][-1])
+    table = np.asarray(table, np.float64)
+    assert len(table) == lay["R"] and cbeg[NC] == lay["R"] and cbeg[0] == 0
+    idx_of = lambda words, j, tid: (int(words[j // 2, tid]) >> (16 * (j & 1))) & 0xffff
+
+    def scan(acc, tails, has_end, first_row, wcrow_seg, add):
+        """open tails of a segment -> the next row end of the wave, or the wave's carry"""
+        for w in range(W):
+            x = 0.0
+            for lane in range(64):
+                tid = w * 64 + lane
+                if has_end[tid]:
+                    acc[first_row[tid]] += x
+                    x = tails[tid]
+                else:
+                    x += tails[tid]
+            add.append((int(wcrow_seg[w]), x))
+
+    for r in range(R_):
+        row0, row1 = int(lay["row_begin"][r]), int(lay["row_begin"][r + 1])
+        n = row1 - row0
+        lds = np.full(lay["tfloats"], np.nan)
+
+        def load(c):
+            lds[off[c]:off[c] + cbeg[c + 1] - cbeg[c]] = table[cbeg[c]:cbeg[c + 1]]
+        nc = lay["ncomp"][r]
+        acc = [np.full(max(int(nc[0]), 1), np.nan), np.full(max(int(nc[1]), 1), np.nan)]     # compact rows of list 0 / 1
+        for ps in (0, 1):
+            acc[ps][lay["uncovered"][r, ps]:] = 0.0
+            m = lay["rmap"][ps, row0:row1]
+            assert sorted(m[m >= 0]) == list(range(int(nc[ps])))        # the present rows, numbered in order
+        accS = np.zeros(max(n, 1))                                       # rank-local rows
+        carries = []
+        pb = lay["pbeg"][r]
+
+        def resident(ps):
+            tails, has_end = np.zeros(T), np.zeros(T, bool)
+            for tid in range(T):
+                e, c, sm = int(lay["ends"][r, ps, tid]), int(lay["first_row"][r, ps, tid]), 0.0
+                assert all((j + 1) % lay["estep"] == 0 for j in range(Q) if (e >> j) & 1)
+                for j in range(Q):
+                    sm += lds[idx_of(lay["idx2"][r], ps * Q + j, tid)] * float(lay["prob"][r, ps * Q + j, tid])
+                    if (e >> j) & 1:
+                        acc[ps][c] = sm; c += 1; sm = 0.0
+                tails[tid], has_end[tid] = sm, e != 0
+            scan(acc[ps], tails, has_end, lay["first_row"][r, ps], lay["wcrow"][r, ps], carries)
+
+        def streamed(c):
+            if pb[c + 1] == pb[c]:
+                assert (lay["wcrow"][r, 2 + c] == -1).all()
+                return
+            tails, has_end = np.zeros(T), np.zeros(T, bool)
+            for tid in range(T):
+                cc, sm, had = int(lay["sfirst_row"][r, c, tid]), 0.0, False
+                for p in range(pb[c], pb[c + 1]):
+                    e = int(lay["sends"][p, tid])
+                    assert all((j + 1) % lay["estep"] == 0 for j in range(SP) if (e >> j) & 1)
+                    for j in range(SP):
+                        sm += lds[idx_of(lay["sidx2"][p], j, tid)] * float(lay["sprob"][p, j, tid])
+                        if (e >> j) & 1:
+                            accS[cc] += sm; cc += 1; sm = 0.0
+                    had = had or e != 0
+                tails[tid], has_end[tid] = sm, had
+            scan(accS, tails, has_end, lay["sfirst_row"][r, c], lay["wcrow"][r, 2 + c], carries)
+
+        load(0); load(1)
+        resident(0)
+        streamed(0)
+        if NC > 2:
+            load(2)
+        resident(1)
+        streamed(1)
+        for c in range(2, NC):
+            if c + 1 < NC:
+                load(c + 1)
+            streamed(c)
+        rows = accS.copy()
+        for ps in (0, 1):
+            m = lay["rmap"][ps, row0:row1]
+            rows[:n] += np.where(m >= 0, acc[ps][np.maximum(m, 0)], 0.0)
+        for q, x in carries:
+            if q >= 0:
+                rows[q] += x
+        out[row0:row1] = rows[:n]
+    return out
+
+
+@pytest.mark.parametrize("case", ["default", "bigstate", "overflow", "overflow_estep1", "chunks", "chunks_overflow", "res1", "res2_chunks"])
+def test_den_graph_persistent2_layouts(case, monkeypatch):
+    """Second persistent layout (chain_den_persist2.hip): table chunks, two resident passes, streamed overflow.  The numpy
+    model of the kernel's frame reproduces both recursions' row sums: back-to-back chunks (default), a row spanning several
+    waves (bigstate), lists longer than the resident slots (overflow: PK2_DP2_RES=8 leaves 8 register slots per pass), a
+    vector longer than the LDS table (chunks: PK2_DP2_TCAP=512 -> two 256-entry buffers, up to 6 chunks), and both."""
+    S, A, P, seed = 300, 6000, 23, 7
+    kw = dict(loop_pdf_differs=True)
+    monkeypatch.setenv("PK2_DEN_ORDER", "none")
+    if case == "bigstate":
+        S, A = 200, 40000
+    if case.startswith("overflow"):
+        S, A = 600, 300000
+        kw["multi_entry_frac"] = 0.2
+        monkeypatch.setenv("PK2_DP2_RES", "8")
+        if case == "overflow_estep1":
+            monkeypatch.setenv("PK2_DEN_ESTEP", "1")
+    if case == "res1":              # what the GPU parity tests use to reach the streamed path on small graphs
+        monkeypatch.setenv("PK2_DP2_RES", "1")
+        S, A = 400, 30000
+    if case == "res2_chunks":
+        monkeypatch.setenv("PK2_DP2_RES", "2")
+        monkeypatch.setenv("PK2_DP2_TCAP", "1024")
+        S, A = 1400, 50000
+        kw["multi_entry_frac"] = 0.3
+    if case.startswith("chunks"):
+        S, A = 1100, 20000
+        monkeypatch.setenv("PK2_DP2_TCAP", "512")
+        if case == "chunks_overflow":
+            A = 200000
+            monkeypatch.setenv("PK2_DP2_RES", "8")
+    g = synth.den_graph_arcs(S, A, P, seed, **kw)
+    if case == "bigstate":
+        g["dst"][:30000] = 5
+        g["pdf"][:20000] = 1; g["pdf"][20000:28000] = 2; g["pdf"][28000:30000] = 3
+    G = chain.DenominatorGraph(g, P)
+    of = G.debug_ordering(3)
+    voff, vpdf, lpdf, lprob = of["voff"], of["vpdf"], of["loop_pdf"], of["loop_prob"].astype(np.float64)
+    S_, V = g["num_states"], len(of["vpdf"])
+    vstate = np.repeat(np.arange(S_), np.diff(voff))
+    rng = np.random.default_rng(1)
+    al, be, x = rng.random(S_), rng.random(S_), rng.random(P)
+    xv = np.where(vpdf >= 0, x[np.maximum(vpdf, 0)], 1.0)
+    xl = np.where(lpdf >= 0, x[np.maximum(lpdf, 0)], 1.0)
+    src, dst, pdf, prob = g["src"], g["dst"], g["pdf"], g["prob"].astype(np.float64)
+    pf, pb = G.debug_persist2(0), G.debug_persist2(1)
+    assert pf is not None and pb is not None
+    assert pf["R"] == S_ and pb["R"] == V and pf["row_begin"][-1] == V and pb["row_begin"][-1] == S_
+    assert (voff[pf["grp_begin"]] == pf["row_begin"]).all()                     # whole states per workgroup
+    if case in ("default", "bigstate"):
+        assert pf["K"] == 2 and pb["K"] == 2 and pf["pieces"] == 0 and pb["pieces"] == 0
+        assert pf["lds_off"][1] == pf["cbeg"][1] or pf["cbeg"][1] == pf["cbeg"][2]      # back to back
+    if case.startswith("overflow"):
+        assert pf["pieces"] > 0 and pb["pieces"] > 0 and pf["K"] == 2
+        assert (pf["uncovered"] < pf["ncomp"]).any()                              # some list really is truncated
+    if case == "res1":
+        assert pf["estep"] == 1 and pf["pieces"] > 0 and pb["pieces"] > 0
+    if case == "res2_chunks":
+        assert pf["estep"] <= 2 and pf["K"] == 3 and pb["K"] >= 3 and pf["pieces"] > 0
+    if case.startswith("chunks"):
+        assert pf["K"] == 5 and pb["K"] >= 5 and pf["tfloats"] == 512 and pf["lds_off"][:5] == [0, 256, 0, 256, 0]
+        assert pf["pieces"] > 0            # chunks >= 2 have no resident pass
+    rows = _emulate_persist2(pf, al)
+    got = np.bincount(vstate, weights=rows * xv, minlength=S_) + al * lprob * xl
+    want = np.bincount(dst, weights=al[src] * prob * x[pdf], minlength=S_)
+    assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    got = _emulate_persist2(pb, be[vstate] * xv) + lprob * xl * be
+    want = np.bincount(src, weights=be[dst] * prob * x[pdf], minlength=S_)
+    assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    # the per-row constants the backward recursion predicts its sums with are those of the first layout
+    p1 = G.debug_persist(0)
+    if p1 is not None:
+        assert np.array_equal(p1["row_leak"], pf["row_leak"]) and np.array_equal(p1["row_psum"], pf["row_psum"])
+
+
 def test_den_graph_internal_state_order_is_invisible():
     """By default the library renumbers the states by in-degree (gather locality); initial_probs() still answers in the
     caller's numbering."""

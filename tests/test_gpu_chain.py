@@ -23,7 +23,9 @@ _KIND = dict(chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_p
 
 
 @pytest.mark.parametrize("path", ["state_x", "general_forced", "arc_pdf", "chain_topology", "multi_entry", "arc_pdf_sx_forced",
-                                  "chain_topology_general", "state_x_frames", "chain_topology_frames", "multi_entry_frames"])
+                                  "chain_topology_general", "state_x_frames", "chain_topology_frames", "multi_entry_frames",
+                                  "chain_topology_persist1", "multi_entry_persist1", "chain_topology_p2stream",
+                                  "multi_entry_p2stream", "chain_topology_p2chunks", "multi_entry_p2chunkstream"])
 @pytest.mark.parametrize("S,A,P,lens,leaky", [
     (8, 30, 5, [6], 1e-2),
     (200, 3000, 40, [51, 17, 33], 1e-4),
@@ -47,6 +49,18 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
     frames = path.endswith("_frames")       # the launch-per-frame state-x kernels (the default is the persistent kernel)
     if frames:
         monkeypatch.setenv("PK2_DEN_PERSIST", "0")
+    # forms of the persistent kernel: the first (everything resident: csrc/chain_den_persist.hip) and variants of the second
+    # (csrc/chain_den_persist2.hip, the default) that these small graphs would not reach by themselves: 1 or 2 register slots
+    # per resident pass (everything else streamed in pieces), an LDS table of 1024 entries (4 - 6 table chunks through two
+    # buffers), both.  The layout variables are read when the graph is created.
+    form = {"persist1": 1, "p2stream": 2, "p2chunks": 2, "p2chunkstream": 2}.get(path.rsplit("_", 1)[-1], 0)
+    if form:
+        monkeypatch.setenv("PK2_DEN_PERSIST", str(form))
+        path, variant = path.rsplit("_", 1)
+        if variant in ("p2stream", "p2chunkstream"):
+            monkeypatch.setenv("PK2_DP2_RES", "1" if variant == "p2stream" else "2")
+        if variant in ("p2chunks", "p2chunkstream"):
+            monkeypatch.setenv("PK2_DP2_TCAP", "1024")
     arc_pdf = path.startswith("arc_pdf")
     g, G, ref = _mk(S, A, P, seed=S, arc_pdf=arc_pdf, **_KIND.get(path.replace("_general", "").replace("_frames", ""), {}))
     if A == 20000:
@@ -58,6 +72,11 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
     if not arc_pdf:             # (a random pdf per arc: the library decides by the number of virtual states)
         want_path = 0 if path in ("general_forced", "chain_topology_general") else (1 if frames else 2)
         assert G.kernel_path(len(lens)) == want_path, (path, G.kernel_path(len(lens)))
+        if want_path == 2:
+            assert G.persist_form(len(lens)) == (form or 2)
+            if form == 2:
+                lay = G.debug_persist2(0)
+                assert ("stream" not in variant or lay["pieces"] > 0) and ("chunk" not in variant or S < 1024 or lay["K"] > 2)
     rng = np.random.default_rng(1)
     T = max(lens)
     lg = rng.normal(0, 3, size=(len(lens), T, P)).astype(np.float32)
