@@ -98,7 +98,7 @@ class DenominatorGraph:
                    ends=np.empty((R, 2, T), np.uint32), first_row=np.empty((R, 2, T), np.int32),
                    uncovered=np.empty((R, 2), np.int32), ncomp=np.empty((R, 2), np.int32), rmap=np.empty((2, rows), np.int16),
                    pbeg=np.empty((R, MC + 1), np.int32),
-                   sprob=np.empty((pieces, SP, T), np.float32), sidx2=np.empty((pieces, SP // 2, T), np.uint32),
+                   sprob=np.empty((pieces, T, SP), np.float32), sidx2=np.empty((pieces, T, SP // 2), np.uint32),
                    sends=np.empty((pieces, T), np.uint32), sfirst_row=np.empty((R, MC, T), np.int32),
                    wcrow=np.empty((R, SEG, W), np.int32), row_begin=np.empty(R + 1, np.int32),
                    grp_begin=np.empty(R + 1, np.int32), row_leak=np.empty(rows, np.float32), row_psum=np.empty(rows, np.float32))

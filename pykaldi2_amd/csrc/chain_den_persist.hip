@@ -597,7 +597,7 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, c
   hipLaunchKernelGGL(den_persist_kernel, dim3(8 * kPR), dim3(kPT), lds, stream, sc.params, sc.ctl);
 #ifdef PK2_DP_PROFILE
   { int tot = 0; for (int n = 0; n < N; ++n) tot += lengths_host[n];
-    hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4)); }   // (rank 0 of every team adds up)
+    hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4), 1); }   // (rank 0 of every team adds up)
 #endif
   PK2_LAUNCH_CHECK();
   if (g_den_persist_state < 0) {     // first use on this device: every recursion done, nobody timed out?

@@ -40,6 +40,7 @@ struct DenPersist2Params {
   int cap;                // LDS row buffers
   int ntasks;
   int fwd_stream, bwd_stream;   // the ordering has streamed pieces (or more than two table chunks)
+  int pspt;                     // 2 or kPSPT: epilogue entries per thread
   short task_seq[kMaxTasks];
   unsigned char task_dir[kMaxTasks];
 };
@@ -112,13 +113,34 @@ __device__ __forceinline__ int dma_chunk(cgfloat* src, CDev2& o, int c, float* t
   }
   return n;
 }
+// The copy of chunk 1, issued from INSIDE pass A.  An LDS-DMA instruction does not retire into a deep queue: a CU moves
+// ~60 KB/us and a wave that issues copies faster than that stalls at the issue (measured: 16 back-to-back instructions per
+// wave take 2.1 us to issue).  So "start both chunks, compute on chunk 0 meanwhile" does not work from one instruction stream
+// -- the stream is stuck issuing until chunk 1 has all but landed.  Instead one copy instruction of chunk 1 is placed after
+// every group of 8 gathers and after every group of 8 multiply-adds of pass A (8 places: 64 rows = 64 KB per workgroup,
+// about what the pass takes to run): each finds room in the queue, and the pass and the copy finish together.
+struct Chunk1Dma {
+  cgfloat* src;      // this lane's 16 bytes of row 0 of chunk 1
+  float* dst;        // LDS address of row 0 of chunk 1
+  int rows, limit;   // rows of the chunk; floats from this lane's address to the (granule-rounded) end of the vector
+  int w;
+  __device__ __forceinline__ void operator()(int j) const {
+    if (j * kPW < rows) {                       // (wave-uniform: every wave copies ceil(rows / kPW) rows, the last one again
+      int row = w + j * kPW;                    //  if it has none of its own -- the counts stay equal across the waves)
+      row = row < rows ? row : rows - 1;
+      const int off = row << 8;
+      if (off < limit) dma256(src + off, dst + off);
+    }
+  }
+};
+struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
 
 // Row sums of NS register slots (slots J0 .. J0+NS-1 of the thread's arrays) over the LDS table into `acc`: complete rows
 // are stored by the lane, the piece before the first row end gets the carry of the earlier lanes (segmented wave scan), the
 // open tail of the wave goes to wcarry[w].  Rows end only after slots ESTEP-1 (mod ESTEP).
-template <int ESTEP, int J0, int NS>
+template <int ESTEP, int J0, int NS, typename DMA>
 __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint32_t ends, int frow,
-                                          const float* table, float* acc, float* wcarry) {
+                                          const float* table, float* acc, float* wcarry, const DMA& dma) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float sum = 0.f;
   int c = frow;
@@ -136,9 +158,10 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
   };
   float a[2][8];
   gather(0, a[0]);
+  dma(0);
 #pragma unroll
   for (int g = 0; g < NS / 8; ++g) {
-    if (g + 1 < NS / 8) gather(8 * (g + 1), a[(g + 1) & 1]);
+    if (g + 1 < NS / 8) { gather(8 * (g + 1), a[(g + 1) & 1]); dma(2 * g + 2); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int jj = 8 * g + j;
@@ -147,6 +170,7 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
         if (__builtin_add_overflow(m, m, &m)) { acc[c] = sum; ++c; sum = 0.f; }
       }
     }
+    dma(2 * g + 1);
   }
   float x[1] = {sum};
   int fl = ends != 0u ? 1 : 0;
@@ -160,33 +184,38 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
   if (ends != 0u) acc[frow] += cin;               // the lane's own first row end (stored above by this lane)
   if (lane == 63) wcarry[w] = x[0];
 }
-template <int J0>
+template <int J0, typename DMA>
 __device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint32_t ends,
-                                              int frow, const float* table, float* acc, float* wcarry) {
+                                              int frow, const float* table, float* acc, float* wcarry, const DMA& dma) {
   switch (estep) {
-    case 8: pass_rows<8, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
-    case 4: pass_rows<4, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
-    case 2: pass_rows<2, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
-    default: pass_rows<1, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry); break;
+    case 8: pass_rows<8, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
+    case 4: pass_rows<4, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
+    case 2: pass_rows<2, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
+    default: pass_rows<1, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
   }
 }
 
-// A streamed piece: kSP slots per thread, read from memory in every frame.  The sums ADD to `acc` (the rows also have slots
-// in a resident pass or in another segment; a barrier separates the segments).
+// A streamed piece: kSP slots per thread, read from memory in every frame (two 16-byte loads of probabilities, one of packed
+// LDS offsets, the row-end bits).  The sums ADD to `acc` (the rows may have slots in other segments; a barrier separates the
+// segments); the value a row end adds to is read from LDS one row end ahead, so the add does not wait for it.
 struct Piece { float prob[kSP]; uint32_t idx2[kSP / 2]; uint32_t ends; };
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4v;
 __device__ __forceinline__ void piece_load(CDev2& o, int piece, Piece& q) {
-  const int tid = threadIdx.x;
-  const __attribute__((address_space(1))) float* sp = (const __attribute__((address_space(1))) float*)o.sprob;
-  const __attribute__((address_space(1))) uint32_t* si = (const __attribute__((address_space(1))) uint32_t*)o.sidx2;
+  const size_t at = (size_t)piece * kPT + threadIdx.x;
+  const __attribute__((address_space(1))) f32x4* sp = (const __attribute__((address_space(1))) f32x4*)o.sprob + at * (kSP / 4);
+  const __attribute__((address_space(1))) u32x4v* si = (const __attribute__((address_space(1))) u32x4v*)o.sidx2 + at;
   const __attribute__((address_space(1))) uint32_t* se = (const __attribute__((address_space(1))) uint32_t*)o.sends;
-#pragma unroll
-  for (int j = 0; j < kSP; ++j) q.prob[j] = sp[((size_t)piece * kSP + j) * kPT + tid];
-#pragma unroll
-  for (int j = 0; j < kSP / 2; ++j) q.idx2[j] = si[((size_t)piece * (kSP / 2) + j) * kPT + tid];
-  q.ends = se[(size_t)piece * kPT + tid];
+  static_assert(kSP == 8, "a piece is two float4 of probabilities and one uint4 of packed offsets per thread");
+  const f32x4 p0 = sp[0], p1 = sp[1];
+  const u32x4v ix = si[0];
+  q.prob[0] = p0.x; q.prob[1] = p0.y; q.prob[2] = p0.z; q.prob[3] = p0.w;
+  q.prob[4] = p1.x; q.prob[5] = p1.y; q.prob[6] = p1.z; q.prob[7] = p1.w;
+  q.idx2[0] = ix.x; q.idx2[1] = ix.y; q.idx2[2] = ix.z; q.idx2[3] = ix.w;
+  q.ends = se[at];
 }
 template <int ESTEP>
-__device__ __forceinline__ void piece_rows(const Piece& q, const float* table, float* acc, float& sum, int& c) {
+__device__ __forceinline__ void piece_rows(const Piece& q, const float* table, float* acc, float& sum, int& c, float& old) {
   uint32_t packed = 0;
 #pragma unroll
   for (int k = 0; k < kSP / ESTEP; ++k) packed |= ((q.ends >> (k * ESTEP + ESTEP - 1)) & 1u) << k;
@@ -202,22 +231,21 @@ __device__ __forceinline__ void piece_rows(const Piece& q, const float* table, f
   for (int j = 0; j < kSP; ++j) {
     sum = fmaf(a[j], q.prob[j], sum);
     if ((j + 1) % ESTEP == 0) {
-      if (__builtin_add_overflow(m, m, &m)) { acc[c] += sum; ++c; sum = 0.f; }
+      if (__builtin_add_overflow(m, m, &m)) { acc[c] = old + sum; ++c; sum = 0.f; old = acc[c]; }
     }
   }
 }
-__device__ __forceinline__ void piece_rows_any(int estep, const Piece& q, const float* table, float* acc, float& sum, int& c) {
+__device__ __forceinline__ void piece_rows_any(int estep, const Piece& q, const float* table, float* acc, float& sum, int& c, float& old) {
   switch (estep) {
-    case 8: piece_rows<8>(q, table, acc, sum, c); break;
-    case 4: piece_rows<4>(q, table, acc, sum, c); break;
-    case 2: piece_rows<2>(q, table, acc, sum, c); break;
-    default: piece_rows<1>(q, table, acc, sum, c); break;
+    case 8: piece_rows<8>(q, table, acc, sum, c, old); break;
+    case 4: piece_rows<4>(q, table, acc, sum, c, old); break;
+    case 2: piece_rows<2>(q, table, acc, sum, c, old); break;
+    default: piece_rows<1>(q, table, acc, sum, c, old); break;
   }
 }
 
 // The streamed segment of chunk c: pieces [p0, p1) of this rank; `cur` holds piece p0 already (prefetched), on return it
-// holds piece p1 if that exists (p1 < pend: the first piece of the next segment, or of the next frame's first segment when
-// the caller wraps around).
+// holds the piece the thread needs next (the first of the next segment, or -- wrapping around -- of the next frame).
 __device__ __forceinline__ void streamed_segment(CDev2& o, int rank, int c, int p0, int p1, int pnext_valid, int pwrap, Piece& cur,
                                                  const Lds2& L) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -226,12 +254,13 @@ __device__ __forceinline__ void streamed_segment(CDev2& o, int rank, int c, int 
   float sum = 0.f;
   int cc = frow;
   uint32_t had = 0;
+  float old = L.accS[frow];
   for (int p = p0; p < p1; ++p) {
     Piece nxt;
     const int pn = p + 1 < p1 ? p + 1 : (pnext_valid ? p1 : pwrap);      // what the thread will need next
     piece_load(o, pn, nxt);
     had |= cur.ends;
-    piece_rows_any(o.estep, cur, L.table, L.accS, sum, cc);
+    piece_rows_any(o.estep, cur, L.table, L.accS, sum, cc, old);
     cur = nxt;
   }
   float x[1] = {sum};
@@ -257,9 +286,12 @@ struct FrameRegs {
 struct StreamState { Piece cur; int pb[kMaxChunks + 1]; };
 struct NoStream { };
 struct RowSpan { int nrows, uncA, ncA, uncB, ncB; };
-template <bool STREAM, typename ST>
+// `stage`: the caller's LDS staging of values it prefetched from memory (x of own rows).  It runs behind the wait for chunk 1,
+// where every older memory operation has completed anyway: placed before the copies, the wait for those prefetches -- and
+// with it, vmcnt being in order, for the previous frame's history stores -- would delay the copies.
+template <bool STREAM, typename ST, typename STAGE>
 __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, const RowSpan& rs, const FrameRegs& r,
-                                           ST& st, const Lds2& L) {
+                                           ST& st, const Lds2& L, DpTimers& dp_, STAGE stage) {
   const int tid = threadIdx.x;
   if constexpr (STREAM) {
     // the streamed segments add up in accS; compact rows past a truncated resident list get no store from their pass
@@ -268,19 +300,31 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     for (int q = rs.uncB + tid; q < rs.ncB; q += kPT) L.accB[q] = 0.f;
   }
   dma_chunk(src, o, 0, L.table);
-  const int n1 = dma_chunk(src, o, 1, L.table);
-  wait_vm(n1);                           // chunk 0 has landed (this wave's part); chunk 1 may still be in flight
-  lds_only_barrier();                    // (__syncthreads() would wait for chunk 1 as well: it is vmcnt(0) + s_barrier)
-  pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry);
+  DP_T(0);
+  wait_vm(0);                            // chunk 0 has landed (this wave's part)
+  lds_only_barrier();
+  DP_T(1);
+  DP_TLF(2);
+  Chunk1Dma c1;
+  {
+    const int lane = tid & 63, b1 = o.cbeg[1], e1 = o.cbeg[2];
+    c1.src = src + b1 + lane * 4; c1.dst = L.table + o.lds_off[1];
+    c1.rows = (e1 - b1 + 255) >> 8; c1.limit = ((e1 + 3) & ~3) - b1 - lane * 4; c1.w = tid >> 6;
+  }
+  pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry, c1);
+  for (int j = 8; j * kPW < c1.rows; ++j) c1(j);     // (a chunk 1 of more than 64 rows: the rest, stalling at the issue)
+  DP_T(2);
+  DP_TLF(3);
   if constexpr (STREAM) {
     const int (&pb)[kMaxChunks + 1] = st.pb;
     const int K = o.K;
     const int pfirst = pb[0], pend = pb[K];
     if (pb[1] > pb[0]) streamed_segment(o, rank, 0, pb[0], pb[1], pb[1] < pend, pfirst, st.cur, L);
     wait_vm(0);
+    stage();
     __syncthreads();                       // chunk 1 is complete, and buffer 0 is free
     if (K > 2) dma_chunk(src, o, 2, L.table);
-    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW);
+    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW, NoDma());
     // (consecutive segments add to the same rows of accS: the barrier between two chunks separates them)
     if (pb[2] > pb[1]) streamed_segment(o, rank, 1, pb[1], pb[2], pb[2] < pend, pfirst, st.cur, L);
     for (int c = 2; c < K; ++c) {
@@ -291,9 +335,12 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     }
   } else {
     wait_vm(0);
+    stage();
     __syncthreads();                       // chunk 1 is complete
-    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW);
+    DP_T(3);
+    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW, NoDma());
   }
+  DP_T(4);
 }
 
 // Value of rank-local row q after the frame's passes: its entries in the two compact row arrays (and the streamed one) plus
@@ -336,7 +383,7 @@ __device__ __forceinline__ void load_frame_regs(CDev2& o, int rank, FrameRegs& r
 }
 
 // alpha recursion of sequence g (T frames).
-template <bool STREAM>
+template <bool STREAM, int PSPT>
 __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
                                       unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
   CParams2* pp = uni(pp_);
@@ -366,9 +413,9 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   }
   for (int r = tid; r < nrows; r += kPT) L.leak[r] = o.row_leak[row0 + r];
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
-  int st_lo[kPSPT], st_hi[kPSPT], st_o[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
+  int st_lo[PSPT], st_hi[PSPT], st_o[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) {
+  for (int i = 0; i < PSPT; ++i) {
     const int r = tid + i * kPT;
     st_ok[i] = r < ngrp;
     st_lo[i] = st_hi[i] = st_o[i] = 0; st_pl[i] = st_pi[i] = 0.f;
@@ -386,17 +433,17 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     const int q = L.wcrow[k];
     bool mine = false;
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) mine = mine || (st_ok[i] && q >= st_lo[i] && q < st_hi[i]);
+    for (int i = 0; i < PSPT; ++i) mine = mine || (st_ok[i] && q >= st_lo[i] && q < st_hi[i]);
     if (q >= 0 && mine) cmask |= 1ull << k;
   }
 
   const size_t f0 = (size_t)g * (d.Tmax + 1);
   cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
   cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
-  float xr[kPSPT], xlr[kPSPT];
+  float xr[PSPT], xlr[PSPT];
   auto prefetch = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
       xr[i] = r < nrows ? xv_g[(size_t)t * V + row0 + r] : 0.f;
       xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + g0 + r] : 0.f;
@@ -406,15 +453,16 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   if constexpr (STREAM) {
     if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
   }
-  float own_a[kPSPT];
+  float own_a[PSPT];
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) own_a[i] = st_pi[i];          // alpha[0, .] = pi
+  for (int i = 0; i < PSPT; ++i) own_a[i] = st_pi[i];          // alpha[0, .] = pi
   Spin spin(ctl);
   DP_T0();
   for (int t = 0; t < T; ++t) {
     float as;
     cgfloat* src;
     DP_TL(0, 0);
+    DP_TLSET(0);
     if (t == 0) {
       as = d.pi_sum;
       src = G(d.pi);
@@ -430,29 +478,23 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     // copies (no store sits between them and their waits), long before the stores it has to precede
     const bool publish = t + 1 < T;
     if (tid == 0 && publish) st_agent(word_of(pring, t + 2, rank, 0), __uint_as_float(kRingSentinel));
+    frame_rows<STREAM>(o, src, rank, rs, fr, st, L, dp_, [&]() {
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
-      const int r = tid + i * kPT;
-      if (r < nrows) L.xown[r] = xr[i];
-    }
-    DP_T(0);
-    // Every prefetched value is "used" here on all paths: the compiler then waits for those loads HERE, not -- because one of
-    // their registers gets reused behind a branch that skipped the use -- between the two table copies of frame_rows.
-#pragma unroll
-    for (int i = 0; i < kPSPT; ++i) asm volatile("" :: "v"(xr[i]), "v"(xlr[i]));
-    frame_rows<STREAM>(o, src, rank, rs, fr, st, L);
-    DP_T(2);
+      for (int i = 0; i < PSPT; ++i) {
+        const int r = tid + i * kPT;
+        if (r < nrows) L.xown[r] = xr[i];
+      }
+    });
     DP_TL(0, 4);
     __syncthreads();
-    DP_T(3);
     if (rank == 0 && tid == 0) G(d.asum)[f0 + t] = as;
     const float lk = d.leaky * as, inv_as = 1.0f / as;
     // rows are virtual states (dst, pdf); a thread per real state sums its rows and adds the peeled self-loop.  First
     // only what the other workgroups wait for: the ring entries, then (once they are in L2) the partial sum.
     gfloat* ring_n = ring + (size_t)((t + 1) & 1) * p.rpad;
-    float outv[kPSPT], loopv[kPSPT], loc = 0.f, unused = 0.f;
+    float outv[PSPT], loopv[PSPT], loc = 0.f, unused = 0.f;
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       outv[i] = 0.f; loopv[i] = 0.f;
       if (!st_ok[i]) continue;
       float sum = 0.f;
@@ -467,19 +509,19 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
       own_a[i] = sum;          // alpha[t+1] of the own state: the next frame's loop term
       loc += sum;
     }
-    DP_T(4);
+    DP_T(5);
     DP_TL(0, 5);
     wait_stores();        // this rank's slice of frame t+1 (and the reset above) is in L2 before its partial sum says so
     block_sum2<kPW>(loc, unused, L.red);
     if (tid == 0 && publish) st_agent(word_of(pring, t + 1, rank, 0), loc);
-    DP_T(5);
+    DP_T(6);
     DP_TL(0, 6);
     // the history the parallel passes read (nobody waits for these stores)
     gfloat* alpha_n = G(d.alpha) + (f0 + t + 1) * (size_t)S;
     gfloat* alphav_n = G(d.alphav) + (f0 + t + 1) * (size_t)Vo;
     if (tid == 0) G(d.apart)[(f0 + t + 1) * kPR + rank] = loc;
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       if (!st_ok[i]) continue;
       alpha_n[g0 + tid + i * kPT] = outv[i];
       if (sep) {
@@ -488,13 +530,13 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
       }
     }
     if (publish) prefetch(t + 1);
-    DP_T(6);
+    DP_T(7);
   }
   DP_FLUSH(0);
 }
 
 // btilde' recursion of sequence g, T-1 down to 0 (see chain_den_persist.hip: run_bwd for the algebra).
-template <bool STREAM>
+template <bool STREAM, int PSPT>
 __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPersistCtl::Team* team_,
                                       unsigned* nbar, int g_, int T_, int rank_, float* ring_, float* pring_) {
   CParams2* pp = uni(pp_);
@@ -522,9 +564,9 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
   }
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
-  int st_v0[kPSPT], st_v1[kPSPT]; float st_pl[kPSPT], st_pi[kPSPT]; bool st_ok[kPSPT];
+  int st_v0[PSPT], st_v1[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) {
+  for (int i = 0; i < PSPT; ++i) {
     const int r = tid + i * kPT;
     st_ok[i] = r < nrows;
     st_v0[i] = st_v1[i] = 0; st_pl[i] = st_pi[i] = 0.f;
@@ -542,20 +584,20 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     const int q = L.wcrow[k];
     bool mine = false;
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) mine = mine || (st_ok[i] && q == tid + i * kPT);
+    for (int i = 0; i < PSPT; ++i) mine = mine || (st_ok[i] && q == tid + i * kPT);
     if (q >= 0 && mine) cmask |= 1ull << k;
   }
 
   const size_t f0 = (size_t)g * (d.Tmax + 1);
   cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
   cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
-  float xl_cur[kPSPT], xl_prev[kPSPT], xw[kPSPT], bh[kPSPT];
+  float xl_cur[PSPT], xl_prev[PSPT], xw[PSPT], bh[PSPT];
   const float cst_last = 1.0f / d.pi_sum + d.leaky;
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) { bh[i] = cst_last; xl_cur[i] = 0.f; }
+  for (int i = 0; i < PSPT; ++i) { bh[i] = cst_last; xl_cur[i] = 0.f; }
   auto prefetch = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
       xl_prev[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
       xw[i] = r < nvirt ? xv_g[(size_t)t * V + vfirst + r] : 0.f;
@@ -563,7 +605,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   };
   auto stage_x = [&]() {
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
       if (r < nvirt) L.xown[r] = xw[i];
     }
@@ -572,7 +614,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     gfloat* ring_n = ring + (size_t)(t & 1) * p.rpad + vfirst;
     float pB = 0.f, pU = 0.f;
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       if (!st_ok[i]) continue;
       for (int q = st_v0[i]; q < st_v1[i]; ++q) {
         const float w = L.xown[q] * bh[i];
@@ -595,7 +637,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   __syncthreads();
   emit(T);
 #pragma unroll
-  for (int i = 0; i < kPSPT; ++i) xl_cur[i] = xl_prev[i];
+  for (int i = 0; i < PSPT; ++i) xl_cur[i] = xl_prev[i];
   if (T >= 2) prefetch(T - 2);
   if constexpr (STREAM) {
     if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
@@ -604,6 +646,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   DP_T0();
   for (int t = T - 1; t >= 0; --t) {
     DP_TL(1, 0);
+    DP_TLSET(1);
     poll_words(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 0, 2, spin, L);
     __syncthreads();
     DP_TL(1, 1);
@@ -613,22 +656,16 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     // the words this rank will publish two frames from now must read "not yet written" by then: reset here, before the
     // copies, long before the stores they have to precede (the waits of emit cover it)
     if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
-    if (publish) stage_x();
-    DP_T(0);
-#pragma unroll
-    for (int i = 0; i < kPSPT; ++i) asm volatile("" :: "v"(xl_prev[i]), "v"(xw[i]));      // (see run_fwd2)
-    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, st, L);
-    DP_T(2);
+    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, st, L, dp_, [&]() { if (publish) stage_x(); });
     DP_TL(1, 4);
     __syncthreads();
-    DP_T(3);
     // rows are source states: btilde'[t, s] = row + peeled loop, then beta-hat[t, s] with the sums received above
     const float cu = lB + d.wu * lU;
     const float inv_c = cu > 0.f ? 1.0f / cu : 0.f;
     const float lkr = d.leaky * lB * inv_c;
-    float vs[kPSPT];
+    float vs[PSPT];
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       vs[i] = 0.f;
       if (!st_ok[i]) continue;
       float v = row_val<STREAM>(L, cmask, tid + i * kPT);
@@ -636,19 +673,19 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
       vs[i] = v;
       bh[i] = v * inv_c + lkr;
     }
-    DP_T(4);
+    DP_T(5);
     DP_TL(1, 5);
     if (publish) emit(t);
-    DP_T(5);
+    DP_T(6);
     DP_TL(1, 6);
     gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
 #pragma unroll
-    for (int i = 0; i < kPSPT; ++i) {
+    for (int i = 0; i < PSPT; ++i) {
       if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
       xl_cur[i] = xl_prev[i];
     }
     if (t >= 2) prefetch(t - 2);
-    DP_T(6);
+    DP_T(7);
   }
   DP_FLUSH(1);
 }
@@ -695,12 +732,14 @@ __global__ void __launch_bounds__(kPT) den_persist2_kernel(const DenPersist2Para
     if (s_abort || k >= p.ntasks) return;
     const int g = p.task_seq[k], T = p.d.lengths[g];
     if (!team_barrier(ctl, team, &nbar, &s_abort)) return;      // everybody has left the previous recursion
+    // (PSPT: rows / states / own virtual states a thread handles in the row epilogues -- 2 when no rank has more than
+    // 2 * kPT of any of them: the per-state constants then take half the registers)
     if (p.task_dir[k] == 0) {
-      if (p.fwd_stream) run_fwd2<true>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
-      else run_fwd2<false>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+      if (p.fwd_stream) { if (p.pspt == 2) run_fwd2<true, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_fwd2<true, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
+      else { if (p.pspt == 2) run_fwd2<false, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_fwd2<false, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
     } else {
-      if (p.bwd_stream) run_bwd2<true>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
-      else run_bwd2<false>(pp, ctl, team, &nbar, g, T, rank, ring, pring);
+      if (p.bwd_stream) { if (p.pspt == 2) run_bwd2<true, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_bwd2<true, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
+      else { if (p.pspt == 2) run_bwd2<false, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_bwd2<false, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
     }
     __syncthreads();
     if (s_abort) return;
@@ -771,6 +810,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   p.fwd = g->p2fwd; p.bwd = g->p2bwd;
   p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
   p.rpad = rpad; p.tfloats = den2_tfloats(g); p.cap = g->p2_cap;
+  p.pspt = g->p2_cap <= 2 * kPT ? 2 : kPSPT;
   p.fwd_stream = (!g->h_p2fwd.sends.empty() || g->h_p2fwd.K > 2) ? 1 : 0;
   p.bwd_stream = (!g->h_p2bwd.sends.empty() || g->h_p2bwd.K > 2) ? 1 : 0;
   std::vector<std::pair<int, int>> order;    // (-T, task id = 2 n + dir), longest first
@@ -794,7 +834,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   hipLaunchKernelGGL(den_persist2_kernel, dim3(8 * kPR), dim3(kPT), lds, stream, sc.params, sc.ctl);
 #ifdef PK2_DP_PROFILE
   { int tot = 0; for (int n = 0; n < N; ++n) tot += lengths_host[n];
-    hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4)); }
+    hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4), 2); }
 #endif
   PK2_LAUNCH_CHECK();
   if (g_den_persist2_state < 0) {     // first use on this device: every recursion done, nobody timed out?

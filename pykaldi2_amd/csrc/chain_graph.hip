@@ -318,7 +318,7 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
 // ---- second persistent layout (chain_internal.h: HostPersist2; kernel: chain_den_persist2.hip) ----------------------------
 // Contiguous ranges of whole groups for the kPR ranks, balanced by arcs (+1 per row: every row costs a slot in every list).
 static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const int32_t* group_of_row, int num_groups,
-                            HostPersist2* out) {
+                            int max_rows_per_rank, HostPersist2* out) {
   std::vector<int64_t> rarcs(num_rows, 0);
   for (int64_t i = 0; i < A; ++i) rarcs[key[i]]++;
   std::vector<int32_t> grow(num_groups + 1, 0);
@@ -346,7 +346,7 @@ static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const i
     int64_t have = 0; int rows = 0, groups = 0;
     while (g < num_groups) {
       const int gr = grow[g + 1] - grow[g];
-      if (rows + gr > kPMaxRows || groups + 1 > kPMaxRows) break;
+      if (rows + gr > max_rows_per_rank || groups + 1 > max_rows_per_rank) break;
       if (have >= target) break;
       have += gcost[g]; rows += gr; ++groups; ++g;
     }
@@ -358,19 +358,21 @@ static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const i
 }
 
 // Table chunks of an ordering whose vector has R entries, for an LDS table of `tcap` floats (a multiple of 512).
-static bool persist2_chunks(int64_t A, const int32_t* idx, int R, int tcap, HostPersist2* out) {
+static bool persist2_chunks(int64_t A, const int32_t* idx, int R, int num_rows, int tcap, HostPersist2* out) {
   out->R = R;
   const int rpad = (R + 255) / 256 * 256;
   if (rpad <= tcap) {
-    // Back to back.  Pass A may only gather from chunk 0 (chunk 1 is still arriving), pass B from both, so the lists can be
-    // balanced per rank as long as a little more than half of the gathers are eligible for pass A: the boundary is where 55 %
-    // of the gathers lie below it, at least one 1 KB row, and -- when the vector has two rows -- not the whole vector
-    // unless the gathers demand it.
-    std::vector<int64_t> cnt(rpad / 256, 0);
+    // Back to back.  Pass A may only gather from chunk 0 (chunk 1 is copied while it runs), pass B from both, so arcs into
+    // chunk 0 can go to either list.  Chunk 0's copy is exposed, chunk 1's hides behind pass A: chunk 1 as large as pass A can
+    // carry (64 rows: one copy instruction per wave at each of its 8 issue places), chunk 0 at least large enough that list
+    // B is left with no more than its register slots (0.94 of them: rows are padded) -- and at least one row.
+    const int trows = rpad / 256;
+    std::vector<int64_t> cnt(trows, 0);
     for (int64_t i = 0; i < A; ++i) cnt[idx[i] / 256]++;
+    const double need = std::max(0.02, 1.0 - 0.94 * (double)kPR * kQ * kPT / ((double)A + 0.5 * num_rows));
     int b = 0; int64_t below = 0;
-    while (b < rpad / 256 && 100 * below < 55 * A) below += cnt[b++];
-    b = std::max(1, b);
+    while (b < trows && (double)below < need * (double)A) below += cnt[b++];
+    b = std::max({1, b, trows - 64});
     out->K = 2;
     out->cbeg[0] = 0; out->cbeg[1] = std::min(R, b * 256); out->cbeg[2] = R;
     out->lds_off[0] = 0; out->lds_off[1] = b * 256;
@@ -602,8 +604,8 @@ static bool persist2_lists(int64_t A, int num_rows, const float* prob, const flo
             const int64_t s2 = (int64_t)tid * spt + p;
             if (s2 >= ns) break;
             const int piece = npieces + p / kSP, j = p % kSP;
-            out->sprob[((size_t)piece * kSP + j) * kPT + tid] = rarc[s2] >= 0 ? prob[rarc[s2]] : 0.f;
-            uint32_t& w2 = out->sidx2[((size_t)piece * (kSP / 2) + j / 2) * kPT + tid];
+            out->sprob[((size_t)piece * kPT + tid) * kSP + j] = rarc[s2] >= 0 ? prob[rarc[s2]] : 0.f;
+            uint32_t& w2 = out->sidx2[((size_t)piece * kPT + tid) * (kSP / 2) + j / 2];
             w2 = (w2 & ~(0xffffu << (16 * (j & 1)))) | ((uint32_t)sidx[s2] << (16 * (j & 1)));
             if (rend[s2]) out->sends[(size_t)piece * kPT + tid] |= 1u << j;
           }
@@ -634,17 +636,24 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
   f = HostPersist2(); b = HostPersist2();
   g->p2_cap = 0;
   const int S = g->S, V = g->V;
-  if (V >= 65536 || S >= 65536) return;
-  if (!persist2_assign(A2, V, arc_v, vstate, S, &f)) return;
-  if (!persist2_assign(A2, S, src2, nullptr, S, &b)) return;
-  // the backward workgroups also stage x for their own virtual states: max_groups = how many
-  b.max_groups = 0;
-  for (int r = 0; r < kPR; ++r) b.max_groups = std::max(b.max_groups, g->voff[b.row_begin[r + 1]] - g->voff[b.row_begin[r]]);
-  if (b.max_groups > kPMaxRows) return;
+  if (V >= 65536 || S >= 65536) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); return; }
+  // Rows per rank: at most 2 * kPT when that is possible (the row epilogues then handle two entries per thread and keep half
+  // the per-state constants in registers; the passes cost the same however full their slots are), else up to kPMaxRows.
+  bool assigned = false;
+  for (int lim : {2 * kPT, kPMaxRows}) {
+    if (!persist2_assign(A2, V, arc_v, vstate, S, lim, &f) || !persist2_assign(A2, S, src2, nullptr, S, lim, &b)) continue;
+    // the backward workgroups also stage x for their own virtual states: max_groups = how many
+    b.max_groups = 0;
+    for (int r = 0; r < kPR; ++r) b.max_groups = std::max(b.max_groups, g->voff[b.row_begin[r + 1]] - g->voff[b.row_begin[r]]);
+    if (b.max_groups > lim) continue;
+    assigned = true;
+    break;
+  }
+  if (!assigned) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); return; }
   const int cap = (std::max({f.max_rows, f.max_groups, b.max_rows, b.max_groups, 1}) + 3) / 4 * 4;
   int64_t tcap = ((int64_t)kDenPersistMaxLds / 4 - kP2RowArrays * (int64_t)cap - kP2FixedFloats) / 512 * 512;
   if (const char* env = getenv("PK2_DP2_TCAP")) tcap = std::min<int64_t>(tcap, std::max(512, atoi(env) / 512 * 512));
-  if (tcap < 512) return;
+  if (tcap < 512) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); return; }
   int res = kQ;
   if (const char* env = getenv("PK2_DP2_RES")) res = std::max(1, std::min(kQ, atoi(env)));     // (tests: force streaming)
   const char* env_e = getenv("PK2_DEN_ESTEP");
@@ -657,7 +666,7 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
     const int rows = which == 0 ? V : S, R = which == 0 ? S : V;
     const int32_t* key = which == 0 ? arc_v : src2;
     const int32_t* idx = which == 0 ? src2 : arc_v;
-    if (!persist2_chunks(A2, idx, R, (int)tcap, &h)) { f.ok = b.ok = false; return; }
+    if (!persist2_chunks(A2, idx, R, rows, (int)tcap, &h)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
     std::vector<int64_t> ptr(rows + 1, 0);
     for (int64_t i = 0; i < A2; ++i) ptr[key[i] + 1]++;
     for (int r = 0; r < rows; ++r) ptr[r + 1] += ptr[r];
@@ -673,15 +682,15 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
       if ((forced > 0 && estep != forced) || res % estep != 0) continue;      // (a cut must fall between whole rows' slots)
       HostPersist2 cand = h;
       if (!persist2_arc_lists(A2, idx, cand, estep, ptr, perm, &list_of, &lidx) ||
-          !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, estep, res, &cand)) { f.ok = b.ok = false; return; }
+          !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, estep, res, &cand)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
       const double cost = arcs_us(estep) + 0.6 * cand.max_pieces + (cand.max_pieces ? 0.3 : 0.0);
       if (cost < best_cost) { best_cost = cost; best_h = std::move(cand); }
       if (best_h.max_pieces == 0 && best_h.K == 2) break;
     }
-    if (best_cost > 1e29) { f.ok = b.ok = false; return; }
+    if (best_cost > 1e29) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
     h = std::move(best_h);
   }
-  if (!(f.ok && b.ok)) { f.ok = b.ok = false; return; }
+  if (!(f.ok && b.ok)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
   g->p2_cap = cap;
 }
 
@@ -823,17 +832,18 @@ static int build_graph_ordered(int32_t S, int32_t P, int64_t A, const int32_t* s
   return PK2_OK;
 }
 
-// State numbering: the persistent kernel (chain_den_persist.hip) gathers from LDS and only needs the rows of its 32
-// workgroups balanced, which the caller's numbering gives for any graph without a degree trend along the state ids; the
-// launch-per-frame kernels gather from L2 and gain from the in-degree order.  So: the caller's numbering when the
-// persistent layouts fit with it, else the in-degree order.  PK2_DEN_ORDER = none | indegree | degree forces one.
+// State numbering: the persistent kernels gather from LDS and only need the rows of their 32 workgroups balanced, which the
+// caller's numbering gives for any graph without a degree trend along the state ids (the in-degree order does the opposite:
+// its last workgroups would own thousands of rows); the launch-per-frame kernels gather from L2 and gain from the in-degree
+// order.  So: the caller's numbering when a persistent layout fits with it, else the in-degree order.
+// PK2_DEN_ORDER = none | indegree | degree forces one.
 static int build_graph(int32_t S, int32_t P, int64_t A, const int32_t* src_in, const int32_t* dst_in,
                        const int32_t* pdf, const float* prob, int32_t start, pk2_den_graph** out) {
   const char* env = getenv("PK2_DEN_ORDER");
   if (env) return build_graph_ordered(S, P, A, src_in, dst_in, pdf, prob, start, env, out);
   int rc = build_graph_ordered(S, P, A, src_in, dst_in, pdf, prob, start, "none", out);
   if (rc) return rc;
-  if (den_persist_fits(*out)) return PK2_OK;
+  if (den_persist_fits(*out) || den_persist2_fits(*out)) return PK2_OK;
   delete *out;
   *out = nullptr;
   return build_graph_ordered(S, P, A, src_in, dst_in, pdf, prob, start, "indegree", out);

@@ -125,7 +125,7 @@ struct DevPersist {
 //  * Pass A and pass B sum into their own compact LDS row arrays (plain stores, one per row), the streamed segments add into
 //    a third, row-indexed one; the row epilogue adds them up together with the wave carry-outs of every segment.
 constexpr int kQ = kPK / 2;             // register slots per thread of one resident pass
-constexpr int kSP = 16;                 // slots per thread of a streamed piece
+constexpr int kSP = 8;                  // slots per thread of a streamed piece
 constexpr int kMaxChunks = 6;
 constexpr int kSegs = 2 + kMaxChunks;   // row-sum segments of a frame: pass A, pass B, streamed segment of chunk 0 .. K-1
 struct HostPersist2 {
@@ -148,8 +148,8 @@ struct HostPersist2 {
   std::vector<int32_t> ncomp;            // [r*2 + pass] rows of the rank that have a slot in list `pass` (its compact rows)
   std::vector<int16_t> rmap;             // [pass*rows + row] compact index of a row in list `pass` of its rank, -1 = absent
   std::vector<int32_t> pbeg;             // [r*(kMaxChunks+1) + c] pieces of rank r, chunk c: [pbeg[c], pbeg[c+1]) (global ids)
-  std::vector<float> sprob;              // [(piece*kSP + j)*kPT + tid]
-  std::vector<uint32_t> sidx2;           // [(piece*kSP/2 + j/2)*kPT + tid]
+  std::vector<float> sprob;              // [(piece*kPT + tid)*kSP + j]      (a thread reads its piece with two 16-byte loads)
+  std::vector<uint32_t> sidx2;           // [(piece*kPT + tid)*kSP/2 + j/2]
   std::vector<uint32_t> sends;           // [piece*kPT + tid] bit j (< kSP): a row ends after slot j of the piece
   std::vector<int32_t> sfirst_row;       // [(r*kMaxChunks + c)*kPT + tid]
   std::vector<int32_t> wcrow;            // [(r*kSegs + seg)*kPW + w] rank-local row open after the last slot of wave w (-1: none)

@@ -354,7 +354,7 @@ def _emulate_persist2(lay, table):
                     e = int(lay["sends"][p, tid])
                     assert all((j + 1) % lay["estep"] == 0 for j in range(SP) if (e >> j) & 1)
                     for j in range(SP):
-                        sm += lds[idx_of(lay["sidx2"][p], j, tid)] * float(lay["sprob"][p, j, tid])
+                        sm += lds[(int(lay["sidx2"][p, tid, j // 2]) >> (16 * (j & 1))) & 0xffff] * float(lay["sprob"][p, tid, j])
                         if (e >> j) & 1:
                             accS[cc] += sm; cc += 1; sm = 0.0
                     had = had or e != 0

@@ -76,7 +76,8 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
             assert G.persist_form(len(lens)) == (form or 2)
             if form == 2:
                 lay = G.debug_persist2(0)
-                assert ("stream" not in variant or lay["pieces"] > 0) and ("chunk" not in variant or S < 1024 or lay["K"] > 2)
+                # (1 register slot per pass = 512 slots per workgroup: only the 60000-arc graph overflows them)
+                assert ("stream" not in variant or A < 60000 or lay["pieces"] > 0) and ("chunk" not in variant or S < 1024 or lay["K"] > 2)
     rng = np.random.default_rng(1)
     T = max(lens)
     lg = rng.normal(0, 3, size=(len(lens), T, P)).astype(np.float32)
