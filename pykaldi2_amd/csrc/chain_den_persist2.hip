@@ -776,8 +776,9 @@ static bool den_is_8x32() {
   return cus == 8 * kPR;
 }
 
-// Which form runs: the forced one if it fits; by default the second form (it takes every graph the first takes and overlaps
-// the table copy), the first only when PK2_DEN_PERSIST=1 asks for it.
+// Which form runs: the forced one if it fits; else the second form whenever the whole graph is resident in it (it takes
+// every graph the first form takes and is a little faster); when it has to stream pieces or rotate table chunks, whichever of
+// it and the launch-per-frame kernels the measured cost model (profiles/r03_den_sweep.txt) predicts to be faster.
 int den_persist_version(const pk2_den_graph* g, int N) {
   const char* env = getenv("PK2_DEN_PERSIST");
   const int want = env ? atoi(env) : -1;
@@ -786,7 +787,19 @@ int den_persist_version(const pk2_den_graph* g, int N) {
   const bool ok2 = g_den_persist2_state != 0 && den_persist2_fits(g);
   if (want == 1) return ok1 ? 1 : 0;
   if (want == 2) return ok2 ? 2 : 0;
-  return ok2 ? 2 : (ok1 ? 1 : 0);
+  if (!ok2) return ok1 ? 1 : 0;
+  const HostPersist2& f = g->h_p2fwd; const HostPersist2& b = g->h_p2bwd;
+  const int pieces = std::max(f.max_pieces, b.max_pieces), K = std::max(f.K, b.K);
+  if (pieces == 0 && K == 2) return 2;
+  // microseconds per frame, fitted to the sweep: the streaming frame grows with the vector (table copy, row epilogues,
+  // the row-indexed sums of the segments) and by ~0.9 per streamed piece of 4096 slots; the frame kernels stream both arc
+  // lists once per frame for up to 4 sequences at a time
+  const double S = (double)g->S * 1e-3, A = (double)g->A * 1e-6;
+  const double us2 = 5.2 + 0.26 * S + 0.9 * pieces;
+  const double usf = 6.0 + 0.12 * S + 10.5 * A;
+  // 2 N recursions on 8 XCDs (each sequence's two recursions side by side) against ceil(N / 4) groups of frame launches
+  const double t2 = us2 * std::max(1.0, 2.0 * N / 8.0), tf = usf * ((N + 3) / 4);
+  return t2 <= tf ? 2 : (ok1 ? 1 : 0);
 }
 
 int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, const int32_t* lengths_host, int N,

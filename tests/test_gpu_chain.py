@@ -304,3 +304,36 @@ def test_bench_size_objective_with_alignment_built_supervisions_matches_c_oracle
     assert np.abs(got[0] - want_out[0]).max() <= 1e-3 * np.abs(want_out[0]).max(), (got[0], want_out[0])
     assert abs(got[0].sum() - want_out[0].sum()) <= 1e-3 * abs(want_out[0].sum())
     assert np.abs(grad.cpu().numpy() - want_grad).max() < 1e-4
+
+
+def test_graph_beyond_the_register_slots_streams_its_overflow():
+    """A graph with more arcs than the ~1.05 M register slots of a team (no capacity cliff): the persistent
+    kernel keeps 2 x 32 slots per thread resident and streams the rest in pieces (csrc/chain_den_persist2.hip) instead of
+    falling to the launch-per-frame kernels.  S = 3000, A = 1.3 M, P = 600, three ragged sequences, against the float64
+    C oracle and against the frame kernels."""
+    from oracle import chain_c
+    S, A, P = 3000, 1300000, 600
+    g = synth.den_graph_arcs(S, A, P, seed=11, loop_pdf_differs=True, multi_entry_frac=0.1)
+    G = chain.DenominatorGraph(g, P)
+    lens = [41, 17, 30]
+    assert G.kernel_path(len(lens)) == 2 and G.persist_form(len(lens)) == 2
+    lay = G.debug_persist2(0)
+    assert lay["pieces"] > 0 and lay["K"] == 2 and G.debug_persist(0) is None       # the first form does not hold this graph
+    pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
+                             g["prob"].astype(np.float64), 0)
+    rng = np.random.default_rng(4)
+    lg = rng.normal(0, 2, size=(3, max(lens), P)).astype(np.float32)
+    x = torch.from_numpy(lg).cuda()
+    lp, gamma = chain.den_forward_backward(G, x, lens, 1e-4)
+    lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, chk = chain_c.den_fb(g, pi, lg[n, :Tn], 1e-4, double=True)
+        assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp), (n, lp[n], want_lp)
+        assert np.abs(gamma[n, :Tn] - want_g).max() < 1e-4
+    os.environ["PK2_DEN_PERSIST"] = "0"
+    try:
+        lp_f, gamma_f = chain.den_forward_backward(G, x, lens, 1e-4)
+    finally:
+        del os.environ["PK2_DEN_PERSIST"]
+    assert np.abs(lp_f.cpu().numpy() - lp).max() <= 1e-5 * np.abs(lp).max()
+    assert np.abs(gamma_f.cpu().numpy() - gamma).max() < 1e-5
