@@ -224,6 +224,18 @@ def gemm_mfma_roofline(dev, rows, reps=10):
                 ms_per_launch=round(ms, 4))
 
 
+def persistent_health(den, batch):
+    """After the run: did any persistent kernel give up (a poll timed out -> abort flag, NaN-poisoned output) or fall back
+    to its launch-per-step / per-frame form?  (with RCCL's kernels on the side stream the persistent kernels
+    share the CUs; a timeout would show here, not as a hang.)"""
+    import ctypes
+    from pykaldi2_amd import _lib
+    flag = ctypes.c_uint32(7)
+    rc = _lib.lib().pk2_lstm_persist_status(ctypes.byref(flag))
+    return dict(lstm_persist_abort=int(flag.value) if rc == 0 else -1, den_kernel_path=den.kernel_path(batch),
+                den_persist_form=den.persist_form(batch))
+
+
 def usable_cores():
     """Cores this process may really use (affinity mask and cgroup quota), capped at 32."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -720,6 +732,7 @@ def main():
                      "schedule": getattr(tr.opt, "_mode", "single"), "calibration_steps": calibration_steps,
                      "api": "pk2_allreduce_bucket" if hvd.comm_library() else "torch.distributed.all_reduce"},
         "roofline": roof, "roofline_lstm": roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
+        "persistent_health": persistent_health(den, args.batch),
     }
     if world == 1 and not args.no_cpu_baseline:
         log("cpu baseline + parity (child process, %d cores)" % usable_cores())

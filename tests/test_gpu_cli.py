@@ -233,3 +233,46 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     # and every rank switches to the same one; bench.py runs that calibration to its end BEFORE its warm-up steps
     assert "[hvd] gradient exchange schedule: " in out.stderr and d["exchange"]["schedule"] in ("single", "overlap")
     assert d["exchange"]["calibration_steps"] == 14 and d["steps"] == 4
+
+
+def test_overlap_schedule_50_steps_keeps_the_persistent_kernels(tmp_path):
+    """the bucketed schedule (RCCL all-reduces of finished buckets on the side stream, here on a one-rank
+    communicator) pinned for 50 LF-MMI steps: no persistent kernel may time out or fall back while RCCL's kernels share the
+    chip with them (lstm_persist abort flag 0, denominator still on the persistent path), and the objective equals the
+    single-schedule run of the same steps."""
+    import json
+    base = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "2", "--no-cpu-baseline"]
+    env = dict(os.environ, PK2_HVD_SINGLE_RANK_GROUP="1", PK2_HVD_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", "29551"] + base,
+                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert dist.returncode == 0, dist.stdout[-2000:] + dist.stderr[-3000:]
+    solo = subprocess.run([sys.executable] + base, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert solo.returncode == 0, solo.stdout[-2000:] + solo.stderr[-3000:]
+    a = json.loads(dist.stdout.strip().splitlines()[-1])
+    b = json.loads(solo.stdout.strip().splitlines()[-1])
+    assert a["exchange"]["schedule"] == "overlap" and a["exchange"]["api"] == "pk2_allreduce_bucket"
+    for d in (a, b):
+        assert d["persistent_health"] == dict(lstm_persist_abort=0, den_kernel_path=2, den_persist_form=2), d["persistent_health"]
+        assert np.isfinite(d["last_objf_per_frame"])
+    # 52 optimiser steps apart the two runs still agree (split-K float atomics: equal up to summation order)
+    assert abs(a["last_objf_per_frame"] - b["last_objf_per_frame"]) <= 5e-3 * abs(b["last_objf_per_frame"]) + 1e-3
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo():
+    """The driver's N = 8 line (`torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`) with all ranks on this GPU
+    over gloo: rendezvous, parameter broadcast, the start-up trial of the two exchange schedules, the same number of
+    collectives on every rank, one JSON line from rank 0 with the whole-job aggregate."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29553", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                         env=dict(os.environ, PK2_HVD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 32
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["exchange"]["calibration_steps"] == 14
+    assert d["persistent_health"]["lstm_persist_abort"] == 0
