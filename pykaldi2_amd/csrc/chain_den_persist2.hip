@@ -795,7 +795,7 @@ int den_persist_version(const pk2_den_graph* g, int N) {
   // the row-indexed sums of the segments) and by ~0.9 per streamed piece of 4096 slots; the frame kernels stream both arc
   // lists once per frame for up to 4 sequences at a time
   const double S = (double)g->S * 1e-3, A = (double)g->A * 1e-6;
-  const double us2 = 5.2 + 0.26 * S + 0.9 * pieces;
+  const double us2 = 5.2 + 0.30 * S + 0.9 * pieces;
   const double usf = 6.0 + 0.12 * S + 10.5 * A;
   // 2 N recursions on 8 XCDs (each sequence's two recursions side by side) against ceil(N / 4) groups of frame launches
   const double t2 = us2 * std::max(1.0, 2.0 * N / 8.0), tf = usf * ((N + 3) / 4);

@@ -111,7 +111,7 @@ def test_latgen_from_files_writes_the_decoders_lattices(tmp_path):
                           "-prior_path", str(tmp_path / "final.occs"), "-out_file", out_file, "-trans_model", str(tmp_path / "final.mdl"),
                           "-graph_dir", str(tmp_path / "graph")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lats = kaldi_io.read_compact_lattice_ark(out_file)
+    lats = dict(kaldi_io.read_compact_lattice_ark(out_file))
     utts = sorted(r["wavs"])
     assert sorted(lats) == utts
     # the same decode in-process from the arrays: same best path cost, words printed through words.txt
