@@ -202,6 +202,13 @@ def lstm_flops_per_frame(feat=80, hidden=512, layers=3, pdfs=P):
     return f + 2 * d_in * pdfs
 
 
+def transformer_flops_per_frame(T, feat=80, dim=512, ff=2048, layers=12, pdfs=P):
+    """Forward FLOPs of TransformerAM (models/transformer.py:52-94) per frame of a T-frame utterance: input Linear, per layer
+    the QKV / output projections, the two T x T attention products over all heads, the FFN, Conv1d(k = 3), and the output Linear."""
+    per_layer = 2 * dim * 3 * dim + 2 * dim * dim + 2 * 2 * T * dim + 2 * 2 * dim * ff + 2 * 3 * dim * dim
+    return 2 * feat * dim + layers * per_layer + 2 * dim * pdfs
+
+
 def gemm_mfma_roofline(dev, rows, reps=10):
     """MFMA utilisation of the BLSTM GEMMs (north star): the layer-1/2 input projection of this minibatch,
     [rows, 1024] x [1024, 4096] (both directions' gates), f32 MFMA, timed with events on the launch stream."""
@@ -705,12 +712,20 @@ def main():
     # whole-model MFMA utilisation of the breakdown step: all BLSTM + output-layer FLOPs (forward + backward) of the real
     # (unpadded) frames over the time of the two model phases, against the f32 MFMA peak
     lstm_ms = breakdown["lstm_fwd"] + breakdown["lstm_bwd"]
-    lstm_tf = 3.0 * lstm_flops_per_frame() * sum(lens) / (lstm_ms * 1e-3) / 1e12
-    roof_lstm = dict(bound="mfma", achieved=round(lstm_tf, 2), peak=157.3, unit="TFLOP/s", frac=round(lstm_tf / 157.3, 4),
-                     kernel="3x512 BLSTM + output layer, forward + backward of the breakdown minibatch (recurrence "
-                     "step kernels + f32 MFMA GEMMs)", frames=int(sum(lens)), padded_rows=len(lens) * max(lens),
-                     ms=round(lstm_ms, 3), flops_per_frame_fwd_bwd=3 * lstm_flops_per_frame(),
-                     input_projection_gemm=gemm_mfma_roofline(dev, len(lens) * max(lens)))
+    if args.transformer:      # the model phases hold the 12-layer TransformerAM: its own FLOP count and label
+        flops = 3.0 * sum(transformer_flops_per_frame(T) * T for T in lens)
+        model_tf = flops / (lstm_ms * 1e-3) / 1e12
+        roof_lstm = dict(bound="mfma", achieved=round(model_tf, 2), peak=157.3, unit="TFLOP/s", frac=round(model_tf / 157.3, 4),
+                         kernel="12-layer TransformerAM (dim 512, 8 heads, FFN 2048, conv k=3) + output layer, forward + backward "
+                         "of the breakdown minibatch (f32 MFMA GEMMs, fused attention, row kernels)", frames=int(sum(lens)),
+                         padded_rows=len(lens) * max(lens), ms=round(lstm_ms, 3), flops_fwd_bwd=flops)
+    else:
+        lstm_tf = 3.0 * lstm_flops_per_frame() * sum(lens) / (lstm_ms * 1e-3) / 1e12
+        roof_lstm = dict(bound="mfma", achieved=round(lstm_tf, 2), peak=157.3, unit="TFLOP/s", frac=round(lstm_tf / 157.3, 4),
+                         kernel="3x512 BLSTM + output layer, forward + backward of the breakdown minibatch (recurrence "
+                         "step kernels + f32 MFMA GEMMs)", frames=int(sum(lens)), padded_rows=len(lens) * max(lens),
+                         ms=round(lstm_ms, 3), flops_per_frame_fwd_bwd=3 * lstm_flops_per_frame(),
+                         input_projection_gemm=gemm_mfma_roofline(dev, len(lens) * max(lens)))
     result = {
         "metric": "iRTF (hrs audio/hr) 3x512 BLSTM LF-MMI, LibriSpeech-shaped synthetic utterances",
         "value": round(audio / dt, 2), "unit": "hours of audio per wall-clock hour",
@@ -731,7 +746,7 @@ def main():
                      if torch.distributed.is_initialized() else "none")),
                      "schedule": getattr(tr.opt, "_mode", "single"), "calibration_steps": calibration_steps,
                      "api": "pk2_allreduce_bucket" if hvd.comm_library() else "torch.distributed.all_reduce"},
-        "roofline": roof, "roofline_lstm": roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
+        "roofline": roof, ("roofline_model" if args.transformer else "roofline_lstm"): roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
         "persistent_health": persistent_health(den, args.batch),
     }
     if world == 1 and not args.no_cpu_baseline:
