@@ -596,6 +596,12 @@ extern "C" int pk2_lstm_layer_fwd(const float* gx, const float* whh, const float
     if (prc) return prc;
     if (ran) return PK2_OK;
   }
+  if (lstm_big_wanted(B, H, D)) {           // large batches: one launch, W_hh slices resident in LDS (lstm_persist_big.hip)
+    bool ran = false;
+    int prc = lstm_fwd_big_launch(gx, whh, bhh, B, T, H, D, y, gates, cells, stream, &ran);
+    if (prc) return prc;
+    if (ran) return PK2_OK;
+  }
   ParamSlot<LstmFwdParams>* slot;
   int rc = get_param_slot(g_fwd_slots, H * 4 + D, stream, &slot);
   if (rc) return rc;
@@ -646,9 +652,10 @@ extern "C" int pk2_lstm_persist_status(uint32_t* abort_flag) {
   PK2_REQUIRE(abort_flag, "lstm_persist_status: null pointer");
   unsigned f = 0;
   int rc = lstm_persist_status(&f);
-  unsigned f2 = 0;
+  unsigned f2 = 0, f3 = 0;
   if (!rc) rc = lstm_seq_status(&f2);
-  f |= f2;
+  if (!rc) rc = lstm_big_status(&f3);
+  f |= f2 | f3;
   *abort_flag = f;
   return rc;
 }
@@ -673,6 +680,12 @@ extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float
   if (lstm_persist_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {   // one launch for the whole sequence (lstm_persist.hip)
     bool ran = false;      // the mailboxes (1 MB) live where the step kernels keep W_hh^T
     int prc = lstm_bwd_persist_launch(dy, whh, gates, cells, B, T, H, D, dgx, scratch, stream, &ran);
+    if (prc) return prc;
+    if (ran) return PK2_OK;
+  }
+  if (lstm_big_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {   // large batches, one launch (lstm_persist_big.hip)
+    bool ran = false;
+    int prc = lstm_bwd_big_launch(dy, whh, gates, cells, B, T, H, D, dgx, stream, &ran);
     if (prc) return prc;
     if (ran) return PK2_OK;
   }

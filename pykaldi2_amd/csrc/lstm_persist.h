@@ -29,4 +29,13 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
                         int D, float* dgx, hipStream_t stream, bool* ran);
 int lstm_seq_status(unsigned* abort_flag);
 
+// Large batches (B >= 32, H = 512; lstm_persist_big.hip): a (direction, 64-row batch tile) task per XCD team, the rank's
+// W_hh slice resident in LDS, one launch per layer.
+bool lstm_big_wanted(int B, int H, int D);
+int lstm_fwd_big_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
+                        float* gates, float* cells, hipStream_t stream, bool* ran);
+int lstm_bwd_big_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
+                        int D, float* dgx, hipStream_t stream, bool* ran);
+int lstm_big_status(unsigned* abort_flag);
+
 }  // namespace pk2

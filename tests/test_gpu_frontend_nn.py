@@ -193,10 +193,13 @@ def test_persistent_recurrence_long_sequences_match_torch_cpu(B, T, bi, layers, 
 
 
 @pytest.mark.parametrize("B,T,H,bi", [(70, 9, 128, True), (256, 5, 512, True), (33, 6, 64, False),
-                                      (7, 9, 128, True), (20, 6, 256, True), (3, 11, 64, False), (31, 4, 512, True)])
+                                      (7, 9, 128, True), (20, 6, 256, True), (3, 11, 64, False), (31, 4, 512, True),
+                                      (70, 7, 512, True), (33, 6, 512, False), (130, 12, 512, True), (600, 3, 512, True)])
 def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
-    """B >= 32 takes the GEMM-tiled recurrence kernels (ragged last 64-row tile at B=70 / 33); smaller batches the
-    step kernels that loop over groups of 4 batch rows (4x4x1 MFMA)."""
+    """B >= 32 takes the GEMM-tiled recurrence kernels (ragged last 64-row tile at B=70 / 33) -- at H = 512 the persistent
+    ones of csrc/lstm_persist_big.hip (a (direction, 64-row batch tile) task per XCD team; B = 600: 20 tasks for the 8
+    teams, which take turns from the queue); smaller batches the step kernels that loop over groups of 4 batch rows
+    (4x4x1 MFMA)."""
     torch.manual_seed(1)
     P, Din = 50, 40
     m = lstm.LSTMAM(Din, P, H, 2, 0.0, bi)
@@ -219,6 +222,9 @@ def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
         want = refg[name]
         e = (p.grad.cpu() - want).abs().max().item()
         assert e < 2e-4 * max(1e-3, want.abs().max().item()), (name, e, want.abs().max().item())
+    from pykaldi2_amd import _lib
+    flag = __import__("ctypes").c_uint32(7)
+    assert _lib.lib().pk2_lstm_persist_status(__import__("ctypes").byref(flag)) == 0 and flag.value == 0   # no poll timed out
 
 
 def test_full_size_ce_configuration_matches_torch_cpu():
