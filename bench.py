@@ -169,7 +169,7 @@ def den_roofline(den, dev, reps=5):
     # read live.  Only reported when the profile was taken on the same lengths and graph shape.
     traffic, traffic_note = None, "no PMC profile of this workload committed"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_den_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_den_traffic.json")) as f:
             prof = json.load(f)
         if prof.get("lengths") == lens and prof.get("topology") == DEN_TOPOLOGY and prof.get("arcs") == A:
             traffic = int(prof["traffic_bytes_raw"])
@@ -177,8 +177,12 @@ def den_roofline(den, dev, reps=5):
                             "(gfx950 wide-read correction, an upper bound here): %d" % int(prof["traffic_bytes_fetch_x2"]))
     except Exception:
         pass
+    # what the memory system really moved per second (counter bytes of the committed profile over this run's timing): the
+    # formula counts the per-frame arc re-stream the persistent kernel no longer performs
+    counter = None if traffic is None else round(traffic / (ms * 1e-3) / 1e9, 1)
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=traffic, traffic_note=traffic_note,
+                traffic=traffic, traffic_note=traffic_note, achieved_counter=counter,
+                frac_counter=None if counter is None else round(counter / HBM_PEAK_GBS, 4),
                 persist_form=den.persist_form(len(lens)),
                 kernel={2: ("pk2::den_persist2_kernel" if den.persist_form(len(lens)) == 2 else "pk2::den_persist_kernel") +
                            " (one launch per denominator call: the alpha and beta recursions of the 4 "
