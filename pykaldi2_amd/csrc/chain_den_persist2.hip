@@ -1,21 +1,21 @@
-// Persistent denominator recursion, second form: no capacity cliff, and the table copy overlaps the arcs (gfx950).
+// Persistent denominator recursion, second form: no capacity cliff, and half of the table copy under the arcs (gfx950).
 //
 // chain_den_persist.hip keeps ALL arcs of a recursion in registers and the WHOLE state vector in LDS, which bounds the
 // graphs it takes (~1.05 M arc slots, ~36 k states) -- one arc more and a call fell to the launch-per-frame kernels, 2.2x
 // slower.  Same recursion per XCD, same exchange through the XCD's L2 here, but a frame's row sums are built from PASSES:
 //  * the state vector is cut into table chunks (chain_internal.h: HostPersist2).  A vector that fits LDS has two, back to
-//    back: both LDS-DMAs are started when the frame's words are valid, the arcs that gather from chunk 0 (pass A: 32 register
-//    slots per thread) run as soon as chunk 0 has landed -- s_waitcnt vmcnt(n) with n = the DMA instructions of chunk 1 still
-//    allowed in flight -- and pass B (the other 32 slots) follows when chunk 1 is there: ~half of the 2 us copy of v1's frame
-//    disappears behind pass A.  A longer vector goes through two half-size LDS buffers, chunk c+2 copied into the buffer
-//    chunk c has just left;
+//    back: chunk 0 is copied (LDS-DMA) when the frame's words are valid; pass A -- 32 register slots per thread, arcs that
+//    gather from chunk 0 -- runs on it while the copy of chunk 1 is issued FROM INSIDE the pass, one instruction behind every
+//    group of 8 gathers / multiply-adds (a wave that issues copies back to back stalls at the issue: the DMA queue is
+//    shallow); pass B -- the other 32 slots, gathering from both chunks -- follows when chunk 1 is there.  A longer vector
+//    goes through two half-size LDS buffers, chunk c+2 copied into the buffer chunk c has just left;
 //  * arcs that do not fit the 2 x 32 register slots of a thread (and all arcs gathering from chunks >= 2) are STREAMED: read
-//    again in every frame from the XCD's L2 in pieces of 16 slots per thread, the next piece on its way while one is summed.
-//    A graph a little too large costs one piece per frame (~0.5 us of ~7), not a fall to another kernel family;
+//    again in every frame from the XCD's L2 in pieces of 8 slots per thread, the next piece on its way while one is summed.
+//    A graph a little too large costs a few pieces per frame, not a fall to another kernel family;
 //  * every pass sums complete rows in a lane / finishes rows crossing lanes by a segmented wave scan / leaves the wave's
-//    open tail as a carry, exactly as den_persist_kernel does for its single list; pass A and pass B store into their own LDS
-//    row arrays (one plain store per row), streamed segments add into pass A's array behind a barrier, the row epilogue adds
-//    up the arrays and the carries of all segments.
+//    open tail as a carry, exactly as den_persist_kernel does for its single list; pass A and pass B store into their own
+//    compact LDS row arrays (one plain store per row that has an arc in the list), streamed segments add into a row-indexed
+//    one, the row epilogue adds up the arrays and the carries of all segments.
 // Everything else -- teams by arrival order per XCD, the task queue, NaN-sentinel words, one exchange per frame in both
 // directions, history stores after the words other workgroups wait for, the 1 s poll timeout -- is chain_den_persist.hip's
 // (den_persist_dev.h).  Replaces the same DenominatorComputation (reference ops/ops.py:265, bin/train_chain.py:202).
