@@ -439,6 +439,85 @@ static void persist2_deal(int64_t n, int spt, const std::vector<int32_t>& srow, 
   }
 }
 
+// Bank-aware deal of a resident pass, row by row: ALL slots of a row (they may lie in several lanes, even waves) are
+// interchangeable, and lanes of a half wave that read the SAME address are served by one broadcast -- what a 32-lane
+// ds_read_b32 costs is the largest number of DISTINCT addresses in one of the 32 banks.  Greedy over the rows in order
+// (slot by slot the arc whose address is already read at that (half wave, slot index), else the one whose bank holds the
+// fewest addresses there), then `rounds` passes in which every row is taken out and dealt again against all others.
+// On the BASELINE graph: 2.85 -> see tools/dbg/den_bank_conflicts.py cycles per half-wave gather (random: 3.53).
+static void persist2_deal_rows(int64_t n, int spt, const std::vector<int32_t>& srow, std::vector<int64_t>& sarc, const int32_t* lidx,
+                               std::vector<int32_t>& sidx, int null_base, int null_span, int rounds) {
+  sidx.assign(n, null_base);
+  if (n == 0) return;
+  if (rounds < 0) {                       // (a sizing run of the layout: any valid assignment)
+    for (int64_t i = 0; i < n; ++i) sidx[i] = sarc[i] >= 0 ? lidx[sarc[i]] : null_base;
+    return;
+  }
+  const int nhw = (int)((n + (int64_t)32 * spt - 1) / ((int64_t)32 * spt));
+  // per (half wave hw, slot index j): the <= 32 distinct addresses its lanes read, with the number of lanes reading each,
+  // and cnt[bank] = distinct addresses in that bank
+  struct Cell { int32_t addr[32]; uint8_t refs[32]; uint8_t cnt[32]; int n; };
+  std::vector<Cell> cells((size_t)nhw * spt);
+  for (Cell& c : cells) { c.n = 0; for (int b = 0; b < 32; ++b) c.cnt[b] = 0; }
+  auto cell_of = [&](int64_t pos) -> Cell& { return cells[(size_t)(pos / ((int64_t)32 * spt)) * spt + (size_t)(pos % spt)]; };
+  auto put = [&](int64_t pos, int addr) {
+    Cell& c = cell_of(pos);
+    for (int k = 0; k < c.n; ++k) if (c.addr[k] == addr) { c.refs[k]++; return; }
+    c.addr[c.n] = addr; c.refs[c.n] = 1; c.n++; c.cnt[addr & 31]++;
+  };
+  auto take = [&](int64_t pos, int addr) {
+    Cell& c = cell_of(pos);
+    for (int k = 0; k < c.n; ++k)
+      if (c.addr[k] == addr) {
+        if (--c.refs[k] == 0) { c.cnt[addr & 31]--; c.n--; c.addr[k] = c.addr[c.n]; c.refs[k] = c.refs[c.n]; }
+        return;
+      }
+  };
+  auto cost = [&](int64_t pos, int addr) {
+    const Cell& c = cell_of(pos);
+    for (int k = 0; k < c.n; ++k) if (c.addr[k] == addr) return -1;      // a broadcast: free
+    return (int)c.cnt[addr & 31];
+  };
+  auto null_addr = [&](int64_t pos) {
+    int best = null_base, best_c = 1 << 30;
+    for (int b2 = 0; b2 < null_span; ++b2) { const int c = cost(pos, null_base + b2); if (c < best_c) { best_c = c; best = null_base + b2; } }
+    return best;
+  };
+  std::vector<int64_t> cand;
+  auto deal_row = [&](int64_t s, int64_t e) {
+    cand.assign(sarc.begin() + s, sarc.begin() + e);
+    for (int64_t pos = s; pos < e; ++pos) {
+      size_t best = 0; int best_c = 1 << 30;
+      // (a very long row: the first 256 candidates are choice enough)
+      const size_t lim = std::min<size_t>(cand.size(), 256);
+      for (size_t c = 0; c < lim; ++c) {
+        const int cc = cand[c] < 0 ? 1 << 20 : cost(pos, lidx[cand[c]]);      // nulls last: they can go anywhere
+        if (cc < best_c) { best_c = cc; best = c; }
+      }
+      const int64_t a = cand[best];
+      cand[best] = cand.back(); cand.pop_back();
+      sarc[pos] = a;
+      sidx[pos] = a >= 0 ? lidx[a] : null_addr(pos);
+      put(pos, sidx[pos]);
+    }
+  };
+  // first deal
+  for (int64_t s = 0; s < n;) {
+    int64_t e = s;
+    while (e < n && srow[e] == srow[s]) ++e;
+    deal_row(s, e);
+    s = e;
+  }
+  for (int r = 0; r < rounds; ++r)
+    for (int64_t s = 0; s < n;) {
+      int64_t e = s;
+      while (e < n && srow[e] == srow[s]) ++e;
+      for (int64_t pos = s; pos < e; ++pos) take(pos, sidx[pos]);
+      deal_row(s, e);
+      s = e;
+    }
+}
+
 // Which list every arc goes to (and the LDS offset of the entry it gathers): the chunk it gathers from -- except that with
 // back-to-back chunks (`flexible`) pass B sees chunk 0 as well, so arcs into chunk 0 are moved to list 1 until the two lists
 // of a rank are equally long.  Row by row, the split is taken from the few values around the proportional share that cost
@@ -494,7 +573,7 @@ static bool persist2_arc_lists(int64_t A, const int32_t* idx, const HostPersist2
 //    with EVERY row from its first one on (a null slot where a row has nothing): it adds into a row-indexed array.
 static bool persist2_lists(int64_t A, int num_rows, const float* prob, const float* piprob, const std::vector<int64_t>& ptr,
                            const std::vector<int64_t>& perm, const std::vector<uint8_t>& chunk, const std::vector<int32_t>& lidx,
-                           int estep, int res, HostPersist2* out) {
+                           int estep, int res, bool deal, HostPersist2* out) {
   out->estep = estep;
   const int K = out->K;
   out->prob.assign((size_t)kPR * kPSlots, 0.f);
@@ -550,7 +629,7 @@ static bool persist2_lists(int64_t A, int num_rows, const float* prob, const flo
         // resident pass: thread tid owns the sorted slots tid*res .. tid*res + res-1
         std::vector<int32_t> rrow(scomp.begin(), scomp.begin() + nres);
         std::vector<int64_t> rarc(sarc.begin(), sarc.begin() + nres);
-        persist2_deal(nres, res, rrow, rarc, lidx.data(), sidx, null_base[c], null_span[c]);
+        persist2_deal_rows(nres, res, rrow, rarc, lidx.data(), sidx, null_base[c], null_span[c], deal ? 2 : -1);
         for (int tid = 0; tid < kPT; ++tid) {
           uint32_t e = 0;
           for (int j = 0; j < res; ++j) {
@@ -592,7 +671,8 @@ static bool persist2_lists(int64_t A, int num_rows, const float* prob, const flo
         const int64_t ns = (int64_t)rrow.size();
         const int pieces = (int)((ns + (int64_t)kPT * kSP - 1) / ((int64_t)kPT * kSP));
         const int spt = pieces * kSP;
-        persist2_deal(ns, spt, rrow, rarc, lidx.data(), sidx, null_base[c], null_span[c]);
+        if (deal) persist2_deal(ns, spt, rrow, rarc, lidx.data(), sidx, null_base[c], null_span[c]);
+        else { sidx.assign(ns, null_base[c]); for (int64_t i = 0; i < ns; ++i) if (rarc[i] >= 0) sidx[i] = lidx[rarc[i]]; }
         out->sprob.resize((size_t)(npieces + pieces) * kSP * kPT, 0.f);
         out->sidx2.resize((size_t)(npieces + pieces) * (kSP / 2) * kPT, 0u);
         out->sends.resize((size_t)(npieces + pieces) * kPT, 0u);
@@ -676,19 +756,20 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
       for (int64_t i = 0; i < A2; ++i) perm[cur[key[i]]++] = i;
     }
     // the widest row padding without a streamed piece; if every width streams, the cheapest frame
-    HostPersist2 best_h; double best_cost = 1e30;
+    int best_estep = 0; double best_cost = 1e30;
     std::vector<uint8_t> list_of; std::vector<int32_t> lidx;
-    for (int estep : {8, 4, 2, 1}) {
+    for (int estep : {8, 4, 2, 1}) {        // sizing runs (no bank-aware deal)
       if ((forced > 0 && estep != forced) || res % estep != 0) continue;      // (a cut must fall between whole rows' slots)
       HostPersist2 cand = h;
       if (!persist2_arc_lists(A2, idx, cand, estep, ptr, perm, &list_of, &lidx) ||
-          !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, estep, res, &cand)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
+          !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, estep, res, false, &cand)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
       const double cost = arcs_us(estep) + 0.6 * cand.max_pieces + (cand.max_pieces ? 0.3 : 0.0);
-      if (cost < best_cost) { best_cost = cost; best_h = std::move(cand); }
-      if (best_h.max_pieces == 0 && best_h.K == 2) break;
+      if (cost < best_cost) { best_cost = cost; best_estep = estep; }
+      if (cand.max_pieces == 0 && cand.K == 2) break;
     }
-    if (best_cost > 1e29) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
-    h = std::move(best_h);
+    if (best_estep == 0) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
+    if (!persist2_arc_lists(A2, idx, h, best_estep, ptr, perm, &list_of, &lidx) ||
+        !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, best_estep, res, true, &h)) { f.ok = b.ok = false; return; }
   }
   if (!(f.ok && b.ok)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
   g->p2_cap = cap;
