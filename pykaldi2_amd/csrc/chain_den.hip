@@ -1457,11 +1457,11 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
                          b.lengths, g->d_vpdf, b.beta, g->V, g->d_loop_pdf, b.xl, g->S, Tmax, zv);
     }
     PK2_LAUNCH_CHECK();
-    bool ran = false;
+    bool ran = false, num_rode = false;
     int persist_form = 0;
     if (persist) {      // both recursions of every sequence in one launch (chain_den_persist.hip / chain_den_persist2.hip)
       const int form = den_persist_version(g, ge.N);
-      rc = form == 2 ? den_persist2_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran)
+      rc = form == 2 ? den_persist2_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran, tail, &num_rode)
                      : den_persist_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran);
       if (rc) return rc;
       persist_form = ran ? form : 0;
@@ -1500,7 +1500,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_n[NG] = true;
     }
-    if (tail && tail->valid) {
+    if (tail && tail->valid && !num_rode) {
       if (lds_row && std::max(row_lds, (size_t)tail->lds) <= kGammaMaxLds)
         hipLaunchKernelGGL((den_gamma_states_num<NG, true>), dim3(Tmax + tail->N, G), dim3(kGammaThreads),
                            std::max(row_lds, (size_t)tail->lds), stream, p, b.csum, b.kscale, tail->p, tail->N, tail->stage ? 1 : 0);

@@ -25,6 +25,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "chain_num.h"
 #include "den_persist_dev.h"
 
 namespace pk2 {
@@ -38,7 +39,8 @@ struct DenPersist2Params {
   int rpad;               // floats per ring slot
   int tfloats;            // LDS table floats
   int cap;                // LDS row buffers
-  int ntasks;
+  int ntasks;                   // recursions first (longest first), then the numerators (task_dir 2)
+  NumParams np;                 // the minibatch's numerator forward-backward, if it rides in this launch
   int fwd_stream, bwd_stream;   // the ordering has streamed pieces (or more than two table chunks)
   int pspt;                     // 2 or kPSPT: epilogue entries per thread
   short task_seq[kMaxTasks];
@@ -732,6 +734,24 @@ __global__ void __launch_bounds__(kPT) den_persist2_kernel(const DenPersist2Para
     if (s_abort || k >= p.ntasks) return;
     const int g = p.task_seq[k], T = p.d.lengths[g];
     if (!team_barrier(ctl, team, &nbar, &s_abort)) return;      // everybody has left the previous recursion
+    if (p.task_dir[k] == 2) {
+      // A numerator forward-backward (chain_num.h: two waves, everything staged in LDS) in the idle time of a team whose
+      // recursions are done -- the recursions are queued longest first, so the teams of the short sequences get here while
+      // the longest is still running.  Rank 0's workgroup does it (the LDS of the finished recursion is free); its other
+      // waves execute the routine's barriers with it.
+      if (rank == 0) {
+        if (tid < 128) {
+          NumParams np = pp_->np;      // (through the generic pointer: the struct is passed on by reference)
+          num_fwd_bwd_two_waves(np, g, den_persist2_smem);
+        } else {
+#pragma unroll
+          for (int q = 0; q < kNumTwoWaveBarriers; ++q) __syncthreads();
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
     // (PSPT: rows / states / own virtual states a thread handles in the row epilogues -- 2 when no rank has more than
     // 2 * kPT of any of them: the per-state constants then take half the registers)
     if (p.task_dir[k] == 0) {
@@ -803,8 +823,9 @@ int den_persist_version(const pk2_den_graph* g, int N) {
 }
 
 int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, const int32_t* lengths_host, int N,
-                        hipStream_t stream, bool* ran) {
+                        hipStream_t stream, bool* ran, const NumDeferred* tail, bool* num_ran) {
   *ran = false;
+  if (num_ran) *num_ran = false;
   DenPersist2Scratch& sc = g_den2_scratch[stream];
   const int rpad = den2_rpad(g);
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(DenPersistCtl)));
@@ -835,6 +856,16 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   for (int k = 0; k < p.ntasks; ++k) { p.task_seq[k] = (short)(order[k].second >> 1); p.task_dir[k] = (unsigned char)(order[k].second & 1); }
   sc.ntasks = 0;
   if (p.ntasks == 0) { *ran = true; return PK2_OK; }
+  // The numerator forward-backward of the minibatch (two waves per sequence, LDS-staged) as further tasks behind the
+  // recursions: the teams of the short sequences run them while the longest recursion is still going.  Not during the
+  // first, verified launch of a process (a fallback would have to undo the posteriors already added to the gradient).
+  const bool with_num = tail && tail->valid && tail->stage && num_ran && g_den_persist2_state == 1 && tail->N == N &&
+                        tail->lds <= (size_t)den2_tfloats(g) * sizeof(float) && p.ntasks + N <= kMaxTasks &&
+                        !(getenv("PK2_DEN_NUM_RIDE") && atoi(getenv("PK2_DEN_NUM_RIDE")) == 0);
+  if (with_num) {
+    p.np = tail->p;
+    for (int n = 0; n < N; ++n) { p.task_seq[p.ntasks] = (short)n; p.task_dir[p.ntasks] = 2; ++p.ntasks; }
+  }
   const size_t lds = den_persist2_lds_bytes(p.tfloats, p.cap);
   static bool attr = false;
   if (!attr) {
@@ -862,6 +893,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   }
   sc.ntasks = p.ntasks;
   *ran = true;
+  if (with_num) *num_ran = true;
   return PK2_OK;
 }
 

@@ -151,6 +151,9 @@ __device__ __forceinline__ float num_frame_sum(float v, int count) {
   return wave_sum(v);
 }
 
+// (kNumTwoWaveBarriers __syncthreads() inside: a caller whose workgroup has further waves alive lets those execute the same
+// number of barriers -- den_persist2_kernel, where the numerators ride in the idle time of the teams that finish early.)
+constexpr int kNumTwoWaveBarriers = 4;
 __device__ __forceinline__ void num_fwd_bwd_two_waves(const NumParams& p, int n, float* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* info = p.seqinfo + n * 8;

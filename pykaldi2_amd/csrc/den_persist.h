@@ -31,8 +31,11 @@ constexpr int kP2RowArrays = 7;
 constexpr int kP2FixedFloats = 2 * kPW + 4 + 2 * kSegs * kPW + 16;
 inline size_t den_persist2_lds_bytes(int tfloats, int cap) { return ((size_t)tfloats + kP2RowArrays * (size_t)cap + kP2FixedFloats) * sizeof(float); }
 bool den_persist2_fits(const pk2_den_graph* g);
+// `tail`: the minibatch's deferred numerator forward-backward (may be null); *num_ran = true when it rode in this launch
+// (as tasks behind the recursions) and must not be launched again.
+struct NumDeferred;
 int den_persist2_launch(pk2_den_graph* g, const DenParams& p, const float* xv, const int32_t* lengths_host, int N,
-                        hipStream_t stream, bool* ran);
+                        hipStream_t stream, bool* ran, const NumDeferred* tail = nullptr, bool* num_ran = nullptr);
 void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream);
 // Which recursion kernel a call of N sequences takes: 0 = the launch-per-frame kernels, 1 = den_persist_kernel (everything
 // resident: graphs up to ~1.05 M arc slots and ~36 k states), 2 = den_persist2_kernel.  PK2_DEN_PERSIST = 0 | 1 | 2 forces one
