@@ -13,7 +13,7 @@ torch.cuda.synchronize()
 host = []
 t0 = time.perf_counter()
 for i in range(16):
-    a = time.perf_counter(); tr.step(batches[i % 8]); host.append(time.perf_counter() - a)
+    a = time.perf_counter(); tr.prefetch(batches[(i + 1) % 8]); tr.step(batches[i % 8]); host.append(time.perf_counter() - a)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
