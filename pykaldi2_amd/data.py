@@ -235,6 +235,8 @@ def epoch_plan(source, batch_size, hours, rank=0, world=1, epoch=0, length_bucke
         durs = synth.utterance_durations(rng, n_steps * batch_size).reshape(n_steps, batch_size)
         return [list(map(float, row)) for row in durs]
     n = len(source.items)
+    if n == 0:
+        return []
     group = world * batch_size
     perm = rng.permutation(n)
     total = -(-n // group) * group

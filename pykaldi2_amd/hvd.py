@@ -80,11 +80,18 @@ def _create_comm():
     store = dist.distributed_c10d._get_default_store()
     if dist.get_rank() == 0:
         buf = C.create_string_buffer(n)
-        _lib.check(L.pk2_comm_unique_id(buf))
+        try:
+            _lib.check(L.pk2_comm_unique_id(buf))
+        except Exception:
+            # the other ranks are blocked in store.get: tell them, so that every rank falls back together
+            store.set("pk2_comm_unique_id", b"FAILED")
+            raise
         store.set("pk2_comm_unique_id", buf.raw)
         uid = buf.raw
     else:
         uid = bytes(store.get("pk2_comm_unique_id"))
+        if uid == b"FAILED":
+            raise RuntimeError("rank 0 could not create the RCCL unique id")
     h = C.c_void_p()
     _lib.check(L.pk2_comm_init(dist.get_rank(), dist.get_world_size(), uid, C.byref(h)))
     return h
