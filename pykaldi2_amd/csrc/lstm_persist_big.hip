@@ -134,14 +134,14 @@ __device__ __forceinline__ bool bg_wait_flags(BigCtl* ctl, const unsigned* flags
   return s_i[3] == 0;
 }
 
-// A rank's 64 gate rows of W_hh -> LDS as Wl[k4][n][4]: n = 4 * (unit - u0) + gate, the four floats = k 4*k4 .. 4*k4+3.
-// (A lane that is column n of a 32x32x2 MFMA and k-phase kq reads, for the chunk of 8 k's c, ONE 16-byte word at
-// k4 = 2c + kq and feeds element j of it to the j-th of four MFMAs; the A operand's lane does the same with 16 contiguous
+// A rank's 64 gate rows of W_hh -> LDS as Wl[k4][n][4]: n = 16 * gate + (unit - u0), the four floats = k 4*k4 .. 4*k4+3.
+// (A lane that is column n of a 16x16x4 MFMA and k-phase kq reads, for the chunk of 16 k's c, ONE 16-byte word at
+// k4 = 4c + kq and feeds element j of it to the j-th of four MFMAs; the A operand's lane does the same with 16 contiguous
 // bytes of h -- the sum over k does not care in which order the MFMAs take the k's.)
 __device__ __forceinline__ void bg_load_w(const float* whh_d, int u0, float* Wl) {
   for (int idx = threadIdx.x; idx < 64 * (kBgH / 4); idx += 256) {
     const int n = idx / (kBgH / 4), k4 = idx % (kBgH / 4);
-    const int u = n >> 2, g = n & 3;
+    const int g = n >> 4, u = n & 15;
     const bg_f32x4 v = *reinterpret_cast<const bg_f32x4*>(whh_d + ((size_t)g * kBgH + u0 + u) * kBgH + 4 * k4);
     *reinterpret_cast<bg_f32x4*>(Wl + ((size_t)k4 * 64 + n) * 4) = v;
   }
@@ -158,11 +158,23 @@ struct BigFwdParams {
   int B, T, D;
 };
 
+typedef float bg_f32x4acc __attribute__((ext_vector_type(4)));
+
+// The product of a step is 64 (batch rows) x 64 (16 units x 4 gates) x 512 on 16x16x4 MFMAs: wave w owns the 16-row strip
+// 16w .. 16w+15 of the batch tile and all four column tiles -- tile g = gate g of the 16 units -- so every byte of h is read
+// ONCE per workgroup (2x2 waves of 32x32 tiles read each half of the batch tile twice: 256 KB per step out of an L2 stream
+// that gives a CU 28-34 KB/us, 9 of the step's 12 us).  The tiles are computed TRANSPOSED (the W word is the MFMA's A
+// operand, the h word its B operand): the accumulators then leave the four gates of (4 consecutive units, one batch row) in
+// one lane -- the gate math runs in those registers, no transposition through LDS, and gx / gates / cells / h move as
+// 16-byte words (10 memory instructions per lane and step instead of 40).
+__device__ __forceinline__ void bg_store16_agent(float* p, bg_f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 __global__ void __launch_bounds__(256) lstm_fwd_big_persist(BigFwdParams p, BigCtl* ctl) {
   constexpr int H = kBgH;
   extern __shared__ __attribute__((aligned(16))) float bg_smem[];
   float* Wl = bg_smem;                                   // [H/4][64][4]
-  float (*Cs)[65] = reinterpret_cast<float (*)[65]>(bg_smem + kBgWFloats);
   int* s_i = reinterpret_cast<int*>(bg_smem + kBgWFloats + 64 * 65);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   BigRole role;
@@ -171,112 +183,107 @@ __global__ void __launch_bounds__(256) lstm_fwd_big_persist(BigFwdParams p, BigC
   const int u0 = 16 * rank;
   const int mtiles = (B + 63) / 64;
   const size_t yrow = (size_t)D * H;
-  const int wm = (w >> 1) * 32, wn = (w & 1) * 32, kq = lane >> 5;
+  const int kq = lane >> 4;                              // k-phase of the operand words
+  const int uu = u0 + 4 * kq;                            // the lane's results: units uu .. uu+3 of batch row m0 + 16w + (lane & 15)
   for (int iter = 0; iter <= kBgMaxTasks; ++iter) {
     const int task = bg_next_task(ctl, role, iter, D * mtiles, s_i);
     if (task < 0) return;
     const int d = task % D, m0 = (task / D) * 64;
     __syncthreads();                                     // (everybody has left the previous task's LDS)
     bg_load_w(p.whh + (size_t)d * 4 * H * H, u0, Wl);
-    // the 4 (row, unit) items of this thread in the gate math
-    float bias[4][4], cprev[4];
+    bg_f32x4 bias[4], cprev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int u = (tid + j * 256) & 15;
-      cprev[j] = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bias[j][g] = p.bhh ? p.bhh[(size_t)d * 4 * H + (size_t)g * H + u0 + u] : 0.f;
-    }
+    for (int g = 0; g < 4; ++g)
+      bias[g] = p.bhh ? *reinterpret_cast<const bg_f32x4*>(p.bhh + (size_t)d * 4 * H + (size_t)g * H + uu) : bg_f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned* flags = p.flags + (size_t)task * T * kBgR;
-    const int arow = min(m0 + wm + (lane & 31), B - 1);  // (rows past the batch: a valid row, results never stored)
-    const float* bbase = Wl + ((size_t)kq * 64 + wn + (lane & 31)) * 4;
+    const int b = m0 + 16 * w + (lane & 15);
+    const bool live = b < B;
+    const int arow = min(b, B - 1);                      // (rows past the batch: a valid row, results never stored)
+    const float* wbase = Wl + ((size_t)kq * 64 + (lane & 15)) * 4;
     __syncthreads();
     BG_T0();
     for (int s = 0; s < T; ++s) {
       const int t = d == 0 ? s : T - 1 - s;
       const int tp = d == 0 ? t - 1 : t + 1;
       // gate pre-activations of this step's items: issued now, used behind the matrix product
-      float pre[4][4];
+      bg_f32x4 pre[4];
+      {
+        const float* gxr = p.gx + ((size_t)t * B + arow) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + uu;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = tid + j * 256, i = idx >> 4, u = idx & 15, b = m0 + i;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre[j][g] = 0.f;
-        if (b < B) {
-          const float* gxr = p.gx + ((size_t)t * B + b) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + u0 + u;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) pre[j][g] = gxr[(size_t)g * H];
-        }
+        for (int g = 0; g < 4; ++g) pre[g] = *reinterpret_cast<const bg_f32x4*>(gxr + (size_t)g * H);
       }
       BG_T(0);
+      bg_f32x4acc acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = bg_f32x4acc{0.f, 0.f, 0.f, 0.f};
       if (s > 0) {
         if (!bg_wait_flags(ctl, flags + (size_t)(s - 1) * kBgR, s_i)) return;
         BG_T(1);
-        // h_{prev}[batch tile][0 .. H) x W_slice^T: 64 chunks of 8 k's, four 32x32x2 MFMAs each; the A words come
-        // straight from L2, kDepth chunks ahead
-        const float* abase = p.y + ((size_t)tp * B + arow) * yrow + (size_t)d * H + 4 * kq;
-        // (8 words in flight per lane: 28 KB/us per CU, a product of 9 us; 16 in flight changed nothing -- the 32 CUs of the
-        // team read the same 128 KB in 32-byte pieces, and that broadcast, not latency, bounds the stream)
-        constexpr int kDepth = 8;
-        bg_f32x4 a[kDepth];
+        // W_slice x h_{prev}[strip]^T: 32 chunks of 16 k's, sixteen 16x16x4 MFMAs each; the h words come straight from L2,
+        // kDepth chunks ahead; the W words of the next chunk (LDS) are read under this chunk's MFMAs
+        const float* hbase = p.y + ((size_t)tp * B + arow) * yrow + (size_t)d * H + 4 * kq;
+        constexpr int kDepth = 8, kChunks = H / 16;
+        bg_f32x4 hv[kDepth];
 #pragma unroll
-        for (int c = 0; c < kDepth; ++c) a[c] = *reinterpret_cast<const bg_f32x4*>(abase + 8 * c);
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < kDepth; ++c) hv[c] = *reinterpret_cast<const bg_f32x4*>(hbase + 16 * c);
         // (the scheduling barriers keep every load where it is written, kDepth chunks ahead of its use: left alone the
         // scheduler sinks the loads to just before their MFMAs -- two in flight, a round trip to L2 every other chunk)
         __builtin_amdgcn_sched_barrier(0);
-        bg_f32x4 bv = *reinterpret_cast<const bg_f32x4*>(bbase);
-        for (int c0 = 0; c0 < H / 8; c0 += kDepth) {
+        bg_f32x4 wv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wv[g] = *reinterpret_cast<const bg_f32x4*>(wbase + 64 * g);
+        for (int c0 = 0; c0 < kChunks; c0 += kDepth) {
 #pragma unroll
           for (int cc = 0; cc < kDepth; ++cc) {
             const int c = c0 + cc;
-            const bg_f32x4 av = a[cc], bc = bv;
-            // the next chunk's B word (LDS) and the A word kDepth chunks on (L2) are issued before this chunk's MFMAs
-            bv = *reinterpret_cast<const bg_f32x4*>(bbase + (size_t)min(c + 1, H / 8 - 1) * (2 * 64 * 4));
-            if (c + kDepth < H / 8) a[cc] = *reinterpret_cast<const bg_f32x4*>(abase + 8 * (c + kDepth));
+            const bg_f32x4 hc = hv[cc];
+            bg_f32x4 wc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wc[g] = wv[g];
+            const float* wn = wbase + (size_t)min(c + 1, kChunks - 1) * (4 * 64 * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[g] = *reinterpret_cast<const bg_f32x4*>(wn + 64 * g);
+            if (c + kDepth < kChunks) hv[cc] = *reinterpret_cast<const bg_f32x4*>(hbase + 16 * (c + kDepth));
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc.w, acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[g].x, hc.x, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[g].y, hc.y, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[g].z, hc.z, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[g].w, hc.w, acc[g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        const int col = wn + (lane & 31), rh = 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Cs[wm + (r & 3) + 8 * (r >> 2) + rh][col] = acc[r];
-        bg_lds_barrier();
         BG_T(2);
       }
-      float gi_[4], gf_[4], gg_[4], go_[4];
+      // accumulator element j of tile g = gate g of (unit uu + j, batch row b)
+      bg_f32x4 gi_, gf_, gg_, go_, hh;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int idx = tid + j * 256, i = idx >> 4, u = idx & 15, b = m0 + i;
-        float v[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = (pre[j][g] + bias[j][g]) + (s == 0 ? 0.f : Cs[i][u * 4 + g]);
-        const float ig = bg_sig(v[0]), fg = bg_sig(v[1]), gg = bg_tanh(v[2]), og = bg_sig(v[3]);
+        const float ig = bg_sig((pre[0][j] + bias[0][j]) + acc[0][j]), fg = bg_sig((pre[1][j] + bias[1][j]) + acc[1][j]);
+        const float gg = bg_tanh((pre[2][j] + bias[2][j]) + acc[2][j]), og = bg_sig((pre[3][j] + bias[3][j]) + acc[3][j]);
         const float c = fg * cprev[j] + ig * gg;
-        const float h = og * bg_tanh(c);
+        hh[j] = og * bg_tanh(c);
         cprev[j] = c;
         gi_[j] = ig; gf_[j] = fg; gg_[j] = gg; go_[j] = og;
-        if (b < B) bg_store_f(p.y + ((size_t)t * B + b) * yrow + (size_t)d * H + u0 + u, h);
       }
+      if (live) bg_store16_agent(p.y + ((size_t)t * B + b) * yrow + (size_t)d * H + uu, hh);
       BG_T(3);
-      // h of this step is in L2 before the flag says so (and the gate tile may be overwritten); what only the backward
-      // pass reads -- cells, gates -- goes out behind the flag, off the other ranks' critical path
+      // h of this step is in L2 before the flag says so; what only the backward pass reads -- cells, gates -- goes out
+      // behind the flag, off the other ranks' critical path
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) bg_store_u(const_cast<unsigned*>(flags) + (size_t)s * kBgR + rank, 1u);
       BG_T(4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = tid + j * 256, i = idx >> 4, u = idx & 15, b = m0 + i;
-        if (b < B) {
-          p.cells[(((size_t)d * T + t) * B + b) * H + u0 + u] = cprev[j];
-          float* gr = p.gates + (((size_t)d * T + t) * B + b) * 4 * H + u0 + u;
-          gr[0] = gi_[j]; gr[(size_t)H] = gf_[j]; gr[(size_t)2 * H] = gg_[j]; gr[(size_t)3 * H] = go_[j];
-        }
+      if (live) {
+        *reinterpret_cast<bg_f32x4*>(p.cells + (((size_t)d * T + t) * B + b) * H + uu) = cprev;
+        float* gr = p.gates + (((size_t)d * T + t) * B + b) * 4 * H + uu;
+        *reinterpret_cast<bg_f32x4*>(gr) = gi_;
+        *reinterpret_cast<bg_f32x4*>(gr + (size_t)H) = gf_;
+        *reinterpret_cast<bg_f32x4*>(gr + (size_t)2 * H) = gg_;
+        *reinterpret_cast<bg_f32x4*>(gr + (size_t)3 * H) = go_;
       }
       BG_T(5);
     }
@@ -314,8 +321,6 @@ struct BigBwdParams {
   unsigned* flags;    // [ntasks][T][kBgR], zero on entry
   int B, T, D;
 };
-
-typedef float bg_f32x4acc __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) lstm_bwd_big_persist(BigBwdParams p, BigCtl* ctl) {
   constexpr int H = kBgH;
@@ -467,6 +472,10 @@ bool lstm_big_wanted(int B, int H, int D) {
 int lstm_fwd_big_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
                         float* gates, float* cells, hipStream_t stream, bool* ran) {
   *ran = false;
+  // (the kernel moves gx / h / cells / gates / the bias as 16-byte words: tensors that are not 16-byte aligned keep the
+  // step kernels)
+  if (((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gates) |
+        reinterpret_cast<uintptr_t>(cells) | reinterpret_cast<uintptr_t>(bhh)) & 15) != 0) return PK2_OK;
   const int ntasks = D * ((B + 63) / 64);
   BigScratch* sc = nullptr;
   int rc = big_scratch(stream, (size_t)ntasks * T * kBgR, &sc);
