@@ -451,8 +451,14 @@ int pk2_lattice_batch_destroy(pk2_lattice_batch* b);
 int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, int64_t seq_stride,
                        int64_t frame_stride, int32_t num_pdfs, const int32_t* tid2pdf, int32_t num_tids,
                        void* workspace, void* stream);
+/* By default all frames of an utterance are decoded inside ONE persistent launch by a team of PK2_LAT_TEAM (8 / 16 / 32)
+ * workgroups of one XCD (csrc/lattice_decode_frames.hip; PK2_LAT_DECODER=frames: a few launches per frame, =wg: one
+ * workgroup per utterance).  *state: 1 = in use on this device, 0 = disabled or failed its first (host-verified) launch
+ * -- the launch-per-frame decoder has taken over --, -1 = not tried yet; *abort_flag: some later launch timed out (its
+ * utterances were reported with status 5, "not decoded").  Synchronises the device. */
+int pk2_lattice_persist_status(int32_t* state, uint32_t* abort_flag);
 /* Synchronises `stream` and reports per utterance: status (0 ok, 1 token pool overflow, 2 link pool
- * overflow, 3 no surviving token, 4 epsilon closure did not converge), tokens and links created, cost of
+ * overflow, 3 no surviving token, 4 epsilon closure did not converge, 5 not decoded), tokens and links created, cost of
  * the best path.  Returns PK2_ERR_LIMIT / PK2_ERR_NUMERIC if any utterance failed.  Any output may be NULL. */
 int pk2_lattice_summary(const pk2_lattice_batch* b, const void* workspace, int32_t* status,
                         int32_t* num_tokens, int32_t* num_links, float* best_cost, void* stream);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "pk2_lattice_batch_destroy": (C.c_int, [_vp]),
     "pk2_lattice_decode": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
     "pk2_lattice_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pk2_lattice_persist_status": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "pk2_lattice_mmi": (C.c_int, [_vp, _vp, _vp, _i64, _vp, C.c_double, C.c_double, _i32, _vp, _i64, _i64, _vp, _vp]),
     "pk2_lattice_mpe": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _vp, _i64, _i64,
                                   _vp, _vp]),

@@ -262,3 +262,12 @@ extern "C" int pk2_lattice_decode(pk2_lattice_batch* b, const float* loglikes, i
   b->decoded = true;
   return PK2_OK;
 }
+
+extern "C" int pk2_lattice_persist_status(int32_t* state, uint32_t* abort_flag) {
+  PK2_REQUIRE(state && abort_flag, "lattice_persist_status: null pointer");
+  PK2_HIP(hipDeviceSynchronize());
+  unsigned f = 0;
+  *state = lattice_persist_status(&f);
+  *abort_flag = f;
+  return PK2_OK;
+}

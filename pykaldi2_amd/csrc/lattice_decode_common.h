@@ -594,5 +594,6 @@ __device__ void prune_segments(const DecodeParams& p, const UttView& V, Shared& 
 
 // lattice_decode_frames.hip: `team` workgroups per utterance, a few launches per frame (replayed from hipGraphs).
 int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream);
+int lattice_persist_status(unsigned* abort_flag);
 
 }  // namespace pk2

@@ -33,6 +33,7 @@ namespace pk2 {
 template <typename T>
 __device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+
 struct TeamCtx {
   UttView V;
   LatFrame* F;
@@ -50,6 +51,18 @@ __device__ __forceinline__ TeamCtx team_ctx(const DecodeParams& p, const StepCou
   c.V = make_view(p, c.n, U);
   c.F = p.L.frame + c.n;
   c.live = cnt->base + local < cnt->T && c.t < c.T && c.F->status == kLatOk;
+  return c;
+}
+
+// The same for a team inside the persistent kernel: utterance n, rank wg of G, frame t (status is looked at by the caller).
+__device__ __forceinline__ TeamCtx team_ctx_of(const DecodeParams& p, int n, int wg, int G, int t) {
+  TeamCtx c;
+  c.n = n; c.wg = wg; c.G = G; c.t = t;
+  const LatUtt U = p.L.utt[n];
+  c.T = U.T;
+  c.V = make_view(p, n, U);
+  c.F = p.L.frame + n;
+  c.live = true;
   return c;
 }
 
@@ -96,8 +109,24 @@ __device__ __forceinline__ int wave_alloc_n(int32_t* counter, int count) {
   return __shfl(base, 63, 64) + incl - count;
 }
 
+// Index ownership of the epsilon list: the team's waves take turns (wave w of workgroup g owns entries (w G + g) 64 .. + 63
+// of every G * 1024) -- a frame has one or two thousand entries, which whole workgroups in a row would leave to two of them.
+__device__ __forceinline__ int team_entry(int wg, int G) {
+  return (((int)threadIdx.x >> 6) * G + wg) * 64 + ((int)threadIdx.x & 63);
+}
+
+// A token whose state has more than kHeavyDegree epsilon arcs joins the team's heavy list (false: the list is full, the
+// token stays on the ordinary epsilon list and its owner walks the arcs).
+__device__ __forceinline__ bool team_register_heavy(LatFrame* F, int G, int tok) {
+  const int h = atomicAdd(&F->n_hlist, 1);
+  if (h >= kLatTeamHeavy) return false;
+  F->hlist[h] = tok;
+  for (int w = 0; w < G; ++w) F->hlast[h * kLatMaxTeam + w] = INFINITY;
+  return true;
+}
+
 // Called by every lane that created the token of state d (old == kEmpty); others pass create = false.
-__device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int fb, int d,
+__device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int G, int fb, int d,
                                                     bool create = true) {
   const int idx = wave_alloc(&F->n_new, create);
   bool eps = false;
@@ -106,7 +135,9 @@ __device__ __forceinline__ void team_register_token(const DecodeParams& p, const
       V.ts[fb + idx] = d;
       V.tc[fb + idx] = INFINITY;
       st_coherent(&V.stt[d], idx);
-      eps = p.g.n_off[d + 1] > p.g.n_off[d];
+      const int deg = p.g.n_off[d + 1] - p.g.n_off[d];
+      eps = deg > 0;
+      if (deg > kHeavyDegree && team_register_heavy(F, G, fb + idx)) eps = false;
     } else {
       st_coherent(&F->status, (int32_t)kLatTokenOverflow);
     }
@@ -117,12 +148,63 @@ __device__ __forceinline__ void team_register_token(const DecodeParams& p, const
   }
 }
 
-// One relaxation round over the epsilon-list entries [0, ne) owned by this workgroup.  Returns (to all threads)
-// whether this workgroup lowered a cost.
+// The arcs of the team's heavy tokens [0, nh): workgroup wg of G walks arcs wg * 1024 + thread, + G * 1024, ... of each.
+// track: a relaxation round -- the share is walked only if the token got cheaper since THIS workgroup last walked it
+// (slots of the team of Gteam workgroups; the single workgroup of the tail pass, G = 1, walks everything when any share is
+// behind and brings all slots up to date).  Contains workgroup barriers.
+template <typename Body>
+__device__ __forceinline__ void team_heavy_arcs(const DecodeParams& p, const UttView& V, LatFrame* F, Shared& sh, int nh,
+                                                int wg, int G, int Gteam, float cutoff, bool track, Body body) {
+  const int tid = threadIdx.x;
+  for (int h = 0; h < nh; ++h) {
+    const int i = F->hlist[h];
+    const int s = V.ts[i];
+    if (tid == 0) {
+      const float cc = dec_cost(ld_coherent(&V.stc[s]));
+      bool act = cc < cutoff;
+      if (track && act) {
+        float* last = F->hlast + h * kLatMaxTeam;
+        if (G == Gteam) {
+          act = cc < last[wg];
+          if (act) last[wg] = cc;
+        } else {
+          float behind = last[0];
+          for (int w = 1; w < Gteam; ++w) behind = fmaxf(behind, last[w]);
+          act = cc < behind;
+          if (act) for (int w = 0; w < Gteam; ++w) last[w] = cc;
+        }
+      }
+      sh.heavy_cost[0] = cc;
+      sh.heavy_tok[0] = act ? 1 : 0;
+    }
+    __syncthreads();
+    const float cc = sh.heavy_cost[0];
+    const bool act = sh.heavy_tok[0] != 0;
+    __syncthreads();
+    if (act)
+      for (int a = p.g.n_off[s] + wg * kLatThreads + tid; a < p.g.n_off[s + 1]; a += G * kLatThreads) body(i, cc, a);
+  }
+}
+
+// One relaxation round over the epsilon-list entries [0, ne) owned by this workgroup and its share of the heavy tokens
+// [0, nh).  Returns (to all threads) whether this workgroup lowered a cost.
 __device__ __forceinline__ int eps_round(const DecodeParams& p, const UttView& V, LatFrame* F, Shared& sh, int fb,
-                                         float cutoff, int ne, int wg, int G) {
+                                         float cutoff, int ne, int nh, int wg, int G, int Gteam) {
   const uint32_t kcut = enc_cost(cutoff);
   int changed = 0;
+  auto relax = [&](int i, float c, int a) {
+    const float tot = c + p.g.n_w[a];
+    const uint32_t k = enc_cost(tot);
+    if (k < kcut) {
+      const int d = p.g.n_dst[a];
+      const uint32_t old = atomicMin(&V.stc[d], k);
+      if (k < old) {
+        // another round is needed only if the state that got cheaper has epsilon arcs of its own
+        if (p.g.n_off[d + 1] > p.g.n_off[d]) changed = 1;
+        if (old == kEmpty) team_register_token(p, V, F, Gteam, fb, d);
+      }
+    }
+  };
   for_each_arc(sh, V.elist, ne, V.ts, p.g.n_off,
                [&](int i, float* c) {
                  const float cc = dec_cost(ld_coherent(&V.stc[V.ts[i]]));
@@ -131,90 +213,107 @@ __device__ __forceinline__ int eps_round(const DecodeParams& p, const UttView& V
                  *c = cc;
                  return cc < cutoff;
                },
-               [&](int i, float c, int a) {
-                 const float tot = c + p.g.n_w[a];
-                 const uint32_t k = enc_cost(tot);
-                 if (k < kcut) {
-                   const int d = p.g.n_dst[a];
-                   const uint32_t old = atomicMin(&V.stc[d], k);
-                   if (k < old) {
-                     // another round is needed only if the state that got cheaper has epsilon arcs of its own
-                     if (p.g.n_off[d + 1] > p.g.n_off[d]) changed = 1;
-                     if (old == kEmpty) team_register_token(p, V, F, fb, d);
-                   }
-                 }
-               },
-               wg * kLatThreads + (int)threadIdx.x, G * kLatThreads);
+               relax, team_entry(wg, G), G * kLatThreads);
+  team_heavy_arcs(p, V, F, sh, nh, wg, G, Gteam, cutoff, true, relax);
   return __syncthreads_or(changed);
 }
 
 // ---- step 0 only: the start token ----
-__global__ void lat_frames_init(const DecodeParams p) {
-  const int n = blockIdx.x;
+__device__ __forceinline__ void phase_init(const DecodeParams& p, int n, int G) {
   if (threadIdx.x != 0) return;
   const LatUtt U = p.L.utt[n];
   const UttView V = make_view(p, n, U);
   LatFrame* F = p.L.frame + n;
   F->f0 = 0; F->f1 = 0; F->link_end = 0; F->n_new = 0; F->n_link = 0; F->n_elist = 0; F->n_arcs = 0; F->ne_snap = 0;
+  F->n_hlist = 0; F->nh_snap = 0;
   F->best_key = kEmpty; F->best_next = kEmpty; F->nmin_key = kEmpty;
   F->cur_cutoff = INFINITY; F->adaptive = p.beam; F->build_cutoff = p.beam;   // InitDecoding: ProcessNonemitting(beam)
   F->status = kLatOk; F->arrive = 0;
   for (int r = 0; r <= kLatEpsRounds; ++r) F->changed[r] = 0;
   F->ll_base = p.loglikes + (int64_t)n * p.seq_stride; F->ll_stride = p.frame_stride;
   V.stc[p.g.start] = enc_cost(0.f);
-  team_register_token(p, V, F, 0, p.g.start);
-  F->ne_snap = F->n_elist;
+  team_register_token(p, V, F, G, 0, p.g.start);
+  F->ne_snap = F->n_elist; F->nh_snap = min(F->n_hlist, kLatTeamHeavy);
   V.ftok[0] = 0; V.seg[0] = 0;
 }
+__global__ void lat_frames_init(const DecodeParams p, int G) { phase_init(p, blockIdx.x, G); }
 
 // ---- GetCutoff ----
 // Number of costs below hi = lo + beam and, when more than k of them are, the exact k-th smallest (0-based): one
 // pass builds 2047 linear bins of [lo, hi) (bin 2047 = the rest), which gives the count and the bin of the k-th;
 // a second pass collects that bin's members (a handful) in LDS, where each is ranked against the others.
 // Returns false when at most k costs lie below hi.  Falls back to kth_smallest_in_range for a crowded bin.
+#ifdef PK2_LATP_PROFILE
+__device__ long long g_cut[8];
+#define CUT_T(k) do { if (threadIdx.x == 0) { const long long n_ = wall_clock64(); g_cut[k] += n_ - cut_last; cut_last = n_; } } while (0)
+#else
+#define CUT_T(k) do { } while (0)
+#endif
 __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, Shared& sh, float* out) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef PK2_LATP_PROFILE
+  long long cut_last = wall_clock64();
+#endif
   const float scale = 2047.0f / (hi - lo);
   auto bin_of = [&](float c) { return c >= hi ? 2047 : min(2046, (int)((c - lo) * scale)); };
+  // The first kCutRegs * 1024 costs stay in registers for both passes: all their loads are in flight together (a
+  // load -> LDS atomic loop waits for L2 once per iteration: 4.6 us for 8.5 k costs) and the second pass reads nothing.
+  constexpr int kCutRegs = 10;
+  float cr[kCutRegs];
+#pragma unroll
+  for (int q = 0; q < kCutRegs; ++q) {
+    const int i = tid + q * kLatThreads;
+    cr[q] = i < n ? cost[i] : 0.f;
+  }
   for (int i = tid; i < 2048; i += kLatThreads) sh.hist[i] = 0;
   if (tid == 0) { sh.sel_k = -1; sh.redi[0] = 0; }
   __syncthreads();
-  for (int i = tid; i < n; i += kLatThreads) atomicAdd(&sh.hist[bin_of(cost[i])], 1u);
+  CUT_T(0);
+#pragma unroll
+  for (int q = 0; q < kCutRegs; ++q)
+    if (tid + q * kLatThreads < n) atomicAdd(&sh.hist[bin_of(cr[q])], 1u);
+  for (int i = tid + kCutRegs * kLatThreads; i < n; i += kLatThreads) atomicAdd(&sh.hist[bin_of(cost[i])], 1u);
   __syncthreads();
-  if (tid < 64) {
-    int mine = 0;
-    for (int b = 0; b < 32; ++b) mine += (int)sh.hist[tid * 32 + b];
+  CUT_T(1);
+  {
+    // prefix sums of the 2048 bins by all threads: two bins per thread, a shuffle scan per wave, the waves' totals through LDS
+    const int h0 = (int)sh.hist[2 * tid], h1 = (int)sh.hist[2 * tid + 1];
+    const int mine = h0 + h1;
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(incl, o, 64);
-      if (tid >= o) incl += y;
+      if (lane >= o) incl += y;
     }
-    const int before = incl - mine;
+    if (lane == 63) sh.heavy_tok[w] = incl;            // (the heavy-token queue is idle in this phase)
+    __syncthreads();
+    int before = incl - mine;
+    for (int v = 0; v < w; ++v) before += sh.heavy_tok[v];
     const int c_lt = n - (int)sh.hist[2047];
-    if (c_lt > k && k >= before && k < incl) {
-      int kk = k - before, b = 0;
-      for (; b < 32; ++b) {
-        const int c = (int)sh.hist[tid * 32 + b];
-        if (kk < c) break;
-        kk -= c;
-      }
-      sh.sel_prefix = (uint32_t)(tid * 32 + b);
+    if (c_lt > k && k >= before && k < before + mine) {
+      int kk = k - before, b = 2 * tid;
+      if (kk >= h0) { kk -= h0; ++b; }
+      sh.sel_prefix = (uint32_t)b;
       sh.sel_k = kk;
     }
   }
   __syncthreads();
+  CUT_T(2);
   if (sh.sel_k < 0) return false;
   const int sel_bin = (int)sh.sel_prefix, kk = sh.sel_k;
   __syncthreads();
-  for (int i = tid; i < n; i += kLatThreads) {
-    const float c = cost[i];
+  auto member = [&](float c) {
     if (bin_of(c) == sel_bin) {
       const int m = atomicAdd(&sh.redi[0], 1);
       if (m < 2048) sh.hist[m] = enc_cost(c);     // the bins are no longer needed
     }
-  }
+  };
+#pragma unroll
+  for (int q = 0; q < kCutRegs; ++q)
+    if (tid + q * kLatThreads < n) member(cr[q]);
+  for (int i = tid + kCutRegs * kLatThreads; i < n; i += kLatThreads) member(cost[i]);
   __syncthreads();
+  CUT_T(3);
   const int m = sh.redi[0];
   if (m > 2048) {             // many equal costs: the general selection
     __syncthreads();
@@ -230,12 +329,11 @@ __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, S
   __syncthreads();
   *out = dec_cost(sh.sel_prefix);
   __syncthreads();
+  CUT_T(4);
   return true;
 }
 
-__global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ Shared sh;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_cutoff(const DecodeParams& p, const TeamCtx& c, Shared& sh) {
   if (!c.live || c.t < 0) return;
   const int tid = threadIdx.x;
   if (tid == 0) sh.n_heavy = 0;
@@ -263,12 +361,13 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodePar
   }
   if (tid == 0) { F->cur_cutoff = cur_cutoff; F->adaptive = adaptive; F->n_arcs = 0; F->nmin_key = kEmpty; }
 }
+__global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  phase_cutoff(p, team_ctx(p, cnt, local), sh);
+}
 
 // ---- arc work list of the surviving tokens, arc costs, best new cost ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ Shared sh;
-  __shared__ int s_base;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_base) {
   if (!c.live || c.t < 0) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -339,11 +438,14 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
   nmin = block_min(nmin, sh);
   if (tid == 0 && nmin < INFINITY) atomicMin(&F->nmin_key, enc_cost(nmin));
 }
+__global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  __shared__ int s_base;
+  phase_list(p, team_ctx(p, cnt, local), sh, s_base);
+}
 
 // ---- tokens and emitting links of frame t+1 ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ int s_flag;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCtx& c, int& s_flag) {
   if (!c.live || c.t < 0) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -389,6 +491,16 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodePar
     }
     int ti = wave_alloc_n(&F->n_new, n_made);
     int n_eps = 0;
+    {
+      int tq = ti;      // heavy states go to the team's list (rare: a per-lane atomic)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (eps[q] && p.g.n_off[er[q].x + 1] - p.g.n_off[er[q].x] > kHeavyDegree && fb + tq < V.tok_cap &&
+            team_register_heavy(F, c.G, fb + tq))
+          eps[q] = false;
+        tq += made[q];
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) n_eps += eps[q];
     int ei = wave_alloc_n(&F->n_elist, n_eps);
@@ -420,15 +532,17 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodePar
   }
   if (team_last(F, c.G, &s_flag) && tid == 0) {
     F->ne_snap = min(ld_coherent(&F->n_elist), V.tok_cap);
+    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
     F->build_cutoff = next_cutoff;
   }
 }
+__global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ int s_flag;
+  phase_expand(p, team_ctx(p, cnt, local), s_flag);
+}
 
 // ---- link destinations (state -> token index), epsilon relaxation round 0 ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_round0(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ Shared sh;
-  __shared__ int s_flag;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag) {
   if (!c.live) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -437,36 +551,45 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_round0(const DecodePar
   const int fb = F->f1, l0 = F->link_end, nl = min(F->n_link, V.link_cap - l0);
   for (int l = l0 + c.wg * kLatThreads + tid; l < l0 + nl; l += c.G * kLatThreads) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
   __syncthreads();
-  const int changed = eps_round(p, V, F, sh, fb, F->build_cutoff, F->ne_snap, c.wg, c.G);
+  const int changed = eps_round(p, V, F, sh, fb, F->build_cutoff, F->ne_snap, F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[0], 1);
   if (team_last(F, c.G, &s_flag) && tid == 0) {
     F->link_end = l0 + nl;
     V.seg[2 * c.t + 2] = l0 + nl;
     st_coherent(&F->n_link, 0);
     F->ne_snap = min(ld_coherent(&F->n_elist), V.tok_cap);
+    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
   }
+}
+__global__ void __launch_bounds__(kLatThreads) lat_frames_round0(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  __shared__ int s_flag;
+  phase_round0(p, team_ctx(p, cnt, local), sh, s_flag);
 }
 
 // ---- epsilon relaxation round r >= 1 ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_round(const DecodeParams p, const StepCounter* cnt, int local, int r) {
-  __shared__ Shared sh;
-  __shared__ int s_flag;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_round(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, int r) {
   if (!c.live) return;
   LatFrame* F = c.F;
   if (!F->changed[r - 1]) return;
   const int tid = threadIdx.x;
   if (tid == 0) sh.n_heavy = 0;
   __syncthreads();
-  const int changed = eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, F->ne_snap, c.wg, c.G);
+  const int changed = eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, F->ne_snap, F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[r], 1);
-  if (team_last(F, c.G, &s_flag) && tid == 0) F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  if (team_last(F, c.G, &s_flag) && tid == 0) {
+    F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
+  }
+}
+__global__ void __launch_bounds__(kLatThreads) lat_frames_round(const DecodeParams p, const StepCounter* cnt, int local, int r) {
+  __shared__ Shared sh;
+  __shared__ int s_flag;
+  phase_round(p, team_ctx(p, cnt, local), sh, s_flag, r);
 }
 
 // ---- deeper epsilon chains: one workgroup relaxes to the fixed point ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_tail(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ Shared sh;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_tail(const DecodeParams& p, const TeamCtx& c, Shared& sh) {
   if (!c.live) return;
   LatFrame* F = c.F;
   if (!F->changed[kLatEpsRounds]) return;
@@ -475,19 +598,24 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_tail(const DecodeParam
   __syncthreads();
   for (int rounds = 0; ; ++rounds) {
     const int ne = min(ld_coherent(&F->n_elist), c.V.tok_cap);   // single workgroup: its own appends, ordered by the barriers
-    if (!eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, ne, 0, 1)) break;
+    const int nh = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
+    if (!eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, ne, nh, 0, 1, c.G)) break;
     if (ld_coherent(&F->status) != kLatOk) break;
     if (rounds > kMaxEpsRounds) { if (tid == 0) F->status = kLatEpsilonLoop; break; }
   }
   __syncthreads();
-  if (tid == 0) F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  if (tid == 0) {
+    F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
+  }
+}
+__global__ void __launch_bounds__(kLatThreads) lat_frames_tail(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  phase_tail(p, team_ctx(p, cnt, local), sh);
 }
 
 // ---- the frame is closed: epsilon links from the final costs, final token costs, arc ranges, best cost ----
-__global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ Shared sh;
-  __shared__ int s_flag;
-  const TeamCtx c = team_ctx(p, cnt, local);
+__device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag) {
   if (!c.live) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -496,21 +624,22 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodePara
   __syncthreads();
   const int fb = F->f1, l0 = F->link_end;
   const float cutoff = F->build_cutoff;
+  auto eps_link = [&](int i, float cc, int a) {
+    const float tot = cc + p.g.n_w[a];
+    const int li = l0 + wave_alloc(&F->n_link, tot < cutoff);
+    if (tot < cutoff) {
+      if (li < V.link_cap) {
+        V.lrec[li] = make_int4(i, fb + V.stt[p.g.n_dst[a]], 0, __float_as_int(p.g.n_w[a]));
+        V.lac[li] = 0.f;
+      } else {
+        st_coherent(&F->status, (int32_t)kLatLinkOverflow);
+      }
+    }
+  };
   for_each_arc(sh, V.elist, F->ne_snap, V.ts, p.g.n_off,
                [&](int i, float* cc) { *cc = dec_cost(V.stc[V.ts[i]]); return *cc < cutoff; },
-               [&](int i, float cc, int a) {
-                 const float tot = cc + p.g.n_w[a];
-                 const int li = l0 + wave_alloc(&F->n_link, tot < cutoff);
-                 if (tot < cutoff) {
-                   if (li < V.link_cap) {
-                     V.lrec[li] = make_int4(i, fb + V.stt[p.g.n_dst[a]], 0, __float_as_int(p.g.n_w[a]));
-                     V.lac[li] = 0.f;
-                   } else {
-                     st_coherent(&F->status, (int32_t)kLatLinkOverflow);
-                   }
-                 }
-               },
-               c.wg * kLatThreads + tid, c.G * kLatThreads);
+               eps_link, team_entry(c.wg, c.G), c.G * kLatThreads);
+  team_heavy_arcs(p, V, F, sh, F->nh_snap, c.wg, c.G, c.G, cutoff, false, eps_link);
   // final costs and arc ranges of the new tokens (the state table is cleared by the next frame's list launch)
   const int cnt_new = min(F->n_new, V.tok_cap - fb);
   uint32_t kmin = kEmpty;
@@ -544,10 +673,188 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodePara
     F->f0 = fb; F->f1 = tok_end; F->link_end = link_end;
     F->best_key = ld_coherent(&F->best_next);
     st_coherent(&F->best_next, kEmpty);
-    st_coherent(&F->n_new, 0); st_coherent(&F->n_link, 0); st_coherent(&F->n_elist, 0);
-    F->ne_snap = 0;
+    st_coherent(&F->n_new, 0); st_coherent(&F->n_link, 0); st_coherent(&F->n_elist, 0); st_coherent(&F->n_hlist, 0);
+    F->ne_snap = 0; F->nh_snap = 0;
     for (int r = 0; r <= kLatEpsRounds; ++r) st_coherent(&F->changed[r], 0);
   }
+}
+__global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodeParams p, const StepCounter* cnt, int local) {
+  __shared__ Shared sh;
+  __shared__ int s_flag;
+  phase_close(p, team_ctx(p, cnt, local), sh, s_flag);
+}
+
+// ---- the same frames inside ONE launch: a team of workgroups of one XCD per utterance ----
+// A kernel boundary between two phases of a frame costs the graph-replayed launch chain ~4-5 us (dependent launch, cold
+// L1s, parameters) around 2-4 us of work; eight of them per frame.  Here the phases of ALL frames of an utterance run
+// inside one launch: the G workgroups of a team sit on the CUs of ONE XCD (teams form by arrival order under the XCC_ID
+// register, as in the persistent recurrences; utterances are handed out from a queue), so everything they exchange lives
+// in that XCD's L2.  Between two phases: every thread waits for its stores (the vector L1 writes through: they are in
+// L2 then), the team meets at a counter in L2 (one agent-scope atomic per workgroup, one thread polls), and the L1 is
+// invalidated (buffer_inv sc1) before the next phase reads what the others wrote.  The phase bodies are the launch-per-
+// frame kernels' own; rounds that have nothing to do are skipped WITH their barrier (the flags they test are final
+// behind the barrier of the round before), and an utterance stops at its own last frame, not at the longest one's.
+// A poll that waits longer than 1 s raises the abort flag: everybody leaves, lat_persist_check marks the utterances "not
+// decoded" and the caller's summary reports it; the first launch on a device is verified on the host and the launch-per-
+// frame decoder takes over when it does not come back complete.
+constexpr int kLatTeamsPerXcd = 4;
+constexpr int kLatMaxIter = 64;
+constexpr long long kLatSpinTicks = 1000LL * 1000 * 100;     // 1 s of the 100 MHz wall clock
+struct LatTeamCtl {
+  unsigned arrive[8];
+  unsigned next_utt, abort, done, pad[5];
+  struct Team { unsigned task[kLatMaxIter + 1]; unsigned bar; unsigned pad[62]; } team[8][kLatTeamsPerXcd];
+};
+
+struct LatSpin {
+  LatTeamCtl* ctl; long long t0; unsigned n;
+  __device__ __forceinline__ explicit LatSpin(LatTeamCtl* c) : ctl(c), t0(0), n(0) {}
+  __device__ __forceinline__ bool expired() {
+    if ((++n & 255u) != 0u) return false;
+    const long long now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    if (now - t0 > kLatSpinTicks || ld_coherent(&ctl->abort)) {
+      st_coherent(&ctl->abort, 1u);
+      return true;
+    }
+    return false;
+  }
+};
+
+// Team barrier between two phases (see above).  Returns false after an abort.
+__device__ __forceinline__ bool lat_team_barrier(LatTeamCtl* ctl, LatTeamCtl::Team* tm, int G, unsigned* nbar, int* s_abort, int inv_mode) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned target = (unsigned)G * ++*nbar;
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(&tm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      LatSpin spin(ctl);
+      while (ld_coherent(&tm->bar) < target) {
+        if (spin.expired()) { *s_abort = 1; break; }
+      }
+    }
+    // what the other workgroups wrote before the barrier is in L2: drop the (now possibly stale) lines of this CU's L1
+    // and of the scalar cache -- ONE wave does it for the workgroup
+    if (inv_mode == 1) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (inv_mode == 2) asm volatile("buffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (inv_mode == 0) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (inv_mode == 3) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  return *s_abort == 0;
+}
+
+__global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodeParams p, LatTeamCtl* ctl, int N, int G, int teams_per_xcd, int inv_mode) {
+  __shared__ Shared sh;
+  __shared__ int s_flag, s_base, s_abort, s_i[4];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    unsigned xcd;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
+    xcd &= 7u;
+    const unsigned slot = __hip_atomic_fetch_add(&ctl->arrive[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_i[0] = (int)(slot % (unsigned)G); s_i[1] = (int)(slot / (unsigned)G); s_i[2] = (int)xcd;
+    s_abort = 0;
+  }
+  __syncthreads();
+  const int rank = s_i[0];
+  if (s_i[1] >= teams_per_xcd) return;                     // (whole teams only; the host sizes them for 32 CUs per XCD)
+  LatTeamCtl::Team* tm = &ctl->team[s_i[2]][s_i[1]];
+  unsigned nbar = 0;
+#ifdef PK2_LATP_PROFILE
+  long long lp_acc[16], lp_last = 0; int lp_frames = 0;
+  for (int k = 0; k < 16; ++k) lp_acc[k] = 0;
+#define LP_T(k) do { const long long n_ = wall_clock64(); lp_acc[k] += n_ - lp_last; lp_last = n_; } while (0)
+#else
+#define LP_T(k) do { } while (0)
+#endif
+  for (int iter = 0; iter <= kLatMaxIter; ++iter) {
+    // the team's next utterance
+    if (tid == 0) {
+      unsigned k;
+      if (rank == 0) {
+        k = __hip_atomic_fetch_add(&ctl->next_utt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_coherent(&tm->task[iter], k + 1u);
+      } else {
+        LatSpin spin(ctl);
+        unsigned k1;
+        while ((k1 = ld_coherent(&tm->task[iter])) == 0u) {
+          if (spin.expired()) { s_abort = 1; k1 = 1u << 30; break; }
+        }
+        k = k1 - 1u;
+      }
+      s_i[3] = (int)k;
+    }
+    __syncthreads();
+    const int n = s_i[3];
+    if (s_abort || n >= N) return;
+    if (rank == 0) phase_init(p, n, G);
+    if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+    const int T = p.L.utt[n].T;
+    LatFrame* F = p.L.frame + n;
+    for (int t = -1; t < T; ++t) {
+      const TeamCtx c = team_ctx_of(p, n, rank, G, t);
+#ifdef PK2_LATP_PROFILE
+      lp_last = wall_clock64(); ++lp_frames;
+#endif
+      if (t >= 0) {
+        // (nobody writes the status between the barrier that closed the previous frame and the one behind the cutoff)
+        if (ld_coherent(&F->status) != kLatOk) break;
+        if (rank == 0) phase_cutoff(p, c, sh);
+        LP_T(0);
+        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LP_T(1);
+        phase_list(p, c, sh, s_base);
+        LP_T(2);
+        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LP_T(3);
+        phase_expand(p, c, s_flag);
+        LP_T(4);
+        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LP_T(5);
+      }
+      phase_round0(p, c, sh, s_flag);
+      LP_T(6);
+      if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+      LP_T(7);
+      for (int r = 1; r <= kLatEpsRounds; ++r) {
+        if (!ld_coherent(&F->changed[r - 1])) break;       // (later rounds find their flag clear as well)
+        phase_round(p, c, sh, s_flag, r);
+        LP_T(8);
+        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LP_T(9);
+      }
+      if (ld_coherent(&F->changed[kLatEpsRounds])) {
+        if (rank == 0) phase_tail(p, c, sh);
+        LP_T(10);
+        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LP_T(11);
+      }
+      phase_close(p, c, sh, s_flag);
+      LP_T(12);
+      if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+      LP_T(13);
+    }
+#ifdef PK2_LATP_PROFILE
+    if (tid == 0 && rank == 0 && n == 0)
+      printf("kth_below, 10 ns ticks per frame: zero hist %lld | pass 1 %lld | scan %lld | pass 2 %lld | rank %lld\n", g_cut[0] / lp_frames,
+             g_cut[1] / lp_frames, g_cut[2] / lp_frames, g_cut[3] / lp_frames, g_cut[4] / lp_frames);
+    if (tid == 0 && rank < 2 && n == 0)
+      printf("lat_frames_persist rank %d utt 0, %d frames, 10 ns ticks per frame: cutoff %lld bar %lld | list %lld bar %lld | expand %lld bar %lld | round0 %lld bar %lld | rounds %lld bar %lld | tail %lld bar %lld | close %lld bar %lld\n",
+             rank, lp_frames, lp_acc[0] / lp_frames, lp_acc[1] / lp_frames, lp_acc[2] / lp_frames, lp_acc[3] / lp_frames, lp_acc[4] / lp_frames,
+             lp_acc[5] / lp_frames, lp_acc[6] / lp_frames, lp_acc[7] / lp_frames, lp_acc[8] / lp_frames, lp_acc[9] / lp_frames, lp_acc[10] / lp_frames,
+             lp_acc[11] / lp_frames, lp_acc[12] / lp_frames, lp_acc[13] / lp_frames);
+#endif
+    if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Behind the persistent launch: an aborted or incomplete launch leaves every utterance "not decoded".
+__global__ void lat_persist_check(const DecodeParams p, const LatTeamCtl* ctl, int N, unsigned* sticky) {
+  if (ctl->abort == 0u && ctl->done == (unsigned)N) return;
+  *sticky = 1u;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) p.L.frame[n].status = kLatNotDecoded;
 }
 
 // ---- after the last frame: final costs + lattice-beam pruning, or the failure report ----
@@ -740,11 +1047,93 @@ struct LatGraphSlot { int id; uint64_t last_use; };
 static std::map<std::string, LatGraphSlot> g_lat_keys;
 static uint64_t g_lat_clock = 0;
 
+// ---- host side of the persistent decoder ----
+struct LatPersistScratch { LatTeamCtl* ctl = nullptr; unsigned* sticky = nullptr; };
+static std::map<hipStream_t, LatPersistScratch> g_lat_persist;
+static int g_lat_persist_state = -1;      // -1: not tried on this device yet, 1: verified, 0: did not come back complete -> launch per frame
+
+static bool lat_persist_wanted(int team) {
+  static const int mode = [] {
+    const char* e = getenv("PK2_LAT_DECODER");
+    return (e && strcmp(e, "frames") == 0) ? 0 : 1;
+  }();
+  if (!mode || g_lat_persist_state == 0 || (team != 8 && team != 16 && team != 32)) return false;
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  return cus == 256;                      // 8 XCDs x 32 CUs: what the team formation assumes
+}
+
+static int lat_persist_launch(const DecodeParams& p, int N, int team, hipStream_t stream, bool* ran) {
+  *ran = false;
+  LatPersistScratch& sc = g_lat_persist[stream];
+  if (!sc.ctl) {
+    PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(LatTeamCtl)));
+    PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.sticky), sizeof(unsigned)));
+    PK2_HIP(hipMemsetAsync(sc.sticky, 0, sizeof(unsigned), stream));
+  }
+  PK2_HIP(hipMemsetAsync(sc.ctl, 0, sizeof(LatTeamCtl), stream));
+  // one team per XCD while the utterances fit (an utterance then has its XCD's L2 to itself), more when there are more
+  const int tpx = std::max(1, std::min({32 / team, kLatTeamsPerXcd, (N + 7) / 8}));
+  static const int inv_mode = [] { const char* e = getenv("PK2_LAT_INV"); return e ? atoi(e) : 1; }();
+  hipLaunchKernelGGL(lat_frames_persist, dim3(256), dim3(kLatThreads), 0, stream, p, sc.ctl, N, team, tpx, inv_mode);
+  PK2_LAUNCH_CHECK();
+  if (g_lat_persist_state < 0) {          // first use on this device: every utterance done, nobody timed out?
+    LatTeamCtl* h = new LatTeamCtl;
+    hipError_t e = hipMemcpyAsync(h, sc.ctl, sizeof(LatTeamCtl), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)N;
+    delete h;
+    if (e != hipSuccess) { set_error("lattice decode (persistent): %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
+    g_lat_persist_state = ok ? 1 : 0;
+    if (!ok) {                            // the caller decodes again, a launch per frame: give it clean state tables
+      PK2_HIP(hipMemsetAsync(p.L.st_cost, 0xFF, sizeof(uint32_t) * (size_t)N * p.g.S, stream));
+      PK2_HIP(hipMemsetAsync(p.L.st_tok, 0xFF, sizeof(int32_t) * (size_t)N * p.g.S, stream));
+      return PK2_OK;
+    }
+  }
+  hipLaunchKernelGGL(lat_persist_check, dim3(1), dim3(64), 0, stream, p, sc.ctl, N, sc.sticky);
+  PK2_LAUNCH_CHECK();
+  *ran = true;
+  return PK2_OK;
+}
+
+// 1: the persistent decoder is in use on this device, 0: it is not (disabled, or it failed its first launch), -1: not tried;
+// *abort_flag: some launch since start-up was marked "not decoded" by its check kernel.
+int lattice_persist_status(unsigned* abort_flag) {
+  unsigned any = 0;
+  for (auto& kv : g_lat_persist) {
+    unsigned st = 0;
+    if (kv.second.sticky && hipMemcpy(&st, kv.second.sticky, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) any |= st;
+  }
+  *abort_flag = any;
+  return g_lat_persist_state;
+}
+
+static int lattice_decode_frames_graphs(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream);
+static int lattice_finish_and_prune(const DecodeParams& p, int N, hipStream_t stream);
+
 int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream) {
+  bool ran = false;
+  if (lat_persist_wanted(team)) {
+    int rc = lat_persist_launch(p, N, team, stream, &ran);
+    if (rc) return rc;
+  }
+  if (!ran) {
+    int rc = lattice_decode_frames_graphs(p, N, Tmax, team, stream);
+    if (rc) return rc;
+  }
+  return lattice_finish_and_prune(p, N, stream);
+}
+
+static int lattice_decode_frames_graphs(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream) {
   StepCounter*& counter = g_lat_counters[stream];
   if (!counter) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&counter), sizeof(StepCounter)));
   const StepCounter* cnt = counter;
-  hipLaunchKernelGGL(lat_frames_init, dim3(N), dim3(64), 0, stream, p);
+  hipLaunchKernelGGL(lat_frames_init, dim3(N), dim3(64), 0, stream, p, team);
   PK2_LAUNCH_CHECK();
   // the log-likelihood tensor is the one pointer that moves from call to call: the frame kernels take it from the
   // per-utterance state (written by lat_frames_init), not from the baked parameters
@@ -780,7 +1169,11 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
     hipLaunchKernelGGL(lat_frames_tail, one, thr, 0, s, pk, cnt, j);
     hipLaunchKernelGGL(lat_frames_close, all, thr, 0, s, pk, cnt, j);
   });
-  if (rc) return rc;
+  return rc;
+}
+
+static int lattice_finish_and_prune(const DecodeParams& p, int N, hipStream_t stream) {
+  const dim3 thr(kLatThreads);
   // lattice-beam pruning: the per-link constants in parallel, then the serial pass with two frames' extra costs in LDS
   constexpr int kFinCap = 19456;                   // tokens of a frame the LDS arrays hold (2 x 76 KB)
   static bool attr = false;

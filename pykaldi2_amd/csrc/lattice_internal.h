@@ -51,6 +51,8 @@ enum LatStatus : int32_t {
 // Decoding state of one utterance between the launches of a frame (lattice_decode_frames.hip: a team of workgroups
 // per utterance, several launches per frame).  Counters are bumped with agent-scope atomics; the plain fields are
 // written by the last workgroup of a launch to finish and read by the next launch.
+constexpr int kLatTeamHeavy = 16;  // heavy tokens of a frame the team list holds (further ones stay with their owner)
+constexpr int kLatMaxTeam = 64;    // workgroups per team (PK2_LAT_TEAM) the per-workgroup bookkeeping has room for
 constexpr int kLatEpsRounds = 2;   // epsilon relaxation launches per frame after round 0; a one-workgroup tail finishes deeper chains
 struct LatFrame {
   int32_t f0, f1;              // tokens of the frame being expanded (utterance-local); new tokens are appended at f1
@@ -63,6 +65,12 @@ struct LatFrame {
   float cur_cutoff, adaptive, build_cutoff;
   int32_t status, arrive;
   int32_t changed[kLatEpsRounds + 1];
+  // Tokens of the frame being built whose state has very many epsilon arcs (the word-loop state: one per word): their arcs
+  // are dealt to ALL workgroups of the team (left to the token's owner, that workgroup walked 20 k arcs while the others
+  // waited: 6 of the 9 us of every relaxation round).  hlast[h][w] = the token's cost when workgroup w last walked its share.
+  int32_t n_hlist, nh_snap;
+  int32_t hlist[kLatTeamHeavy];
+  float hlast[kLatTeamHeavy * kLatMaxTeam];
   const float* ll_base;        // the utterance's log-likelihood rows (kept out of the graph-baked parameters)
   int64_t ll_stride;
   double fb_tot, fb_score;     // lattice forward-backward: total log-likelihood, expected accuracy

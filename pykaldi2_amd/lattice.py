@@ -396,6 +396,16 @@ class LatticeBatch:
                     best_cost=float(total[end]))
 
 
+def persistent_decoder_status():
+    """(state, abort): state 1 = all frames of an utterance are decoded inside one persistent launch on this device,
+    0 = disabled or it failed its host-verified first launch (the launch-per-frame decoder has taken over), -1 = no decode
+    yet; abort != 0: a later launch timed out and its utterances were reported "not decoded"."""
+    import ctypes
+    state, flag = ctypes.c_int32(-1), ctypes.c_uint32(0)
+    _lib.check(_lib.lib().pk2_lattice_persist_status(ctypes.byref(state), ctypes.byref(flag)))
+    return int(state.value), int(flag.value)
+
+
 class MappedLatticeFasterRecognizer:
     """On-the-fly lattice generator with the reference's construction signature
     (bin/train_se.py:180-183: `MappedLatticeFasterRecognizer.from_files(trans_model, HCLG, words_txt,

@@ -290,6 +290,41 @@ def test_one_workgroup_decoder_variant():
     assert " passed" in out.stdout and "failed" not in out.stdout
 
 
+@pytest.mark.parametrize("env", [dict(PK2_LAT_DECODER="frames"), dict(PK2_LAT_TEAM="8"), dict(PK2_LAT_TEAM="32")],
+                         ids=["launch_per_frame", "persistent_team8", "persistent_team32"])
+def test_team_decoder_variants(env):
+    """The default decoder runs all frames of an utterance inside one persistent launch (a team of 16 workgroups of one
+    XCD); the launch-per-frame decoder (its fallback) and the other team sizes pass the same oracle comparisons in their own
+    processes (the choice is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_lattice.py"), "-q", "-m", "gpu",
+                          "-k", "matches_oracle or ragged or heavy or overflow or persistent_decoder_is_in_use"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+def test_persistent_decoder_is_in_use():
+    """After a decode on an MI355X the library reports which decoder ran: the persistent one unless PK2_LAT_DECODER says
+    otherwise, and never a time-out."""
+    import os
+    g = synth.decoding_graph_arcs(30, 40, seed=3)
+    tm = synth.transition_model_arrays(40)
+    rec = _recognizer(g, tm, 10.0, 5.0, 1.0)
+    rng = np.random.default_rng(5)
+    lat = rec.decode_batch(torch.from_numpy(rng.standard_normal((3, 25, 40)).astype(np.float32)).cuda(), [25, 11, 18])
+    assert (lat.status == 0).all()
+    state, abort = lattice.persistent_decoder_status()
+    assert abort == 0
+    if os.environ.get("PK2_LAT_DECODER") in ("frames", "wg"):
+        assert state in (-1, 0)
+    else:
+        assert state == 1
+
+
 FULL_SIZE_WORKER = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %(root)r)
