@@ -125,6 +125,26 @@ __device__ __forceinline__ bool team_register_heavy(LatFrame* F, int G, int tok)
   return true;
 }
 
+// Two such reservations with both atomics in flight together (one round trip to L2 instead of two).
+__device__ __forceinline__ void wave_alloc_n2(int32_t* counter_a, int count_a, int32_t* counter_b, int count_b, int* first_a,
+                                              int* first_b) {
+  const int lane = threadIdx.x & 63;
+  int ia = count_a, ib = count_b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ya = __shfl_up(ia, o, 64), yb = __shfl_up(ib, o, 64);
+    if (lane >= o) { ia += ya; ib += yb; }
+  }
+  const int ta = __shfl(ia, 63, 64), tb = __shfl(ib, 63, 64);
+  int base_a = 0, base_b = 0;
+  if (lane == 63) {
+    if (ta > 0) base_a = atomicAdd(counter_a, ta);
+    if (tb > 0) base_b = atomicAdd(counter_b, tb);
+  }
+  *first_a = __shfl(base_a, 63, 64) + ia - count_a;
+  *first_b = __shfl(base_b, 63, 64) + ib - count_b;
+}
+
 // Called by every lane that created the token of state d (old == kEmpty); others pass create = false.
 __device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int G, int fb, int d,
                                                     bool create = true) {
@@ -478,32 +498,30 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
       n_acc += acc[q];
       if (acc[q]) er[q] = V.erec[wk[q].y];
     }
+    // one hop: atomicMin on the table, the link slots, the epsilon degree of the destinations
+    int deg[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (acc[q]) old[q] = atomicMin(&V.stc[er[q].x], enc_cost(tc2[q].x));
+    for (int q = 0; q < 4; ++q) {
+      deg[q] = 0;
+      if (acc[q]) {
+        old[q] = atomicMin(&V.stc[er[q].x], enc_cost(tc2[q].x));
+        deg[q] = p.g.n_off[er[q].x + 1] - p.g.n_off[er[q].x];
+      }
+    }
     int li = l0 + wave_alloc_n(&F->n_link, n_acc);
-    int n_made = 0;
+    int n_made = 0, n_eps = 0;
+    bool heavy[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       made[q] = acc[q] && old[q] == kEmpty;
       n_made += made[q];
-      eps[q] = made[q] && p.g.n_off[er[q].x + 1] > p.g.n_off[er[q].x];
+      heavy[q] = made[q] && deg[q] > kHeavyDegree;          // -> the team's heavy list
+      eps[q] = made[q] && deg[q] > 0 && !heavy[q];
+      n_eps += eps[q];
     }
-    int ti = wave_alloc_n(&F->n_new, n_made);
-    int n_eps = 0;
-    {
-      int tq = ti;      // heavy states go to the team's list (rare: a per-lane atomic)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (eps[q] && p.g.n_off[er[q].x + 1] - p.g.n_off[er[q].x] > kHeavyDegree && fb + tq < V.tok_cap &&
-            team_register_heavy(F, c.G, fb + tq))
-          eps[q] = false;
-        tq += made[q];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) n_eps += eps[q];
-    int ei = wave_alloc_n(&F->n_elist, n_eps);
+    // one hop: token slots and epsilon-list slots together
+    int ti, ei;
+    wave_alloc_n2(&F->n_new, n_made, &F->n_elist, n_eps, &ti, &ei);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!acc[q]) continue;
@@ -515,6 +533,10 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
           if (eps[q]) {
             if (ei < V.tok_cap) V.elist[ei] = fb + ti; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
             ++ei;
+          }
+          if (heavy[q] && !team_register_heavy(F, c.G, fb + ti)) {      // (rare; the list is full: an ordinary entry)
+            const int e = atomicAdd(&F->n_elist, 1);
+            if (e < V.tok_cap) V.elist[e] = fb + ti; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
           }
         } else {
           st_coherent(&F->status, (int32_t)kLatTokenOverflow);
@@ -791,10 +813,11 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
     if (s_abort || n >= N) return;
     if (rank == 0) phase_init(p, n, G);
     if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
-    const int T = p.L.utt[n].T;
-    LatFrame* F = p.L.frame + n;
+    TeamCtx c = team_ctx_of(p, n, rank, G, -1);            // (the utterance's record and views: once, not per frame)
+    const int T = c.T;
+    LatFrame* F = c.F;
     for (int t = -1; t < T; ++t) {
-      const TeamCtx c = team_ctx_of(p, n, rank, G, t);
+      c.t = t;
 #ifdef PK2_LATP_PROFILE
       lp_last = wall_clock64(); ++lp_frames;
 #endif
