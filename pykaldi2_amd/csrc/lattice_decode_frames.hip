@@ -757,13 +757,11 @@ __device__ __forceinline__ bool lat_team_barrier(LatTeamCtl* ctl, LatTeamCtl::Te
       }
     }
     // what the other workgroups wrote before the barrier is in L2: drop the (now possibly stale) lines of this CU's L1
-    // and of the scalar cache -- ONE wave does it for the workgroup
+    // and of the scalar cache -- ONE wave does it for the workgroup (PK2_LAT_INV=0, every wave: the decode took 2.2x as long)
     if (inv_mode == 1) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (inv_mode == 2) asm volatile("buffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   __syncthreads();
   if (inv_mode == 0) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  if (inv_mode == 3) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   return *s_abort == 0;
 }
 

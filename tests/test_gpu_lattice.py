@@ -301,10 +301,31 @@ def test_team_decoder_variants(env):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_lattice.py"), "-q", "-m", "gpu",
-                          "-k", "matches_oracle or ragged or heavy or overflow or persistent_decoder_is_in_use"],
+                          "-k", "matches_oracle or ragged or heavy or overflow or persistent_decoder_is_in_use or take_turns"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+def test_more_utterances_than_teams_take_turns():
+    """21 ragged utterances against the oracle, one by one: with a team of 16 workgroups per utterance the persistent decoder
+    has 2 teams per XCD = 16 teams, so five teams decode a second utterance from the queue (PK2_LAT_TEAM=32: 8 teams, up to
+    three each); a word-loop graph, so every frame has a heavy token dealt to the whole team."""
+    P, beam, lb, ac = 80, 9.0, 4.0, 0.5
+    g, tm, _, rng = _setup(70, P, 1, 21)
+    lens = [int(v) for v in rng.integers(5, 60, size=21)]
+    lls = [(2.0 * rng.standard_normal((T, P))).astype(np.float32) for T in lens]
+    x = torch.zeros(len(lens), max(lens), P)
+    for n, a in enumerate(lls):
+        x[n, :lens[n]] = torch.from_numpy(a)
+    rec = _recognizer(g, tm, beam, lb, ac)
+    lat = rec.decode_batch(x.cuda(), lens)
+    assert (lat.status == 0).all()
+    for n, a in enumerate(lls):
+        want = lr.decode(_ref_graph(g), a, tm["tid2pdf"], lr.DecoderOptionsRef(beam, lb, 2 ** 31 - 1, 200, 0.5, ac))
+        assert lat.best_cost[n] == np.float32(want.best_cost), n
+        got, ref = _canon(lat.export(n)), _canon(want.arrays())
+        assert got[0] == ref[0] and got[1] == ref[1], n
 
 
 def test_persistent_decoder_is_in_use():
