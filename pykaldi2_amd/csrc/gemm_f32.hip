@@ -165,8 +165,22 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   bt.ksplit = 1;
   bt.klen = K;
   const char* fsplit = getenv("PK2_GEMM_SPLITK");
-  if (big_tiles <= 256 && K >= 2048 && (!fsplit || atoi(fsplit) != 1)) {   // (measured: no gain above one tile per CU)
+  // (above one 128x128 tile per CU a plain grid of them gains nothing from slices -- but below two per CU the plain choice
+  // is 64x64 tiles at half the intensity: 5768 x 1024 x 20480, the CE output layer's weight gradient, ran at 81 TFLOP/s, 92
+  // over three slices, ~125 over eleven; weight-gradient form only -- 2276 x 2560 x 2048 (A W^T) lost 7 % -- PK2_GEMM_SPLIT_MID=0 restores it)
+  static const bool split_mid = [] { const char* e = getenv("PK2_GEMM_SPLIT_MID"); return !(e && atoi(e) == 0); }();
+  if ((big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= 2048 && (!fsplit || atoi(fsplit) != 1)) {
     int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / PK2_GEMM_MIN_KSLICE);
+    if (big_tiles > 256) {
+      // between one and two tiles per CU: the slice count that fills whole rounds of the 512 workgroup slots best (368 tiles:
+      // 3 slices leave the last round 28 % idle; measured 2598 us with 3, 2246 with 4, 1998 with 8, 1902 with 16 slices)
+      double best = -1.0;
+      for (int c = 2; c <= std::min(16, K / 1024); ++c) {
+        const int64_t n = big_tiles * c;
+        const double eff = (double)n / (double)((n + 511) / 512 * 512);
+        if (eff >= best) { best = eff; ks = c; }
+      }
+    }
     if (fsplit && atoi(fsplit) > 1) ks = atoi(fsplit);
     if (ks > 1 && (int64_t)n0 * bt.n1 * ks <= 65535) {
       tiles = 2;
