@@ -427,6 +427,199 @@ __global__ void __launch_bounds__(256) lstm_bwd_big_persist(BigBwdParams p, BigC
   }
 }
 
+// ---- backward, 4 x 8 decomposition of the team (the default since the end of round 3) ---------------------------------------
+// The all-gather form above makes every CU read the batch tile's d gates of ALL 4H gate rows, 512 KB per step, out of an L2
+// stream that gives a CU ~34 KB/us: 14.9 of the step's 18.3 us.  Here rank r = (gate g = r / 8, unit group ug = r % 8) keeps
+// W_hh[g H .. g H + 511][64 ug .. + 63] (512 x 64 floats, 128 KB) in LDS and multiplies the tile's d gates OF GATE g ONLY
+// (64 x 512, 128 KB per step) into a PARTIAL d h for its 64 units -- the same 64 x 64 x 512 product as the forward kernel,
+// on the same transposed 16x16x4 tiles.  The four partials of a unit group meet through a 16 KB mailbox per rank in L2
+// (agent-scope 16-byte stores, one "partials ready" flag per rank and step); rank (g, ug) then adds them for batch rows
+// 16 g .. 16 g + 15, computes the gate derivatives of (16 rows, 64 units) and stores all four gates' d gx with agent-scope
+// stores, announced by the step's second flag (which the next step's product waits for on all 32 ranks, as above).
+// Two exchanges per step instead of one, a quarter of the operand traffic.
+struct BigBwd2Params {
+  const float* dy; const float* whh; const float* gates; const float* cells;
+  float* dgx;
+  float* mail;        // [ntasks][kBgR][64][64]: a rank's partial d h of the step
+  unsigned* flags;    // [ntasks][T][kBgR]: d gx of the step stored
+  unsigned* pflags;   // [ntasks][T][kBgR]: partials of the step stored
+  int B, T, D;
+};
+
+__device__ __forceinline__ bg_f32x4 bg_load16_agent(const float* p) {
+  bg_f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// W_hh[g H + k][U0 + n], k < 512, n < 64 -> LDS as Wg[k4][n][4]: the four floats = k 4 k4 .. 4 k4 + 3 (the A operand of the
+// transposed tiles: a lane that is unit n of a column tile and k-phase kq reads ONE 16-byte word per chunk of 16 k's).
+__device__ __forceinline__ void bg_load_w_gate(const float* whh_d, int g, int U0, float* Wg) {
+  for (int idx = threadIdx.x; idx < kBgH * 16; idx += 256) {            // one 16-byte piece (4 of the 64 units) of a gate row
+    const int k = idx >> 4, n4 = idx & 15;
+    const bg_f32x4 v = *reinterpret_cast<const bg_f32x4*>(whh_d + ((size_t)g * kBgH + k) * kBgH + U0 + 4 * n4);
+    float* dst = Wg + ((size_t)(k >> 2) * 64 + 4 * n4) * 4 + (k & 3);
+    dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+  }
+}
+
+// One wave waits for the four ranks of its unit group (lanes 0..3 poll rank 8 g' + ug).
+__device__ __forceinline__ bool bg_wait_group(BigCtl* ctl, const unsigned* pflags, int ug, int* s_i) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    BigSpin spin(ctl);
+    bool ok = true;
+    unsigned v = lane < 4 ? bg_load_u(pflags + 8 * lane + ug) : 1u;
+    while (__ballot(v == 0u) != 0ull) {
+      if (spin.expired()) { ok = false; break; }
+      if (v == 0u) v = bg_load_u(pflags + 8 * lane + ug);
+    }
+    if (!ok && lane == 0) s_i[3] = 1;
+  }
+  __syncthreads();
+  return s_i[3] == 0;
+}
+
+__global__ void __launch_bounds__(256) lstm_bwd_big_persist2(BigBwd2Params p, BigCtl* ctl) {
+  constexpr int H = kBgH;
+  extern __shared__ __attribute__((aligned(16))) float bg_smem[];
+  float* Wg = bg_smem;                                   // [H/4][64][4]
+  int* s_i = reinterpret_cast<int*>(bg_smem + kBgWFloats + 64 * 65);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  BigRole role;
+  if (!bg_register(ctl, s_i, &role)) return;
+  const int rank = role.rank, B = p.B, T = p.T, D = p.D;
+  const int g = rank >> 3, ug = rank & 7, U0 = 64 * ug;
+  const int mtiles = (B + 63) / 64;
+  const size_t yrow = (size_t)D * H, G4 = 4 * H;
+  const int kq = lane >> 4;
+  // the product's lane: batch row 16 w + (lane & 15) of the tile, units 16 nt + 4 kq .. + 3 of the group for nt = 0..3
+  // the pointwise thread: batch row 16 g + (tid >> 4), units 4 (tid & 15) .. + 3
+  const int prow = 16 * g + (tid >> 4), pu = U0 + 4 * (tid & 15);
+  for (int iter = 0; iter <= kBgMaxTasks; ++iter) {
+    const int task = bg_next_task(ctl, role, iter, D * mtiles, s_i);
+    if (task < 0) return;
+    const int d = task % D, m0 = (task / D) * 64;
+    __syncthreads();
+    bg_load_w_gate(p.whh + (size_t)d * 4 * H * H, g, U0, Wg);
+    const unsigned* flags = p.flags + (size_t)task * T * kBgR;
+    const unsigned* pflags = p.pflags + (size_t)task * T * kBgR;
+    float* mail = p.mail + (size_t)task * kBgR * 64 * 64;
+    const int arow = min(m0 + 16 * w + (lane & 15), B - 1);   // (rows past the batch: a valid row, results never used)
+    const float* wbase = Wg + ((size_t)kq * 64 + (lane & 15)) * 4;
+    const int pb = m0 + prow;
+    const bool live = pb < B;
+    const int pbc = min(pb, B - 1);
+    bg_f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    BG_T0();
+    for (int bs = 0; bs < T; ++bs) {
+      const int fstep = T - 1 - bs;
+      const int t = d == 0 ? fstep : T - 1 - fstep;
+      const int tp = d == 0 ? t - 1 : t + 1;             // the forward pass's previous step (c_{t-1})
+      const int tn = d == 0 ? t + 1 : t - 1;             // the step processed just before this one
+      const bool first_fwd = fstep == 0;
+      // forward-pass values of the pointwise items: issued before the waits
+      bg_f32x4 dyv, gt[4], cc, cp = {0.f, 0.f, 0.f, 0.f};
+      {
+        dyv = *reinterpret_cast<const bg_f32x4*>(p.dy + ((size_t)t * B + pbc) * yrow + (size_t)d * H + pu);
+        const float* gr = p.gates + (((size_t)d * T + t) * B + pbc) * G4 + pu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gt[q] = *reinterpret_cast<const bg_f32x4*>(gr + (size_t)q * H);
+        cc = *reinterpret_cast<const bg_f32x4*>(p.cells + (((size_t)d * T + t) * B + pbc) * H + pu);
+        if (!first_fwd) cp = *reinterpret_cast<const bg_f32x4*>(p.cells + (((size_t)d * T + tp) * B + pbc) * H + pu);
+      }
+      BG_T(0);
+      bg_f32x4 dh = dyv;
+      if (bs > 0) {
+        if (!bg_wait_flags(ctl, flags + (size_t)(bs - 1) * kBgR, s_i)) return;
+        BG_T(1);
+        // W_gate x (d gates of gate g)^T: 32 chunks of 16 k's, sixteen 16x16x4 MFMAs each (as the forward kernel)
+        const float* abase = p.dgx + ((size_t)tn * B + arow) * ((size_t)D * G4) + (size_t)d * G4 + (size_t)g * H + 4 * kq;
+        constexpr int kDepth = 8, kChunks = H / 16;
+        bg_f32x4 av[kDepth];
+#pragma unroll
+        for (int c = 0; c < kDepth; ++c) av[c] = *reinterpret_cast<const bg_f32x4*>(abase + 16 * c);
+        __builtin_amdgcn_sched_barrier(0);
+        bg_f32x4 wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const bg_f32x4*>(wbase + 64 * q);
+        bg_f32x4acc acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = bg_f32x4acc{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < kChunks; c0 += kDepth) {
+#pragma unroll
+          for (int cc_ = 0; cc_ < kDepth; ++cc_) {
+            const int c = c0 + cc_;
+            const bg_f32x4 ac = av[cc_];
+            bg_f32x4 wc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wc[q] = wv[q];
+            const float* wn = wbase + (size_t)min(c + 1, kChunks - 1) * (4 * 64 * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const bg_f32x4*>(wn + 64 * q);
+            if (c + kDepth < kChunks) av[cc_] = *reinterpret_cast<const bg_f32x4*>(abase + 16 * (c + kDepth));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q].x, ac.x, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q].y, ac.y, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q].z, ac.z, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q].w, ac.w, acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        BG_T(2);
+        // the partial of (row 16 w + (lane & 15), units 16 q + 4 kq .. + 3) -> this rank's mailbox
+        {
+          float* mrow = mail + ((size_t)rank * 64 + 16 * w + (lane & 15)) * 64 + 4 * kq;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bg_store16_agent(mrow + 16 * q, bg_f32x4{acc[q][0], acc[q][1], acc[q][2], acc[q][3]});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) bg_store_u(const_cast<unsigned*>(pflags) + (size_t)bs * kBgR + rank, 1u);
+        if (!bg_wait_group(ctl, pflags + (size_t)bs * kBgR, ug, s_i)) return;
+        BG_T(3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // (always in the order of the gates: the sum is the same in every rank)
+          const bg_f32x4 pv = bg_load16_agent(mail + ((size_t)(8 * q + ug) * 64 + prow) * 64 + 4 * (tid & 15));
+          dh += pv;
+        }
+      }
+      // gate derivatives of forward step fstep for (row prow, units pu .. pu + 3)
+      bg_f32x4 di, df, dg, dO;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float tc = bg_tanh(cc[j]);
+        const float dcv = dc[j] + dh[j] * gt[3][j] * (1.f - tc * tc);
+        dc[j] = dcv * gt[1][j];
+        di[j] = dcv * gt[2][j] * gt[0][j] * (1.f - gt[0][j]);
+        df[j] = dcv * cp[j] * gt[1][j] * (1.f - gt[1][j]);
+        dg[j] = dcv * gt[0][j] * (1.f - gt[2][j] * gt[2][j]);
+        dO[j] = dh[j] * tc * gt[3][j] * (1.f - gt[3][j]);
+      }
+      if (live) {
+        float* o = p.dgx + ((size_t)t * B + pb) * ((size_t)D * G4) + (size_t)d * G4 + pu;
+        bg_store16_agent(o, di);
+        bg_store16_agent(o + (size_t)H, df);
+        bg_store16_agent(o + (size_t)2 * H, dg);
+        bg_store16_agent(o + (size_t)3 * H, dO);
+      }
+      BG_T(4);
+      // this step's d gates are in L2 before the flag says so
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) bg_store_u(const_cast<unsigned*>(flags) + (size_t)bs * kBgR + rank, 1u);
+      BG_T(5);
+    }
+    BG_PRINT("lstm_bwd_big_persist2 (forward-pass loads | flag wait | product | partials out + group wait | partials in + gate derivatives + d gx stores | ack + barrier + flag)", T);
+    if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // A launch in which a poll timed out (or a task was never finished) must not pass for a result.
 __global__ void lstm_big_check(const BigCtl* ctl, unsigned ntasks, float* out, size_t n, unsigned* sticky) {
   if (ctl->abort == 0u && ctl->done == ntasks) return;
@@ -435,7 +628,8 @@ __global__ void lstm_big_check(const BigCtl* ctl, unsigned ntasks, float* out, s
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
-struct BigScratch { BigCtl* ctl = nullptr; unsigned* flags = nullptr; size_t flag_words = 0; unsigned* sticky = nullptr; };
+struct BigScratch { BigCtl* ctl = nullptr; unsigned* flags = nullptr; size_t flag_words = 0; unsigned* sticky = nullptr;
+                    float* mail = nullptr; size_t mail_floats = 0; };
 static std::map<hipStream_t, BigScratch> g_big_scratch;
 static int g_big_state = -1;             // -1 untested, 0 unusable, 1 verified on this device
 
@@ -512,18 +706,40 @@ int lstm_bwd_big_launch(const float* dy, const float* whh, const float* gates, c
   if (g_big_state != 1) return PK2_OK;   // the forward pass verifies the device first
   const int ntasks = D * ((B + 63) / 64);
   BigScratch* sc = nullptr;
-  int rc = big_scratch(stream, (size_t)ntasks * T * kBgR, &sc);
+  int rc = big_scratch(stream, (size_t)2 * ntasks * T * kBgR, &sc);      // "d gx stored" flags, then "partials stored" flags
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(BigCtl), stream));
-  PK2_HIP(hipMemsetAsync(sc->flags, 0, (size_t)ntasks * T * kBgR * sizeof(unsigned), stream));
+  PK2_HIP(hipMemsetAsync(sc->flags, 0, (size_t)2 * ntasks * T * kBgR * sizeof(unsigned), stream));
   static bool attr = false;
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_big_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     attr = true;
   }
-  BigBwdParams p{dy, whh, gates, cells, dgx, sc->flags, B, T, D};
-  hipLaunchKernelGGL(lstm_bwd_big_persist, dim3(8 * kBgR), dim3(256), kBgLds, stream, p, sc->ctl);
+  // PK2_LSTM_BIG_BWD=1: the all-gather form (every rank reads all 4H d gates); default: the 4 x 8 decomposition
+  static const bool form2 = [] { const char* e = getenv("PK2_LSTM_BIG_BWD"); return !(e && atoi(e) == 1); }();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gates) | reinterpret_cast<uintptr_t>(cells) |
+                         reinterpret_cast<uintptr_t>(dgx)) & 15) == 0;
+  if (form2 && aligned) {
+    const size_t mail_floats = (size_t)ntasks * kBgR * 64 * 64;
+    if (sc->mail_floats < mail_floats) {
+      if (sc->mail) PK2_HIP(hipFree(sc->mail));
+      sc->mail = nullptr; sc->mail_floats = 0;
+      PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc->mail), mail_floats * sizeof(float)));
+      sc->mail_floats = mail_floats;
+    }
+    static bool attr2 = false;
+    if (!attr2) {
+      PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_big_persist2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+      attr2 = true;
+    }
+    BigBwd2Params p2{dy, whh, gates, cells, dgx, sc->mail, sc->flags, sc->flags + (size_t)ntasks * T * kBgR, B, T, D};
+    hipLaunchKernelGGL(lstm_bwd_big_persist2, dim3(8 * kBgR), dim3(256), kBgLds, stream, p2, sc->ctl);
+  } else {
+    BigBwdParams p{dy, whh, gates, cells, dgx, sc->flags, B, T, D};
+    hipLaunchKernelGGL(lstm_bwd_big_persist, dim3(8 * kBgR), dim3(256), kBgLds, stream, p, sc->ctl);
+  }
   hipLaunchKernelGGL(lstm_big_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)ntasks, dgx, (size_t)T * B * D * 4 * H, sc->sticky);
   PK2_LAUNCH_CHECK();
   *ran = true;
