@@ -227,6 +227,21 @@ def test_large_batch_lstm_matches_torch_cpu(B, T, H, bi):
     assert _lib.lib().pk2_lstm_persist_status(__import__("ctypes").byref(flag)) == 0 and flag.value == 0   # no poll timed out
 
 
+def test_large_batch_backward_all_gather_form():
+    """The large-batch backward recurrence has two forms (csrc/lstm_persist_big.hip): the default 4 x 8 decomposition of the
+    team with a second exchange of partial sums, and the all-gather form (PK2_LSTM_BIG_BWD=1, read once per process): the
+    H = 512 cases of the test above in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_frontend_nn.py"), "-q", "-m", "gpu",
+                          "-k", "test_large_batch_lstm_matches_torch_cpu and 512"], env=dict(os.environ, PK2_LSTM_BIG_BWD="1"),
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
+
+
 def test_full_size_ce_configuration_matches_torch_cpu():
     """configs[1] at its full size (VERDICT r2 #1d): 256 chunks x 80 frames x 80 fbank bins, 3x512 BLSTM, P = 5768,
     dropout 0 -- the large-batch recurrence kernels at the shape bench.py --ce times them -- against the reference's
