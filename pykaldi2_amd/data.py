@@ -83,14 +83,22 @@ class ZipWavSource:
         return self.get(int(self.rng.integers(len(self.items))))
 
     def durations(self):
-        """Seconds per utterance from the archive directory (16-bit mono PCM payload size), without decoding."""
+        """Seconds per utterance from the WAV headers in the archives (fmt chunk: channels, rate, bits; data chunk: payload
+        size), without decoding the audio.  A member whose header cannot be parsed counts as 16 kHz 16-bit mono."""
         if not hasattr(self, "_dur"):
-            sizes = {}
-            for zpath in sorted({it[0] for it in self.items}):
+            want = {}
+            for it in self.items:
+                want.setdefault(it[0], set()).add(it[1])
+            secs = {}
+            for zpath in sorted(want):
                 with zipfile.ZipFile(zpath) as z:
                     for info in z.infolist():
-                        sizes[(zpath, info.filename)] = info.file_size
-            self._dur = np.array([max(0, sizes[(it[0], it[1])] - 44) / 2.0 / 16000.0 for it in self.items])
+                        if info.filename not in want[zpath]:
+                            continue
+                        with z.open(info) as f:
+                            head = f.read(4096)
+                        secs[(zpath, info.filename)] = _wav_seconds(head, info.file_size)
+            self._dur = np.array([secs[(it[0], it[1])] for it in self.items])
         return self._dur
 
     def get(self, index):
@@ -102,6 +110,27 @@ class ZipWavSource:
             lab = lab[:n]
             wav = wav[:401 + 160 * (n - 1)] if n < T else wav
         return wav, lab, aux, utt
+
+
+def _wav_seconds(head, file_size):
+    """Duration from the first bytes of a RIFF/WAVE file: walks the chunks up to `data`."""
+    import struct
+    fallback = max(0, file_size - 44) / 2.0 / 16000.0
+    if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+        return fallback
+    pos, rate, block = 12, None, None
+    while pos + 8 <= len(head):
+        tag, size = head[pos:pos + 4], struct.unpack("<I", head[pos + 4:pos + 8])[0]
+        if tag == b"fmt " and pos + 24 <= len(head):
+            _, ch, rate, _, block, bits = struct.unpack("<HHIIHH", head[pos + 8:pos + 24])
+            block = block or max(1, ch * bits // 8)
+        elif tag == b"data":
+            if not rate or not block:
+                return fallback
+            payload = min(size, file_size - (pos + 8)) if size not in (0, 0xFFFFFFFF) else file_size - (pos + 8)
+            return max(0, payload) / float(block) / float(rate)
+        pos += 8 + size + (size & 1)
+    return fallback
 
 
 class SyntheticSource:
@@ -221,7 +250,8 @@ def epoch_plan(source, batch_size, hours, rank=0, world=1, epoch=0, length_bucke
     * Finite source (ZipWavSource): the reference's DistributedSampler (data/dataloader.py:83-84): a permutation of the
       utterance list seeded by (seed, epoch) identically on every rank, padded by wrapping to a multiple of
       world * batch_size, rank r taking every world-th group -- each utterance once per epoch, same count everywhere.
-      `hours` caps the epoch (sweep_size) through the mean duration of the list.
+      `hours` (of audio PER RANK, as for the synthetic source and as the reference's per-process sweep_size) caps the
+      epoch through the mean duration of the list.
     * Synthetic source: n = ceil(hours * 3600 / (12.3 s * batch_size)) steps on every rank.
     * length_bucketed: the ranks of one step get utterances of similar length (a step waits at the all-reduce for its
       longest minibatch): super-blocks of 16 steps are sorted by duration and dealt group by group to the ranks, the
@@ -246,7 +276,7 @@ def epoch_plan(source, batch_size, hours, rank=0, world=1, epoch=0, length_bucke
     n_steps = total // group
     if hours and hours > 0:
         mean = float(np.mean(source.durations())) if n else 1.0
-        n_steps = max(1, min(n_steps, int(np.ceil(hours * 3600.0 / (max(mean, 1e-3) * batch_size * world)))))
+        n_steps = max(1, min(n_steps, int(np.ceil(hours * 3600.0 / (max(mean, 1e-3) * batch_size)))))      # hours PER RANK
     perm = perm[:n_steps * group]
     if length_bucketed:
         dur = source.durations()

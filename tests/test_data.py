@@ -119,3 +119,26 @@ def test_length_bucketed_plan_gives_the_ranks_of_a_step_similar_lengths(tmp_path
     a = data.epoch_plan(data.SyntheticSource(50, rank=0, world=2), 2, 0.05, 0, 2, length_bucketed=True)
     b = data.epoch_plan(data.SyntheticSource(50, rank=1, world=2), 2, 0.05, 1, 2, length_bucketed=True)
     assert a == b and all(isinstance(x, float) for st in a for x in st)
+
+
+def test_wav_durations_come_from_the_headers():
+    """durations() reads the fmt / data chunks (any rate, channel count, extra chunks before `data`); an unreadable header
+    falls back to 16 kHz 16-bit mono with a 44-byte header."""
+    import io
+    import struct
+    import wave
+    from pykaldi2_amd.data import _wav_seconds
+
+    def mk(rate, ch, n):
+        b = io.BytesIO()
+        with wave.open(b, "wb") as w:
+            w.setnchannels(ch); w.setsampwidth(2); w.setframerate(rate); w.writeframes(b"\0" * (2 * ch * n))
+        return b.getvalue()
+    x = mk(16000, 1, 32000)
+    assert _wav_seconds(x[:4096], len(x)) == 2.0
+    x = mk(8000, 2, 8000)
+    assert _wav_seconds(x[:4096], len(x)) == 1.0
+    x = mk(16000, 1, 16000)
+    y = x[:36] + b"LIST" + struct.pack("<I", 10) + b"0123456789" + x[36:]
+    assert _wav_seconds(y[:4096], len(y)) == 1.0
+    assert _wav_seconds(b"junk", 32044) == 1.0
