@@ -85,7 +85,11 @@ def test_pad_roll_subsample_matches_reference_golden(golden):
                                          # row bands (608 tiles), split-K, exactly one tile per CU, a partial last k-slab
                                          # behind the pipelined loop, a shallow product on 64x64 tiles
                                          (0, 1, 2356, 4096, 520), (0, 0, 300, 1024, 4100), (0, 1, 2048, 2048, 512), (0, 1, 2356, 6048, 600),
-                                         (0, 1, 1280, 3200, 48), (1, 0, 700, 260, 2357), (1, 1, 640, 520, 1030)])
+                                         (0, 1, 1280, 3200, 48), (1, 0, 700, 260, 2357), (1, 1, 640, 520, 1030),
+                                         # few tiles and a short K (the TransformerAM's products), all four operand layouts, ragged
+                                         # M / N edges, a K that is no multiple of 16
+                                         (0, 1, 2276, 512, 512), (0, 0, 2276, 512, 1536), (1, 0, 500, 130, 772), (1, 1, 70, 190, 260),
+                                         (0, 1, 65, 64, 1028), (0, 0, 129, 67, 256)])
 def test_gemm_f32_matches_float64(ta, tb, M, N, K):
     rng = np.random.default_rng(M + N)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
