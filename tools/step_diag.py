@@ -1,0 +1,49 @@
+"""Where a slow box loses its time (one gpurun box in ~ten runs the LF-MMI loop at 20 ms per step instead of 14): per step,
+host enqueue time, GPU time between events at the step's first and last kernel, and the wall clock; plus the host's CPUs."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+import bench
+from pykaldi2_amd import chain
+
+print(subprocess.run("lscpu | grep -E 'Model name|^CPU\\(s\\)|MHz|Thread|NUMA node\\(s\\)'; nproc; uptime", shell=True, capture_output=True, text=True).stdout)
+dev = torch.device('cuda', 0)
+g = bench.den_graph_arrays()
+den = chain.DenominatorGraph(g, bench.P)
+rng = np.random.default_rng(1234)
+batches = bench.make_batches(rng, 8, 4, dev)
+tr = bench.Trainer(dev, den)
+for i in range(5):
+    tr.step(batches[i % 8])
+torch.cuda.synchronize()
+N = 24
+host, ev = [], []
+t0 = time.perf_counter()
+for i in range(N):
+    a = time.perf_counter()
+    e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    if i + 1 < N:
+        tr.prefetch(batches[(5 + i + 1) % 8])
+    tr.step(batches[(5 + i) % 8])
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    host.append(time.perf_counter() - a); ev.append((e0, e1))
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+gpu = [a.elapsed_time(b) for a, b in ev]
+gap = [ev[i][1].elapsed_time(ev[i + 1][0]) for i in range(N - 1)]
+print("wall per step %.2f ms | host enqueue mean %.2f max %.2f | GPU first-to-last event mean %.2f max %.2f | GPU gap between steps mean %.3f max %.3f"
+      % (1e3 * (t2 - t0) / N, 1e3 * np.mean(host), 1e3 * max(host), np.mean(gpu), max(gpu), np.mean(gap), max(gap)))
+print("host ms per step:", " ".join("%.1f" % (1e3 * h) for h in host))
+print("gpu  ms per step:", " ".join("%.1f" % v for v in gpu))
+# the same steps with the host blocked on the device after each (GPU time of a step alone)
+alone = []
+for i in range(8):
+    torch.cuda.synchronize(); a = time.perf_counter(); tr.step(batches[i % 8]); torch.cuda.synchronize(); alone.append(1e3 * (time.perf_counter() - a))
+print("synchronised steps ms:", " ".join("%.1f" % v for v in alone))
