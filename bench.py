@@ -589,6 +589,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reserve-gb", type=int, default=12, help="HBM handed to the caching allocator in one piece at start-up "
+                    "(0: let it grow lazily)")
     ap.add_argument("--length-bucketed", action="store_true", help="N > 1: every rank draws the same utterance lengths "
                     "(different audio / alignments), i.e. length-bucketed data parallelism without stragglers")
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
@@ -621,6 +623,14 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", hvd.local_device())
     torch.cuda.set_device(dev)
+    # Start-up, like building the graphs: the caching allocator gets the run's memory in ONE piece (288 GB of HBM: a few GB are
+    # nothing), so that it never has to go back to the driver inside the timed region.  Its growth is lazy -- the longest
+    # minibatch of the run may first appear among the timed steps (W < 8 unique minibatches) -- and a hipMalloc of a few GB costs
+    # ~1 ms on most boxes of the pool but ~100 ms on some (memory cleared on allocation): two of ~25 bench runs of rounds 2 / 3
+    # read 20.2 / 20.3 ms per step for 14.6 with an unchanged per-step GPU time (tools/step_diag.py).
+    if args.reserve_gb > 0:
+        reserve = torch.empty(args.reserve_gb << 30, dtype=torch.uint8, device=dev)
+        del reserve
 
     if args.ce:
         return ce_workload(args, dev, rank, world)
@@ -762,7 +772,8 @@ def main():
                                "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"
                                % args.batch,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY}},
+                   "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY},
+                   "allocator_reserve_gb": args.reserve_gb},
         "exchange": {"library": hvd.comm_library() or ("torch.distributed/" + (torch.distributed.get_backend()
                      if torch.distributed.is_initialized() else "none")),
                      "schedule": getattr(tr.opt, "_mode", "single"), "calibration_steps": calibration_steps,

@@ -14,6 +14,9 @@ from pykaldi2_amd import chain
 
 print(subprocess.run("lscpu | grep -E 'Model name|^CPU\\(s\\)|MHz|Thread|NUMA node\\(s\\)'; nproc; uptime", shell=True, capture_output=True, text=True).stdout)
 dev = torch.device('cuda', 0)
+if len(sys.argv) > 1 and int(sys.argv[1]) > 0:      # argument: GB handed to the caching allocator up front (bench.py --reserve-gb)
+    r = torch.empty(int(sys.argv[1]) << 30, dtype=torch.uint8, device=dev)
+    del r
 g = bench.den_graph_arrays()
 den = chain.DenominatorGraph(g, bench.P)
 rng = np.random.default_rng(1234)
@@ -47,3 +50,4 @@ alone = []
 for i in range(8):
     torch.cuda.synchronize(); a = time.perf_counter(); tr.step(batches[i % 8]); torch.cuda.synchronize(); alone.append(1e3 * (time.perf_counter() - a))
 print("synchronised steps ms:", " ".join("%.1f" % v for v in alone))
+print("allocator: reserved %.2f GB, peak allocated %.2f GB" % (torch.cuda.max_memory_reserved() / 2 ** 30, torch.cuda.max_memory_allocated() / 2 ** 30))
