@@ -1,4 +1,6 @@
-// On-the-fly lattice generation, launch-per-frame variant: a TEAM of workgroups per utterance.
+// On-the-fly lattice generation by a TEAM of workgroups per utterance: the phases of a frame as device functions, run either
+// inside ONE persistent launch per minibatch (lat_frames_persist, further down: the default on an MI355X) or as a few
+// graph-replayed launches per frame (the lat_frames_* kernels right below: the fallback, PK2_LAT_DECODER=frames).
 //
 // lattice_decode.hip gives every utterance one workgroup for the whole decode: with the 8 utterances per GPU of
 // the lattice-MMI configuration 248 of the 256 CUs idle while 8 run a serial chain of ~125 us frames.  Here a

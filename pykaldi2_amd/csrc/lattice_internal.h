@@ -5,9 +5,9 @@
 // MI355X design: the reference decodes every utterance on the CPU with Kaldi's LatticeFasterDecoder, copies
 // the lattice posteriors to the GPU and loops over utterances in Python (reference ops/ops.py:55-66,
 // bin/train_se.py:237-249).  Here the whole minibatch is decoded on the device and the lattices never leave HBM:
-// by default a team of workgroups per utterance with a few graph-replayed launches per frame
-// (lattice_decode_frames.hip), or one workgroup per utterance inside one launch (lattice_decode.hip: utterances are
-// independent, so that recursion needs workgroup barriers only).  Per utterance the workspace holds
+// by default a team of workgroups of one XCD per utterance, all frames inside one persistent launch (or a few
+// graph-replayed launches per frame: lattice_decode_frames.hip), or one workgroup per utterance inside one launch
+// (lattice_decode.hip: utterances are independent, so that recursion needs workgroup barriers only).  Per utterance the workspace holds
 //   * a dense per-state table {best cost, token index} for the frame being built (reset sparsely),
 //   * frame-layered token arrays and link arrays (pools sized from the utterance length: 288 GB of HBM make
 //     Kaldi's periodic pruning unnecessary; one backward pruning pass runs after the last frame),
