@@ -484,6 +484,7 @@ def ce_workload(args, dev, rank, world):
                           "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
                           "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "loss": round(float(loss.item()), 4),
                           "cpu_baseline": base, "parity": parity,
+                          "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           "reference_published": "README.md:43-45: 190 iRTF (64x80, 1 V100), 520 iRTF (256x80, 4 V100)"}),
               flush=True)
     hvd.shutdown()
@@ -565,6 +566,7 @@ def se_workload(args, dev, rank, world):
                           "lattice_tokens_per_frame": round(float(lat.num_tokens.sum()) / float(np.sum(frames)), 1),
                           "lattice_links_per_frame": round(float(lat.num_links.sum()) / float(np.sum(frames)), 1),
                           "loss": round(float(loss.item()), 2),
+                          "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           "reference_published": "README.md:47-49: lattice MMI 16.7 iRTF (1 V100, 4 utterances), 34.5 iRTF (4 V100)"}),
               flush=True)
     hvd.shutdown()
@@ -589,8 +591,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reserve-gb", type=int, default=12, help="HBM handed to the caching allocator in one piece at start-up "
-                    "(0: let it grow lazily)")
+    ap.add_argument("--reserve-gb", type=int, default=None, help="HBM handed to the caching allocator in one piece at start-up "
+                    "(0: let it grow lazily; default 12, --se 48: their runs peak at 8 / 33 GB)")
     ap.add_argument("--length-bucketed", action="store_true", help="N > 1: every rank draws the same utterance lengths "
                     "(different audio / alignments), i.e. length-bucketed data parallelism without stragglers")
     ap.add_argument("--den-only", action="store_true", help="time only the denominator forward-backward")
@@ -628,6 +630,8 @@ def main():
     # minibatch of the run may first appear among the timed steps (W < 8 unique minibatches) -- and a hipMalloc of a few GB costs
     # ~1 ms on most boxes of the pool but ~100 ms on some (memory cleared on allocation): two of ~25 bench runs of rounds 2 / 3
     # read 20.2 / 20.3 ms per step for 14.6 with an unchanged per-step GPU time (tools/step_diag.py).
+    if args.reserve_gb is None:
+        args.reserve_gb = 48 if args.se else 12
     if args.reserve_gb > 0:
         reserve = torch.empty(args.reserve_gb << 30, dtype=torch.uint8, device=dev)
         del reserve
@@ -773,7 +777,8 @@ def main():
                                % args.batch,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY},
-                   "allocator_reserve_gb": args.reserve_gb},
+                   "allocator_reserve_gb": args.reserve_gb,
+                   "hbm_peak_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2)},
         "exchange": {"library": hvd.comm_library() or ("torch.distributed/" + (torch.distributed.get_backend()
                      if torch.distributed.is_initialized() else "none")),
                      "schedule": getattr(tr.opt, "_mode", "single"), "calibration_steps": calibration_steps,
