@@ -662,25 +662,37 @@ def main():
             print("gemm ta=%d tb=%d M=%5d N=%5d K=%5d  %7.1f us  %6.1f TFLOP/s" % (ta, tb, M, N, K, 1e3 * ms, 2.0 * M * N * K / ms / 1e9), flush=True)
         return
     if args.lstm_only:
+        # one layer's recurrences alone (forward and backward pass), us per time step: the BASELINE minibatch shape
         from pykaldi2_amd import _lib
-        T, B, H, D = 589, 4, 512, 2
-        gx = torch.randn(T, B, D * 4 * H, device=dev) * 0.1
-        whh = torch.randn(D, 4 * H, H, device=dev) * 0.04
-        y = torch.empty(T, B, D * H, device=dev); gates = torch.empty(D, T, B, 4 * H, device=dev)
-        cells = torch.empty(D, T, B, H, device=dev)
         L = _lib.lib()
-        def run():
-            _lib.check(L.pk2_lstm_layer_fwd(_lib.ptr(gx), _lib.ptr(whh), None, B, T, H, D, _lib.ptr(y), _lib.ptr(gates),
-                                            _lib.ptr(cells), None, _lib.stream_ptr()))
-        for _ in range(2):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            run()
-        e1.record(); torch.cuda.synchronize()
-        print("lstm_fwd us/step %.2f" % (1e3 * e0.elapsed_time(e1) / 5 / T), flush=True)
+        for (T, B) in ((589, 4), (1166, 4), (200, 4)):
+            H, D = 512, 2
+            gx = torch.randn(T, B, D * 4 * H, device=dev) * 0.1
+            whh = torch.randn(D, 4 * H, H, device=dev) * 0.04
+            y = torch.empty(T, B, D * H, device=dev); gates = torch.empty(D, T, B, 4 * H, device=dev)
+            cells = torch.empty(D, T, B, H, device=dev)
+            dy = torch.randn(T, B, D * H, device=dev) * 0.1
+            dgx = torch.empty(T, B, D * 4 * H, device=dev)
+            scratch = torch.empty(max(1, L.pk2_lstm_bwd_scratch_floats(B, H, D)), device=dev)
+            def fwd():
+                _lib.check(L.pk2_lstm_layer_fwd(_lib.ptr(gx), _lib.ptr(whh), None, B, T, H, D, _lib.ptr(y), _lib.ptr(gates),
+                                                _lib.ptr(cells), None, _lib.stream_ptr()))
+            def bwd():
+                _lib.check(L.pk2_lstm_layer_bwd(_lib.ptr(dy), _lib.ptr(whh), _lib.ptr(gates), _lib.ptr(cells), B, T, H, D,
+                                                _lib.ptr(dgx), _lib.ptr(scratch), _lib.stream_ptr()))
+            res = {}
+            for name, fn in (("fwd", fwd), ("bwd", bwd)):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                res[name] = 1e3 * e0.elapsed_time(e1) / 5 / T
+            print("lstm recurrences T=%d B=%d: fwd %.3f us/step, bwd %.3f us/step  (y %.4f dgx %.4f)" % (
+                T, B, res["fwd"], res["bwd"], y.abs().mean().item(), dgx.abs().mean().item()), flush=True)
         return
     log("rank %d/%d: building synthetic den graph" % (rank, world))
     g = den_graph_arrays()

@@ -58,7 +58,18 @@ __device__ __forceinline__ u32x4 seq_load16(const float* p) {
 __device__ __forceinline__ void seq_store16(float* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void seq_store16_mode(float* p, u32x4 v, int mode) {
+  if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void seq_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The hand-over stores of the round-4 kernels by cache policy (experiment switch; 0 = agent scope as everywhere else).
+__device__ __forceinline__ void seq_store_mode(float* p, float v, int mode) {
+  if (mode == 1) asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  else if (mode == 2) asm volatile("global_store_dword %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ unsigned seq_load_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool seq_has_sentinel(u32x4 v) {
   return v.x == kSeqSentinel || v.y == kSeqSentinel || v.z == kSeqSentinel || v.w == kSeqSentinel;
@@ -73,6 +84,22 @@ __device__ __forceinline__ float seq_dpp(float v) {
 // Workgroup barrier that waits for the LDS traffic only: __syncthreads() also waits for every outstanding global store
 // and load of the thread (s_waitcnt vmcnt(0)), i.e. for the HBM traffic of the previous step.
 __device__ __forceinline__ void seq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// -DPK2_SEQ_PROFILE: phase timers of wave 0 of rank 0 of every team on its first pair (shader clock, s_memtime; the
+// wall clock brackets the whole recurrence so that clocks convert to time), printed per team at the end of the pair.
+#ifdef PK2_SEQ_PROFILE
+#define SQ_NPH 8
+#define SQ_T0() long long sq_acc_[SQ_NPH] = {0, 0, 0, 0, 0, 0, 0, 0}; long long sq_last_ = clock64(); const long long sq_w0_ = wall_clock64(); const long long sq_c0_ = sq_last_
+#define SQ_T(k) do { const long long n_ = clock64(); sq_acc_[k] += n_ - sq_last_; sq_last_ = n_; } while (0)
+#define SQ_PRINT(name, labels, steps) do { if (tid == 0 && rank == 0 && iter == 0) { const long long wt_ = wall_clock64() - sq_w0_, ct_ = clock64() - sq_c0_; \
+    printf("%s xcd %d, %d steps, %.1f ns per step (wall), %.0f clocks per step; clocks per step %s: %lld | %lld | %lld | %lld | %lld | %lld | %lld | %lld\n", name, s_i[2], steps, \
+           10.0 * (double)wt_ / (steps), (double)ct_ / (steps), labels, sq_acc_[0] / (steps), sq_acc_[1] / (steps), sq_acc_[2] / (steps), sq_acc_[3] / (steps), sq_acc_[4] / (steps), \
+           sq_acc_[5] / (steps), sq_acc_[6] / (steps), sq_acc_[7] / (steps)); } } while (0)
+#else
+#define SQ_T0() do { } while (0)
+#define SQ_T(k) do { } while (0)
+#define SQ_PRINT(name, labels, steps) do { } while (0)
+#endif
 
 // A poll that keeps failing reads the wall clock every 256 rounds; after 1 s (or when somebody else gave up) it raises
 // the abort flag.
@@ -150,6 +177,8 @@ struct SeqFwdParams {
   float* gates;       // [D][T][B][4H]
   float* cells;       // [D][T][B][H]
   int B, T, D;
+  int pre_sleep, loop_sleep;   // round-4 kernels: s_sleep units (64 clocks) before the first poll of a step / between polls
+  int store_mode;
 };
 
 __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl) {
@@ -204,6 +233,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
     for (int k = 0; k < 4; ++k) gxm[k] = gxn[k];
     load_gx(1);
     SeqSpin spin(ctl);
+    SQ_T0();
     for (int step = 0; step < T; ++step) {
       const int t = d == 0 ? step : T - 1 - step;
       const int tp = d == 0 ? t - 1 : t + 1;
@@ -223,8 +253,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
         }
         *reinterpret_cast<u32x4*>(&hs[buf][(gran >> 5) * kPhasePitch + 4 * (gran & 31)]) = v;
       }
+      SQ_T(0);
       if (timed_out) s_i[3] = 1;
       seq_lds_barrier();
+      SQ_T(1);
       if (s_i[3]) return;
       load_gx(step + 2);
       // ---- recurrent product: this lane's quarter of its gate row ------------------------------------------------------
@@ -246,6 +278,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
       }
       // the four gates of a unit: lanes +0, +4, +8, +12 of its 16-lane row
       const float sf = seq_dpp<0x104>(s), sg = seq_dpp<0x108>(s), so = seq_dpp<0x10C>(s);
+#ifdef PK2_SEQ_PROFILE
+      asm volatile("" : "+v"(s));
+#endif
+      SQ_T(2);
       if (unit_lane) {
         const float ig = seq_sig(pre[0] + s), fg = seq_sig(pre[1] + sf), gg = seq_tanh(pre[2] + sg), og = seq_sig(pre[3] + so);
         cstate = fg * cstate + ig * gg;
@@ -255,7 +291,9 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq(SeqFwdParams p, SeqCtl* ctl)
         float* gr = p.gates + (((size_t)d * T + t) * B + b) * 4 * H + gu;
         gr[0] = ig; gr[(size_t)H] = fg; gr[(size_t)2 * H] = gg; gr[(size_t)3 * H] = og;
       }
+      SQ_T(3);
     }
+    SQ_PRINT("lstm_fwd_seq", "(poll | lds + barrier | product | gates + stores)", T);
     if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!seq_team_barrier(ctl, role, &nbar, s_i)) return;     // (the LDS buffers and the team's pace are per pair)
   }
@@ -269,6 +307,7 @@ struct SeqBwdParams {
   float* dgx;          // [T][B][D*4H]
   float* mail;         // [teams][3][32 readers][32 writers][16 units], all sentinel
   int B, T, D;
+  int pre_sleep, loop_sleep, store_mode;
 };
 
 __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl) {
@@ -320,6 +359,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
     m_dy = n_dy; m_i = n_i; m_f = n_f; m_g = n_g; m_o = n_o; m_c = n_c; m_cp = n_cp;
     load_pw(1);
     SeqSpin spin(ctl);
+    SQ_T0();
     for (int step = 0; step < T; ++step) {
       const int fstep = T - 1 - step;
       const int t = d == 0 ? fstep : T - 1 - fstep;
@@ -345,6 +385,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
         }
         if (timed_out) s_i[3] = 1;
         __syncthreads();
+        SQ_T(0);
         if (s_i[3]) {            // loud failure: the gradient of this layer turns NaN
           if (tid == 0) p.dgx[(size_t)d * G4 + 16 * rank] = __int_as_float(0x7fc00000);
           return;
@@ -375,12 +416,14 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
           o[0] = dgi; o[(size_t)H] = dgf; o[(size_t)2 * H] = dgg; o[(size_t)3 * H] = dgo;
         }
       };
+      SQ_T(1);
       if (step == T - 1) { store_dgx(); break; }
       // Three mailbox buffers: the one read (and reset) in step s is written again by the peers in their step s+2, after they
       // have read this workgroup's partials of step s+2 -- which go out behind the barrier of step s+1, and the polling
       // threads reach that barrier only after their reset stores have been acknowledged (a poll waits for the thread's
       // outstanding stores).  So no wait for the resets here (with two buffers it cost an L2 round trip per step).
       seq_lds_barrier();
+      SQ_T(2);
       store_dgx();
       load_pw(step + 2);             // the pointwise operands of the step after next
       // ---- own 64 rows of dgates x own W_hh rows: the lane's two columns ---------------------------------------------------
@@ -398,7 +441,388 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
       const int k0 = 128 * w + lane, k1 = k0 + 64;
       seq_store(box + ((size_t)(k0 >> 4) * kSWgs + rank) * 16 + (k0 & 15), a0 + a1);
       seq_store(box + ((size_t)(k1 >> 4) * kSWgs + rank) * 16 + (k1 & 15), b0 + b1);
+      SQ_T(3);
     }
+    SQ_PRINT("lstm_bwd_seq", "(mailbox poll by waves 2, 3 + barrier | partial sums + gate derivatives | lds barrier | product + mailbox stores)", T);
+    if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!seq_team_barrier(ctl, role, &nbar, s_i)) return;     // nobody writes a mailbox of the next pair before everybody has read the last of this one
+  }
+}
+
+// ---- Round 4: the same recurrences with the step's critical path cut down (lstm_fwd_seq2 / lstm_bwd_seq2) ---------------
+// What the timers of the kernels above (-DPK2_SEQ_PROFILE) charge a step besides the exchange through L2, and what changes:
+//  * `s_waitcnt vmcnt(0)` is a counter of the WAVE, not of the lane: a poll waits for every vector-memory operation the
+//    wave has in flight, whichever lanes issued it.  Forward, every wave prefetches input projections and polls; here the
+//    input projections arrive through the SCALAR cache (s_load_dwordx4 of the wave's 4 units x 4 gates, counted by
+//    lgkmcnt, issued behind the product's last LDS read two steps ahead) and are dealt to the gate lanes with
+//    v_writelane, so the only vector loads of a compute wave are its polls.  Backward, the wave that polls keeps no
+//    other loads: wave 1 prefetches the forward pass's values two steps ahead, turns them into the five per-unit
+//    factors of the gate derivatives (everything that does not depend on the incoming d h, including tanh(c)) and
+//    hands them over in LDS; it also writes d gx out of LDS behind the barrier.
+//  * Forward product: a lane owns a 32-k slice of the FOUR gate rows of one unit (was: 128 k's of one row): 8
+//    ds_read_b128 instead of 32 per lane and step (the four waves share one LDS port), packed FMAs (v_pk_fma_f32), the
+//    16 slices of a unit are the 16 lanes of a DPP row and are added by a 4-level butterfly (the sums are identical in
+//    all lanes of the row); lane j of the row applies gate j's nonlinearity (tanh as a scaled sigmoid: one exp2 + one
+//    rcp for all four gates at once), lane 0 collects them with three DPP moves.
+//  * Backward: ONE wave gathers the mailbox (two 16-byte granules per lane: writers j and j + 16, a DPP row per
+//    group of 4 units), adds the 32 partials with the same butterfly and finishes the gate derivatives in the same
+//    lanes: no LDS round trip and no barrier between the poll and the pointwise work, no 32-deep serial sum on 16 threads.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PK2_CONSTANT_AS __attribute__((address_space(4)))
+
+// Butterfly sum over the 16 lanes of a DPP row; every lane of the row ends with the same bits (each level adds a pair of
+// values that both partners hold, and float addition is commutative).
+__device__ __forceinline__ float seq_row_sum(float v) {
+  v += seq_dpp<0xB1>(v);         // quad_perm [1,0,3,2]
+  v += seq_dpp<0x4E>(v);         // quad_perm [2,3,0,1]
+  v += seq_dpp<0x141>(v);        // row_half_mirror: the other quad of the half row (quads are uniform by now)
+  v += seq_dpp<0x140>(v);        // row_mirror: the other half row
+  return v;
+}
+// Four of them at once, level by level (left to the compiler the four chains are paired into v_pk_add_f32, which has no
+// DPP form: two v_mov_dpp + a packed add per level and pair -- three times the instructions).  A DPP operand written by
+// the previous VALU instruction needs two wait states: the s_nop covers the first level, the other three chains the rest.
+__device__ __forceinline__ void seq_row_sum4(float& a, float& b, float& c, float& d) {
+#define PK2_SEQ_DPP_LEVEL(ctrl)                                              \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" PK2_SEQ_DPP_LEVEL("quad_perm:[1,0,3,2]") PK2_SEQ_DPP_LEVEL("quad_perm:[2,3,0,1]")
+               PK2_SEQ_DPP_LEVEL("row_half_mirror") PK2_SEQ_DPP_LEVEL("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef PK2_SEQ_DPP_LEVEL
+}
+__device__ __forceinline__ const float* seq_uniform_ptr(const float* ptr) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+// 16 contiguous bytes through the scalar cache (the address must be wave-uniform and 16-byte aligned).
+__device__ __forceinline__ f32x4 seq_sload16(const float* ptr) {
+  return *reinterpret_cast<const PK2_CONSTANT_AS f32x4*>(reinterpret_cast<unsigned long long>(ptr));
+}
+template <int LANE>
+__device__ __forceinline__ float seq_writelane(float v, float old) {        // old with lane LANE replaced by the (uniform) v
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(LANE));
+  return old;
+}
+
+__global__ void __launch_bounds__(256) lstm_fwd_seq2(SeqFwdParams p, SeqCtl* ctl) {
+  constexpr int H = kSH;
+  constexpr int kSlicePitch = 36;           // 32 + 4: the 16 slices a lane group reads side by side start on 16 different bank quads
+  __shared__ __attribute__((aligned(16))) float hs[2][16 * kSlicePitch];
+  __shared__ float gxs[3][64];              // input projections [step % 3][gate * 16 + unit], written two steps ahead by wave 2
+  __shared__ float outs[2][80];             // [step & 1]: gate activations [gate * 16 + unit], cells [64 + unit]; wave 3 writes them out
+  __shared__ int s_i[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  SeqRole role;
+  if (!seq_register(ctl, s_i, &role)) return;
+  const int rank = role.rank, B = p.B, T = p.T, D = p.D;
+  // lane roles: a 16-lane DPP row = one hidden unit, lane % 16 = its k-slice; lane j < 4 of the row finishes gate j
+  const int ul = lane >> 4, l16 = lane & 15;
+  const int uw = 4 * w + ul;                             // unit within the workgroup
+  const int gu = 16 * rank + uw;
+  const bool unit_lane = l16 == 0, gate_lane = l16 < 4;
+  const bool poller = w < 2;                             // waves 0, 1 poll (a granule per lane); waves 2, 3 do the HBM traffic
+  const int gran = w * 64 + lane;                        // granule of h this lane polls (128 per step)
+  // gate j's nonlinearity as a * rcp(1 + exp2(s * x)) + b: sigmoid (1, -log2 e, 0), tanh (2, -2 log2 e, -1)
+  const float act_s = l16 == 2 ? -2.8853900817779268f : -1.4426950408889634f;
+  const float act_a = l16 == 2 ? 2.0f : 1.0f, act_b = l16 == 2 ? -1.0f : 0.0f;
+  const int pre_idx = 16 * (l16 & 3) + uw, out_idx = gate_lane ? 16 * l16 + uw : 0;
+  const size_t yrow = (size_t)D * H;
+  unsigned nbar = 0;
+  for (int iter = 0; iter <= kSeqMaxTasks; ++iter) {
+    const int task = seq_next_task(ctl, role, iter, B * D, s_i);
+    if (task < 0) return;
+    const int b = task / D, d = task % D;
+    f32x2 wa[4][16];                                     // W_hh[d][g*H + gu][32 l16 + 2 i, + 1]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float* wrow = p.whh + ((size_t)d * 4 * H + (size_t)g * H + gu) * H + 32 * l16;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + i * 4);
+        wa[g][2 * i] = f32x2{v[0], v[1]};
+        wa[g][2 * i + 1] = f32x2{v[2], v[3]};
+      }
+    }
+    const float bias = (gate_lane && p.bhh) ? p.bhh[(size_t)d * 4 * H + (size_t)l16 * H + gu] : 0.f;
+    // Everything addressed by time walks a pointer: t = step (d = 0) or T - 1 - step (d = 1).
+    const ptrdiff_t tdir = d == 0 ? 1 : -1;
+    const size_t t0 = d == 0 ? 0 : (size_t)(T - 1);
+    const ptrdiff_t y_stride = tdir * (ptrdiff_t)((size_t)B * yrow);
+    float* y_out = p.y + (t0 * B + b) * yrow + (size_t)d * H + gu;                        // h_t of the lane's unit
+    const float* y_poll = p.y + (t0 * B + b) * yrow + (size_t)d * H + 4 * gran - y_stride;  // the granule of h_{t-1}
+    // wave 2: lane = gate * 16 + unit of the workgroup's input projections; wave 3: the same lanes store the activations,
+    // its lanes 0..15 the cells
+    const ptrdiff_t gx_stride = tdir * (ptrdiff_t)((size_t)B * D * 4 * H);
+    const float* gx_in = p.gx + (t0 * B + b) * ((size_t)D * 4 * H) + (size_t)d * 4 * H + (size_t)(lane >> 4) * H + 16 * rank + (lane & 15);
+    const ptrdiff_t gates_stride = tdir * (ptrdiff_t)((size_t)B * 4 * H), cells_stride = tdir * (ptrdiff_t)((size_t)B * H);
+    float* gates_out = p.gates + (((size_t)d * T + t0) * B + b) * 4 * H + (size_t)(lane >> 4) * H + 16 * rank + (lane & 15);
+    float* cells_out = p.cells + (((size_t)d * T + t0) * B + b) * H + 16 * rank + (lane & 15);
+    // (loads are unconditional and walk a clamped pointer: a load under a branch makes the compiler wait for it at the
+    // join, i.e. at once)
+    float gnext = 0.f;
+    if (w == 2) {
+      gxs[0][lane] = gx_in[0];
+      gx_in += T > 1 ? gx_stride : 0;
+      gxs[1][lane] = gx_in[0];
+      gx_in += T > 2 ? gx_stride : 0;
+      gnext = gx_in[0];
+      gx_in += T > 3 ? gx_stride : 0;
+    }
+    // W_hh, bias and the first input projections have arrived BEFORE the loop: left to itself the compiler waits for them
+    // at their first use, inside the loop -- an s_waitcnt vmcnt(0) in every step's product, which then also waits for the
+    // step's own stores and prefetches.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    __syncthreads();
+    float cstate = 0.f;
+    bool timed_out = false;
+    SeqSpin spin(ctl);
+    SQ_T0();
+    for (int step = 0; step < T; ++step) {
+      const int buf = step & 1;
+      const float pre = gxs[step % 3][pre_idx] + bias;
+      // ---- gather h_{t-1} of this (sequence, direction): 512 floats = 128 granules of 16 bytes -----------------------
+      if (step > 0 && poller) {
+        for (int i = 0; i < p.pre_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+        u32x4 v = seq_load16(y_poll);
+        while (seq_has_sentinel(v)) {
+          if (spin.expired()) { timed_out = true; break; }
+          for (int i = 0; i < p.loop_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+          v = seq_load16(y_poll);
+        }
+        *reinterpret_cast<u32x4*>(&hs[buf][(gran >> 3) * kSlicePitch + 4 * (gran & 7)]) = v;
+      }
+      y_poll += y_stride;
+      SQ_T(0);
+      if (timed_out) s_i[3] = 1;
+      seq_lds_barrier();
+      SQ_T(1);
+      if (s_i[3]) return;
+      // ---- recurrent product: the lane's 32-k slice of the unit's four gate rows ---------------------------------------
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      if (step > 0) {
+        const float* hq = &hs[buf][l16 * kSlicePitch];
+        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, c0 = a0, c1 = a0, c2 = a0, c3 = a0;
+        f32x4 hva[8];                                     // all eight reads in flight before the first FMA
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hva[i] = *reinterpret_cast<const f32x4*>(hq + 4 * i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 hv = hva[i];
+          const f32x2 h01 = {hv[0], hv[1]}, h23 = {hv[2], hv[3]};
+          a0 = __builtin_elementwise_fma(wa[0][2 * i], h01, a0); c0 = __builtin_elementwise_fma(wa[0][2 * i + 1], h23, c0);
+          a1 = __builtin_elementwise_fma(wa[1][2 * i], h01, a1); c1 = __builtin_elementwise_fma(wa[1][2 * i + 1], h23, c1);
+          a2 = __builtin_elementwise_fma(wa[2][2 * i], h01, a2); c2 = __builtin_elementwise_fma(wa[2][2 * i + 1], h23, c2);
+          a3 = __builtin_elementwise_fma(wa[3][2 * i], h01, a3); c3 = __builtin_elementwise_fma(wa[3][2 * i + 1], h23, c3);
+        }
+        s0 = (a0[0] + a0[1]) + (c0[0] + c0[1]);
+        s1 = (a1[0] + a1[1]) + (c1[0] + c1[1]);
+        s2 = (a2[0] + a2[1]) + (c2[0] + c2[1]);
+        s3 = (a3[0] + a3[1]) + (c3[0] + c3[1]);
+        seq_row_sum4(s0, s1, s2, s3);
+      }
+#ifdef PK2_SEQ_PROFILE
+      asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+#endif
+      SQ_T(2);
+      // ---- gates: lane j of the row takes gate j --------------------------------------------------------------------------
+      const float x = pre + (l16 == 0 ? s0 : l16 == 1 ? s1 : l16 == 2 ? s2 : s3);
+      const float act = fmaf(act_a, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(act_s * x)), act_b);
+      const float fg = seq_dpp<0x101>(act), gg = seq_dpp<0x102>(act), og = seq_dpp<0x103>(act);     // row_shl 1, 2, 3
+      cstate = fg * cstate + act * gg;                    // (meaningful in the row's lane 0 only)
+      const float h = og * seq_tanh(cstate);
+      if (unit_lane) seq_store_mode(y_out, h, p.store_mode);
+      y_out += y_stride;
+      SQ_T(3);
+      // ---- behind the hand-over: what the backward pass needs goes to HBM through wave 3, the input projections of the
+      // step after next come in through wave 2 (the polling waves keep no other vector-memory operation in flight) ---------
+      if (gate_lane) outs[buf][out_idx] = act;
+      if (unit_lane) outs[buf][64 + uw] = cstate;
+      if (w == 2) {
+        gxs[(step + 2) % 3][lane] = gnext;                // (loaded a step ago)
+        gnext = *gx_in;                                   // step + 3 (clamped to the last step)
+        gx_in += step + 4 < T ? gx_stride : 0;
+      }
+      if (w == 3 && step > 0) {                           // the previous step's values (a barrier lies between)
+        *gates_out = outs[buf ^ 1][lane];
+        if (lane < 16) *cells_out = outs[buf ^ 1][64 + lane];
+        gates_out += gates_stride; cells_out += cells_stride;
+      }
+      SQ_T(4);
+    }
+    __syncthreads();
+    if (w == 3) {
+      *gates_out = outs[(T - 1) & 1][lane];
+      if (lane < 16) *cells_out = outs[(T - 1) & 1][64 + lane];
+    }
+    SQ_PRINT("lstm_fwd_seq2", "(poll | lds + barrier | product + row sums | gates + h store | lds hand-over, wave 2 / 3 traffic)", T);
+    if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!seq_team_barrier(ctl, role, &nbar, s_i)) return;
+  }
+}
+
+__global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl) {
+  constexpr int H = kSH, G4 = 4 * kSH;
+  __shared__ __attribute__((aligned(16))) float dgl[64];               // this workgroup's dgates [gate * 16 + unit]
+  __shared__ __attribute__((aligned(16))) float cst[3][16][8];         // [step % 3][unit]{dy, A, F, Ci, Cf, Cg, Co, -}: written two steps ahead
+  __shared__ int s_i[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  SeqRole role;
+  if (!seq_register(ctl, s_i, &role)) return;
+  const int rank = role.rank, B = p.B, T = p.T, D = p.D;
+  float* mail0 = p.mail + (size_t)role.team_index * kSeqMailFloats;
+  const u32x4 sent = {kSeqSentinel, kSeqSentinel, kSeqSentinel, kSeqSentinel};
+  const int row = lane >> 4, l16 = lane & 15;
+  const bool pw_lane = w == 0 && l16 < 4;               // wave 0, lane j of row r: unit 4 r + j of the workgroup
+  const int pw_unit = (4 * row + l16) & 15;
+  const bool io = w == 1;                               // wave 1: prefetches and prepares the factors, writes d gx
+  const bool io16 = io && lane < 16;
+  unsigned nbar = 0;
+  for (int iter = 0; iter <= kSeqMaxTasks; ++iter) {
+    const int task = seq_next_task(ctl, role, iter, B * D, s_i);
+    if (task < 0) return;
+    const int b = task / D, d = task % D;
+    // W_hh[d][(r/16)*H + 16*rank + r%16][k] for the 64 own rows r and the lane's two columns k = 128 w + lane (+ 64)
+    f32x2 wb[64];
+    {
+      const float* wbase = p.whh + (size_t)d * G4 * H + 128 * w + lane;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) {
+        const float* wrow = wbase + ((size_t)(r >> 4) * H + 16 * rank + (r & 15)) * H;
+        wb[r] = f32x2{wrow[0], wrow[64]};
+      }
+    }
+    float dcarry = 0.f;
+    bool timed_out = false;
+    // Everything addressed by time walks a pointer: the backward pass visits t = T - 1 - step (d = 0) or step (d = 1).
+    const ptrdiff_t tdir = d == 0 ? -1 : 1;
+    const size_t t0 = d == 0 ? (size_t)(T - 1) : 0;
+    const ptrdiff_t dy_stride = tdir * (ptrdiff_t)((size_t)B * D * H), gates_stride = tdir * (ptrdiff_t)((size_t)B * G4);
+    const ptrdiff_t cells_stride = tdir * (ptrdiff_t)((size_t)B * H), dgx_stride = tdir * (ptrdiff_t)((size_t)B * D * G4);
+    const float* dy_in = p.dy + (t0 * B + b) * ((size_t)D * H) + (size_t)d * H + 16 * rank + (lane & 15);
+    const float* gates_in = p.gates + (((size_t)d * T + t0) * B + b) * G4 + 16 * rank + (lane & 15);
+    const float* cells_in = p.cells + (((size_t)d * T + t0) * B + b) * H + 16 * rank + (lane & 15);
+    float* dgx_out = p.dgx + (t0 * B + b) * ((size_t)D * G4) + (size_t)d * G4 + (size_t)(lane >> 4) * H + 16 * rank + (lane & 15);
+    // wave 1, lanes 0..15: the forward pass's values of step s + 4 (in flight) and of step s + 3
+    // wave 1: the forward pass's values of the step after next but one, in flight for a whole step.  The loads are
+    // unconditional, from pointers that stop at the last step (a load under a branch makes the compiler wait for it at the
+    // join, i.e. at once; so does a register rotation: it copies the values just requested); lanes 16..63 of the wave
+    // repeat the addresses of lanes 0..15.
+    const float* cellsp_in = cells_in + (T > 1 ? cells_stride : 0);    // the cell of the time step before (forward order)
+    float n_dy = 0.f, n_i = 0.f, n_f = 0.f, n_g = 0.f, n_o = 0.f, n_c = 0.f, n_cp = 0.f;
+    auto load_pw = [&](int step_) {                      // (called for step_ = 0, 1, 2, ...: the pointers walk along)
+      const bool more = step_ + 1 < T, more2 = step_ + 2 < T;
+      n_dy = *dy_in;
+      n_i = gates_in[0]; n_f = gates_in[H]; n_g = gates_in[2 * H]; n_o = gates_in[3 * H];
+      n_c = *cells_in;
+      n_cp = *cellsp_in;
+      dy_in += more ? dy_stride : 0; gates_in += more ? gates_stride : 0; cells_in += more ? cells_stride : 0;
+      cellsp_in += more2 ? cells_stride : 0;
+    };
+    auto put_factors = [&](int step_, int slot) {        // from the values in flight (step step_) into cst[slot]
+      const float cp = step_ == T - 1 ? 0.f : n_cp;      // the last step of the backward pass has no previous cell
+      if (io16) {
+        const float tc = seq_tanh(n_c);
+        float* o = &cst[slot][lane][0];
+        *reinterpret_cast<f32x4*>(o) = f32x4{n_dy, n_o * (1.f - tc * tc), n_f, n_g * n_i * (1.f - n_i)};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{cp * n_f * (1.f - n_f), n_i * (1.f - n_g * n_g), tc * n_o * (1.f - n_o), 0.f};
+      }
+    };
+    if (io) {
+      load_pw(0); put_factors(0, 0);
+      load_pw(1); put_factors(1, 1);
+      load_pw(2);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): W_hh is there before the loop (no waits for it inside)
+    __syncthreads();
+    // the mailbox of the step: [step % 3][reader][writer][16 units]; wave 0 reads [.][rank][writer l16 (+ 16)][units 4 row ..]
+    float* mail_rd = mail0 + (size_t)rank * (kSWgs * 16) + (size_t)l16 * 16 + 4 * row;
+    const int k0 = 128 * w + lane, k1 = k0 + 64;
+    float* mail_wr0 = mail0 + ((size_t)(k0 >> 4) * kSWgs + rank) * 16 + (k0 & 15);       // peer k/16 reads [writer = rank][unit k%16]
+    float* mail_wr1 = mail0 + ((size_t)(k1 >> 4) * kSWgs + rank) * 16 + (k1 & 15);
+    constexpr int kBox = kSWgs * kSWgs * 16;
+    int s3 = 0;                                          // step % 3
+    SeqSpin spin(ctl);
+    SQ_T0();
+    for (int step = 0; step < T; ++step) {
+      const int s3n = s3 == 2 ? 0 : s3 + 1;
+      if (w == 0) {
+        // the step's factors (written by wave 1 two steps ago: a barrier lies between)
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(&cst[s3][pw_unit][0]);
+        const f32x4 fb = *reinterpret_cast<const f32x4*>(&cst[s3][pw_unit][4]);
+        // ---- gather the 32 partials of d h for the own 16 units (written by the peers during the previous step) --------
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+          float* src = mail_rd + s3 * kBox;
+          u32x4 v0, v1;
+          for (int i = 0; i < p.pre_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+          for (;;) {
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1) : "v"(src) : "memory");
+            if (!seq_has_sentinel(v0) && !seq_has_sentinel(v1)) break;
+            if (spin.expired()) { timed_out = true; break; }
+            for (int i = 0; i < p.loop_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+          }
+          seq_store16_mode(src, sent, p.store_mode);     // free again (ordered before this wave's next stores by the next poll's wait)
+          seq_store16_mode(src + 256, sent, p.store_mode);
+          float q0 = __uint_as_float(v0.x) + __uint_as_float(v1.x), q1 = __uint_as_float(v0.y) + __uint_as_float(v1.y);
+          float q2 = __uint_as_float(v0.z) + __uint_as_float(v1.z), q3 = __uint_as_float(v0.w) + __uint_as_float(v1.w);
+          seq_row_sum4(q0, q1, q2, q3);
+          r4 = f32x4{q0, q1, q2, q3};
+        }
+        SQ_T(0);
+        if (timed_out) s_i[3] = 1;
+        // ---- gate derivatives of the own units: lane j of row r, unit 4 r + j -------------------------------------------
+        const float rec = l16 == 0 ? r4[0] : l16 == 1 ? r4[1] : l16 == 2 ? r4[2] : r4[3];
+        const float dh = fa[0] + rec;
+        const float dcv = fmaf(dh, fa[1], dcarry);
+        dcarry = dcv * fa[2];
+        if (pw_lane) {
+          dgl[pw_unit] = dcv * fa[3]; dgl[16 + pw_unit] = dcv * fb[0]; dgl[32 + pw_unit] = dcv * fb[1]; dgl[48 + pw_unit] = dh * fb[2];
+        }
+        SQ_T(1);
+      }
+      seq_lds_barrier();
+      SQ_T(2);
+      if (s_i[3]) {              // loud failure: the gradient of this layer turns NaN
+        if (tid == 0) p.dgx[(size_t)d * G4 + 16 * rank] = __int_as_float(0x7fc00000);
+        return;
+      }
+      float dg_own = dgl[lane];                // (wave 1 writes it out behind the product; wave 0 may be a step ahead by then:
+      asm volatile("" : "+v"(dg_own));         // the read must not sink below the mailbox stores)
+      if (step < T - 1) {
+        // ---- own 64 rows of dgates x own W_hh rows: the lane's two columns -------------------------------------------------
+        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        f32x4 dva[16];                                      // all sixteen (broadcast) reads in flight before the first FMA
+#pragma unroll
+        for (int r4i = 0; r4i < 16; ++r4i) dva[r4i] = *reinterpret_cast<const f32x4*>(&dgl[4 * r4i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r4i = 0; r4i < 16; ++r4i) {
+          const f32x4 dv = dva[r4i];
+          a0 = __builtin_elementwise_fma(f32x2{dv[0], dv[0]}, wb[4 * r4i], a0);
+          a1 = __builtin_elementwise_fma(f32x2{dv[1], dv[1]}, wb[4 * r4i + 1], a1);
+          a2 = __builtin_elementwise_fma(f32x2{dv[2], dv[2]}, wb[4 * r4i + 2], a2);
+          a3 = __builtin_elementwise_fma(f32x2{dv[3], dv[3]}, wb[4 * r4i + 3], a3);
+        }
+        a0 += a2; a1 += a3;
+        seq_store_mode(mail_wr0 + s3n * kBox, a0[0] + a1[0], p.store_mode);
+        seq_store_mode(mail_wr1 + s3n * kBox, a0[1] + a1[1], p.store_mode);
+      }
+      SQ_T(3);
+      if (io) {                  // behind the hand-over: d gx of the step to HBM, the factors two steps ahead, the prefetch
+        *dgx_out = dg_own;
+        dgx_out += dgx_stride;
+        put_factors(step + 2, s3 == 0 ? 2 : s3 - 1);                   // slot (step + 2) % 3, from the loads of a step ago
+        load_pw(step + 3);
+      }
+      s3 = s3n;
+    }
+    SQ_PRINT("lstm_bwd_seq2", "(wave 0: mailbox poll + row sums | gate derivatives | lds barrier | product + mailbox stores)", T);
     if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!seq_team_barrier(ctl, role, &nbar, s_i)) return;     // nobody writes a mailbox of the next pair before everybody has read the last of this one
   }
@@ -439,6 +863,16 @@ static int seq_teams(int pairs) {
   return std::max(1, std::min(most, (pairs + 7) / 8));
 }
 
+// PK2_LSTM_SEQ_FORM=1 keeps the round-2 kernels (lstm_fwd_seq / lstm_bwd_seq) for A/B runs; default: the round-4 forms.
+static int seq_form() {
+  static int form = -1;
+  if (form < 0) {
+    const char* env = getenv("PK2_LSTM_SEQ_FORM");
+    form = (env && atoi(env) == 1) ? 1 : 2;
+  }
+  return form;
+}
+
 bool lstm_seq_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_SEQ");
   if (env && atoi(env) == 0) return false;
@@ -461,8 +895,12 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(y), (int)kSeqSentinel, (size_t)T * B * D * H, stream));
-  SeqFwdParams p{gx, whh, bhh, y, gates, cells, B, T, D};
-  hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
+  static const int pre = getenv("PK2_SEQ_FWD_PRESLEEP") ? atoi(getenv("PK2_SEQ_FWD_PRESLEEP")) : 0;
+  static const int lps = getenv("PK2_SEQ_FWD_LOOPSLEEP") ? atoi(getenv("PK2_SEQ_FWD_LOOPSLEEP")) : 0;
+  static const int smode = getenv("PK2_SEQ_STORE_MODE") ? atoi(getenv("PK2_SEQ_STORE_MODE")) : 1;
+  SeqFwdParams p{gx, whh, bhh, y, gates, cells, B, T, D, pre, lps, smode};
+  if (seq_form() == 1) hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
+  else hipLaunchKernelGGL(lstm_fwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   PK2_LAUNCH_CHECK();
   if (g_seq_state < 0) {                 // first use on this device: every pair done, nobody timed out?
     SeqCtl* h = new SeqCtl;
@@ -488,8 +926,12 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * kSeqTeams * kSeqMailFloats, stream));
-  SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D};
-  hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
+  static const int pre = getenv("PK2_SEQ_BWD_PRESLEEP") ? atoi(getenv("PK2_SEQ_BWD_PRESLEEP")) : 0;
+  static const int lps = getenv("PK2_SEQ_BWD_LOOPSLEEP") ? atoi(getenv("PK2_SEQ_BWD_LOOPSLEEP")) : 0;
+  static const int smode = getenv("PK2_SEQ_STORE_MODE") ? atoi(getenv("PK2_SEQ_STORE_MODE")) : 1;
+  SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D, pre, lps, smode};
+  if (seq_form() == 1) hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
+  else hipLaunchKernelGGL(lstm_bwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky);
   PK2_LAUNCH_CHECK();
   *ran = true;
