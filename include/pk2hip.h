@@ -127,6 +127,12 @@ int pk2_chain_den_fwd_bwd(const pk2_den_graph* g, const float* logits, int64_t s
                           int64_t gamma_seq_stride, int64_t gamma_frame_stride, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Test hook: the objective / guard rule of pk2_chain_objf_and_deriv (Kaldi ComputeChainObjfAndDeriv: objf finite and
+ * |alpha-beta product - 1| <= 2.0, else objf = -10 * weight * frames and a zero derivative) applied to given device arrays
+ * of N per-sequence quantities.  out: device f32[3N] = {objf, num_lp, den_lp}; flags: device i32[N]. */
+int pk2_chain_debug_flags(const float* num_lp, const float* den_lp, const float* alpha_beta_product,
+                          const int32_t* lengths, int32_t N, float weight, float* out, int32_t* flags, void* stream);
+
 /* ------------------------------------------------------------------ *
  * Chain supervision of one utterance from its alignment (host-side integer work, no device memory).
  * Replaces, for bin/train_chain.py:262-272 of the reference,
@@ -388,6 +394,19 @@ int pk2_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int pk2_sgd_step(float* param, const float* grad, float* momentum_buf /* NULL = none */,
                  int64_t n, float lr, float momentum, float weight_decay, int32_t first_step,
                  float max_norm, const float* norm, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Guard of the persistent kernels (no reference counterpart: cuDNN / Kaldi kernels cannot time out).
+ * The one-launch recurrences, the persistent denominator and the persistent lattice decoder poll each other's results
+ * with a 1 s time-out; a launch that gave up has its output poisoned with NaN by a check kernel, which also raises this
+ * per-device guard.  While it is raised pk2_adam_step / pk2_sgd_step leave parameters and moments untouched (so that a
+ * poisoned gradient never reaches the weights, e.g. in bin/train_ce.py, which has no Kaldi-style NaN guard), and
+ * pk2_persist_guard_status reports it WITHOUT synchronising (host-mapped word): pykaldi2_amd.optim raises at the next
+ * step().  pk2_persist_guard_clear lowers it (synchronises); pk2_persist_guard_raise raises it from the device (tests).
+ * ------------------------------------------------------------------ */
+int pk2_persist_guard_status(uint32_t* raised);
+int pk2_persist_guard_clear(void);
+int pk2_persist_guard_raise(void* stream);
 
 /* ------------------------------------------------------------------ *
  * Lattice path: on-the-fly lattice generation + lattice forward-backward for the MMI / sMBR / MPFE

@@ -159,7 +159,8 @@ void orc_chain_batch(int S, int P, int64_t A, const int32_t* src, const int32_t*
     double den = orc_den_fb(S, P, A, src, dst, pdf, prob, pi, lg, row_stride, T, leaky, -weight, g, row_stride,
                             &check);
     double objf = weight * (num - den);
-    if (!isfinite(objf) || !(fabs(check - 1.0) <= 0.05)) {
+    /* Kaldi: abandon when |alpha-beta product - num_sequences| > 2.0 (BetaGeneralFrameDebug), num_sequences = 1 here */
+    if (!isfinite(objf) || !(fabs(check - 1.0) <= 2.0)) {
       objf = -10.0 * weight * T;
       for (int t = 0; t < T; ++t) memset(g + (int64_t)t * row_stride, 0, sizeof(float) * P);
     }

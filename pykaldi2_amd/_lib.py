@@ -57,6 +57,7 @@ SIGNATURES = {
                                            _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "pk2_chain_den_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _f32, _vp, _vp, _i64, _i64,
                                         _vp, _sz, _vp]),
+    "pk2_chain_debug_flags": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "pk2_split_to_phones": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "pk2_sup_model_create": (_vp, [_i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp,
                                    _vp, _vp, _i32, _vp]),
@@ -120,6 +121,9 @@ SIGNATURES = {
     "pk2_lstm_fwd_workspace_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pk2_lstm_persist_status": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "pk2_persist_guard_status": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "pk2_persist_guard_clear": (C.c_int, []),
+    "pk2_persist_guard_raise": (C.c_int, [_vp]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pk2_dropout_f32": (C.c_int, [_vp, _vp, _i64, _f32, C.c_uint64, _vp]),
@@ -153,6 +157,23 @@ def check(status):
     if status != 0:
         msg = lib().pk2_last_error()
         raise Pk2Error("libpk2hip status %d: %s" % (status, msg.decode() if msg else ""))
+
+
+def persist_guard_raised():
+    """True once a persistent kernel of this process has given up on the current device (include/pk2hip.h: guard of the
+    persistent kernels).  Reads a host-mapped word: no device synchronisation."""
+    flag = C.c_uint32(0)
+    check(lib().pk2_persist_guard_status(C.byref(flag)))
+    return flag.value != 0
+
+
+def check_persist_guard(where):
+    if persist_guard_raised():
+        raise Pk2Error("%s: a persistent kernel (one-launch LSTM recurrence / denominator / lattice decoder) timed out on "
+                       "this device; its output was poisoned with NaN and the optimiser kernels have been leaving the "
+                       "weights untouched since.  Typical causes: the GPU is shared with another process, or fewer than "
+                       "256 CUs are available to the launch.  PK2_LSTM_SEQ=0 PK2_LSTM_PERSIST=0 PK2_DEN_PERSIST=0 "
+                       "PK2_LAT_DECODER=frames select the launch-per-step kernels." % where)
 
 
 def ptr(t):

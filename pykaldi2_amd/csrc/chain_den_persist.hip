@@ -517,9 +517,11 @@ __global__ void __launch_bounds__(kPT) den_persist_kernel(const DenPersistParams
 }
 
 // A launch that did not complete every recursion (a poll timed out) must not look like a result.
-__global__ void den_persist_check(const DenPersistCtl* ctl, int ntasks, float* den_lp, int n) {
-  if (ctl->abort != 0u || ctl->done != (unsigned)ntasks)
+__global__ void den_persist_check(const DenPersistCtl* ctl, int ntasks, float* den_lp, int n, unsigned* guard_dev, unsigned* guard_host) {
+  if (ctl->abort != 0u || ctl->done != (unsigned)ntasks) {
+    if (threadIdx.x == 0) persist_guard_raise(guard_dev, guard_host);
     for (int i = threadIdx.x; i < n; i += blockDim.x) den_lp[i] = __uint_as_float(0x7fc00000u);
+  }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -617,7 +619,9 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, c
 
 void den_persist_check_launch(float* den_lp, int N, hipStream_t stream) {
   const DenPersistScratch& sc = g_den_scratch[stream];
-  if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N);
+  PersistGuard guard;
+  (void)persist_guard(&guard);
+  if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N, guard.dev, guard.host_dev);
 }
 
 }  // namespace pk2

@@ -2,6 +2,7 @@
 // the team control block, agent-scope loads / stores, the exchange words and their poll, LDS-DMA, wave reductions.
 #pragma once
 #include "den_persist.h"
+#include "persist_guard.h"
 #include "step_graph.h"
 
 namespace pk2 {

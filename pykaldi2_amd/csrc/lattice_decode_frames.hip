@@ -28,6 +28,7 @@
 #include <map>
 
 #include "lattice_decode_common.h"
+#include "persist_guard.h"
 #include "step_graph.h"
 
 namespace pk2 {
@@ -874,9 +875,10 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
 }
 
 // Behind the persistent launch: an aborted or incomplete launch leaves every utterance "not decoded".
-__global__ void lat_persist_check(const DecodeParams p, const LatTeamCtl* ctl, int N, unsigned* sticky) {
+__global__ void lat_persist_check(const DecodeParams p, const LatTeamCtl* ctl, int N, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host) {
   if (ctl->abort == 0u && ctl->done == (unsigned)N) return;
   *sticky = 1u;
+  if (threadIdx.x == 0) persist_guard_raise(guard_dev, guard_host);
   for (int n = threadIdx.x; n < N; n += blockDim.x) p.L.frame[n].status = kLatNotDecoded;
 }
 
@@ -1118,7 +1120,9 @@ static int lat_persist_launch(const DecodeParams& p, int N, int team, hipStream_
       return PK2_OK;
     }
   }
-  hipLaunchKernelGGL(lat_persist_check, dim3(1), dim3(64), 0, stream, p, sc.ctl, N, sc.sticky);
+  PersistGuard guard;
+  (void)persist_guard(&guard);
+  hipLaunchKernelGGL(lat_persist_check, dim3(1), dim3(64), 0, stream, p, sc.ctl, N, sc.sticky, guard.dev, guard.host_dev);
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;

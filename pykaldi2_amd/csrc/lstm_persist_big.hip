@@ -25,6 +25,7 @@
 
 #include "gemm_tile.h"
 #include "lstm_persist.h"
+#include "persist_guard.h"
 
 namespace pk2 {
 
@@ -621,15 +622,15 @@ __global__ void __launch_bounds__(256) lstm_bwd_big_persist2(BigBwd2Params p, Bi
 }
 
 // A launch in which a poll timed out (or a task was never finished) must not pass for a result.
-__global__ void lstm_big_check(const BigCtl* ctl, unsigned ntasks, float* out, size_t n, unsigned* sticky) {
+__global__ void lstm_big_check(const BigCtl* ctl, unsigned ntasks, float* out, size_t n, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host) {
   if (ctl->abort == 0u && ctl->done == ntasks) return;
-  if (threadIdx.x == 0) *sticky = 1u;
+  if (threadIdx.x == 0) { *sticky = 1u; persist_guard_raise(guard_dev, guard_host); }
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
 struct BigScratch { BigCtl* ctl = nullptr; unsigned* flags = nullptr; size_t flag_words = 0; unsigned* sticky = nullptr;
-                    float* mail = nullptr; size_t mail_floats = 0; };
+                    float* mail = nullptr; size_t mail_floats = 0; PersistGuard guard; };
 static std::map<hipStream_t, BigScratch> g_big_scratch;
 static int g_big_state = -1;             // -1 untested, 0 unusable, 1 verified on this device
 
@@ -640,6 +641,7 @@ static int big_scratch(hipStream_t stream, size_t flag_words, BigScratch** out) 
     PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.sticky), sizeof(unsigned)));
     PK2_HIP(hipMemsetAsync(sc.sticky, 0, sizeof(unsigned), stream));
   }
+  if (!sc.guard.dev) { int rc = persist_guard(&sc.guard); if (rc) return rc; }
   if (sc.flag_words < flag_words) {
     if (sc.flags) PK2_HIP(hipFree(sc.flags));
     sc.flags = nullptr; sc.flag_words = 0;
@@ -695,7 +697,7 @@ int lstm_fwd_big_launch(const float* gx, const float* whh, const float* bhh, int
     g_big_state = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
-  hipLaunchKernelGGL(lstm_big_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)ntasks, y, (size_t)T * B * D * H, sc->sticky);
+  hipLaunchKernelGGL(lstm_big_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)ntasks, y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
   *ran = true;
   return PK2_OK;
 }
@@ -740,7 +742,7 @@ int lstm_bwd_big_launch(const float* dy, const float* whh, const float* gates, c
     BigBwdParams p{dy, whh, gates, cells, dgx, sc->flags, B, T, D};
     hipLaunchKernelGGL(lstm_bwd_big_persist, dim3(8 * kBgR), dim3(256), kBgLds, stream, p, sc->ctl);
   }
-  hipLaunchKernelGGL(lstm_big_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)ntasks, dgx, (size_t)T * B * D * 4 * H, sc->sticky);
+  hipLaunchKernelGGL(lstm_big_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)ntasks, dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "lstm_persist.h"
+#include "persist_guard.h"
 
 namespace pk2 {
 
@@ -32,7 +33,11 @@ constexpr int kSWgs = 32;                   // workgroups of a team = CUs of an 
 constexpr int kSeqTeams = 8;                // teams per XCD the control block has room for
 constexpr int kSeqMaxTasks = 64;
 constexpr long long kSeqSpinTicks = 1000LL * 1000 * 100;     // 1 s of the 100 MHz wall clock
-constexpr int kSeqMailFloats = 3 * kSWgs * kSWgs * 16;       // per team: [step % 3][reader][writer][16 units]
+// per team: [step % depth][reader][writer][16 units].  The round-2 kernel uses three slots; the round-4 kernel, whose
+// hand-over stores are plain (XCD-local) ones, walks all eight: a slot's reset by its reader then has seven steps and as
+// many dependent exchanges to land before a writer stores to the slot again.
+constexpr int kSeqMailDepth = 8;
+constexpr int kSeqMailFloats = kSeqMailDepth * kSWgs * kSWgs * 16;
 
 struct SeqCtl {
   unsigned arrive[8];
@@ -104,13 +109,13 @@ __device__ __forceinline__ void seq_lds_barrier() { asm volatile("s_waitcnt lgkm
 // A poll that keeps failing reads the wall clock every 256 rounds; after 1 s (or when somebody else gave up) it raises
 // the abort flag.
 struct SeqSpin {
-  SeqCtl* ctl; long long t0; unsigned n;
-  __device__ __forceinline__ explicit SeqSpin(SeqCtl* c) : ctl(c), t0(0), n(0) {}
+  SeqCtl* ctl; long long t0; unsigned n; long long limit;
+  __device__ __forceinline__ explicit SeqSpin(SeqCtl* c) : ctl(c), t0(0), n(0), limit(kSeqSpinTicks) {}
   __device__ __forceinline__ bool expired() {
     if ((++n & 255u) != 0u) return false;
     const long long now = wall_clock64();
     if (t0 == 0) t0 = now;
-    if (now - t0 > kSeqSpinTicks || seq_load_u(&ctl->abort)) {
+    if (now - t0 > limit || seq_load_u(&ctl->abort)) {
       __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return true;
     }
@@ -130,7 +135,7 @@ __device__ __forceinline__ bool seq_register(SeqCtl* ctl, int* s_i, SeqRole* rol
   if (s_i[1] >= kSeqTeams) return false;
   role->rank = s_i[0];
   role->team = &ctl->team[s_i[2]][s_i[1]];
-  role->team_index = s_i[2] * kSeqTeams + s_i[1];
+  role->team_index = s_i[1] * 8 + s_i[2];       // (team-major: the teams a launch uses are the first 8 * teams mailboxes)
   return true;
 }
 // Next pair of this team (-1: none left / abort).  s_i[3] = abort flag of the workgroup, s_i[4] = the task.
@@ -450,23 +455,41 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
 }
 
 // ---- Round 4: the same recurrences with the step's critical path cut down (lstm_fwd_seq2 / lstm_bwd_seq2) ---------------
-// What the timers of the kernels above (-DPK2_SEQ_PROFILE) charge a step besides the exchange through L2, and what changes:
-//  * `s_waitcnt vmcnt(0)` is a counter of the WAVE, not of the lane: a poll waits for every vector-memory operation the
-//    wave has in flight, whichever lanes issued it.  Forward, every wave prefetches input projections and polls; here the
-//    input projections arrive through the SCALAR cache (s_load_dwordx4 of the wave's 4 units x 4 gates, counted by
-//    lgkmcnt, issued behind the product's last LDS read two steps ahead) and are dealt to the gate lanes with
-//    v_writelane, so the only vector loads of a compute wave are its polls.  Backward, the wave that polls keeps no
-//    other loads: wave 1 prefetches the forward pass's values two steps ahead, turns them into the five per-unit
-//    factors of the gate derivatives (everything that does not depend on the incoming d h, including tanh(c)) and
-//    hands them over in LDS; it also writes d gx out of LDS behind the barrier.
+// What the phase timers (-DPK2_SEQ_PROFILE, profiles/r04_seq_phases.txt) charged a step of the kernels above besides the
+// round trip through L2, and what changed (forward 1.47 -> 0.97 us, backward 1.79 -> 1.14 us per step, T = 589, B = 4):
+//  * The hand-over stores were agent-scope (sc1) stores.  On this multi-XCD part an agent-scope store is written THROUGH
+//    the XCD's L2 to the fabric; a team lives on one XCD, whose L2 is the coherence point of its 32 CUs, so plain stores
+//    (which the write-through vector L1 forwards to L2, and which vmcnt acknowledges there) are enough as long as the
+//    readers poll with L1-bypassing loads: backward 1.95 -> 1.22 us per step by that alone (its 2 KB of scattered partial
+//    sums per workgroup and step), forward 1.09 -> 0.98.  (PK2_SEQ_STORE_MODE=0 restores sc1 for A/B.)  The data is
+//    polled on itself over a sentinel, so no ordering between stores is assumed; the backward mailboxes are a ring of
+//    eight step slots, so that a slot's reset has seven steps to land before the slot is written again.
+//  * `s_waitcnt vmcnt(0)` counts the WAVE's operations, not the lane's: a poll waits for every vector-memory operation the
+//    wave has in flight.  Forward: waves 0, 1 poll (a granule per lane) and have nothing else in flight but their h
+//    stores; wave 2 prefetches the input projections of the whole workgroup two steps ahead into an LDS ring, wave 3
+//    writes gate activations and cells (handed over in LDS) to HBM a step later -- both behind their h stores.
+//    Backward: wave 0 polls; wave 1 prefetches the forward pass's values, turns them into the per-unit factors of the
+//    gate derivatives (everything that does not depend on the incoming d h, tanh(c) included) two steps ahead in LDS,
+//    and writes d gx out -- behind its share of the partial sums.  (Scalar loads for the prefetch were tried first:
+//    slower, the scalar cache misses queue up behind each other and the LDS waits share their counter.)
+//  * What the compiler does to a persistent loop: it waits for a load where the VALUE is first needed, so (i) the waits
+//    for W_hh landed inside the step loop (an `s_waitcnt vmcnt(0)` in every product, which then waits for the step's own
+//    stores and prefetches: explicit wait before the loop), (ii) a load under a branch is waited for at the join, i.e. at
+//    once (unconditional loads from clamped pointers), (iii) a register rotation copies the values just requested (no
+//    rotation: one set of registers in flight for a whole step).  Addresses walk pointers (the per-step 64-bit index
+//    arithmetic was 150-300 clocks of a 2300-clock step: a lone wave issues an instruction every ~5 clocks).
 //  * Forward product: a lane owns a 32-k slice of the FOUR gate rows of one unit (was: 128 k's of one row): 8
-//    ds_read_b128 instead of 32 per lane and step (the four waves share one LDS port), packed FMAs (v_pk_fma_f32), the
-//    16 slices of a unit are the 16 lanes of a DPP row and are added by a 4-level butterfly (the sums are identical in
-//    all lanes of the row); lane j of the row applies gate j's nonlinearity (tanh as a scaled sigmoid: one exp2 + one
-//    rcp for all four gates at once), lane 0 collects them with three DPP moves.
-//  * Backward: ONE wave gathers the mailbox (two 16-byte granules per lane: writers j and j + 16, a DPP row per
-//    group of 4 units), adds the 32 partials with the same butterfly and finishes the gate derivatives in the same
-//    lanes: no LDS round trip and no barrier between the poll and the pointwise work, no 32-deep serial sum on 16 threads.
+//    ds_read_b128 instead of 32 per lane and step, all in flight before the first FMA, packed FMAs in eight independent
+//    chains (tools/ubench/valu_rate.hip: 5.1 clocks per v_pk_fma_f32 in independent chains, 8.4 in one chain); the 16
+//    slices of a unit are the 16 lanes of a DPP row, added by a 4-level butterfly (v_add_f32_dpp in inline asm: left to
+//    the compiler the four chains become v_pk_add_f32 with two v_mov_dpp each); lane j of the row applies gate j's
+//    nonlinearity (tanh as a scaled sigmoid: one exp2 + one rcp for all four gates at once), lane 0 collects them.
+//  * Backward: ONE wave gathers the mailbox (two 16-byte granules per lane: writers j and j + 16, a DPP row per group
+//    of 4 units), adds the 32 partials with the same butterfly and finishes the gate derivatives in the same lanes: no
+//    LDS round trip and no barrier between the poll and the pointwise work, no 32-deep serial sum on 16 threads.  A lane
+//    PAIR owns a 16-byte granule of the partial d h (4 columns x half of the rows each), so the partials leave as one
+//    16-byte store per pair instead of two scattered 4-byte stores per lane; the reader resets a slot behind its own
+//    partials (issuing the two reset stores takes ~300 clocks).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PK2_CONSTANT_AS __attribute__((address_space(4)))
 
@@ -580,8 +603,10 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq2(SeqFwdParams p, SeqCtl* ctl
     float cstate = 0.f;
     bool timed_out = false;
     SeqSpin spin(ctl);
+    spin.limit = 10 * kSeqSpinTicks;      // until the first exchange has worked: a team mate dispatched late is not a deadlock
     SQ_T0();
     for (int step = 0; step < T; ++step) {
+      if (step == 2) { spin.limit = kSeqSpinTicks; spin.t0 = 0; }
       const int buf = step & 1;
       const float pre = gxs[step % 3][pre_idx] + bias;
       // ---- gather h_{t-1} of this (sequence, direction): 512 floats = 128 granules of 16 bytes -----------------------
@@ -686,14 +711,20 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
     const int task = seq_next_task(ctl, role, iter, B * D, s_i);
     if (task < 0) return;
     const int b = task / D, d = task % D;
-    // W_hh[d][(r/16)*H + 16*rank + r%16][k] for the 64 own rows r and the lane's two columns k = 128 w + lane (+ 64)
-    f32x2 wb[64];
+    // A lane pair owns one 16-byte granule of the partial d h -- columns k = 4 G .. 4 G + 3, G = 32 w + lane / 2, i.e. units
+    // 4 (G % 4) .. of reader G / 4 -- and each lane of the pair half of the workgroup's 64 rows (lane % 2 = 0: gates i, f;
+    // 1: gates g, o): W_hh[d][(gate)*H + 16*rank + unit][4 G + j] for its 32 rows.  The pair's sums meet by one DPP add per
+    // value and the even lane stores the granule: one 16-byte store per lane pair and step.
+    const int gidx = 32 * w + (lane >> 1), half = lane & 1;
+    f32x2 wb[32][2];
     {
-      const float* wbase = p.whh + (size_t)d * G4 * H + 128 * w + lane;
+      const float* wbase = p.whh + (size_t)d * G4 * H + 4 * gidx;
 #pragma unroll
-      for (int r = 0; r < 64; ++r) {
-        const float* wrow = wbase + ((size_t)(r >> 4) * H + 16 * rank + (r & 15)) * H;
-        wb[r] = f32x2{wrow[0], wrow[64]};
+      for (int r = 0; r < 32; ++r) {
+        const int rr = 32 * half + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wbase + ((size_t)(rr >> 4) * H + 16 * rank + (rr & 15)) * H);
+        wb[r][0] = f32x2{v[0], v[1]};
+        wb[r][1] = f32x2{v[2], v[3]};
       }
     }
     float dcarry = 0.f;
@@ -739,17 +770,18 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): W_hh is there before the loop (no waits for it inside)
     __syncthreads();
-    // the mailbox of the step: [step % 3][reader][writer][16 units]; wave 0 reads [.][rank][writer l16 (+ 16)][units 4 row ..]
+    // the mailbox of the step: [step % 8][reader][writer][16 units]; wave 0 reads [.][rank][writer l16 (+ 16)][units 4 row ..]
     float* mail_rd = mail0 + (size_t)rank * (kSWgs * 16) + (size_t)l16 * 16 + 4 * row;
-    const int k0 = 128 * w + lane, k1 = k0 + 64;
-    float* mail_wr0 = mail0 + ((size_t)(k0 >> 4) * kSWgs + rank) * 16 + (k0 & 15);       // peer k/16 reads [writer = rank][unit k%16]
-    float* mail_wr1 = mail0 + ((size_t)(k1 >> 4) * kSWgs + rank) * 16 + (k1 & 15);
+    float* mail_wr = mail0 + ((size_t)(gidx >> 2) * kSWgs + rank) * 16 + 4 * (gidx & 3);  // peer G/4 reads [writer = rank][units 4 (G%4) ..]
     constexpr int kBox = kSWgs * kSWgs * 16;
     int s3 = 0;                                          // step % 3
     SeqSpin spin(ctl);
+    spin.limit = 10 * kSeqSpinTicks;      // (as in the forward kernel)
     SQ_T0();
     for (int step = 0; step < T; ++step) {
+      if (step == 2) { spin.limit = kSeqSpinTicks; spin.t0 = 0; }
       const int s3n = s3 == 2 ? 0 : s3 + 1;
+      const int m8 = step & (kSeqMailDepth - 1), m8n = (step + 1) & (kSeqMailDepth - 1);
       if (w == 0) {
         // the step's factors (written by wave 1 two steps ago: a barrier lies between)
         const f32x4 fa = *reinterpret_cast<const f32x4*>(&cst[s3][pw_unit][0]);
@@ -757,18 +789,26 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
         // ---- gather the 32 partials of d h for the own 16 units (written by the peers during the previous step) --------
         f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-          float* src = mail_rd + s3 * kBox;
+          float* src = mail_rd + m8 * kBox;
           u32x4 v0, v1;
           for (int i = 0; i < p.pre_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+#ifdef PK2_SEQ_PROFILE
+          { const long long c0_ = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sq_acc_[4] += clock64() - c0_; }   // own stores acknowledged
+          bool first_ = true; const long long c1_ = clock64();
+#endif
           for (;;) {
             asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(v0), "=&v"(v1) : "v"(src) : "memory");
+#ifdef PK2_SEQ_PROFILE
+            if (first_) { sq_acc_[5] += clock64() - c1_; first_ = false; }
+#endif
             if (!seq_has_sentinel(v0) && !seq_has_sentinel(v1)) break;
             if (spin.expired()) { timed_out = true; break; }
             for (int i = 0; i < p.loop_sleep; ++i) __builtin_amdgcn_s_sleep(1);
           }
-          seq_store16_mode(src, sent, p.store_mode);     // free again (ordered before this wave's next stores by the next poll's wait)
-          seq_store16_mode(src + 256, sent, p.store_mode);
+#ifdef PK2_SEQ_PROFILE
+          sq_acc_[6] += clock64() - c1_;           // the whole poll loop
+#endif
           float q0 = __uint_as_float(v0.x) + __uint_as_float(v1.x), q1 = __uint_as_float(v0.y) + __uint_as_float(v1.y);
           float q2 = __uint_as_float(v0.z) + __uint_as_float(v1.z), q3 = __uint_as_float(v0.w) + __uint_as_float(v1.w);
           seq_row_sum4(q0, q1, q2, q3);
@@ -796,22 +836,40 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
       asm volatile("" : "+v"(dg_own));         // the read must not sink below the mailbox stores)
       if (step < T - 1) {
         // ---- own 64 rows of dgates x own W_hh rows: the lane's two columns -------------------------------------------------
-        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-        f32x4 dva[16];                                      // all sixteen (broadcast) reads in flight before the first FMA
+        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, c0 = a0, c1 = a0, c2 = a0, c3 = a0;     // eight independent chains
+        f32x4 dva[8];                                       // all eight reads in flight before the first FMA
 #pragma unroll
-        for (int r4i = 0; r4i < 16; ++r4i) dva[r4i] = *reinterpret_cast<const f32x4*>(&dgl[4 * r4i]);
+        for (int r4i = 0; r4i < 8; ++r4i) dva[r4i] = *reinterpret_cast<const f32x4*>(&dgl[32 * half + 4 * r4i]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r4i = 0; r4i < 16; ++r4i) {
+        for (int r4i = 0; r4i < 8; ++r4i) {
           const f32x4 dv = dva[r4i];
-          a0 = __builtin_elementwise_fma(f32x2{dv[0], dv[0]}, wb[4 * r4i], a0);
-          a1 = __builtin_elementwise_fma(f32x2{dv[1], dv[1]}, wb[4 * r4i + 1], a1);
-          a2 = __builtin_elementwise_fma(f32x2{dv[2], dv[2]}, wb[4 * r4i + 2], a2);
-          a3 = __builtin_elementwise_fma(f32x2{dv[3], dv[3]}, wb[4 * r4i + 3], a3);
+          a0 = __builtin_elementwise_fma(f32x2{dv[0], dv[0]}, wb[4 * r4i][0], a0);     c0 = __builtin_elementwise_fma(f32x2{dv[0], dv[0]}, wb[4 * r4i][1], c0);
+          a1 = __builtin_elementwise_fma(f32x2{dv[1], dv[1]}, wb[4 * r4i + 1][0], a1); c1 = __builtin_elementwise_fma(f32x2{dv[1], dv[1]}, wb[4 * r4i + 1][1], c1);
+          a2 = __builtin_elementwise_fma(f32x2{dv[2], dv[2]}, wb[4 * r4i + 2][0], a2); c2 = __builtin_elementwise_fma(f32x2{dv[2], dv[2]}, wb[4 * r4i + 2][1], c2);
+          a3 = __builtin_elementwise_fma(f32x2{dv[3], dv[3]}, wb[4 * r4i + 3][0], a3); c3 = __builtin_elementwise_fma(f32x2{dv[3], dv[3]}, wb[4 * r4i + 3][1], c3);
         }
-        a0 += a2; a1 += a3;
-        seq_store_mode(mail_wr0 + s3n * kBox, a0[0] + a1[0], p.store_mode);
-        seq_store_mode(mail_wr1 + s3n * kBox, a0[1] + a1[1], p.store_mode);
+        a0 = (a0 + a1) + (a2 + a3); c0 = (c0 + c1) + (c2 + c3);
+        float g0 = a0[0], g1 = a0[1], g2 = c0[0], g3 = c0[1];
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                     : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
+        if (half == 0) {
+          const f32x4 gv = {g0, g1, g2, g3};
+          u32x4 gu4;
+          __builtin_memcpy(&gu4, &gv, 16);
+          seq_store16_mode(mail_wr + m8n * kBox, gu4, p.store_mode);
+        }
+      }
+      // The mailbox slot read in this step is free again: its reset goes out behind the step's own partials (issuing the
+      // two stores takes ~300 clocks, which the poll of the next step has to spare) and has until the slot's next use, seven
+      // steps on, to land.
+      if (w == 0 && step > 0) {
+        seq_store16_mode(mail_rd + m8 * kBox, sent, p.store_mode);
+        seq_store16_mode(mail_rd + m8 * kBox + 256, sent, p.store_mode);
       }
       SQ_T(3);
       if (io) {                  // behind the hand-over: d gx of the step to HBM, the factors two steps ahead, the prefetch
@@ -822,7 +880,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
       }
       s3 = s3n;
     }
-    SQ_PRINT("lstm_bwd_seq2", "(wave 0: mailbox poll + row sums | gate derivatives | lds barrier | product + mailbox stores)", T);
+    SQ_PRINT("lstm_bwd_seq2", "(wave 0: mailbox poll + row sums | gate derivatives | lds barrier | product + mailbox stores || inside the poll: own stores acknowledged | first poll round trip | poll loop)", T);
     if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!seq_team_barrier(ctl, role, &nbar, s_i)) return;     // nobody writes a mailbox of the next pair before everybody has read the last of this one
   }
@@ -832,14 +890,14 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
 // pass keeps its NaN sentinels in y, but the backward pass would leave dgx -- freshly allocated memory -- partly
 // unwritten.  One workgroup after every persistent launch turns the launch's output into NaN in that case and raises a
 // sticky flag (the control block itself is cleared by the next launch) that pk2_lstm_persist_status reports.
-__global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky) {
+__global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host) {
   if (ctl->abort == 0u && ctl->done == pairs) return;
-  if (threadIdx.x == 0) *sticky = 1u;
+  if (threadIdx.x == 0) { *sticky = 1u; persist_guard_raise(guard_dev, guard_host); }
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
-struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; };
+struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; PersistGuard guard; };
 static std::map<hipStream_t, SeqScratch> g_seq_scratch;
 static int g_seq_state = -1;             // -1 untested, 0 unusable, 1 verified on this device
 
@@ -851,6 +909,7 @@ static int seq_scratch(hipStream_t stream, SeqScratch** out) {
     PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.sticky), sizeof(unsigned)));
     PK2_HIP(hipMemsetAsync(sc.sticky, 0, sizeof(unsigned), stream));
   }
+  if (!sc.guard.dev) { int rc = persist_guard(&sc.guard); if (rc) return rc; }
   *out = &sc;
   return PK2_OK;
 }
@@ -912,7 +971,7 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
     g_seq_state = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
-  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky);
+  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
   *ran = true;
   return PK2_OK;
 }
@@ -925,14 +984,14 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   int rc = seq_scratch(stream, &sc);
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
-  PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * kSeqTeams * kSeqMailFloats, stream));
+  PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * seq_teams(B * D) * kSeqMailFloats, stream));
   static const int pre = getenv("PK2_SEQ_BWD_PRESLEEP") ? atoi(getenv("PK2_SEQ_BWD_PRESLEEP")) : 0;
   static const int lps = getenv("PK2_SEQ_BWD_LOOPSLEEP") ? atoi(getenv("PK2_SEQ_BWD_LOOPSLEEP")) : 0;
   static const int smode = getenv("PK2_SEQ_STORE_MODE") ? atoi(getenv("PK2_SEQ_STORE_MODE")) : 1;
   SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D, pre, lps, smode};
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   else hipLaunchKernelGGL(lstm_bwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
-  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky);
+  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "persist_guard.h"
 
 namespace pk2 {
 
@@ -54,7 +55,9 @@ __global__ void __launch_bounds__(kOptThreads) adam_kernel(float* __restrict__ p
                                                            float* __restrict__ vmax, int64_t n, float lr,
                                                            float b1, float b2, float eps, float wd,
                                                            float bc1, float bc2_sqrt, float max_norm,
-                                                           const float* norm, float grad_scale) {
+                                                           const float* norm, float grad_scale,
+                                                           const unsigned* guard) {
+  if (*guard != 0u) return;       // a persistent kernel gave up in this process: the gradients may be poison (persist_guard.h)
   const float coef = clip_coef(max_norm, norm) * grad_scale;
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kOptThreads) {
@@ -80,7 +83,9 @@ template <bool MOMENTUM>
 __global__ void __launch_bounds__(kOptThreads) sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ buf, int64_t n, float lr,
                                                           float momentum, float wd, int first_step,
-                                                          float max_norm, const float* norm, float grad_scale) {
+                                                          float max_norm, const float* norm, float grad_scale,
+                                                          const unsigned* guard) {
+  if (*guard != 0u) return;       // (persist_guard.h)
   const float coef = clip_coef(max_norm, norm) * grad_scale;
   for (int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kOptThreads) {
     float pi = p[i];
@@ -126,14 +131,16 @@ extern "C" int pk2_adam_step(float* param, const float* grad, float* exp_avg, fl
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  PersistGuard guard;
+  { int rc = persist_guard(&guard); if (rc) return rc; }
   if (max_exp_avg_sq)
     hipLaunchKernelGGL(adam_kernel<true>, dim3(opt_blocks(n)), dim3(kOptThreads), 0, stream, param, grad,
                        exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
-                       max_norm, norm, grad_scale);
+                       max_norm, norm, grad_scale, guard.dev);
   else
     hipLaunchKernelGGL(adam_kernel<false>, dim3(opt_blocks(n)), dim3(kOptThreads), 0, stream, param, grad,
                        exp_avg, exp_avg_sq, nullptr, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
-                       max_norm, norm, grad_scale);
+                       max_norm, norm, grad_scale, guard.dev);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }
@@ -143,12 +150,14 @@ extern "C" int pk2_sgd_step(float* param, const float* grad, float* momentum_buf
                             const float* norm, float grad_scale, void* stream_) {
   PK2_REQUIRE(param && grad && n > 0, "sgd_step: bad args");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PersistGuard guard;
+  { int rc = persist_guard(&guard); if (rc) return rc; }
   if (momentum_buf && momentum != 0.f)
     hipLaunchKernelGGL(sgd_kernel<true>, dim3(opt_blocks(n)), dim3(kOptThreads), 0, stream, param, grad,
-                       momentum_buf, n, lr, momentum, weight_decay, first_step, max_norm, norm, grad_scale);
+                       momentum_buf, n, lr, momentum, weight_decay, first_step, max_norm, norm, grad_scale, guard.dev);
   else
     hipLaunchKernelGGL(sgd_kernel<false>, dim3(opt_blocks(n)), dim3(kOptThreads), 0, stream, param, grad,
-                       nullptr, n, lr, momentum, weight_decay, first_step, max_norm, norm, grad_scale);
+                       nullptr, n, lr, momentum, weight_decay, first_step, max_norm, norm, grad_scale, guard.dev);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -103,6 +103,7 @@ class Adam(_FlatOptimizer):
         self.state = None
 
     def step(self):
+        _lib.check_persist_guard("Adam.step")     # (no synchronisation; raises at the first step after a time-out)
         p, g = self._flat()
         if self.state is None or self.state["exp_avg"].device != p.device:
             self.state = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p),
@@ -155,6 +156,7 @@ class SGD(_FlatOptimizer):
         self.buf = None
 
     def step(self):
+        _lib.check_persist_guard("SGD.step")
         p, g = self._flat()
         first = self.buf is None
         if self.momentum != 0 and first:

@@ -181,6 +181,34 @@ def test_reference_operator_convention_and_nan_guard():
     assert out[0, 0].item() == -10.0 * T and not grad.any().item()
 
 
+def test_alpha_beta_guard_follows_kaldis_rule():
+    """Kaldi abandons a minibatch when the objective is not finite or |sum_h alpha'[0,h] beta[0,h] - num_sequences| > 2.0
+    (DenominatorComputation::BetaGeneralFrameDebug); a product that is merely not ApproxEqual to it is trained on.  Rounds
+    1-3 abandoned beyond 0.05: the band (0.05, 2] is checked here through the rule's own kernel, because a
+    healthy sequence never produces such a product."""
+    import ctypes
+    from pykaldi2_amd import _lib
+    ck = np.array([1.0, 1.04, 1.06, 0.5, 2.9, 3.0, 3.1, -1.0, -1.1, np.nan, np.inf, 1.5, 1.5], dtype=np.float32)
+    N = len(ck)
+    num = np.full(N, -200.0, dtype=np.float32); den = np.full(N, -180.0, dtype=np.float32)
+    num[11] = np.nan; den[12] = np.inf
+    lens = np.arange(10, 10 + N, dtype=np.int32)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    d_num, d_den, d_ck, d_len = dev(num), dev(den), dev(ck), dev(lens)
+    out = torch.empty(3 * N, device="cuda"); flags = torch.empty(N, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().pk2_chain_debug_flags(_lib.ptr(d_num), _lib.ptr(d_den), _lib.ptr(d_ck), _lib.ptr(d_len), N,
+                                                ctypes.c_float(0.5), _lib.ptr(out), _lib.ptr(flags), _lib.stream_ptr()))
+    want_ok = np.array([1, 1, 1, 1, 1, 1, 0, 1, 0, 0, 0, 0, 0], dtype=np.int32)
+    assert np.array_equal(flags.cpu().numpy(), want_ok)
+    got = out.cpu().numpy()
+    for n in range(N):
+        want = 0.5 * (num[n] - den[n]) if want_ok[n] else -10.0 * 0.5 * lens[n]
+        assert got[n] == np.float32(want), (n, got[n], want)
+    # the float64 numpy oracle applies the same rule
+    for c, ok in ((1.5, True), (2.9, True), (3.1, False)):
+        assert (abs(c - 1.0) <= 2.0) == ok
+
+
 def test_persistent_kernel_more_recursions_than_teams():
     """9 ragged sequences (18 recursions for the 8 teams of the persistent kernel: every team takes several from the
     queue, the ring buffers are reused), lengths down to 1, against the oracle and against the launch-per-frame kernels."""

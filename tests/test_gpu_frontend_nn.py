@@ -326,6 +326,39 @@ def test_fused_optimisers_match_reference_golden(golden, name):
         assert np.abs(model.p.cpu().numpy() - g["opt_%s_traj" % name][i]).max() < 2e-6
 
 
+@pytest.mark.parametrize("name", ["adam", "sgd"])
+def test_raised_persist_guard_keeps_the_optimisers_off_the_weights(name):
+    """A persistent kernel that timed out poisons its output with NaN and raises the per-device guard (include/pk2hip.h,
+    csrc/persist_guard.h): from then on the fused optimiser kernels must leave weights and moments alone -- the launch is
+    already queued when the host finds out -- and the next step() must raise.  The guard is raised here the way a check
+    kernel does it (pk2_persist_guard_raise: a kernel on the stream), behind a first, healthy step."""
+    from pykaldi2_amd import _lib
+    L = _lib.lib()
+    model = _Flat(torch.linspace(-1.0, 1.0, 4096).cuda())
+    opt = optim.Adam(model, lr=1e-2, amsgrad=True) if name == "adam" else optim.SGD(model, lr=1e-2, momentum=0.9)
+    try:
+        model.g.fill_(0.5)
+        opt.step()                                    # healthy
+        before = model.p.clone()
+        _lib.check(L.pk2_persist_guard_raise(_lib.stream_ptr()))
+        model.g.fill_(float("nan"))                   # what a poisoned backward pass would leave
+        try:                                          # the host may or may not have seen the word yet: either the call
+            opt.step()                                # raises, or its kernel finds the device word set
+        except _lib.Pk2Error:
+            pass
+        torch.cuda.synchronize()
+        assert torch.equal(model.p, before) and bool(torch.isfinite(model.p).all())
+        with pytest.raises(_lib.Pk2Error, match="persistent kernel"):
+            opt.step()
+        assert torch.equal(model.p, before)
+    finally:
+        _lib.check(L.pk2_persist_guard_clear())
+    model.g.fill_(0.5)
+    opt.step()                                        # lowered: updates again
+    torch.cuda.synchronize()
+    assert not torch.equal(model.p, before) and not _lib.persist_guard_raised()
+
+
 def test_chunking_and_mvn_match_reference_golden(golden):
     g = golden("chunk_mvn")
     for i in range(5):
