@@ -119,18 +119,30 @@ __device__ __forceinline__ gfloat* G(float* p) { return (gfloat*)p; }
 __device__ __forceinline__ cgfloat* G(const float* p) { return (cgfloat*)p; }
 __device__ __forceinline__ gunsigned* G(unsigned* p) { return (gunsigned*)p; }
 __device__ __forceinline__ float ld_agent(cgfloat* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(gfloat* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(gfloat* p, float v) {      // the exchange words (and their resets)
+#if PK2_DP_STOREMODE == 1
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+#endif
+}
 __device__ __forceinline__ unsigned ld_agent_u(gunsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool is_sentinel(float v) { return __float_as_uint(v) == kRingSentinel; }
 __device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// How the state vectors travel (build-time switches for A/B runs).  Default: agent-scope (sc1) stores and loads, as in
-// lstm_persist.hip.  Plain stores + s_waitcnt are NOT enough -- the partial sum that announces a slice overtook the slice
-// on small graphs (wrong results) -- and plain loads behind `buffer_inv sc0` were no faster (11.77 vs 11.75 ms per call).
+// How the state vectors travel (build-time switches for A/B runs).  Loads: agent-scope (sc1, L1-bypassing); plain loads
+// behind `buffer_inv sc0` were no faster (11.77 vs 11.75 ms per call) and keep stale lines.  Stores: PLAIN since round 4.
+// A recursion's team lives on one XCD, whose L2 is the coherence point of its 32 CUs: the write-through vector L1
+// forwards a plain store there and vmcnt acknowledges it there, so "slice stored -> s_waitcnt vmcnt(0) -> barrier -> word"
+// is a release inside the XCD; an agent-scope store is additionally written through the L2 to the fabric on this
+// multi-XCD part and its acknowledgement waits for that.  tools/ubench/handoff_plain.hip hammers exactly this protocol
+// (32 workgroups of one XCD, uneven load): 0 stale words in 10^11 reads, for plain data + agent-scope flag and for plain
+// data + plain flag alike; round 2's "the announcing word overtakes the data on small graphs" did not reproduce on the
+// round-3/4 kernels (3 x 78 chain tests, small graphs included).  -DPK2_DP_STOREMODE=1 restores the agent-scope stores.
 #ifndef PK2_DP_LOADMODE
 #define PK2_DP_LOADMODE 0      // 0: agent-scope loads; 1: buffer_inv sc0 + plain loads; 2: buffer_inv sc1 + plain loads
 #endif
 #ifndef PK2_DP_STOREMODE
-#define PK2_DP_STOREMODE 1     // 0: plain stores; 1: agent-scope stores
+#define PK2_DP_STOREMODE 0     // 0: plain stores; 1: agent-scope stores
 #endif
 __device__ __forceinline__ void invalidate_l1() {
 #if PK2_DP_LOADMODE == 1

@@ -65,7 +65,21 @@ __device__ __forceinline__ unsigned bg_xcc_id() {
 }
 __device__ __forceinline__ unsigned bg_load_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void bg_store_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void bg_store_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Data a team hands over inside its XCD goes out with PLAIN stores (round 4): the vector L1 writes through, vmcnt
+// acknowledges a store once the XCD's L2 -- the coherence point of the team's 32 CUs -- has it, and the readers' loads
+// bypass their L1; an agent-scope (sc1) store is additionally written through the L2 to the fabric on this multi-XCD part
+// and its acknowledgement waits for that (tools/ubench/handoff_plain.hip: 0 stale words in 10^11 reads under uneven load;
+// lstm_persist_seq.hip: backward step 1.95 -> 1.22 us).  -DPK2_BIG_STOREMODE=1 restores the agent-scope stores.
+#ifndef PK2_BIG_STOREMODE
+#define PK2_BIG_STOREMODE 0
+#endif
+__device__ __forceinline__ void bg_store_f(float* p, float v) {
+#if PK2_BIG_STOREMODE == 1
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+#endif
+}
 __device__ __forceinline__ float bg_sig(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float bg_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 __device__ __forceinline__ void bg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -169,7 +183,11 @@ typedef float bg_f32x4acc __attribute__((ext_vector_type(4)));
 // one lane -- the gate math runs in those registers, no transposition through LDS, and gx / gates / cells / h move as
 // 16-byte words (10 memory instructions per lane and step instead of 40).
 __device__ __forceinline__ void bg_store16_agent(float* p, bg_f32x4 v) {
+#if PK2_BIG_STOREMODE == 1
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#endif
 }
 
 __global__ void __launch_bounds__(256) lstm_fwd_big_persist(BigFwdParams p, BigCtl* ctl) {
