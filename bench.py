@@ -141,6 +141,56 @@ class Trainer:
         return loss
 
 
+def scaling_report(step_events, exchange_timing, audio, dev, rank, world):
+    """What an N > 1 line needs to explain its own scaling, from device events of the timed steps:
+    per rank the GPU time of a step (mean / max), the time until its last all-reduce was issued (`pre_exchange`: forward,
+    loss and backward -- in the bucketed schedule the earlier buckets overlap the rest of backward), the duration of its
+    all-reduce calls; gathered over the ranks, per step:  straggler wait of rank r = max over ranks of pre_exchange -
+    pre_exchange of r (a collective finishes when its slowest rank arrives), exchange net of it = duration of the last
+    all-reduce call - that wait; `ideal_weak_irtf` = sum over ranks of audio / (GPU time - straggler wait), i.e. what weak
+    scaling would give if no rank ever waited for another and the exchange cost what it costs net."""
+    K = len(step_events)
+    gpu = np.array([a.elapsed_time(b) for a, b in step_events], dtype=np.float64)
+    pre = gpu.copy()
+    last = np.zeros(K); total = np.zeros(K); nbytes = 0
+    for i, calls in enumerate(exchange_timing or []):
+        if i >= K or not calls:
+            continue
+        pre[i] = step_events[i][0].elapsed_time(calls[-1][0])
+        last[i] = calls[-1][0].elapsed_time(calls[-1][1])
+        total[i] = sum(a.elapsed_time(b) for a, b, _ in calls)
+        nbytes = sum(n for _, _, n in calls)
+    mine = np.stack([gpu, pre, last, total])                       # [4, K]
+    if world > 1:
+        t = torch.from_numpy(mine).to(dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allv, t)
+        allv = np.stack([a.cpu().numpy() for a in allv])           # [world, 4, K]
+        a_t = torch.tensor([audio], dtype=torch.float64, device=t.device)
+        audios = [torch.zeros_like(a_t) for _ in range(world)]
+        torch.distributed.all_gather(audios, a_t)
+        audios = [float(a.item()) for a in audios]
+    else:
+        allv, audios = mine[None], [audio]
+    wait = allv[:, 1, :].max(axis=0, keepdims=True) - allv[:, 1, :]            # [world, K]
+    net = np.maximum(allv[:, 2, :] - wait, 0.0)
+    own = np.maximum(allv[:, 0, :] - wait, 1e-6)
+    per_rank = []
+    for r in range(allv.shape[0]):
+        per_rank.append({"rank": r, "gpu_ms_mean": round(float(allv[r, 0].mean()), 3), "gpu_ms_max": round(float(allv[r, 0].max()), 3),
+                         "pre_exchange_ms_mean": round(float(allv[r, 1].mean()), 3),
+                         "exchange_ms_mean": round(float(allv[r, 3].mean()), 3),
+                         "straggler_wait_ms_mean": round(float(wait[r].mean()), 3),
+                         "audio_s": round(audios[r], 2), "own_irtf": round(audios[r] / (own[r].sum() * 1e-3), 2)})
+    return {"per_rank": per_rank, "ideal_weak_irtf": round(sum(p["own_irtf"] for p in per_rank), 2),
+            "exchange": {"exchange_ms": round(float(allv[:, 3, :].mean()), 3), "exchange_net_ms": round(float(net.mean()), 3),
+                         "straggler_wait_ms": round(float(wait.mean()), 3), "straggler_wait_ms_worst_rank": round(float(wait.mean(axis=1).max()), 3),
+                         "bytes_per_step": int(nbytes),
+                         "how_to_read": "gpu_ms = pre_exchange + last all-reduce (incl. the wait for the slowest rank) + optimiser; "
+                         "value falls short of ideal_weak_irtf by straggler_wait (utterance lengths differ per rank: see "
+                         "irtf_bucketed) plus exchange_net (RCCL over xGMI)"}}
+
+
 def dump_chain_parity_inputs(tr, mb, path):
     """The logits of the breakdown minibatch, its alignments, and what the device computes for them (objective per
     sequence, d objf / d logits): the `parity` leg of the cpu-baseline child checks them against the C port."""
@@ -259,7 +309,7 @@ def persistent_health(den, batch):
     flag = ctypes.c_uint32(7)
     rc = _lib.lib().pk2_lstm_persist_status(ctypes.byref(flag))
     return dict(lstm_persist_abort=int(flag.value) if rc == 0 else -1, den_kernel_path=den.kernel_path(batch),
-                den_persist_form=den.persist_form(batch))
+                den_persist_form=den.persist_form(batch), guard_raised=bool(_lib.persist_guard_raised()))
 
 
 def usable_cores():
@@ -722,19 +772,50 @@ def main():
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
+    # device events around every timed step and around every all-reduce call of it (two event records per step and per
+    # call; read after the timed region): what the N > 1 line reports per rank
+    tr.opt.timing = []
+    step_events = []
     t0 = time.perf_counter()
     audio = 0.0
     for i in range(args.steps):
         mb = batches[(args.warmup + i) % n_unique]
         if i + 1 < args.steps:          # the next step's supervisions: built by the worker thread during this step
             tr.prefetch(batches[(args.warmup + i + 1) % n_unique])
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
         tr.step(mb)
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        step_events.append((e0, e1))
         audio += mb["seconds"]
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     log("timed region done: %.3f s" % dt)
+    exchange_timing, tr.opt.timing = tr.opt.timing, None
+    scaling = scaling_report(step_events, exchange_timing, audio, dev, rank, world)
+    irtf_bucketed = None
+    if world > 1 and not args.length_bucketed:
+        # the same job on minibatches whose utterance lengths are bucketed across the ranks (bin/train_chain.py
+        # -length_bucketed): a second, short timed window, so that one line shows what the stragglers of the default
+        # protocol (everything seeded per rank) cost
+        bb = make_batches(np.random.default_rng(4321 + rank), n_unique, args.batch, dev, np.random.default_rng(4321))
+        k2 = max(2, min(args.steps, 10))
+        for i in range(2):
+            tr.step(bb[i % n_unique])
+        torch.cuda.synchronize(); torch.distributed.barrier()
+        tb = time.perf_counter()
+        audio_b = 0.0
+        for i in range(k2):
+            tr.step(bb[(2 + i) % n_unique])
+            audio_b += bb[(2 + i) % n_unique]["seconds"]
+        torch.cuda.synchronize(); torch.distributed.barrier()
+        sb = torch.tensor([time.perf_counter() - tb, audio_b], dtype=torch.float64, device=dev)
+        tb_max = sb[0:1].clone(); torch.distributed.all_reduce(tb_max, op=torch.distributed.ReduceOp.MAX)
+        ab_sum = sb[1:2].clone(); torch.distributed.all_reduce(ab_sum, op=torch.distributed.ReduceOp.SUM)
+        irtf_bucketed = {"value": round(float(ab_sum.item()) / float(tb_max.item()), 2), "steps": k2,
+                         "protocol": "utterance lengths of a step drawn from one stream shared by the ranks"}
+        del bb
     stats = torch.tensor([dt, audio], dtype=torch.float64, device=dev)
     if torch.distributed.is_initialized():
         tmax = stats[0:1].clone()
@@ -791,10 +872,13 @@ def main():
                    "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY},
                    "allocator_reserve_gb": args.reserve_gb,
                    "hbm_peak_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2)},
-        "exchange": {"library": hvd.comm_library() or ("torch.distributed/" + (torch.distributed.get_backend()
-                     if torch.distributed.is_initialized() else "none")),
-                     "schedule": getattr(tr.opt, "_mode", "single"), "calibration_steps": calibration_steps,
-                     "api": "pk2_allreduce_bucket" if hvd.comm_library() else "torch.distributed.all_reduce"},
+        "exchange": dict({"library": hvd.comm_library() or ("torch.distributed/" + (torch.distributed.get_backend()
+                          if torch.distributed.is_initialized() else "none")),
+                          "ranks": hvd.comm_ranks(),
+                          "schedule": getattr(tr.opt, "_mode", "single"), "calibration_steps": calibration_steps,
+                          "api": "pk2_allreduce_bucket" if hvd.comm_library() else "torch.distributed.all_reduce"},
+                         **scaling["exchange"]),
+        "per_rank": scaling["per_rank"], "ideal_weak_irtf": scaling["ideal_weak_irtf"], "irtf_bucketed": irtf_bucketed,
         "roofline": roof, ("roofline_model" if args.transformer else "roofline_lstm"): roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
         "persistent_health": persistent_health(den, args.batch),
     }

@@ -1353,15 +1353,15 @@ static StepGraphs g_den_graphs;
 static std::map<std::pair<int, hipStream_t>, ParamSlot<DenParams>> g_den_slots;
 
 // One internal side stream (+ fork/join events) per caller stream, created on first use.
-static std::map<hipStream_t, SideStream> g_side_streams;
+static std::map<DevStream, SideStream> g_side_streams;
 int get_side_stream(hipStream_t main, SideStream** out) {
-  auto it = g_side_streams.find(main);
+  auto it = g_side_streams.find(dev_stream(main));
   if (it == g_side_streams.end()) {
     SideStream s;
     PK2_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     PK2_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
     PK2_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
-    it = g_side_streams.emplace(main, s).first;
+    it = g_side_streams.emplace(dev_stream(main), s).first;
   }
   *out = &it->second;
   return PK2_OK;
@@ -1417,7 +1417,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   if (persist) { p.fwd.n_chunks = kPR; p.bwd.n_chunks = kPR; }     // partial sums per frame: one per workgroup of a team
 
   const size_t lds = den_lds_bytes(g->P, NG);
-  static bool attr_set[8] = {false};
+  struct attr_set_t { bool f[8]; }; static PerDevice<attr_set_t> attr_set_pd(attr_set_t{}); bool (&attr_set)[8] = attr_set_pd.ref().f;
   if (!attr_set[NG]) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_fwd_step<NG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1441,7 +1441,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     auto slices = [&](int n) { return std::max(1, std::min((n + 1023) / 1024, (4096 + Tmax * G - 1) / (Tmax * G))); };
     const size_t exp_lds = (size_t)g->P * NG * sizeof(float);
     if (persist || (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER"))) {
-      static bool attr_e[8] = {false};
+      struct attr_e_t { bool f[8]; }; static PerDevice<attr_e_t> attr_e_pd(attr_e_t{}); bool (&attr_e)[8] = attr_e_pd.ref().f;
       if (!attr_e[NG]) {
         PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_exp_states_lds<NG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1490,7 +1490,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
     const size_t row_lds = (size_t)g->P * NG * sizeof(float);
     const bool lds_row = row_lds <= kGammaMaxLds && !getenv("PK2_DEN_GAMMA_GATHER");
-    static bool attr_n[8] = {false};
+    struct attr_n_t { bool f[8]; }; static PerDevice<attr_n_t> attr_n_pd(attr_n_t{}); bool (&attr_n)[8] = attr_n_pd.ref().f;
     if (!attr_n[NG]) {
       PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_gamma_states_num<NG, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -527,10 +527,10 @@ __global__ void den_persist_check(const DenPersistCtl* ctl, int ntasks, float* d
 // ----------------------------------------------------------------------------------------
 // host
 // ----------------------------------------------------------------------------------------
-static int g_den_persist_state = -1;     // -1: not verified yet, 0: unusable on this device, 1: verified
+static PerDevice<int> g_den_persist_state_pd(-1);     // -1: not verified yet, 0: unusable on this device, 1: verified
 struct DenPersistParams;
 struct DenPersistScratch { DenPersistParams* params = nullptr; DenPersistCtl* ctl = nullptr; float* ring = nullptr; float* pring = nullptr; int rpad = 0; int ntasks = 0; };
-static std::map<hipStream_t, DenPersistScratch> g_den_scratch;
+static std::map<DevStream, DenPersistScratch> g_den_scratch;
 
 static int den_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 63) / 64 * 64; }
 static int den_cap(const pk2_den_graph* g) {
@@ -547,9 +547,9 @@ bool den_persist_fits(const pk2_den_graph* g) {
 bool den_persist_wanted(const pk2_den_graph* g, int N) {
   const char* env = getenv("PK2_DEN_PERSIST");
   if (env && atoi(env) == 0) return false;
-  if (g_den_persist_state == 0 || !den_persist_fits(g) || !den_use_sx(g)) return false;
+  if (g_den_persist_state_pd.ref() == 0 || !den_persist_fits(g) || !den_use_sx(g)) return false;
   if (N < 1 || 2 * N > kMaxTasks) return false;
-  static int cus = -1;
+  static PerDevice<int> cus_pd(-1); int& cus = cus_pd.ref();
   if (cus < 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -561,7 +561,7 @@ bool den_persist_wanted(const pk2_den_graph* g, int N) {
 int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, const int32_t* lengths_host, int N,
                        hipStream_t stream, bool* ran) {
   *ran = false;
-  DenPersistScratch& sc = g_den_scratch[stream];
+  DenPersistScratch& sc = g_den_scratch[dev_stream(stream)];
   const int rpad = den_rpad(g);
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(DenPersistCtl)));
   if (!sc.params) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.params), sizeof(DenPersistParams)));
@@ -588,7 +588,7 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, c
   sc.ntasks = 0;
   if (p.ntasks == 0) { *ran = true; return PK2_OK; }
   const size_t lds = den_persist_lds_bytes(g);
-  static bool attr = false;
+  static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
@@ -602,14 +602,14 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, c
     hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4), 1); }   // (rank 0 of every team adds up)
 #endif
   PK2_LAUNCH_CHECK();
-  if (g_den_persist_state < 0) {     // first use on this device: every recursion done, nobody timed out?
+  if (g_den_persist_state_pd.ref() < 0) {     // first use on this device: every recursion done, nobody timed out?
     DenPersistCtl* h = new DenPersistCtl;
     hipError_t e = hipMemcpyAsync(h, sc.ctl, sizeof(DenPersistCtl), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)p.ntasks;
     delete h;
     if (e != hipSuccess) { set_error("den_persist: %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
-    g_den_persist_state = ok ? 1 : 0;
+    g_den_persist_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;
   }
   sc.ntasks = p.ntasks;
@@ -618,7 +618,7 @@ int den_persist_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, c
 }
 
 void den_persist_check_launch(float* den_lp, int N, hipStream_t stream) {
-  const DenPersistScratch& sc = g_den_scratch[stream];
+  const DenPersistScratch& sc = g_den_scratch[dev_stream(stream)];
   PersistGuard guard;
   (void)persist_guard(&guard);
   if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N, guard.dev, guard.host_dev);

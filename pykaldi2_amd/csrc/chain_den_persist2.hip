@@ -777,9 +777,9 @@ __global__ void den_persist2_check(const DenPersistCtl* ctl, int ntasks, float* 
 // ----------------------------------------------------------------------------------------
 // host
 // ----------------------------------------------------------------------------------------
-static int g_den_persist2_state = -1;     // -1: not verified yet, 0: unusable on this device, 1: verified
+static PerDevice<int> g_den_persist2_state_pd(-1);     // -1: not verified yet, 0: unusable on this device, 1: verified
 struct DenPersist2Scratch { DenPersist2Params* params = nullptr; DenPersistCtl* ctl = nullptr; float* ring = nullptr; float* pring = nullptr; int rpad = 0; int ntasks = 0; };
-static std::map<hipStream_t, DenPersist2Scratch> g_den2_scratch;
+static std::map<DevStream, DenPersist2Scratch> g_den2_scratch;
 
 static int den2_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 255) / 256 * 256 + 256; }
 static int den2_tfloats(const pk2_den_graph* g) { return std::max(g->h_p2fwd.tfloats, g->h_p2bwd.tfloats); }
@@ -789,7 +789,7 @@ bool den_persist2_fits(const pk2_den_graph* g) {
 }
 
 static bool den_is_8x32() {
-  static int cus = -1;
+  static PerDevice<int> cus_pd(-1); int& cus = cus_pd.ref();
   if (cus < 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -806,7 +806,7 @@ int den_persist_version(const pk2_den_graph* g, int N) {
   const int want = env ? atoi(env) : -1;
   if (want == 0 || !den_use_sx(g) || N < 1 || 2 * N > kMaxTasks || !den_is_8x32()) return 0;
   const bool ok1 = den_persist_wanted(g, N);
-  const bool ok2 = g_den_persist2_state != 0 && den_persist2_fits(g);
+  const bool ok2 = g_den_persist2_state_pd.ref() != 0 && den_persist2_fits(g);
   if (want == 1) return ok1 ? 1 : 0;
   if (want == 2) return ok2 ? 2 : 0;
   if (!ok2) return ok1 ? 1 : 0;
@@ -828,7 +828,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
                         hipStream_t stream, bool* ran, const NumDeferred* tail, bool* num_ran) {
   *ran = false;
   if (num_ran) *num_ran = false;
-  DenPersist2Scratch& sc = g_den2_scratch[stream];
+  DenPersist2Scratch& sc = g_den2_scratch[dev_stream(stream)];
   const int rpad = den2_rpad(g);
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(DenPersistCtl)));
   if (!sc.params) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.params), sizeof(DenPersist2Params)));
@@ -861,7 +861,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   // The numerator forward-backward of the minibatch (two waves per sequence, LDS-staged) as further tasks behind the
   // recursions: the teams of the short sequences run them while the longest recursion is still going.  Not during the
   // first, verified launch of a process (a fallback would have to undo the posteriors already added to the gradient).
-  const bool with_num = tail && tail->valid && tail->stage && num_ran && g_den_persist2_state == 1 && tail->N == N &&
+  const bool with_num = tail && tail->valid && tail->stage && num_ran && g_den_persist2_state_pd.ref() == 1 && tail->N == N &&
                         tail->lds <= (size_t)den2_tfloats(g) * sizeof(float) && p.ntasks + N <= kMaxTasks &&
                         !(getenv("PK2_DEN_NUM_RIDE") && atoi(getenv("PK2_DEN_NUM_RIDE")) == 0);
   if (with_num) {
@@ -869,7 +869,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
     for (int n = 0; n < N; ++n) { p.task_seq[p.ntasks] = (short)n; p.task_dir[p.ntasks] = 2; ++p.ntasks; }
   }
   const size_t lds = den_persist2_lds_bytes(p.tfloats, p.cap);
-  static bool attr = false;
+  static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_persist2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
@@ -883,14 +883,14 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
     hipLaunchKernelGGL(dp_prof_print, dim3(1), dim3(1), 0, stream, std::max(1, tot / 4), 2); }
 #endif
   PK2_LAUNCH_CHECK();
-  if (g_den_persist2_state < 0) {     // first use on this device: every recursion done, nobody timed out?
+  if (g_den_persist2_state_pd.ref() < 0) {     // first use on this device: every recursion done, nobody timed out?
     DenPersistCtl* h = new DenPersistCtl;
     hipError_t e = hipMemcpyAsync(h, sc.ctl, sizeof(DenPersistCtl), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)p.ntasks;
     delete h;
     if (e != hipSuccess) { set_error("den_persist2: %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
-    g_den_persist2_state = ok ? 1 : 0;
+    g_den_persist2_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;
   }
   sc.ntasks = p.ntasks;
@@ -900,7 +900,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
 }
 
 void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream) {
-  const DenPersist2Scratch& sc = g_den2_scratch[stream];
+  const DenPersist2Scratch& sc = g_den2_scratch[dev_stream(stream)];
   PersistGuard guard;
   (void)persist_guard(&guard);
   if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist2_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N, guard.dev, guard.host_dev);

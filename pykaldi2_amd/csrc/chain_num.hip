@@ -109,7 +109,7 @@ int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride
   const size_t staged = lds + ((size_t)2 * Tmax + 2 + 5 * (size_t)nb->total_arcs) * sizeof(float);
   const bool stage = staged <= 128 * 1024;
   if (stage) lds = staged;
-  static bool attr_set = false;
+  static PerDevice<bool> attr_set_pd(false); bool& attr_set = attr_set_pd.ref();
   if (!attr_set) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&num_fwd_bwd),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -41,6 +41,28 @@ void set_error(const char* fmt, ...);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Host-side state of the library is kept PER DEVICE: "verified on this device", "this kernel's LDS attribute is
+// set", the CU count and the per-stream scratch blocks belong to the device that is current when they are used -- a process
+// that drives a second GPU must verify, configure and allocate there again (the null stream is the same handle on every
+// device, so a stream alone does not identify one).
+inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
+template <typename T>
+struct PerDevice {
+  static constexpr int kMax = 64;
+  T v[kMax];
+  explicit PerDevice(const T& init) { for (int i = 0; i < kMax; ++i) v[i] = init; }
+  T& ref() { return v[current_device() & (kMax - 1)]; }
+};
+struct DevStream {
+  int dev; hipStream_t stream;
+  bool operator<(const DevStream& o) const { return dev != o.dev ? dev < o.dev : stream < o.stream; }
+};
+inline DevStream dev_stream(hipStream_t s) { return DevStream{current_device(), s}; }
+
 // Carves aligned sub-buffers out of a caller-owned workspace.
 struct Carver {
   char* base;

@@ -1059,7 +1059,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
 }
 
 static StepGraphs g_lat_graphs;
-static std::map<hipStream_t, StepCounter*> g_lat_counters;
+static std::map<DevStream, StepCounter*> g_lat_counters;
 
 // The kernels take the call's parameters BY VALUE: a pointer to a parameter block would put one more dependent
 // memory round trip (~1 us) in front of each of the ~11 launches of a frame.  The values are baked into the
@@ -1074,16 +1074,16 @@ static uint64_t g_lat_clock = 0;
 
 // ---- host side of the persistent decoder ----
 struct LatPersistScratch { LatTeamCtl* ctl = nullptr; unsigned* sticky = nullptr; };
-static std::map<hipStream_t, LatPersistScratch> g_lat_persist;
-static int g_lat_persist_state = -1;      // -1: not tried on this device yet, 1: verified, 0: did not come back complete -> launch per frame
+static std::map<DevStream, LatPersistScratch> g_lat_persist;
+static PerDevice<int> g_lat_persist_state_pd(-1);      // -1: not tried on this device yet, 1: verified, 0: did not come back complete -> launch per frame
 
 static bool lat_persist_wanted(int team) {
   static const int mode = [] {
     const char* e = getenv("PK2_LAT_DECODER");
     return (e && strcmp(e, "frames") == 0) ? 0 : 1;
   }();
-  if (!mode || g_lat_persist_state == 0 || (team != 8 && team != 16 && team != 32)) return false;
-  static int cus = -1;
+  if (!mode || g_lat_persist_state_pd.ref() == 0 || (team != 8 && team != 16 && team != 32)) return false;
+  static PerDevice<int> cus_pd(-1); int& cus = cus_pd.ref();
   if (cus < 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -1094,7 +1094,7 @@ static bool lat_persist_wanted(int team) {
 
 static int lat_persist_launch(const DecodeParams& p, int N, int team, hipStream_t stream, bool* ran) {
   *ran = false;
-  LatPersistScratch& sc = g_lat_persist[stream];
+  LatPersistScratch& sc = g_lat_persist[dev_stream(stream)];
   if (!sc.ctl) {
     PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(LatTeamCtl)));
     PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.sticky), sizeof(unsigned)));
@@ -1106,14 +1106,14 @@ static int lat_persist_launch(const DecodeParams& p, int N, int team, hipStream_
   static const int inv_mode = [] { const char* e = getenv("PK2_LAT_INV"); return e ? atoi(e) : 1; }();
   hipLaunchKernelGGL(lat_frames_persist, dim3(256), dim3(kLatThreads), 0, stream, p, sc.ctl, N, team, tpx, inv_mode);
   PK2_LAUNCH_CHECK();
-  if (g_lat_persist_state < 0) {          // first use on this device: every utterance done, nobody timed out?
+  if (g_lat_persist_state_pd.ref() < 0) {          // first use on this device: every utterance done, nobody timed out?
     LatTeamCtl* h = new LatTeamCtl;
     hipError_t e = hipMemcpyAsync(h, sc.ctl, sizeof(LatTeamCtl), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)N;
     delete h;
     if (e != hipSuccess) { set_error("lattice decode (persistent): %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
-    g_lat_persist_state = ok ? 1 : 0;
+    g_lat_persist_state_pd.ref() = ok ? 1 : 0;
     if (!ok) {                            // the caller decodes again, a launch per frame: give it clean state tables
       PK2_HIP(hipMemsetAsync(p.L.st_cost, 0xFF, sizeof(uint32_t) * (size_t)N * p.g.S, stream));
       PK2_HIP(hipMemsetAsync(p.L.st_tok, 0xFF, sizeof(int32_t) * (size_t)N * p.g.S, stream));
@@ -1137,7 +1137,7 @@ int lattice_persist_status(unsigned* abort_flag) {
     if (kv.second.sticky && hipMemcpy(&st, kv.second.sticky, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) any |= st;
   }
   *abort_flag = any;
-  return g_lat_persist_state;
+  return g_lat_persist_state_pd.ref();
 }
 
 static int lattice_decode_frames_graphs(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream);
@@ -1157,7 +1157,7 @@ int lattice_decode_frames(const DecodeParams& p, int N, int Tmax, int team, hipS
 }
 
 static int lattice_decode_frames_graphs(const DecodeParams& p, int N, int Tmax, int team, hipStream_t stream) {
-  StepCounter*& counter = g_lat_counters[stream];
+  StepCounter*& counter = g_lat_counters[dev_stream(stream)];
   if (!counter) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&counter), sizeof(StepCounter)));
   const StepCounter* cnt = counter;
   hipLaunchKernelGGL(lat_frames_init, dim3(N), dim3(64), 0, stream, p, team);
@@ -1203,7 +1203,7 @@ static int lattice_finish_and_prune(const DecodeParams& p, int N, hipStream_t st
   const dim3 thr(kLatThreads);
   // lattice-beam pruning: the per-link constants in parallel, then the serial pass with two frames' extra costs in LDS
   constexpr int kFinCap = 19456;                   // tokens of a frame the LDS arrays hold (2 x 76 KB)
-  static bool attr = false;
+  static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_frames_finish), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * kFinCap * (int)sizeof(uint32_t)));

@@ -372,7 +372,7 @@ static int fb_launch(int mode, const pk2_lattice_batch* b, void* workspace, FbPa
   lattice_carve(b, workspace, &p.L);
   const dim3 two(2, b->N), many(64, b->N), thr(kFbThreads);
   constexpr int kFbCap = 19456;                    // tokens of a frame the LDS array holds (152 KB of doubles)
-  static bool attr = false;
+  static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_fb_alpha_beta), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kFbCap * (int)sizeof(double)));

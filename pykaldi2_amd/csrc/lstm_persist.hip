@@ -472,17 +472,17 @@ __global__ void __launch_bounds__(256) lstm_bwd_persist(PersistBwdParams p, Pers
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
-static std::map<hipStream_t, PersistCtl*> g_ctls;   // device control blocks, one per caller stream (launches on different
+static std::map<DevStream, PersistCtl*> g_ctls;   // device control blocks, one per caller stream (launches on different
                                                     // streams may overlap; each needs its own role counters)
 static PersistCtl* g_ctl_last = nullptr;
-static int g_persist_state = -1;         // -1 untested, 0 unusable, 1 verified on this device
+static PerDevice<int> g_persist_state_pd(-1);         // -1 untested, 0 unusable, 1 verified on this device
 
 static int get_ctl(hipStream_t stream, PersistCtl** out) {
-  auto it = g_ctls.find(stream);
+  auto it = g_ctls.find(dev_stream(stream));
   if (it == g_ctls.end()) {
     PersistCtl* c = nullptr;
     PK2_HIP(hipMalloc(reinterpret_cast<void**>(&c), sizeof(PersistCtl)));
-    it = g_ctls.emplace(stream, c).first;
+    it = g_ctls.emplace(dev_stream(stream), c).first;
   }
   *out = g_ctl_last = it->second;
   return PK2_OK;
@@ -491,7 +491,7 @@ static int get_ctl(hipStream_t stream, PersistCtl** out) {
 bool lstm_persist_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_PERSIST");
   if (env && atoi(env) == 0) return false;
-  return g_persist_state != 0 && H == kPH && B >= 1 && B <= 8 && (D == 1 || D == 2);
+  return g_persist_state_pd.ref() != 0 && H == kPH && B >= 1 && B <= 8 && (D == 1 || D == 2);
 }
 
 int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
@@ -513,13 +513,13 @@ int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh,
   hipLaunchKernelGGL(pp_print, dim3(1), dim3(1), 0, stream, T);
 #endif
   PK2_LAUNCH_CHECK();
-  if (g_persist_state < 0) {             // first use on this device: verify that the roles were filled and nobody timed out
+  if (g_persist_state_pd.ref() < 0) {             // first use on this device: verify that the roles were filled and nobody timed out
     PersistCtl h;
     PK2_HIP(hipMemcpyAsync(&h, g_ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
     PK2_HIP(hipStreamSynchronize(stream));
     bool ok = h.abort == 0;
     for (int d = 0; d < D; ++d) ok = ok && h.reg[d] >= (unsigned)kPWgs;
-    g_persist_state = ok ? 1 : 0;
+    g_persist_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // caller falls back to the step kernels (and keeps doing so)
   }
   *ran = true;
@@ -529,7 +529,7 @@ int lstm_fwd_persist_launch(const float* gx, const float* whh, const float* bhh,
 int lstm_bwd_persist_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
                             int D, float* dgx, float* mailboxes, hipStream_t stream, bool* ran) {
   *ran = false;
-  if (g_persist_state != 1) return PK2_OK;   // the forward pass verifies the device first
+  if (g_persist_state_pd.ref() != 1) return PK2_OK;   // the forward pass verifies the device first
   PersistCtl* g_ctl = nullptr;
   int crc = get_ctl(stream, &g_ctl);
   if (crc) return crc;

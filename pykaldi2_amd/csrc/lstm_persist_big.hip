@@ -649,11 +649,11 @@ __global__ void lstm_big_check(const BigCtl* ctl, unsigned ntasks, float* out, s
 // ---- host -------------------------------------------------------------------------------------------------------------
 struct BigScratch { BigCtl* ctl = nullptr; unsigned* flags = nullptr; size_t flag_words = 0; unsigned* sticky = nullptr;
                     float* mail = nullptr; size_t mail_floats = 0; PersistGuard guard; };
-static std::map<hipStream_t, BigScratch> g_big_scratch;
-static int g_big_state = -1;             // -1 untested, 0 unusable, 1 verified on this device
+static std::map<DevStream, BigScratch> g_big_scratch;
+static PerDevice<int> g_big_state_pd(-1);             // -1 untested, 0 unusable, 1 verified on this device
 
 static int big_scratch(hipStream_t stream, size_t flag_words, BigScratch** out) {
-  BigScratch& sc = g_big_scratch[stream];
+  BigScratch& sc = g_big_scratch[dev_stream(stream)];
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(BigCtl)));
   if (!sc.sticky) {
     PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.sticky), sizeof(unsigned)));
@@ -673,8 +673,8 @@ static int big_scratch(hipStream_t stream, size_t flag_words, BigScratch** out) 
 bool lstm_big_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_BIG_PERSIST");
   if (env && atoi(env) == 0) return false;
-  if (g_big_state == 0 || H != kBgH || B < 32 || (D != 1 && D != 2) || D * ((B + 63) / 64) > kBgMaxTasks) return false;
-  static int cus = -1;
+  if (g_big_state_pd.ref() == 0 || H != kBgH || B < 32 || (D != 1 && D != 2) || D * ((B + 63) / 64) > kBgMaxTasks) return false;
+  static PerDevice<int> cus_pd(-1); int& cus = cus_pd.ref();
   if (cus < 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -696,7 +696,7 @@ int lstm_fwd_big_launch(const float* gx, const float* whh, const float* bhh, int
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(BigCtl), stream));
   PK2_HIP(hipMemsetAsync(sc->flags, 0, (size_t)ntasks * T * kBgR * sizeof(unsigned), stream));
-  static bool attr = false;
+  static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_big_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
@@ -705,14 +705,14 @@ int lstm_fwd_big_launch(const float* gx, const float* whh, const float* bhh, int
   BigFwdParams p{gx, whh, bhh, y, gates, cells, sc->flags, B, T, D};
   hipLaunchKernelGGL(lstm_fwd_big_persist, dim3(8 * kBgR), dim3(256), kBgLds, stream, p, sc->ctl);
   PK2_LAUNCH_CHECK();
-  if (g_big_state < 0) {                 // first use on this device: every task done, nobody timed out?
+  if (g_big_state_pd.ref() < 0) {                 // first use on this device: every task done, nobody timed out?
     BigCtl* h = new BigCtl;
     hipError_t e = hipMemcpyAsync(h, sc->ctl, sizeof(BigCtl), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)ntasks;
     delete h;
     if (e != hipSuccess) { set_error("lstm_big: %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
-    g_big_state = ok ? 1 : 0;
+    g_big_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
   hipLaunchKernelGGL(lstm_big_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)ntasks, y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
@@ -723,14 +723,14 @@ int lstm_fwd_big_launch(const float* gx, const float* whh, const float* bhh, int
 int lstm_bwd_big_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
                         int D, float* dgx, hipStream_t stream, bool* ran) {
   *ran = false;
-  if (g_big_state != 1) return PK2_OK;   // the forward pass verifies the device first
+  if (g_big_state_pd.ref() != 1) return PK2_OK;   // the forward pass verifies the device first
   const int ntasks = D * ((B + 63) / 64);
   BigScratch* sc = nullptr;
   int rc = big_scratch(stream, (size_t)2 * ntasks * T * kBgR, &sc);      // "d gx stored" flags, then "partials stored" flags
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(BigCtl), stream));
   PK2_HIP(hipMemsetAsync(sc->flags, 0, (size_t)2 * ntasks * T * kBgR * sizeof(unsigned), stream));
-  static bool attr = false;
+  static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_big_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
@@ -748,7 +748,7 @@ int lstm_bwd_big_launch(const float* dy, const float* whh, const float* gates, c
       PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc->mail), mail_floats * sizeof(float)));
       sc->mail_floats = mail_floats;
     }
-    static bool attr2 = false;
+    static PerDevice<bool> attr2_pd(false); bool& attr2 = attr2_pd.ref();
     if (!attr2) {
       PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_big_persist2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));

@@ -898,11 +898,11 @@ __global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, si
 
 // ---- host -------------------------------------------------------------------------------------------------------------
 struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; PersistGuard guard; };
-static std::map<hipStream_t, SeqScratch> g_seq_scratch;
-static int g_seq_state = -1;             // -1 untested, 0 unusable, 1 verified on this device
+static std::map<DevStream, SeqScratch> g_seq_scratch;
+static PerDevice<int> g_seq_state_pd(-1);             // -1 untested, 0 unusable, 1 verified on this device
 
 static int seq_scratch(hipStream_t stream, SeqScratch** out) {
-  SeqScratch& sc = g_seq_scratch[stream];
+  SeqScratch& sc = g_seq_scratch[dev_stream(stream)];
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(SeqCtl)));
   if (!sc.mail) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.mail), (size_t)8 * kSeqTeams * kSeqMailFloats * sizeof(float)));
   if (!sc.sticky) {
@@ -936,8 +936,8 @@ bool lstm_seq_wanted(int B, int H, int D) {
   const char* env = getenv("PK2_LSTM_SEQ");
   if (env && atoi(env) == 0) return false;
   // (up to 4 pairs per XCD one after the other; larger batches are better served by the batched step kernels)
-  if (g_seq_state == 0 || H != kSH || B < 1 || B * D > 32 || (D != 1 && D != 2)) return false;
-  static int cus = -1;
+  if (g_seq_state_pd.ref() == 0 || H != kSH || B < 1 || B * D > 32 || (D != 1 && D != 2)) return false;
+  static PerDevice<int> cus_pd(-1); int& cus = cus_pd.ref();
   if (cus < 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -961,14 +961,14 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   else hipLaunchKernelGGL(lstm_fwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   PK2_LAUNCH_CHECK();
-  if (g_seq_state < 0) {                 // first use on this device: every pair done, nobody timed out?
+  if (g_seq_state_pd.ref() < 0) {                 // first use on this device: every pair done, nobody timed out?
     SeqCtl* h = new SeqCtl;
     hipError_t e = hipMemcpyAsync(h, sc->ctl, sizeof(SeqCtl), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     const bool ok = e == hipSuccess && h->abort == 0u && h->done == (unsigned)(B * D);
     delete h;
     if (e != hipSuccess) { set_error("lstm_seq: %s", hipGetErrorString(e)); return PK2_ERR_HIP; }
-    g_seq_state = ok ? 1 : 0;
+    g_seq_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
   hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
@@ -979,7 +979,7 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
 int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
                         int D, float* dgx, hipStream_t stream, bool* ran) {
   *ran = false;
-  if (g_seq_state != 1) return PK2_OK;   // the forward pass verifies the device first
+  if (g_seq_state_pd.ref() != 1) return PK2_OK;   // the forward pass verifies the device first
   SeqScratch* sc = nullptr;
   int rc = seq_scratch(stream, &sc);
   if (rc) return rc;

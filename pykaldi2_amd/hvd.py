@@ -50,6 +50,7 @@ def init(backend=None):
         local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
+            _ranks_share_a_device(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count())
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
         _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local, group=True)
@@ -70,6 +71,21 @@ def init(backend=None):
                 if _state["rank"] == 0:
                     sys.stderr.write("[hvd] library communicator unavailable (%s): gradients go through torch.distributed\n" % err)
     _state["initialized"] = True
+
+
+def _ranks_share_a_device(local_world, devices):
+    """One process per GPU is the deployment.  When several ranks of a node are mapped onto ONE device
+    (tests that run the N-rank protocol on a one-GPU box), their persistent kernels -- each wants 32 co-resident
+    workgroups on every XCD -- hold parts of the chip against each other until their polls time out, and since round 4 a
+    time-out stops training (include/pk2hip.h: guard of the persistent kernels).  Such a job is switched to the
+    launch-per-step kernels, which need no co-residency; explicit settings of the caller win."""
+    if devices <= 0 or local_world <= devices:
+        return
+    changed = [k for k, v in (("PK2_LSTM_SEQ", "0"), ("PK2_LSTM_PERSIST", "0"), ("PK2_LSTM_BIG_PERSIST", "0"), ("PK2_DEN_PERSIST", "0"),
+                              ("PK2_LAT_DECODER", "frames")) if os.environ.setdefault(k, v) == v]
+    if changed and os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("[hvd] %d local ranks on %d device(s): ranks share a GPU, persistent kernels off (%s)\n"
+                         % (local_world, devices, ", ".join(changed)))
 
 
 def _create_comm():
@@ -95,6 +111,17 @@ def _create_comm():
     h = C.c_void_p()
     _lib.check(L.pk2_comm_init(dist.get_rank(), dist.get_world_size(), uid, C.byref(h)))
     return h
+
+
+def comm_ranks():
+    """Ranks of the communicator the gradients travel on: pk2_comm_info of the RCCL communicator, else the size of the
+    torch.distributed group (gloo / CPU tests), else 1."""
+    if _state["comm"] is not None:
+        from . import _lib
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        _lib.check(_lib.lib().pk2_comm_info(_state["comm"], C.byref(r), C.byref(w), None, 0))
+        return int(w.value)
+    return size()
 
 
 def comm_library():
@@ -290,6 +317,10 @@ class DistributedOptimizer:
         self._overlap = self._mode == "overlap"     # (kept for introspection by tests)
         self._done = []          # [lo, hi) ranges of the flat gradient already exchanged in this step
         self._reduced = False
+        # bench.py / diagnostics: with `timing = []` every step appends the (start, end) device events of its all-reduce
+        # calls, in issue order, on whichever stream they ran (bench.py reads them after its timed region)
+        self.timing = None
+        self._step_events = []
 
     def __getattr__(self, name):
         return getattr(self._opt, name)
@@ -304,7 +335,7 @@ class DistributedOptimizer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(grad_slice.device))
             self._side.wait_event(ev)
-            _allreduce_sum(grad_slice, self._side)
+            self._timed_allreduce(grad_slice, self._side)
         else:
             _allreduce_sum(grad_slice)
         lo, hi = self._opt.model._buckets[name]
@@ -320,11 +351,21 @@ class DistributedOptimizer:
             pos = 0
             for lo, hi in sorted(self._done) + [(gflat.numel(), gflat.numel())]:
                 if lo > pos:
-                    _allreduce_sum(gflat[pos:lo])
+                    self._timed_allreduce(gflat[pos:lo], None)
                 pos = max(pos, hi)
             self._done = []
             self._reduced = True
             self._trial_mark_exchanged()
+
+    def _timed_allreduce(self, t, stream):
+        if self.timing is None or not t.is_cuda:
+            return _allreduce_sum(t, stream)
+        st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        _allreduce_sum(t, stream)
+        e1.record(st)
+        self._step_events.append((e0, e1, int(t.numel()) * 4))
 
     def zero_grad(self, *a, **k):
         self._reduced = False
@@ -394,5 +435,8 @@ class DistributedOptimizer:
         # backward, which must be followed by a fresh exchange
         self._reduced = False
         self._done = []
+        if self.timing is not None:
+            self.timing.append(self._step_events)
+            self._step_events = []
         self._trial_step_done()
         return out

@@ -208,8 +208,33 @@ def test_bench_rccl_path_single_rank_group():
     # the gradients went through the library's own RCCL communicator (pk2_comm_init / pk2_allreduce_bucket), bucketed
     assert a["exchange"]["api"] == "pk2_allreduce_bucket" and "rccl" in a["exchange"]["library"]
     assert a["exchange"]["schedule"] == "overlap" and b["exchange"]["api"] == "torch.distributed.all_reduce"
+    # the communicator's own rank count (pk2_comm_info), the per-rank block of one rank, no bucketed second window
+    assert a["exchange"]["ranks"] == 1 and b["exchange"]["ranks"] == 1 and len(a["per_rank"]) == 1 and a["irtf_bucketed"] is None
+    assert a["exchange"]["exchange_ms"] > 0 and a["exchange"]["straggler_wait_ms"] == 0 and b["exchange"]["exchange_ms"] == 0
+    assert a["per_rank"][0]["gpu_ms_max"] >= a["per_rank"][0]["gpu_ms_mean"] > 0 and a["ideal_weak_irtf"] > 0
     # split-K GEMMs accumulate with float atomics: equal up to summation order
     assert abs(a["last_objf_per_frame"] - b["last_objf_per_frame"]) <= 2e-3 * abs(b["last_objf_per_frame"]) + 1e-4
+
+
+def _check_scaling_fields(d, world):
+    """an N > 1 line must explain its own scaling -- ranks of the communicator, per-rank GPU time of the
+    timed steps, exchange / straggler split, the weak-scaling ideal, and the length-bucketed protocol's number from a
+    second short window (bench.py::scaling_report; DESIGN section 6 says how to read them)."""
+    ex = d["exchange"]
+    assert ex["ranks"] == world
+    for k in ("exchange_ms", "exchange_net_ms", "straggler_wait_ms", "straggler_wait_ms_worst_rank", "bytes_per_step"):
+        assert k in ex and ex[k] >= 0, k
+    assert ex["exchange_ms"] > 0 and 80e6 < ex["bytes_per_step"] < 90e6          # the flat gradient buffer: 21 M floats
+    assert ex["exchange_net_ms"] <= ex["exchange_ms"] + 1e-6
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(world))
+    for p in pr:
+        assert 0 < p["gpu_ms_mean"] <= p["gpu_ms_max"] and 0 < p["pre_exchange_ms_mean"] <= p["gpu_ms_mean"]
+        assert p["audio_s"] > 0 and p["own_irtf"] > 0 and p["straggler_wait_ms_mean"] >= 0
+    # somebody is the slowest rank of every step, nobody waits a negative time
+    assert min(p["straggler_wait_ms_mean"] for p in pr) <= ex["straggler_wait_ms"] <= max(p["straggler_wait_ms_mean"] for p in pr) + 1e-6
+    assert abs(d["ideal_weak_irtf"] - sum(p["own_irtf"] for p in pr)) < 0.05 * world
+    assert d["irtf_bucketed"]["value"] > 0 and d["irtf_bucketed"]["steps"] >= 2
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
@@ -233,6 +258,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     # and every rank switches to the same one; bench.py runs that calibration to its end BEFORE its warm-up steps
     assert "[hvd] gradient exchange schedule: " in out.stderr and d["exchange"]["schedule"] in ("single", "overlap")
     assert d["exchange"]["calibration_steps"] == 14 and d["steps"] == 4
+    _check_scaling_fields(d, 2)
 
 
 def test_overlap_schedule_50_steps_keeps_the_persistent_kernels(tmp_path):
@@ -253,7 +279,7 @@ def test_overlap_schedule_50_steps_keeps_the_persistent_kernels(tmp_path):
     b = json.loads(solo.stdout.strip().splitlines()[-1])
     assert a["exchange"]["schedule"] == "overlap" and a["exchange"]["api"] == "pk2_allreduce_bucket"
     for d in (a, b):
-        assert d["persistent_health"] == dict(lstm_persist_abort=0, den_kernel_path=2, den_persist_form=2), d["persistent_health"]
+        assert d["persistent_health"] == dict(lstm_persist_abort=0, den_kernel_path=2, den_persist_form=2, guard_raised=False), d["persistent_health"]
         assert np.isfinite(d["last_objf_per_frame"])
     # 52 optimiser steps apart the two runs still agree (split-K float atomics: equal up to summation order)
     assert abs(a["last_objf_per_frame"] - b["last_objf_per_frame"]) <= 5e-3 * abs(b["last_objf_per_frame"]) + 1e-3
@@ -276,3 +302,4 @@ def test_bench_eight_ranks_on_one_gpu_over_gloo():
     assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 32
     assert d["scaling"] == "weak" and d["value"] > 0 and d["exchange"]["calibration_steps"] == 14
     assert d["persistent_health"]["lstm_persist_abort"] == 0
+    _check_scaling_fields(d, 8)
