@@ -106,6 +106,9 @@ typedef struct {
   const float* final_weight;
   const int32_t* final_off;     /* host pointer, int32[N+1] */
   int64_t total_arcs;
+  int64_t max_seq_arcs;         /* arcs of the largest single sequence (0 = unknown: total_arcs is the bound).  Decides
+                                 * whether a sequence's frame table and arcs fit the LDS of its workgroup (the staged
+                                 * forward-backward, which also rides inside the persistent denominator launch). */
 } pk2_num_batch;
 
 size_t pk2_chain_workspace_bytes(const pk2_den_graph* g, int32_t num_seqs, int32_t max_frames,

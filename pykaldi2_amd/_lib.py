@@ -22,7 +22,7 @@ class NumBatch(C.Structure):
     _fields_ = [("arc_src", C.c_void_p), ("arc_dst", C.c_void_p), ("arc_pdf", C.c_void_p),
                 ("arc_weight", C.c_void_p), ("frame_off", C.c_void_p), ("state_off", C.c_void_p),
                 ("final_state", C.c_void_p), ("final_weight", C.c_void_p), ("final_off", C.c_void_p),
-                ("total_arcs", C.c_int64)]
+                ("total_arcs", C.c_int64), ("max_seq_arcs", C.c_int64)]
 
 
 class DecoderOpts(C.Structure):

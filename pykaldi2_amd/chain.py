@@ -370,7 +370,7 @@ class _SupervisionBatch:
         base = self.dev.data_ptr()
         p = [C.c_void_p(base + int(o) * 4) for o in offs[:7]]
         self.struct = _lib.NumBatch(p[0], p[1], p[2], p[5], p[3], _lib.ptr(self.state_off), p[4], p[6],
-                                    _lib.ptr(self.final_off), self.total_arcs)
+                                    _lib.ptr(self.final_off), self.total_arcs, int(np.diff(arcs).max()) if n else 0)
         self.n = n
 
 

@@ -106,7 +106,11 @@ int num_compute(const pk2_num_batch* nb, const float* logits, int64_t seq_stride
   // LDS: alpha, beta, reduction scratch; plus, when it fits, the sequence's frame table and arc arrays (bounded here
   // by the batch totals: the per-sequence counts live on the device)
   size_t lds = ((size_t)2 * max_states + 8) * sizeof(float);
-  const size_t staged = lds + ((size_t)2 * Tmax + 2 + 5 * (size_t)nb->total_arcs) * sizeof(float);
+  // (round 4: by the largest SEQUENCE when the caller says so -- the batch total kept every minibatch with more than ~6k
+  // arcs, i.e. about 30 s of audio in four utterances, off the staged path and out of the persistent denominator launch:
+  // its numerator then ran unstaged on four workgroups for up to 1.8 ms behind the occupancy pass)
+  const size_t arc_bound = (size_t)(nb->max_seq_arcs > 0 ? std::min(nb->max_seq_arcs, nb->total_arcs) : nb->total_arcs);
+  const size_t staged = lds + ((size_t)2 * Tmax + 2 + 5 * arc_bound) * sizeof(float);
   const bool stage = staged <= 128 * 1024;
   if (stage) lds = staged;
   static PerDevice<bool> attr_set_pd(false); bool& attr_set = attr_set_pd.ref();

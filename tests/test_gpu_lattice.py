@@ -94,6 +94,43 @@ def test_mmi_matches_oracle(case, frame_values, monkeypatch):
         assert np.abs(post[0].cpu().numpy() - wp).max() < 2e-6
 
 
+def _link_keys(a):
+    fr, st = a["tok_frame"], a["tok_state"]
+    return set((int(fr[s]), int(st[s]), int(st[d]), int(t)) for s, d, t in zip(a["link_src"], a["link_dst"], a["link_tid"]))
+
+
+@pytest.mark.parametrize("order", ["ascending", "descending", "random"])
+def test_device_lattice_against_kaldis_serial_cutoff_rule(order):
+    """The decoder keeps an arc iff its cost is below the frame's FINAL cutoff; Kaldi's ProcessEmitting tightens
+    next_cutoff while it walks its hash list (oracle/lattice_ref.py header).  The oracle-only test
+    (test_oracle_lattice.py::test_final_cutoff_rule_...) measures the difference between the two rules; here the DEVICE
+    lattice itself is held against the emulation of the serial rule at the configuration's beams (13 / 7, max_active
+    binding on every frame): best-first order reproduces the device lattice exactly, any other order leaves the best path
+    alone, adds at most 0.2 % links (all between the two cutoffs), and moves the device's MMI posteriors by <= 2e-4."""
+    nw, P, T, seed, beam, lb, ac, maxa, mina = CASES[2]
+    g, tm, ll, rng = _setup(nw, P, T, seed)
+    graph = _ref_graph(g)
+    opts = lr.DecoderOptionsRef(beam, lb, maxa, mina, 0.5, ac)
+    rec = _recognizer(g, tm, beam, lb, ac, maxa, mina)
+    lat = rec.decode(torch.from_numpy(ll).cuda())
+    assert lat.status[0] == 0
+    dev = lat.export(0)
+    dev_links = _link_keys(dev)
+    serial = lr.decode(graph, ll, tm["tid2pdf"], opts, serial_order=np.random.default_rng(5) if order == "random" else order)
+    ser_links = _link_keys(serial.arrays())
+    assert lat.best_cost[0] == np.float32(serial.best_cost)
+    ali = _ali_near_lattice(rng, lr.decode(graph, ll, tm["tid2pdf"], opts), P)
+    like, post = lat.mmi([ali], 1.0, 0.2, False)
+    wl, wp = lr.lattice_mmi(serial, ali, tm["tid2pdf"], P, 1.0, 0.2, False)
+    if order == "ascending":
+        assert dev_links == ser_links
+        assert np.abs(post[0].cpu().numpy() - wp).max() < 2e-6
+    else:
+        assert len(ser_links - dev_links) <= 0.002 * len(dev_links) and len(dev_links - ser_links) <= 0.002 * len(dev_links)
+        assert np.abs(post[0].cpu().numpy() - wp).max() <= 2e-4
+        assert abs(like.item() - wl) <= 1e-3 * max(1.0, abs(wl))
+
+
 @pytest.mark.parametrize("criterion", ["smbr", "mpfe"])
 def test_mpe_matches_oracle(criterion):
     nw, P, T, seed, beam, lb, ac, maxa, mina = CASES[1]
