@@ -9,10 +9,11 @@ only the finished lattices come back to the host to be written.
 
 Per utterance it prints what the reference prints (bin/latgen.py:173-178): the best word sequence (`words.txt` symbols
 when -graph_dir has one, ids otherwise) and the per-frame log-likelihood of the best path.  The lattices are Kaldi
-CompactLattices of the raw, lattice-beam-pruned state-level lattice; they are NOT determinised (the reference sets
-`decoder_opts.determinize_lattice = True`): run Kaldi's lattice-determinize-pruned on the archive for the reference's
-form.  -out_file ending in .txt writes a text archive ("ark,t:").  -synthetic N decodes N seeded utterances against a
-synthetic word-loop HCLG.
+CompactLattices, DETERMINISED on their word labels like the reference's (`decoder_opts.determinize_lattice = True`,
+reference bin/latgen.py:149): every word sequence once, with the costs and the alignment of its best path, pruned with
+the lattice beam (pykaldi2_amd.lattice.determinize_lattice: host-side restatement of Kaldi's DeterminizeLatticePruned);
+-no_determinize writes the raw lattice-beam-pruned state-level lattice instead (arc = decoder link).  -out_file ending
+in .txt writes a text archive ("ark,t:").  -synthetic N decodes N seeded utterances against a synthetic word-loop HCLG.
 """
 import argparse
 import json
@@ -50,6 +51,8 @@ def main():
     parser.add_argument("-graph_dir", help="the decoding graph directory")
     parser.add_argument("-sweep_size", default=200, type=float, help="process n hours of data per sweep (default:60)")
     parser.add_argument("-data_loader_threads", default=4, type=int, help="number of workers for data loading")
+    parser.add_argument("-no_determinize", action="store_true", help="write the raw state-level lattices (the reference "
+                        "determinises: decoder_opts.determinize_lattice = True)")
     parser.add_argument("-synthetic", type=int, default=0, help="decode this many seeded synthetic utterances instead")
     parser.add_argument("-synthetic_words", type=int, default=500, help="(synthetic) vocabulary of the word-loop HCLG")
     args = parser.parse_args()
@@ -118,7 +121,7 @@ def main():
             lat = asr_decoder.decode_batch(loglikes, [int(t) for t in frames])      # the whole minibatch in one call
             for j in range(len(chunk)):
                 key = chunk[j][3]
-                cl = lat.compact_lattice(j)
+                cl = lat.compact_lattice(j, determinize=not args.no_determinize)
                 text = " ".join(words.get(w, str(w)) for w in cl["best_words"])
                 print(key, text)
                 print("Log-like per-frame for utterance {} is {}".format(key, -cl["best_cost"] / frames[j]))

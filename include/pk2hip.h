@@ -509,6 +509,27 @@ int pk2_lattice_export(const pk2_lattice_batch* b, const void* workspace, int32_
                        float* tok_final, int32_t* link_src, int32_t* link_dst, int32_t* link_tid,
                        float* link_graph, float* link_ac, void* stream);
 
+/* Lattice determinisation on word labels (host arrays in, host handle out; no device work).  Replaces, for the lattice
+ * dump of reference bin/latgen.py:143-181, what PyKaldi's recogniser does when `determinize_lattice = True`
+ * (bin/latgen.py:149: Kaldi's DeterminizeLatticePhonePrunedWrapper): the result accepts every word sequence of the raw
+ * state-level lattice once, with the (graph, acoustic) costs and the transition-id alignment of its best path
+ * (CompactLattice semantics, no minimisation).  Arc i of the input: src[i] -> dst[i], word[i] (0 = epsilon), tid[i] (0 =
+ * none), costs graph[i], acoustic[i]; final_cost[s] (+inf = not final).  beam: what lies on no complete path within beam
+ * of the best one is dropped, before and after the subset construction (pass the decoder's lattice beam); more than
+ * max_states output states -> PK2_ERR_LIMIT (retry with a smaller beam, as Kaldi's wrapper does). */
+typedef struct pk2_det_lattice pk2_det_lattice;
+int pk2_lattice_determinize(int32_t num_states, int32_t start, int64_t num_arcs, const int32_t* src, const int32_t* dst,
+                            const int32_t* word, const int32_t* tid, const float* graph, const float* acoustic,
+                            const float* final_cost, double beam, int64_t max_states, pk2_det_lattice** out);
+int pk2_det_lattice_sizes(const pk2_det_lattice* h, int32_t* num_states, int32_t* start, int64_t* num_arcs,
+                          int64_t* arc_tids, int64_t* final_tids);
+/* Arcs sorted by (source state, word): src, dst, word, graph, acoustic [num_arcs], tid_off [num_arcs + 1] into tids;
+ * per state final_graph / final_acoustic (+inf = not final) and final_tid_off [num_states + 1] into final_tids. */
+int pk2_det_lattice_export(const pk2_det_lattice* h, int32_t* src, int32_t* dst, int32_t* word, float* graph,
+                           float* acoustic, int64_t* tid_off, int32_t* tids, float* final_graph, float* final_acoustic,
+                           int64_t* final_tid_off, int32_t* final_tids);
+void pk2_det_lattice_destroy(pk2_det_lattice* h);
+
 /* ------------------------------------------------------------------------------------------------
  * Gradient exchange: RCCL all-reduce over xGMI, one communicator per process (= per GPU).
  * Replaces horovod.torch's NCCL all-reduce hidden in hvd.DistributedOptimizer.step()

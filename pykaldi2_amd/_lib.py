@@ -121,6 +121,10 @@ SIGNATURES = {
     "pk2_lstm_fwd_workspace_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pk2_lstm_persist_status": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "pk2_lattice_determinize": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i64, C.POINTER(_vp)]),
+    "pk2_det_lattice_sizes": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "pk2_det_lattice_export": (C.c_int, [_vp] * 12),
+    "pk2_det_lattice_destroy": (None, [_vp]),
     "pk2_persist_guard_status": (C.c_int, [C.POINTER(C.c_uint32)]),
     "pk2_persist_guard_clear": (C.c_int, []),
     "pk2_persist_guard_raise": (C.c_int, [_vp]),

@@ -79,7 +79,9 @@ class CompactLatticeWriter:
     {f32 graph, f32 acoustic, int32 n, n x int32 transition-ids} (+inf, +inf, 0 = not final) and int64 num_arcs, per arc
     {int32 ilabel, int32 olabel, weight as above, int32 nextstate}.
     "ark,t:<file>": text -- key line, arcs ``src dst word graph,acoustic,t1_t2``, finals ``state graph,acoustic,``, blank
-    line.  Kaldi writes the start state first: states are renumbered so that the start state is 0."""
+    line.  Kaldi writes the start state first: states are renumbered so that the start state is 0.
+    A determinised lattice (lattice.determinize_lattice / compact_lattice(determinize=True)) carries a transition-id STRING
+    per arc and per final weight (`tid_off` / `tids`, `final_acoustic`, `final_tid_off` / `final_tids`) instead of one `tid`."""
 
     def __init__(self, wspecifier):
         opts, _, path = wspecifier.partition(":")
@@ -111,14 +113,22 @@ class CompactLatticeWriter:
         by_src = np.argsort(src, kind="stable")
         counts = np.bincount(src, minlength=n)
         fin = np.asarray(lat["final"], np.float32)[order]
+        if "tid_off" in lat:          # determinised: strings
+            arc_ids = lambda l: [int(t) for t in lat["tids"][lat["tid_off"][l]:lat["tid_off"][l + 1]]]
+            fin_ac = np.asarray(lat["final_acoustic"], np.float32)[order]
+            fin_ids = lambda s_: [int(t) for t in lat["final_tids"][lat["final_tid_off"][order[s_]]:lat["final_tid_off"][order[s_] + 1]]]
+        else:
+            arc_ids = lambda l: [int(lat["tid"][l])] if int(lat["tid"][l]) > 0 else []
+            fin_ac = np.zeros(n, np.float32)
+            fin_ids = lambda s_: []
         if self._text:
             lines = [key]
             for l in by_src:
-                t = int(lat["tid"][l])
                 lines.append("%d\t%d\t%d\t%s,%s,%s" % (src[l], dst[l], lat["word"][l], repr(float(lat["graph"][l])),
-                                                          repr(float(lat["acoustic"][l])), str(t) if t > 0 else ""))
+                                                          repr(float(lat["acoustic"][l])), "_".join(str(t) for t in arc_ids(l))))
             for s_ in np.flatnonzero(np.isfinite(fin)):
-                lines.append("%d\t%s,0," % (s_, repr(float(fin[s_]))))
+                lines.append("%d\t%s,%s,%s" % (s_, repr(float(fin[s_])), repr(float(fin_ac[s_])) if fin_ac[s_] != 0 else "0",
+                                                "_".join(str(t) for t in fin_ids(s_))))
             self._f.write(("\n".join(lines) + "\n\n").encode())
             return
 
@@ -129,15 +139,16 @@ class CompactLatticeWriter:
         pos = 0
         for s_ in range(n):
             if np.isfinite(fin[s_]):
-                out.append(struct.pack("<ffi", float(fin[s_]), 0.0, 0))
+                ids = fin_ids(s_)
+                out.append(struct.pack("<ffi%di" % len(ids), float(fin[s_]), float(fin_ac[s_]), len(ids), *ids))
             else:
                 out.append(struct.pack("<ffi", float("inf"), float("inf"), 0))
             out.append(struct.pack("<q", int(counts[s_])))
             for l in by_src[pos:pos + counts[s_]]:
-                t = int(lat["tid"][l])
+                ids = arc_ids(l)
                 w = int(lat["word"][l])
                 out.append(struct.pack("<iiff", w, w, float(lat["graph"][l]), float(lat["acoustic"][l])))
-                out.append(struct.pack("<ii", 1, t) if t > 0 else struct.pack("<i", 0))
+                out.append(struct.pack("<i%di" % len(ids), len(ids), *ids))
                 out.append(struct.pack("<i", int(dst[l])))
             pos += counts[s_]
         self._f.write(b"".join(out))

@@ -274,6 +274,7 @@ class LatticeBatch:
         self.status = self.num_tokens = self.num_links = self.best_cost = None
         self.time_major = False
         self._acoustic_scale = 1.0
+        self._lattice_beam = 10.0
 
     def __del__(self):
         try:
@@ -347,7 +348,20 @@ class LatticeBatch:
         return a
 
 
-    def compact_lattice(self, n, acoustic_scale=None):
+    def compact_lattice(self, n, acoustic_scale=None, determinize=False, beam=None, max_states=2000000):
+        """`determinize=True`: the determinised form the reference's recogniser returns (determinize_lattice = True,
+        bin/latgen.py:149) -- see determinize_lattice(); `beam` defaults to the decoder's lattice beam, costs are taken with
+        the acoustic scale applied (as Kaldi prunes) and written with it removed."""
+        raw = self._compact_lattice_raw(n, acoustic_scale)
+        if not determinize:
+            return raw
+        sc = self._acoustic_scale if acoustic_scale is None else acoustic_scale
+        det = determinize_lattice(raw, self._lattice_beam if beam is None else beam, max_states, acoustic_scale=sc)
+        for k in ("best_words", "best_tids", "best_cost"):
+            det[k] = raw[k]
+        return det
+
+    def _compact_lattice_raw(self, n, acoustic_scale=None):
         """Utterance n as a Kaldi CompactLattice (what `decoder_out["lattice"]` holds at reference bin/latgen.py:181): state =
         lattice token, arc = lattice link with ilabel = olabel = word id of the HCLG arc, weight (graph cost, acoustic
         cost with the acoustic scale removed) and the transition-id string ([tid], empty for epsilon links) -- Kaldi's
@@ -451,6 +465,7 @@ class MappedLatticeFasterRecognizer:
             ws = torch.empty(L.pk2_lattice_batch_bytes(h), dtype=torch.uint8, device=dev)
             batch = LatticeBatch(h, ws, lens.tolist(), dev, self.trans_model, P, self.graph)
             batch._acoustic_scale = self.acoustic_scale
+            batch._lattice_beam = float(self.decoder_opts.lattice_beam)
             _lib.check(L.pk2_lattice_decode(h, _lib.ptr(loglikes), loglikes.stride(0), loglikes.stride(1), P, _lib.ptr(t2p),
                                             self.trans_model.num_transition_ids(), _lib.ptr(ws), _lib.stream_ptr(dev)))
             status = np.zeros(N, np.int32); ntok = np.zeros(N, np.int32); nlink = np.zeros(N, np.int32)
@@ -471,3 +486,51 @@ class MappedLatticeFasterRecognizer:
     def decode(self, loglikes):
         """One utterance [T, P] -> LatticeBatch of one (the reference's per-utterance call, ops/ops.py:55)."""
         return self.decode_batch(loglikes.unsqueeze(0), [loglikes.shape[0]])
+
+
+def determinize_lattice(lat, beam, max_states=2000000, acoustic_scale=1.0):
+    """Determinises a raw state-level lattice (the dict LatticeBatch.compact_lattice returns: arcs src / dst / word / tid /
+    graph / acoustic, per-state final costs) on its word labels -- pk2_lattice_determinize, the host-side restatement of
+    Kaldi's DeterminizeLatticePruned that replaces PyKaldi's `determinize_lattice = True` (reference bin/latgen.py:149).
+    Every word sequence of the input survives once, with the costs and the transition-id alignment of its best path;
+    what lies more than `beam` above the best path (total cost = graph + acoustic_scale * acoustic) is dropped.  When the
+    construction exceeds `max_states` the beam is halved (at most 6 times), as Kaldi's wrapper retries with a tighter beam.
+    Returns a dict in the writer's format: arcs carry transition-id STRINGS (`tid_off`, `tids`), finals a cost pair."""
+    import ctypes as C
+    L = _lib.lib()
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    src, dst, word, tid = i32(lat["src"]), i32(lat["dst"]), i32(lat["word"]), i32(lat["tid"])
+    graph, ac = f32(lat["graph"]), f32(np.asarray(lat["acoustic"], np.float64) * acoustic_scale)
+    fin = f32(lat["final"])
+    h = C.c_void_p()
+    b = float(beam)
+    for attempt in range(7):
+        rc = L.pk2_lattice_determinize(int(lat["num_states"]), int(lat["start"]), src.shape[0], _lib.ptr(src), _lib.ptr(dst),
+                                       _lib.ptr(word), _lib.ptr(tid), _lib.ptr(graph), _lib.ptr(ac), _lib.ptr(fin), b,
+                                       int(max_states), C.byref(h))
+        if rc == 0:
+            break
+        if rc != -3 or attempt == 6:         # PK2_ERR_LIMIT = -3: too many states at this beam
+            _lib.check(rc)
+        b *= 0.5
+    try:
+        ns, st, na, nt, nf = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(L.pk2_det_lattice_sizes(h, C.byref(ns), C.byref(st), C.byref(na), C.byref(nt), C.byref(nf)))
+        ns, na, nt, nf = ns.value, na.value, nt.value, nf.value
+        o = dict(src=np.empty(na, np.int32), dst=np.empty(na, np.int32), word=np.empty(na, np.int32),
+                 graph=np.empty(na, np.float32), acoustic=np.empty(na, np.float32), tid_off=np.empty(na + 1, np.int64),
+                 tids=np.empty(max(1, nt), np.int32), final=np.empty(ns, np.float32), final_acoustic=np.empty(ns, np.float32),
+                 final_tid_off=np.empty(ns + 1, np.int64), final_tids=np.empty(max(1, nf), np.int32))
+        _lib.check(L.pk2_det_lattice_export(h, *[_lib.ptr(o[k]) for k in ("src", "dst", "word", "graph", "acoustic", "tid_off",
+                                                                          "tids", "final", "final_acoustic", "final_tid_off",
+                                                                          "final_tids")]))
+    finally:
+        L.pk2_det_lattice_destroy(h)
+    o["tids"], o["final_tids"] = o["tids"][:nt], o["final_tids"][:nf]
+    if acoustic_scale != 1.0 and acoustic_scale != 0.0:       # stored with the acoustic scale removed, like the raw lattice
+        o["acoustic"] = (o["acoustic"].astype(np.float64) / acoustic_scale).astype(np.float32)
+        o["final_acoustic"] = np.where(np.isfinite(o["final_acoustic"]), o["final_acoustic"].astype(np.float64) / acoustic_scale,
+                                       np.inf).astype(np.float32)
+    o.update(num_states=ns, start=st.value, beam_used=b, determinized=True)
+    return o

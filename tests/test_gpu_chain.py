@@ -306,6 +306,46 @@ def test_bench_size_denominator_matches_c_oracle(monkeypatch):
     assert np.abs(gamma_f.cpu().numpy() - gamma).max() < 1e-5
 
 
+@pytest.mark.parametrize("S,A", [(50000, 1000000), (40000, 1500000)], ids=["S50k_A1M", "S40k_A1.5M"])
+def test_large_state_graphs_match_c_oracle(S, A):
+    """Graphs beyond the fully resident persistent form (bin/train_chain.py:167,202 accepts any den.fst):
+    50 k states (the state vector no longer fits the LDS table: four table chunks, or the launch-per-frame kernels --
+    whichever the cost model picks, reported by kernel_path / persist_form) and 40 k states with 1.5 M arcs (streamed
+    overflow pieces).  Den log-prob 1e-3 rel and occupancies 1e-4 abs against the float64 build of oracle/chain_oracle.c,
+    P = 6048, chain topology, 3 ragged sequences; both kernel families must agree with each other as well."""
+    from oracle import chain_c
+    P = 6048
+    g = synth.den_graph_arcs(S, A, P, seed=1, loop_pdf_differs=True)
+    G = chain.DenominatorGraph(g, P)
+    lens = [90, 41, 66]
+    pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
+                             g["prob"].astype(np.float64), 0)
+    assert np.abs(G.initial_probs() - pi).max() < 1e-6
+    rng = np.random.default_rng(11)
+    lg = rng.normal(0, 2, size=(3, 90, P)).astype(np.float32)
+    x = torch.from_numpy(lg).cuda()
+    results = {}
+    for mode in ("default", "0", "2"):
+        if mode != "default":
+            os.environ["PK2_DEN_PERSIST"] = mode
+        try:
+            path, form = G.kernel_path(len(lens)), G.persist_form(len(lens))
+            lp, gamma = chain.den_forward_backward(G, x, lens, 1e-4)
+            results[mode] = (path, form, lp.cpu().numpy(), gamma.cpu().numpy())
+        finally:
+            os.environ.pop("PK2_DEN_PERSIST", None)
+    assert results["0"][0] == 1                                   # the launch-per-frame kernels
+    print("S = %d, A = %d: default path %d form %d; forced persistent: path %d form %d"
+          % (S, A, results["default"][0], results["default"][1], results["2"][0], results["2"][1]))
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, chk = chain_c.den_fb(g, pi, lg[n, :Tn], 1e-4, double=True)
+        assert abs(chk - 1.0) < 1e-3
+        for mode, (path, form, lp, gamma) in results.items():
+            assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp), (mode, n, lp[n], want_lp)
+            assert np.abs(gamma[n, :Tn] - want_g).max() < 1e-4, (mode, n)
+            assert not gamma[n, Tn:].any()
+
+
 def test_bench_size_objective_with_alignment_built_supervisions_matches_c_oracle():
     """Full LF-MMI objective and logit gradient at the bench configuration (S = 30 k / A = 1 M / P = 6048, supervisions
     built from transition-id alignments as bench.py and bin/train_chain.py:262-272 do, xent_regularize 0.1) against

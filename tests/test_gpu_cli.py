@@ -143,10 +143,21 @@ def test_latgen_cli_synthetic_writes_compact_lattices(tmp_path):
     lats = list(kaldi_io.read_compact_lattice_ark(str(tmp_path / "lat.ark")))
     assert [k for k, _ in lats] == ["synth-1", "synth-2", "synth-3"]
     for key, lat in lats:
-        assert lat["start"] == 0 and len(lat["arcs"]) > 500 and any(np.isfinite(f[0]) for f in lat["finals"])
-        assert all(0 <= a[1] < lat["num_states"] and a[2] == a[3] for a in lat["arcs"])
-        assert any(a[2] > 0 for a in lat["arcs"]) and all(len(a[4][2]) <= 1 for a in lat["arcs"])
+        # determinised on the word labels, like the reference's (decoder_opts.determinize_lattice = True): every arc carries
+        # a word and a transition-id string, no two arcs of a state carry the same word
+        assert lat["start"] == 0 and len(lat["arcs"]) >= 1 and any(np.isfinite(f[0]) for f in lat["finals"])
+        assert all(0 <= a[1] < lat["num_states"] and a[2] == a[3] and a[2] > 0 for a in lat["arcs"])
+        assert len(set((a[0], a[2]) for a in lat["arcs"])) == len(lat["arcs"])
+        assert sum(len(a[4][2]) for a in lat["arcs"]) > 0
         assert "Log-like per-frame for utterance %s is " % key in out.stdout
+    # -no_determinize: the raw lattice-beam-pruned state-level lattice (arc = decoder link, at most one transition-id)
+    raw = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "latgen.py"), "-config", str(tmp_path / "se.yaml"), "-no_determinize",
+                          "-out_file", str(tmp_path / "raw.ark"), "-synthetic", "3", "-synthetic_words", "300", "-batch_size", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert raw.returncode == 0, raw.stdout[-2000:] + raw.stderr[-2000:]
+    for (key, lat), (_, det) in zip(kaldi_io.read_compact_lattice_ark(str(tmp_path / "raw.ark")), lats):
+        assert len(lat["arcs"]) > 500 and len(lat["arcs"]) > len(det["arcs"]) and all(len(a[4][2]) <= 1 for a in lat["arcs"])
+        assert any(a[2] > 0 for a in lat["arcs"])
     # the best word sequence of every utterance is printed (ids: the synthetic graph has no words.txt)
     texts = [l for l in out.stdout.splitlines() if l.startswith("synth-")]
     assert len(texts) == 3 and all(len(t.split()) >= 2 and all(w.isdigit() for w in t.split()[1:]) for t in texts)
@@ -170,6 +181,22 @@ def test_best_path_of_the_compact_lattice_is_the_decoders():
     assert set(cl["best_words"]) <= set(g["olabel"][g["olabel"] > 0].tolist())
     # every word arc of the lattice carries the label of a word-entry arc of the graph; emitting links carry none
     assert (cl["word"][cl["tid"] > 0] == 0).all() and (cl["word"] >= 0).all()
+    # determinised form (reference bin/latgen.py:149): deterministic on words, and its best path costs what the decoder's does
+    det = lat.compact_lattice(0, determinize=True)
+    assert det["determinized"] and (det["word"] > 0).all() and det["src"].shape[0] < cl["src"].shape[0]
+    assert len(set(zip(det["src"].tolist(), det["word"].tolist()))) == det["src"].shape[0]
+    n = det["num_states"]
+    d = np.full(n, np.inf); d[det["start"]] = 0.0
+    cost = det["graph"].astype(np.float64) + 0.3 * det["acoustic"].astype(np.float64)
+    for _ in range(n):                                   # Bellman-Ford on the small acyclic result
+        nd = d.copy()
+        np.minimum.at(nd, det["dst"], d[det["src"]] + cost)
+        if np.array_equal(nd, d):
+            break
+        d = nd
+    fin = det["final"].astype(np.float64) + 0.3 * np.where(np.isfinite(det["final_acoustic"]), det["final_acoustic"], 0.0)
+    assert abs(float(np.min(d + fin)) - cl["best_cost"]) < 2e-3 * max(1.0, abs(cl["best_cost"]))
+    assert det["best_words"] == cl["best_words"]
 
 
 def test_decode_py_dumps_subsampled_loglikes(tmp_path):

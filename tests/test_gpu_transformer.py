@@ -108,16 +108,18 @@ def test_transformer_state_dict_keys_and_init_follow_torch():
     assert torch.equal(a.conv1d.weight, b.conv1d.weight)
 
 
-def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle():
+@pytest.mark.parametrize("P,param_grads", [(600, True), (6048, False)], ids=["P600_all_links", "P6048_full_width"])
+def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle(P, param_grads):
     """BASELINE configs[4]: the 12-layer TransformerAM (dim 512, 8 heads, FFN 2048, conv k=3; reference
     bin/train_transformer_se.py:128,243-258 model call with a key-padding mask) feeding ChainObjtiveBatch
     (ops/ops.py:243-280).  Three links, each against its own reference: logits vs the torch CPU forward of the same
     modules; objective and d objf / d logits vs the LF-MMI oracle on those logits; parameter gradients of the
-    composition vs torch CPU autograd fed with the oracle's gradient.  T = 60 subsampled frames."""
+    composition vs torch CPU autograd fed with the oracle's gradient.  T = 60 subsampled frames.  P = 600 runs all three
+    links; P = 6048 (the configuration's full output width, VERDICT r3 #7) the logits and objective / derivative links."""
     from oracle import chain_ref as R
     from pykaldi2_amd import chain, ops, synth
     torch.manual_seed(0)
-    P, T, B, L = 600, 60, 2, 12
+    T, B, L = 60, 2, 12
     m = transformer.TransformerAM(80, 512, 8, 2048, L, 0.0, P)
     for lp in m.transformer.layers:
         for p in lp.parameters():
@@ -158,6 +160,8 @@ def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle
         grad_o[:n, i] = torch.from_numpy(dg)
     assert abs(loss.item() - total) <= 1e-3 * abs(total), (loss.item(), total)
     assert (dlogits.double() + grad_o).abs().max().item() < 1e-4
+    if not param_grads:
+        return
     # (3) parameter gradients of the composition: torch CPU autograd fed with the gradient the device put at the logits
     # (checked against the oracle above), with the same modules in float64 as the truth and the reference's float32 CPU
     # run beside it.  In float32 a ReLU input that is ~0 can land on the other side of the kink than in float64 (FFN and
