@@ -331,6 +331,13 @@ size_t pk2_lstm_bwd_scratch_floats(int32_t B, int32_t H, int32_t num_dirs);
 int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, const float* cells,
                        int32_t B, int32_t T, int32_t H, int32_t num_dirs, float* dgx,
                        float* scratch, void* stream);
+/* The same with the bias gradients where the kernel can produce them on the way: dbias_ih / dbias_hh (device f32
+ * [D][4H], may be NULL) are ACCUMULATED into (+=; the caller zeroes them) with the sum over frames and sequences of dgx --
+ * b_ih and b_hh of torch's LSTM receive the same gradient.  *bias_done = 1 when they were filled, 0 when the path taken
+ * cannot (the caller then calls pk2_colsum_f32 on dgx). */
+int pk2_lstm_layer_bwd_bias(const float* dy, const float* whh, const float* gates, const float* cells,
+                            int32_t B, int32_t T, int32_t H, int32_t num_dirs, float* dgx, float* scratch,
+                            float* dbias_ih, float* dbias_hh, int32_t* bias_done, void* stream);
 /* The W_hh gradient dwhh[d] = sum_t dgates[d][t]^T h[d][t-1] (t+1 for the reverse direction)
  * is one pk2_gemm_f32 by the caller over row-shifted slices of dgx and y. */
 

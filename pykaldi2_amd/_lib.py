@@ -129,6 +129,7 @@ SIGNATURES = {
     "pk2_persist_guard_clear": (C.c_int, []),
     "pk2_persist_guard_raise": (C.c_int, [_vp]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
+    "pk2_lstm_layer_bwd_bias": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp]),
     "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "pk2_dropout_f32": (C.c_int, [_vp, _vp, _i64, _f32, C.c_uint64, _vp]),
     "pk2_grad_norm": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),

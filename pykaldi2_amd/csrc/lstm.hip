@@ -664,18 +664,40 @@ extern "C" size_t pk2_lstm_bwd_scratch_floats(int32_t B, int32_t H, int32_t D) {
   return (size_t)D * H * 4 * H + (size_t)D * B * H + 64 + (B >= kBigBatch ? (size_t)kBigSplitK * D * B * H : 0);
 }
 
+static int lstm_layer_bwd_impl(const float* dy, const float* whh, const float* gates, const float* cells, int32_t B, int32_t T,
+                               int32_t H, int32_t D, float* dgx, float* scratch, float* dbias_ih, float* dbias_hh,
+                               int32_t* bias_done, void* stream_);
+
 extern "C" int pk2_lstm_layer_bwd(const float* dy, const float* whh, const float* gates, const float* cells,
                                   int32_t B, int32_t T, int32_t H, int32_t D, float* dgx, float* scratch,
                                   void* stream_) {
+  return lstm_layer_bwd_impl(dy, whh, gates, cells, B, T, H, D, dgx, scratch, nullptr, nullptr, nullptr, stream_);
+}
+
+// The same, with the bias gradients where the kernel can produce them on the way (the one-launch recurrence of a
+// (sequence, direction) pair per XCD sums its d gates over the frames in registers): dbias_ih / dbias_hh [D][4H] are
+// ACCUMULATED into (+=, the caller zeroes them); *bias_done = 0 when the path taken did not fill them -- the caller then
+// takes the column sums of dgx itself (pk2_colsum_f32).
+extern "C" int pk2_lstm_layer_bwd_bias(const float* dy, const float* whh, const float* gates, const float* cells,
+                                       int32_t B, int32_t T, int32_t H, int32_t D, float* dgx, float* scratch,
+                                       float* dbias_ih, float* dbias_hh, int32_t* bias_done, void* stream_) {
+  PK2_REQUIRE(bias_done, "lstm_bwd_bias: null bias_done");
+  return lstm_layer_bwd_impl(dy, whh, gates, cells, B, T, H, D, dgx, scratch, dbias_ih, dbias_hh, bias_done, stream_);
+}
+
+static int lstm_layer_bwd_impl(const float* dy, const float* whh, const float* gates, const float* cells, int32_t B, int32_t T,
+                               int32_t H, int32_t D, float* dgx, float* scratch, float* dbias_ih, float* dbias_hh,
+                               int32_t* bias_done, void* stream_) {
   PK2_REQUIRE(dy && whh && gates && cells && dgx && scratch && B > 0 && T > 0 && (D == 1 || D == 2),
               "lstm_bwd: bad args");
   PK2_REQUIRE(lstm_h_ok(H), "lstm_bwd: hidden size %d unsupported (64,128,256,512,1024)", H);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (bias_done) *bias_done = 0;
   if (lstm_seq_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {
-    bool ran = false;
-    int prc = lstm_bwd_seq_launch(dy, whh, gates, cells, B, T, H, D, dgx, stream, &ran);
+    bool ran = false, bdone = false;
+    int prc = lstm_bwd_seq_launch(dy, whh, gates, cells, B, T, H, D, dgx, stream, &ran, dbias_ih, dbias_hh, &bdone);
     if (prc) return prc;
-    if (ran) return PK2_OK;
+    if (ran) { if (bias_done) *bias_done = bdone ? 1 : 0; return PK2_OK; }
   }
   if (lstm_persist_wanted(B, H, D) && !getenv("PK2_LSTM_PERSIST_FWD_ONLY")) {   // one launch for the whole sequence (lstm_persist.hip)
     bool ran = false;      // the mailboxes (1 MB) live where the step kernels keep W_hh^T

@@ -25,8 +25,11 @@ int lstm_persist_status(unsigned* abort_flag);
 bool lstm_seq_wanted(int B, int H, int D);
 int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int B, int T, int H, int D, float* y,
                         float* gates, float* cells, hipStream_t stream, bool* ran);
+// dbias_ih / dbias_hh (may be null): [D][4H] accumulators (+=) of the bias gradient, filled by the round-4 kernel inside its
+// launch; *bias_done says whether it was.
 int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
-                        int D, float* dgx, hipStream_t stream, bool* ran);
+                        int D, float* dgx, hipStream_t stream, bool* ran, float* dbias_ih = nullptr, float* dbias_hh = nullptr,
+                        bool* bias_done = nullptr);
 int lstm_seq_status(unsigned* abort_flag);
 
 // Large batches (B >= 32, H = 512; lstm_persist_big.hip): a (direction, 64-row batch tile) task per XCD team, the rank's

@@ -313,6 +313,8 @@ struct SeqBwdParams {
   float* mail;         // [teams][3][32 readers][32 writers][16 units], all sentinel
   int B, T, D;
   int pre_sleep, loop_sleep, store_mode;
+  float* dbias_ih;     // round-4 kernel: [D][4H] += sum over frames and sequences of d gx (null: not wanted), likewise dbias_hh
+  float* dbias_hh;
 };
 
 __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl) {
@@ -775,6 +777,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
     float* mail_wr = mail0 + ((size_t)(gidx >> 2) * kSWgs + rank) * 16 + 4 * (gidx & 3);  // peer G/4 reads [writer = rank][units 4 (G%4) ..]
     constexpr int kBox = kSWgs * kSWgs * 16;
     int s3 = 0;                                          // step % 3
+    float bias_sum = 0.f;                                // wave 1: sum over the frames of its lane's d gate (the bias gradient)
     SeqSpin spin(ctl);
     spin.limit = 10 * kSeqSpinTicks;      // (as in the forward kernel)
     SQ_T0();
@@ -875,10 +878,17 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
       if (io) {                  // behind the hand-over: d gx of the step to HBM, the factors two steps ahead, the prefetch
         *dgx_out = dg_own;
         dgx_out += dgx_stride;
+        bias_sum += dg_own;
         put_factors(step + 2, s3 == 0 ? 2 : s3 - 1);                   // slot (step + 2) % 3, from the loads of a step ago
         load_pw(step + 3);
       }
       s3 = s3n;
+    }
+    // the bias gradients (b_ih and b_hh receive the same sum) of this (sequence, direction): one atomic per gate row
+    if (io && p.dbias_ih) {
+      const size_t at = (size_t)d * G4 + (size_t)(lane >> 4) * H + 16 * rank + (lane & 15);
+      atomicAdd(p.dbias_ih + at, bias_sum);
+      if (p.dbias_hh) atomicAdd(p.dbias_hh + at, bias_sum);
     }
     SQ_PRINT("lstm_bwd_seq2", "(wave 0: mailbox poll + row sums | gate derivatives | lds barrier | product + mailbox stores || inside the poll: own stores acknowledged | first poll round trip | poll loop)", T);
     if (tid == 0 && rank == 0) __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -897,7 +907,8 @@ __global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, si
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
-struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; PersistGuard guard; };
+struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; PersistGuard guard;
+                    int mail_clean_teams = 0; };      // mailboxes of that many teams per XCD are known to hold only sentinels
 static std::map<DevStream, SeqScratch> g_seq_scratch;
 static PerDevice<int> g_seq_state_pd(-1);             // -1 untested, 0 unusable, 1 verified on this device
 
@@ -977,18 +988,27 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
 }
 
 int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, const float* cells, int B, int T, int H,
-                        int D, float* dgx, hipStream_t stream, bool* ran) {
+                        int D, float* dgx, hipStream_t stream, bool* ran, float* dbias_ih, float* dbias_hh, bool* bias_done) {
   *ran = false;
+  if (bias_done) *bias_done = false;
   if (g_seq_state_pd.ref() != 1) return PK2_OK;   // the forward pass verifies the device first
   SeqScratch* sc = nullptr;
   int rc = seq_scratch(stream, &sc);
   if (rc) return rc;
   PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
-  PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * seq_teams(B * D) * kSeqMailFloats, stream));
+  // Every reader resets the slots it has read, so a launch that completes leaves the mailboxes as it found them: all
+  // sentinels.  They are filled once (and again when a launch needs more teams than have been filled); a launch that
+  // gave up raises the guard, which stops training anyway (persist_guard.h).
+  if (sc->mail_clean_teams < seq_teams(B * D)) {
+    PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sc->mail), (int)kSeqSentinel, (size_t)8 * seq_teams(B * D) * kSeqMailFloats, stream));
+    sc->mail_clean_teams = seq_teams(B * D);
+  }
   static const int pre = getenv("PK2_SEQ_BWD_PRESLEEP") ? atoi(getenv("PK2_SEQ_BWD_PRESLEEP")) : 0;
   static const int lps = getenv("PK2_SEQ_BWD_LOOPSLEEP") ? atoi(getenv("PK2_SEQ_BWD_LOOPSLEEP")) : 0;
   static const int smode = getenv("PK2_SEQ_STORE_MODE") ? atoi(getenv("PK2_SEQ_STORE_MODE")) : 1;
-  SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D, pre, lps, smode};
+  const bool with_bias = seq_form() != 1 && dbias_ih != nullptr;
+  SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D, pre, lps, smode, with_bias ? dbias_ih : nullptr, with_bias ? dbias_hh : nullptr};
+  if (bias_done) *bias_done = with_bias;
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   else hipLaunchKernelGGL(lstm_bwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);

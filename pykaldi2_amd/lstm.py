@@ -18,6 +18,7 @@ array; within a layer the two directions' matrices are adjacent, so both
 directions share one GEMM.
 """
 import math
+import ctypes
 import os
 
 import torch
@@ -131,6 +132,10 @@ class _LstmAmFunction(torch.autograd.Function):
         dev = dlogits.device
         dlogits = dlogits.contiguous()
         gflat = m._grad_flat()
+        # ONE memset of the flat gradient buffer, then every gradient product accumulates (beta = 1): a split-K GEMM no longer
+        # needs its own zeroing launch (gemm_prescale_kernel), a column sum no scale_vec launch, and the bias gradients can
+        # be added from inside the backward recurrence (pk2_lstm_layer_bwd_bias)
+        gflat.zero_()
         views = m._grad_views(gflat)
         y_last = ctx.saved[-1][1]
         # The serial chain is  dlogits -> dy -> recurrence(l=L-1) -> dy -> recurrence(l=L-2) ...; the
@@ -156,8 +161,8 @@ class _LstmAmFunction(torch.autograd.Function):
         _gemm(0, 0, rows, D * H, P, _p(dlogits), P, _p(m.output_layer.weight), D * H, _p(dy), D * H)
 
         def out_grads():
-            _gemm(1, 0, P, D * H, rows, _p(dlogits), P, _p(y_last), D * H, _p(gw), D * H)
-            _lib.check(L.pk2_colsum_f32(_p(dlogits), P, rows, P, 0.0, _p(gb), _lib.stream_ptr()))
+            _gemm(1, 0, P, D * H, rows, _p(dlogits), P, _p(y_last), D * H, _p(gw), D * H, beta=1.0)
+            _lib.check(L.pk2_colsum_f32(_p(dlogits), P, rows, P, 1.0, _p(gb), _lib.stream_ptr()))
             m._bucket_ready("output_layer")
         on_side(out_grads, dlogits, y_last)
         scratch = torch.empty(L.pk2_lstm_bwd_scratch_floats(B, H, D), device=dev, dtype=torch.float32)
@@ -168,17 +173,18 @@ class _LstmAmFunction(torch.autograd.Function):
             w_ih, w_hh, b_ih, b_hh = m._layer_views(l)
             gw_ih, gw_hh, gb_ih, gb_hh = m._layer_views(l, gflat)
             dgx = torch.empty(T, B, D * 4 * H, device=dev, dtype=torch.float32)
-            _lib.check(L.pk2_lstm_layer_bwd(_p(dy), _p(w_hh), _p(gates), _p(cells), B, T, H, D, _p(dgx),
-                                            _p(scratch), sp))
+            bias_done = ctypes.c_int32(0)       # (the one-launch recurrence sums its d gates over the frames on the way)
+            _lib.check(L.pk2_lstm_layer_bwd_bias(_p(dy), _p(w_hh), _p(gates), _p(cells), B, T, H, D, _p(dgx), _p(scratch),
+                                                 _p(gb_ih), _p(gb_hh), ctypes.byref(bias_done), sp))
             G = D * 4 * H
 
             def layer_grads(dgx=dgx, inp=inp, y=y, in_size=in_size, gw_ih=gw_ih, gw_hh=gw_hh, gb_ih=gb_ih,
-                            gb_hh=gb_hh, l=l):
-                # bias gradients (b_ih and b_hh receive the same sum)
-                _lib.check(L.pk2_colsum_f32(_p(dgx), G, rows, G, 0.0, _p(gb_ih), _lib.stream_ptr()))
-                gb_hh.copy_(gb_ih)
+                            gb_hh=gb_hh, l=l, bias_done=bool(bias_done.value)):
+                if not bias_done:          # bias gradients (b_ih and b_hh receive the same sum)
+                    _lib.check(L.pk2_colsum_f32(_p(dgx), G, rows, G, 1.0, _p(gb_ih), _lib.stream_ptr()))
+                    gb_hh.copy_(gb_ih)
                 # dW_ih (both directions at once) = dgx^T inp
-                _gemm(1, 0, G, in_size, rows, _p(dgx), G, _p(inp), in_size, _p(gw_ih), in_size)
+                _gemm(1, 0, G, in_size, rows, _p(dgx), G, _p(inp), in_size, _p(gw_ih), in_size, beta=1.0)
                 # dW_hh[d] = sum_t dg_d[t]^T h_d[t-1] (reverse direction: h_d[t+1]); time-major => row shift by B
                 if T > 1:
                     k = (T - 1) * B
@@ -186,12 +192,10 @@ class _LstmAmFunction(torch.autograd.Function):
                         # both directions in one batched launch (matrix 1 = matrix 0 + these strides: the reverse
                         # direction pairs dg[t] with h[t+1])
                         _lib.check(L.pk2_gemm_f32_batched(1, 0, 4 * H, H, k, 1.0, _p(dgx, B * G), G, 4 * H - B * G, 0,
-                                                          _p(y), D * H, B * D * H + H, 0, 0.0, _p(gw_hh), H,
+                                                          _p(y), D * H, B * D * H + H, 0, 1.0, _p(gw_hh), H,
                                                           4 * H * H, 0, 2, 1, _lib.stream_ptr()))
                     else:
-                        _gemm(1, 0, 4 * H, H, k, _p(dgx, B * G), G, _p(y), D * H, _p(gw_hh), H)
-                else:
-                    gw_hh.zero_()
+                        _gemm(1, 0, 4 * H, H, k, _p(dgx, B * G), G, _p(y), D * H, _p(gw_hh), H, beta=1.0)
                 m._bucket_ready("lstm.l%d" % l)
             # critical path first (next layer's dy), weight gradients on the side stream
             if l > 0 or ctx.need_dx:
