@@ -239,7 +239,15 @@ __global__ void __launch_bounds__(256) lstm_fwd_big_persist(BigFwdParams p, BigC
         if (!bg_wait_flags(ctl, flags + (size_t)(s - 1) * kBgR, s_i)) return;
         BG_T(1);
         // W_slice x h_{prev}[strip]^T: 32 chunks of 16 k's, sixteen 16x16x4 MFMAs each; the h words come straight from L2,
-        // kDepth chunks ahead; the W words of the next chunk (LDS) are read under this chunk's MFMAs
+        // kDepth chunks ahead; the W words of the next chunk (LDS) are read under this chunk's MFMAs.
+        // These are PLAIN loads (a hit in this CU's vector L1 would be stale: other CUs wrote the rows): correct because a
+        // line of y[tp] is touched by this CU for the first time only after bg_wait_flags has seen the flags of ALL 32
+        // ranks of the step -- every writer of every line of the tile's rows has stored and waited for its stores by
+        // then -- and is never written again within the launch, and the L1 is invalidated at the kernel boundary.  A task's
+        // rows (direction, 64-row batch tile) are disjoint from every other task's, so a team that takes several tasks
+        // never revisits a line either (test_large_batch_lstm_matches_torch_cpu runs B = 600: 20 tasks on 8 teams).  The
+        // same holds for the backward kernels' d gates operands.  (agent-scope loads here cost the broadcast
+        // out of L2 its L1 hits: the wave pairs of a strip read every word twice.)
         const float* hbase = p.y + ((size_t)tp * B + arow) * yrow + (size_t)d * H + 4 * kq;
         constexpr int kDepth = 8, kChunks = H / 16;
         bg_f32x4 hv[kDepth];

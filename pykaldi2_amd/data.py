@@ -17,6 +17,7 @@ back), ``lens`` (samples), ``y`` (list of int64 pdf alignments, one per utteranc
 """
 import io
 import os
+import sys
 import wave
 import zipfile
 
@@ -84,20 +85,60 @@ class ZipWavSource:
 
     def durations(self):
         """Seconds per utterance from the WAV headers in the archives (fmt chunk: channels, rate, bits; data chunk: payload
-        size), without decoding the audio.  A member whose header cannot be parsed counts as 16 kHz 16-bit mono."""
+        size), without decoding the audio.  The result is cached next to each archive (`<archive>.durations.json`, keyed by
+        the archive's size and mtime; a directory that cannot be written is simply not cached) -- a 960 h corpus is ~280 k
+        member opens, which every rank of every job would otherwise repeat at start-up.  A header whose `data`
+        chunk lies beyond the first 4 KB (large LIST / bext chunks) is read further, up to 1 MB; a member whose header
+        cannot be parsed at all counts as 16 kHz 16-bit mono and is named in a warning."""
         if not hasattr(self, "_dur"):
+            import json
             want = {}
             for it in self.items:
                 want.setdefault(it[0], set()).add(it[1])
-            secs = {}
+            secs, fell_back = {}, []
             for zpath in sorted(want):
-                with zipfile.ZipFile(zpath) as z:
-                    for info in z.infolist():
-                        if info.filename not in want[zpath]:
-                            continue
-                        with z.open(info) as f:
-                            head = f.read(4096)
-                        secs[(zpath, info.filename)] = _wav_seconds(head, info.file_size)
+                st = os.stat(zpath)
+                cache_path, stamp = zpath + ".durations.json", [int(st.st_size), int(st.st_mtime)]
+                cached = {}
+                try:
+                    with open(cache_path) as f:
+                        blob = json.load(f)
+                    if blob.get("stamp") == stamp:
+                        cached = blob.get("seconds", {})
+                except (OSError, ValueError):
+                    pass
+                missing = [m for m in want[zpath] if m not in cached]
+                if missing:
+                    miss = set(missing)
+                    with zipfile.ZipFile(zpath) as z:
+                        for info in z.infolist():
+                            if info.filename not in miss:
+                                continue
+                            with z.open(info) as f:
+                                head = f.read(4096)
+                                sec = _wav_seconds(head, info.file_size)
+                                while sec is None and len(head) < min(info.file_size, 1 << 20):
+                                    more = f.read(len(head))           # the data chunk was not in what has been read: double it
+                                    if not more:
+                                        break
+                                    head += more
+                                    sec = _wav_seconds(head, info.file_size)
+                            if sec is None:
+                                sec = max(0, info.file_size - 44) / 2.0 / 16000.0
+                                fell_back.append("%s@/%s" % (zpath, info.filename))
+                            cached[info.filename] = sec
+                    try:
+                        tmp = "%s.%d.tmp" % (cache_path, os.getpid())
+                        with open(tmp, "w") as f:
+                            json.dump(dict(stamp=stamp, seconds=cached), f)
+                        os.replace(tmp, cache_path)       # (atomic: several ranks may write the same file)
+                    except OSError:
+                        pass
+                for m in want[zpath]:
+                    secs[(zpath, m)] = cached[m]
+            if fell_back:
+                sys.stderr.write("[data] %d wav header(s) could not be parsed, durations estimated as 16 kHz / 16-bit / mono: %s%s\n"
+                                 % (len(fell_back), ", ".join(fell_back[:5]), " ..." if len(fell_back) > 5 else ""))
             self._dur = np.array([secs[(it[0], it[1])] for it in self.items])
         return self._dur
 
@@ -113,11 +154,11 @@ class ZipWavSource:
 
 
 def _wav_seconds(head, file_size):
-    """Duration from the first bytes of a RIFF/WAVE file: walks the chunks up to `data`."""
+    """Duration from the first bytes of a RIFF/WAVE file: walks the chunks up to `data`.  None when the `data` chunk (or the
+    `fmt ` chunk before it) is not inside `head` or the file is no RIFF/WAVE at all -- the caller reads further or estimates."""
     import struct
-    fallback = max(0, file_size - 44) / 2.0 / 16000.0
     if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
-        return fallback
+        return None
     pos, rate, block = 12, None, None
     while pos + 8 <= len(head):
         tag, size = head[pos:pos + 4], struct.unpack("<I", head[pos + 4:pos + 8])[0]
@@ -126,11 +167,11 @@ def _wav_seconds(head, file_size):
             block = block or max(1, ch * bits // 8)
         elif tag == b"data":
             if not rate or not block:
-                return fallback
+                return None
             payload = min(size, file_size - (pos + 8)) if size not in (0, 0xFFFFFFFF) else file_size - (pos + 8)
             return max(0, payload) / float(block) / float(rate)
         pos += 8 + size + (size & 1)
-    return fallback
+    return None
 
 
 class SyntheticSource:

@@ -3,6 +3,8 @@ import io
 import wave
 import zipfile
 
+import os
+
 import numpy as np
 
 from pykaldi2_amd import data, synth
@@ -141,4 +143,50 @@ def test_wav_durations_come_from_the_headers():
     x = mk(16000, 1, 16000)
     y = x[:36] + b"LIST" + struct.pack("<I", 10) + b"0123456789" + x[36:]
     assert _wav_seconds(y[:4096], len(y)) == 1.0
-    assert _wav_seconds(b"junk", 32044) == 1.0
+    assert _wav_seconds(b"junk", 32044) is None            # (the caller estimates and says so)
+    # a `data` chunk beyond the first 4 KB (a large LIST chunk): not an estimate any more -- the caller reads further
+    z = x[:36] + b"LIST" + struct.pack("<I", 6000) + b"\0" * 6000 + x[36:]
+    assert _wav_seconds(z[:4096], len(z)) is None and _wav_seconds(z[:8192], len(z)) == 1.0
+
+
+def test_durations_read_past_large_header_chunks_and_are_cached(tmp_path, capsys):
+    """ZipWavSource.durations() reads on when the `data` chunk is not in the first 4 KB, names the members it had
+    to estimate, and keeps the result next to the archive (keyed by the archive's size and mtime) so that the next
+    process -- every rank of every job -- does not open every member again."""
+    import io
+    import json
+    import struct
+    import wave
+    import zipfile
+
+    def mk(n):
+        b = io.BytesIO()
+        with wave.open(b, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(b"\0" * (2 * n))
+        return b.getvalue()
+    x = mk(16000)
+    big_list = x[:36] + b"LIST" + struct.pack("<I", 20000) + b"\0" * 20000 + x[36:]
+    zpath = str(tmp_path / "a.zip")
+    with zipfile.ZipFile(zpath, "w") as z:
+        z.writestr("u1.wav", mk(8000)); z.writestr("u2.wav", big_list); z.writestr("u3.wav", b"not a wav file at all" * 100)
+    src = data.ZipWavSource([dict(wav=zpath)])
+    dur = dict(zip([it[2] for it in src.items], src.durations()))
+    assert dur["u1"] == 0.5 and dur["u2"] == 1.0 and abs(dur["u3"] - (2100 - 44) / 32000.0) < 1e-9
+    err = capsys.readouterr().err
+    assert "1 wav header(s) could not be parsed" in err and "u3.wav" in err and "u2.wav" not in err
+    blob = json.load(open(zpath + ".durations.json"))
+    assert blob["seconds"]["u2.wav"] == 1.0 and blob["stamp"][0] == os.path.getsize(zpath)
+    # a second source answers from the cache: no member is opened (the archive's member reader is disabled to prove it)
+    src2 = data.ZipWavSource([dict(wav=zpath)])
+    orig = zipfile.ZipFile.open
+    try:
+        zipfile.ZipFile.open = lambda *a, **k: (_ for _ in ()).throw(AssertionError("member opened although cached"))
+        assert list(src2.durations()) == list(src.durations())
+    finally:
+        zipfile.ZipFile.open = orig
+    # a changed archive invalidates the cache
+    with zipfile.ZipFile(zpath, "a") as z:
+        z.writestr("u4.wav", mk(4000))
+    os.utime(zpath, (1, 1))
+    src3 = data.ZipWavSource([dict(wav=zpath)])
+    assert dict(zip([it[2] for it in src3.items], src3.durations()))["u4"] == 0.25

@@ -227,6 +227,34 @@ hvd.broadcast_optimizer_state(t2, root_rank=0)
 for p in ref_params:
     st = t2.state[p]
     assert same_on_all_ranks(st["exp_avg"]) and float(st["step"]) == 1.0
+# ADVICE r3: (1) a torch.optim optimiser whose state only ROOT holds (only root read the checkpoint): the other ranks
+# allocate to root's header instead of issuing fewer collectives; hyper-parameters travel too
+t3 = torch.optim.Adam(ref_params, lr=1e-3 if rank == 0 else 7.0, betas=(0.8, 0.9) if rank == 0 else (0.5, 0.5), amsgrad=True)
+if rank == 0:
+    for p in ref_params:
+        p.grad = torch.randn_like(p)
+    t3.step()
+hvd.broadcast_optimizer_state(t3, root_rank=0)
+assert t3.param_groups[0]["lr"] == 1e-3 and tuple(t3.param_groups[0]["betas"]) == (0.8, 0.9)
+for p in ref_params:
+    st = t3.state[p]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"} and float(st["step"]) == 1.0
+    assert same_on_all_ranks(st["exp_avg"]) and same_on_all_ranks(st["max_exp_avg_sq"]) and float(st["exp_avg"].abs().sum()) > 0
+# (2) flat optimisers: a rank that holds amsgrad moments root lacks must not issue a broadcast root does not
+a3 = optim.Adam(m, lr=2.0 if rank else 1e-4, amsgrad=(rank == 1), betas=(0.9, 0.99) if rank == 0 else (0.1, 0.2), eps=1e-8 if rank == 0 else 1.0)
+fp = m.flat_parameters()[0]                 # both ranks hold a state (as after a step); only rank 1's includes max_exp_avg_sq
+a3.state = dict(exp_avg=torch.randn_like(fp), exp_avg_sq=torch.rand_like(fp), max_exp_avg_sq=torch.rand_like(fp) if rank == 1 else None)
+a3.step_count = 3 + rank
+hvd.broadcast_optimizer_state(a3, root_rank=0)
+assert a3.state["max_exp_avg_sq"] is None and not a3.amsgrad and same_on_all_ranks(a3.state["exp_avg"])
+assert a3.param_groups[0]["lr"] == 1e-4 and tuple(a3.betas) == (0.9, 0.99) and a3.eps == 1e-8 and a3.step_count == 3
+# (3) root without a state, the others with one: lr still travels, the others drop theirs
+a4 = optim.Adam(m, lr=3e-4 if rank == 0 else 9.0, amsgrad=True)
+if rank == 1:
+    a4.state = dict(exp_avg=torch.randn_like(fp), exp_avg_sq=torch.rand_like(fp), max_exp_avg_sq=torch.rand_like(fp))
+    a4.step_count = 5
+hvd.broadcast_optimizer_state(a4, root_rank=0)
+assert a4.state is None and a4.step_count == 0 and a4.param_groups[0]["lr"] == 3e-4
 print("OK", rank)
 hvd.shutdown()
 """
