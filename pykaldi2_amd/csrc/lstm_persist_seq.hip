@@ -492,6 +492,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq(SeqBwdParams p, SeqCtl* ctl)
 //    PAIR owns a 16-byte granule of the partial d h (4 columns x half of the rows each), so the partials leave as one
 //    16-byte store per pair instead of two scattered 4-byte stores per lane; the reader resets a slot behind its own
 //    partials (issuing the two reset stores takes ~300 clocks).
+//  * Tried and dropped: two polls in flight half a round trip apart (the arrival is noticed with half the granularity, the
+//    polling traffic doubles): forward 1.02 -> 1.04 us per step; s_sleep before the first poll or between polls: slower
+//    with plain stores (it paid only while the stores were agent-scope ones: backward 1.99 -> 1.56 us at 16 x 64 clocks,
+//    i.e. polling a line that is being written through costs the writer).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PK2_CONSTANT_AS __attribute__((address_space(4)))
 
