@@ -234,11 +234,11 @@ def den_roofline(den, dev, reps=5):
     # read live.  Only reported when the profile was taken on the same lengths and graph shape.
     traffic, traffic_note = None, "no PMC profile of this workload committed"
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_den_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_den_traffic.json")) as f:
             prof = json.load(f)
         if prof.get("lengths") == lens and prof.get("topology") == DEN_TOPOLOGY and prof.get("arcs") == A:
             traffic = int(prof["traffic_bytes_raw"])
-            traffic_note = ("rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), raw; with FETCH_SIZE doubled "
+            traffic_note = ("profiles/r04_den_traffic.json: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), raw; with FETCH_SIZE doubled "
                             "(gfx950 wide-read correction, an upper bound here): %d" % int(prof["traffic_bytes_fetch_x2"]))
     except Exception:
         pass
