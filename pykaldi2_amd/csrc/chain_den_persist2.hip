@@ -313,8 +313,15 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     c1.src = src + b1 + lane * 4; c1.dst = L.table + o.lds_off[1];
     c1.rows = (e1 - b1 + 255) >> 8; c1.limit = ((e1 + 3) & ~3) - b1 - lane * 4; c1.w = tid >> 6;
   }
-  pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry, c1);
-  for (int j = 8; j * kPW < c1.rows; ++j) c1(j);     // (a chunk 1 of more than 64 rows: the rest, stalling at the issue)
+  // (round 4) two chunks that take turns in ONE buffer -- a vector of up to twice the LDS table: chunk 1 may only be
+  // copied once every wave has finished pass A (and the streamed segment that gathers from chunk 0)
+  const bool shared = o.K == 2 && o.lds_off[1] == o.lds_off[0] && o.cbeg[2] > o.cbeg[1];
+  if (shared) {
+    pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry, NoDma());
+  } else {
+    pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry, c1);
+    for (int j = 8; j * kPW < c1.rows; ++j) c1(j);     // (a chunk 1 of more than 64 rows: the rest, stalling at the issue)
+  }
   DP_T(2);
   DP_TLF(3);
   if constexpr (STREAM) {
@@ -322,6 +329,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     const int K = o.K;
     const int pfirst = pb[0], pend = pb[K];
     if (pb[1] > pb[0]) streamed_segment(o, rank, 0, pb[0], pb[1], pb[1] < pend, pfirst, st.cur, L);
+    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table); }
     wait_vm(0);
     stage();
     __syncthreads();                       // chunk 1 is complete, and buffer 0 is free
@@ -336,6 +344,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
       if (pb[c + 1] > pb[c]) streamed_segment(o, rank, c, pb[c], pb[c + 1], pb[c + 1] < pend, pfirst, st.cur, L);
     }
   } else {
+    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table); }
     wait_vm(0);
     stage();
     __syncthreads();                       // chunk 1 is complete
@@ -755,11 +764,12 @@ __global__ void __launch_bounds__(kPT) den_persist2_kernel(const DenPersist2Para
     // (PSPT: rows / states / own virtual states a thread handles in the row epilogues -- 2 when no rank has more than
     // 2 * kPT of any of them: the per-state constants then take half the registers)
     if (p.task_dir[k] == 0) {
-      if (p.fwd_stream) { if (p.pspt == 2) run_fwd2<true, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_fwd2<true, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
-      else { if (p.pspt == 2) run_fwd2<false, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_fwd2<false, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
+      // (three entries per thread since round 4: graphs of 33 - 49 k states have 1025 .. 1536 rows per rank)
+      if (p.fwd_stream) { if (p.pspt == 2) run_fwd2<true, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else if (p.pspt == 3) run_fwd2<true, 3>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_fwd2<true, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
+      else { if (p.pspt == 2) run_fwd2<false, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else if (p.pspt == 3) run_fwd2<false, 3>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_fwd2<false, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
     } else {
-      if (p.bwd_stream) { if (p.pspt == 2) run_bwd2<true, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_bwd2<true, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
-      else { if (p.pspt == 2) run_bwd2<false, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_bwd2<false, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
+      if (p.bwd_stream) { if (p.pspt == 2) run_bwd2<true, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else if (p.pspt == 3) run_bwd2<true, 3>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_bwd2<true, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
+      else { if (p.pspt == 2) run_bwd2<false, 2>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else if (p.pspt == 3) run_bwd2<false, 3>(pp, ctl, team, &nbar, g, T, rank, ring, pring); else run_bwd2<false, kPSPT>(pp, ctl, team, &nbar, g, T, rank, ring, pring); }
     }
     __syncthreads();
     if (s_abort) return;
@@ -846,7 +856,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   p.fwd = g->p2fwd; p.bwd = g->p2bwd;
   p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
   p.rpad = rpad; p.tfloats = den2_tfloats(g); p.cap = g->p2_cap;
-  p.pspt = g->p2_cap <= 2 * kPT ? 2 : kPSPT;
+  p.pspt = g->p2_cap <= 2 * kPT ? 2 : (g->p2_cap <= 3 * kPT ? 3 : kPSPT);
   p.fwd_stream = (!g->h_p2fwd.sends.empty() || g->h_p2fwd.K > 2) ? 1 : 0;
   p.bwd_stream = (!g->h_p2bwd.sends.empty() || g->h_p2bwd.K > 2) ? 1 : 0;
   std::vector<std::pair<int, int>> order;    // (-T, task id = 2 n + dir), longest first

@@ -382,6 +382,28 @@ static bool persist2_chunks(int64_t A, const int32_t* idx, int R, int num_rows, 
     return true;
   }
   out->flexible = false;
+  const char* shared_env = getenv("PK2_DP2_SHARED");          // (read per graph: tests switch it)
+  const bool shared_ok = !(shared_env && atoi(shared_env) == 0);
+  if (shared_ok && rpad <= 2 * (tcap / 256 * 256)) {
+    // Round 4: a vector of up to TWICE the LDS table keeps both resident passes.  Two chunks that take turns in ONE buffer:
+    // pass A gathers from chunk 0, the buffer is then overwritten with chunk 1 (nothing hides that copy), pass B gathers
+    // from chunk 1 only -- the lists follow the chunks strictly, so the split is put where half of the arcs gather from
+    // below it (both halves must fit the buffer).  Every arc stays in registers: S = 30 k -> 50 k states at 1.0 M arcs
+    // costs the second, exposed table copy (+2 us per frame) instead of the launch-per-frame kernels (x 2.9).
+    const int trows = rpad / 256, brows = tcap / 256;
+    std::vector<int64_t> cnt(trows, 0);
+    for (int64_t i = 0; i < A; ++i) cnt[idx[i] / 256]++;
+    int b = 0; int64_t below = 0;
+    while (b < trows && 2 * below < A) below += cnt[b++];
+    b = std::max(trows - brows, std::min(b, brows));
+    b = std::max(1, std::min(b, trows - 1));
+    out->K = 2;
+    out->cbeg[0] = 0; out->cbeg[1] = std::min(R, b * 256); out->cbeg[2] = R;
+    out->lds_off[0] = 0; out->lds_off[1] = 0;
+    out->tfloats = std::max(b, trows - b) * 256;
+    for (int c = 3; c <= kMaxChunks; ++c) out->cbeg[c] = R;
+    return true;
+  }
   const int H = tcap / 2 / 256 * 256;
   if (H < 256) return false;
   const int K = (R + H - 1) / H;
@@ -720,7 +742,7 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
   // Rows per rank: at most 2 * kPT when that is possible (the row epilogues then handle two entries per thread and keep half
   // the per-state constants in registers; the passes cost the same however full their slots are), else up to kPMaxRows.
   bool assigned = false;
-  for (int lim : {2 * kPT, kPMaxRows}) {
+  for (int lim : {2 * kPT, 3 * kPT, kPMaxRows}) {
     if (!persist2_assign(A2, V, arc_v, vstate, S, lim, &f) || !persist2_assign(A2, S, src2, nullptr, S, lim, &b)) continue;
     // the backward workgroups also stage x for their own virtual states: max_groups = how many
     b.max_groups = 0;
@@ -763,7 +785,10 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
       HostPersist2 cand = h;
       if (!persist2_arc_lists(A2, idx, cand, estep, ptr, perm, &list_of, &lidx) ||
           !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, estep, res, false, &cand)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
-      const double cost = arcs_us(estep) + 0.6 * cand.max_pieces + (cand.max_pieces ? 0.3 : 0.0);
+      // (round 4: the FIRST streamed piece costs ~5 us per frame -- the streaming variant of the frame: zeroed row arrays,
+      // spill reloads behind the piece loads -- and ~0.9 each after it (profiles/r04_den_sweep.txt: S = 30 k, 1.0 -> 1.5 M
+      // arcs = 4 pieces: 7.75 -> 15.1); the old 0.3 + 0.6 per piece chose padded rows + one piece over unpadded rows)
+      const double cost = arcs_us(estep) + (cand.max_pieces ? 4.5 + 0.9 * cand.max_pieces : 0.0);
       if (cost < best_cost) { best_cost = cost; best_estep = estep; }
       if (cand.max_pieces == 0 && cand.K == 2) break;
     }

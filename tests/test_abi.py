@@ -361,9 +361,15 @@ def _emulate_persist2(lay, table):
                 tails[tid], has_end[tid] = sm, had
             scan(accS, tails, has_end, lay["sfirst_row"][r, c], lay["wcrow"][r, 2 + c], carries)
 
-        load(0); load(1)
+        shared = NC == 2 and off[1] == off[0] and cbeg[2] > cbeg[1]     # two chunks taking turns in one buffer (round 4)
+        load(0)
+        if not shared:
+            load(1)
         resident(0)
         streamed(0)
+        if shared:
+            lds[:] = np.nan                                              # pass B must not depend on what chunk 0 left behind
+            load(1)
         if NC > 2:
             load(2)
         resident(1)
@@ -383,7 +389,8 @@ def _emulate_persist2(lay, table):
     return out
 
 
-@pytest.mark.parametrize("case", ["default", "bigstate", "overflow", "overflow_estep1", "chunks", "chunks_overflow", "res1", "res2_chunks"])
+@pytest.mark.parametrize("case", ["default", "bigstate", "overflow", "overflow_estep1", "chunks", "chunks_overflow", "res1", "res2_chunks",
+                                  "res2_shared", "shared"])
 def test_den_graph_persistent2_layouts(case, monkeypatch):
     """Second persistent layout (chain_den_persist2.hip): table chunks, two resident passes, streamed overflow.  The numpy
     model of the kernel's frame reproduces both recursions' row sums: back-to-back chunks (default), a row spanning several
@@ -403,10 +410,13 @@ def test_den_graph_persistent2_layouts(case, monkeypatch):
     if case == "res1":              # what the GPU parity tests use to reach the streamed path on small graphs
         monkeypatch.setenv("PK2_DP2_RES", "1")
         S, A = 400, 30000
-    if case == "res2_chunks":
-        monkeypatch.setenv("PK2_DP2_RES", "2")
+    if case in ("res2_chunks", "res2_shared", "shared"):
+        if case != "shared":
+            monkeypatch.setenv("PK2_DP2_RES", "2")
         monkeypatch.setenv("PK2_DP2_TCAP", "1024")
-        S, A = 1400, 50000
+        if case == "res2_chunks":          # (a vector of up to twice the table would take the shared-buffer form)
+            monkeypatch.setenv("PK2_DP2_SHARED", "0")
+        S, A = 1400, (150000 if case == "res2_shared" else 50000)      # (res2_shared: lists beyond 2 slots x 512 threads -> streamed pieces)
         kw["multi_entry_frac"] = 0.3
     if case.startswith("chunks"):
         S, A = 1100, 20000
@@ -442,6 +452,12 @@ def test_den_graph_persistent2_layouts(case, monkeypatch):
         assert pf["estep"] == 1 and pf["pieces"] > 0 and pb["pieces"] > 0
     if case == "res2_chunks":
         assert pf["estep"] <= 2 and pf["K"] == 3 and pb["K"] >= 3 and pf["pieces"] > 0
+    if case in ("res2_shared", "shared"):
+        # S = 1400 -> 1536 table entries > the 1024 of the table, <= twice that: two chunks in ONE buffer, both lists resident
+        assert pf["K"] == 2 and pf["lds_off"][:2] == [0, 0] and 0 < pf["cbeg"][1] < pf["cbeg"][2] == S_ and pf["tfloats"] <= 1024
+        assert (pf["pieces"] > 0) == (case == "res2_shared")
+        arcs_below = int((src[src != dst] < pf["cbeg"][1]).sum())
+        assert 0.3 < arcs_below / float((src != dst).sum()) < 0.7       # the split halves the arcs, not the states
     if case.startswith("chunks"):
         assert pf["K"] == 5 and pb["K"] >= 5 and pf["tfloats"] == 512 and pf["lds_off"][:5] == [0, 256, 0, 256, 0]
         assert pf["pieces"] > 0            # chunks >= 2 have no resident pass

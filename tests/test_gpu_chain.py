@@ -25,7 +25,8 @@ _KIND = dict(chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_p
 @pytest.mark.parametrize("path", ["state_x", "general_forced", "arc_pdf", "chain_topology", "multi_entry", "arc_pdf_sx_forced",
                                   "chain_topology_general", "state_x_frames", "chain_topology_frames", "multi_entry_frames",
                                   "chain_topology_persist1", "multi_entry_persist1", "chain_topology_p2stream",
-                                  "multi_entry_p2stream", "chain_topology_p2chunks", "multi_entry_p2chunkstream"])
+                                  "multi_entry_p2stream", "chain_topology_p2chunks", "multi_entry_p2chunkstream",
+                                  "chain_topology_p2shared", "multi_entry_p2sharedstream"])
 @pytest.mark.parametrize("S,A,P,lens,leaky", [
     (8, 30, 5, [6], 1e-2),
     (200, 3000, 40, [51, 17, 33], 1e-4),
@@ -52,15 +53,17 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
     # forms of the persistent kernel: the first (everything resident: csrc/chain_den_persist.hip) and variants of the second
     # (csrc/chain_den_persist2.hip, the default) that these small graphs would not reach by themselves: 1 or 2 register slots
     # per resident pass (everything else streamed in pieces), an LDS table of 1024 entries (4 - 6 table chunks through two
-    # buffers), both.  The layout variables are read when the graph is created.
-    form = {"persist1": 1, "p2stream": 2, "p2chunks": 2, "p2chunkstream": 2}.get(path.rsplit("_", 1)[-1], 0)
+    # buffers; `shared`: a vector of up to twice the table as two chunks taking turns in ONE buffer, round 4), both.  The
+    # layout variables are read when the graph is created.
+    form = {"persist1": 1, "p2stream": 2, "p2chunks": 2, "p2chunkstream": 2, "p2shared": 2, "p2sharedstream": 2}.get(path.rsplit("_", 1)[-1], 0)
     if form:
         monkeypatch.setenv("PK2_DEN_PERSIST", str(form))
         path, variant = path.rsplit("_", 1)
-        if variant in ("p2stream", "p2chunkstream"):
+        if variant in ("p2stream", "p2chunkstream", "p2sharedstream"):
             monkeypatch.setenv("PK2_DP2_RES", "1" if variant == "p2stream" else "2")
-        if variant in ("p2chunks", "p2chunkstream"):
+        if variant in ("p2chunks", "p2chunkstream", "p2shared", "p2sharedstream"):
             monkeypatch.setenv("PK2_DP2_TCAP", "1024")
+        monkeypatch.setenv("PK2_DP2_SHARED", "1" if "shared" in variant else "0")
     arc_pdf = path.startswith("arc_pdf")
     g, G, ref = _mk(S, A, P, seed=S, arc_pdf=arc_pdf, **_KIND.get(path.replace("_general", "").replace("_frames", ""), {}))
     if A == 20000:
@@ -78,6 +81,8 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
                 lay = G.debug_persist2(0)
                 # (1 register slot per pass = 512 slots per workgroup: only the 60000-arc graph overflows them)
                 assert ("stream" not in variant or A < 60000 or lay["pieces"] > 0) and ("chunk" not in variant or S < 1024 or lay["K"] > 2)
+                if "shared" in variant and 1024 < S <= 2048:      # the forward table (S entries) exceeds the 1024 of the LDS table
+                    assert lay["K"] == 2 and lay["lds_off"][:2] == [0, 0] and 0 < lay["cbeg"][1] < lay["cbeg"][2]
     rng = np.random.default_rng(1)
     T = max(lens)
     lg = rng.normal(0, 3, size=(len(lens), T, P)).astype(np.float32)
