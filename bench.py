@@ -654,6 +654,7 @@ def main():
                     "gives) or unique (round 1: one pdf per destination state)")
     ap.add_argument("--lstm-only", action="store_true", help="time only one LSTM layer forward")
     ap.add_argument("--gemm-only", action="store_true", help="time the f32 MFMA GEMM on the model's shapes")
+    ap.add_argument("--gemm-shapes", default="", help="with --gemm-only: 'ta,tb,M,N,K;...' instead of the built-in shapes")
     ap.add_argument("--transformer", action="store_true", help="secondary workload configs[4]: 12-layer TransformerAM "
                     "LF-MMI instead of the BLSTM")
     ap.add_argument("--se", action="store_true", help="secondary workload configs[3]: lattice MMI with on-the-fly lattices "
@@ -696,6 +697,8 @@ def main():
                   (1, 0, 4096, 1024, 2356), (1, 0, 2048, 512, 2352), (0, 0, 2356, 1024, 4096), (0, 1, 2356, 4096, 80),
                   (0, 1, 20480, 4096, 1024), (0, 1, 4096, 4096, 4096),
                   (1, 0, 4096, 1024, 20480), (1, 0, 2048, 512, 20480), (1, 0, 5768, 1024, 20480), (0, 0, 20480, 1024, 4096)]
+        if args.gemm_shapes:      # "ta,tb,M,N,K;..." instead of the built-in list
+            shapes = [tuple(int(v) for v in sh.split(",")) for sh in args.gemm_shapes.split(";") if sh]
         for ta, tb, M, N, K in shapes:
             A = torch.randn((K, M) if ta else (M, K), device=dev)
             Bm = torch.randn((N, K) if tb else (K, N), device=dev)

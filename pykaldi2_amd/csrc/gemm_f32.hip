@@ -76,9 +76,17 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
   }
 #ifdef PK2_GEMM_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (tid == 0 && K == 1024 && N == 4096 && (blockIdx.x + blockIdx.y * gridDim.x) % 97 == 0)
-    printf("gemm tile (%d,%d) of grid (%d,%d) tiles=%d: start %lld main loop %lld epilogue %lld (10 ns ticks)\n", blockIdx.x, blockIdx.y,
-           gridDim.x, gridDim.y, TILES, gp_t0, gp_t1 - gp_t0, wall_clock64() - gp_t1);
+#ifndef PK2_GEMM_PROFILE_N
+#define PK2_GEMM_PROFILE_N 4096
+#define PK2_GEMM_PROFILE_K 1024
+#define PK2_GEMM_PROFILE_EVERY 97
+#endif
+  if (tid == 0 && K == PK2_GEMM_PROFILE_K && N == PK2_GEMM_PROFILE_N && (blockIdx.x + blockIdx.y * gridDim.x) % PK2_GEMM_PROFILE_EVERY == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    printf("gemm tile (%d,%d) of grid (%d,%d) tiles=%d xcc %u: start %lld main loop %lld epilogue %lld (10 ns ticks)\n", blockIdx.x, blockIdx.y,
+           gridDim.x, gridDim.y, TILES, xcc & 7u, gp_t0, gp_t1 - gp_t0, wall_clock64() - gp_t1);
+  }
 #endif
 }
 

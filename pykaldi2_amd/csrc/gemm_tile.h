@@ -81,18 +81,25 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ base, int64_
 // float4 computed ONCE, then `ptr + kt * step` per slab -- no bounds tests, no 64-bit multiplies in the main loop (the
 // general load_slab costs ~60 VALU / SALU instructions and a dozen exec-mask branches per call; with four calls per slab it
 // throttled the MFMA issue: 46 % of peak on the model's shapes against 67-77 % for the same tile shape without it).
+//
+// Edge tiles (rows of the tile beyond the matrix's R rows) take the same path: a row index beyond the matrix is CLAMPED to
+// its last row (to its last aligned group of four rows when the rows are the contiguous dimension), so the loads stay
+// aligned and in bounds and the tile multiplies duplicates of valid rows into accumulator rows / columns the epilogue never
+// stores.  (Until round 4 edge tiles went through the general loader: on R = 2356 frames the last row band of 64x64 tiles
+// ran its main loop 4.6 x as long as the interior ones -- 60 us against 13 in the profile build -- and every product with
+// M = frames waited for it: 2356 x 512 x 512 took 33 us of which the interior tiles needed 15.)
 template <bool KCONTIG, int TILES>
-__device__ __forceinline__ void slab_pointers(const float* __restrict__ base, int64_t ld, int r0, int k0,
+__device__ __forceinline__ void slab_pointers(const float* __restrict__ base, int64_t ld, int r0, int k0, int R,
                                               const float* (&ptr)[TILES], int64_t* step) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int h = 0; h < TILES; ++h) {
     if (KCONTIG) {
       const int r = (tid >> 2) + h * 64, k = (tid & 3) * 4;
-      ptr[h] = base + (int64_t)(r0 + r) * ld + k0 + k;
+      ptr[h] = base + (int64_t)min(r0 + r, R - 1) * ld + k0 + k;
     } else {
       const int k = tid / Geo<TILES>::LPK + h * (kGemmThreads / Geo<TILES>::LPK), r = (tid % Geo<TILES>::LPK) * 4;
-      ptr[h] = base + (int64_t)(k0 + k) * ld + r0 + r;
+      ptr[h] = base + (int64_t)(k0 + k) * ld + min(r0 + r, R - 4);
     }
   }
   *step = KCONTIG ? (int64_t)BK : (int64_t)BK * ld;
@@ -171,25 +178,42 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
   // through precomputed pointers (gemm_tile.h) by straight-line code -- with a branch inside the fetch the compiler can no
   // longer count the loads in flight and waits for all of them (vmcnt(0)) before every LDS store, which exposes a round
   // trip to memory per slab whatever DEPTH is; a last partial slab is multiplied separately behind the loop.
-  const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N;
+  // (an edge tile qualifies when its rows can be clamped: always for a k-contiguous operand, for a row-contiguous one when
+  // the row count is a multiple of four -- slab_pointers)
+  const bool interior = vecA && vecB && (m0 + BM <= M || KCA || ((M & 3) == 0 && M >= 4)) &&
+                        (n0 + BN <= N || KCB || ((N & 3) == 0 && N >= 4));
   const float* pa[TILES]; const float* pb[TILES];
   int64_t stepA = 0, stepB = 0;
-  slab_pointers<KCA, TILES>(A, lda, m0, kbeg, pa, &stepA);
-  slab_pointers<KCB, TILES>(B, ldb, n0, kbeg, pb, &stepB);
+  slab_pointers<KCA, TILES>(A, lda, m0, kbeg, M, pa, &stepA);
+  slab_pointers<KCB, TILES>(B, ldb, n0, kbeg, N, pb, &stepB);
+#ifndef PK2_GEMM_HOIST
+#define PK2_GEMM_HOIST 8        // k-pairs whose operand reads are issued together ahead of their MFMAs (64x64 tiles)
+#endif
   auto multiply = [&](auto C_) {
     constexpr int cur = decltype(C_)::value;
+    // GRP k-pairs at a time: all their operand reads, then their MFMAs.  (Written as "read a pair, multiply it" the
+    // compiler reuses the same registers for every pair and waits lgkmcnt(0) before every two MFMAs of a 64x64 tile: an LDS
+    // round trip of ~100 clocks exposed per 128 clocks of MFMA time.  The 128x128 tiles have eight MFMAs per pair and keep
+    // the plain order: the extra operand registers cost them more than the exposed round trip.)
+    constexpr int GRP = TILES == 1 ? PK2_GEMM_HOIST : 1;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TILES], b[TILES];
+    for (int k0 = 0; k0 < BK / 2; k0 += GRP) {
+      float a[GRP][TILES], b[GRP][TILES];
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) a[i] = As[cur][(kk + kq) * LDA + wm + i * 32 + li];
+      for (int g = 0; g < GRP; ++g) {
 #pragma unroll
-      for (int j = 0; j < TILES; ++j) b[j] = Bs[cur][(kk + kq) * LDB + wn + j * 32 + li];
+        for (int i = 0; i < TILES; ++i) a[g][i] = As[cur][(2 * (k0 + g) + kq) * LDA + wm + i * 32 + li];
 #pragma unroll
-      for (int i = 0; i < TILES; ++i)
+        for (int j = 0; j < TILES; ++j) b[g][j] = Bs[cur][(2 * (k0 + g) + kq) * LDB + wn + j * 32 + li];
+      }
+      if (GRP > 1) __builtin_amdgcn_sched_barrier(0);      // (the scheduler moves the reads back down to their MFMAs otherwise)
 #pragma unroll
-        for (int j = 0; j < TILES; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int i = 0; i < TILES; ++i)
+#pragma unroll
+          for (int j = 0; j < TILES; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][i], b[g][j], acc[i][j], 0, 0, 0);
     }
   };
   // the pipelined loop over `n` slabs; slab i travels in register stage i % DEPTH
