@@ -28,6 +28,12 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
 # hipcc defaults to -ffp-contract=fast, which fuses a*b+c across statements and ignores `#pragma clang fp
 # contract(off)`; the decoder's costs must round like the oracle's separate float32 operations.
 FILE_FLAGS = {"lattice_decode.hip": ["-ffp-contract=off"], "lattice_decode_frames.hip": ["-ffp-contract=off"]}
+# experiment builds: PK2_FILE_FLAGS="gemm_f32.hip:-mllvm,-align-loops=64;..." adds flags to single sources
+for _spec in os.environ.get("PK2_FILE_FLAGS", "").split(";"):
+    if ":" in _spec:
+        _f, _fl = _spec.split(":", 1)
+        FILE_FLAGS.setdefault(_f, [])
+        FILE_FLAGS[_f] = FILE_FLAGS[_f] + _fl.split(",")
 
 
 def _hipcc():

@@ -91,7 +91,7 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
 }
 
 template <bool TA, bool TB, int TILES>
-__global__ void __launch_bounds__(kGemmThreads) gemm_f32_kernel(int M, int N, int K, float alpha,
+__global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_kernel(int M, int N, int K, float alpha,
                                                                 const float* __restrict__ A, int64_t lda,
                                                                 const float* __restrict__ B, int64_t ldb,
                                                                 float beta, float* __restrict__ C, int64_t ldc,
