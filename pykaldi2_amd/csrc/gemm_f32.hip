@@ -167,7 +167,12 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // (A stream-K hybrid -- whole tiles in multiples of the CU count, the k-slabs of the rest dealt evenly to further
   // workgroups that add their pieces with atomics -- was built and measured in round 2: once the 64x64-tile kernel kept six
   // slabs in flight behind LDS-only barriers, the row bands / split-K below were faster on every shape of the models, e.g.
-  // 2356 x 4096 x 1024: 194 us against 244; removed.)
+  // 2356 x 4096 x 1024: 194 us against 244; removed.  Round 4, after the edge tiles had stopped hiding everything else
+  // (gemm_tile.h): a deterministic stream-K -- whole tiles in multiples of the CU count, the k-slabs of the remaining tiles
+  // dealt evenly, partial tiles through a write-through workspace, the last contributor of a tile adds the parts in part
+  // order -- was parity-green and slower again wherever it applied: 2356 x 512 x 512 25.6 -> 31.1 us, 2356 x 2048 x 512
+  // 62.7 -> 74.8, 2356 x 4096 x 1024 203 -> 218 (a second pipeline prologue per workgroup and the partial-tile traffic cost
+  // more than the idle tail they remove); not kept.)
   int tiles = force ? atoi(force) : ((big_tiles >= 512 && K >= 256) ? 2 : 1);      // (shallow products: 64x64 tiles, 27 vs 33 us at K = 80)
   // Deep-K products with few output tiles (the weight gradients: K = frames): 128x128 tiles over K slices.
   bt.ksplit = 1;

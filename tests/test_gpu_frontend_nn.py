@@ -89,7 +89,12 @@ def test_pad_roll_subsample_matches_reference_golden(golden):
                                          # few tiles and a short K (the TransformerAM's products), all four operand layouts, ragged
                                          # M / N edges, a K that is no multiple of 16
                                          (0, 1, 2276, 512, 512), (0, 0, 2276, 512, 1536), (1, 0, 500, 130, 772), (1, 1, 70, 190, 260),
-                                         (0, 1, 65, 64, 1028), (0, 0, 129, 67, 256)])
+                                         (0, 1, 65, 64, 1028), (0, 0, 129, 67, 256),
+                                         # tile counts just above a multiple of the CU count, ragged edges in both dimensions (edge
+                                         # tiles clamp their rows), row counts that are no multiple of four in the contiguous dimension
+                                         # (those edge tiles keep the bounds-tested loader)
+                                         (0, 1, 576, 1856, 144), (0, 0, 1024, 1028, 256), (0, 1, 2354, 512, 512), (1, 0, 2500, 4096, 250),
+                                         (0, 0, 1100, 642, 384), (1, 1, 901, 700, 200), (1, 0, 2502, 1030, 300)])
 def test_gemm_f32_matches_float64(ta, tb, M, N, K):
     rng = np.random.default_rng(M + N)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
@@ -100,8 +105,16 @@ def test_gemm_f32_matches_float64(ta, tb, M, N, K):
     a, b, c, bs = (torch.from_numpy(v).cuda() for v in (A, B, C0.copy(), bias))
     lstm._gemm(ta, tb, M, N, K, lstm._p(a), A.shape[1], lstm._p(b), B.shape[1], lstm._p(c), N, bias=lstm._p(bs),
                alpha=0.5, beta=2.0)
-    err = np.abs(c.cpu().numpy() - want).max()
+    got = c.cpu().numpy()
+    err = np.abs(got - want).max()
     assert err < 2e-4 * np.sqrt(K), err
+    # the same call again gives the same bits (partial tiles are added in part order, whoever arrives last)
+    c2 = torch.from_numpy(C0.copy()).cuda()
+    lstm._gemm(ta, tb, M, N, K, lstm._p(a), A.shape[1], lstm._p(b), B.shape[1], lstm._p(c2), N, bias=lstm._p(bs),
+               alpha=0.5, beta=2.0)
+    big_tiles = -(-M // 128) * -(-N // 128)
+    if not (K >= 2048 and (big_tiles <= 256 or (ta == 1 and tb == 0 and big_tiles < 512))):   # (the deep-K split adds its slices with float atomics)
+        assert np.array_equal(c2.cpu().numpy(), got)
 
 
 def _load_golden_model(g, tag):
