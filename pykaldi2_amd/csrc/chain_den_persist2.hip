@@ -451,16 +451,24 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const size_t f0 = (size_t)g * (d.Tmax + 1);
   cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
   cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
-  float xr[PSPT], xlr[PSPT];
+  // x of the own rows (xr) and of the own states' self-loops (xlr) for the NEXT frame are loaded as soon as the frame has
+  // staged its xr (round 4) -- into xr itself and into a second set xln, which becomes xlr at the end of the frame.  They
+  // used to be issued at the very end of a frame: vmcnt counts in order, so the polling wave's first poll came back behind
+  // its own loads out of HBM -- every rank, even the last to arrive with all 32 words long valid, spent 1.04 us from the top
+  // of a frame to "words valid" against 0.2 us of an L2 round trip (timeline of all ranks, -DPK2_DP_PROFILE; a timing-only
+  // build whose wave 0 skipped its end-of-frame memory work ran the call 6.8 % faster).
+  float xr[PSPT], xlr[PSPT], xln[PSPT];
   auto prefetch = [&](int t) {
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
       xr[i] = r < nrows ? xv_g[(size_t)t * V + row0 + r] : 0.f;
-      xlr[i] = st_ok[i] ? xl_g[(size_t)t * S + g0 + r] : 0.f;
+      xln[i] = st_ok[i] ? xl_g[(size_t)t * S + g0 + r] : 0.f;
     }
   };
   prefetch(0);
+#pragma unroll
+  for (int i = 0; i < PSPT; ++i) xlr[i] = xln[i];
   if constexpr (STREAM) {
     if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
   }
@@ -495,6 +503,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
         const int r = tid + i * kPT;
         if (r < nrows) L.xown[r] = xr[i];
       }
+      if (publish) prefetch(t + 1);
     });
     DP_TL(0, 4);
     __syncthreads();
@@ -540,7 +549,8 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
         if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
       }
     }
-    if (publish) prefetch(t + 1);
+#pragma unroll
+    for (int i = 0; i < PSPT; ++i) xlr[i] = xln[i];
     DP_T(7);
   }
   DP_FLUSH(0);
@@ -602,7 +612,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const size_t f0 = (size_t)g * (d.Tmax + 1);
   cgfloat* xv_g = G(p.xv) + (size_t)g * d.Tmax * V;
   cgfloat* xl_g = G(d.xl) + (size_t)g * d.Tmax * S;
-  float xl_cur[PSPT], xl_prev[PSPT], xw[PSPT], bh[PSPT];
+  float xl_cur[PSPT], xl_prev[PSPT], xl_next[PSPT], xw[PSPT], bh[PSPT];
   const float cst_last = 1.0f / d.pi_sum + d.leaky;
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) { bh[i] = cst_last; xl_cur[i] = 0.f; }
@@ -610,7 +620,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
-      xl_prev[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
+      xl_next[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
       xw[i] = r < nvirt ? xv_g[(size_t)t * V + vfirst + r] : 0.f;
     }
   };
@@ -643,13 +653,18 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     }
   };
   // w[T] = x[T-1, .] * (1 / sum(pi) + leaky)
+  // (the loads of frame t - 2 are issued from inside frame t - 1, behind its staging, not at the end of frame t: run_fwd2)
   prefetch(T - 1);
+#pragma unroll
+  for (int i = 0; i < PSPT; ++i) xl_prev[i] = xl_next[i];
   stage_x();
   __syncthreads();
   emit(T);
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) xl_cur[i] = xl_prev[i];
   if (T >= 2) prefetch(T - 2);
+#pragma unroll
+  for (int i = 0; i < PSPT; ++i) xl_prev[i] = xl_next[i];
   if constexpr (STREAM) {
     if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
   }
@@ -667,7 +682,10 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     // the words this rank will publish two frames from now must read "not yet written" by then: reset here, before the
     // copies, long before the stores they have to precede (the waits of emit cover it)
     if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
-    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, st, L, dp_, [&]() { if (publish) stage_x(); });
+    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, st, L, dp_, [&]() {
+      if (publish) stage_x();
+      if (t >= 2) prefetch(t - 2);          // (xw is free again; xl_next becomes xl_prev at the end of the frame)
+    });
     DP_TL(1, 4);
     __syncthreads();
     // rows are source states: btilde'[t, s] = row + peeled loop, then beta-hat[t, s] with the sums received above
@@ -694,8 +712,8 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int i = 0; i < PSPT; ++i) {
       if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
       xl_cur[i] = xl_prev[i];
+      xl_prev[i] = xl_next[i];
     }
-    if (t >= 2) prefetch(t - 2);
     DP_T(7);
   }
   DP_FLUSH(1);
