@@ -60,8 +60,8 @@ def _bgemm(ta, tb, M, N, K, alpha, A, lda, sA0, sA1, B, ldb, sB0, sB1, beta, C, 
                                                beta, C, ldc, sC0, sC1, n0, n1, _lib.stream_ptr()))
 
 
-def _colsum(A, lda, M, N, out):
-    _lib.check(_lib.lib().pk2_colsum_f32(A, lda, M, N, 0.0, out, _lib.stream_ptr()))
+def _colsum(A, lda, M, N, out, beta=0.0):
+    _lib.check(_lib.lib().pk2_colsum_f32(A, lda, M, N, beta, out, _lib.stream_ptr()))
 
 
 def _dropout(x, p, seed, out=None):
@@ -192,16 +192,19 @@ class _TransformerFunction(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         g = m._grad_views()
         hL, hn, muf, rsf = ctx.final
+        # ONE fill of the flat gradient buffer, then every parameter gradient is ADDED to it (beta = 1): a product whose K
+        # = frames is cut into slices needs no launch that prepares C, a column sum none that clears its output, the
+        # LayerNorm gradients none of their own (round 3 counted 62 + 70 + 62 such launches of ~5 us per step)
+        m.flat_parameters()[1].zero_()
 
         def lin_grads(dout, inp, in_dim, out_dim, wname, bname):
-            _gemm(1, 0, out_dim, in_dim, R, _p(dout), out_dim, _p(inp), in_dim, _p(g[wname]), in_dim)
-            _colsum(_p(dout), out_dim, R, out_dim, _p(g[bname]))
+            _gemm(1, 0, out_dim, in_dim, R, _p(dout), out_dim, _p(inp), in_dim, _p(g[wname]), in_dim, beta=1.0)
+            _colsum(_p(dout), out_dim, R, out_dim, _p(g[bname]), beta=1.0)
 
         lin_grads(dlogits, hn, C, P, "output_layer.weight", "output_layer.bias")
         dhn = new(R, C)
         _gemm(0, 0, R, C, P, _p(dlogits), P, _p(m.output_layer.weight), C, _p(dhn), C)
         nf = m.transformer.norm
-        g["transformer.norm.weight"].zero_(); g["transformer.norm.bias"].zero_()
         dh = new(R, C)
         _lib.check(L.pk2_layernorm_bwd(_p(dhn), _p(hL), _p(muf), _p(rsf), _p(nf.weight), R, C, _p(dh),
                                        _p(g["transformer.norm.weight"]), _p(g["transformer.norm.bias"]), sp))
@@ -214,22 +217,18 @@ class _TransformerFunction(torch.autograd.Function):
             # ReLU + Conv1d
             _lib.check(L.pk2_relu_bwd(_p(s["y"]), _p(dh), dh.numel(), sp))     # dh := dc
             dc = dh
-            _colsum(_p(dc), C, R, C, _p(g[pre + "conv1d.bias"]))
-            dWp = new(3, C, C)
-            _gemm(1, 0, C, C, R, _p(dc), C, _p(s["x2"]), C, _p(dWp, C * C), C)
+            _colsum(_p(dc), C, R, C, _p(g[pre + "conv1d.bias"]), beta=1.0)
+            dWp = torch.zeros(3, C, C, device=dev, dtype=torch.float32)
+            _gemm(1, 0, C, C, R, _p(dc), C, _p(s["x2"]), C, _p(dWp, C * C), C, beta=1.0)
             dx2 = new(R, C)
             _gemm(0, 0, R, C, C, _p(dc), C, _p(s["Wp"], C * C), C, _p(dx2), C)
             if T > 1:
-                _gemm(1, 0, C, C, R - B, _p(dc, B * C), C, _p(s["x2"]), C, _p(dWp, 0), C)
-                _gemm(1, 0, C, C, R - B, _p(dc), C, _p(s["x2"], B * C), C, _p(dWp, 2 * C * C), C)
+                _gemm(1, 0, C, C, R - B, _p(dc, B * C), C, _p(s["x2"]), C, _p(dWp, 0), C, beta=1.0)
+                _gemm(1, 0, C, C, R - B, _p(dc), C, _p(s["x2"], B * C), C, _p(dWp, 2 * C * C), C, beta=1.0)
                 _gemm(0, 0, R - B, C, C, _p(dc, B * C), C, _p(s["Wp"], 0), C, _p(dx2), C, beta=1.0)
                 _gemm(0, 0, R - B, C, C, _p(dc), C, _p(s["Wp"], 2 * C * C), C, _p(dx2, B * C), C, beta=1.0)
-            else:
-                dWp[0].zero_(); dWp[2].zero_()
             g[pre + "conv1d.weight"].copy_(dWp.permute(1, 2, 0))
             # LayerNorm 2 (+ residual)
-            for n_ in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"):
-                g[pre + "encoder_layer." + n_].zero_()
             ds2 = new(R, C)
             _lib.check(L.pk2_layernorm_bwd(_p(dx2), _p(s["s2"]), _p(s["mu2"]), _p(s["rs2"]), _p(e.norm2.weight), R, C,
                                            _p(ds2), _p(g[pre + "encoder_layer.norm2.weight"]),
