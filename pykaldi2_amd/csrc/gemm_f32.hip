@@ -182,7 +182,11 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // is 64x64 tiles at half the intensity: 5768 x 1024 x 20480, the CE output layer's weight gradient, ran at 81 TFLOP/s, 92
   // over three slices, ~125 over eleven; weight-gradient form only -- 2276 x 2560 x 2048 (A W^T) lost 7 % -- PK2_GEMM_SPLIT_MID=0 restores it)
   static const bool split_mid = [] { const char* e = getenv("PK2_GEMM_SPLIT_MID"); return !(e && atoi(e) == 0); }();
-  if ((big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= 2048 && (!fsplit || atoi(fsplit) != 1)) {
+  // (how deep K has to be: 2048, but 1536 for a product of at most 16 tiles -- a 512 x 512 weight gradient over K = 1800
+  // frames ran on 64 CUs for 43 us, 30 in slices; the TransformerAM has 29 of them per step whenever the minibatch has fewer
+  // than 2048 frames.  Measured against it: 48 and 64 tiles at K = 1800 lose 8-10 us in slices, 16 tiles at K = 1000 lose 6)
+  const int deep_k = big_tiles <= 16 ? 1536 : 2048;
+  if ((big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
     int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / PK2_GEMM_MIN_KSLICE);
     if (big_tiles > 256) {
       // between one and two tiles per CU: the slice count that fills whole rounds of the 512 workgroup slots best (368 tiles:
