@@ -892,6 +892,22 @@ __global__ void __launch_bounds__(kExpThreads) den_exp_states_lds(const float* _
   }
 }
 
+// exp(logits) as it is, one row of P entries per frame (1 beyond a sequence's length): what the second persistent kernel
+// gathers its x from by pdf (round 4) -- 57 MB per call on the bench minibatch instead of the 2 x 283 MB of den_exp_states_lds'
+// copies per virtual state and per state.
+__global__ void __launch_bounds__(256) den_exp_rows(const float* __restrict__ logits, int64_t seq_stride, int64_t frame_stride,
+                                                    const int32_t* __restrict__ lengths, float* __restrict__ xp, int P, int Tmax) {
+  const int t = blockIdx.x, g = blockIdx.y;
+  const bool live = t < lengths[g];
+  const float* row = logits + (int64_t)g * seq_stride + (int64_t)t * frame_stride;
+  float* out = xp + ((size_t)g * Tmax + t) * (size_t)P;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    float xx = live ? row[p] : 0.f;
+    xx = xx < -30.f ? -30.f : (xx > 30.f ? 30.f : xx);   // keeps NaN (see den_exp_transpose)
+    out[p] = live ? expf(xx) : 1.0f;
+  }
+}
+
 template <int NG>
 __device__ __forceinline__ void den_fwd_frame_sx(const DenParams& p, int t, int chunk, float* acc, float* red, float* wcarry) {
   DEN_T0();
@@ -1440,7 +1456,15 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     // a frame's entries are cut into slices on grid.z so that short minibatches still fill the chip
     auto slices = [&](int n) { return std::max(1, std::min((n + 1023) / 1024, (4096 + Tmax * G - 1) / (Tmax * G))); };
     const size_t exp_lds = (size_t)g->P * NG * sizeof(float);
-    if (persist || (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER"))) {
+    const int form = persist ? den_persist_version(g, ge.N) : 0;
+    // (the second persistent kernel gathers x by pdf from plain exp(logits) rows, which fit the xv buffer when V >= P;
+    // PK2_DEN_XGATHER=0 keeps the expanded copies)
+    static const bool xg_env = [] { const char* e = getenv("PK2_DEN_XGATHER"); return !(e && atoi(e) == 0); }();
+    const bool xgather = xg_env && form == 2 && NG == 1 && g->P <= 32767 && g->V >= g->P;
+    if (xgather) {
+      hipLaunchKernelGGL(den_exp_rows, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride, b.lengths, b.xv,
+                         g->P, Tmax);
+    } else if (persist || (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER"))) {
       struct attr_e_t { bool f[8]; }; static PerDevice<attr_e_t> attr_e_pd(attr_e_t{}); bool (&attr_e)[8] = attr_e_pd.ref().f;
       if (!attr_e[NG]) {
         PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_exp_states_lds<NG>),
@@ -1460,8 +1484,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     bool ran = false, num_rode = false;
     int persist_form = 0;
     if (persist) {      // both recursions of every sequence in one launch (chain_den_persist.hip / chain_den_persist2.hip)
-      const int form = den_persist_version(g, ge.N);
-      rc = form == 2 ? den_persist2_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran, tail, &num_rode)
+      rc = form == 2 ? den_persist2_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran, tail, &num_rode, xgather)
                      : den_persist_launch(g, p, b.xv, lengths_host, ge.N, stream, &ran);
       if (rc) return rc;
       persist_form = ran ? form : 0;

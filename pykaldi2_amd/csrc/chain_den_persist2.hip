@@ -33,7 +33,10 @@ namespace pk2 {
 struct DenPersist2Params {
   DenParams d;
   DevPersist2 fwd, bwd;
-  const float* xv;        // [G][Tmax][V]
+  const float* xv;        // [G][Tmax][V]; with `xgather`: exp(logits) [G][Tmax][P], gathered by pdf (round 4)
+  const int32_t* vpdf;    // [V] pdf of a virtual state (-1: x = 1)
+  const int32_t* loop_pdf;// [S] pdf of a state's peeled self-loop
+  int xgather;
   float* ring;            // [8 * kMaxTeams][2][rpad]
   float* pring;           // [8 * kMaxTeams][3][kPR][kPWords]
   int rpad;               // floats per ring slot
@@ -66,6 +69,8 @@ struct Lds2 {
   float* aux;      // [cap]  backward: weight of an own virtual state in lU; forward: the finished rows (history stores)
   short* mapA;     // [cap]  compact row of a rank-local row in list 0 / list 1 (-1: the row has no slot there)
   short* mapB;     // [cap]
+  short* pdfv;     // [cap]  pdf of an own row (forward) / own virtual state (backward): x gathered from the frame's exp row
+  short* pdfl;     // [cap]  pdf of an own state's peeled self-loop
   float* red;      // [2 * kPW]
   float* tot;      // [4]
   float* wcarry;   // [kSegs * kPW] open tail of wave w in segment s
@@ -77,7 +82,8 @@ __device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap) {
   L.table = den_persist2_smem; L.accA = L.table + tfloats; L.accB = L.accA + cap; L.accS = L.accB + cap; L.xown = L.accS + cap;
   L.leak = L.xown + cap; L.aux = L.leak + cap;
   L.mapA = reinterpret_cast<short*>(L.aux + cap); L.mapB = L.mapA + cap;
-  L.red = L.aux + 2 * cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
+  L.pdfv = L.mapB + cap; L.pdfl = L.pdfv + cap;
+  L.red = L.aux + 3 * cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
   L.wcrow = reinterpret_cast<int*>(L.wcarry + kSegs * kPW); L.abort = L.wcrow + kSegs * kPW;
   return L;
 }
@@ -423,6 +429,11 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
   }
   for (int r = tid; r < nrows; r += kPT) L.leak[r] = o.row_leak[row0 + r];
+  const bool xg = p.xgather != 0;
+  if (xg) {
+    for (int r = tid; r < nrows; r += kPT) L.pdfv[r] = (short)p.vpdf[row0 + r];
+    for (int r = tid; r < ngrp; r += kPT) L.pdfl[r] = (short)p.loop_pdf[g0 + r];
+  }
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
   int st_lo[PSPT], st_hi[PSPT], st_o[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
@@ -457,8 +468,23 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   // its own loads out of HBM -- every rank, even the last to arrive with all 32 words long valid, spent 1.04 us from the top
   // of a frame to "words valid" against 0.2 us of an L2 round trip (timeline of all ranks, -DPK2_DP_PROFILE; a timing-only
   // build whose wave 0 skipped its end-of-frame memory work ran the call 6.8 % faster).
+  // (round 4: x comes from the frame's exp(logits) row of P entries, gathered by the pdfs kept in LDS -- 24 KB per frame
+  // that the 32 ranks of the team share in L2 -- instead of from copies expanded to V virtual states and S states per frame:
+  // 2 x 283 MB written by den_exp_states_lds and read back here per call on the bench graph)
+  cgfloat* xp_g = G(p.xv) + (size_t)g * d.Tmax * d.P;
   float xr[PSPT], xlr[PSPT], xln[PSPT];
   auto prefetch = [&](int t) {
+    if (xg) {
+      cgfloat* row = xp_g + (size_t)t * d.P;
+#pragma unroll
+      for (int i = 0; i < PSPT; ++i) {
+        const int r = tid + i * kPT;
+        const int pv = r < nrows ? L.pdfv[r] : -1, pl = st_ok[i] ? L.pdfl[r] : -1;
+        xr[i] = r < nrows ? (pv >= 0 ? row[pv] : 1.f) : 0.f;
+        xln[i] = st_ok[i] ? (pl >= 0 ? row[pl] : 1.f) : 0.f;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
@@ -598,6 +624,11 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   }
   // what an own virtual state contributes to the next frame's sums (virtual states are the forward layout's rows)
   for (int r = tid; r < nvirt; r += kPT) { L.leak[r] = p.fwd.row_leak[vfirst + r]; L.aux[r] = p.fwd.row_psum[vfirst + r]; }
+  const bool xg = p.xgather != 0;
+  if (xg) {
+    for (int r = tid; r < nvirt; r += kPT) L.pdfv[r] = (short)p.vpdf[vfirst + r];
+    for (int r = tid; r < nrows; r += kPT) L.pdfl[r] = (short)p.loop_pdf[row0 + r];
+  }
   if (tid < 3 * kPWords) st_agent(pring + ((tid / kPWords) * kPR + rank) * kPWords + tid % kPWords, __uint_as_float(kRingSentinel));
   if (!team_barrier(ctl, team, nbar, L.abort)) return;
   uint64_t cmask = 0;
@@ -616,7 +647,19 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const float cst_last = 1.0f / d.pi_sum + d.leaky;
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) { bh[i] = cst_last; xl_cur[i] = 0.f; }
+  cgfloat* xp_g = G(p.xv) + (size_t)g * d.Tmax * d.P;       // (x gathered from the frame's exp row: run_fwd2)
   auto prefetch = [&](int t) {
+    if (xg) {
+      cgfloat* row = xp_g + (size_t)t * d.P;
+#pragma unroll
+      for (int i = 0; i < PSPT; ++i) {
+        const int r = tid + i * kPT;
+        const int pl = st_ok[i] ? L.pdfl[r] : -1, pv = r < nvirt ? L.pdfv[r] : -1;
+        xl_next[i] = st_ok[i] ? (pl >= 0 ? row[pl] : 1.f) : 0.f;
+        xw[i] = r < nvirt ? (pv >= 0 ? row[pv] : 1.f) : 0.f;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
       const int r = tid + i * kPT;
@@ -853,7 +896,7 @@ int den_persist_version(const pk2_den_graph* g, int N) {
 }
 
 int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, const int32_t* lengths_host, int N,
-                        hipStream_t stream, bool* ran, const NumDeferred* tail, bool* num_ran) {
+                        hipStream_t stream, bool* ran, const NumDeferred* tail, bool* num_ran, bool xgather) {
   *ran = false;
   if (num_ran) *num_ran = false;
   DenPersist2Scratch& sc = g_den2_scratch[dev_stream(stream)];
@@ -873,6 +916,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   p.d = dp;
   p.fwd = g->p2fwd; p.bwd = g->p2bwd;
   p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
+  p.vpdf = g->d_vpdf; p.loop_pdf = g->d_loop_pdf; p.xgather = xgather ? 1 : 0;
   p.rpad = rpad; p.tfloats = den2_tfloats(g); p.cap = g->p2_cap;
   p.pspt = g->p2_cap <= 2 * kPT ? 2 : (g->p2_cap <= 3 * kPT ? 3 : kPSPT);
   p.fwd_stream = (!g->h_p2fwd.sends.empty() || g->h_p2fwd.K > 2) ? 1 : 0;

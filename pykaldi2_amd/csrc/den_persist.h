@@ -27,7 +27,7 @@ void den_persist_check_launch(float* den_lp, int N, hipStream_t stream);
 // LDS of a workgroup: the table, seven row arrays of `cap` floats (sums of pass A, of pass B, of the streamed segments, x
 // of own rows, two per-row constants, and the two 16-bit compact-row maps), and the small fixed part (reduction scratch,
 // the segments' wave carries and their rows, flags).
-constexpr int kP2RowArrays = 7;
+constexpr int kP2RowArrays = 8;      // (the eighth: the pdfs of own rows and own states as shorts, round 4)
 constexpr int kP2FixedFloats = 2 * kPW + 4 + 2 * kSegs * kPW + 16;
 inline size_t den_persist2_lds_bytes(int tfloats, int cap) { return ((size_t)tfloats + kP2RowArrays * (size_t)cap + kP2FixedFloats) * sizeof(float); }
 bool den_persist2_fits(const pk2_den_graph* g);
@@ -35,7 +35,8 @@ bool den_persist2_fits(const pk2_den_graph* g);
 // (as tasks behind the recursions) and must not be launched again.
 struct NumDeferred;
 int den_persist2_launch(pk2_den_graph* g, const DenParams& p, const float* xv, const int32_t* lengths_host, int N,
-                        hipStream_t stream, bool* ran, const NumDeferred* tail = nullptr, bool* num_ran = nullptr);
+                        hipStream_t stream, bool* ran, const NumDeferred* tail = nullptr, bool* num_ran = nullptr,
+                        bool xgather = false);      // xgather: `xv` is exp(logits) [G][Tmax][P], gathered by pdf
 void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream);
 // Which recursion kernel a call of N sequences takes: 0 = the launch-per-frame kernels, 1 = den_persist_kernel (everything
 // resident: graphs up to ~1.05 M arc slots and ~36 k states), 2 = den_persist2_kernel.  PK2_DEN_PERSIST = 0 | 1 | 2 forces one
