@@ -569,7 +569,9 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
       if (!st_ok[i]) continue;
-      alpha_n[g0 + tid + i * kPT] = outv[i];
+      // (the occupancy pass reads alpha per OCCUPANCY state only; the per-state copy has no reader behind this kernel
+      // -- 225 MB of stores per call on the bench graph until round 4 -- unless the two arrays are one: Vo == S)
+      if (!sep) alpha_n[g0 + tid + i * kPT] = outv[i];
       if (sep) {
         for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = L.aux[q];
         if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
