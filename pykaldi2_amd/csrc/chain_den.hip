@@ -1460,7 +1460,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     // (the second persistent kernel gathers x by pdf from plain exp(logits) rows, which fit the xv buffer when V >= P;
     // PK2_DEN_XGATHER=0 keeps the expanded copies)
     static const bool xg_env = [] { const char* e = getenv("PK2_DEN_XGATHER"); return !(e && atoi(e) == 0); }();
-    const bool xgather = xg_env && form == 2 && NG == 1 && g->P <= 32767 && g->V >= g->P;
+    const bool xgather = xg_env && form == 2 && NG == 1 && g->P <= 32767 && g->V >= g->P && g->p2_rowarrays == kP2RowArrays;
     if (xgather) {
       hipLaunchKernelGGL(den_exp_rows, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride, b.lengths, b.xv,
                          g->P, Tmax);

@@ -37,6 +37,7 @@ struct DenPersist2Params {
   const int32_t* vpdf;    // [V] pdf of a virtual state (-1: x = 1)
   const int32_t* loop_pdf;// [S] pdf of a state's peeled self-loop
   int xgather;
+  int rowarrays;          // LDS arrays of `cap` floats (den_persist.h)
   float* ring;            // [8 * kMaxTeams][2][rpad]
   float* pring;           // [8 * kMaxTeams][3][kPR][kPWords]
   int rpad;               // floats per ring slot
@@ -77,13 +78,13 @@ struct Lds2 {
   int* wcrow;      // [kSegs * kPW] the rank-local row it belongs to (-1: none)
   int* abort;      // + rank, team, xcd, task
 };
-__device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap) {
+__device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap, int arrays) {
   Lds2 L;
   L.table = den_persist2_smem; L.accA = L.table + tfloats; L.accB = L.accA + cap; L.accS = L.accB + cap; L.xown = L.accS + cap;
   L.leak = L.xown + cap; L.aux = L.leak + cap;
   L.mapA = reinterpret_cast<short*>(L.aux + cap); L.mapB = L.mapA + cap;
   L.pdfv = L.mapB + cap; L.pdfl = L.pdfv + cap;
-  L.red = L.aux + 3 * cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;
+  L.red = L.aux + (arrays - 5) * cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;      // (without the pdfs: 7 arrays)
   L.wcrow = reinterpret_cast<int*>(L.wcarry + kSegs * kPW); L.abort = L.wcrow + kSegs * kPW;
   return L;
 }
@@ -410,7 +411,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   CParams2& p = *pp;
   CDenParams& d = p.d;
   CDev2& o = p.fwd;
-  const Lds2 L = carve_lds2(p.tfloats, p.cap);
+  const Lds2 L = carve_lds2(p.tfloats, p.cap, p.rowarrays);
   gfloat* ring = G(ring_); gfloat* pring = G(pring_);
   const int tid = threadIdx.x;
   const int S = d.S, V = d.V, Vo = d.Vo;
@@ -595,7 +596,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   CParams2& p = *pp;
   CDenParams& d = p.d;
   CDev2& o = p.bwd;
-  const Lds2 L = carve_lds2(p.tfloats, p.cap);
+  const Lds2 L = carve_lds2(p.tfloats, p.cap, p.rowarrays);
   gfloat* ring = G(ring_); gfloat* pring = G(pring_);
   const int tid = threadIdx.x;
   const int S = d.S, V = d.V;
@@ -767,7 +768,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
 __global__ void __launch_bounds__(kPT) den_persist2_kernel(const DenPersist2Params* __restrict__ pp_, DenPersistCtl* ctl) {
   CParams2* pp = (CParams2*)pp_;
   CParams2& p = *pp;
-  const Lds2 L = carve_lds2(p.tfloats, p.cap);
+  const Lds2 L = carve_lds2(p.tfloats, p.cap, p.rowarrays);
   int& s_abort = L.abort[0];
   int& s_rank = L.abort[1]; int& s_team = L.abort[2]; int& s_xcd = L.abort[3]; int& s_task = L.abort[4];
   const int tid = threadIdx.x;
@@ -858,7 +859,7 @@ static int den2_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 25
 static int den2_tfloats(const pk2_den_graph* g) { return std::max(g->h_p2fwd.tfloats, g->h_p2bwd.tfloats); }
 
 bool den_persist2_fits(const pk2_den_graph* g) {
-  return g->h_p2fwd.ok && g->h_p2bwd.ok && g->p2_cap > 0 && den_persist2_lds_bytes(den2_tfloats(g), g->p2_cap) <= kDenPersistMaxLds;
+  return g->h_p2fwd.ok && g->h_p2bwd.ok && g->p2_cap > 0 && den_persist2_lds_bytes(den2_tfloats(g), g->p2_cap, g->p2_rowarrays) <= kDenPersistMaxLds;
 }
 
 static bool den_is_8x32() {
@@ -918,7 +919,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
   p.d = dp;
   p.fwd = g->p2fwd; p.bwd = g->p2bwd;
   p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
-  p.vpdf = g->d_vpdf; p.loop_pdf = g->d_loop_pdf; p.xgather = xgather ? 1 : 0;
+  p.vpdf = g->d_vpdf; p.loop_pdf = g->d_loop_pdf; p.xgather = xgather ? 1 : 0; p.rowarrays = g->p2_rowarrays;
   p.rpad = rpad; p.tfloats = den2_tfloats(g); p.cap = g->p2_cap;
   p.pspt = g->p2_cap <= 2 * kPT ? 2 : (g->p2_cap <= 3 * kPT ? 3 : kPSPT);
   p.fwd_stream = (!g->h_p2fwd.sends.empty() || g->h_p2fwd.K > 2) ? 1 : 0;
@@ -942,7 +943,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
     p.np = tail->p;
     for (int n = 0; n < N; ++n) { p.task_seq[p.ntasks] = (short)n; p.task_dir[p.ntasks] = 2; ++p.ntasks; }
   }
-  const size_t lds = den_persist2_lds_bytes(p.tfloats, p.cap);
+  const size_t lds = den_persist2_lds_bytes(p.tfloats, p.cap, p.rowarrays);
   static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&den_persist2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -753,7 +753,24 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
   }
   if (!assigned) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); return; }
   const int cap = (std::max({f.max_rows, f.max_groups, b.max_rows, b.max_groups, 1}) + 3) / 4 * 4;
-  int64_t tcap = ((int64_t)kDenPersistMaxLds / 4 - kP2RowArrays * (int64_t)cap - kP2FixedFloats) / 512 * 512;
+  // The eighth row array (pdfs: the kernel then gathers x from plain exp(logits) rows) takes `cap` floats from the table: kept
+  // unless it costs either direction a table chunk (S = 55 k at 1.0 M arcs: 16.5 -> 22.8 us per frame with it).
+  auto tcap_for = [&](int arrays) { return ((int64_t)kDenPersistMaxLds / 4 - arrays * (int64_t)cap - kP2FixedFloats) / 512 * 512; };
+  g->p2_rowarrays = kP2RowArrays;
+  if (tcap_for(kP2RowArrays) >= 512) {
+    for (int which = 0; which < 2; ++which) {
+      HostPersist2 with = which == 0 ? f : b, without = with;
+      const int rows = which == 0 ? V : S, R = which == 0 ? S : V;
+      const int32_t* idx = which == 0 ? src2 : arc_v;
+      const bool ok8 = persist2_chunks(A2, idx, R, rows, (int)tcap_for(kP2RowArrays), &with);
+      const bool ok7 = persist2_chunks(A2, idx, R, rows, (int)tcap_for(kP2RowArrays - 1), &without);
+      if (ok7 && (!ok8 || without.K < with.K)) g->p2_rowarrays = kP2RowArrays - 1;
+    }
+  } else {
+    g->p2_rowarrays = kP2RowArrays - 1;
+  }
+  if (const char* env = getenv("PK2_DP2_ROWARRAYS")) g->p2_rowarrays = atoi(env) == 7 ? 7 : 8;
+  int64_t tcap = tcap_for(g->p2_rowarrays);
   if (const char* env = getenv("PK2_DP2_TCAP")) tcap = std::min<int64_t>(tcap, std::max(512, atoi(env) / 512 * 512));
   if (tcap < 512) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); return; }
   int res = kQ;

@@ -196,6 +196,7 @@ struct pk2_den_graph {
   pk2::HostPersist2 h_p2fwd, h_p2bwd;     // ... and for its second form (chain_den_persist2.hip: chunked table, streamed overflow)
   pk2::DevPersist2 p2fwd, p2bwd;
   int p2_cap = 0;                         // LDS row buffers of that kernel (rows / groups / own virtual states of a rank)
+  int p2_rowarrays = 8;                   // LDS arrays of p2_cap floats: 8 with the pdfs the x gather needs, 7 without them
   const int32_t* d_voff = nullptr;
   const int32_t* d_vpdf = nullptr;
   const int32_t* d_loop_pdf = nullptr;

@@ -27,9 +27,12 @@ void den_persist_check_launch(float* den_lp, int N, hipStream_t stream);
 // LDS of a workgroup: the table, seven row arrays of `cap` floats (sums of pass A, of pass B, of the streamed segments, x
 // of own rows, two per-row constants, and the two 16-bit compact-row maps), and the small fixed part (reduction scratch,
 // the segments' wave carries and their rows, flags).
-constexpr int kP2RowArrays = 8;      // (the eighth: the pdfs of own rows and own states as shorts, round 4)
+constexpr int kP2RowArrays = 8;      // (the eighth: the pdfs of own rows and own states as shorts, round 4 -- left out, with
+                                     // the x gather, for a graph it would cost a table chunk: pk2_den_graph::p2_rowarrays)
 constexpr int kP2FixedFloats = 2 * kPW + 4 + 2 * kSegs * kPW + 16;
-inline size_t den_persist2_lds_bytes(int tfloats, int cap) { return ((size_t)tfloats + kP2RowArrays * (size_t)cap + kP2FixedFloats) * sizeof(float); }
+inline size_t den_persist2_lds_bytes(int tfloats, int cap, int arrays = kP2RowArrays) {
+  return ((size_t)tfloats + arrays * (size_t)cap + kP2FixedFloats) * sizeof(float);
+}
 bool den_persist2_fits(const pk2_den_graph* g);
 // `tail`: the minibatch's deferred numerator forward-backward (may be null); *num_ran = true when it rode in this launch
 // (as tasks behind the recursions) and must not be launched again.
