@@ -642,7 +642,7 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
     cst[n] = ((t + 1) == T) ? (1.0f / p.pi_sum + p.leaky) : 0.f;
   }
   const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.Vo * NG;       // per occupancy state
-  const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (p.brec * NG);   // {btilde'[NG], xd[NG]} per virtual state (brec = 2)
   float* gam_t = p.gamma + ((size_t)g * p.Tmax + t) * (size_t)p.P * NG;
   for (int pdf = tid; pdf < p.P; pdf += 256) {
     float v[NG];
@@ -652,7 +652,7 @@ __device__ __forceinline__ void den_gamma_states_body(const DenParams& p, const 
       const int s = p.ps_state[k];
       float a[NG], b[NG];
       ldv<NG>(alpha_n + (size_t)s * NG, a);
-      ldv<NG>(beta_n + (size_t)p.ovirt[s] * (2 * NG), b);
+      ldv<NG>(beta_n + (size_t)p.ovirt[s] * (p.brec * NG), b);
 #pragma unroll
       for (int n = 0; n < NG; ++n) v[n] += a[n] * (gat[n] ? b[n] * inv_c[n] + lkr[n] : cst[n]);
     }
@@ -699,7 +699,7 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
 
   __syncthreads();
   const float* alpha_n = p.alphav + (frame + 1) * (size_t)p.Vo * NG;      // per occupancy state
-  const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (2 * NG);   // {btilde'[NG], xd[NG]} per virtual state
+  const float* beta_n = p.beta + (frame + 1) * (size_t)p.V * (p.brec * NG);   // {btilde'[NG], xd[NG]} per virtual state (brec = 2)
   for (int s0 = tid; s0 < p.Vo; s0 += 4 * kGammaThreads) {
     float a[4][NG], b[4][NG]; int pdf[4], vi[4];
 #pragma unroll
@@ -714,7 +714,7 @@ __device__ __forceinline__ void den_gamma_states_lds_body(const DenParams& p, co
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (pdf[q] >= 0) ldv<NG>(beta_n + (size_t)vi[q] * (2 * NG), b[q]);
+      if (pdf[q] >= 0) ldv<NG>(beta_n + (size_t)vi[q] * (p.brec * NG), b[q]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (pdf[q] < 0) continue;
@@ -1427,6 +1427,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   p.ps_off = g->d_po_off; p.ps_state = g->d_po_occ;
   p.voff = g->d_voff; p.ooff = g->d_ooff; p.opdf = g->d_opdf; p.ovirt = g->d_ovirt; p.loop_prob = g->d_loop_prob;
   p.alphav = b.alphav; p.xl = b.xl; p.V = sx ? g->V : g->S; p.Vo = sx ? g->Vo : g->S;
+  p.brec = 2;
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
   p.leaky = leaky; p.pi_sum = (float)g->pi_sum; p.wu = (float)(kBetaFloor * g->pi_sum / g->S);
   p.debug = getenv("PK2_DEN_DEBUG") ? atoi(getenv("PK2_DEN_DEBUG")) : 0;
@@ -1459,8 +1460,10 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     const int form = persist ? den_persist_version(g, ge.N) : 0;
     // (the second persistent kernel gathers x by pdf from plain exp(logits) rows, which fit the xv buffer when V >= P;
     // PK2_DEN_XGATHER=0 keeps the expanded copies)
-    static const bool xg_env = [] { const char* e = getenv("PK2_DEN_XGATHER"); return !(e && atoi(e) == 0); }();
+    const char* xg_e = getenv("PK2_DEN_XGATHER");      // (read per call: the tests switch it inside one process)
+    const bool xg_env = !(xg_e && atoi(xg_e) == 0);
     const bool xgather = xg_env && form == 2 && NG == 1 && g->P <= 32767 && g->V >= g->P && g->p2_rowarrays == kP2RowArrays;
+    if (form == 2 && NG == 1) p.brec = 1;       // (dense btilde' records: den_kernels.h; the frame kernels' copy of p keeps 2)
     if (xgather) {
       hipLaunchKernelGGL(den_exp_rows, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride, b.lengths, b.xv,
                          g->P, Tmax);

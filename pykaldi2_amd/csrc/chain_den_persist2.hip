@@ -753,10 +753,10 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     if (publish) emit(t);
     DP_T(6);
     DP_TL(1, 6);
-    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * 2;
+    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * d.brec;
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
-      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * 2] = vs[i];
+      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * d.brec] = vs[i];
       xl_cur[i] = xl_prev[i];
       xl_prev[i] = xl_next[i];
     }

@@ -49,6 +49,8 @@ struct DenParams {
   int S, P, Tmax;
   float leaky, pi_sum;
   float wu;    // kBetaFloor * sum(pi)/S: uniform floor of the backward normaliser's weights (state-x path)
+  int brec;    // floats per beta record and sequence: 2 = {btilde', x} (frame kernels, first persistent kernel), 1 = btilde' alone
+               // (second persistent kernel, round 4: nobody reads the x halves there; the occupancy pass gathers half the lines)
   int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop, 4 = load half of the arc records
 };
 

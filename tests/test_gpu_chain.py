@@ -26,7 +26,8 @@ _KIND = dict(chain_topology=dict(loop_pdf_differs=True), multi_entry=dict(loop_p
                                   "chain_topology_general", "state_x_frames", "chain_topology_frames", "multi_entry_frames",
                                   "chain_topology_persist1", "multi_entry_persist1", "chain_topology_p2stream",
                                   "multi_entry_p2stream", "chain_topology_p2chunks", "multi_entry_p2chunkstream",
-                                  "chain_topology_p2shared", "multi_entry_p2sharedstream"])
+                                  "chain_topology_p2shared", "multi_entry_p2sharedstream",
+                                  "chain_topology_p2expanded", "multi_entry_p2rows7"])
 @pytest.mark.parametrize("S,A,P,lens,leaky", [
     (8, 30, 5, [6], 1e-2),
     (200, 3000, 40, [51, 17, 33], 1e-4),
@@ -55,7 +56,10 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
     # per resident pass (everything else streamed in pieces), an LDS table of 1024 entries (4 - 6 table chunks through two
     # buffers; `shared`: a vector of up to twice the table as two chunks taking turns in ONE buffer, round 4), both.  The
     # layout variables are read when the graph is created.
-    form = {"persist1": 1, "p2stream": 2, "p2chunks": 2, "p2chunkstream": 2, "p2shared": 2, "p2sharedstream": 2}.get(path.rsplit("_", 1)[-1], 0)
+    # `expanded`: x read from the copies expanded per virtual state / state instead of gathered by pdf (round 4's default);
+    # `rows7`: the LDS layout without the pdf arrays (a graph the eighth row array would cost a table chunk), which implies it.
+    form = {"persist1": 1, "p2stream": 2, "p2chunks": 2, "p2chunkstream": 2, "p2shared": 2, "p2sharedstream": 2, "p2expanded": 2,
+            "p2rows7": 2}.get(path.rsplit("_", 1)[-1], 0)
     if form:
         monkeypatch.setenv("PK2_DEN_PERSIST", str(form))
         path, variant = path.rsplit("_", 1)
@@ -64,6 +68,10 @@ def test_denominator_matches_oracle(S, A, P, lens, leaky, path, monkeypatch):
         if variant in ("p2chunks", "p2chunkstream", "p2shared", "p2sharedstream"):
             monkeypatch.setenv("PK2_DP2_TCAP", "1024")
         monkeypatch.setenv("PK2_DP2_SHARED", "1" if "shared" in variant else "0")
+        if variant == "p2expanded":
+            monkeypatch.setenv("PK2_DEN_XGATHER", "0")
+        if variant == "p2rows7":
+            monkeypatch.setenv("PK2_DP2_ROWARRAYS", "7")
     arc_pdf = path.startswith("arc_pdf")
     g, G, ref = _mk(S, A, P, seed=S, arc_pdf=arc_pdf, **_KIND.get(path.replace("_general", "").replace("_frames", ""), {}))
     if A == 20000:
