@@ -99,11 +99,7 @@ __device__ __forceinline__ void slab_pointers(const float* __restrict__ base, in
       ptr[h] = base + (int64_t)min(r0 + r, R - 1) * ld + k0 + k;
     } else {
       const int k = tid / Geo<TILES>::LPK + h * (kGemmThreads / Geo<TILES>::LPK), r = (tid % Geo<TILES>::LPK) * 4;
-#ifdef PK2_GEMM_NOCLAMP_ROWS
-      ptr[h] = base + (int64_t)(k0 + k) * ld + r0 + r;
-#else
       ptr[h] = base + (int64_t)(k0 + k) * ld + min(r0 + r, R - 4);
-#endif
     }
   }
   *step = KCONTIG ? (int64_t)BK : (int64_t)BK * ld;
