@@ -114,6 +114,30 @@ __global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_kernel(int M, int N,
                             blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1);
 }
 
+// The row bands of a plain 2-D product in ONE launch (round 4): workgroups [0, nbig) take the 128x128 tiles of rows
+// [0, m_split), the others the 64x64 tiles of rows [m_split, M).  As two launches the 64x64 tiles started when the last
+// 128x128 tile had finished and ended with a round of their own on a quarter of the CUs (2356 x 4096 x 1024: 125 + 45 us
+// + two launch / prologue / epilogue costs = 206 us); here they take the third workgroup slot of a CU from the start and the
+// slots the first of them free.
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_bands_kernel(int M, int N, int K, float alpha,
+                                                                         const float* __restrict__ A, int64_t lda,
+                                                                         const float* __restrict__ B, int64_t ldb,
+                                                                         float beta, float* __restrict__ C, int64_t ldc,
+                                                                         const float* __restrict__ bias, bool vecA,
+                                                                         bool vecB, int nbig, int big_cols, int m_split,
+                                                                         int small_cols) {
+  const int b = blockIdx.x;
+  if (b < nbig) {
+    gemm_block<TA, TB, 2>(M, N, K, 0, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, (b / big_cols) * 128,
+                          (b % big_cols) * 128, false);
+  } else {
+    const int s = b - nbig;
+    gemm_block<TA, TB, 1>(M, N, K, 0, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, m_split + (s / small_cols) * 64,
+                          (s % small_cols) * 64, false);
+  }
+}
+
 // C = beta * C + bias ahead of a split-K product (blockIdx.z = batch entry).
 __global__ void __launch_bounds__(256) gemm_prescale_kernel(int M, int N, float beta, float* __restrict__ C,
                                                             int64_t ldc, const float* __restrict__ bias, GemmBatch bt) {
@@ -249,6 +273,22 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
       if (c < best - 1e-9) { best = c; best_r = r; }
     }
     if (best_r < R) {
+      static const bool one_launch = [] { const char* e = getenv("PK2_GEMM_BANDS_ONE"); return !(e && atoi(e) == 0); }();
+      if (best_r > 0 && one_launch) {
+        const int m_split = best_r * 128, small_rows = (M - m_split + 63) / 64;
+        const int nbig = best_r * Cn;
+        dim3 grid(nbig + small_rows * Cs), block(kGemmThreads);
+#define PK2_GEMM_BANDS(TA, TB)                                                                                          \
+  hipLaunchKernelGGL((gemm_f32_bands_kernel<TA, TB>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C,   \
+                     ldc, bias, vecA, vecB, nbig, Cn, m_split, Cs)
+        if (!transa && !transb) PK2_GEMM_BANDS(false, false);
+        else if (!transa && transb) PK2_GEMM_BANDS(false, true);
+        else if (transa && !transb) PK2_GEMM_BANDS(true, false);
+        else PK2_GEMM_BANDS(true, true);
+#undef PK2_GEMM_BANDS
+        PK2_LAUNCH_CHECK();
+        return PK2_OK;
+      }
       if (best_r > 0) launch(2, 0, best_r * 128);
       launch(1, best_r * 128, M - best_r * 128);
       PK2_LAUNCH_CHECK();
