@@ -107,7 +107,7 @@ class DenominatorGraph:
         _lib.check(L.pk2_den_graph_debug_persist2(self._h, which, _lib.ptr(info), *[_lib.ptr(out[k]) for k in order]))
         out.update(estep=int(info[1]), K=int(info[2]), R=int(info[3]), tfloats=int(info[4]), max_rows=int(info[5]),
                    max_groups=int(info[6]), pieces=pieces, cap=int(info[8]), cbeg=[int(v) for v in info[10:10 + MC + 1]],
-                   lds_off=[int(v) for v in info[20:20 + MC]], SP=SP, W=W, T=T, slots=K)
+                   lds_off=[int(v) for v in info[20:20 + MC]], SP=SP, W=W, T=T, slots=K, row_arrays=int(info[19]))
         return out
 
     def debug_persist(self, which):

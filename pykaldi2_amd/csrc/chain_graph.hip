@@ -1190,8 +1190,8 @@ extern "C" int pk2_den_graph_debug_virtual(const pk2_den_graph* g, int which, in
 }
 
 // Test hook: the second persistent layout of an ordering (which: 0 forward, 1 backward).  info[32] = {ok, estep, K, R,
-// tfloats, max_rows, max_groups, pieces, cap, rows, cbeg[0..kMaxChunks] at 10.., lds_off[0..kMaxChunks-1] at 20..,
-// kPR, kPT, kPK, kPW, kSP, kSegs at 26..}; the arrays (may be null) are sized from it (chain_internal.h: HostPersist2).
+// tfloats, max_rows, max_groups, pieces, cap, rows, cbeg[0..kMaxChunks] at 10.., row arrays of the LDS layout (8: with the pdfs
+// the x gather needs, 7: without) at 19, lds_off[0..kMaxChunks-1] at 20.., kPR, kPT, kPK, kPW, kSP, kSegs at 26..}; the arrays (may be null) are sized from it (chain_internal.h: HostPersist2).
 extern "C" int pk2_den_graph_debug_persist2(const pk2_den_graph* g, int which, int32_t* info, float* prob, uint32_t* idx2,
                                             uint32_t* ends, int32_t* first_row, int32_t* uncovered, int32_t* ncomp, int16_t* rmap,
                                             int32_t* pbeg, float* sprob,
@@ -1203,6 +1203,8 @@ extern "C" int pk2_den_graph_debug_persist2(const pk2_den_graph* g, int which, i
   info[0] = h.ok ? 1 : 0; info[1] = h.estep; info[2] = h.K; info[3] = h.R; info[4] = h.tfloats; info[5] = h.max_rows;
   info[6] = h.max_groups; info[7] = (int32_t)(h.sends.size() / kPT); info[8] = g->p2_cap; info[9] = (int32_t)h.row_leak.size();
   for (int c = 0; c <= kMaxChunks; ++c) info[10 + c] = h.cbeg[c];
+  static_assert(10 + kMaxChunks < 19, "info[19] is free");
+  info[19] = g->p2_rowarrays;
   for (int c = 0; c < kMaxChunks; ++c) info[20 + c] = h.lds_off[c];
   info[26] = kPR; info[27] = kPT; info[28] = kPK; info[29] = kPW; info[30] = kSP; info[31] = kSegs;
   if (!h.ok) return PK2_OK;

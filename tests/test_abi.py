@@ -390,7 +390,7 @@ def _emulate_persist2(lay, table):
 
 
 @pytest.mark.parametrize("case", ["default", "bigstate", "overflow", "overflow_estep1", "chunks", "chunks_overflow", "res1", "res2_chunks",
-                                  "res2_shared", "shared"])
+                                  "res2_shared", "shared", "rows7"])
 def test_den_graph_persistent2_layouts(case, monkeypatch):
     """Second persistent layout (chain_den_persist2.hip): table chunks, two resident passes, streamed overflow.  The numpy
     model of the kernel's frame reproduces both recursions' row sums: back-to-back chunks (default), a row spanning several
@@ -418,6 +418,8 @@ def test_den_graph_persistent2_layouts(case, monkeypatch):
             monkeypatch.setenv("PK2_DP2_SHARED", "0")
         S, A = 1400, (150000 if case == "res2_shared" else 50000)      # (res2_shared: lists beyond 2 slots x 512 threads -> streamed pieces)
         kw["multi_entry_frac"] = 0.3
+    if case == "rows7":             # the LDS layout without the pdf arrays of the x gather (a graph they would cost a table chunk)
+        monkeypatch.setenv("PK2_DP2_ROWARRAYS", "7")
     if case.startswith("chunks"):
         S, A = 1100, 20000
         monkeypatch.setenv("PK2_DP2_TCAP", "512")
@@ -442,7 +444,8 @@ def test_den_graph_persistent2_layouts(case, monkeypatch):
     assert pf is not None and pb is not None
     assert pf["R"] == S_ and pb["R"] == V and pf["row_begin"][-1] == V and pb["row_begin"][-1] == S_
     assert (voff[pf["grp_begin"]] == pf["row_begin"]).all()                     # whole states per workgroup
-    if case in ("default", "bigstate"):
+    assert pf["row_arrays"] == (7 if case == "rows7" else 8)      # (small graphs: the eighth array never costs a chunk)
+    if case in ("default", "bigstate", "rows7"):
         assert pf["K"] == 2 and pb["K"] == 2 and pf["pieces"] == 0 and pb["pieces"] == 0
         assert pf["lds_off"][1] == pf["cbeg"][1] or pf["cbeg"][1] == pf["cbeg"][2]      # back to back
     if case.startswith("overflow"):
