@@ -417,6 +417,15 @@ int pk2_sgd_step(float* param, const float* grad, float* momentum_buf /* NULL = 
 int pk2_persist_guard_status(uint32_t* raised);
 int pk2_persist_guard_clear(void);
 int pk2_persist_guard_raise(void* stream);
+/* Several ranks (hvd.DistributedOptimizer, reference bin/train_chain.py:141-145): the guard is COLLECTIVE.  Before the
+ * gradients are exchanged every rank exports its guard word into a one-float device slot, the slots are combined over the
+ * ranks (pk2_allreduce_guarded below, or any max / sum all-reduce), and pk2_persist_guard_import raises the local guard
+ * when any rank's was raised -- so no rank's optimiser kernel applies a gradient that holds a failed rank's NaN -- and
+ * publishes the verdict of step `stamp` (1, 2, ...) in host-mapped memory.  pk2_persist_guard_verdict reads it without
+ * synchronising; every rank reads the SAME verdict for the same stamp, so all ranks stop at the same step. */
+int pk2_persist_guard_export(float* slot, void* stream);
+int pk2_persist_guard_import(const float* slot, uint32_t stamp, void* stream);
+int pk2_persist_guard_verdict(uint32_t stamp, uint32_t* ready, uint32_t* raised);
 
 /* ------------------------------------------------------------------ *
  * Lattice path: on-the-fly lattice generation + lattice forward-backward for the MMI / sMBR / MPFE
@@ -556,6 +565,9 @@ int pk2_comm_init(int32_t rank, int32_t world, const void* unique_id, pk2_comm**
  * (hipStream_t): the compute stream, or a side stream the caller fences with events.  Averaging (1/world) is folded
  * into the optimiser kernel (pk2_adam_step / pk2_sgd_step grad_scale), not done here. */
 int pk2_allreduce_bucket(pk2_comm* comm, float* buf, int64_t count, void* stream);
+/* The same plus, in the same RCCL group (one launch), the max over the ranks of the one-float guard slot
+ * (pk2_persist_guard_export / _import above). */
+int pk2_allreduce_guarded(pk2_comm* comm, float* buf, int64_t count, float* guard_slot, void* stream);
 /* rank / world of the communicator and the path of the RCCL library in use (any output may be NULL). */
 int pk2_comm_info(const pk2_comm* comm, int32_t* rank, int32_t* world, char* lib_path, int32_t lib_path_bytes);
 int pk2_comm_destroy(pk2_comm* comm);

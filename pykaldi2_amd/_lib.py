@@ -89,6 +89,7 @@ SIGNATURES = {
     "pk2_comm_unique_id": (C.c_int, [_vp]),
     "pk2_comm_init": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
     "pk2_allreduce_bucket": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "pk2_allreduce_guarded": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pk2_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32]),
     "pk2_comm_destroy": (C.c_int, [_vp]),
     "pk2_sim_apply_rir": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp, _vp]),
@@ -128,6 +129,9 @@ SIGNATURES = {
     "pk2_persist_guard_status": (C.c_int, [C.POINTER(C.c_uint32)]),
     "pk2_persist_guard_clear": (C.c_int, []),
     "pk2_persist_guard_raise": (C.c_int, [_vp]),
+    "pk2_persist_guard_export": (C.c_int, [_vp, _vp]),
+    "pk2_persist_guard_import": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "pk2_persist_guard_verdict": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "pk2_lstm_bwd_scratch_floats": (_sz, [_i32, _i32, _i32]),
     "pk2_lstm_layer_bwd_bias": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp]),
     "pk2_lstm_layer_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -172,8 +176,8 @@ def persist_guard_raised():
     return flag.value != 0
 
 
-def check_persist_guard(where):
-    if persist_guard_raised():
+def check_persist_guard(where, raised=None):
+    if persist_guard_raised() if raised is None else raised:
         raise Pk2Error("%s: a persistent kernel (one-launch LSTM recurrence / denominator / lattice decoder) timed out on "
                        "this device; its output was poisoned with NaN and the optimiser kernels have been leaving the "
                        "weights untouched since.  Typical causes: the GPU is shared with another process, or fewer than "

@@ -30,6 +30,12 @@
 
 namespace pk2 {
 
+#if PK2_DP_LOADMODE == 0
+#define PK2_DMA_SC " sc1"
+#else
+#define PK2_DMA_SC ""
+#endif
+
 struct DenPersist2Params {
   DenParams d;
   DevPersist2 fwd, bwd;
@@ -107,16 +113,27 @@ __device__ __forceinline__ void wait_vm(int n) {
 // LDS-DMA of table chunk c of the vector at `src` into its LDS buffer: 1 KB rows dealt to the waves round robin; every wave
 // issues the SAME number of instructions (a wave without a row of its own copies the last row again), which is returned: the
 // count a later s_waitcnt may leave in flight.
-__device__ __forceinline__ int dma_chunk(cgfloat* src, CDev2& o, int c, float* table) {
+// Round 5, measured and left off: the ranks of a team copy the SAME vector at the same time, starting at the same row --
+// would they be faster if rank r started `rank * rows / kPR` rows into the chunk and wrapped around, so that the 32 CUs ask
+// 32 different L2 channels at any moment (-DPK2_DP2_ROTATE=1)?  No: 7.30 us per frame against 7.22 (same job, two runs
+// each, profiles/r05_den_ab.txt).  Many CUs reading one line at about the same time is what an XCD's L2 serves best; the
+// copy rate of ~55 KB/us per CU is the CU's own limit (1 KB LDS-DMA instructions in flight x L2 latency), not a channel's.
+#ifndef PK2_DP2_ROTATE
+#define PK2_DP2_ROTATE 0
+#endif
+__device__ __forceinline__ int dma_rot(int rank, int rows) { return PK2_DP2_ROTATE ? (rank * rows) / kPR : 0; }
+__device__ __forceinline__ int dma_chunk(cgfloat* src, CDev2& o, int c, float* table, int rank) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = o.cbeg[c], e = o.cbeg[c + 1];
   const int rows = (e - b + 255) >> 8;
   const int n = (rows + kPW - 1) / kPW;
   const int e4 = (e + 3) & ~3;
+  const int rot = dma_rot(rank, rows);
   float* dst = table + o.lds_off[c];
   for (int k = 0; k < n; ++k) {
     int row = w + k * kPW;
     row = row < rows ? row : rows - 1;
+    row += rot; row = row >= rows ? row - rows : row;
     const int off = row << 8;
     if (b + off + lane * 4 < e4) dma256(src + b + off + lane * 4, dst + off);
   }
@@ -128,18 +145,69 @@ __device__ __forceinline__ int dma_chunk(cgfloat* src, CDev2& o, int c, float* t
 // -- the stream is stuck issuing until chunk 1 has all but landed.  Instead one copy instruction of chunk 1 is placed after
 // every group of 8 gathers and after every group of 8 multiply-adds of pass A (8 places: 64 rows = 64 KB per workgroup,
 // about what the pass takes to run): each finds room in the queue, and the pass and the copy finish together.
-struct Chunk1Dma {
-  cgfloat* src;      // this lane's 16 bytes of row 0 of chunk 1
-  float* dst;        // LDS address of row 0 of chunk 1
-  int rows, limit;   // rows of the chunk; floats from this lane's address to the (granule-rounded) end of the vector
-  int w;
-  __device__ __forceinline__ void operator()(int j) const {
-    if (j * kPW < rows) {                       // (wave-uniform: every wave copies ceil(rows / kPW) rows, the last one again
-      int row = w + j * kPW;                    //  if it has none of its own -- the counts stay equal across the waves)
-      row = row < rows ? row : rows - 1;
-      const int off = row << 8;
-      if (off < limit) dma256(src + off, dst + off);
+// LDS byte address of a pointer into dynamic shared memory, and plain LDS accesses through such addresses (ds_read_b32 /
+// ds_write_b32 with the address register as it stands: no base to add).
+typedef __attribute__((address_space(3))) float lfloat;
+__device__ __forceinline__ uint32_t lds_addr(const float* p) { return (uint32_t)(uintptr_t)(const lfloat*)p; }
+__device__ __forceinline__ float lds_load(uint32_t a) { return *(const lfloat*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_store(uint32_t a, float v) { *(lfloat*)(uintptr_t)a = v; }
+
+// The places of one task never change: which row a wave copies at place j, and which of its lanes lie inside the vector,
+// are formed once per task (DmaPlan, scalar registers); a frame adds its source address.
+struct DmaPlan {
+  uint64_t mask[8];  // lanes of the wave's row at place j that lie inside the vector (0: the wave has no row there)
+  uint32_t off4[8];  // byte offset of that row from the first row of chunk 1
+  uint32_t dst;      // LDS byte address of row 0 of chunk 1
+  int rows, efl, w;  // rows of the chunk; floats from its first to the (granule-rounded) end of the vector; wave
+  int rot;           // first row of this rank (dma_rot)
+  uint32_t lane16;   // lane * 16: the per-lane part of the address
+  __device__ __forceinline__ void place(int j, uint64_t* mask_out, uint32_t* off4_out) const {
+    int row = w + j * kPW;                    // (every wave copies ceil(rows / kPW) rows, the last one again if it has
+    row = row < rows ? row : rows - 1;        //  none of its own -- the counts stay equal across the waves)
+    row += rot; row = row >= rows ? row - rows : row;
+    const int off = row << 8;
+    int n = (efl - off + 3) >> 2;             // lanes (16 bytes each) inside the vector
+    n = j * kPW < rows ? n : 0;
+    n = n < 0 ? 0 : n;
+    *mask_out = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    *off4_out = (uint32_t)off * 4u;
+  }
+  __device__ __forceinline__ void init(CDev2& o, const float* table, int rank) {
+    const int b1 = o.cbeg[1], e1 = o.cbeg[2];
+    dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(table + o.lds_off[1]));
+    rows = (e1 - b1 + 255) >> 8; efl = ((e1 + 3) & ~3) - b1; w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    lane16 = (threadIdx.x & 63u) * 16u;
+    rot = dma_rot(rank, rows);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      place(j, &mask[j], &off4[j]);
+      // (opaque: scalar registers to keep, not expressions to evaluate again in every frame)
+      asm volatile("" : "+s"(mask[j]), "+s"(off4[j]));
     }
+  }
+};
+__device__ __forceinline__ void dma_issue(uint64_t mask, uint32_t m0v, uint32_t lane16, uint64_t g) {
+  asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %2, %3" PK2_DMA_SC "\n\ts_mov_b64 exec, -1"
+               : : "s"(mask), "s"(m0v), "v"(lane16), "s"(g) : "memory");      // (m0 is written too: the compiler sets it anew before each of its own uses)
+}
+struct Chunk1Dma {
+  uint64_t src;      // byte address of row 0 of chunk 1 in global memory (wave-uniform)
+  const DmaPlan* pl;
+  // Round 5: branch-free, and no VALU work.  The copy used to sit in two nested conditional blocks (wave-uniform "this wave
+  // still has a row", per-lane "inside the vector"); at the join behind every one of them the compiler waited for ALL
+  // outstanding LDS reads (s_waitcnt lgkmcnt(0): 8 times per pass A), so the gathers issued ahead for the next group of 8
+  // slots were waited for on the spot and the double buffer hid nothing; and each place cost 9 VALU instructions of address
+  // and predicate arithmetic per wave and frame.  Here the row, its LDS and global addresses and the lane mask are scalar
+  // values (the lanes inside the vector are the first n of the wave), the predicate is the exec mask around one
+  // instruction inside a single asm statement -- no control flow -- and the global address is scalar base + lane * 16.
+  // (The compiler does not know of the extra vmcnt event: its own vmcnt waits only become stricter; the frame waits with
+  // vmcnt(0) for the copy.  exec is all ones here: every thread of the workgroup runs the passes.)
+  __device__ __forceinline__ void operator()(int j) const {
+    if (j < 8) { dma_issue(pl->mask[j], pl->dst + pl->off4[j], pl->lane16, src + pl->off4[j]); return; }
+    uint64_t mask; uint32_t off4;             // (a chunk 1 of more than 64 rows: the places behind the pass)
+    pl->place(j, &mask, &off4);
+    dma_issue(mask, pl->dst + off4, pl->lane16, src + off4);
   }
 };
 struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
@@ -147,25 +215,81 @@ struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
 // Row sums of NS register slots (slots J0 .. J0+NS-1 of the thread's arrays) over the LDS table into `acc`: complete rows
 // are stored by the lane, the piece before the first row end gets the carry of the earlier lanes (segmented wave scan), the
 // open tail of the wave goes to wcarry[w].  Rows end only after slots ESTEP-1 (mod ESTEP).
+// Round 5 (profiles/r05_den_sq_pmc.txt: 535 VALU + 361 SALU + 104 LDS instructions per wave and frame, two waves per SIMD --
+// the passes are bound by instruction issue, not by the LDS: it is busy 20 % of a frame, 44 % of that in bank conflicts):
+//  * `addr` holds ABSOLUTE LDS byte addresses (table base + 4 x index, formed once per task): a gather is ds_read_b32 on the
+//    register as it stands.  The compiler had hoisted the unpacking of the 16-bit offsets out of the frame loop anyway (64
+//    VGPRs) but added the table base to every one of them in every frame;
+//  * the row-end mask word is made opaque once per pass.  With a loop-invariant word the compiler precomputed the 32 exec
+//    masks of a thread's row-end places, kept them in VGPR lanes (SGPR spills) and paid 2 v_readlane + 2 SALU to fetch
+//    each, 6 VALU + 4 SALU per place; now a place is v_add_co (the mask IS vcc) + s_and_saveexec + 3 VALU + restore;
+//  * the current row is a byte address that advances by 4, not an index shifted and added to a base per store.
+//  * (PK2_DP2_PASS_ASM, default) gathers, row-end places and waits are inline asm.  Left to the compiler, every group of 8
+//    multiply-adds of pass A began with s_waitcnt lgkmcnt(0) -- behind the gathers issued ahead for the NEXT group, which
+//    were therefore waited for on the spot (the in-pass copy is an asm statement / a conditional block the compiler's
+//    wait-count bookkeeping does not see through).  LDS operations complete in order: the wait for group g may leave the
+//    row-end stores of group g-1 and the 8 gathers of group g+1 in flight, and says so (lgkmcnt(8 + 8 / ESTEP)).
+#ifndef PK2_DP2_PASS_ASM
+#define PK2_DP2_PASS_ASM 1
+#endif
+__device__ __forceinline__ void lds_gather8(const uint32_t* ad, float (&a)[8]) {
+  asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+               "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15"
+               : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+               : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]) : "memory");
+}
+// s_waitcnt lgkmcnt(N) that the uses of a[] cannot be scheduled ahead of.
+template <int N>
+__device__ __forceinline__ void lds_wait8(float (&a)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               : "n"(N) : "memory");
+}
+// A row-end place: the top bit of m says whether this lane's row ends here; if so its sum is stored, the row address moves on.
+__device__ __forceinline__ void row_end_place(unsigned& m, uint32_t& cb, float& sum) {
+  uint64_t save;
+  asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\ts_and_saveexec_b64 %3, vcc\n\tds_write_b32 %1, %2\n\t"
+               "v_add_u32 %1, 4, %1\n\tv_mov_b32 %2, 0\n\ts_or_b64 exec, exec, %3"
+               : "+v"(m), "+v"(cb), "+v"(sum), "=&s"(save) : : "vcc", "scc", "memory");
+}
+
 template <int ESTEP, int J0, int NS, typename DMA>
-__device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint32_t ends, int frow,
-                                          const float* table, float* acc, float* wcarry, const DMA& dma) {
+__device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32_t (&addr)[kPK], uint32_t ends, int frow,
+                                          float* acc, float* wcarry, const DMA& dma) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float sum = 0.f;
-  int c = frow;
+  uint32_t cb = lds_addr(acc) + 4u * (uint32_t)frow;
   uint32_t packed = 0;
 #pragma unroll
   for (int k = 0; k < NS / ESTEP; ++k) packed |= ((ends >> (k * ESTEP + ESTEP - 1)) & 1u) << k;
   unsigned m = __builtin_bitreverse32(packed);
-  auto gather = [&](int j0, float (&a)[8]) {
+  asm volatile("" : "+v"(m));
+  float a[2][8];
+#if PK2_DP2_PASS_ASM
+  constexpr int NG = NS / 8;
+  constexpr int kStores = 8 / ESTEP;                 // row-end stores of one group
+  lds_gather8(&addr[J0], a[0]);
+  dma(0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) { lds_gather8(&addr[J0 + 8 * (g + 1)], a[(g + 1) & 1]); dma(2 * g + 2); }
+    // younger than the gathers of group g: the stores of group g-1, the gathers of group g+1
+    constexpr int kMost = 15;
+    if (g == 0) lds_wait8<(NG > 1 ? 8 : 0)>(a[0]);
+    else if (g + 1 < NG) lds_wait8<(8 + kStores < kMost ? 8 + kStores : kMost)>(a[g & 1]);
+    else lds_wait8<kStores>(a[g & 1]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t pk = idx2[(J0 + j0 + j) >> 1];
-      const uint32_t byte_off = ((J0 + j0 + j) & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
-      a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + byte_off);
+      const int jj = 8 * g + j;
+      sum = fmaf(a[g & 1][j], prob[J0 + jj], sum);
+      if ((jj + 1) % ESTEP == 0) row_end_place(m, cb, sum);
     }
+    dma(2 * g + 1);
+  }
+#else
+  auto gather = [&](int j0, float (&a)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = lds_load(addr[J0 + j0 + j]);
   };
-  float a[2][8];
   gather(0, a[0]);
   dma(0);
 #pragma unroll
@@ -176,11 +300,12 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
       const int jj = 8 * g + j;
       sum = fmaf(a[g & 1][j], prob[J0 + jj], sum);
       if ((jj + 1) % ESTEP == 0) {
-        if (__builtin_add_overflow(m, m, &m)) { acc[c] = sum; ++c; sum = 0.f; }
+        if (__builtin_add_overflow(m, m, &m)) { lds_store(cb, sum); cb += 4u; sum = 0.f; }
       }
     }
     dma(2 * g + 1);
   }
+#endif
   float x[1] = {sum};
   int fl = ends != 0u ? 1 : 0;
   seg_scan_step<1, 0x111, 0xf>(x, fl);
@@ -194,13 +319,13 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
   if (lane == 63) wcarry[w] = x[0];
 }
 template <int J0, typename DMA>
-__device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&idx2)[kPK / 2], uint32_t ends,
-                                              int frow, const float* table, float* acc, float* wcarry, const DMA& dma) {
+__device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&addr)[kPK], uint32_t ends,
+                                              int frow, float* acc, float* wcarry, const DMA& dma) {
   switch (estep) {
-    case 8: pass_rows<8, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
-    case 4: pass_rows<4, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
-    case 2: pass_rows<2, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
-    default: pass_rows<1, J0, kQ>(prob, idx2, ends, frow, table, acc, wcarry, dma); break;
+    case 8: pass_rows<8, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
+    case 4: pass_rows<4, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
+    case 2: pass_rows<2, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
+    default: pass_rows<1, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
   }
 }
 
@@ -288,7 +413,7 @@ __device__ __forceinline__ void streamed_segment(CDev2& o, int rank, int c, int 
 // The frame's row sums once its words are valid: both resident passes and every streamed segment over the vector at `src`.
 // On return a barrier has NOT been passed yet: the caller's __syncthreads() precedes the first read of the sums.
 struct FrameRegs {
-  float prob[kPK]; uint32_t idx2[kPK / 2]; uint32_t endsA, endsB; int frowA, frowB;
+  float prob[kPK]; uint32_t addr[kPK]; uint32_t endsA, endsB; int frowA, frowB;      // addr: absolute LDS byte addresses
 };
 // STREAM = false: the rank-independent fact "this ordering has no streamed piece at all" compiled in -- no piece registers,
 // no segment barriers, chunks beyond the two resident ones cannot exist.
@@ -300,7 +425,7 @@ struct RowSpan { int nrows, uncA, ncA, uncB, ncB; };
 // with it, vmcnt being in order, for the previous frame's history stores -- would delay the copies.
 template <bool STREAM, typename ST, typename STAGE>
 __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, const RowSpan& rs, const FrameRegs& r,
-                                           ST& st, const Lds2& L, DpTimers& dp_, STAGE stage) {
+                                           const DmaPlan& plan, ST& st, const Lds2& L, DpTimers& dp_, STAGE stage) {
   const int tid = threadIdx.x;
   if constexpr (STREAM) {
     // the streamed segments add up in accS; compact rows past a truncated resident list get no store from their pass
@@ -308,7 +433,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     for (int q = rs.uncA + tid; q < rs.ncA; q += kPT) L.accA[q] = 0.f;
     for (int q = rs.uncB + tid; q < rs.ncB; q += kPT) L.accB[q] = 0.f;
   }
-  dma_chunk(src, o, 0, L.table);
+  dma_chunk(src, o, 0, L.table, rank);
   DP_T(0);
   wait_vm(0);                            // chunk 0 has landed (this wave's part)
   lds_only_barrier();
@@ -316,18 +441,19 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
   DP_TLF(2);
   Chunk1Dma c1;
   {
-    const int lane = tid & 63, b1 = o.cbeg[1], e1 = o.cbeg[2];
-    c1.src = src + b1 + lane * 4; c1.dst = L.table + o.lds_off[1];
-    c1.rows = (e1 - b1 + 255) >> 8; c1.limit = ((e1 + 3) & ~3) - b1 - lane * 4; c1.w = tid >> 6;
+    const uint64_t sb = (uint64_t)(src + o.cbeg[1]);
+    c1.src = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sb >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb);
+    c1.pl = &plan;
   }
   // (round 4) two chunks that take turns in ONE buffer -- a vector of up to twice the LDS table: chunk 1 may only be
   // copied once every wave has finished pass A (and the streamed segment that gathers from chunk 0)
   const bool shared = o.K == 2 && o.lds_off[1] == o.lds_off[0] && o.cbeg[2] > o.cbeg[1];
   if (shared) {
-    pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry, NoDma());
+    pass_rows_any<0>(o.estep, r.prob, r.addr, r.endsA, r.frowA, L.accA, L.wcarry, NoDma());
   } else {
-    pass_rows_any<0>(o.estep, r.prob, r.idx2, r.endsA, r.frowA, L.table, L.accA, L.wcarry, c1);
-    for (int j = 8; j * kPW < c1.rows; ++j) c1(j);     // (a chunk 1 of more than 64 rows: the rest, stalling at the issue)
+    pass_rows_any<0>(o.estep, r.prob, r.addr, r.endsA, r.frowA, L.accA, L.wcarry, c1);
+    for (int j = 8; j * kPW < plan.rows; ++j) c1(j);     // (a chunk 1 of more than 64 rows: the rest, stalling at the issue)
   }
   DP_T(2);
   DP_TLF(3);
@@ -336,27 +462,27 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     const int K = o.K;
     const int pfirst = pb[0], pend = pb[K];
     if (pb[1] > pb[0]) streamed_segment(o, rank, 0, pb[0], pb[1], pb[1] < pend, pfirst, st.cur, L);
-    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table); }
+    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
     wait_vm(0);
     stage();
     __syncthreads();                       // chunk 1 is complete, and buffer 0 is free
-    if (K > 2) dma_chunk(src, o, 2, L.table);
-    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW, NoDma());
+    if (K > 2) dma_chunk(src, o, 2, L.table, rank);
+    pass_rows_any<kQ>(o.estep, r.prob, r.addr, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
     // (consecutive segments add to the same rows of accS: the barrier between two chunks separates them)
     if (pb[2] > pb[1]) streamed_segment(o, rank, 1, pb[1], pb[2], pb[2] < pend, pfirst, st.cur, L);
     for (int c = 2; c < K; ++c) {
       wait_vm(0);
       __syncthreads();                     // chunk c is complete, and the buffer of chunk c-1 is free
-      if (c + 1 < K) dma_chunk(src, o, c + 1, L.table);
+      if (c + 1 < K) dma_chunk(src, o, c + 1, L.table, rank);
       if (pb[c + 1] > pb[c]) streamed_segment(o, rank, c, pb[c], pb[c + 1], pb[c + 1] < pend, pfirst, st.cur, L);
     }
   } else {
-    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table); }
+    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
     wait_vm(0);
     stage();
     __syncthreads();                       // chunk 1 is complete
     DP_T(3);
-    pass_rows_any<kQ>(o.estep, r.prob, r.idx2, r.endsB, r.frowB, L.table, L.accB, L.wcarry + kPW, NoDma());
+    pass_rows_any<kQ>(o.estep, r.prob, r.addr, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
   }
   DP_T(4);
 }
@@ -390,12 +516,18 @@ __device__ __forceinline__ void block_sum2(float& u, float& v, float* red) {
   u = a; v = b;
 }
 
-__device__ __forceinline__ void load_frame_regs(CDev2& o, int rank, FrameRegs& r) {
+__device__ __forceinline__ void load_frame_regs(CDev2& o, int rank, FrameRegs& r, const float* table) {
   const int tid = threadIdx.x;
+  const uint32_t base = lds_addr(table);
 #pragma unroll
   for (int j = 0; j < kPK; ++j) r.prob[j] = o.prob[((size_t)rank * kPK + j) * kPT + tid];
 #pragma unroll
-  for (int j = 0; j < kPK / 2; ++j) r.idx2[j] = o.idx2[((size_t)rank * (kPK / 2) + j) * kPT + tid];
+  for (int j = 0; j < kPK / 2; ++j) {
+    const uint32_t pk = o.idx2[((size_t)rank * (kPK / 2) + j) * kPT + tid];
+    r.addr[2 * j] = base + ((pk & 0xffffu) << 2); r.addr[2 * j + 1] = base + ((pk >> 16) << 2);
+    // (opaque: otherwise the compiler keeps the offsets and adds the -- uniform -- base again at every use)
+    asm volatile("" : "+v"(r.addr[2 * j]), "+v"(r.addr[2 * j + 1]));
+  }
   r.endsA = o.ends[((size_t)rank * 2 + 0) * kPT + tid]; r.endsB = o.ends[((size_t)rank * 2 + 1) * kPT + tid];
   r.frowA = o.first_row[((size_t)rank * 2 + 0) * kPT + tid]; r.frowB = o.first_row[((size_t)rank * 2 + 1) * kPT + tid];
 }
@@ -417,7 +549,9 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const int S = d.S, V = d.V, Vo = d.Vo;
   const bool sep = d.alphav != d.alpha;
   FrameRegs fr;
-  load_frame_regs(o, rank, fr);
+  load_frame_regs(o, rank, fr, L.table);
+  DmaPlan plan;
+  plan.init(o, L.table, rank);
   const int row0 = o.row_begin[rank], nrows = o.row_begin[rank + 1] - row0;
   const int g0 = o.grp_begin[rank], ngrp = o.grp_begin[rank + 1] - g0;
   RowSpan rs;
@@ -524,7 +658,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     // copies (no store sits between them and their waits), long before the stores it has to precede
     const bool publish = t + 1 < T;
     if (tid == 0 && publish) st_agent(word_of(pring, t + 2, rank, 0), __uint_as_float(kRingSentinel));
-    frame_rows<STREAM>(o, src, rank, rs, fr, st, L, dp_, [&]() {
+    frame_rows<STREAM>(o, src, rank, rs, fr, plan, st, L, dp_, [&]() {
 #pragma unroll
       for (int i = 0; i < PSPT; ++i) {
         const int r = tid + i * kPT;
@@ -601,7 +735,9 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const int tid = threadIdx.x;
   const int S = d.S, V = d.V;
   FrameRegs fr;
-  load_frame_regs(o, rank, fr);
+  load_frame_regs(o, rank, fr, L.table);
+  DmaPlan plan;
+  plan.init(o, L.table, rank);
   const int row0 = o.row_begin[rank], nrows = o.row_begin[rank + 1] - row0;
   const int vfirst = d.voff[row0], nvirt = d.voff[row0 + nrows] - vfirst;     // own virtual states: a contiguous range
   RowSpan rs;
@@ -728,7 +864,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     // the words this rank will publish two frames from now must read "not yet written" by then: reset here, before the
     // copies, long before the stores they have to precede (the waits of emit cover it)
     if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
-    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, st, L, dp_, [&]() {
+    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, plan, st, L, dp_, [&]() {
       if (publish) stage_x();
       if (t >= 2) prefetch(t - 2);          // (xw is free again; xl_next becomes xl_prev at the end of the frame)
     });

@@ -30,6 +30,8 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   char path[256] = {0};
 };
@@ -63,6 +65,8 @@ static int rccl_load() {
   g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     set_error("comm: %s lacks the nccl entry points", g_rccl.path);
@@ -113,6 +117,21 @@ extern "C" int pk2_allreduce_bucket(pk2_comm* comm, float* buf, int64_t count, v
   if (count == 0) return PK2_OK;
   ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, comm->comm, static_cast<hipStream_t>(stream));
   if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+  return PK2_OK;
+}
+
+extern "C" int pk2_allreduce_guarded(pk2_comm* comm, float* buf, int64_t count, float* guard_slot, void* stream) {
+  PK2_REQUIRE(comm && comm->comm && buf && guard_slot && count >= 0, "allreduce_guarded: bad args");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool group = g_rccl.GroupStart && g_rccl.GroupEnd && count > 0;
+  ncclResult_t r = ncclSuccess;
+  if (group && (r = g_rccl.GroupStart()) != ncclSuccess) return rccl_fail("ncclGroupStart", r);
+  if (count > 0) r = g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, comm->comm, st);
+  ncclResult_t r2 = g_rccl.AllReduce(guard_slot, guard_slot, 1, ncclFloat32, ncclMax, comm->comm, st);
+  ncclResult_t r3 = group ? g_rccl.GroupEnd() : ncclSuccess;
+  if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+  if (r2 != ncclSuccess) return rccl_fail("ncclAllReduce (guard slot)", r2);
+  if (r3 != ncclSuccess) return rccl_fail("ncclGroupEnd", r3);
   return PK2_OK;
 }
 

@@ -904,10 +904,15 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
 // pass keeps its NaN sentinels in y, but the backward pass would leave dgx -- freshly allocated memory -- partly
 // unwritten.  One workgroup after every persistent launch turns the launch's output into NaN in that case and raises a
 // sticky flag (the control block itself is cleared by the next launch) that pk2_lstm_persist_status reports.
-__global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host) {
+// `mail` (backward pass): an aborted launch leaves consumed and unconsumed hand-overs in the mailboxes, which the next
+// launch would read as valid ones -- the same workgroup fills them with sentinels again, so that a caller who
+// lowers the guard (pk2_persist_guard_clear) and carries on does not compute on stale words.
+__global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host,
+                               float* mail, size_t mail_n) {
   if (ctl->abort == 0u && ctl->done == pairs) return;
   if (threadIdx.x == 0) { *sticky = 1u; persist_guard_raise(guard_dev, guard_host); }
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
+  for (size_t i = threadIdx.x; i < mail_n; i += blockDim.x) mail[i] = __uint_as_float(kSeqSentinel);
 }
 
 // ---- host -------------------------------------------------------------------------------------------------------------
@@ -916,7 +921,13 @@ struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* stic
 static std::map<DevStream, SeqScratch> g_seq_scratch;
 static PerDevice<int> g_seq_state_pd(-1);             // -1 untested, 0 unusable, 1 verified on this device
 
+// pk2_persist_guard_clear: whatever an aborted launch left behind, the next backward launch fills every mailbox again
+// (belt and braces next to the refill by lstm_seq_check: a launch that was killed never reached its check kernel).
+static void seq_mail_dirty() { for (auto& kv : g_seq_scratch) kv.second.mail_clean_teams = 0; }
+
 static int seq_scratch(hipStream_t stream, SeqScratch** out) {
+  static const bool hooked = (persist_guard_on_clear(seq_mail_dirty), true);
+  (void)hooked;
   SeqScratch& sc = g_seq_scratch[dev_stream(stream)];
   if (!sc.ctl) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.ctl), sizeof(SeqCtl)));
   if (!sc.mail) PK2_HIP(hipMalloc(reinterpret_cast<void**>(&sc.mail), (size_t)8 * kSeqTeams * kSeqMailFloats * sizeof(float)));
@@ -986,7 +997,8 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
     g_seq_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
-  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
+  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
+                     nullptr, (size_t)0);
   *ran = true;
   return PK2_OK;
 }
@@ -1015,7 +1027,8 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   if (bias_done) *bias_done = with_bias;
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   else hipLaunchKernelGGL(lstm_bwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
-  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev);
+  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
+                     sc->mail, (size_t)8 * kSeqTeams * kSeqMailFloats);
   PK2_LAUNCH_CHECK();
   *ran = true;
   return PK2_OK;

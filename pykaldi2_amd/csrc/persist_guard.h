@@ -16,10 +16,19 @@ struct PersistGuard {
   unsigned* dev = nullptr;        // device memory: read by kernels
   unsigned* host_dev = nullptr;   // device address of the host-mapped word: written by the check kernels
   volatile unsigned* host = nullptr;
+  // Verdicts of the COLLECTIVE guard (several ranks, round 5): ring of kGuardRing host-mapped words, word[stamp % ring] =
+  // (stamp << 1) | raised, written by pk2_persist_guard_import after the ranks exchanged their guard words, so that every
+  // rank reads the same verdict for the same step and stops at the same step (pykaldi2_amd/hvd.py).
+  unsigned* ring_dev = nullptr;
+  volatile unsigned* ring = nullptr;
 };
+constexpr unsigned kGuardRing = 8;
 
 // The guard of the current device (created on first use); PK2_OK or an error code.
 int persist_guard(PersistGuard* out);
+// `fn` runs whenever pk2_persist_guard_clear lowers a guard: scratch state an aborted launch may have left behind is
+// marked for re-initialisation (lstm_persist_seq.hip: the backward mailboxes).
+void persist_guard_on_clear(void (*fn)());
 
 __device__ __forceinline__ void persist_guard_raise(unsigned* dev, unsigned* host_dev) {
   if (dev) *dev = 1u;

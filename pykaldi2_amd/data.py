@@ -98,7 +98,8 @@ class ZipWavSource:
             secs, fell_back = {}, []
             for zpath in sorted(want):
                 st = os.stat(zpath)
-                cache_path, stamp = zpath + ".durations.json", [int(st.st_size), int(st.st_mtime)]
+                # (stamp: archive size, mtime, cache format version -- a fixed header parser invalidates old caches)
+                cache_path, stamp = zpath + ".durations.json", [int(st.st_size), int(st.st_mtime), _DURATIONS_CACHE_VERSION]
                 cached = {}
                 try:
                     with open(cache_path) as f:
@@ -108,6 +109,7 @@ class ZipWavSource:
                 except (OSError, ValueError):
                     pass
                 missing = [m for m in want[zpath] if m not in cached]
+                estimated = {}        # fall-back estimates are NOT cached: the next run parses (and warns) again
                 if missing:
                     miss = set(missing)
                     with zipfile.ZipFile(zpath) as z:
@@ -117,16 +119,18 @@ class ZipWavSource:
                             with z.open(info) as f:
                                 head = f.read(4096)
                                 sec = _wav_seconds(head, info.file_size)
-                                while sec is None and len(head) < min(info.file_size, 1 << 20):
+                                # (a member that is no RIFF/WAVE file at all is not read any further)
+                                while sec is None and head[:4] == b"RIFF" and len(head) < min(info.file_size, 1 << 20):
                                     more = f.read(len(head))           # the data chunk was not in what has been read: double it
                                     if not more:
                                         break
                                     head += more
                                     sec = _wav_seconds(head, info.file_size)
                             if sec is None:
-                                sec = max(0, info.file_size - 44) / 2.0 / 16000.0
+                                estimated[info.filename] = max(0, info.file_size - 44) / 2.0 / 16000.0
                                 fell_back.append("%s@/%s" % (zpath, info.filename))
-                            cached[info.filename] = sec
+                            else:
+                                cached[info.filename] = sec
                     try:
                         tmp = "%s.%d.tmp" % (cache_path, os.getpid())
                         with open(tmp, "w") as f:
@@ -135,7 +139,7 @@ class ZipWavSource:
                     except OSError:
                         pass
                 for m in want[zpath]:
-                    secs[(zpath, m)] = cached[m]
+                    secs[(zpath, m)] = cached[m] if m in cached else estimated[m]
             if fell_back:
                 sys.stderr.write("[data] %d wav header(s) could not be parsed, durations estimated as 16 kHz / 16-bit / mono: %s%s\n"
                                  % (len(fell_back), ", ".join(fell_back[:5]), " ..." if len(fell_back) > 5 else ""))
@@ -151,6 +155,9 @@ class ZipWavSource:
             lab = lab[:n]
             wav = wav[:401 + 160 * (n - 1)] if n < T else wav
         return wav, lab, aux, utt
+
+
+_DURATIONS_CACHE_VERSION = 2
 
 
 def _wav_seconds(head, file_size):

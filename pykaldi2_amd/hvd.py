@@ -50,7 +50,7 @@ def init(backend=None):
         local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-            _ranks_share_a_device(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count())
+            _ranks_share_a_device(_local_world_size(), torch.cuda.device_count())
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
         _state.update(rank=dist.get_rank(), size=dist.get_world_size(), local_rank=local, group=True)
@@ -73,13 +73,27 @@ def init(backend=None):
     _state["initialized"] = True
 
 
+def _local_world_size():
+    """Ranks of this node, from whichever launcher started the job: torchrun (LOCAL_WORLD_SIZE), Open MPI / horovodrun
+    (OMPI_COMM_WORLD_LOCAL_SIZE), MPICH / Intel MPI (MPI_LOCALNRANKS), Slurm (SLURM_NTASKS_PER_NODE).  None when nothing
+    says: a multi-node job started without these variables has WORLD_SIZE > device_count on every node, and guessing
+    "ranks share a GPU" from that silently took a correct one-process-per-GPU deployment off the persistent kernels
+    (ADVICE r4)."""
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE"):
+        v = os.environ.get(k, "")
+        digits = v.split("(")[0]
+        if digits.isdigit() and int(digits) > 0:
+            return int(digits)
+    return None
+
+
 def _ranks_share_a_device(local_world, devices):
     """One process per GPU is the deployment.  When several ranks of a node are mapped onto ONE device
     (tests that run the N-rank protocol on a one-GPU box), their persistent kernels -- each wants 32 co-resident
     workgroups on every XCD -- hold parts of the chip against each other until their polls time out, and since round 4 a
     time-out stops training (include/pk2hip.h: guard of the persistent kernels).  Such a job is switched to the
     launch-per-step kernels, which need no co-residency; explicit settings of the caller win."""
-    if devices <= 0 or local_world <= devices:
+    if local_world is None or devices <= 0 or local_world <= devices:
         return
     changed = [k for k, v in (("PK2_LSTM_SEQ", "0"), ("PK2_LSTM_PERSIST", "0"), ("PK2_LSTM_BIG_PERSIST", "0"), ("PK2_DEN_PERSIST", "0"),
                               ("PK2_LAT_DECODER", "frames")) if os.environ.setdefault(k, v) == v]
@@ -134,17 +148,26 @@ def comm_library():
     return buf.value.decode()
 
 
-def _allreduce_sum(t, stream=None):
-    """In-place sum of a contiguous f32 tensor over the ranks, enqueued on `stream` (default: the current stream)."""
+def _allreduce_sum(t, stream=None, guard_slot=None):
+    """In-place sum of a contiguous f32 tensor over the ranks, enqueued on `stream` (default: the current stream).
+    `guard_slot` (a one-float device tensor, current stream only): its max over the ranks travels with the same call
+    (pk2_allreduce_guarded: one RCCL group) -- the collective guard of DistributedOptimizer."""
     if _state["comm"] is not None and t.is_cuda:
         from . import _lib
         st = stream if stream is not None else torch.cuda.current_stream(t.device)
-        _lib.check(_lib.lib().pk2_allreduce_bucket(_state["comm"], C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st.cuda_stream)))
-    elif stream is not None and t.is_cuda:
+        if guard_slot is not None:
+            _lib.check(_lib.lib().pk2_allreduce_guarded(_state["comm"], C.c_void_p(t.data_ptr()), t.numel(),
+                                                        C.c_void_p(guard_slot.data_ptr()), C.c_void_p(st.cuda_stream)))
+        else:
+            _lib.check(_lib.lib().pk2_allreduce_bucket(_state["comm"], C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st.cuda_stream)))
+        return
+    if stream is not None and t.is_cuda:
         with torch.cuda.stream(stream):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    else:
+    elif t.numel():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if guard_slot is not None:
+        dist.all_reduce(guard_slot, op=dist.ReduceOp.MAX)
 
 
 def shutdown():
@@ -363,6 +386,21 @@ class DistributedOptimizer:
         self._overlap = self._mode == "overlap"     # (kept for introspection by tests)
         self._done = []          # [lo, hi) ranges of the flat gradient already exchanged in this step
         self._reduced = False
+        # Collective guard of the persistent kernels: a rank whose one-launch kernel timed out holds a NaN-poisoned
+        # gradient, and the all-reduce hands that NaN to every peer -- whose own guards are down.  So each rank's guard word
+        # rides with the gradients (a one-float slot, max over the ranks, same RCCL group as the last piece of the
+        # gradient), and every rank raises its own guard from the combined word BEFORE its optimiser kernel runs.  The
+        # ranks also have to STOP together (a rank that raises alone leaves its peers blocked in the next all-reduce):
+        # the combined word of step s is published in host-mapped memory, and every rank's step s + 2 reads the verdict
+        # of step s -- the same word everywhere -- and raises Pk2Error there; the local, unsynchronised check of the
+        # wrapped optimiser is switched off.  (Two steps back: the host never waits for the device in a healthy job.)
+        self._guard_slot = None
+        self._guard_stamp = 0
+        if self._flat and _collective() and torch.cuda.is_available() and os.environ.get("PK2_HVD_GUARD", "1") != "0":
+            dev = next(iter(optimizer.model.parameters())).device
+            if dev.type == "cuda":
+                self._guard_slot = torch.zeros(1, dtype=torch.float32, device=dev)
+                optimizer.guard_check = False
         # bench.py / diagnostics: with `timing = []` every step appends the (start, end) device events of its all-reduce
         # calls, in issue order, on whichever stream they ran (bench.py reads them after its timed region)
         self.timing = None
@@ -394,22 +432,54 @@ class DistributedOptimizer:
                 torch.cuda.current_stream().wait_stream(self._side)
             # whatever no bucket hook has covered (everything, in the single schedule; nothing, normally, in the
             # bucketed one; the whole buffer for a model without hooks) goes out now on the compute stream
-            pos = 0
+            pos, pieces = 0, []
             for lo, hi in sorted(self._done) + [(gflat.numel(), gflat.numel())]:
                 if lo > pos:
-                    self._timed_allreduce(gflat[pos:lo], None)
+                    pieces.append((pos, lo))
                 pos = max(pos, hi)
+            slot = self._guard_slot if gflat.is_cuda else None
+            if slot is not None:
+                from . import _lib
+                _lib.check(_lib.lib().pk2_persist_guard_export(_lib.ptr(slot), _lib.stream_ptr(slot.device)))
+                if not pieces:
+                    pieces = [(0, 0)]          # every bucket went out on the side stream: the slot travels alone
+            for i, (lo, hi) in enumerate(pieces):
+                self._timed_allreduce(gflat[lo:hi], None, slot if i == len(pieces) - 1 else None)
+            if slot is not None:
+                self._guard_stamp += 1
+                _lib.check(_lib.lib().pk2_persist_guard_import(_lib.ptr(slot), self._guard_stamp, _lib.stream_ptr(slot.device)))
             self._done = []
             self._reduced = True
             self._trial_mark_exchanged()
 
-    def _timed_allreduce(self, t, stream):
-        if self.timing is None or not t.is_cuda:
-            return _allreduce_sum(t, stream)
+    def _guard_verdict(self):
+        """Raises on EVERY rank at the same step: the combined guard word of two steps ago (host-mapped, no device
+        synchronisation in a healthy job: the device is never two whole steps behind the host for long)."""
+        want = self._guard_stamp - 2
+        if self._guard_slot is None or want < 1:
+            return
+        import time
+        from . import _lib
+        ready, raised = C.c_uint32(0), C.c_uint32(0)
+        t0 = None
+        while True:
+            _lib.check(_lib.lib().pk2_persist_guard_verdict(want, C.byref(ready), C.byref(raised)))
+            if ready.value:
+                break
+            t0 = t0 or time.time()
+            if time.time() - t0 > 120.0:
+                raise _lib.Pk2Error("hvd: the guard verdict of step %d never arrived (device hung?)" % want)
+            time.sleep(0.0002)
+        _lib.check_persist_guard("DistributedOptimizer.step (rank %d, verdict of step %d over all ranks)" % (rank(), want),
+                                 raised=bool(raised.value))
+
+    def _timed_allreduce(self, t, stream, guard_slot=None):
+        if self.timing is None or not t.is_cuda or t.numel() == 0:
+            return _allreduce_sum(t, stream, guard_slot)
         st = stream if stream is not None else torch.cuda.current_stream(t.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        _allreduce_sum(t, stream)
+        _allreduce_sum(t, stream, guard_slot)
         e1.record(st)
         self._step_events.append((e0, e1, int(t.numel()) * 4))
 
@@ -476,6 +546,7 @@ class DistributedOptimizer:
                 for p in params:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
                     p.grad.div_(size())
+            self._guard_verdict()
         out = self._opt.step(*a, **k)
         # the exchange guard never depends on the caller invoking zero_grad(): gradients are overwritten by the next
         # backward, which must be followed by a fresh exchange

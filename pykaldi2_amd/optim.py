@@ -25,6 +25,9 @@ class _FlatOptimizer:
         self._ws = None
         self.grad_scale = 1.0
         self.step_count = 0
+        # several ranks: hvd.DistributedOptimizer checks the guard of ALL ranks itself (same step on every rank) and
+        # switches this local, unsynchronised check off -- a rank that raises alone leaves its peers in the next all-reduce
+        self.guard_check = True
 
     def zero_grad(self, set_to_none=True):
         # gradients are overwritten by the next backward (LSTMAM publishes p.grad itself)
@@ -103,7 +106,8 @@ class Adam(_FlatOptimizer):
         self.state = None
 
     def step(self):
-        _lib.check_persist_guard("Adam.step")     # (no synchronisation; raises at the first step after a time-out)
+        if self.guard_check:
+            _lib.check_persist_guard("Adam.step")     # (no synchronisation; raises at the first step after a time-out)
         p, g = self._flat()
         if self.state is None or self.state["exp_avg"].device != p.device:
             self.state = dict(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p),
@@ -156,7 +160,8 @@ class SGD(_FlatOptimizer):
         self.buf = None
 
     def step(self):
-        _lib.check_persist_guard("SGD.step")
+        if self.guard_check:
+            _lib.check_persist_guard("SGD.step")
         p, g = self._flat()
         first = self.buf is None
         if self.momentum != 0 and first:

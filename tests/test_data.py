@@ -176,14 +176,21 @@ def test_durations_read_past_large_header_chunks_and_are_cached(tmp_path, capsys
     assert "1 wav header(s) could not be parsed" in err and "u3.wav" in err and "u2.wav" not in err
     blob = json.load(open(zpath + ".durations.json"))
     assert blob["seconds"]["u2.wav"] == 1.0 and blob["stamp"][0] == os.path.getsize(zpath)
-    # a second source answers from the cache: no member is opened (the archive's member reader is disabled to prove it)
+    # an estimate is NOT cached (a later run -- or a fixed parser -- looks at the member again and warns again)
+    assert "u3.wav" not in blob["seconds"] and blob["stamp"][2] == data._DURATIONS_CACHE_VERSION
+    # a second source answers from the cache: no parsed member is opened again (the archive's member reader records it)
     src2 = data.ZipWavSource([dict(wav=zpath)])
-    orig = zipfile.ZipFile.open
+    orig, opened = zipfile.ZipFile.open, []
     try:
-        zipfile.ZipFile.open = lambda *a, **k: (_ for _ in ()).throw(AssertionError("member opened although cached"))
+        def spy(self, name, *a, **k):
+            opened.append(getattr(name, "filename", name))
+            return orig(self, name, *a, **k)
+        zipfile.ZipFile.open = spy
         assert list(src2.durations()) == list(src.durations())
     finally:
         zipfile.ZipFile.open = orig
+    assert opened == ["u3.wav"]
+    assert "u3.wav" in capsys.readouterr().err
     # a changed archive invalidates the cache
     with zipfile.ZipFile(zpath, "a") as z:
         z.writestr("u4.wav", mk(4000))
