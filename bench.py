@@ -193,13 +193,37 @@ def scaling_report(step_events, exchange_timing, audio, dev, rank, world):
 
 def dump_chain_parity_inputs(tr, mb, path):
     """The logits of the breakdown minibatch, its alignments, and what the device computes for them (objective per
-    sequence, d objf / d logits): the `parity` leg of the cpu-baseline child checks them against the C port."""
+    sequence, d objf / d logits): the `parity` leg of the cpu-baseline child checks them against the C port.  TransformerAM
+    (configs[4]): also the model input, the padding mask and the weights, so that the child can run the torch CPU modules
+    on the same minibatch and compare the logits."""
     logits = tr.last["logits"].detach().transpose(0, 1).contiguous()          # [N, T', P]
     out, grad = chain.compute_chain_objf_and_deriv(tr.opts, tr.den, tr.last["sups"], logits)
     torch.cuda.synchronize()
     arrs = {"ali%d" % n: np.asarray(a) for n, a in enumerate(mb["alis"])}
     np.savez(path, n=len(mb["alis"]), xent=tr.opts.xent_regularize, logits=logits.cpu().numpy(),
              gpu_out=out.cpu().numpy(), gpu_grad=grad.cpu().numpy(), **arrs)
+    if tr.arch == "transformer":
+        with torch.no_grad():      # (the logits above are those of the step BEFORE its update: these are of the saved weights)
+            feats, frames, row_off = tr.fb(mb["wav"], mb["lens"])
+            x = tr.fb.pad_roll_subsample(feats, row_off, frames, shift=0, subsample=3, time_major=True)
+            kpm = torch.ones(len(frames), x.shape[0], dtype=torch.bool)
+            for n_, f_ in enumerate(frames):
+                kpm[n_, :-(-int(f_) // 3)] = False
+            now = tr.model(x, None, kpm.to(x.device)).transpose(0, 1).contiguous()
+        torch.save(dict(state_dict={k: v.cpu() for k, v in tr.model.state_dict().items()}, x=x.cpu(), frames=list(frames),
+                        logits=now.cpu()), path + ".model.pt")
+
+
+def transformer_reference_forward(m, x, kpm):
+    """The torch CPU computation of the reference's TransformerAM (models/transformer.py:52-94) on the modules
+    pykaldi2_amd.transformer.TransformerAM keeps as parameter containers, layer by layer (the fast-path probe
+    of torch >= 2 rejects the custom layer)."""
+    import torch.nn.functional as F
+    h = m.input_layer(x)
+    for lp in m.transformer.layers:
+        h = lp.encoder_layer(h, None, kpm)
+        h = F.relu(lp.conv1d(h.permute(1, 2, 0))).permute(2, 0, 1)
+    return m.output_layer(m.transformer.norm(h))
 
 
 DEN_ROOF_LENS = [589, 410, 377, 502]     # the fixed denominator workload of `--den-only`, the PMC passes and `roofline`
@@ -365,9 +389,36 @@ def cpu_baseline_worker(seed, threads, parity_path=None):
     rng = np.random.default_rng(seed)
     ali_model = chain_model()[2]
     torch.manual_seed(0)
-    rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
-    lin = torch.nn.Linear(1024, P)
-    params = list(rnn.parameters()) + list(lin.parameters())
+    arch = os.environ.get("PK2_BENCH_ARCH", "blstm")
+    if arch == "transformer":        # configs[4]: the reference's torch modules of TransformerAM on the host
+        from pykaldi2_amd import transformer
+        tf = transformer.TransformerAM(80, 512, 8, 2048, 12, 0.0, P)
+        params = list(tf.parameters())
+        if parity_path and parity is not None and os.path.exists(parity_path + ".model.pt"):
+            try:                     # logits of the run's own minibatch and weights: device vs torch CPU
+                blob = torch.load(parity_path + ".model.pt")
+                tf.load_state_dict(blob["state_dict"])
+                Tp = blob["x"].shape[0]
+                kpm = torch.ones(len(blob["frames"]), Tp, dtype=torch.bool)
+                for n_, f_ in enumerate(blob["frames"]):
+                    kpm[n_, :-(-int(f_) // 3)] = False
+                with torch.no_grad():
+                    want = transformer_reference_forward(tf.eval(), blob["x"], kpm).transpose(0, 1)     # [N, T', P]
+                got = blob["logits"]
+                valid = ~kpm
+                err = float((got - want)[valid].abs().max())
+                scale = float(want[valid].abs().max())
+                parity["logits_max_abs_err"] = float("%.3g" % err)
+                parity["logits_rel_to_max"] = float("%.3g" % (err / max(scale, 1e-30)))
+                parity["logits_against"] = "torch CPU forward of the reference's TransformerAM modules with the run's weights"
+                parity["ok"] = bool(parity.get("ok") and err <= 2e-4 * max(1.0, scale))
+                tf.train()
+            except Exception as e:
+                parity["logits_error"] = repr(e)[:200]
+    else:
+        rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
+        lin = torch.nn.Linear(1024, P)
+        params = list(rnn.parameters()) + list(lin.parameters())
     opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True)
     mel = fbank.mel_filterbank()
     # a bounded sample of the same workload: whole training steps until ~12 s of host work are done (at most 8 minibatches)
@@ -377,7 +428,13 @@ def cpu_baseline_worker(seed, threads, parity_path=None):
         t0 = time.time()
         feats = [frontend_ref.cmn(frontend_ref.logfbank(w, mel)).astype(np.float32) for w, _ in host]
         x = torch.from_numpy(frontend_ref.pad_roll_subsample(feats, 0, 3).copy())
-        logits = lin(rnn(x)[0])
+        if arch == "transformer":
+            kpm = torch.ones(x.shape[0], x.shape[1], dtype=torch.bool)
+            for n_, f_ in enumerate(feats):
+                kpm[n_, :-(-f_.shape[0] // 3)] = False
+            logits = transformer_reference_forward(tf, x.transpose(0, 1), kpm).transpose(0, 1)
+        else:
+            logits = lin(rnn(x)[0])
         sups = build_supervisions([a for _, a in host])
         out, grad = chain_c.chain_batch(g, pi, logits.detach().numpy(), sups, 1e-4, 0.1)
         opt.zero_grad()
@@ -389,9 +446,10 @@ def cpu_baseline_worker(seed, threads, parity_path=None):
         steps += 1
     print(json.dumps(dict(value=round(seconds / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
                           kind="port", parity=parity,
-                          sample="%d minibatches of 4 utterances (%.1f s audio): numpy fbank oracle + torch CPU 3x512 "
-                                 "BLSTM fwd/bwd + C port of the LF-MMI objective (OpenMP over sequences) + Adam; "
-                                 "%.1f s wall on %d threads" % (steps, seconds, dt, threads))), flush=True)
+                          sample="%d minibatches of 4 utterances (%.1f s audio): numpy fbank oracle + torch CPU %s fwd/bwd + "
+                                 "C port of the LF-MMI objective (OpenMP over sequences) + Adam; %.1f s wall on %d threads"
+                                 % (steps, seconds, "12-layer TransformerAM" if arch == "transformer" else "3x512 BLSTM", dt, threads))),
+          flush=True)
 
 
 def ce_parity(path):
@@ -513,6 +571,16 @@ def ce_workload(args, dev, rank, world):
     audio = args.steps * BATCH * CH * 0.01
     if rank == 0:
         base = parity = None
+        # whole-step MFMA utilisation (125.5 MFLOP per network frame forward + backward at P = 5768, all of it
+        # MFMA-eligible) and the dominant GEMM of the step measured alone, events on the launch stream
+        ms_step = 1e3 * dt / args.steps
+        flops = 3.0 * lstm_flops_per_frame(pdfs=PC) * BATCH * CH
+        tf = flops / (ms_step * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=round(tf, 1), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), traffic=None,
+                    kernel="whole CE step (3x512 BLSTM + output layer forward + backward, f32 MFMA GEMMs pk2::gemm_f32_kernel + "
+                    "the persistent recurrences pk2::lstm_*_big_persist) over the step's wall time",
+                    flops_per_step=flops, ms=round(ms_step, 3),
+                    input_projection_gemm=gemm_mfma_roofline(dev, BATCH * CH))
         if world == 1 and not args.no_cpu_baseline:
             import tempfile
             with tempfile.TemporaryDirectory() as td:
@@ -532,8 +600,11 @@ def ce_workload(args, dev, rank, world):
             parity = base.pop("parity", None)
         print(json.dumps({"metric": "iRTF (hrs audio/hr) 3x512 BLSTM CE, 256x80 chunks (secondary workload, configs[1])",
                           "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
+                          "unit": "hours of audio per wall-clock hour", "higher_is_better": True,
+                          "config": {"workload": "SECONDARY configs[1]: 3x512 BLSTM CE, batch 256 x 80 x 80 fbank from raw waveforms in "
+                                     "HBM, P=5768, dropout 0.2, Adam(amsgrad)+clip 5"},
                           "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "loss": round(float(loss.item()), 4),
-                          "cpu_baseline": base, "parity": parity,
+                          "roofline": roof, "cpu_baseline": base, "parity": parity,
                           "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           "reference_published": "README.md:43-45: 190 iRTF (64x80, 1 V100), 520 iRTF (256x80, 4 V100)"}),
               flush=True)
@@ -607,8 +678,44 @@ def se_workload(args, dev, rank, world):
         ev[2].record()
         torch.cuda.synchronize()
     if rank == 0:
+        # Dominant kernel: the persistent lattice decoder (integer / pointer work on HBM-resident graphs; no MFMA).  Algorithmic
+        # bytes per decode call: per link created 56 B (16 B HCLG arc record + 4 B log-likelihood read, 16 B of
+        # the per-state {cost, token} table read and written, 16 B link record + 4 B acoustic cost written), per token 48 B
+        # (20 B token fields written, read again by the next frame, 8 B arc-range lookup) -- over the kept links / tokens
+        # the call reports, so a lower bound of what the search touched.
+        dec_ms = ev[0].elapsed_time(ev[1])
+        toks, links = float(lat.num_tokens.sum()), float(lat.num_links.sum())
+        byts = 56.0 * links + 48.0 * toks
+        ach = byts / (dec_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                    kernel="pk2::lat_frames_persist + the pruning kernels behind it (one decode-and-prune call of the minibatch: "
+                    "a team of workgroups per utterance, all frames in one launch); latency-bound token passing, see DESIGN.md 4.4",
+                    ms_per_launch=round(dec_ms, 2), algorithmic_bytes=int(byts),
+                    us_per_frame=round(1e3 * dec_ms / float(np.max(frames)), 2))
+        base = parity = None
+        if world == 1 and not args.no_cpu_baseline and crit_name == "mmi":
+            import tempfile
+            F = min(120, int(frames[0]))       # bounded sample: the first 1.2 s of utterance 0 of this minibatch
+            with torch.no_grad():
+                ll0 = ll[0, :F].contiguous()
+                lat0 = rec.decode(ll0)
+                ali0 = np.asarray(mb["aux"][0])[:F]
+                like0, post0 = lat0.mmi([ali0], 1.0, 0.2, True)
+                torch.cuda.synchronize()
+                exp0 = lat0.export(0)          # the kept (pruned) lattice as arrays
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "se_parity.npz")
+                np.savez(path, ll=ll0.cpu().numpy(), ali=ali0, words=words, wav=mb["wav"][:401 + 160 * (F - 1)].cpu().numpy(),
+                         best_cost=np.float32(lat0.best_cost[0]), num_links=int(len(exp0["link_src"])), num_tokens=int(lat0.num_tokens[0]),
+                         like=float(like0.item()), post=post0[0].cpu().numpy())
+                base = cpu_baseline(0, timeout=300, worker="--cpu-se-worker", parity_path=path)
+            parity = base.pop("parity", None)
         print(json.dumps({"metric": "iRTF (hrs audio/hr) 3x512 BLSTM lattice-%s, on-the-fly lattices (secondary workload, configs[3])" % crit_name.upper(),
-                          "value": round(audio / dt * world, 2), "n_gpus": world, "steps": args.steps,
+                          "value": round(audio / dt * world, 2), "unit": "hours of audio per wall-clock hour", "higher_is_better": True,
+                          "config": {"workload": "SECONDARY configs[3]: 3x512 BLSTM lattice-%s (train_se.py), on-the-fly lattices, batch %d x "
+                                     "var-len per GPU at 100 fps, P=5768, %d-word HCLG, beam 13 / lattice_beam 7 / max_active 7000, "
+                                     "CE regulariser 0.1, SGD+clip 5" % (crit_name.upper(), batch, words)},
+                          "n_gpus": world, "steps": args.steps,
                           "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "batch_per_gpu": batch,
                           "hclg": {"states": rec.graph.num_states, "arcs": rec.graph.num_arcs},
                           "lattice_ms": {"decode_and_prune": round(ev[0].elapsed_time(ev[1]), 2),
@@ -616,10 +723,93 @@ def se_workload(args, dev, rank, world):
                           "lattice_tokens_per_frame": round(float(lat.num_tokens.sum()) / float(np.sum(frames)), 1),
                           "lattice_links_per_frame": round(float(lat.num_links.sum()) / float(np.sum(frames)), 1),
                           "loss": round(float(loss.item()), 2),
+                          "roofline": roof, "cpu_baseline": base, "parity": parity,
                           "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           "reference_published": "README.md:47-49: lattice MMI 16.7 iRTF (1 V100, 4 utterances), 34.5 iRTF (4 V100)"}),
               flush=True)
     hvd.shutdown()
+
+
+def cpu_se_worker(threads, parity_path):
+    """configs[3] on the host, in a child process, on a BOUNDED sample (the first 1.2 s of one utterance of the run): numpy fbank
+    oracle, the reference's torch CPU modules (nn.LSTM 3x512 bidirectional + Linear), the numpy restatement of Kaldi's
+    LatticeFasterDecoder and of the lattice MMI forward-backward (oracle/lattice_ref.py) on the DEVICE's log-likelihoods of that
+    sample -- which is also the parity leg: the device's lattice (best cost, kept links, MMI log-likelihood, posteriors) against
+    the oracle's on the same input --, backward through the model, clip 5, SGD."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    torch.set_num_threads(threads)
+    from oracle import frontend_ref, lattice_ref as LR
+    d = np.load(parity_path)
+    PS, F = d["ll"].shape[1], d["ll"].shape[0]
+    g = synth.decoding_graph_arcs(int(d["words"]), PS, seed=0)
+    tm = synth.transition_model_arrays(PS)
+    G = LR.DecodeGraphRef(g["num_states"], g["start"], g["src"], g["dst"], g["ilabel"], g["weight"], g["final"])
+    o = LR.DecoderOptionsRef(beam=13.0, lattice_beam=7.0, max_active=7000, min_active=200, beam_delta=0.5, acoustic_scale=0.1)
+    torch.manual_seed(0)
+    rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, bidirectional=True)
+    lin = torch.nn.Linear(1024, PS)
+    params = list(rnn.parameters()) + list(lin.parameters())
+    opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9)
+    mel = fbank.mel_filterbank()
+    t0 = time.time()
+    feats = frontend_ref.cmn(frontend_ref.logfbank(d["wav"], mel)).astype(np.float32)[:F]
+    logits = lin(rnn(torch.from_numpy(feats[None].copy()))[0])
+    want = LR.decode(G, d["ll"], tm["tid2pdf"], o)
+    wl, wp = LR.lattice_mmi(want, d["ali"], tm["tid2pdf"], PS, 1.0, 0.2, True)
+    opt.zero_grad()
+    logits.backward(torch.from_numpy(-wp[None, :logits.shape[1]].astype(np.float32)))
+    torch.nn.utils.clip_grad_norm_(params, 5.0)
+    opt.step()
+    dt = time.time() - t0
+    perr = float(np.abs(d["post"] - wp).max())
+    lrel = float(abs(float(d["like"]) - wl) / max(1.0, abs(wl)))
+    parity = dict(best_cost_device=float(d["best_cost"]), best_cost_oracle=float(np.float32(want.best_cost)),
+                  kept_links_device=int(d["num_links"]), kept_links_oracle=int(len(want.link_src)),
+                  mmi_loglike_rel_err=float("%.3g" % lrel), posterior_max_abs_err=float("%.3g" % perr),
+                  tolerance={"best_cost": "bit-equal (float32)", "kept_links": "equal", "loglike_rel": 1e-9, "posterior_abs": 2e-6},
+                  ok=bool(np.float32(d["best_cost"]) == np.float32(want.best_cost) and int(d["num_links"]) == len(want.link_src)
+                          and lrel <= 1e-9 and perr <= 2e-6), frames=int(F),
+                  against="oracle/lattice_ref.py (numpy restatement of Kaldi's LatticeFasterDecoder + lattice MMI forward-backward; "
+                          "unpinned at the Kaldi boundary) on the device's log-likelihoods of the sample")
+    print(json.dumps(dict(value=round(F * 0.01 / dt, 2), unit="hours of audio per wall-clock hour", cores=threads, kind="port",
+                          parity=parity,
+                          sample="the first %d frames (%.1f s) of one utterance: numpy fbank oracle + torch CPU 3x512 BLSTM fwd/bwd + numpy "
+                                 "lattice decoder / MMI oracle (single-threaded) + SGD: %.1f s wall, %d threads for torch"
+                                 % (F, F * 0.01, dt, threads))), flush=True)
+
+
+def run_secondaries():
+    """BASELINE configs[1], [3], [4] next to the headline: each runs as a short child job of its own
+    (`bench.py --ce | --se | --transformer`: own process, own HIP context, this GPU; the parent is idle meanwhile) with its own
+    timed window, roofline of its dominant kernel, CPU baseline on a bounded sample and parity check; the parent keeps the
+    fields a reader needs.  Nothing of this runs inside the headline's timed region."""
+    import subprocess
+    out = {}
+    for name, flags in (("ce", ["--ce", "--steps", "8", "--warmup", "3"]), ("se", ["--se", "--steps", "3", "--warmup", "1"]),
+                        ("transformer", ["--transformer", "--steps", "8", "--warmup", "3"])):
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + flags, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = dict(error=("exit %d: " % r.returncode) + r.stderr[-300:])
+                continue
+            d = json.loads(line[-1])
+            roof = d.get("roofline_model") if name == "transformer" else d.get("roofline")
+            keep = dict(metric=d["metric"], workload=d.get("config", {}).get("workload"), value=d["value"], unit=d.get("unit"),
+                        ms_per_step=d["ms_per_step"], steps=d["steps"], dtype=d.get("dtype"),
+                        roofline=None if roof is None else {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")},
+                        cpu_baseline=d.get("cpu_baseline"), parity=d.get("parity"), wall_s=round(time.time() - t0, 1))
+            if name == "transformer":
+                keep["roofline_denominator"] = {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_frame")}
+                keep["breakdown_ms"] = d.get("breakdown_ms")
+            if name == "se":
+                keep["lattice_ms"] = d.get("lattice_ms")
+            out[name] = keep
+        except subprocess.TimeoutExpired:
+            out[name] = dict(error="exceeded 420 s")
+        log("secondary %s done (%.0f s)" % (name, time.time() - t0))
+    return out
 
 
 def log(msg):
@@ -635,12 +825,16 @@ def main():
         return cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-ce-worker":
         return cpu_ce_worker(int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-se-worker":
+        return cpu_se_worker(int(sys.argv[3]), sys.argv[4])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short child runs of configs[1], [3], [4] that the default "
+                    "one-GPU run appends to its line as `secondary`")
     ap.add_argument("--reserve-gb", type=int, default=None, help="HBM handed to the caching allocator in one piece at start-up "
                     "(0: let it grow lazily; default 12, --se 48: their runs peak at 8 / 33 GB)")
     ap.add_argument("--length-bucketed", action="store_true", help="N > 1: every rank draws the same utterance lengths "
@@ -762,6 +956,8 @@ def main():
                            np.random.default_rng(1234) if args.length_bucketed else None)
     log("%d minibatches ready" % n_unique)
     tr = Trainer(dev, den, arch="transformer" if args.transformer else "blstm")
+    if args.transformer:
+        os.environ["PK2_BENCH_ARCH"] = "transformer"      # the cpu-baseline child runs the same architecture
 
     # world > 1: hvd times its two gradient-exchange schedules against each other during the first steps of a job (with a
     # host synchronisation per step).  That calibration is start-up work, like building the graphs: it is run to its end
@@ -858,7 +1054,8 @@ def main():
                          ms=round(lstm_ms, 3), flops_per_frame_fwd_bwd=3 * lstm_flops_per_frame(),
                          input_projection_gemm=gemm_mfma_roofline(dev, len(lens) * max(lens)))
     result = {
-        "metric": "iRTF (hrs audio/hr) 3x512 BLSTM LF-MMI, LibriSpeech-shaped synthetic utterances",
+        "metric": ("iRTF (hrs audio/hr) 12-layer TransformerAM LF-MMI (secondary workload, configs[4])" if args.transformer else
+                   "iRTF (hrs audio/hr) 3x512 BLSTM LF-MMI, LibriSpeech-shaped synthetic utterances"),
         "value": round(audio / dt, 2), "unit": "hours of audio per wall-clock hour",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -896,6 +1093,12 @@ def main():
     else:
         result["cpu_baseline"] = None
         result["parity"] = None
+    # the other BASELINE configurations, as short child jobs behind the headline (one GPU, default workload only)
+    if world == 1 and not (args.no_secondary or args.no_cpu_baseline or args.transformer or args.den_states or args.den_arcs
+                           or args.den_topology or args.batch != 4 or "RANK" in os.environ):
+        del tr, batches
+        torch.cuda.empty_cache()
+        result["secondary"] = run_secondaries()
     print(json.dumps(result), flush=True)
     hvd.shutdown()
 

@@ -572,6 +572,18 @@ int pk2_allreduce_guarded(pk2_comm* comm, float* buf, int64_t count, float* guar
 int pk2_comm_info(const pk2_comm* comm, int32_t* rank, int32_t* world, char* lib_path, int32_t lib_path_bytes);
 int pk2_comm_destroy(pk2_comm* comm);
 
+/* ------------------------------------------------------------------------------------------------
+ * Side streams confined to a part of the chip (no reference counterpart: cuBLAS / cuDNN own the whole GPU).  The weight
+ * gradients of a layer hang off the serial chain of the backward pass (reference models/lstm.py:49-58 through autograd);
+ * pykaldi2_amd.lstm can launch them on a side stream (PK2_SIDE_STREAM=1), and with PK2_SIDE_CU_PER_XCD=k that stream is
+ * created with a CU mask: the first k CUs of every XCD (hipExtStreamCreateWithCUMask; mask bit i = CU i / 8 of XCD i % 8 on
+ * this 8-XCD part -- pk2_debug_where reports where the workgroups of a launch really ran).
+ * ---------------------------------------------------------------------------------------------- */
+int pk2_stream_create_cu_mask(int32_t cus_per_xcd, void** stream_out);
+int pk2_stream_destroy(void* stream);
+/* out[3 * b + {0, 1, 2}] = XCC id, shader engine, CU of workgroup b of a `blocks`-workgroup launch on `stream` (HW_ID). */
+int pk2_debug_where(int32_t* out, int32_t blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,13 @@ def lib(double=False):
     if double not in _libs:
         _libs[double] = C.CDLL(build_oracle.build(double))
         _libs[double].orc_den_fb.restype = C.c_double
+        _libs[double].orc_set_beta_seed.argtypes = [C.c_double]
     return _libs[double]
+
+
+def set_beta_seed(v, double=False):
+    """Test hook (tests of the abandon rule): beta'[T] = v / tot; 1.0 restores Kaldi's seed."""
+    lib(double).orc_set_beta_seed(C.c_double(v))
 
 
 def _p(a):

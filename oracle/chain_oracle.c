@@ -25,6 +25,11 @@
 #endif
 typedef ORC_REAL real;
 
+/* Test hook: beta'[T] = seed / tot instead of 1 / tot (scales the alpha-beta product of the consistency check: the tests
+ * of the abandon rule drive it on real inputs through this).  1.0 = Kaldi. */
+static double g_beta_seed = 1.0;
+void orc_set_beta_seed(double v) { g_beta_seed = v > 0.0 ? v : 1.0; }
+
 double orc_den_fb(int S, int P, int64_t A, const int32_t* src, const int32_t* dst, const int32_t* pdf,
                   const float* prob, const float* pi, const float* logits, int64_t row_stride, int T,
                   float leaky, float scale, float* gamma, int64_t grow_stride, double* check) {
@@ -60,7 +65,7 @@ double orc_den_fb(int S, int P, int64_t A, const int32_t* src, const int32_t* ds
   logp += log(tot);
   /* beta */
   double pb = 0.0;
-  for (int h = 0; h < S; ++h) { bnext[h] = (real)(1.0 / tot); pb += (double)pi[h] * bnext[h]; }
+  for (int h = 0; h < S; ++h) { bnext[h] = (real)(g_beta_seed / tot); pb += (double)pi[h] * bnext[h]; }
   for (int h = 0; h < S; ++h) bnext[h] += (real)leaky * (real)pb;
   for (int t = T - 1; t >= 0; --t) {
     const float* row = logits + (int64_t)t * row_stride;

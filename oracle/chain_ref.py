@@ -60,6 +60,9 @@ def initial_probs_ref(S, src, dst, prob, start, iters=100):
     return avg
 
 
+BETA_SEED = 1.0     # test hook: beta'[T] = BETA_SEED / tot (tests of the abandon rule on real inputs); 1.0 = Kaldi
+
+
 def den_forward_backward(logits, g, leaky, dtype=np.float64):
     """Denominator forward-backward, probability space with per-frame rescaling.
 
@@ -98,7 +101,7 @@ def den_forward_backward(logits, g, leaky, dtype=np.float64):
     logprob = np.log(np.float64(tot)) + np.log(asum[:T].astype(np.float64)).sum()
 
     gamma = np.zeros((T, P), dtype=dtype)
-    beta_dash = np.full(S, 1.0 / tot, dtype=dtype)
+    beta_dash = np.full(S, BETA_SEED / tot, dtype=dtype)
     beta = beta_dash + ell * (pi * beta_dash).sum()
     for t in range(T - 1, -1, -1):
         f = prob * x[t][g.pdf] * beta[g.dst] / asum[t]

@@ -141,6 +141,9 @@ SIGNATURES = {
     "pk2_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32,
                                 _vp, _f32, _vp]),
     "pk2_sgd_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _f32, _vp, _f32, _vp]),
+    "pk2_stream_create_cu_mask": (C.c_int, [_i32, C.POINTER(_vp)]),
+    "pk2_stream_destroy": (C.c_int, [_vp]),
+    "pk2_debug_where": (C.c_int, [_vp, _i32, _vp]),
 }
 
 _lib = None

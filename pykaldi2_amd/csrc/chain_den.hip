@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum
   const size_t f0 = (size_t)g * (p.Tmax + 1);
   for (int t = T + 1 + tid; t <= p.Tmax; t += 256) Kf[(f0 + t) * NG + n] = 0.f;
   if (T <= 0) { if (tid == 0) check[g * NG + n] = 1.f; return; }
-  const double lkT = log((double)p.pi_sum) + log((double)p.inv_tot[g * NG + n]);
+  const double lkT = log((double)p.pi_sum) + log((double)p.inv_tot[g * NG + n]) + log((double)p.beta_seed);
   if (tid == 0) { Kf[(f0 + T) * NG + n] = (float)exp(lkT); carry_s = lkT; }
   __syncthreads();
   // walk t = T-1 .. 0 in tiles of 256 (thread i of a tile handles t = hi - i)
@@ -1431,6 +1431,8 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   p.S = g->S; p.P = g->P; p.Tmax = Tmax;
   p.leaky = leaky; p.pi_sum = (float)g->pi_sum; p.wu = (float)(kBetaFloor * g->pi_sum / g->S);
   p.debug = getenv("PK2_DEN_DEBUG") ? atoi(getenv("PK2_DEN_DEBUG")) : 0;
+  p.beta_seed = 1.0f;
+  if (const char* env = getenv("PK2_DEN_DEBUG_BETA_SEED")) { const float v = (float)atof(env); if (v > 0.f) p.beta_seed = v; }
   if (persist) { p.fwd.n_chunks = kPR; p.bwd.n_chunks = kPR; }     // partial sums per frame: one per workgroup of a team
 
   const size_t lds = den_lds_bytes(g->P, NG);

@@ -51,6 +51,8 @@ struct DenParams {
   float wu;    // kBetaFloor * sum(pi)/S: uniform floor of the backward normaliser's weights (state-x path)
   int brec;    // floats per beta record and sequence: 2 = {btilde', x} (frame kernels, first persistent kernel), 1 = btilde' alone
                // (second persistent kernel, round 4: nobody reads the x halves there; the occupancy pass gathers half the lines)
+  float beta_seed;   // test hook (PK2_DEN_DEBUG_BETA_SEED, default 1): beta'(T) = beta_seed / tot -- scales every beta, the occupancies
+                     // and the alpha-beta consistency product, so that a test can drive the abandon rule on real inputs
   int debug;   // PK2_DEN_DEBUG ablation bits (profiling only): 1 = all gathers hit state 0, 2 = skip the arc loop, 4 = load half of the arc records
 };
 

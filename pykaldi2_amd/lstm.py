@@ -316,9 +316,20 @@ class LSTMAM(nn.Module):
         return seg("weight_ih", in_size), seg("weight_hh", H), seg("bias_ih", 1), seg("bias_hh", 1)
 
     def _side_stream(self, dev):
+        """The stream of the weight-gradient products under PK2_SIDE_STREAM=1; with PK2_SIDE_CU_PER_XCD=k a stream whose
+        kernels only get the first k CUs of every XCD (pk2_stream_create_cu_mask), so that they share fewer CUs with the
+        one-launch recurrences of the main stream (measured, round 5)."""
         st = getattr(self, "_side", None)
         if st is None or st.device != dev:
-            st = torch.cuda.Stream(device=dev)
+            k = int(os.environ.get("PK2_SIDE_CU_PER_XCD", "0"))
+            if k > 0:
+                h = ctypes.c_void_p()
+                with torch.cuda.device(dev):
+                    _lib.check(_lib.lib().pk2_stream_create_cu_mask(k, ctypes.byref(h)))
+                st = torch.cuda.ExternalStream(h.value, device=dev)
+                self._side_handle = h        # (lives as long as the model)
+            else:
+                st = torch.cuda.Stream(device=dev)
             self._side = st
         return st
 

@@ -217,9 +217,45 @@ def test_alpha_beta_guard_follows_kaldis_rule():
     for n in range(N):
         want = 0.5 * (num[n] - den[n]) if want_ok[n] else -10.0 * 0.5 * lens[n]
         assert got[n] == np.float32(want), (n, got[n], want)
-    # the float64 numpy oracle applies the same rule
-    for c, ok in ((1.5, True), (2.9, True), (3.1, False)):
-        assert (abs(c - 1.0) <= 2.0) == ok
+
+
+@pytest.mark.parametrize("seed,ok", [(1.06, True), (1.5, True), (2.9, True), (3.1, False), (40.0, False)])
+def test_alpha_beta_guard_product_and_both_oracles_on_the_same_input(seed, ok, monkeypatch):
+    """the abandon rule on REAL inputs, product, numpy oracle and C oracle side by side.  A healthy sequence
+    has an alpha-beta product of 1; the three implementations share a test hook that seeds the backward recursion with
+    beta'(T) = seed / tot, which scales every beta -- and so the product of the consistency check, exactly -- by `seed`:
+    products inside (0.05, 2] of 1 are trained on (with occupancies scaled like everything else), beyond 2.0 the sequence is
+    abandoned (-10 per frame, zero gradient).  Kaldi compares with num_sequences; the reference calls once per utterance
+    (ops/ops.py:265), i.e. num_sequences = 1: the per-sequence rule here."""
+    from oracle import chain_c
+    S, A, P = 200, 3000, 40
+    g, G, ref = _mk(S, A, P, seed=5, **_KIND["chain_topology"])
+    rng = np.random.default_rng(4)
+    sups = [_sup(synth.pdf_alignment(rng, T, P), P) for T in (91, 55)]
+    lens = [s.frames_per_sequence for s in sups]
+    lg = rng.normal(0, 2, size=(2, max(lens), P)).astype(np.float32)
+    opts = chain.ChainTrainingOptions(leaky_hmm_coefficient=1e-4, xent_regularize=0.1)
+    pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64), g["prob"].astype(np.float64), 0)
+    monkeypatch.setenv("PK2_DEN_DEBUG_BETA_SEED", repr(seed))
+    monkeypatch.setattr(R, "BETA_SEED", seed)
+    chain_c.set_beta_seed(seed, double=True)
+    try:
+        out, grad = chain.compute_chain_objf_and_deriv(opts, G, sups, torch.from_numpy(lg).cuda())
+        c_out, c_grad = chain_c.chain_batch(g, pi, lg, sups, 1e-4, 0.1, double=True)
+    finally:
+        chain_c.set_beta_seed(1.0, double=True)
+    out, grad = out.cpu().numpy(), grad.cpu().numpy()
+    for n, s in enumerate(sups):
+        T = lens[n]
+        objf, want, aux = R.chain_objf_and_deriv(lg[n, :T].astype(np.float64), ref, _ref_fst(s), leaky=1e-4, xent_regularize=0.1)
+        assert aux["ok"] == ok and abs(aux["check"] - seed) < 1e-6 * seed          # the hook scales the product exactly
+        if ok:
+            assert abs(out[0, n] - objf) <= 1e-3 * abs(objf) and abs(c_out[0, n] - objf) <= 1e-9 * abs(objf)
+            assert np.abs(grad[n, :T] - want).max() < 1e-4 * max(1.0, seed) and np.abs(c_grad[n, :T] - want).max() < 1e-5 * max(1.0, seed)
+            assert np.abs(want).max() > 0.1                      # (a real gradient, scaled occupancies and all)
+        else:
+            assert out[0, n] == -10.0 * T and c_out[0, n] == -10.0 * T and objf == -10.0 * T
+            assert not grad[n].any() and not c_grad[n].any() and not want.any()
 
 
 def test_persistent_kernel_more_recursions_than_teams():
