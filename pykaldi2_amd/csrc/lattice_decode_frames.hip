@@ -917,8 +917,20 @@ __global__ void __launch_bounds__(256) lat_link_delta(const DecodeParams p) {
   }
 }
 
+// Round 5: __syncthreads() / __syncthreads_or() are workgroup-scope release / acquire fences -- each waits for every
+// outstanding global load of the wave (s_waitcnt vmcnt(0)), i.e. for the link records fetched ahead "to land while the
+// rounds run": they were waited for at the first round's barrier instead.  Frames whose extra costs live in LDS exchange
+// nothing through memory: their barriers order LDS accesses only, the "did any lane lower a value" vote goes through three
+// rotating LDS words (one barrier per round), and the epsilon records of frame t-1 are requested as soon as the rounds of
+// frame t are over (they land under the write-back, the initialisation and the emitting links).
+__device__ __forceinline__ void fin_barrier(bool lds_only) {
+  if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
 __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodeParams p, int cap) {
   __shared__ float s_redf[kLatWaves];
+  __shared__ int s_vote[3];
   const int n = blockIdx.x, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
   const UttView V = make_view(p, n, U);
@@ -939,17 +951,55 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
   bool a_lds = cnt <= cap;               // a frame with more tokens (frame 0: one per word) is worked on in global memory
   if (a_lds)
     for (int i = tid; i < cnt; i += kLatThreads) A[i] = teu[base + i];
+  if (tid < 3) s_vote[tid] = 0;
   __syncthreads();
+  int vote_round = 0;
+  // "did any thread of the workgroup change a value" with ONE LDS-only barrier: the word of round r + 1 was last read in
+  // round r - 2, before every thread's arrival at the barrier of round r - 1 -- thread 0 may clear it in round r
+  auto any_changed = [&](int changed) -> bool {
+    const int r = vote_round % 3;
+    if (changed) s_vote[r] = 1;
+    if (tid == 0) s_vote[(vote_round + 1) % 3] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ++vote_round;
+    return s_vote[r] != 0;
+  };
 #ifdef PK2_LAT_FIN_DEBUG
   long long ph[6] = {0, 0, 0, 0, 0, 0}, last = wall_clock64(); int nrounds = 0;
 #define FIN_T(k) do { __syncthreads(); const long long now_ = wall_clock64(); ph[k] += now_ - last; last = now_; } while (0)
 #else
 #define FIN_T(k) do { } while (0)
 #endif
+  // The segment bounds of a frame are loaded one frame before its records are requested (the address of a record load
+  // would otherwise wait for them on the spot): sc = frame t's {first emitting link t-1 -> t, first epsilon link, end of the
+  // epsilon links, first token of frame t-1}.
+  struct FinSc { int m0, e0, e1, pb; };
+  auto load_sc = [&](int t, FinSc& c) {
+    c.m0 = c.e0 = c.e1 = c.pb = 0;
+    if (t < 0) return;
+    if (t > 0) { c.m0 = V.seg[2 * t - 1]; c.pb = V.ftok[t - 1]; }
+    c.e0 = V.seg[2 * t]; c.e1 = V.seg[2 * t + 1];
+  };
+  FinSc sc, scn;
+  load_sc(T, sc);
+  // epsilon links inside a frame, the first kFinEps per thread (relative to the frame's first token)
+  int es[kFinEps], ed[kFinEps]; float el[kFinEps];
+  int e0 = 0, e1 = 0;
+  auto load_eps = [&](const FinSc& c, int tbase) {
+    e0 = c.e0; e1 = c.e1;
+#pragma unroll
+    for (int q = 0; q < kFinEps; ++q) {
+      const int l = e0 + tid + q * kLatThreads;
+      es[q] = -1; ed[q] = 0; el[q] = 0.f;
+      if (l < e1) { const int4 r = V.lrec[l]; es[q] = r.x - tbase; ed[q] = r.y - tbase; el[q] = delta[l]; }
+    }
+  };
+  load_eps(sc, base);
   for (int t = T; t >= 0; --t) {
+    load_sc(t - 1, scn);
     // the emitting links t-1 -> t do not depend on the epsilon rounds below: their loads are issued first and land
     // while the rounds run (one exposed round trip to memory per frame instead of two)
-    const int m0 = t > 0 ? V.seg[2 * t - 1] : 0, m1 = t > 0 ? V.seg[2 * t] : 0;
+    const int m0 = t > 0 ? sc.m0 : 0, m1 = t > 0 ? sc.e0 : 0;
     int2 mr[kFinEmit]; float md[kFinEmit];
 #pragma unroll
     for (int q = 0; q < kFinEmit; ++q) {
@@ -958,15 +1008,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
       if (l < m1) { mr[q] = *reinterpret_cast<const int2*>(&V.lrec[l]); md[q] = delta[l]; }
     }
     // epsilon links inside frame t, to the fixed point
-    const int e0 = V.seg[2 * t], e1 = V.seg[2 * t + 1];
     if (e1 > e0 && a_lds) {
-      int es[kFinEps], ed[kFinEps]; float el[kFinEps];
-#pragma unroll
-      for (int q = 0; q < kFinEps; ++q) {
-        const int l = e0 + tid + q * kLatThreads;
-        es[q] = -1; ed[q] = 0; el[q] = 0.f;
-        if (l < e1) { const int4 r = V.lrec[l]; es[q] = r.x - base; ed[q] = r.y - base; el[q] = delta[l]; }
-      }
       auto relax = [&](int s, int d, float dl) -> int {
         const float x = __uint_as_float(A[d]);
         if (x < INFINITY) {
@@ -983,6 +1025,12 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
       };
       for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
         int changed = 0;
+        // One dependent LDS chain per link, with its early exits: most links of a round fail the first test (their destination
+        // has no finite extra cost yet, or the sum leaves the lattice beam).  Measured and dropped in round 5
+        // (profiles/r05_lat.txt): the same links as straight-line batches -- all gathers, all candidates, all compares, then
+        // the ds_min's -- 7.3 us per frame for the rounds against 5.5 (the batches pay every LDS read the exits skip);
+        // and, on top, a wave whose 64 links all enter ONE token (the word-loop state: a link per word) reducing them
+        // with DPP moves into a single ds_min: 8.0 us (the `k < A[s]` guard already keeps most of them from being issued).
 #pragma unroll
         for (int q = 0; q < kFinEps; ++q)
           if (es[q] >= 0) changed |= relax(es[q], ed[q], el[q]);
@@ -993,7 +1041,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
 #ifdef PK2_LAT_FIN_DEBUG
         ++nrounds;
 #endif
-        if (!__syncthreads_or(changed)) break;
+        if (!any_changed(changed)) break;
       }
     } else if (e1 > e0) {
       for (int rounds = 0; rounds < kMaxEpsRounds; ++rounds) {
@@ -1019,11 +1067,12 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
       for (int i = tid; i < cnt; i += kLatThreads) teu[base + i] = A[i];
     FIN_T(1);
     if (t > 0) {
-      const int pbase = V.ftok[t - 1], pcnt = base - pbase;
+      const int pbase = sc.pb, pcnt = base - pbase;
       const bool b_lds = pcnt <= cap;
+      load_eps(scn, pbase);              // the epsilon records of the frame before: requested now, used after the emitting links
       if (b_lds)
         for (int i = tid; i < pcnt; i += kLatThreads) B[i] = 0x7f800000u;
-      __syncthreads();
+      fin_barrier(a_lds && b_lds);
       FIN_T(2);
       // emitting links t-1 -> t
       auto emit = [&](int s, int d, float dl) {
@@ -1035,17 +1084,39 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodePar
           if (b_lds) { if (k < B[s - pbase]) atomicMin(&B[s - pbase], k); } else atomicMin(&teu[s], k);
         }
       };
+      if (a_lds && b_lds) {
+        // (round 5) straight-line batches: all gathers of the destination tokens' extra costs, all candidates, all compares
+        // against the source tokens' current values, then the ds_min's that would lower one
+        uint32_t xd[kFinEmit], kq[kFinEmit], cur[kFinEmit];
 #pragma unroll
-      for (int q = 0; q < kFinEmit; ++q)
-        if (m0 + tid + q * kLatThreads < m1) emit(mr[q].x, mr[q].y, md[q]);
+        for (int q = 0; q < kFinEmit; ++q) {
+          const bool have = m0 + tid + q * kLatThreads < m1;
+          xd[q] = have ? A[mr[q].y - base] : 0x7f800000u;
+        }
+#pragma unroll
+        for (int q = 0; q < kFinEmit; ++q) {
+          const float x = __uint_as_float(xd[q]), le = x + md[q];
+          kq[q] = (m0 + tid + q * kLatThreads < m1 && x < INFINITY && le <= lbeam) ? __float_as_uint(fmaxf(le, 0.f)) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < kFinEmit; ++q) cur[q] = kq[q] != 0xFFFFFFFFu ? B[mr[q].x - pbase] : 0u;
+#pragma unroll
+        for (int q = 0; q < kFinEmit; ++q)
+          if (kq[q] < cur[q]) atomicMin(&B[mr[q].x - pbase], kq[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < kFinEmit; ++q)
+          if (m0 + tid + q * kLatThreads < m1) emit(mr[q].x, mr[q].y, md[q]);
+      }
       for (int l = m0 + tid + kFinEmit * kLatThreads; l < m1; l += kLatThreads) {
         const int2 r = *reinterpret_cast<const int2*>(&V.lrec[l]);
         emit(r.x, r.y, delta[l]);
       }
-      __syncthreads();
+      fin_barrier(a_lds && b_lds);
       FIN_T(3);
       uint32_t* tmp = A; A = B; B = tmp;
       base = pbase; cnt = pcnt; a_lds = b_lds;
+      sc = scn;
     }
   }
 #ifdef PK2_LAT_FIN_DEBUG

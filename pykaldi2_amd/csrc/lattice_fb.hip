@@ -125,12 +125,19 @@ __device__ __forceinline__ double final_like(const FbParams& p, const FbView& v,
 
 // alpha (workgroup x = 0) and beta (x = 1) are independent recursions: they run side by side.  x = 0 also leaves the
 // total log-likelihood in the utterance's frame state.
-// The values of the frame being ACCUMULATED live in LDS (one array of doubles; the log-adds are 64-bit LDS
-// compare-and-swaps, the epsilon levels of the frame never leave the CU); a finished frame is written back, and the
-// next frame reads its sources from there.  A frame with more than `cap` tokens (frame 0: a token per word) is
-// accumulated in global memory as before.  (With everything in global memory a frame cost ~14 us of dependent round
-// trips and CAS loops through L2.)
-constexpr int kFbEps = 4;       // epsilon links per thread kept in registers over the levels of a frame
+// The values of the frame being ACCUMULATED live in LDS (an array of doubles; the log-adds are 64-bit LDS
+// compare-and-swaps, the epsilon levels of the frame never leave the CU); a finished frame is written back for the
+// posterior pass.  A frame with more than `cap` tokens (frame 0: a token per word) is accumulated in global memory.
+// (With everything in global memory a frame cost ~14 us of dependent round trips and CAS loops through L2.)
+// Round 5 (18 ms per step on this chain, 7.5 us per frame and direction): a frame was still a string of
+// exposed round trips -- link records loaded when the frame began, then the source values of the frame before gathered
+// from global memory behind them, then the epsilon records and, behind those, their levels.  Now
+//  * TWO frames live in LDS: the one being accumulated and the one before it, which the emitting links gather from
+//    (cap = half the array each; a frame with more tokens takes the global path as before, per frame);
+//  * the link records of the NEXT frame (emitting links, epsilon links and their levels, the frame's bounds) are loaded
+//    one frame ahead into registers: the chain of a frame is LDS traffic, barriers and the write-back stores.
+constexpr int kFbEps = 2;       // epsilon links per thread kept in registers over the levels of a frame (a pruned lattice keeps ~1.5 links per thread and frame)
+constexpr int kFbEmit = 2;      // emitting links per thread loaded a frame ahead
 extern __shared__ __attribute__((aligned(16))) double lat_fb_smem[];
 
 __device__ __forceinline__ void lds_log_add(double* addr, double v) {
@@ -144,9 +151,22 @@ __device__ __forceinline__ void lds_log_add(double* addr, double v) {
   } while (old != assumed);
 }
 
+// __syncthreads() is a workgroup-scope release / acquire: it waits for EVERY outstanding global load of the wave first
+// (s_waitcnt vmcnt(0)) -- also for the records loaded a frame ahead, which would then be waited for where they were
+// issued.  Between phases that only exchange data through LDS the barrier orders LDS accesses alone.
+__device__ __forceinline__ void fb_barrier(bool lds_only) {
+  if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
+// The bounds of a frame (its tokens, its emitting and epsilon link segments, its epsilon depth): loaded TWO frames ahead, so
+// that the record loads of the next frame can be issued without waiting for them.
+struct FbSc { int base, cnt, m0, m1, e0, e1, nlev; };
+struct FbEmit { int m0, m1; int src[kFbEmit], dst[kFbEmit]; double like[kFbEmit]; };
+struct FbEpsR { int e0, e1, nlev; int src[kFbEps], dst[kFbEps], lev[kFbEps]; double like[kFbEps]; };
+
 __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int cap) {
   __shared__ double red[kFbWaves];
-  double* cur = lat_fb_smem;
   const int n = blockIdx.y, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
   if (U.status != kLatOk) { if (tid == 0 && blockIdx.x == 0) p.out[n] = NAN; return; }
@@ -155,63 +175,111 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
   const int fT0 = v.ftok[T], fT1 = v.ftok[T + 1];
   const bool fwd = blockIdx.x == 0;
   double* val = fwd ? v.alpha : v.beta;          // the recursion's values in global memory
+  double* A = lat_fb_smem;                       // the frame being accumulated / finished
+  double* P = lat_fb_smem + cap;                 // its neighbour: the frame before it (alpha), the one being built (beta)
   for (int i = tid; i < v.nt; i += kFbThreads) { val[i] = -INFINITY; (fwd ? v.af : v.ab)[i] = 0.0; }
   if (fwd)
     for (int t = tid; t < T; t += kFbThreads) v.ref_post[t] = 0.0;
   __syncthreads();
-  // Epsilon links of frame t inside the LDS array (or global memory), level by level; dir = +1: source level ascending
-  // and values flow src -> dst (alpha), -1: descending and dst -> src (beta).
-  auto eps_levels = [&](int t, int base, bool lds) {
-    const int e0 = v.seg[2 * t], e1 = e0 + v.kept[2 * t];
-    const int nlev = v.maxlev[t];
-    if (nlev <= 0 || e1 <= e0) return;
-    int es[kFbEps], ed[kFbEps], el[kFbEps]; double ek[kFbEps];
+  auto load_sc = [&](int t, FbSc& c) {
+    c.base = c.cnt = c.m0 = c.m1 = c.e0 = c.e1 = c.nlev = 0;
+    if (t < 0 || t > T) return;
+    c.base = v.ftok[t]; c.cnt = v.ftok[t + 1] - c.base;
+    if (t > 0) { c.m0 = v.seg[2 * t - 1]; c.m1 = c.m0 + v.kept[2 * t - 1]; }
+    c.e0 = v.seg[2 * t]; c.e1 = c.e0 + v.kept[2 * t]; c.nlev = v.maxlev[t];
+  };
+  // the emitting links t-1 -> t (segment 2t-1), the first kFbEmit per thread
+  auto load_emit = [&](const FbSc& c, FbEmit& m) {
+    m.m0 = c.m0; m.m1 = c.m1;
+#pragma unroll
+    for (int q = 0; q < kFbEmit; ++q) {
+      const int l = m.m0 + tid + q * kFbThreads;
+      m.src[q] = -1; m.dst[q] = 0; m.like[q] = 0.0;
+      if (l < m.m1) { const int4 r = v.lrec[l]; m.src[q] = r.x; m.dst[q] = r.y; m.like[q] = link_like(p, v, r, l); }
+    }
+  };
+  // the epsilon links inside frame t (segment 2t), the first kFbEps per thread -- and, in a second step issued later (the
+  // gather needs the record: issued right behind it, the wave would wait for the record on the spot), the level of each
+  // link's source token
+  auto load_eps = [&](const FbSc& c, FbEpsR& e) {
+    e.e0 = c.e0; e.e1 = c.e1; e.nlev = c.nlev;
 #pragma unroll
     for (int q = 0; q < kFbEps; ++q) {
-      const int l = e0 + tid + q * kFbThreads;
-      es[q] = -1; ed[q] = 0; el[q] = -1; ek[q] = 0.0;
-      if (l < e1) { const int4 r = v.lrec[l]; es[q] = r.x; ed[q] = r.y; el[q] = v.tl[r.x]; ek[q] = link_like(p, v, r, l); }
+      const int l = e.e0 + tid + q * kFbThreads;
+      e.src[q] = -1; e.dst[q] = 0; e.lev[q] = -1; e.like[q] = 0.0;
+      if (e.nlev > 0 && l < e.e1) { const int4 r = v.lrec[l]; e.src[q] = r.x; e.dst[q] = r.y; e.like[q] = link_like(p, v, r, l); }
     }
+  };
+  auto load_eps_levels = [&](FbEpsR& e) {
+#pragma unroll
+    for (int q = 0; q < kFbEps; ++q)
+      if (e.src[q] >= 0) e.lev[q] = v.tl[e.src[q]];
+  };
+  // Epsilon links of frame t inside the LDS array A (or global memory), level by level; alpha: source level ascending and
+  // values flow src -> dst, beta: descending and dst -> src.
+  auto eps_levels = [&](const FbEpsR& e, int base, bool lds) {
+    if (e.nlev <= 0 || e.e1 <= e.e0) return;
     auto one = [&](int s, int d, double like) {
       const int from = fwd ? s : d, to = fwd ? d : s;
-      if (lds) lds_log_add(&cur[to - base], cur[from - base] + like);
+      if (lds) lds_log_add(&A[to - base], A[from - base] + like);
       else atomic_log_add(&val[to], ldc(&val[from]) + like);
     };
-    for (int k = 0; k < nlev; ++k) {
-      const int lev = fwd ? k : nlev - 1 - k;
+    for (int k = 0; k < e.nlev; ++k) {
+      const int lev = fwd ? k : e.nlev - 1 - k;
 #pragma unroll
       for (int q = 0; q < kFbEps; ++q)
-        if (es[q] >= 0 && el[q] == lev) one(es[q], ed[q], ek[q]);
-      for (int l = e0 + tid + kFbEps * kFbThreads; l < e1; l += kFbThreads) {
+        if (e.src[q] >= 0 && e.lev[q] == lev) one(e.src[q], e.dst[q], e.like[q]);
+      for (int l = e.e0 + tid + kFbEps * kFbThreads; l < e.e1; l += kFbThreads) {
         const int4 r = v.lrec[l];
         if (v.tl[r.x] == lev) one(r.x, r.y, link_like(p, v, r, l));
       }
-      __syncthreads();
+      fb_barrier(lds);
     }
   };
+  FbEmit cm, nm; FbEpsR ce, ne;
+  FbSc s0, s1, s2;               // the frame at hand, the next one, the one after it (in the direction of the recursion)
   if (fwd) {
+    load_sc(0, s0); load_sc(1, s1);
+    load_emit(s0, cm);           // (frame 0 has no emitting links: empty)
+    load_eps(s0, ce);
+    load_eps_levels(ce);
+    int pbase = 0; bool plds = false;
     for (int t = 0; t <= T; ++t) {
-      const int base = v.ftok[t], cnt = v.ftok[t + 1] - base;
+      const int base = s0.base, cnt = s0.cnt;
       const bool lds = cnt <= cap;
       if (lds)
-        for (int i = tid; i < cnt; i += kFbThreads) cur[i] = (t == 0 && i == 0) ? 0.0 : -INFINITY;
+        for (int i = tid; i < cnt; i += kFbThreads) A[i] = (t == 0 && i == 0) ? 0.0 : -INFINITY;
       else if (t == 0 && tid == 0)
         val[0] = 0.0;
-      __syncthreads();
+      load_sc(t + 2, s2);            // bounds two frames ahead, records one frame ahead: on their way while this frame is worked on
+      load_emit(s1, nm);
+      load_eps(s1, ne);
+      fb_barrier(lds);
       if (t > 0) {
-        const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
-        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+        auto push = [&](int s, int d, double like) {
+          const double x = (plds ? P[s - pbase] : ldc(&val[s])) + like;
+          if (lds) lds_log_add(&A[d - base], x); else atomic_log_add(&val[d], x);
+        };
+#pragma unroll
+        for (int q = 0; q < kFbEmit; ++q)
+          if (cm.src[q] >= 0) push(cm.src[q], cm.dst[q], cm.like[q]);
+        for (int l = cm.m0 + tid + kFbEmit * kFbThreads; l < cm.m1; l += kFbThreads) {
           const int4 r = v.lrec[l];
-          const double x = ldc(&val[r.x]) + link_like(p, v, r, l);
-          if (lds) lds_log_add(&cur[r.y - base], x); else atomic_log_add(&val[r.y], x);
+          push(r.x, r.y, link_like(p, v, r, l));
         }
-        __syncthreads();
+        fb_barrier(lds);
       }
-      eps_levels(t, base, lds);
+      eps_levels(ce, base, lds);
+      load_eps_levels(ne);         // (the records have arrived by now)
       if (lds)
-        for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = cur[i];
-      __syncthreads();          // (the frame's values are in memory before the next frame gathers them)
+        for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = A[i];        // (for the posterior pass: nobody here waits for it)
+      else
+        __syncthreads();        // a frame on the global path: its values are in memory before the next frame gathers them
+      double* tmp = A; A = P; P = tmp;
+      pbase = base; plds = lds;
+      cm = nm; ce = ne; s0 = s1; s1 = s2;
     }
+    __syncthreads();             // the last frame's values are in memory
     // total likelihood over the final tokens (stable log-sum-exp)
     double mx = -INFINITY;
     for (int i = fT0 + tid; i < fT1; i += kFbThreads)
@@ -227,28 +295,42 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
     bool lds = cnt <= cap;
     for (int i = tid; i < cnt; i += kFbThreads) {
       const double b0 = v.tf[base + i] < INFINITY ? final_like(p, v, base + i) : -INFINITY;
-      if (lds) cur[i] = b0; else val[base + i] = b0;
+      if (lds) A[i] = b0; else val[base + i] = b0;
     }
+    load_sc(T, s0); load_sc(T - 1, s1);
+    load_eps(s0, ce);
+    load_eps_levels(ce);
+    load_emit(s0, cm);
     __syncthreads();
     for (int t = T; t >= 0; --t) {
-      eps_levels(t, base, lds);
+      load_sc(t - 2, s2);
+      load_eps(s1, ne);              // the records of frame t-1: on their way while this frame is finished
+      load_emit(s1, nm);
+      eps_levels(ce, base, lds);
+      load_eps_levels(ne);
       if (lds)
-        for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = cur[i];
-      __syncthreads();
+        for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = A[i];
       if (t > 0) {
-        const int pbase = v.ftok[t - 1], pcnt = base - pbase;
+        const int pbase = s1.base, pcnt = s1.cnt;
         const bool plds = pcnt <= cap;
         if (plds)
-          for (int i = tid; i < pcnt; i += kFbThreads) cur[i] = -INFINITY;
-        __syncthreads();
-        const int m0 = v.seg[2 * t - 1], m1 = m0 + v.kept[2 * t - 1];
-        for (int l = m0 + tid; l < m1; l += kFbThreads) {
+          for (int i = tid; i < pcnt; i += kFbThreads) P[i] = -INFINITY;
+        fb_barrier(lds && plds);  // (P is initialised; a frame on the global path: its values are in memory)
+        auto push = [&](int s, int d, double like) {
+          const double x = (lds ? A[d - base] : ldc(&val[d])) + like;
+          if (plds) lds_log_add(&P[s - pbase], x); else atomic_log_add(&val[s], x);
+        };
+#pragma unroll
+        for (int q = 0; q < kFbEmit; ++q)
+          if (cm.src[q] >= 0) push(cm.src[q], cm.dst[q], cm.like[q]);
+        for (int l = cm.m0 + tid + kFbEmit * kFbThreads; l < cm.m1; l += kFbThreads) {
           const int4 r = v.lrec[l];
-          const double x = ldc(&val[r.y]) + link_like(p, v, r, l);
-          if (plds) lds_log_add(&cur[r.x - pbase], x); else atomic_log_add(&val[r.x], x);
+          push(r.x, r.y, link_like(p, v, r, l));
         }
-        __syncthreads();
+        fb_barrier(plds);
+        double* tmp = A; A = P; P = tmp;
         base = pbase; cnt = pcnt; lds = plds;
+        cm = nm; ce = ne; s0 = s1; s1 = s2;
       }
     }
   }
@@ -371,7 +453,7 @@ static int fb_launch(int mode, const pk2_lattice_batch* b, void* workspace, FbPa
   PK2_REQUIRE(b->decoded, "lattice forward-backward: pk2_lattice_decode has not run on this batch");
   lattice_carve(b, workspace, &p.L);
   const dim3 two(2, b->N), many(64, b->N), thr(kFbThreads);
-  constexpr int kFbCap = 19456;                    // tokens of a frame the LDS array holds (152 KB of doubles)
+  constexpr int kFbCap = 19456;                    // doubles of LDS (152 KB): two frames of kFbCap / 2 tokens each
   static PerDevice<bool> attr_pd(false); bool& attr = attr_pd.ref();
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_fb_alpha_beta), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -379,7 +461,7 @@ static int fb_launch(int mode, const pk2_lattice_batch* b, void* workspace, FbPa
     attr = true;
   }
   const char* cap_env = getenv("PK2_LAT_FIN_CAP");       // (test hook, shared with the pruning pass of the decoder)
-  const int cap = cap_env ? std::max(0, std::min(kFbCap, atoi(cap_env))) : kFbCap;
+  const int cap = cap_env ? std::max(0, std::min(kFbCap / 2, atoi(cap_env))) : kFbCap / 2;
   hipLaunchKernelGGL(lat_fb_alpha_beta, two, thr, kFbCap * sizeof(double), stream, p, cap);
   if (mode == 0) {
     hipLaunchKernelGGL(lat_fb_posteriors<0>, many, thr, 0, stream, p);
