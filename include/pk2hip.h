@@ -583,6 +583,9 @@ int pk2_stream_create_cu_mask(int32_t cus_per_xcd, void** stream_out);
 int pk2_stream_destroy(void* stream);
 /* out[3 * b + {0, 1, 2}] = XCC id, shader engine, CU of workgroup b of a `blocks`-workgroup launch on `stream` (HW_ID). */
 int pk2_debug_where(int32_t* out, int32_t blocks, void* stream);
+/* Stand-in for the collective library's all-reduce kernel on a one-GPU box (PK2_HVD_FAKE_PEER in pykaldi2_amd/hvd.py):
+ * `blocks` workgroups stream dst[i] += src[i] over n floats, `passes` times, on `stream`. */
+int pk2_debug_peer_reduce(float* dst, const float* src, int64_t n, int32_t blocks, int32_t passes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,7 @@ SIGNATURES = {
     "pk2_stream_create_cu_mask": (C.c_int, [_i32, C.POINTER(_vp)]),
     "pk2_stream_destroy": (C.c_int, [_vp]),
     "pk2_debug_where": (C.c_int, [_vp, _i32, _vp]),
+    "pk2_debug_peer_reduce": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
 }
 
 _lib = None

@@ -121,7 +121,7 @@ extern "C" int pk2_allreduce_bucket(pk2_comm* comm, float* buf, int64_t count, v
 }
 
 extern "C" int pk2_allreduce_guarded(pk2_comm* comm, float* buf, int64_t count, float* guard_slot, void* stream) {
-  PK2_REQUIRE(comm && comm->comm && buf && guard_slot && count >= 0, "allreduce_guarded: bad args");
+  PK2_REQUIRE(comm && comm->comm && guard_slot && count >= 0 && (buf || count == 0), "allreduce_guarded: bad args");      // (count = 0: the slot travels alone)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool group = g_rccl.GroupStart && g_rccl.GroupEnd && count > 0;
   ncclResult_t r = ncclSuccess;

@@ -155,6 +155,7 @@ def _allreduce_sum(t, stream=None, guard_slot=None):
     if _state["comm"] is not None and t.is_cuda:
         from . import _lib
         st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        _fake_peer(t, st)
         if guard_slot is not None:
             _lib.check(_lib.lib().pk2_allreduce_guarded(_state["comm"], C.c_void_p(t.data_ptr()), t.numel(),
                                                         C.c_void_p(guard_slot.data_ptr()), C.c_void_p(st.cuda_stream)))
@@ -168,6 +169,26 @@ def _allreduce_sum(t, stream=None, guard_slot=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if guard_slot is not None:
         dist.all_reduce(guard_slot, op=dist.ReduceOp.MAX)
+
+
+_peer_zeros = {}
+
+
+def _fake_peer(t, st):
+    """PK2_HVD_FAKE_PEER="blocks,passes" (one-GPU boxes: DESIGN.md 6, tools/gpu_r05_peer.sh): in front of every all-reduce
+    call, on its stream, a kernel that does to the chip what the all-reduce kernel of an 8-rank job would -- `blocks`
+    workgroups streaming a reduce-copy over the bucket `passes` times -- so that the schedules can be priced, and the
+    persistent kernels' time-outs provoked, without a second GPU.  The bucket keeps its values (it adds zeros)."""
+    spec = os.environ.get("PK2_HVD_FAKE_PEER")
+    if not spec or t.numel() == 0:
+        return
+    from . import _lib
+    blocks, passes = (int(v) for v in spec.split(","))
+    z = _peer_zeros.get(t.device)
+    if z is None or z.numel() < t.numel():
+        z = _peer_zeros[t.device] = torch.zeros(max(t.numel(), 22_000_000), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.lib().pk2_debug_peer_reduce(C.c_void_p(t.data_ptr()), C.c_void_p(z.data_ptr()), t.numel(), blocks, passes,
+                                                C.c_void_p(st.cuda_stream)))
 
 
 def shutdown():
