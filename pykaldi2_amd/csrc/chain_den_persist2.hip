@@ -82,7 +82,8 @@ struct Lds2 {
   float* tot;      // [4]
   float* wcarry;   // [kSegs * kPW] open tail of wave w in segment s
   int* wcrow;      // [kSegs * kPW] the rank-local row it belongs to (-1: none)
-  int* abort;      // + rank, team, xcd, task
+  int* abort;      // + rank, team, xcd, task; [8] = ranks whose words have been seen valid in the poll under way
+  uint32_t* need;  // [kP2NeedRows] ranks whose slices a 1 KB row of chunk 0 holds
 };
 __device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap, int arrays) {
   Lds2 L;
@@ -92,6 +93,7 @@ __device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap, int arrays) {
   L.pdfv = L.mapB + cap; L.pdfl = L.pdfv + cap;
   L.red = L.aux + (arrays - 5) * cap; L.tot = L.red + 2 * kPW; L.wcarry = L.tot + 4;      // (without the pdfs: 7 arrays)
   L.wcrow = reinterpret_cast<int*>(L.wcarry + kSegs * kPW); L.abort = L.wcrow + kSegs * kPW;
+  L.need = reinterpret_cast<uint32_t*>(L.abort + 16);
   return L;
 }
 
@@ -210,6 +212,89 @@ struct Chunk1Dma {
     dma_issue(mask, pl->dst + off4, pl->lane16, src + off4);
   }
 };
+// Round 5, measured and left off (-DPK2_DP2_POLLCOPY=1): the copy of chunk 0 FOLLOWING the poll.  The frame waits until the
+// words of all 32 ranks are valid and only then starts copying the vector -- 0.95 us of exposed copy behind ~0.7 us of poll,
+// although a rank's word says that ITS slice is in L2.  Here wave 0 publishes, in an LDS word, the ranks it has seen valid so
+// far, and waves 1..7 copy the 1 KB rows of chunk 0 (dealt to them round robin) as soon as the ranks whose slices a row holds
+// (L.need, formed once per task from the ranks' slice bounds) are all there.  Parity-green -- and no faster: 7.27 us per frame
+// against 7.20 (same job, two runs each; a first version whose copy loop read its need masks from LDS row by row: 8.2).
+// The 0.7 us of the poll are the PATH of a poll (own stores acknowledged, one L2 round trip), not waiting for a slow rank:
+// the ranks of a team arrive within ~0.1 us of each other, so there is nothing for the copy to hide under.
+#ifndef PK2_DP2_POLLCOPY
+#define PK2_DP2_POLLCOPY 0
+#endif
+template <typename SLICE>
+__device__ __forceinline__ void need_masks(const Lds2& L, CDev2& o, SLICE slice_begin) {      // slice_begin(r): first table index rank r publishes
+  const int b = o.cbeg[0], e = o.cbeg[1];
+  const int rows = (e - b + 255) >> 8;
+  for (int j = threadIdx.x; j < rows && j < kP2NeedRows; j += kPT) {
+    const int lo = b + (j << 8), hi = min(lo + 256, e);
+    uint32_t m = 0;
+    for (int r = 0; r < kPR; ++r)
+      if (slice_begin(r) < hi && slice_begin(r + 1) > lo) m |= 1u << r;
+    L.need[j] = m;
+  }
+  if (threadIdx.x == 0) L.abort[8] = 0;
+}
+// Wave 0: poll_words' loop, publishing its progress; waves 1..kPW-1: the copies.  Ends like poll_words (L.tot, L.abort) with
+// every row of chunk 0 issued; the caller's barrier and wait_vm(0) follow.  Returns false when chunk 0 has more rows than
+// L.need holds (the caller copies it the old way).
+__device__ __forceinline__ bool poll_and_copy0(cgfloat* ps, int nwords, Spin& spin, const Lds2& L, cgfloat* src, CDev2& o) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = o.cbeg[0], e = o.cbeg[1];
+  const int rows = (e - b + 255) >> 8;
+  volatile uint32_t* prog = reinterpret_cast<volatile uint32_t*>(L.abort + 8);
+  if (rows > kP2NeedRows) { poll_words(ps, 0, nwords, spin, L); return false; }
+  if (w == 0) {
+    const bool mine = (lane >> 5) < nwords;
+    cgfloat* wsrc = ps + (lane & (kPR - 1)) * kPWords + (lane >> 5);
+    float pv = mine ? ld_agent(wsrc) : 0.f;
+    bool ok = true;
+    for (;;) {
+      const unsigned long long bad = __ballot(mine && is_sentinel(pv));
+      // a rank is there when all its words are (backward: two)
+      const uint32_t have = ~((uint32_t)bad | (uint32_t)(bad >> 32));
+      if (lane == 0) *prog = have;
+      if (bad == 0ull) break;
+      if (spin.expired()) { ok = false; break; }
+      if (mine && is_sentinel(pv)) pv = ld_agent(wsrc);
+    }
+    if (!ok) { pv = 0.f; if (lane == 0) { *L.abort = 1; *prog = 0xFFFFFFFFu; } }
+    const float a = wave_sum_dpp(lane < kPR ? pv : 0.f), bsum = wave_sum_dpp(lane < kPR ? 0.f : pv);
+    if (lane == 0) { L.tot[0] = a; L.tot[1] = bsum; }
+  } else {
+    // this wave's rows: w-1, w-1 + (kPW-1), ...: lane k looks after row k of them (its need mask in a register for the task
+    // would be better still; an LDS read per poll sweep is what it costs here), one ballot says which are ready, and the
+    // ready ones are issued by scalar code (dma_issue: exec mask + m0 + scalar base, as the in-pass copy)
+    const int w1 = __builtin_amdgcn_readfirstlane(w - 1);        // (wave-uniform by construction: scalar registers below)
+    const int nmine = (rows - w1 + (kPW - 2)) / (kPW - 1);
+    const int myrow = w1 + lane * (kPW - 1);
+    const uint32_t myneed = lane < nmine ? L.need[myrow] : 0xFFFFFFFFu;
+    const int efl = ((e + 3) & ~3) - b;                 // floats from the chunk's first to the granule-rounded end
+    const uint32_t dst0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(L.table + o.lds_off[0]));
+    const uint64_t sb = (uint64_t)(src + b);
+    const uint64_t src0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sb >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    uint64_t pend = nmine >= 64 ? ~0ull : ((1ull << (nmine > 0 ? nmine : 0)) - 1ull);
+    while (pend) {
+      const uint32_t have = *prog;
+      uint64_t ready = __ballot((myneed & ~have) == 0u) & pend;
+      pend &= ~ready;
+      while (ready) {
+        const int k = __builtin_ctzll(ready);
+        ready &= ready - 1;
+        const int off = (w1 + k * (kPW - 1)) << 8;
+        int nl = (efl - off + 3) >> 2;                   // lanes (16 bytes each) inside the vector
+        nl = nl < 0 ? 0 : nl;
+        const uint64_t mask = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
+        dma_issue(mask, dst0 + (uint32_t)off * 4u, lane16, src0 + (uint64_t)(uint32_t)off * 4u);
+      }
+    }
+  }
+  return true;
+}
+
 struct NoDma { __device__ __forceinline__ void operator()(int) const {} };
 
 // Row sums of NS register slots (slots J0 .. J0+NS-1 of the thread's arrays) over the LDS table into `acc`: complete rows
@@ -425,7 +510,8 @@ struct RowSpan { int nrows, uncA, ncA, uncB, ncB; };
 // with it, vmcnt being in order, for the previous frame's history stores -- would delay the copies.
 template <bool STREAM, typename ST, typename STAGE>
 __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, const RowSpan& rs, const FrameRegs& r,
-                                           const DmaPlan& plan, ST& st, const Lds2& L, DpTimers& dp_, STAGE stage) {
+                                           const DmaPlan& plan, ST& st, const Lds2& L, DpTimers& dp_, STAGE stage,
+                                           bool chunk0_issued = false) {
   const int tid = threadIdx.x;
   if constexpr (STREAM) {
     // the streamed segments add up in accS; compact rows past a truncated resident list get no store from their pass
@@ -433,7 +519,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     for (int q = rs.uncA + tid; q < rs.ncA; q += kPT) L.accA[q] = 0.f;
     for (int q = rs.uncB + tid; q < rs.ncB; q += kPT) L.accB[q] = 0.f;
   }
-  dma_chunk(src, o, 0, L.table, rank);
+  if (!chunk0_issued) dma_chunk(src, o, 0, L.table, rank);      // (else: copied while the poll was under way)
   DP_T(0);
   wait_vm(0);                            // chunk 0 has landed (this wave's part)
   lds_only_barrier();
@@ -570,6 +656,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int r = tid; r < ngrp; r += kPT) L.pdfl[r] = (short)p.loop_pdf[g0 + r];
   }
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
+  need_masks(L, o, [&](int r) { return (int)o.grp_begin[r]; });        // rank r publishes the states of its groups
   int st_lo[PSPT], st_hi[PSPT], st_o[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) {
@@ -643,16 +730,22 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     cgfloat* src;
     DP_TL(0, 0);
     DP_TLSET(0);
+    bool chunk0_issued = false;
     if (t == 0) {
       as = d.pi_sum;
       src = G(d.pi);
     } else {
+      src = ring + (size_t)(t & 1) * p.rpad;
+#if PK2_DP2_POLLCOPY
+      chunk0_issued = poll_and_copy0(pring + (size_t)(t % 3) * kPR * kPWords, 1, spin, L, src, o);
+#else
       poll_words(pring + (size_t)(t % 3) * kPR * kPWords, 0, 1, spin, L);
+#endif
       __syncthreads();
       DP_TL(0, 1);
       if (*L.abort) return;
       as = L.tot[0];
-      src = ring + (size_t)(t & 1) * p.rpad;
+      if (tid == 0) L.abort[8] = 0;        // (every wave has left the poll: the next one starts from "nobody there")
     }
     // the word this rank will publish two frames from now must read "not yet written" by then: reset here, before the
     // copies (no store sits between them and their waits), long before the stores it has to precede
@@ -665,7 +758,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
         if (r < nrows) L.xown[r] = xr[i];
       }
       if (publish) prefetch(t + 1);
-    });
+    }, chunk0_issued);
     DP_TL(0, 4);
     __syncthreads();
     if (rank == 0 && tid == 0) G(d.asum)[f0 + t] = as;
@@ -750,6 +843,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
   }
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
+  need_masks(L, o, [&](int r) { return (int)d.voff[o.row_begin[r]]; });      // rank r publishes the virtual states of its states
   int st_v0[PSPT], st_v1[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) {
@@ -855,19 +949,26 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   for (int t = T - 1; t >= 0; --t) {
     DP_TL(1, 0);
     DP_TLSET(1);
+    cgfloat* src_t = ring + (size_t)((t + 1) & 1) * p.rpad;
+#if PK2_DP2_POLLCOPY
+    const bool chunk0_issued = poll_and_copy0(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 2, spin, L, src_t, o);
+#else
+    const bool chunk0_issued = false;
     poll_words(pring + (size_t)((t + 1) % 3) * kPR * kPWords, 0, 2, spin, L);
+#endif
     __syncthreads();
     DP_TL(1, 1);
     if (*L.abort) return;
     const float lB = L.tot[0], lU = L.tot[1];        // sums of btilde'[t, .], known before it is computed
+    if (tid == 0) L.abort[8] = 0;
     const bool publish = t > 0;
     // the words this rank will publish two frames from now must read "not yet written" by then: reset here, before the
     // copies, long before the stores they have to precede (the waits of emit cover it)
     if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
-    frame_rows<STREAM>(o, ring + (size_t)((t + 1) & 1) * p.rpad, rank, rs, fr, plan, st, L, dp_, [&]() {
+    frame_rows<STREAM>(o, src_t, rank, rs, fr, plan, st, L, dp_, [&]() {
       if (publish) stage_x();
       if (t >= 2) prefetch(t - 2);          // (xw is free again; xl_next becomes xl_prev at the end of the frame)
-    });
+    }, chunk0_issued);
     DP_TL(1, 4);
     __syncthreads();
     // rows are source states: btilde'[t, s] = row + peeled loop, then beta-hat[t, s] with the sums received above
