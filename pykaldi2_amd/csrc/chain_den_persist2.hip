@@ -220,9 +220,6 @@ struct Chunk1Dma {
 // against 7.20 (same job, two runs each; a first version whose copy loop read its need masks from LDS row by row: 8.2).
 // The 0.7 us of the poll are the PATH of a poll (own stores acknowledged, one L2 round trip), not waiting for a slow rank:
 // the ranks of a team arrive within ~0.1 us of each other, so there is nothing for the copy to hide under.
-#ifndef PK2_DP2_POLLCOPY
-#define PK2_DP2_POLLCOPY 0
-#endif
 template <typename SLICE>
 __device__ __forceinline__ void need_masks(const Lds2& L, CDev2& o, SLICE slice_begin) {      // slice_begin(r): first table index rank r publishes
   const int b = o.cbeg[0], e = o.cbeg[1];
@@ -656,7 +653,9 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int r = tid; r < ngrp; r += kPT) L.pdfl[r] = (short)p.loop_pdf[g0 + r];
   }
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
+#if PK2_DP2_POLLCOPY
   need_masks(L, o, [&](int r) { return (int)o.grp_begin[r]; });        // rank r publishes the states of its groups
+#endif
   int st_lo[PSPT], st_hi[PSPT], st_o[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) {
@@ -843,7 +842,9 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
   }
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
+#if PK2_DP2_POLLCOPY
   need_masks(L, o, [&](int r) { return (int)d.voff[o.row_begin[r]]; });      // rank r publishes the virtual states of its states
+#endif
   int st_v0[PSPT], st_v1[PSPT]; float st_pl[PSPT], st_pi[PSPT]; bool st_ok[PSPT];
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) {

@@ -329,10 +329,19 @@ static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const i
     for (int g = 0; g <= num_groups; ++g) grow[g] = g;
   }
   if (grow[num_groups] != num_rows) return false;
+  // What a row costs next to its arcs.  With the slots nearly full (the bench graph: 1.01 M arcs on 1.05 M slots) the ranks
+  // must be balanced by slots: 2 per row (padding).  A graph with FEWER arcs has slots to spare, and balancing it by arcs
+  // alone makes the ranks' ROW counts uneven -- the LDS row arrays are sized by the largest rank, and every float they take
+  // comes out of the state table: S = 55 k states with 0.5 M arcs got 1890 rows on its largest rank (mean 1719), 8 row
+  // arrays of 1892 floats, a table 200 floats too small for the two-chunk form and fell to five chunks + 163 streamed pieces,
+  // i.e. to the launch-per-frame kernels (18.1 us per frame), while the same states with TWICE the arcs kept the persistent
+  // form (13.6; profiles/r04_den_sweep.txt).  The spare slots are spread over the rows as weight.
+  const int64_t spare = (int64_t)(0.92 * (double)kPR * (double)kPSlots) - A - 2 * (int64_t)num_rows;
+  const int64_t row_w = 2 + std::min<int64_t>(62, std::max<int64_t>(0, spare / std::max(1, num_rows)));
   std::vector<int64_t> gcost(num_groups, 0);
   int64_t total = 0;
   for (int g = 0; g < num_groups; ++g) {
-    for (int r = grow[g]; r < grow[g + 1]; ++r) gcost[g] += rarcs[r] + 2;
+    for (int r = grow[g]; r < grow[g + 1]; ++r) gcost[g] += rarcs[r] + row_w;
     total += gcost[g];
   }
   out->row_begin.assign(kPR + 1, num_rows);

@@ -29,7 +29,10 @@ void den_persist_check_launch(float* den_lp, int N, hipStream_t stream);
 // the segments' wave carries and their rows, flags).
 constexpr int kP2RowArrays = 8;      // (the eighth: the pdfs of own rows and own states as shorts, round 4 -- left out, with
                                      // the x gather, for a graph it would cost a table chunk: pk2_den_graph::p2_rowarrays)
-constexpr int kP2NeedRows = 128;     // 1 KB rows of table chunk 0: which ranks' slices each one holds (round 5: the copy follows the poll)
+#ifndef PK2_DP2_POLLCOPY
+#define PK2_DP2_POLLCOPY 0          // chain_den_persist2.hip: the copy of chunk 0 following the poll (round 5: measured, off)
+#endif
+constexpr int kP2NeedRows = PK2_DP2_POLLCOPY ? 128 : 0;     // 1 KB rows of table chunk 0: which ranks' slices each one holds
 constexpr int kP2FixedFloats = 2 * kPW + 4 + 2 * kSegs * kPW + 16 + kP2NeedRows;
 inline size_t den_persist2_lds_bytes(int tfloats, int cap, int arrays = kP2RowArrays) {
   return ((size_t)tfloats + arrays * (size_t)cap + kP2FixedFloats) * sizeof(float);

@@ -355,13 +355,19 @@ def test_bench_size_denominator_matches_c_oracle(monkeypatch):
     assert np.abs(gamma_f.cpu().numpy() - gamma).max() < 1e-5
 
 
-@pytest.mark.parametrize("S,A", [(50000, 1000000), (40000, 1500000)], ids=["S50k_A1M", "S40k_A1.5M"])
-def test_large_state_graphs_match_c_oracle(S, A):
+@pytest.mark.parametrize("S,A,want_form", [(50000, 1000000, None), (40000, 1500000, None), (55000, 500000, 2), (55000, 1000000, 2),
+                                      (65000, 1000000, 0)],
+                         ids=["S50k_A1M", "S40k_A1.5M", "S55k_A0.5M_rows7", "S55k_A1M_rows7", "S65k_A1M_frames"])
+def test_large_state_graphs_match_c_oracle(S, A, want_form):
     """Graphs beyond the fully resident persistent form (bin/train_chain.py:167,202 accepts any den.fst):
     50 k states (the state vector no longer fits the LDS table: four table chunks, or the launch-per-frame kernels --
     whichever the cost model picks, reported by kernel_path / persist_form) and 40 k states with 1.5 M arcs (streamed
     overflow pieces).  Den log-prob 1e-3 rel and occupancies 1e-4 abs against the float64 build of oracle/chain_oracle.c,
-    P = 6048, chain topology, 3 ragged sequences; both kernel families must agree with each other as well."""
+    P = 6048, chain topology, 3 ragged sequences; both kernel families must agree with each other as well.
+    Round 5: 55 k states -- the LDS layout WITHOUT the pdf arrays ("rows7": the eighth row array
+    would cost a table chunk), two chunks taking turns in one buffer -- at 1.0 M arcs and at 0.5 M, which fell to the
+    launch-per-frame kernels until the ranks were balanced by rows as well (csrc/chain_graph.hip: persist2_assign); and
+    65 k states, which no persistent layout takes (the launch-per-frame kernels)."""
     from oracle import chain_c
     P = 6048
     g = synth.den_graph_arcs(S, A, P, seed=1, loop_pdf_differs=True)
@@ -384,6 +390,10 @@ def test_large_state_graphs_match_c_oracle(S, A):
         finally:
             os.environ.pop("PK2_DEN_PERSIST", None)
     assert results["0"][0] == 1                                   # the launch-per-frame kernels
+    if want_form is not None:
+        assert results["default"][1] == want_form, results["default"][:2]
+        if want_form == 2:
+            assert G.debug_persist2(0)["row_arrays"] == 7 and G.debug_persist2(0)["pieces"] == 0
     print("S = %d, A = %d: default path %d form %d; forced persistent: path %d form %d"
           % (S, A, results["default"][0], results["default"][1], results["2"][0], results["2"][1]))
     for n, Tn in enumerate(lens):
