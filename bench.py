@@ -257,15 +257,17 @@ def den_roofline(den, dev, reps=5):
     # HBM bytes per call from the committed PMC passes (tools/gpu_profile.sh) of this same workload: counters cannot be
     # read live.  Only reported when the profile was taken on the same lengths and graph shape.
     traffic, traffic_note = None, "no PMC profile of this workload committed"
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_den_traffic.json")) as f:
-            prof = json.load(f)
-        if prof.get("lengths") == lens and prof.get("topology") == DEN_TOPOLOGY and prof.get("arcs") == A:
-            traffic = int(prof["traffic_bytes_raw"])
-            traffic_note = ("profiles/r04_den_traffic.json: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), raw; with FETCH_SIZE doubled "
-                            "(gfx950 wide-read correction, an upper bound here): %d" % int(prof["traffic_bytes_fetch_x2"]))
-    except Exception:
-        pass
+    for name in ("r05_den_traffic.json", "r04_den_traffic.json"):         # the newest committed PMC passes of this workload
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                prof = json.load(f)
+            if prof.get("lengths") == lens and prof.get("topology") == DEN_TOPOLOGY and prof.get("arcs") == A:
+                traffic = int(prof["traffic_bytes_raw"])
+                traffic_note = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), raw; with FETCH_SIZE doubled "
+                                "(gfx950 wide-read correction, an upper bound here): %d" % (name, int(prof["traffic_bytes_fetch_x2"])))
+                break
+        except Exception:
+            pass
     # what the memory system really moved per second (counter bytes of the committed profile over this run's timing): the
     # formula counts the per-frame arc re-stream the persistent kernel no longer performs
     counter = None if traffic is None else round(traffic / (ms * 1e-3) / 1e9, 1)

@@ -43,18 +43,37 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _digest(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p_ in sorted(paths):
+        h.update(os.path.basename(p_).encode())
+        with open(p_, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
+    """Incremental by CONTENT, not by time stamps (a checkout or a copied tree has arbitrary mtimes -- a
+    build that finds a library next to sources it was not made from must not trust it): every object carries a stamp
+    `<obj>.sha` = sha256 of its source, all headers and the flags; the library one over the objects' stamps."""
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "pk2hip.h"))
-    hdr_m = max(os.path.getmtime(h) for h in hdrs)
+    hdr_sig = _digest(hdrs)
     hipcc = _hipcc()
-    jobs = []
+    jobs, stamps = [], {}
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+        sig = _digest([src], hdr_sig + " ".join(FLAGS + FILE_FLAGS.get(s, [])))
+        stamps[obj] = sig
+        old = None
+        if os.path.exists(obj + ".sha"):
+            with open(obj + ".sha") as f:
+                old = f.read().strip()
+        if force or not os.path.exists(obj) or old != sig:
             jobs.append((src, obj))
 
     def cc(job):
@@ -70,13 +89,22 @@ def build(force=False, verbose=True):
                     sys.stderr.write(r.stderr)
                 if r.returncode:
                     raise RuntimeError("hipcc failed on %s" % src)
+                with open(os.path.join(OBJ, os.path.basename(src)[:-4] + ".o.sha"), "w") as f:
+                    f.write(stamps[os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")])
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
-    if jobs or not os.path.exists(LIB) or force:
+    lib_sig = _digest([], "".join(stamps[o] for o in objs))
+    old = None
+    if os.path.exists(LIB + ".sha"):
+        with open(LIB + ".sha") as f:
+            old = f.read().strip()
+    if jobs or not os.path.exists(LIB) or force or old != lib_sig:
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stderr)
             raise RuntimeError("link failed")
+        with open(LIB + ".sha", "w") as f:
+            f.write(lib_sig)
     return LIB
 
 
