@@ -196,10 +196,43 @@ class _TransformerFunction(torch.autograd.Function):
         # = frames is cut into slices needs no launch that prepares C, a column sum none that clears its output, the
         # LayerNorm gradients none of their own (round 3 counted 62 + 70 + 62 such launches of ~5 us per step)
         m.flat_parameters()[1].zero_()
+        # Round 5: the parameter gradients (a weight-gradient product + a column sum per linear layer, three products for
+        # the convolution) hang off the chain  d out -> d in -> next layer; nothing but the optimiser waits for them, and a
+        # product of this model fills a third of the chip (296 tiles of 64 x 64 in 768 slots).  They go to a side stream --
+        # there is no persistent kernel in this model whose co-residency they could hurt (the BLSTM's recurrences lose more
+        # than the overlap returns: lstm.py) -- fenced by events; backward ends with the compute stream waiting for them.
+        # PK2_TR_SIDE_STREAM=0 keeps everything on one stream.
+        main = torch.cuda.current_stream(dev)
+        side = m._side_stream(dev) if os.environ.get("PK2_TR_SIDE_STREAM", "1") != "0" else None
+
+        def on_side(fn, *tensors):
+            """Runs fn on the side stream behind what the compute stream has enqueued so far; returns an event the compute
+            stream must wait for before it OVERWRITES one of `tensors` (None on one stream)."""
+            if side is None:
+                fn()
+                return None
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+                done = torch.cuda.Event()
+                done.record(side)
+            for t_ in tensors:
+                t_.record_stream(side)
+            return done
+
+        def before_overwrite(done):
+            if done is not None:
+                main.wait_event(done)
 
         def lin_grads(dout, inp, in_dim, out_dim, wname, bname):
-            _gemm(1, 0, out_dim, in_dim, R, _p(dout), out_dim, _p(inp), in_dim, _p(g[wname]), in_dim, beta=1.0)
-            _colsum(_p(dout), out_dim, R, out_dim, _p(g[bname]), beta=1.0)
+            def work():
+                st = _lib.stream_ptr()
+                _lib.check(L.pk2_gemm_f32(1, 0, out_dim, in_dim, R, 1.0, _p(dout), out_dim, _p(inp), in_dim, 1.0, _p(g[wname]), in_dim,
+                                          None, st))
+                _lib.check(L.pk2_colsum_f32(_p(dout), out_dim, R, out_dim, 1.0, _p(g[bname]), st))
+            return on_side(work, dout, inp)
 
         lin_grads(dlogits, hn, C, P, "output_layer.weight", "output_layer.bias")
         dhn = new(R, C)
@@ -217,17 +250,26 @@ class _TransformerFunction(torch.autograd.Function):
             # ReLU + Conv1d
             _lib.check(L.pk2_relu_bwd(_p(s["y"]), _p(dh), dh.numel(), sp))     # dh := dc
             dc = dh
-            _colsum(_p(dc), C, R, C, _p(g[pre + "conv1d.bias"]), beta=1.0)
-            dWp = torch.zeros(3, C, C, device=dev, dtype=torch.float32)
-            _gemm(1, 0, C, C, R, _p(dc), C, _p(s["x2"]), C, _p(dWp, C * C), C, beta=1.0)
+            x2 = s["x2"]
+
+            def conv_grads(dc=dc, x2=x2, pre=pre):
+                st = _lib.stream_ptr()
+
+                def tn(Mo, No, Ko, A, Bm, Cm):
+                    _lib.check(L.pk2_gemm_f32(1, 0, Mo, No, Ko, 1.0, A, C, Bm, C, 1.0, Cm, C, None, st))
+                _lib.check(L.pk2_colsum_f32(_p(dc), C, R, C, 1.0, _p(g[pre + "conv1d.bias"]), st))
+                dWp = torch.zeros(3, C, C, device=dev, dtype=torch.float32)
+                tn(C, C, R, _p(dc), _p(x2), _p(dWp, C * C))
+                if T > 1:
+                    tn(C, C, R - B, _p(dc, B * C), _p(x2), _p(dWp, 0))
+                    tn(C, C, R - B, _p(dc), _p(x2, B * C), _p(dWp, 2 * C * C))
+                g[pre + "conv1d.weight"].copy_(dWp.permute(1, 2, 0))
+            on_side(conv_grads, dc, x2)
             dx2 = new(R, C)
             _gemm(0, 0, R, C, C, _p(dc), C, _p(s["Wp"], C * C), C, _p(dx2), C)
             if T > 1:
-                _gemm(1, 0, C, C, R - B, _p(dc, B * C), C, _p(s["x2"]), C, _p(dWp, 0), C, beta=1.0)
-                _gemm(1, 0, C, C, R - B, _p(dc), C, _p(s["x2"], B * C), C, _p(dWp, 2 * C * C), C, beta=1.0)
                 _gemm(0, 0, R - B, C, C, _p(dc, B * C), C, _p(s["Wp"], 0), C, _p(dx2), C, beta=1.0)
                 _gemm(0, 0, R - B, C, C, _p(dc), C, _p(s["Wp"], 2 * C * C), C, _p(dx2, B * C), C, beta=1.0)
-            g[pre + "conv1d.weight"].copy_(dWp.permute(1, 2, 0))
             # LayerNorm 2 (+ residual)
             ds2 = new(R, C)
             _lib.check(L.pk2_layernorm_bwd(_p(dx2), _p(s["s2"]), _p(s["mu2"]), _p(s["rs2"]), _p(e.norm2.weight), R, C,
@@ -235,7 +277,7 @@ class _TransformerFunction(torch.autograd.Function):
                                            _p(g[pre + "encoder_layer.norm2.bias"]), sp))
             df2 = _dropout(ds2, drop, s["seed2"]) if drop > 0 else ds2
             # FFN
-            lin_grads(df2, s["f1d"], F, C, pre + "encoder_layer.linear2.weight", pre + "encoder_layer.linear2.bias")
+            read_ds2 = lin_grads(df2, s["f1d"], F, C, pre + "encoder_layer.linear2.weight", pre + "encoder_layer.linear2.bias")
             df1 = new(R, F)
             _gemm(0, 0, R, F, C, _p(df2), C, _p(e.linear2.weight), F, _p(df1), F)
             if drop > 0:
@@ -243,6 +285,8 @@ class _TransformerFunction(torch.autograd.Function):
             _lib.check(L.pk2_relu_bwd(_p(s["f1"]), _p(df1), df1.numel(), sp))
             lin_grads(df1, s["x1"], C, F, pre + "encoder_layer.linear1.weight", pre + "encoder_layer.linear1.bias")
             dx1 = ds2 if drop == 0 else ds2    # residual branch: d x1 = d s2 (+ FFN path below)
+            if df2 is ds2:
+                before_overwrite(read_ds2)     # (the side stream reads d s2 as linear2's output gradient: the add below writes it)
             _gemm(0, 0, R, C, F, _p(df1), F, _p(e.linear1.weight), C, _p(dx1), C, beta=1.0)
             # LayerNorm 1 (+ residual)
             ds1 = new(R, C)
@@ -250,8 +294,8 @@ class _TransformerFunction(torch.autograd.Function):
                                            _p(ds1), _p(g[pre + "encoder_layer.norm1.weight"]),
                                            _p(g[pre + "encoder_layer.norm1.bias"]), sp))
             dao = _dropout(ds1, drop, s["seed1"]) if drop > 0 else ds1
-            lin_grads(dao, s["cx"], C, C, pre + "encoder_layer.self_attn.out_proj.weight",
-                      pre + "encoder_layer.self_attn.out_proj.bias")
+            read_ds1 = lin_grads(dao, s["cx"], C, C, pre + "encoder_layer.self_attn.out_proj.weight",
+                                 pre + "encoder_layer.self_attn.out_proj.bias")
             dcx = new(R, C)
             _gemm(0, 0, R, C, C, _p(dao), C, _p(a.out_proj.weight), C, _p(dcx), C)
             # attention: dP = dctx V^T ; dV = Pd^T dctx ; dS = softmax'(P, dP) ; dQ = a dS K ; dK = a dS^T Q
@@ -268,6 +312,8 @@ class _TransformerFunction(torch.autograd.Function):
             lin_grads(dqkv, s["h_in"], C, 3 * C, pre + "encoder_layer.self_attn.in_proj_weight",
                       pre + "encoder_layer.self_attn.in_proj_bias")
             dh = ds1 if drop == 0 else ds1     # residual branch of the attention block
+            if dao is ds1:
+                before_overwrite(read_ds1)
             _gemm(0, 0, R, C, 3 * C, _p(dqkv), 3 * C, _p(a.in_proj_weight), C, _p(dh), C, beta=1.0)
             ctx.saved[li] = None
         lin_grads(dh, ctx.x.view(R, Din), Din, C, "input_layer.weight", "input_layer.bias")
@@ -275,6 +321,8 @@ class _TransformerFunction(torch.autograd.Function):
         if ctx.x.requires_grad:
             dx = new(T, B, Din)
             _gemm(0, 0, R, Din, C, _p(dh), C, _p(m.input_layer.weight), Din, _p(dx), Din)
+        if side is not None:
+            main.wait_stream(side)
         params = dict(m.named_parameters())
         for name, v in g.items():
             p_ = params[name]
@@ -317,6 +365,12 @@ class TransformerAM(nn.Module):
             flat[o:o + c].copy_(params[n].data.reshape(-1))
             params[n].data = flat[o:o + c].view(params[n].shape)
         self._flat, self._layout, self._gflat = flat, layout, None
+
+    def _side_stream(self, dev):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != dev:
+            st = self._side = torch.cuda.Stream(device=dev)
+        return st
 
     def flat_parameters(self):
         self._ensure_flat()

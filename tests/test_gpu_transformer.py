@@ -23,7 +23,13 @@ def _reference_forward(m, x, src_mask, kpm):
 
 @pytest.mark.parametrize("cfg", [dict(D=20, C=64, H=4, FF=128, L=2, P=37, T=11, B=3, look=2),
                                  dict(D=80, C=512, H=8, FF=2048, L=2, P=301, T=48, B=2, look=-1)])
-def test_transformer_matches_torch_cpu(cfg):
+def test_transformer_matches_torch_cpu(cfg, monkeypatch):
+    # Round 5: the deep-K products (the FFN's K = 2048) are cut into slices that ADD with float atomics -- equal up to
+    # summation order, i.e. the forward pass is not bitwise reproducible (tools/dbg/tr_fwd_determinism.py: 2e-7), and an
+    # activation within that noise of zero flips its ReLU mask: one element of a 96 x 2048 mask changes a weight-gradient
+    # tensor by 0.2-2 % of its maximum, which made this test fail in ~15 % of its runs (either stream layout).  The parity
+    # check runs with whole-K products; the sliced products have their own test against torch in test_gpu_frontend_nn.py.
+    monkeypatch.setenv("PK2_GEMM_SPLITK", "1")
     torch.manual_seed(0)
     m = transformer.TransformerAM(cfg["D"], cfg["C"], cfg["H"], cfg["FF"], cfg["L"], 0.0, cfg["P"])
     for lp in m.transformer.layers:          # break the deep-copy symmetry of the default init
@@ -109,7 +115,7 @@ def test_transformer_state_dict_keys_and_init_follow_torch():
 
 
 @pytest.mark.parametrize("P,param_grads", [(600, True), (6048, False)], ids=["P600_all_links", "P6048_full_width"])
-def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle(P, param_grads):
+def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle(P, param_grads, monkeypatch):
     """BASELINE configs[4]: the 12-layer TransformerAM (dim 512, 8 heads, FFN 2048, conv k=3; reference
     bin/train_transformer_se.py:128,243-258 model call with a key-padding mask) feeding ChainObjtiveBatch
     (ops/ops.py:243-280).  Three links, each against its own reference: logits vs the torch CPU forward of the same
@@ -118,6 +124,7 @@ def test_12_layer_transformer_into_lf_mmi_matches_torch_cpu_and_the_chain_oracle
     links; P = 6048 (the configuration's full output width, VERDICT r3 #7) the logits and objective / derivative links."""
     from oracle import chain_ref as R
     from pykaldi2_amd import chain, ops, synth
+    monkeypatch.setenv("PK2_GEMM_SPLITK", "1")        # (whole-K products: see test_transformer_matches_torch_cpu)
     torch.manual_seed(0)
     T, B, L = 60, 2, 12
     m = transformer.TransformerAM(80, 512, 8, 2048, L, 0.0, P)
