@@ -336,8 +336,11 @@ static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const i
   // arrays of 1892 floats, a table 200 floats too small for the two-chunk form and fell to five chunks + 163 streamed pieces,
   // i.e. to the launch-per-frame kernels (18.1 us per frame), while the same states with TWICE the arcs kept the persistent
   // form (13.6; profiles/r04_den_sweep.txt).  The spare slots are spread over the rows as weight.
+  // (only where the row arrays compete with the table: more than 2 kPT rows per rank on average.  Below that the heaviest
+  // rank's arcs matter more -- its slack decides how widely rows can be padded: S = 10 k / A = 0.5 M lost its estep to the
+  // weighting, 5.3 -> 6.1 us per frame, profiles/r05_den_sweep.txt mid-round)
   const int64_t spare = (int64_t)(0.92 * (double)kPR * (double)kPSlots) - A - 2 * (int64_t)num_rows;
-  const int64_t row_w = 2 + std::min<int64_t>(62, std::max<int64_t>(0, spare / std::max(1, num_rows)));
+  const int64_t row_w = num_rows <= 2 * kPT * kPR ? 2 : 2 + std::min<int64_t>(62, std::max<int64_t>(0, spare / std::max(1, num_rows)));
   std::vector<int64_t> gcost(num_groups, 0);
   int64_t total = 0;
   for (int g = 0; g < num_groups; ++g) {

@@ -329,3 +329,23 @@ def test_reference_transformer_state_dict_loads_strict(golden):
         assert np.abs(sd["pos_encoder.pe"][:8].numpy() - g[tag + "_pe_head"]).max() < 1e-6
         m.load_state_dict(sd, strict=True)
         assert sorted(n for n, _ in m.named_parameters()) == sorted(k[len(tag) + 6:] for k in g.files if k.startswith(tag + "_grad_"))
+
+
+def test_local_world_size_comes_from_the_launcher_or_is_unknown(monkeypatch):
+    """ranks are only taken to share a GPU when the launcher says how many ranks a node has -- torchrun,
+    Open MPI / horovodrun, MPICH / Intel MPI, Slurm -- never from WORLD_SIZE alone (a multi-node mpirun job has
+    WORLD_SIZE > device_count on every node and is a correct one-process-per-GPU deployment)."""
+    from pykaldi2_amd import hvd
+    keys = ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE")
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "64")
+    assert hvd._local_world_size() is None
+    for k, v, want in (("SLURM_NTASKS_PER_NODE", "8(x4)", 8), ("MPI_LOCALNRANKS", "4", 4), ("OMPI_COMM_WORLD_LOCAL_SIZE", "8", 8),
+                       ("LOCAL_WORLD_SIZE", "2", 2)):
+        monkeypatch.setenv(k, v)
+        assert hvd._local_world_size() == want          # (the more specific variables are asked first)
+    # unknown local size: nothing is switched, whatever the device count
+    before = {k: os.environ.get(k) for k in ("PK2_LSTM_SEQ", "PK2_DEN_PERSIST", "PK2_LAT_DECODER")}
+    hvd._ranks_share_a_device(None, 1)
+    assert {k: os.environ.get(k) for k in before} == before
