@@ -334,8 +334,27 @@ __device__ __forceinline__ void row_end_place(unsigned& m, uint32_t& cb, float& 
                : "+v"(m), "+v"(cb), "+v"(sum), "=&s"(save) : : "vcc", "scc", "memory");
 }
 
-template <int ESTEP, int J0, int NS, typename DMA>
-__device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32_t (&addr)[kPK], uint32_t ends, int frow,
+// PACKED (the orderings with streamed pieces, round 5): `addr` holds the offsets as the layout stores them -- two 16-bit table
+// indices to a word, kPK / 2 registers -- and `base` the table's LDS address; an address is formed when its gather is
+// issued.  The 32 registers that frees are what the pieces in flight need (the streaming kernels spilled 50-90 registers per
+// thread with 64 absolute addresses + three pieces); the two extra VALU instructions per slot are free: the passes are
+// not bound by instruction issue.
+template <bool PACKED, int J0>
+__device__ __forceinline__ void slot_addresses(const uint32_t (&addr)[kPK], uint32_t base, int j0, uint32_t (&out)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int s = J0 + j0 + j;
+    if (PACKED) {
+      uint32_t pk = addr[s >> 1];
+      if ((s & 1) == 0) asm volatile("" : "+v"(pk));      // (opaque per use: the compiler would hoist the unpacking out of the frame loop -- 64 registers again)
+      out[j] = base + ((s & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2);
+    } else {
+      out[j] = addr[s];
+    }
+  }
+}
+template <int ESTEP, int J0, int NS, bool PACKED, typename DMA>
+__device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32_t (&addr)[kPK], uint32_t base, uint32_t ends, int frow,
                                           float* acc, float* wcarry, const DMA& dma) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float sum = 0.f;
@@ -349,11 +368,13 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
 #if PK2_DP2_PASS_ASM
   constexpr int NG = NS / 8;
   constexpr int kStores = 8 / ESTEP;                 // row-end stores of one group
-  lds_gather8(&addr[J0], a[0]);
+  uint32_t ad[8];
+  slot_addresses<PACKED, J0>(addr, base, 0, ad);
+  lds_gather8(ad, a[0]);
   dma(0);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) { lds_gather8(&addr[J0 + 8 * (g + 1)], a[(g + 1) & 1]); dma(2 * g + 2); }
+    if (g + 1 < NG) { slot_addresses<PACKED, J0>(addr, base, 8 * (g + 1), ad); lds_gather8(ad, a[(g + 1) & 1]); dma(2 * g + 2); }
     // younger than the gathers of group g: the stores of group g-1, the gathers of group g+1
     constexpr int kMost = 15;
     if (g == 0) lds_wait8<(NG > 1 ? 8 : 0)>(a[0]);
@@ -369,8 +390,10 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
   }
 #else
   auto gather = [&](int j0, float (&a)[8]) {
+    uint32_t ad2[8];
+    slot_addresses<PACKED, J0>(addr, base, j0, ad2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = lds_load(addr[J0 + j0 + j]);
+    for (int j = 0; j < 8; ++j) a[j] = lds_load(ad2[j]);
   };
   gather(0, a[0]);
   dma(0);
@@ -400,38 +423,38 @@ __device__ __forceinline__ void pass_rows(const float (&prob)[kPK], const uint32
   if (ends != 0u) acc[frow] += cin;               // the lane's own first row end (stored above by this lane)
   if (lane == 63) wcarry[w] = x[0];
 }
-template <int J0, typename DMA>
-__device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&addr)[kPK], uint32_t ends,
-                                              int frow, float* acc, float* wcarry, const DMA& dma) {
+template <int J0, bool PACKED, typename DMA>
+__device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK], const uint32_t (&addr)[kPK], uint32_t base,
+                                              uint32_t ends, int frow, float* acc, float* wcarry, const DMA& dma) {
   switch (estep) {
-    case 8: pass_rows<8, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
-    case 4: pass_rows<4, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
-    case 2: pass_rows<2, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
-    default: pass_rows<1, J0, kQ>(prob, addr, ends, frow, acc, wcarry, dma); break;
+    case 8: pass_rows<8, J0, kQ, PACKED>(prob, addr, base, ends, frow, acc, wcarry, dma); break;
+    case 4: pass_rows<4, J0, kQ, PACKED>(prob, addr, base, ends, frow, acc, wcarry, dma); break;
+    case 2: pass_rows<2, J0, kQ, PACKED>(prob, addr, base, ends, frow, acc, wcarry, dma); break;
+    default: pass_rows<1, J0, kQ, PACKED>(prob, addr, base, ends, frow, acc, wcarry, dma); break;
   }
 }
 
 // A streamed piece: kSP slots per thread, read from memory in every frame (two 16-byte loads of probabilities, one of packed
 // LDS offsets, the row-end bits).  The sums ADD to `acc` (the rows may have slots in other segments; a barrier separates the
 // segments); the value a row end adds to is read from LDS one row end ahead, so the add does not wait for it.
-struct Piece { float prob[kSP]; uint32_t idx2[kSP / 2]; uint32_t ends; };
+// (round 5: the members are native vectors, not arrays -- with float prob[8] / uint32_t idx2[4] the compiler kept every
+// Piece in SCRATCH MEMORY: the loads of a piece were stored to the stack, copied from slot to slot there ("cur = nxt") and read
+// back one field at a time, ~60 scratch operations per piece and frame)
 typedef float __attribute__((ext_vector_type(4))) f32x4;
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4v;
+struct Piece { f32x4 p0, p1; u32x4v ix; uint32_t ends; };
 __device__ __forceinline__ void piece_load(CDev2& o, int piece, Piece& q) {
   const size_t at = (size_t)piece * kPT + threadIdx.x;
   const __attribute__((address_space(1))) f32x4* sp = (const __attribute__((address_space(1))) f32x4*)o.sprob + at * (kSP / 4);
   const __attribute__((address_space(1))) u32x4v* si = (const __attribute__((address_space(1))) u32x4v*)o.sidx2 + at;
   const __attribute__((address_space(1))) uint32_t* se = (const __attribute__((address_space(1))) uint32_t*)o.sends;
   static_assert(kSP == 8, "a piece is two float4 of probabilities and one uint4 of packed offsets per thread");
-  const f32x4 p0 = sp[0], p1 = sp[1];
-  const u32x4v ix = si[0];
-  q.prob[0] = p0.x; q.prob[1] = p0.y; q.prob[2] = p0.z; q.prob[3] = p0.w;
-  q.prob[4] = p1.x; q.prob[5] = p1.y; q.prob[6] = p1.z; q.prob[7] = p1.w;
-  q.idx2[0] = ix.x; q.idx2[1] = ix.y; q.idx2[2] = ix.z; q.idx2[3] = ix.w;
+  q.p0 = sp[0]; q.p1 = sp[1];
+  q.ix = si[0];
   q.ends = se[at];
 }
 template <int ESTEP>
-__device__ __forceinline__ void piece_rows(const Piece& q, const float* table, float* acc, float& sum, int& c, float& old) {
+__device__ __forceinline__ void piece_rows(const Piece q, const float* table, float* acc, float& sum, int& c, float& old) {
   uint32_t packed = 0;
 #pragma unroll
   for (int k = 0; k < kSP / ESTEP; ++k) packed |= ((q.ends >> (k * ESTEP + ESTEP - 1)) & 1u) << k;
@@ -439,19 +462,19 @@ __device__ __forceinline__ void piece_rows(const Piece& q, const float* table, f
   float a[kSP];
 #pragma unroll
   for (int j = 0; j < kSP; ++j) {
-    const uint32_t pk = q.idx2[j >> 1];
+    const uint32_t pk = q.ix[j >> 1];
     const uint32_t byte_off = (j & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
     a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + byte_off);
   }
 #pragma unroll
   for (int j = 0; j < kSP; ++j) {
-    sum = fmaf(a[j], q.prob[j], sum);
+    sum = fmaf(a[j], j < 4 ? q.p0[j & 3] : q.p1[j & 3], sum);
     if ((j + 1) % ESTEP == 0) {
       if (__builtin_add_overflow(m, m, &m)) { acc[c] = old + sum; ++c; sum = 0.f; old = acc[c]; }
     }
   }
 }
-__device__ __forceinline__ void piece_rows_any(int estep, const Piece& q, const float* table, float* acc, float& sum, int& c, float& old) {
+__device__ __forceinline__ void piece_rows_any(int estep, const Piece q, const float* table, float* acc, float& sum, int& c, float& old) {
   switch (estep) {
     case 8: piece_rows<8>(q, table, acc, sum, c, old); break;
     case 4: piece_rows<4>(q, table, acc, sum, c, old); break;
@@ -460,24 +483,53 @@ __device__ __forceinline__ void piece_rows_any(int estep, const Piece& q, const 
   }
 }
 
-// The streamed segment of chunk c: pieces [p0, p1) of this rank; `cur` holds piece p0 already (prefetched), on return it
-// holds the piece the thread needs next (the first of the next segment, or -- wrapping around -- of the next frame).
-__device__ __forceinline__ void streamed_segment(CDev2& o, int rank, int c, int p0, int p1, int pnext_valid, int pwrap, Piece& cur,
-                                                 const Lds2& L) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// The streamed segment of chunk c: pieces [p0, p1) of this rank.  Round 5: the pieces of a rank form ONE cyclic sequence
+// (segment after segment, then the next frame's first piece again), and kPieceDepth of them travel in registers: st.ring[0]
+// is the piece to be summed now, the others are on their way.  (With one piece ahead a piece's loads were issued one piece's
+// arithmetic -- ~0.2 us -- before they were needed, against ~1 us of L2 latency under load: every piece waited, 1.15 us each
+// in the phase timers of a 1.5 M-arc graph.)  `frow` -- the row a thread's first slot of the segment belongs to -- is a
+// constant of the task and comes from a register (it used to be a global load at the head of every segment of every frame,
+// with the LDS read of that row's running sum behind it).
+constexpr int kPieceDepth = 2;
+struct StreamState { Piece r0, r1; int pb[kMaxChunks + 1]; int frow[kMaxChunks]; int pend; };      // (named members, not an array: registers)
+static_assert(kPieceDepth == 2, "StreamState holds two pieces");
+__device__ __forceinline__ void stream_init(CDev2& o, int rank, StreamState& st) {
+#pragma unroll
+  for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
   const __attribute__((address_space(1))) int32_t* sfr = (const __attribute__((address_space(1))) int32_t*)o.sfirst_row;
-  const int frow = sfr[((size_t)rank * kMaxChunks + c) * kPT + tid];
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) st.frow[c] = st.pb[c + 1] > st.pb[c] ? sfr[((size_t)rank * kMaxChunks + c) * kPT + threadIdx.x] : 0;
+  st.pend = st.pb[0];            // = pb[K], picked with static indices (a dynamic index would keep the whole struct in scratch memory)
+#pragma unroll
+  for (int c = 1; c <= kMaxChunks; ++c) st.pend = c == o.K ? st.pb[c] : st.pend;
+}
+// the piece `d` places behind piece q in the cyclic sequence [pfirst, pend)
+__device__ __forceinline__ int piece_after(int q, int d, int pfirst, int pend) {
+  int r = q + d;
+  const int n = pend - pfirst;
+  while (r >= pend) r -= n;
+  return r;
+}
+__device__ __forceinline__ void stream_prime(CDev2& o, StreamState& st) {
+  const int pfirst = st.pb[0], pend = st.pend;
+  if (pend <= pfirst) return;
+  piece_load(o, piece_after(pfirst, 0, pfirst, pend), st.r0);
+  piece_load(o, piece_after(pfirst, 1, pfirst, pend), st.r1);
+}
+__device__ __forceinline__ void streamed_segment(CDev2& o, int c, int p0, int p1, StreamState& st, const Lds2& L) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pfirst = st.pb[0], pend = st.pend;
+  const int frow = st.frow[c];
   float sum = 0.f;
   int cc = frow;
   uint32_t had = 0;
   float old = L.accS[frow];
   for (int p = p0; p < p1; ++p) {
     Piece nxt;
-    const int pn = p + 1 < p1 ? p + 1 : (pnext_valid ? p1 : pwrap);      // what the thread will need next
-    piece_load(o, pn, nxt);
-    had |= cur.ends;
-    piece_rows_any(o.estep, cur, L.table, L.accS, sum, cc, old);
-    cur = nxt;
+    piece_load(o, piece_after(p, kPieceDepth, pfirst, pend), nxt);      // (kPieceDepth pieces ahead, cyclically)
+    had |= st.r0.ends;
+    piece_rows_any(o.estep, st.r0, L.table, L.accS, sum, cc, old);
+    st.r0 = st.r1; st.r1 = nxt;
   }
   float x[1] = {sum};
   int fl = had != 0u ? 1 : 0;
@@ -495,11 +547,10 @@ __device__ __forceinline__ void streamed_segment(CDev2& o, int rank, int c, int 
 // The frame's row sums once its words are valid: both resident passes and every streamed segment over the vector at `src`.
 // On return a barrier has NOT been passed yet: the caller's __syncthreads() precedes the first read of the sums.
 struct FrameRegs {
-  float prob[kPK]; uint32_t addr[kPK]; uint32_t endsA, endsB; int frowA, frowB;      // addr: absolute LDS byte addresses
+  float prob[kPK]; uint32_t addr[kPK]; uint32_t base; uint32_t endsA, endsB; int frowA, frowB;      // addr: absolute LDS byte addresses, or (streaming orderings) addr[0 .. kPK/2) = the packed offsets and base = the table
 };
 // STREAM = false: the rank-independent fact "this ordering has no streamed piece at all" compiled in -- no piece registers,
 // no segment barriers, chunks beyond the two resident ones cannot exist.
-struct StreamState { Piece cur; int pb[kMaxChunks + 1]; };
 struct NoStream { };
 struct RowSpan { int nrows, uncA, ncA, uncB, ncB; };
 // `stage`: the caller's LDS staging of values it prefetched from memory (x of own rows).  It runs behind the wait for chunk 1,
@@ -533,9 +584,9 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
   // copied once every wave has finished pass A (and the streamed segment that gathers from chunk 0)
   const bool shared = o.K == 2 && o.lds_off[1] == o.lds_off[0] && o.cbeg[2] > o.cbeg[1];
   if (shared) {
-    pass_rows_any<0>(o.estep, r.prob, r.addr, r.endsA, r.frowA, L.accA, L.wcarry, NoDma());
+    pass_rows_any<0, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsA, r.frowA, L.accA, L.wcarry, NoDma());
   } else {
-    pass_rows_any<0>(o.estep, r.prob, r.addr, r.endsA, r.frowA, L.accA, L.wcarry, c1);
+    pass_rows_any<0, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsA, r.frowA, L.accA, L.wcarry, c1);
     for (int j = 8; j * kPW < plan.rows; ++j) c1(j);     // (a chunk 1 of more than 64 rows: the rest, stalling at the issue)
   }
   DP_T(2);
@@ -543,21 +594,22 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
   if constexpr (STREAM) {
     const int (&pb)[kMaxChunks + 1] = st.pb;
     const int K = o.K;
-    const int pfirst = pb[0], pend = pb[K];
-    if (pb[1] > pb[0]) streamed_segment(o, rank, 0, pb[0], pb[1], pb[1] < pend, pfirst, st.cur, L);
+    if (pb[1] > pb[0]) streamed_segment(o, 0, pb[0], pb[1], st, L);
     if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
     wait_vm(0);
     stage();
     __syncthreads();                       // chunk 1 is complete, and buffer 0 is free
     if (K > 2) dma_chunk(src, o, 2, L.table, rank);
-    pass_rows_any<kQ>(o.estep, r.prob, r.addr, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
+    pass_rows_any<kQ, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
     // (consecutive segments add to the same rows of accS: the barrier between two chunks separates them)
-    if (pb[2] > pb[1]) streamed_segment(o, rank, 1, pb[1], pb[2], pb[2] < pend, pfirst, st.cur, L);
-    for (int c = 2; c < K; ++c) {
+    if (pb[2] > pb[1]) streamed_segment(o, 1, pb[1], pb[2], st, L);
+#pragma unroll
+    for (int c = 2; c < kMaxChunks; ++c) {       // (static indices: a dynamic one would put the arrays of `st` into scratch memory)
+      if (c >= K) break;
       wait_vm(0);
       __syncthreads();                     // chunk c is complete, and the buffer of chunk c-1 is free
       if (c + 1 < K) dma_chunk(src, o, c + 1, L.table, rank);
-      if (pb[c + 1] > pb[c]) streamed_segment(o, rank, c, pb[c], pb[c + 1], pb[c + 1] < pend, pfirst, st.cur, L);
+      if (pb[c + 1] > pb[c]) streamed_segment(o, c, pb[c], pb[c + 1], st, L);
     }
   } else {
     if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
@@ -565,7 +617,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     stage();
     __syncthreads();                       // chunk 1 is complete
     DP_T(3);
-    pass_rows_any<kQ>(o.estep, r.prob, r.addr, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
+    pass_rows_any<kQ, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
   }
   DP_T(4);
 }
@@ -599,14 +651,17 @@ __device__ __forceinline__ void block_sum2(float& u, float& v, float* red) {
   u = a; v = b;
 }
 
+template <bool PACKED>
 __device__ __forceinline__ void load_frame_regs(CDev2& o, int rank, FrameRegs& r, const float* table) {
   const int tid = threadIdx.x;
   const uint32_t base = lds_addr(table);
+  r.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
   for (int j = 0; j < kPK; ++j) r.prob[j] = o.prob[((size_t)rank * kPK + j) * kPT + tid];
 #pragma unroll
   for (int j = 0; j < kPK / 2; ++j) {
     const uint32_t pk = o.idx2[((size_t)rank * (kPK / 2) + j) * kPT + tid];
+    if (PACKED) { r.addr[j] = pk; continue; }
     r.addr[2 * j] = base + ((pk & 0xffffu) << 2); r.addr[2 * j + 1] = base + ((pk >> 16) << 2);
     // (opaque: otherwise the compiler keeps the offsets and adds the -- uniform -- base again at every use)
     asm volatile("" : "+v"(r.addr[2 * j]), "+v"(r.addr[2 * j + 1]));
@@ -632,7 +687,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const int S = d.S, V = d.V, Vo = d.Vo;
   const bool sep = d.alphav != d.alpha;
   FrameRegs fr;
-  load_frame_regs(o, rank, fr, L.table);
+  load_frame_regs<STREAM>(o, rank, fr, L.table);
   DmaPlan plan;
   plan.init(o, L.table, rank);
   const int row0 = o.row_begin[rank], nrows = o.row_begin[rank + 1] - row0;
@@ -642,10 +697,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   rs.ncA = o.ncomp[rank * 2]; rs.ncB = o.ncomp[rank * 2 + 1];
   for (int r = tid; r < nrows; r += kPT) { L.mapA[r] = o.rmap[row0 + r]; L.mapB[r] = o.rmap[(size_t)o.num_rows + row0 + r]; }
   typename std::conditional<STREAM, StreamState, NoStream>::type st;
-  if constexpr (STREAM) {
-#pragma unroll
-    for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
-  }
+  if constexpr (STREAM) stream_init(o, rank, st);
   for (int r = tid; r < nrows; r += kPT) L.leak[r] = o.row_leak[row0 + r];
   const bool xg = p.xgather != 0;
   if (xg) {
@@ -716,9 +768,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   prefetch(0);
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) xlr[i] = xln[i];
-  if constexpr (STREAM) {
-    if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
-  }
+  if constexpr (STREAM) stream_prime(o, st);
   float own_a[PSPT];
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) own_a[i] = st_pi[i];          // alpha[0, .] = pi
@@ -827,7 +877,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   const int tid = threadIdx.x;
   const int S = d.S, V = d.V;
   FrameRegs fr;
-  load_frame_regs(o, rank, fr, L.table);
+  load_frame_regs<STREAM>(o, rank, fr, L.table);
   DmaPlan plan;
   plan.init(o, L.table, rank);
   const int row0 = o.row_begin[rank], nrows = o.row_begin[rank + 1] - row0;
@@ -837,10 +887,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   rs.ncA = o.ncomp[rank * 2]; rs.ncB = o.ncomp[rank * 2 + 1];
   for (int r = tid; r < nrows; r += kPT) { L.mapA[r] = o.rmap[row0 + r]; L.mapB[r] = o.rmap[(size_t)o.num_rows + row0 + r]; }
   typename std::conditional<STREAM, StreamState, NoStream>::type st;
-  if constexpr (STREAM) {
-#pragma unroll
-    for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
-  }
+  if constexpr (STREAM) stream_init(o, rank, st);
   if (tid < kSegs * kPW) L.wcrow[tid] = o.wcrow[(size_t)rank * kSegs * kPW + tid];
 #if PK2_DP2_POLLCOPY
   need_masks(L, o, [&](int r) { return (int)d.voff[o.row_begin[r]]; });      // rank r publishes the virtual states of its states
@@ -942,9 +989,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   if (T >= 2) prefetch(T - 2);
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) xl_prev[i] = xl_next[i];
-  if constexpr (STREAM) {
-    if (st.pb[o.K] > st.pb[0]) piece_load(o, st.pb[0], st.cur);
-  }
+  if constexpr (STREAM) stream_prime(o, st);
   Spin spin(ctl);
   DP_T0();
   for (int t = T - 1; t >= 0; --t) {
