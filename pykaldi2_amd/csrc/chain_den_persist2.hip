@@ -100,16 +100,23 @@ __device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap, int arrays) {
 // Workgroup barrier that orders LDS accesses only: the LDS-DMA instructions a wave has in flight stay in flight.
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant).
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant).  As the BUILTIN, not as inline
+// assembly (round 5): the compiler's own wait-count pass reads an s_waitcnt instruction it finds and knows afterwards that
+// its earlier loads have landed; behind an opaque asm it kept waiting for registers loaded frames ago with vmcnt(few) --
+// which, the counter being in order, also waited for the LDS-DMA copies issued in between (a streamed piece consumed during
+// the copy of chunk 1 stalled until that copy was nearly complete).
+__device__ __forceinline__ constexpr int vmcnt_imm(int k) { return (k & 15) | ((k >> 4) << 14) | 0x70 | 0xF00; }     // gfx9: expcnt, lgkmcnt left alone
 __device__ __forceinline__ void wait_vm(int n) {
+  asm volatile("" ::: "memory");
   switch (__builtin_amdgcn_readfirstlane(n)) {
-#define PK2_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#define PK2_VM_CASE(k) case k: __builtin_amdgcn_s_waitcnt(vmcnt_imm(k)); break;
     PK2_VM_CASE(1) PK2_VM_CASE(2) PK2_VM_CASE(3) PK2_VM_CASE(4) PK2_VM_CASE(5) PK2_VM_CASE(6) PK2_VM_CASE(7) PK2_VM_CASE(8)
     PK2_VM_CASE(9) PK2_VM_CASE(10) PK2_VM_CASE(11) PK2_VM_CASE(12) PK2_VM_CASE(13) PK2_VM_CASE(14) PK2_VM_CASE(15) PK2_VM_CASE(16)
     PK2_VM_CASE(17) PK2_VM_CASE(18) PK2_VM_CASE(19) PK2_VM_CASE(20)
 #undef PK2_VM_CASE
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); break;
   }
+  asm volatile("" ::: "memory");
 }
 
 // LDS-DMA of table chunk c of the vector at `src` into its LDS buffer: 1 KB rows dealt to the waves round robin; every wave
@@ -483,53 +490,49 @@ __device__ __forceinline__ void piece_rows_any(int estep, const Piece q, const f
   }
 }
 
-// The streamed segment of chunk c: pieces [p0, p1) of this rank.  Round 5: the pieces of a rank form ONE cyclic sequence
-// (segment after segment, then the next frame's first piece again), and kPieceDepth of them travel in registers: st.ring[0]
-// is the piece to be summed now, the others are on their way.  (With one piece ahead a piece's loads were issued one piece's
-// arithmetic -- ~0.2 us -- before they were needed, against ~1 us of L2 latency under load: every piece waited, 1.15 us each
-// in the phase timers of a 1.5 M-arc graph.)  `frow` -- the row a thread's first slot of the segment belongs to -- is a
-// constant of the task and comes from a register (it used to be a global load at the head of every segment of every frame,
-// with the LDS read of that row's running sum behind it).
+// The streamed segment of chunk c: pieces [p0, p1) of this rank.  Round 5: the pieces of a rank form ONE sequence per frame
+// (segment after segment), and kPieceDepth of them travel in registers: st.r0 is the piece to be summed now, st.r1 is on its
+// way.  (With one piece ahead a piece's loads were issued one piece's arithmetic -- ~0.2 us -- before they were needed,
+// against ~1 us of L2 latency under load: every piece waited, 1.15 us each in the phase timers of a 1.5 M-arc graph.)  The
+// first two pieces of a frame are requested at the END of the frame before (stream_prime, behind the publication of the
+// rank's slice: the poll, the copy of chunk 0 and pass A lie between the request and the use); the sequence does not wrap,
+// so no request is in flight at the frame's last barriers, which wait for vmcnt(0).  `frow` -- the row a thread's first slot
+// of the segment belongs to -- is a constant of the task and comes from a register (it used to be a global load at the head
+// of every segment of every frame, with the LDS read of that row's running sum behind it).
 constexpr int kPieceDepth = 2;
-struct StreamState { Piece r0, r1; int pb[kMaxChunks + 1]; int frow[kMaxChunks]; int pend; };      // (named members, not an array: registers)
+constexpr int kPieceLoads = 4;       // memory instructions of piece_load (two x4 of probabilities, one x4 of offsets, the row ends)
+struct StreamState { Piece r0, r1; int pb[kMaxChunks + 1]; int frow[2]; int pend; };      // (named members, not an array: registers)
 static_assert(kPieceDepth == 2, "StreamState holds two pieces");
 __device__ __forceinline__ void stream_init(CDev2& o, int rank, StreamState& st) {
 #pragma unroll
-  for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = o.pbeg[rank * (kMaxChunks + 1) + c];
+  for (int c = 0; c <= kMaxChunks; ++c) st.pb[c] = __builtin_amdgcn_readfirstlane(o.pbeg[rank * (kMaxChunks + 1) + c]);
   const __attribute__((address_space(1))) int32_t* sfr = (const __attribute__((address_space(1))) int32_t*)o.sfirst_row;
 #pragma unroll
-  for (int c = 0; c < kMaxChunks; ++c) st.frow[c] = st.pb[c + 1] > st.pb[c] ? sfr[((size_t)rank * kMaxChunks + c) * kPT + threadIdx.x] : 0;
+  for (int c = 0; c < 2; ++c) st.frow[c] = st.pb[c + 1] > st.pb[c] ? sfr[((size_t)rank * kMaxChunks + c) * kPT + threadIdx.x] : 0;      // (chunks 2.. : read per frame -- rare, and six registers more cost spills in the passes)
   st.pend = st.pb[0];            // = pb[K], picked with static indices (a dynamic index would keep the whole struct in scratch memory)
 #pragma unroll
   for (int c = 1; c <= kMaxChunks; ++c) st.pend = c == o.K ? st.pb[c] : st.pend;
 }
-// the piece `d` places behind piece q in the cyclic sequence [pfirst, pend)
-__device__ __forceinline__ int piece_after(int q, int d, int pfirst, int pend) {
-  int r = q + d;
-  const int n = pend - pfirst;
-  while (r >= pend) r -= n;
-  return r;
-}
 __device__ __forceinline__ void stream_prime(CDev2& o, StreamState& st) {
   const int pfirst = st.pb[0], pend = st.pend;
-  if (pend <= pfirst) return;
-  piece_load(o, piece_after(pfirst, 0, pfirst, pend), st.r0);
-  piece_load(o, piece_after(pfirst, 1, pfirst, pend), st.r1);
+  if (pfirst < pend) piece_load(o, pfirst, st.r0);
+  if (pfirst + 1 < pend) piece_load(o, pfirst + 1, st.r1);
 }
-__device__ __forceinline__ void streamed_segment(CDev2& o, int c, int p0, int p1, StreamState& st, const Lds2& L) {
+// Returns the number of pieces it requested (each kPieceLoads memory instructions, the youngest this wave has in flight).
+__device__ __forceinline__ int streamed_segment(CDev2& o, int rank, int c, int p0, int p1, StreamState& st, const Lds2& L) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int pfirst = st.pb[0], pend = st.pend;
-  const int frow = st.frow[c];
+  const int pend = st.pend;
+  const int frow = c < 2 ? st.frow[c < 2 ? c : 0]
+                         : ((const __attribute__((address_space(1))) int32_t*)o.sfirst_row)[((size_t)rank * kMaxChunks + c) * kPT + tid];
   float sum = 0.f;
-  int cc = frow;
+  int cc = frow, issued = 0;
   uint32_t had = 0;
   float old = L.accS[frow];
   for (int p = p0; p < p1; ++p) {
-    Piece nxt;
-    piece_load(o, piece_after(p, kPieceDepth, pfirst, pend), nxt);      // (kPieceDepth pieces ahead, cyclically)
     had |= st.r0.ends;
     piece_rows_any(o.estep, st.r0, L.table, L.accS, sum, cc, old);
-    st.r0 = st.r1; st.r1 = nxt;
+    st.r0 = st.r1;               // (the request goes out BEHIND the piece's arithmetic, into the registers it has freed: a
+    if (p + kPieceDepth < pend) { piece_load(o, p + kPieceDepth, st.r1); ++issued; }      // third piece in registers cost spills)
   }
   float x[1] = {sum};
   int fl = had != 0u ? 1 : 0;
@@ -542,6 +545,7 @@ __device__ __forceinline__ void streamed_segment(CDev2& o, int c, int p0, int p1
   const float cin = dpp_f<0x138, 0xf>(x[0]);
   if (had != 0u) L.accS[frow] += cin;
   if (lane == 63) L.wcarry[(2 + c) * kPW + w] = x[0];
+  return issued;
 }
 
 // The frame's row sums once its words are valid: both resident passes and every streamed segment over the vector at `src`.
@@ -594,22 +598,25 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
   if constexpr (STREAM) {
     const int (&pb)[kMaxChunks + 1] = st.pb;
     const int K = o.K;
-    if (pb[1] > pb[0]) streamed_segment(o, 0, pb[0], pb[1], st, L);
-    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
-    wait_vm(0);
+    int young = 0;
+    if (pb[1] > pb[0]) young = streamed_segment(o, rank, 0, pb[0], pb[1], st, L);
+    if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); young = 0; }
+    // chunk 1 has landed (this wave's part) -- the pieces requested behind its copy (the first ones of the next segment) stay
+    // in flight through pass B: the barrier orders LDS only (a __syncthreads() would wait for vmcnt(0))
+    wait_vm(kPieceLoads * (young < kPieceDepth ? young : kPieceDepth));
     stage();
-    __syncthreads();                       // chunk 1 is complete, and buffer 0 is free
+    lds_only_barrier();                    // chunk 1 is complete, and buffer 0 is free
     if (K > 2) dma_chunk(src, o, 2, L.table, rank);
     pass_rows_any<kQ, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
     // (consecutive segments add to the same rows of accS: the barrier between two chunks separates them)
-    if (pb[2] > pb[1]) streamed_segment(o, 1, pb[1], pb[2], st, L);
+    if (pb[2] > pb[1]) streamed_segment(o, rank, 1, pb[1], pb[2], st, L);
 #pragma unroll
     for (int c = 2; c < kMaxChunks; ++c) {       // (static indices: a dynamic one would put the arrays of `st` into scratch memory)
       if (c >= K) break;
       wait_vm(0);
       __syncthreads();                     // chunk c is complete, and the buffer of chunk c-1 is free
       if (c + 1 < K) dma_chunk(src, o, c + 1, L.table, rank);
-      if (pb[c + 1] > pb[c]) streamed_segment(o, c, pb[c], pb[c + 1], st, L);
+      if (pb[c + 1] > pb[c]) streamed_segment(o, rank, c, pb[c], pb[c + 1], st, L);
     }
   } else {
     if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
@@ -837,6 +844,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     wait_stores();        // this rank's slice of frame t+1 (and the reset above) is in L2 before its partial sum says so
     block_sum2<kPW>(loc, unused, L.red);
     if (tid == 0 && publish) st_agent(word_of(pring, t + 1, rank, 0), loc);
+    if constexpr (STREAM) { if (publish) stream_prime(o, st); }      // the next frame's first pieces: requested now, used behind its pass A
     DP_T(6);
     DP_TL(0, 6);
     // the history the parallel passes read (nobody waits for these stores)
@@ -1034,6 +1042,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     DP_T(5);
     DP_TL(1, 5);
     if (publish) emit(t);
+    if constexpr (STREAM) { if (publish) stream_prime(o, st); }
     DP_T(6);
     DP_TL(1, 6);
     gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * d.brec;
