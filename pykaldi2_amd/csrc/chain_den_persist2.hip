@@ -460,33 +460,55 @@ __device__ __forceinline__ void piece_load(CDev2& o, int piece, Piece& q) {
   q.ix = si[0];
   q.ends = se[at];
 }
+// Round 5: the piece's arithmetic in the form of the resident passes (gathers and waits as inline asm, a row-end place as
+// v_add_co + s_and_saveexec + one LDS instruction) -- with ds_add_f32 where a pass stores: the sums ADD to the row, and the
+// LDS adds them itself instead of the lane reading the old value one row end ahead, waiting for it (lgkmcnt(0), 2 multiply-
+// adds behind the read) and storing the sum.  Same value: old + sum either way.
+__device__ __forceinline__ void row_end_add(unsigned& m, uint32_t& cb, float& sum) {
+  uint64_t save;
+  asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\ts_and_saveexec_b64 %3, vcc\n\tds_add_f32 %1, %2\n\t"
+               "v_add_u32 %1, 4, %1\n\tv_mov_b32 %2, 0\n\ts_or_b64 exec, exec, %3"
+               : "+v"(m), "+v"(cb), "+v"(sum), "=&s"(save) : : "vcc", "scc", "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(float& a0, float& a1, float& a2, float& a3) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
+}
 template <int ESTEP>
-__device__ __forceinline__ void piece_rows(const Piece q, const float* table, float* acc, float& sum, int& c, float& old) {
+__device__ __forceinline__ void piece_rows(const Piece q, uint32_t base, uint32_t& cb, float& sum) {
   uint32_t packed = 0;
 #pragma unroll
   for (int k = 0; k < kSP / ESTEP; ++k) packed |= ((q.ends >> (k * ESTEP + ESTEP - 1)) & 1u) << k;
   unsigned m = __builtin_bitreverse32(packed);
-  float a[kSP];
+  uint32_t ad[8];
 #pragma unroll
   for (int j = 0; j < kSP; ++j) {
     const uint32_t pk = q.ix[j >> 1];
-    const uint32_t byte_off = (j & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2;
-    a[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + byte_off);
+    ad[j] = base + ((j & 1) ? (pk >> 16) << 2 : (pk & 0xffffu) << 2);
   }
+  float a[8];
+  lds_gather8(ad, a);
+  // LDS operations complete in order: the first four gathers have landed when four operations are outstanding; the second
+  // wait leaves the row-end adds of the first half in flight (one instruction per place, whatever its exec mask)
+  lds_wait4<4>(a[0], a[1], a[2], a[3]);
 #pragma unroll
-  for (int j = 0; j < kSP; ++j) {
-    sum = fmaf(a[j], j < 4 ? q.p0[j & 3] : q.p1[j & 3], sum);
-    if ((j + 1) % ESTEP == 0) {
-      if (__builtin_add_overflow(m, m, &m)) { acc[c] = old + sum; ++c; sum = 0.f; old = acc[c]; }
-    }
+  for (int j = 0; j < 4; ++j) {
+    sum = fmaf(a[j], q.p0[j], sum);
+    if ((j + 1) % ESTEP == 0) row_end_add(m, cb, sum);
+  }
+  lds_wait4<(ESTEP <= 4 ? 4 / ESTEP : 0)>(a[4], a[5], a[6], a[7]);
+#pragma unroll
+  for (int j = 4; j < 8; ++j) {
+    sum = fmaf(a[j], q.p1[j & 3], sum);
+    if ((j + 1) % ESTEP == 0) row_end_add(m, cb, sum);
   }
 }
-__device__ __forceinline__ void piece_rows_any(int estep, const Piece q, const float* table, float* acc, float& sum, int& c, float& old) {
+__device__ __forceinline__ void piece_rows_any(int estep, const Piece q, uint32_t base, uint32_t& cb, float& sum) {
   switch (estep) {
-    case 8: piece_rows<8>(q, table, acc, sum, c, old); break;
-    case 4: piece_rows<4>(q, table, acc, sum, c, old); break;
-    case 2: piece_rows<2>(q, table, acc, sum, c, old); break;
-    default: piece_rows<1>(q, table, acc, sum, c, old); break;
+    case 8: piece_rows<8>(q, base, cb, sum); break;
+    case 4: piece_rows<4>(q, base, cb, sum); break;
+    case 2: piece_rows<2>(q, base, cb, sum); break;
+    default: piece_rows<1>(q, base, cb, sum); break;
   }
 }
 
@@ -494,9 +516,9 @@ __device__ __forceinline__ void piece_rows_any(int estep, const Piece q, const f
 // (segment after segment), and kPieceDepth of them travel in registers: st.r0 is the piece to be summed now, st.r1 is on its
 // way.  (With one piece ahead a piece's loads were issued one piece's arithmetic -- ~0.2 us -- before they were needed,
 // against ~1 us of L2 latency under load: every piece waited, 1.15 us each in the phase timers of a 1.5 M-arc graph.)  The
-// first two pieces of a frame are requested at the END of the frame before (stream_prime, behind the publication of the
-// rank's slice: the poll, the copy of chunk 0 and pass A lie between the request and the use); the sequence does not wrap,
-// so no request is in flight at the frame's last barriers, which wait for vmcnt(0).  `frow` -- the row a thread's first slot
+// first two pieces of a frame are requested in the frame before, as soon as its last segment has emptied the registers
+// (frame_rows: the epilogue, the poll, the copy of chunk 0 and pass A lie between the request and the use); the sequence does not wrap,
+// and the barriers between the request and the epilogue's stores order LDS only.  `frow` -- the row a thread's first slot
 // of the segment belongs to -- is a constant of the task and comes from a register (it used to be a global load at the head
 // of every segment of every frame, with the LDS read of that row's running sum behind it).
 constexpr int kPieceDepth = 2;
@@ -525,12 +547,13 @@ __device__ __forceinline__ int streamed_segment(CDev2& o, int rank, int c, int p
   const int frow = c < 2 ? st.frow[c < 2 ? c : 0]
                          : ((const __attribute__((address_space(1))) int32_t*)o.sfirst_row)[((size_t)rank * kMaxChunks + c) * kPT + tid];
   float sum = 0.f;
-  int cc = frow, issued = 0;
+  int issued = 0;
   uint32_t had = 0;
-  float old = L.accS[frow];
+  uint32_t cb = lds_addr(L.accS) + 4u * (uint32_t)frow;
+  const uint32_t base = lds_addr(L.table);
   for (int p = p0; p < p1; ++p) {
     had |= st.r0.ends;
-    piece_rows_any(o.estep, st.r0, L.table, L.accS, sum, cc, old);
+    piece_rows_any(o.estep, st.r0, base, cb, sum);
     st.r0 = st.r1;               // (the request goes out BEHIND the piece's arithmetic, into the registers it has freed: a
     if (p + kPieceDepth < pend) { piece_load(o, p + kPieceDepth, st.r1); ++issued; }      // third piece in registers cost spills)
   }
@@ -563,7 +586,7 @@ struct RowSpan { int nrows, uncA, ncA, uncB, ncB; };
 template <bool STREAM, typename ST, typename STAGE>
 __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, const RowSpan& rs, const FrameRegs& r,
                                            const DmaPlan& plan, ST& st, const Lds2& L, DpTimers& dp_, STAGE stage,
-                                           bool chunk0_issued = false) {
+                                           bool chunk0_issued = false, bool prime_next = false) {
   const int tid = threadIdx.x;
   if constexpr (STREAM) {
     // the streamed segments add up in accS; compact rows past a truncated resident list get no store from their pass
@@ -600,14 +623,17 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     const int K = o.K;
     int young = 0;
     if (pb[1] > pb[0]) young = streamed_segment(o, rank, 0, pb[0], pb[1], st, L);
+    DP_T(8);
     if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); young = 0; }
     // chunk 1 has landed (this wave's part) -- the pieces requested behind its copy (the first ones of the next segment) stay
     // in flight through pass B: the barrier orders LDS only (a __syncthreads() would wait for vmcnt(0))
     wait_vm(kPieceLoads * (young < kPieceDepth ? young : kPieceDepth));
     stage();
     lds_only_barrier();                    // chunk 1 is complete, and buffer 0 is free
+    DP_T(3);
     if (K > 2) dma_chunk(src, o, 2, L.table, rank);
     pass_rows_any<kQ, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
+    DP_T(4);
     // (consecutive segments add to the same rows of accS: the barrier between two chunks separates them)
     if (pb[2] > pb[1]) streamed_segment(o, rank, 1, pb[1], pb[2], st, L);
 #pragma unroll
@@ -618,6 +644,10 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
       if (c + 1 < K) dma_chunk(src, o, c + 1, L.table, rank);
       if (pb[c + 1] > pb[c]) streamed_segment(o, rank, c, pb[c], pb[c + 1], st, L);
     }
+    // the next frame's first pieces: requested now, into the registers the last segment has emptied -- they flow in while
+    // the epilogue works on LDS (the caller's barrier orders LDS only); requested behind the publication instead, the
+    // poll's answers queued behind them: +1.5 us per frame between "published" and "words valid" in the phase timers
+    if (prime_next) stream_prime(o, st);
   } else {
     if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
     wait_vm(0);
@@ -626,7 +656,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     DP_T(3);
     pass_rows_any<kQ, STREAM>(o.estep, r.prob, r.addr, r.base, r.endsB, r.frowB, L.accB, L.wcarry + kPW, NoDma());
   }
-  DP_T(4);
+  if constexpr (STREAM) DP_T(9); else DP_T(4);
 }
 
 // Value of rank-local row q after the frame's passes: its entries in the two compact row arrays (and the streamed one) plus
@@ -814,9 +844,9 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
         if (r < nrows) L.xown[r] = xr[i];
       }
       if (publish) prefetch(t + 1);
-    }, chunk0_issued);
+    }, chunk0_issued, publish);
     DP_TL(0, 4);
-    __syncthreads();
+    if constexpr (STREAM) lds_only_barrier(); else __syncthreads();      // (the row sums are in LDS; a streaming frame has piece loads in flight)
     if (rank == 0 && tid == 0) G(d.asum)[f0 + t] = as;
     const float lk = d.leaky * as, inv_as = 1.0f / as;
     // rows are virtual states (dst, pdf); a thread per real state sums its rows and adds the peeled self-loop.  First
@@ -844,7 +874,6 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     wait_stores();        // this rank's slice of frame t+1 (and the reset above) is in L2 before its partial sum says so
     block_sum2<kPW>(loc, unused, L.red);
     if (tid == 0 && publish) st_agent(word_of(pring, t + 1, rank, 0), loc);
-    if constexpr (STREAM) { if (publish) stream_prime(o, st); }      // the next frame's first pieces: requested now, used behind its pass A
     DP_T(6);
     DP_TL(0, 6);
     // the history the parallel passes read (nobody waits for these stores)
@@ -1022,9 +1051,9 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     frame_rows<STREAM>(o, src_t, rank, rs, fr, plan, st, L, dp_, [&]() {
       if (publish) stage_x();
       if (t >= 2) prefetch(t - 2);          // (xw is free again; xl_next becomes xl_prev at the end of the frame)
-    }, chunk0_issued);
+    }, chunk0_issued, publish);
     DP_TL(1, 4);
-    __syncthreads();
+    if constexpr (STREAM) lds_only_barrier(); else __syncthreads();
     // rows are source states: btilde'[t, s] = row + peeled loop, then beta-hat[t, s] with the sums received above
     const float cu = lB + d.wu * lU;
     const float inv_c = cu > 0.f ? 1.0f / cu : 0.f;
@@ -1042,7 +1071,6 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     DP_T(5);
     DP_TL(1, 5);
     if (publish) emit(t);
-    if constexpr (STREAM) { if (publish) stream_prime(o, st); }
     DP_T(6);
     DP_TL(1, 6);
     gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * d.brec;

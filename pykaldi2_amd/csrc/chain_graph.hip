@@ -824,6 +824,7 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
     if (best_estep == 0) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
     if (!persist2_arc_lists(A2, idx, h, best_estep, ptr, perm, &list_of, &lidx) ||
         !persist2_lists(A2, rows, prob2, piprob2, ptr, perm, list_of, lidx, best_estep, res, true, &h)) { f.ok = b.ok = false; return; }
+    if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: %s rows padded to %d slots, %d table chunks, at most %d streamed pieces per rank\n", which == 0 ? "fwd" : "bwd", best_estep, h.K, h.max_pieces);
   }
   if (!(f.ok && b.ok)) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); f.ok = b.ok = false; return; }
   g->p2_cap = cap;

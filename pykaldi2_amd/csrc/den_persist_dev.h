@@ -15,11 +15,11 @@ constexpr long long kDenSpinTicks = 1000LL * 1000 * 100;   // 1 s of the 100 MHz
 #ifdef PK2_DP_PROFILE
 // Phase timers of rank 0 / thread 0 (shader clocks, averaged over the frames of a call) and the wall-clock timeline of one
 // frame on every rank.  The counters live in `dp_` (DP_T0 declares it; helper functions receive it by reference).
-struct DpTimers { long long last; unsigned long long acc[8]; int tl_on, tl_dir, tl_rank; };
-static __device__ unsigned long long g_dp_prof[2][8];
-#define DP_T0() DpTimers dp_; dp_.last = clock64(); for (int k_ = 0; k_ < 8; ++k_) dp_.acc[k_] = 0
+struct DpTimers { long long last; unsigned long long acc[10]; int tl_on, tl_dir, tl_rank; };
+static __device__ unsigned long long g_dp_prof[2][10];
+#define DP_T0() DpTimers dp_; dp_.last = clock64(); for (int k_ = 0; k_ < 10; ++k_) dp_.acc[k_] = 0
 #define DP_T(k) do { const long long n_ = clock64(); dp_.acc[k] += (unsigned long long)(n_ - dp_.last); dp_.last = n_; } while (0)
-#define DP_FLUSH(dir) do { if (rank == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_dp_prof[dir][k_], dp_.acc[k_]); } while (0)
+#define DP_FLUSH(dir) do { if (rank == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&g_dp_prof[dir][k_], dp_.acc[k_]); } while (0)
 static __device__ long long g_dp_tl[2][kPR][8];     // wall-clock (10 ns) timeline of frame 100 of the first sequence, per rank
 #define DP_TL(dir, k) do { if (g == 0 && t == 100 && threadIdx.x == 0) g_dp_tl[dir][rank][k] = wall_clock64(); } while (0)
 #define DP_TLSET(dir) do { dp_.tl_on = (g == 0 && t == 100) ? 1 : 0; dp_.tl_dir = dir; dp_.tl_rank = rank; } while (0)
@@ -35,14 +35,14 @@ static __global__ void dp_prof_print(int frames, int form) {
   }
   for (int dir = 0; dir < 2; ++dir) {
     if (form == 2)
-      printf("den_persist2 %s rank 0 thread 0, shader clocks per frame over %d frames: poll + sync + stage + copies issued %llu | chunk 0 landed + barrier %llu | pass A %llu | chunk 1 landed + barrier %llu | pass B (+ streamed) %llu | barrier + epilogue %llu | wait stores + block sum + publish %llu | history + prefetch %llu\n",
+      printf("den_persist2 %s rank 0 thread 0, shader clocks per frame over %d frames: poll + sync + stage + copies issued %llu | chunk 0 landed + barrier %llu | pass A %llu | chunk 1 landed + barrier %llu | pass B (+ streamed) %llu | barrier + epilogue %llu | wait stores + block sum + publish %llu | history + prefetch %llu | streamed segment 0 %llu | streamed segments 1.. %llu\n",
              dir ? "bwd" : "fwd", frames, g_dp_prof[dir][0] / frames, g_dp_prof[dir][1] / frames, g_dp_prof[dir][2] / frames,
-             g_dp_prof[dir][3] / frames, g_dp_prof[dir][4] / frames, g_dp_prof[dir][5] / frames, g_dp_prof[dir][6] / frames, g_dp_prof[dir][7] / frames);
+             g_dp_prof[dir][3] / frames, g_dp_prof[dir][4] / frames, g_dp_prof[dir][5] / frames, g_dp_prof[dir][6] / frames, g_dp_prof[dir][7] / frames, g_dp_prof[dir][8] / frames, g_dp_prof[dir][9] / frames);
     else
       printf("den_persist %s rank 0 thread 0, shader clocks per frame over %d frames: exchange (poll + table) %llu | barrier %llu | arcs %llu | barrier+fixup+barrier %llu | epilogue %llu | wait stores + block sum + publish %llu | prefetch %llu\n",
              dir ? "bwd" : "fwd", frames, g_dp_prof[dir][0] / frames, g_dp_prof[dir][1] / frames, g_dp_prof[dir][2] / frames,
              g_dp_prof[dir][3] / frames, g_dp_prof[dir][4] / frames, g_dp_prof[dir][5] / frames, g_dp_prof[dir][6] / frames);
-    for (int k = 0; k < 8; ++k) g_dp_prof[dir][k] = 0;
+    for (int k = 0; k < 10; ++k) g_dp_prof[dir][k] = 0;
   }
 }
 #else
