@@ -100,6 +100,39 @@ __device__ __forceinline__ Lds2 carve_lds2(int tfloats, int cap, int arrays) {
 // Workgroup barrier that orders LDS accesses only: the LDS-DMA instructions a wave has in flight stay in flight.
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Loads / stores of data touched once per call (x of the frames, the alpha / beta history): non-temporal in the kernels
+// WITHOUT streamed pieces (round 5; -DPK2_DP2_NT=0 for plain ones).  Measured (profiles/r05_den_stream.txt): the bench graph
+// 7.24 -> 7.04 us per frame -- the once-only lines no longer displace the state vectors the 32 ranks copy in every frame
+// from the XCD's L2; the streaming kernels got SLOWER with them (S = 30 k, 1.5 M arcs: 11.2 -> 12.7 us; the stores then go
+// out to memory at once, over the fabric the pieces come in by), so they keep plain accesses.
+#ifndef PK2_DP2_NT
+#define PK2_DP2_NT 1
+#endif
+template <bool NT>
+__device__ __forceinline__ float once_load(cgfloat* p) {
+  if constexpr (NT && PK2_DP2_NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void once_store(gfloat* p, float v) {
+  if constexpr (NT && PK2_DP2_NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// The streaming kernels sit at the 256-register limit, and whatever the compiler hoists out of the frame loop (per-thread
+// 64-bit addresses, LDS addresses of the thread's map entries) it spills -- and reloads with s_waitcnt vmcnt(0), behind the
+// streamed pieces in flight.  An index made opaque per frame is recomputed instead (one or two VALU instructions).
+template <bool ON>
+__device__ __forceinline__ int per_frame(int r) {
+  if constexpr (ON) asm volatile("" : "+v"(r));
+  return r;
+}
+// x[ubase + idx] with a uniform base and a 32-bit per-thread index: SGPR base + VGPR offset, no 64-bit per-thread address.
+__device__ __forceinline__ float ld_uniform_base(cgfloat* ubase, int idx) {
+  typedef __attribute__((address_space(1))) const char gchar;
+  return *(cgfloat*)((gchar*)ubase + (uint32_t)idx * 4u);
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate has to be a constant).  As the BUILTIN, not as inline
 // assembly (round 5): the compiler's own wait-count pass reads an s_waitcnt instruction it finds and knows afterwards that
 // its earlier loads have landed; behind an opaque asm it kept waiting for registers loaded frames ago with vmcnt(few) --
@@ -333,6 +366,10 @@ __device__ __forceinline__ void lds_wait8(float (&a)[8]) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
                : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void lds_wait4(float& a0, float& a1, float& a2, float& a3) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
+}
 // A row-end place: the top bit of m says whether this lane's row ends here; if so its sum is stored, the row address moves on.
 __device__ __forceinline__ void row_end_place(unsigned& m, uint32_t& cb, float& sum) {
   uint64_t save;
@@ -450,15 +487,36 @@ __device__ __forceinline__ void pass_rows_any(int estep, const float (&prob)[kPK
 typedef float __attribute__((ext_vector_type(4))) f32x4;
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4v;
 struct Piece { f32x4 p0, p1; u32x4v ix; uint32_t ends; };
+#ifndef PK2_ST_SADDR
+#define PK2_ST_SADDR 0
+#endif
+#ifndef PK2_ST_OPAQUE
+#define PK2_ST_OPAQUE 1
+#endif
+#ifndef PK2_ST_PRIME_LATE
+#define PK2_ST_PRIME_LATE 0
+#endif
 __device__ __forceinline__ void piece_load(CDev2& o, int piece, Piece& q) {
+  static_assert(kSP == 8, "a piece is two float4 of probabilities and one uint4 of packed offsets per thread");
+#if PK2_ST_SADDR
+  // uniform base (SGPR pair) + one 32-bit byte offset per thread
+  const uint32_t e4 = ((uint32_t)piece * kPT + threadIdx.x) * 4u;           // byte offset of the thread's row-end word
+  typedef __attribute__((address_space(1))) const char gchar;
+  const __attribute__((address_space(1))) f32x4* sp = (const __attribute__((address_space(1))) f32x4*)((gchar*)o.sprob + e4 * 8u);
+  const __attribute__((address_space(1))) u32x4v* si = (const __attribute__((address_space(1))) u32x4v*)((gchar*)o.sidx2 + e4 * 4u);
+  const __attribute__((address_space(1))) uint32_t* se = (const __attribute__((address_space(1))) uint32_t*)((gchar*)o.sends + e4);
+  q.p0 = sp[0]; q.p1 = sp[1];
+  q.ix = si[0];
+  q.ends = se[0];
+#else
   const size_t at = (size_t)piece * kPT + threadIdx.x;
   const __attribute__((address_space(1))) f32x4* sp = (const __attribute__((address_space(1))) f32x4*)o.sprob + at * (kSP / 4);
   const __attribute__((address_space(1))) u32x4v* si = (const __attribute__((address_space(1))) u32x4v*)o.sidx2 + at;
   const __attribute__((address_space(1))) uint32_t* se = (const __attribute__((address_space(1))) uint32_t*)o.sends;
-  static_assert(kSP == 8, "a piece is two float4 of probabilities and one uint4 of packed offsets per thread");
   q.p0 = sp[0]; q.p1 = sp[1];
   q.ix = si[0];
   q.ends = se[at];
+#endif
 }
 // Round 5: the piece's arithmetic in the form of the resident passes (gathers and waits as inline asm, a row-end place as
 // v_add_co + s_and_saveexec + one LDS instruction) -- with ds_add_f32 where a pass stores: the sums ADD to the row, and the
@@ -469,10 +527,6 @@ __device__ __forceinline__ void row_end_add(unsigned& m, uint32_t& cb, float& su
   asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\ts_and_saveexec_b64 %3, vcc\n\tds_add_f32 %1, %2\n\t"
                "v_add_u32 %1, 4, %1\n\tv_mov_b32 %2, 0\n\ts_or_b64 exec, exec, %3"
                : "+v"(m), "+v"(cb), "+v"(sum), "=&s"(save) : : "vcc", "scc", "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_wait4(float& a0, float& a1, float& a2, float& a3) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
 }
 template <int ESTEP>
 __device__ __forceinline__ void piece_rows(const Piece q, uint32_t base, uint32_t& cb, float& sum) {
@@ -647,7 +701,7 @@ __device__ __forceinline__ void frame_rows(CDev2& o, cgfloat* src, int rank, con
     // the next frame's first pieces: requested now, into the registers the last segment has emptied -- they flow in while
     // the epilogue works on LDS (the caller's barrier orders LDS only); requested behind the publication instead, the
     // poll's answers queued behind them: +1.5 us per frame between "published" and "words valid" in the phase timers
-    if (prime_next) stream_prime(o, st);
+    if (prime_next && !PK2_ST_PRIME_LATE) stream_prime(o, st);
   } else {
     if (shared) { lds_only_barrier(); dma_chunk(src, o, 1, L.table, rank); }
     wait_vm(0);
@@ -788,7 +842,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
       cgfloat* row = xp_g + (size_t)t * d.P;
 #pragma unroll
       for (int i = 0; i < PSPT; ++i) {
-        const int r = tid + i * kPT;
+        const int r = per_frame<STREAM && PK2_ST_OPAQUE>(tid + i * kPT);
         const int pv = r < nrows ? L.pdfv[r] : -1, pl = st_ok[i] ? L.pdfl[r] : -1;
         xr[i] = r < nrows ? (pv >= 0 ? row[pv] : 1.f) : 0.f;
         xln[i] = st_ok[i] ? (pl >= 0 ? row[pl] : 1.f) : 0.f;
@@ -797,9 +851,14 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     }
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
-      const int r = tid + i * kPT;
-      xr[i] = r < nrows ? xv_g[(size_t)t * V + row0 + r] : 0.f;
-      xln[i] = st_ok[i] ? xl_g[(size_t)t * S + g0 + r] : 0.f;
+      const int r = per_frame<STREAM && PK2_ST_OPAQUE>(tid + i * kPT);
+      if constexpr (STREAM && PK2_ST_OPAQUE) {
+        xr[i] = r < nrows ? ld_uniform_base(xv_g + ((size_t)t * V + row0), r) : 0.f;
+        xln[i] = st_ok[i] ? ld_uniform_base(xl_g + ((size_t)t * S + g0), r) : 0.f;
+      } else {
+        xr[i] = r < nrows ? once_load<!STREAM>(&xv_g[(size_t)t * V + row0 + r]) : 0.f;
+        xln[i] = st_ok[i] ? once_load<!STREAM>(&xl_g[(size_t)t * S + g0 + r]) : 0.f;
+      }
     }
   };
   prefetch(0);
@@ -874,6 +933,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     wait_stores();        // this rank's slice of frame t+1 (and the reset above) is in L2 before its partial sum says so
     block_sum2<kPW>(loc, unused, L.red);
     if (tid == 0 && publish) st_agent(word_of(pring, t + 1, rank, 0), loc);
+    if constexpr (STREAM && PK2_ST_PRIME_LATE) { if (publish) stream_prime(o, st); }
     DP_T(6);
     DP_TL(0, 6);
     // the history the parallel passes read (nobody waits for these stores)
@@ -885,10 +945,10 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
       if (!st_ok[i]) continue;
       // (the occupancy pass reads alpha per OCCUPANCY state only; the per-state copy has no reader behind this kernel
       // -- 225 MB of stores per call on the bench graph until round 4 -- unless the two arrays are one: Vo == S)
-      if (!sep) alpha_n[g0 + tid + i * kPT] = outv[i];
+      if (!sep) once_store<!STREAM>(&alpha_n[g0 + tid + i * kPT], outv[i]);
       if (sep) {
-        for (int q = st_lo[i]; q < st_hi[i]; ++q) alphav_n[st_o[i] + q - st_lo[i]] = L.aux[q];
-        if (st_pl[i] > 0.f) alphav_n[st_o[i] + st_hi[i] - st_lo[i]] = loopv[i];
+        for (int q = st_lo[i]; q < st_hi[i]; ++q) once_store<!STREAM>(&alphav_n[st_o[i] + q - st_lo[i]], L.aux[q]);
+        if (st_pl[i] > 0.f) once_store<!STREAM>(&alphav_n[st_o[i] + st_hi[i] - st_lo[i]], loopv[i]);
       }
     }
 #pragma unroll
@@ -971,7 +1031,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
       cgfloat* row = xp_g + (size_t)t * d.P;
 #pragma unroll
       for (int i = 0; i < PSPT; ++i) {
-        const int r = tid + i * kPT;
+        const int r = per_frame<STREAM && PK2_ST_OPAQUE>(tid + i * kPT);
         const int pl = st_ok[i] ? L.pdfl[r] : -1, pv = r < nvirt ? L.pdfv[r] : -1;
         xl_next[i] = st_ok[i] ? (pl >= 0 ? row[pl] : 1.f) : 0.f;
         xw[i] = r < nvirt ? (pv >= 0 ? row[pv] : 1.f) : 0.f;
@@ -980,9 +1040,14 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     }
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
-      const int r = tid + i * kPT;
-      xl_next[i] = st_ok[i] ? xl_g[(size_t)t * S + row0 + r] : 0.f;
-      xw[i] = r < nvirt ? xv_g[(size_t)t * V + vfirst + r] : 0.f;
+      const int r = per_frame<STREAM && PK2_ST_OPAQUE>(tid + i * kPT);
+      if constexpr (STREAM && PK2_ST_OPAQUE) {
+        xl_next[i] = st_ok[i] ? ld_uniform_base(xl_g + ((size_t)t * S + row0), r) : 0.f;
+        xw[i] = r < nvirt ? ld_uniform_base(xv_g + ((size_t)t * V + vfirst), r) : 0.f;
+      } else {
+        xl_next[i] = st_ok[i] ? once_load<!STREAM>(&xl_g[(size_t)t * S + row0 + r]) : 0.f;
+        xw[i] = r < nvirt ? once_load<!STREAM>(&xv_g[(size_t)t * V + vfirst + r]) : 0.f;
+      }
     }
   };
   auto stage_x = [&]() {
@@ -1071,12 +1136,13 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     DP_T(5);
     DP_TL(1, 5);
     if (publish) emit(t);
+    if constexpr (STREAM && PK2_ST_PRIME_LATE) { if (publish) stream_prime(o, st); }
     DP_T(6);
     DP_TL(1, 6);
     gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * d.brec;
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
-      if (st_ok[i]) bx_t[(size_t)(vfirst + st_v0[i]) * d.brec] = vs[i];
+      if (st_ok[i]) once_store<!STREAM>(&bx_t[(size_t)(vfirst + st_v0[i]) * d.brec], vs[i]);
       xl_cur[i] = xl_prev[i];
       xl_prev[i] = xl_next[i];
     }
