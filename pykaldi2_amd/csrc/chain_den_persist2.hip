@@ -108,6 +108,20 @@ __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgk
 #ifndef PK2_DP2_NT
 #define PK2_DP2_NT 1
 #endif
+// The history stores of a frame (alpha / beta-hat for the parallel passes: nobody in this kernel waits for them) follow the
+// publication of the rank's slice -- ahead of the next frame's poll, whose first answer (vmcnt counts in order) comes back
+// behind their acknowledgements.  Round 5, measured and left off (-DPK2_DP2_LATE_HISTORY=1): the stores leaving from the
+// NEXT frame's staging point instead (behind the wait for table chunk 1, where every older memory operation has completed)
+// -- 7.16 us per frame against 7.07 on the bench graph, 5.10 against 5.03 at S = 10 k, two rounds each on one box
+// (profiles/r05_den_stream.txt): the poll's 0.6 us behind the stores is time the rank would spend waiting for the slowest
+// rank's words anyway, and the stores then compete with the x prefetch and pass B's row-end traffic.
+#ifndef PK2_DP2_LATE_HISTORY
+#define PK2_DP2_LATE_HISTORY 0
+#endif
+#ifndef PK2_DP2_LATE_STREAM
+#define PK2_DP2_LATE_STREAM 1          // ... in the kernels with streamed pieces too
+#endif
+template <bool STREAM> constexpr bool kLateHistory = PK2_DP2_LATE_HISTORY && (!STREAM || PK2_DP2_LATE_STREAM);
 template <bool NT>
 __device__ __forceinline__ float once_load(cgfloat* p) {
   if constexpr (NT && PK2_DP2_NT) return __builtin_nontemporal_load(p);
@@ -868,6 +882,26 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   float own_a[PSPT];
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) own_a[i] = st_pi[i];          // alpha[0, .] = pi
+  // the history the parallel passes read, frame tt: alpha[tt + 1] (own_a, until the next epilogue), the rows in L.aux
+  float hist_loop[PSPT], hist_loc = 0.f;
+#pragma unroll
+  for (int i = 0; i < PSPT; ++i) hist_loop[i] = 0.f;
+  auto history = [&](int tt) {
+    gfloat* alpha_n = G(d.alpha) + (f0 + tt + 1) * (size_t)S;
+    gfloat* alphav_n = G(d.alphav) + (f0 + tt + 1) * (size_t)Vo;
+    if (tid == 0) G(d.apart)[(f0 + tt + 1) * kPR + rank] = hist_loc;
+#pragma unroll
+    for (int i = 0; i < PSPT; ++i) {
+      if (!st_ok[i]) continue;
+      // (the occupancy pass reads alpha per OCCUPANCY state only; the per-state copy has no reader behind this kernel
+      // -- 225 MB of stores per call on the bench graph until round 4 -- unless the two arrays are one: Vo == S)
+      if (!sep) once_store<!STREAM>(&alpha_n[g0 + tid + i * kPT], own_a[i]);
+      if (sep) {
+        for (int q = st_lo[i]; q < st_hi[i]; ++q) once_store<!STREAM>(&alphav_n[st_o[i] + q - st_lo[i]], L.aux[q]);
+        if (st_pl[i] > 0.f) once_store<!STREAM>(&alphav_n[st_o[i] + st_hi[i] - st_lo[i]], hist_loop[i]);
+      }
+    }
+  };
   Spin spin(ctl);
   DP_T0();
   for (int t = 0; t < T; ++t) {
@@ -902,6 +936,7 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
         const int r = tid + i * kPT;
         if (r < nrows) L.xown[r] = xr[i];
       }
+      if (kLateHistory<STREAM> && t > 0) history(t - 1);
       if (publish) prefetch(t + 1);
     }, chunk0_issued, publish);
     DP_TL(0, 4);
@@ -936,25 +971,15 @@ __device__ __noinline__ void run_fwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     if constexpr (STREAM && PK2_ST_PRIME_LATE) { if (publish) stream_prime(o, st); }
     DP_T(6);
     DP_TL(0, 6);
-    // the history the parallel passes read (nobody waits for these stores)
-    gfloat* alpha_n = G(d.alpha) + (f0 + t + 1) * (size_t)S;
-    gfloat* alphav_n = G(d.alphav) + (f0 + t + 1) * (size_t)Vo;
-    if (tid == 0) G(d.apart)[(f0 + t + 1) * kPR + rank] = loc;
+    hist_loc = loc;
 #pragma unroll
-    for (int i = 0; i < PSPT; ++i) {
-      if (!st_ok[i]) continue;
-      // (the occupancy pass reads alpha per OCCUPANCY state only; the per-state copy has no reader behind this kernel
-      // -- 225 MB of stores per call on the bench graph until round 4 -- unless the two arrays are one: Vo == S)
-      if (!sep) once_store<!STREAM>(&alpha_n[g0 + tid + i * kPT], outv[i]);
-      if (sep) {
-        for (int q = st_lo[i]; q < st_hi[i]; ++q) once_store<!STREAM>(&alphav_n[st_o[i] + q - st_lo[i]], L.aux[q]);
-        if (st_pl[i] > 0.f) once_store<!STREAM>(&alphav_n[st_o[i] + st_hi[i] - st_lo[i]], loopv[i]);
-      }
-    }
+    for (int i = 0; i < PSPT; ++i) hist_loop[i] = loopv[i];
+    if (!kLateHistory<STREAM>) history(t);
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) xlr[i] = xln[i];
     DP_T(7);
   }
+  if (kLateHistory<STREAM> && T > 0) history(T - 1);
   DP_FLUSH(0);
 }
 
@@ -1091,6 +1116,16 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
   if (T >= 2) prefetch(T - 2);
 #pragma unroll
   for (int i = 0; i < PSPT; ++i) xl_prev[i] = xl_next[i];
+  // btilde'[tt, .] of the own states for the parallel passes (run_fwd2: from the next frame's staging point)
+  float vs_hist[PSPT];
+#pragma unroll
+  for (int i = 0; i < PSPT; ++i) vs_hist[i] = 0.f;
+  auto history = [&](int tt) {
+    gfloat* bx_t = G(d.beta) + (f0 + tt) * (size_t)V * d.brec;
+#pragma unroll
+    for (int i = 0; i < PSPT; ++i)
+      if (st_ok[i]) once_store<!STREAM>(&bx_t[(size_t)(vfirst + st_v0[i]) * d.brec], vs_hist[i]);
+  };
   if constexpr (STREAM) stream_prime(o, st);
   Spin spin(ctl);
   DP_T0();
@@ -1115,6 +1150,7 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     if (tid < 2 && publish) st_agent(word_of(pring, t + 2, rank, tid), __uint_as_float(kRingSentinel));   // (t-1) % 3 == (t+2) % 3
     frame_rows<STREAM>(o, src_t, rank, rs, fr, plan, st, L, dp_, [&]() {
       if (publish) stage_x();
+      if (kLateHistory<STREAM> && t + 1 < T) history(t + 1);
       if (t >= 2) prefetch(t - 2);          // (xw is free again; xl_next becomes xl_prev at the end of the frame)
     }, chunk0_issued, publish);
     DP_TL(1, 4);
@@ -1139,15 +1175,16 @@ __device__ __noinline__ void run_bwd2(CParams2* pp_, DenPersistCtl* ctl_, DenPer
     if constexpr (STREAM && PK2_ST_PRIME_LATE) { if (publish) stream_prime(o, st); }
     DP_T(6);
     DP_TL(1, 6);
-    gfloat* bx_t = G(d.beta) + (f0 + t) * (size_t)V * d.brec;
 #pragma unroll
     for (int i = 0; i < PSPT; ++i) {
-      if (st_ok[i]) once_store<!STREAM>(&bx_t[(size_t)(vfirst + st_v0[i]) * d.brec], vs[i]);
+      vs_hist[i] = vs[i];
       xl_cur[i] = xl_prev[i];
       xl_prev[i] = xl_next[i];
     }
+    if (!kLateHistory<STREAM>) history(t);
     DP_T(7);
   }
+  if (kLateHistory<STREAM> && T > 0) history(0);
   DP_FLUSH(1);
 }
 
