@@ -21,6 +21,7 @@
 // (den_persist_dev.h).  Replaces the same DenominatorComputation (reference ops/ops.py:265, bin/train_chain.py:202).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <type_traits>
 #include <vector>
@@ -1264,8 +1265,12 @@ __global__ void __launch_bounds__(kPT) den_persist2_kernel(const DenPersist2Para
   }
 }
 
-__global__ void den_persist2_check(const DenPersistCtl* ctl, int ntasks, float* den_lp, int n, unsigned* guard_dev, unsigned* guard_host) {
-  if (ctl->abort != 0u || ctl->done != (unsigned)ntasks) {
+// (round 5: it also leaves the control block zeroed for the next launch on this stream -- one fill kernel less per call)
+__global__ void den_persist2_check(DenPersistCtl* ctl, int ntasks, float* den_lp, int n, unsigned* guard_dev, unsigned* guard_host) {
+  const bool bad = ctl->abort != 0u || ctl->done != (unsigned)ntasks;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < sizeof(DenPersistCtl) / sizeof(unsigned); i += blockDim.x) reinterpret_cast<unsigned*>(ctl)[i] = 0u;
+  if (bad) {
     if (threadIdx.x == 0) persist_guard_raise(guard_dev, guard_host);
     for (int i = threadIdx.x; i < n; i += blockDim.x) den_lp[i] = __uint_as_float(0x7fc00000u);
   }
@@ -1275,7 +1280,9 @@ __global__ void den_persist2_check(const DenPersistCtl* ctl, int ntasks, float* 
 // host
 // ----------------------------------------------------------------------------------------
 static PerDevice<int> g_den_persist2_state_pd(-1);     // -1: not verified yet, 0: unusable on this device, 1: verified
-struct DenPersist2Scratch { DenPersist2Params* params = nullptr; DenPersistCtl* ctl = nullptr; float* ring = nullptr; float* pring = nullptr; int rpad = 0; int ntasks = 0; };
+struct DenPersist2Scratch { DenPersist2Params* params = nullptr; DenPersistCtl* ctl = nullptr; float* ring = nullptr; float* pring = nullptr; int rpad = 0; int ntasks = 0;
+                            bool ctl_clean = false;         // the last launch's check kernel has zeroed the control block
+                            std::vector<unsigned char> params_host; };      // what `params` holds (a call with the same block skips the store)
 static std::map<DevStream, DenPersist2Scratch> g_den2_scratch;
 
 static int den2_rpad(const pk2_den_graph* g) { return (std::max(g->S, g->V) + 255) / 256 * 256 + 256; }
@@ -1339,6 +1346,7 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
     sc.rpad = rpad;
   }
   DenPersist2Params p;
+  memset(static_cast<void*>(&p), 0, sizeof(p));      // (padding too: the block is compared with the last one stored)
   p.d = dp;
   p.fwd = g->p2fwd; p.bwd = g->p2bwd;
   p.xv = xv; p.ring = sc.ring; p.pring = sc.pring;
@@ -1373,8 +1381,15 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
                                 160 * 1024));
     attr = true;
   }
-  PK2_HIP(hipMemsetAsync(sc.ctl, 0, sizeof(DenPersistCtl), stream));
-  hipLaunchKernelGGL(param_block_store<DenPersist2Params>, dim3(1), dim3(1), 0, stream, p, sc.params);
+  if (!sc.ctl_clean) PK2_HIP(hipMemsetAsync(sc.ctl, 0, sizeof(DenPersistCtl), stream));
+  sc.ctl_clean = false;
+  {
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(&p);
+    if (sc.params_host.size() != sizeof(p) || memcmp(sc.params_host.data(), pb, sizeof(p)) != 0) {
+      hipLaunchKernelGGL(param_block_store<DenPersist2Params>, dim3(1), dim3(1), 0, stream, p, sc.params);
+      sc.params_host.assign(pb, pb + sizeof(p));
+    }
+  }
   hipLaunchKernelGGL(den_persist2_kernel, dim3(8 * kPR), dim3(kPT), lds, stream, sc.params, sc.ctl);
 #ifdef PK2_DP_PROFILE
   { int tot = 0; for (int n = 0; n < N; ++n) tot += lengths_host[n];
@@ -1398,10 +1413,13 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& dp, const float* xv, 
 }
 
 void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream) {
-  const DenPersist2Scratch& sc = g_den2_scratch[dev_stream(stream)];
+  DenPersist2Scratch& sc = g_den2_scratch[dev_stream(stream)];
   PersistGuard guard;
   (void)persist_guard(&guard);
-  if (sc.ctl && sc.ntasks > 0) hipLaunchKernelGGL(den_persist2_check, dim3(1), dim3(64), 0, stream, sc.ctl, sc.ntasks, den_lp, N, guard.dev, guard.host_dev);
+  if (sc.ctl && sc.ntasks > 0) {
+    hipLaunchKernelGGL(den_persist2_check, dim3(1), dim3(256), 0, stream, sc.ctl, sc.ntasks, den_lp, N, guard.dev, guard.host_dev);
+    sc.ctl_clean = true;
+  }
 }
 
 }  // namespace pk2

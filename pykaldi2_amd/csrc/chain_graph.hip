@@ -817,7 +817,10 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
       // (round 4: the FIRST streamed piece costs ~5 us per frame -- the streaming variant of the frame: zeroed row arrays,
       // spill reloads behind the piece loads -- and ~0.9 each after it (profiles/r04_den_sweep.txt: S = 30 k, 1.0 -> 1.5 M
       // arcs = 4 pieces: 7.75 -> 15.1); the old 0.3 + 0.6 per piece chose padded rows + one piece over unpadded rows)
-      const double cost = arcs_us(estep) + (cand.max_pieces ? 4.5 + 0.9 * cand.max_pieces : 0.0);
+      // (round 5, profiles/r05_den_stream.txt: the streaming variant's fixed cost is gone -- pieces in registers, requested
+      // two ahead, no reload in front of a request: S = 30 k, 4 pieces 7.08 -> 10.95, 8 pieces 14.46 -- 0.9 us a piece
+      // and ~0.4 for the variant)
+      const double cost = arcs_us(estep) + (cand.max_pieces ? 0.4 + 0.9 * cand.max_pieces : 0.0);
       if (cost < best_cost) { best_cost = cost; best_estep = estep; }
       if (cand.max_pieces == 0 && cand.K == 2) break;
     }

@@ -907,9 +907,14 @@ __global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl
 // `mail` (backward pass): an aborted launch leaves consumed and unconsumed hand-overs in the mailboxes, which the next
 // launch would read as valid ones -- the same workgroup fills them with sentinels again, so that a caller who
 // lowers the guard (pk2_persist_guard_clear) and carries on does not compute on stale words.
-__global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host,
+// (round 5: the check also leaves the control block zeroed for the next launch on this stream -- one hipMemsetAsync, i.e.
+// one fill kernel, less per recurrence launch: six per LF-MMI step)
+__global__ void lstm_seq_check(SeqCtl* ctl, unsigned pairs, float* out, size_t n, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host,
                                float* mail, size_t mail_n) {
-  if (ctl->abort == 0u && ctl->done == pairs) return;
+  const bool good = ctl->abort == 0u && ctl->done == pairs;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < sizeof(SeqCtl) / sizeof(unsigned); i += blockDim.x) reinterpret_cast<unsigned*>(ctl)[i] = 0u;
+  if (good) return;
   if (threadIdx.x == 0) { *sticky = 1u; persist_guard_raise(guard_dev, guard_host); }
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = __uint_as_float(0x7fc00000u);
   for (size_t i = threadIdx.x; i < mail_n; i += blockDim.x) mail[i] = __uint_as_float(kSeqSentinel);
@@ -917,13 +922,14 @@ __global__ void lstm_seq_check(const SeqCtl* ctl, unsigned pairs, float* out, si
 
 // ---- host -------------------------------------------------------------------------------------------------------------
 struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; PersistGuard guard;
-                    int mail_clean_teams = 0; };      // mailboxes of that many teams per XCD are known to hold only sentinels
+                    int mail_clean_teams = 0;         // mailboxes of that many teams per XCD are known to hold only sentinels
+                    bool ctl_clean = false; };        // the last launch's check kernel has zeroed the control block
 static std::map<DevStream, SeqScratch> g_seq_scratch;
 static PerDevice<int> g_seq_state_pd(-1);             // -1 untested, 0 unusable, 1 verified on this device
 
 // pk2_persist_guard_clear: whatever an aborted launch left behind, the next backward launch fills every mailbox again
 // (belt and braces next to the refill by lstm_seq_check: a launch that was killed never reached its check kernel).
-static void seq_mail_dirty() { for (auto& kv : g_seq_scratch) kv.second.mail_clean_teams = 0; }
+static void seq_mail_dirty() { for (auto& kv : g_seq_scratch) { kv.second.mail_clean_teams = 0; kv.second.ctl_clean = false; } }
 
 static int seq_scratch(hipStream_t stream, SeqScratch** out) {
   static const bool hooked = (persist_guard_on_clear(seq_mail_dirty), true);
@@ -978,7 +984,8 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   SeqScratch* sc = nullptr;
   int rc = seq_scratch(stream, &sc);
   if (rc) return rc;
-  PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
+  if (!sc->ctl_clean) PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
+  sc->ctl_clean = false;
   PK2_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(y), (int)kSeqSentinel, (size_t)T * B * D * H, stream));
   static const int pre = getenv("PK2_SEQ_FWD_PRESLEEP") ? atoi(getenv("PK2_SEQ_FWD_PRESLEEP")) : 0;
   static const int lps = getenv("PK2_SEQ_FWD_LOOPSLEEP") ? atoi(getenv("PK2_SEQ_FWD_LOOPSLEEP")) : 0;
@@ -999,6 +1006,7 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   }
   hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
                      nullptr, (size_t)0);
+  sc->ctl_clean = true;
   *ran = true;
   return PK2_OK;
 }
@@ -1011,7 +1019,8 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   SeqScratch* sc = nullptr;
   int rc = seq_scratch(stream, &sc);
   if (rc) return rc;
-  PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
+  if (!sc->ctl_clean) PK2_HIP(hipMemsetAsync(sc->ctl, 0, sizeof(SeqCtl), stream));
+  sc->ctl_clean = false;
   // Every reader resets the slots it has read, so a launch that completes leaves the mailboxes as it found them: all
   // sentinels.  They are filled once (and again when a launch needs more teams than have been filled); a launch that
   // gave up raises the guard, which stops training anyway (persist_guard.h).
@@ -1030,6 +1039,7 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
                      sc->mail, (size_t)8 * kSeqTeams * kSeqMailFloats);
   PK2_LAUNCH_CHECK();
+  sc->ctl_clean = true;
   *ran = true;
   return PK2_OK;
 }
