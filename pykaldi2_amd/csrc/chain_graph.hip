@@ -820,7 +820,10 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
       // (round 5, profiles/r05_den_stream.txt: the streaming variant's fixed cost is gone -- pieces in registers, requested
       // two ahead, no reload in front of a request: S = 30 k, 4 pieces 7.08 -> 10.95, 8 pieces 14.46 -- 0.9 us a piece
       // and ~0.4 for the variant)
-      const double cost = arcs_us(estep) + (cand.max_pieces ? 0.4 + 0.9 * cand.max_pieces : 0.0);
+      // With more than two table chunks the streaming frame still costs its old fixed price: every further chunk is a
+      // vmcnt(0) + full barrier with the pieces in flight (S = 50 k, 1.0 M arcs: padded rows + one piece 13.9 us against
+      // 10.4 for unpadded rows without one; S = 55 k: 15.1 against 11.1).
+      const double cost = arcs_us(estep) + (cand.max_pieces ? (cand.K > 2 ? 4.5 : 0.4) + 0.9 * cand.max_pieces : 0.0);
       if (cost < best_cost) { best_cost = cost; best_estep = estep; }
       if (cand.max_pieces == 0 && cand.K == 2) break;
     }

@@ -393,7 +393,7 @@ def test_large_state_graphs_match_c_oracle(S, A, want_form):
     if want_form is not None:
         assert results["default"][1] == want_form, results["default"][:2]
         if want_form == 2:
-            assert G.debug_persist2(0)["row_arrays"] == 7 and G.debug_persist2(0)["pieces"] == 0
+            assert G.debug_persist2(0)["row_arrays"] == 7          # (with or without a streamed piece: the builder's cost model decides)
     print("S = %d, A = %d: default path %d form %d; forced persistent: path %d form %d"
           % (S, A, results["default"][0], results["default"][1], results["2"][0], results["2"][1]))
     for n, Tn in enumerate(lens):
