@@ -817,13 +817,12 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
       // (round 4: the FIRST streamed piece costs ~5 us per frame -- the streaming variant of the frame: zeroed row arrays,
       // spill reloads behind the piece loads -- and ~0.9 each after it (profiles/r04_den_sweep.txt: S = 30 k, 1.0 -> 1.5 M
       // arcs = 4 pieces: 7.75 -> 15.1); the old 0.3 + 0.6 per piece chose padded rows + one piece over unpadded rows)
-      // (round 5, profiles/r05_den_stream.txt: the streaming variant's fixed cost is gone -- pieces in registers, requested
-      // two ahead, no reload in front of a request: S = 30 k, 4 pieces 7.08 -> 10.95, 8 pieces 14.46 -- 0.9 us a piece
-      // and ~0.4 for the variant)
-      // With more than two table chunks the streaming frame still costs its old fixed price: every further chunk is a
-      // vmcnt(0) + full barrier with the pieces in flight (S = 50 k, 1.0 M arcs: padded rows + one piece 13.9 us against
-      // 10.4 for unpadded rows without one; S = 55 k: 15.1 against 11.1).
-      const double cost = arcs_us(estep) + (cand.max_pieces ? (cand.K > 2 ? 4.5 : 0.4) + 0.9 * cand.max_pieces : 0.0);
+      // (round 5: between two layouts that both stream the fixed price cancels; against a layout WITHOUT a piece it stays
+      // -- with 0.4 + 0.9 per piece, the S = 30 k figures after the round's work on the pieces (profiles/r05_den_stream.txt),
+      // S = 40 / 50 / 55 k at 1.0 M arcs chose padded rows + one piece and ran 10.8 / 13.9 / 14.9 us per frame instead of
+      // 9.7 / 10.4 / 11.1 with unpadded rows and none: chunks sharing a buffer, or a third chunk, put full barriers between
+      // the pieces in flight)
+      const double cost = arcs_us(estep) + (cand.max_pieces ? 4.5 + 0.9 * cand.max_pieces : 0.0);
       if (cost < best_cost) { best_cost = cost; best_estep = estep; }
       if (cand.max_pieces == 0 && cand.K == 2) break;
     }
