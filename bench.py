@@ -181,7 +181,8 @@ def scaling_report(step_events, exchange_timing, audio, dev, rank, world):
                          "pre_exchange_ms_mean": round(float(allv[r, 1].mean()), 3),
                          "exchange_ms_mean": round(float(allv[r, 3].mean()), 3),
                          "straggler_wait_ms_mean": round(float(wait[r].mean()), 3),
-                         "audio_s": round(audios[r], 2), "own_irtf": round(audios[r] / (own[r].sum() * 1e-3), 2)})
+                         "audio_s": round(audios[r], 2), "own_irtf": round(audios[r] / (own[r].sum() * 1e-3), 2),
+                         "gpu_ms_steps": [round(float(v), 2) for v in allv[r, 0]]})       # (device events around every timed step)
     return {"per_rank": per_rank, "ideal_weak_irtf": round(sum(p["own_irtf"] for p in per_rank), 2),
             "exchange": {"exchange_ms": round(float(allv[:, 3, :].mean()), 3), "exchange_net_ms": round(float(net.mean()), 3),
                          "straggler_wait_ms": round(float(wait.mean()), 3), "straggler_wait_ms_worst_rank": round(float(wait.mean(axis=1).max()), 3),

@@ -34,15 +34,26 @@ constexpr int kNfft = 512, kWin = 400, kHop = 160, kBins = 257, kMel = 80;
 
 __device__ __forceinline__ unsigned rev9(unsigned i) { return __brev(i) >> 23; }
 
-__global__ void __launch_bounds__(256) fbank_frame_kernel(const float* __restrict__ wav, int64_t n_samples,
+// The utterances of one launch (round 5: a launch per utterance left a 4-utterance minibatch with four 12-37 us kernels one
+// after the other, each too small for the chip -- 0.19 ms of the LF-MMI step): sample and feature-row offsets by value, a
+// workgroup per frame of the whole batch looks its utterance up.
+constexpr int kFbankBatch = 32;
+struct FbankBatch { int64_t wav_off[kFbankBatch + 1]; int32_t row_off[kFbankBatch + 1]; int32_t n; };
+
+__global__ void __launch_bounds__(256) fbank_frame_kernel(FbankBatch b, const float* __restrict__ wav_all,
                                                           const float* __restrict__ window,
                                                           const float* __restrict__ tw_re,
                                                           const float* __restrict__ tw_im,
                                                           const float* __restrict__ melT,
-                                                          float* __restrict__ feats) {
+                                                          float* __restrict__ feats_all) {
   __shared__ float re[kNfft], im[kNfft];
   __shared__ float pw[kBins + 3];
-  const int t = blockIdx.x, tid = threadIdx.x;
+  int u = 0;
+  while (u + 1 < b.n && (int)blockIdx.x >= b.row_off[u + 1]) ++u;
+  const float* __restrict__ wav = wav_all + b.wav_off[u];
+  const int64_t n_samples = b.wav_off[u + 1] - b.wav_off[u];
+  float* __restrict__ feats = feats_all + (int64_t)b.row_off[u] * kMel;
+  const int t = (int)blockIdx.x - b.row_off[u], tid = threadIdx.x;
   const int64_t m = n_samples - 1;            // length of the pre-emphasised signal
   const int64_t s0 = (int64_t)t * kHop;
 #pragma unroll
@@ -212,15 +223,23 @@ extern "C" int pk2_fbank_compute(const pk2_fbank* fbc, const float* wav, const i
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   // feat_row_off is a DEVICE array of num_utts+1 int64 (also used by cmn / subsample kernels);
   // wav_off is a HOST array.
-  for (int n = 0; n < num_utts; ++n) {
-    const int64_t ns = wav_off[n + 1] - wav_off[n];
-    const int T = pk2_fbank_num_frames(ns);
-    PK2_REQUIRE(T > 0, "fbank_compute: utterance %d has %lld samples", n, (long long)ns);
-    // rows of this utterance start at host-known prefix of frame counts
-    int64_t row0 = 0;
-    for (int k = 0; k < n; ++k) row0 += pk2_fbank_num_frames(wav_off[k + 1] - wav_off[k]);
-    hipLaunchKernelGGL(fbank_frame_kernel, dim3(T), dim3(256), 0, stream, wav + wav_off[n], ns, fb->d_window,
+  int64_t row0 = 0;                      // rows of an utterance start at the host-known prefix of frame counts
+  for (int n0 = 0; n0 < num_utts; n0 += kFbankBatch) {
+    pk2::FbankBatch b;
+    b.n = std::min<int>(kFbankBatch, num_utts - n0);
+    int rows = 0;
+    for (int k = 0; k < b.n; ++k) {
+      const int64_t ns = wav_off[n0 + k + 1] - wav_off[n0 + k];
+      const int T = pk2_fbank_num_frames(ns);
+      PK2_REQUIRE(T > 0, "fbank_compute: utterance %d has %lld samples", n0 + k, (long long)ns);
+      b.wav_off[k] = wav_off[n0 + k] - wav_off[n0]; b.row_off[k] = rows;
+      rows += T;
+    }
+    b.wav_off[b.n] = wav_off[n0 + b.n] - wav_off[n0]; b.row_off[b.n] = rows;
+    for (int k = b.n + 1; k <= kFbankBatch; ++k) { b.wav_off[k] = b.wav_off[b.n]; b.row_off[k] = rows; }
+    hipLaunchKernelGGL(fbank_frame_kernel, dim3(rows), dim3(256), 0, stream, b, wav + wav_off[n0], fb->d_window,
                        fb->d_tw_re, fb->d_tw_im, fb->d_melT, feats + row0 * kMel);
+    row0 += rows;
   }
   if (apply_cmn)
     hipLaunchKernelGGL(cmn_kernel, dim3(num_utts), dim3(kCmnParts * kMel), 0, stream, feats, feat_row_off);
