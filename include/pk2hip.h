@@ -293,6 +293,14 @@ int pk2_gemm_f32_batched(int32_t transa, int32_t transb, int32_t M, int32_t N, i
                          const float* A, int64_t lda, int64_t strideA0, int64_t strideA1, const float* B,
                          int64_t ldb, int64_t strideB0, int64_t strideB1, float beta, float* C, int64_t ldc,
                          int64_t strideC0, int64_t strideC1, int32_t n0, int32_t n1, void* stream);
+/* Arithmetic of pk2_gemm_f32 / pk2_gemm_f32_batched (process-wide; default from PK2_GEMM_ARITH = bf16x3 | f32):
+ *   0 = "f32":    v_mfma_f32_32x32x2_f32, bit-for-bit a k-ordered f32 fmaf chain (157 TFLOP/s peak);
+ *   1 = "bf16x3": every f32 operand element is split exactly into three bf16 numbers and six of the nine part products
+ *                 run on v_mfma_f32_32x32x16_bf16 with f32 accumulation (csrc/gemm_bf16x3.h): error against float64 no
+ *                 larger than the f32 product's (tests/test_gpu_frontend_nn.py::test_gemm_f32_matches_float64 runs both at
+ *                 one bound), 2.67 x the matrix-core rate.  Same inputs, same outputs, same memory traffic. */
+int pk2_gemm_set_arith(int32_t arith);
+int pk2_gemm_get_arith(void);
 /* out[n] (+)= sum_m A[m][n]  (bias gradients). */
 int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,
                    void* stream);

@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "gemm_tile.h"
+#include "gemm_bf16x3.h"
 
 namespace pk2 {
 
@@ -26,22 +27,39 @@ struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, kle
 
 // One block tile: C[m0.., n0..] (+)= alpha * A[m0.., kbeg..kend) * B[kbeg..kend), n0..].  `atomic`: the tile's k range is
 // shared with other workgroups -- the product is added with float atomics into a C that already holds beta * C + bias.
-template <bool TA, bool TB, int TILES>
-__device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float alpha, const float* __restrict__ A, int64_t lda,
+// LDS bytes of one block tile (two stages of both operands).
+template <bool TA, bool TB, int TILES, bool X3>
+constexpr size_t gemm_smem_bytes() {
+  if (X3) return 2 * 16 * (size_t)(GeoX<TILES>::template slots<!TA>() + GeoX<TILES>::template slots<TB>());
+  return 2 * sizeof(float) * BK * (size_t)(Geo<TILES>::template ld<!TA>() + Geo<TILES>::template ld<TB>());
+}
+
+template <bool TA, bool TB, int TILES, bool X3>
+__device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int kbeg, float alpha, const float* __restrict__ A, int64_t lda,
                                            const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C,
                                            int64_t ldc, const float* __restrict__ bias, bool vecA, bool vecB, int m0, int n0,
                                            bool atomic) {
-  constexpr int LDA = Geo<TILES>::template ld<!TA>(), LDB = Geo<TILES>::template ld<TB>();   // per-operand LDS row pitch
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
 
   f32x16 acc[TILES][TILES];
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 #ifdef PK2_GEMM_PROFILE
   const long long gp_t0 = wall_clock64();
 #endif
-  tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
+  if constexpr (X3) {       // three-way bf16 split, six products per k-step on the bf16 MFMA (gemm_bf16x3.h)
+    typedef u32x4_t (*StA)[GeoX<TILES>::template slots<!TA>()];
+    typedef u32x4_t (*StB)[GeoX<TILES>::template slots<TB>()];
+    StA Ax = reinterpret_cast<StA>(smem);
+    StB Bx = reinterpret_cast<StB>(reinterpret_cast<u32x4_t*>(smem) + 2 * GeoX<TILES>::template slots<!TA>());
+    tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc);
+  } else {
+    constexpr int LDA = Geo<TILES>::template ld<!TA>(), LDB = Geo<TILES>::template ld<TB>();   // per-operand LDS row pitch
+    typedef float (*StA)[BK * LDA];
+    typedef float (*StB)[BK * LDB];
+    StA As = reinterpret_cast<StA>(smem);
+    StB Bs = reinterpret_cast<StB>(reinterpret_cast<float*>(smem) + 2 * BK * LDA);
+    tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
+  }
 #ifdef PK2_GEMM_PROFILE
   const long long gp_t1 = wall_clock64();
 #endif
@@ -90,8 +108,8 @@ __device__ __forceinline__ void gemm_block(int M, int N, int K, int kbeg, float 
 #endif
 }
 
-template <bool TA, bool TB, int TILES>
-__global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_kernel(int M, int N, int K, float alpha,
+template <bool TA, bool TB, int TILES, bool X3>
+__global__ void __launch_bounds__(kGemmThreads, X3 ? 2 : 3) gemm_f32_kernel(int M, int N, int K, float alpha,
                                                                 const float* __restrict__ A, int64_t lda,
                                                                 const float* __restrict__ B, int64_t ldb,
                                                                 float beta, float* __restrict__ C, int64_t ldc,
@@ -110,8 +128,9 @@ __global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_kernel(int M, int N,
     B += i0 * bt.sB0 + i1 * bt.sB1;
     C += i0 * bt.sC0 + i1 * bt.sC1;
   }
-  gemm_block<TA, TB, TILES>(M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
-                            blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1);
+  __shared__ __attribute__((aligned(16))) char smem[gemm_smem_bytes<TA, TB, TILES, X3>()];
+  gemm_block<TA, TB, TILES, X3>(smem, M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
+                                blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1);
 }
 
 // The row bands of a plain 2-D product in ONE launch (round 4): workgroups [0, nbig) take the 128x128 tiles of rows
@@ -119,8 +138,8 @@ __global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_kernel(int M, int N,
 // 128x128 tile had finished and ended with a round of their own on a quarter of the CUs (2356 x 4096 x 1024: 125 + 45 us
 // + two launch / prologue / epilogue costs = 206 us); here they take the third workgroup slot of a CU from the start and the
 // slots the first of them free.
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_bands_kernel(int M, int N, int K, float alpha,
+template <bool TA, bool TB, bool X3>
+__global__ void __launch_bounds__(kGemmThreads, X3 ? 2 : 3) gemm_f32_bands_kernel(int M, int N, int K, float alpha,
                                                                          const float* __restrict__ A, int64_t lda,
                                                                          const float* __restrict__ B, int64_t ldb,
                                                                          float beta, float* __restrict__ C, int64_t ldc,
@@ -128,13 +147,14 @@ __global__ void __launch_bounds__(kGemmThreads, 3) gemm_f32_bands_kernel(int M, 
                                                                          bool vecB, int nbig, int big_cols, int m_split,
                                                                          int small_cols) {
   const int b = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) char smem[std::max(gemm_smem_bytes<TA, TB, 2, X3>(), gemm_smem_bytes<TA, TB, 1, X3>())];
   if (b < nbig) {
-    gemm_block<TA, TB, 2>(M, N, K, 0, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, (b / big_cols) * 128,
-                          (b % big_cols) * 128, false);
+    gemm_block<TA, TB, 2, X3>(smem, M, N, K, 0, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, (b / big_cols) * 128,
+                              (b % big_cols) * 128, false);
   } else {
     const int s = b - nbig;
-    gemm_block<TA, TB, 1>(M, N, K, 0, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, m_split + (s / small_cols) * 64,
-                          (s % small_cols) * 64, false);
+    gemm_block<TA, TB, 1, X3>(smem, M, N, K, 0, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB, m_split + (s / small_cols) * 64,
+                              (s % small_cols) * 64, false);
   }
 }
 
@@ -177,6 +197,26 @@ __global__ void scale_vec_kernel(float* v, int n, float beta) {
 
 using namespace pk2;
 
+// PK2_GEMM_ARITH = f32 (v_mfma_f32_32x32x2_f32, an f32 fmaf chain) | bf16x3 (three-way bf16 split, six products per k-step
+// on v_mfma_f32_32x32x16_bf16, f32 accumulation: gemm_bf16x3.h).  Read once per process; pk2_gemm_set_arith overrides.
+#ifndef PK2_GEMM_ARITH_DEFAULT
+#define PK2_GEMM_ARITH_DEFAULT 1
+#endif
+static int g_gemm_arith = -1;
+static int gemm_arith() {
+  if (g_gemm_arith < 0) {
+    const char* e = getenv("PK2_GEMM_ARITH");
+    g_gemm_arith = e ? (strcmp(e, "f32") == 0 ? 0 : 1) : PK2_GEMM_ARITH_DEFAULT;
+  }
+  return g_gemm_arith;
+}
+extern "C" int pk2_gemm_set_arith(int32_t arith) {
+  PK2_REQUIRE(arith == 0 || arith == 1, "gemm_set_arith: 0 = f32, 1 = bf16x3");
+  g_gemm_arith = arith;
+  return PK2_OK;
+}
+extern "C" int pk2_gemm_get_arith(void) { return gemm_arith(); }
+
 #ifndef PK2_GEMM_MIN_KSLICE
 #define PK2_GEMM_MIN_KSLICE 256   // (measured on the layer-0 weight gradient 4096 x 80 x 2276: 101 -> 64 us)
 #endif
@@ -184,6 +224,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
                        const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
                        int n0, const GemmBatch& bt_in, bool aligned_strides, hipStream_t stream) {
   GemmBatch bt = bt_in;
+  const bool x3 = gemm_arith() == 1;
   const bool vecA = aligned_strides && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
   const bool vecB = aligned_strides && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const int64_t big_tiles = (int64_t)((N + 127) / 128) * ((M + 127) / 128) * n0 * bt.n1;
@@ -238,20 +279,20 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
     const float* Ap = transa ? A + m_off : A + (int64_t)m_off * lda;
     float* Cp = C + (int64_t)m_off * ldc;
     dim3 grid((N + edge - 1) / edge, (m_rows + edge - 1) / edge, n0 * bt.n1 * bt.ksplit), block(kGemmThreads);
+#define PK2_GEMM_T(TA, TB, T, X)                                                                                  \
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, T, X>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B, ldb, \
+                     beta, Cp, ldc, bias, vecA, vecB, bt)
 #define PK2_GEMM(TA, TB)                                                                                          \
   do {                                                                                                            \
-    if (t == 2)                                                                                                   \
-      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B,   \
-                         ldb, beta, Cp, ldc, bias, vecA, vecB, bt);                                               \
-    else                                                                                                          \
-      hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B,   \
-                         ldb, beta, Cp, ldc, bias, vecA, vecB, bt);                                               \
+    if (t == 2) { if (x3) PK2_GEMM_T(TA, TB, 2, true); else PK2_GEMM_T(TA, TB, 2, false); }                       \
+    else        { if (x3) PK2_GEMM_T(TA, TB, 1, true); else PK2_GEMM_T(TA, TB, 1, false); }                       \
   } while (0)
     if (!transa && !transb) PK2_GEMM(false, false);
     else if (!transa && transb) PK2_GEMM(false, true);
     else if (transa && !transb) PK2_GEMM(true, false);
     else PK2_GEMM(true, true);
 #undef PK2_GEMM
+#undef PK2_GEMM_T
   };
   // Tile quantisation: 128x128 tiles are dealt to 256 CUs, so e.g. the 18 x 32 = 576 tiles of the BLSTM input projection
   // (M = 2276 rows) take three tile-times on some CUs for 2.25 tile-times of work.  A plain 2-D product is therefore cut
@@ -278,14 +319,16 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
         const int m_split = best_r * 128, small_rows = (M - m_split + 63) / 64;
         const int nbig = best_r * Cn;
         dim3 grid(nbig + small_rows * Cs), block(kGemmThreads);
-#define PK2_GEMM_BANDS(TA, TB)                                                                                          \
-  hipLaunchKernelGGL((gemm_f32_bands_kernel<TA, TB>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C,   \
+#define PK2_GEMM_BANDS_X(TA, TB, X)                                                                                        \
+  hipLaunchKernelGGL((gemm_f32_bands_kernel<TA, TB, X>), grid, block, 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C,   \
                      ldc, bias, vecA, vecB, nbig, Cn, m_split, Cs)
+#define PK2_GEMM_BANDS(TA, TB) do { if (x3) PK2_GEMM_BANDS_X(TA, TB, true); else PK2_GEMM_BANDS_X(TA, TB, false); } while (0)
         if (!transa && !transb) PK2_GEMM_BANDS(false, false);
         else if (!transa && transb) PK2_GEMM_BANDS(false, true);
         else if (transa && !transb) PK2_GEMM_BANDS(true, false);
         else PK2_GEMM_BANDS(true, true);
 #undef PK2_GEMM_BANDS
+#undef PK2_GEMM_BANDS_X
         PK2_LAUNCH_CHECK();
         return PK2_OK;
       }

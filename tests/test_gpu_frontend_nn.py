@@ -95,7 +95,10 @@ def test_pad_roll_subsample_matches_reference_golden(golden):
                                          # (those edge tiles keep the bounds-tested loader)
                                          (0, 1, 576, 1856, 144), (0, 0, 1024, 1028, 256), (0, 1, 2354, 512, 512), (1, 0, 2500, 4096, 250),
                                          (0, 0, 1100, 642, 384), (1, 1, 901, 700, 200), (1, 0, 2502, 1030, 300)])
-def test_gemm_f32_matches_float64(ta, tb, M, N, K):
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_gemm_f32_matches_float64(ta, tb, M, N, K, arith, gemm_arith):
+    # both arithmetic paths of pk2_gemm_f32 (f32 MFMA; three-way bf16 split on the bf16 MFMA, csrc/gemm_bf16x3.h) at ONE bound
+    gemm_arith(arith)
     rng = np.random.default_rng(M + N)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
     B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
