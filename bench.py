@@ -122,14 +122,14 @@ class Trainer:
             logits = self.model(x, None, kpm.to(x.device))
         else:
             logits = self.model.forward_time_major(x)
-        mark("lstm_fwd")
+        mark("model_fwd" if self.arch == "transformer" else "lstm_fwd")
         fut = self._pending.pop(id(mb), None)    # host work: prefetched by the worker thread, or built here while the
         sups = fut.result() if fut is not None else build_supervisions(mb["alis"])     # device is still in the forward pass
         loss = ops.ChainObjtiveBatch.apply(logits.transpose(0, 1), self.den, sups, self.opts)
         mark("chain")
         self.opt.zero_grad()
         loss.backward()
-        mark("lstm_bwd")
+        mark("model_bwd" if self.arch == "transformer" else "lstm_bwd")
         self.step_no += 1
         lr = utils.noam_decay(self.step_no, 4000, self.base_lr)
         for grp in self.opt.param_groups:
@@ -305,26 +305,59 @@ def transformer_flops_per_frame(T, feat=80, dim=512, ff=2048, layers=12, pdfs=P)
     return 2 * feat * dim + layers * per_layer + 2 * dim * pdfs
 
 
+def gemm_arith_name():
+    from pykaldi2_amd import _lib
+    return "bf16x3" if _lib.lib().pk2_gemm_get_arith() == 1 else "f32"
+
+
+def dtype_string():
+    """The arithmetic the path computes in: f32 storage and accumulation everywhere; the GEMMs multiply either on the f32 MFMA or,
+    by default, on the bf16 MFMA through an exact three-way bf16 split of both operands (csrc/gemm_bf16x3.h)."""
+    return "f32 (GEMMs: bf16x3 split, f32 accumulate)" if gemm_arith_name() == "bf16x3" else "f32"
+
+
 def gemm_mfma_roofline(dev, rows, reps=10):
     """MFMA utilisation of the BLSTM GEMMs (north star): the layer-1/2 input projection of this minibatch,
-    [rows, 1024] x [1024, 4096] (both directions' gates), f32 MFMA, timed with events on the launch stream."""
+    [rows, 1024] x [1024, 4096] (both directions' gates), timed with events on the launch stream under BOTH arithmetic paths of
+    pk2_gemm_f32.  `achieved` is the path the run uses, in f32-equivalent TFLOP/s (2 M N K per product); for bf16x3 the executed
+    bf16 MFMA work is six times that and is priced against the 2.5 PFLOP/s dense bf16 peak."""
+    from pykaldi2_amd import _lib
     from pykaldi2_amd.lstm import _gemm, _p
+    L = _lib.lib()
     M, N, K = int(rows), 4096, 1024
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev)
-    for _ in range(3):
-        _gemm(0, 1, M, N, K, _p(A), K, _p(W), K, _p(C), N)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        _gemm(0, 1, M, N, K, _p(A), K, _p(W), K, _p(C), N)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", achieved=round(tf, 1), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4),
-                kernel="pk2::gemm_f32_kernel (v_mfma_f32_32x32x2_f32): BLSTM input projection %d x %d x %d" % (M, N, K),
-                ms_per_launch=round(ms, 4))
+    active = L.pk2_gemm_get_arith()
+    res = {}
+    for arith in (0, 1):
+        _lib.check(L.pk2_gemm_set_arith(arith))
+        for _ in range(3):
+            _gemm(0, 1, M, N, K, _p(A), K, _p(W), K, _p(C), N)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            _gemm(0, 1, M, N, K, _p(A), K, _p(W), K, _p(C), N)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res[arith] = (ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12)
+    _lib.check(L.pk2_gemm_set_arith(active))
+    ms, tf = res[active]
+    out = dict(bound="mfma", achieved=round(tf, 1), unit="TFLOP/s", ms_per_launch=round(ms, 4),
+               arith="bf16x3" if active == 1 else "f32",
+               f32_path=dict(achieved=round(res[0][1], 1), peak=157.3, frac=round(res[0][1] / 157.3, 4), ms_per_launch=round(res[0][0], 4),
+                             kernel="v_mfma_f32_32x32x2_f32"),
+               bf16x3_path=dict(achieved_f32_equivalent=round(res[1][1], 1), executed_bf16_tflops=round(6 * res[1][1], 1), peak_bf16=2500.0,
+                                frac=round(6 * res[1][1] / 2500.0, 4), ms_per_launch=round(res[1][0], 4),
+                                kernel="v_mfma_f32_32x32x16_bf16, six part products per k-step, f32 accumulate"))
+    if active == 1:
+        out.update(peak=round(2500.0 / 6, 1), frac=round(6 * tf / 2500.0, 4),
+                   kernel="pk2::gemm_f32_kernel<.., bf16x3> (v_mfma_f32_32x32x16_bf16 x 6): BLSTM input projection %d x %d x %d; peak = "
+                          "2.5 PFLOP/s dense bf16 / 6 executed products per f32-equivalent product" % (M, N, K))
+    else:
+        out.update(peak=157.3, frac=round(tf / 157.3, 4),
+                   kernel="pk2::gemm_f32_kernel (v_mfma_f32_32x32x2_f32): BLSTM input projection %d x %d x %d" % (M, N, K))
+    return out
 
 
 def persistent_health(den, batch):
@@ -477,7 +510,8 @@ def ce_parity(path):
 
 def cpu_ce_worker(threads, parity_path=None):
     """SURVEY 8(d) config 1 in a child process: the reference's torch CPU CE path (nn.LSTM + nn.Linear = models/lstm.py:45-54,
-    nn.CrossEntropyLoss, clip 5, Adam(amsgrad, lr 1e-4)) on x[64,80,80], P=5768, dropout 0.2, on the node's host cores."""
+    nn.CrossEntropyLoss, clip 5, Adam(amsgrad, lr 1e-4)) on the GPU leg's own minibatch shape x[256,80,80], P=5768, dropout 0.2,
+    on the node's host cores (the CPU leg used to run 64 chunks against the GPU's 256)."""
     torch.set_num_threads(threads)
     parity = None
     if parity_path:
@@ -486,7 +520,7 @@ def cpu_ce_worker(threads, parity_path=None):
         except Exception as e:
             parity = dict(ok=False, error=repr(e)[:300])
     torch.manual_seed(0)
-    B, T, PC = 64, 80, 5768
+    B, T, PC = 256, 80, 5768
     rnn = torch.nn.LSTM(80, 512, 3, batch_first=True, dropout=0.2, bidirectional=True)
     lin = torch.nn.Linear(1024, PC)
     params = list(rnn.parameters()) + list(lin.parameters())
@@ -503,14 +537,14 @@ def cpu_ce_worker(threads, parity_path=None):
         opt.step()
     step()
     n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < 12.0 and n < 12):
+    while n < 2 or (time.time() - t0 < 15.0 and n < 12):
         step()
         n += 1
     dt = (time.time() - t0) / n
     print(json.dumps(dict(value=round(B * T * 0.01 / dt, 2), unit="hours of audio per wall-clock hour", cores=threads,
                           kind="reference", parity=parity,
                           sample="%d steps of the reference's torch CPU CE path (nn.LSTM 3x512 bidirectional + Linear, "
-                                 "CrossEntropyLoss, clip 5, Adam amsgrad) on x[64,80,80], P=5768: %.2f s per step on %d threads"
+                                 "CrossEntropyLoss, clip 5, Adam amsgrad) on x[256,80,80], P=5768: %.2f s per step on %d threads"
                                  % (n, dt, threads))), flush=True)
 
 
@@ -606,7 +640,7 @@ def ce_workload(args, dev, rank, world):
                           "unit": "hours of audio per wall-clock hour", "higher_is_better": True,
                           "config": {"workload": "SECONDARY configs[1]: 3x512 BLSTM CE, batch 256 x 80 x 80 fbank from raw waveforms in "
                                      "HBM, P=5768, dropout 0.2, Adam(amsgrad)+clip 5"},
-                          "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "loss": round(float(loss.item()), 4),
+                          "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": dtype_string(), "loss": round(float(loss.item()), 4),
                           "roofline": roof, "cpu_baseline": base, "parity": parity,
                           "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           "reference_published": "README.md:43-45: 190 iRTF (64x80, 1 V100), 520 iRTF (256x80, 4 V100)"}),
@@ -952,7 +986,10 @@ def main():
         print(json.dumps(den_roofline(den, dev)), flush=True)
         return
     rng = np.random.default_rng(1234 + rank)
-    n_unique = min(args.steps + args.warmup, 8)
+    #  the number of distinct minibatches divides --steps and the timed step i uses minibatch i % n_unique:
+    # the timed window holds every minibatch steps / n_unique times, whatever --warmup is (8 minibatches over 20 steps read
+    # 4245 iRTF at W = 5 and 4330 at W = 3 for the same code)
+    n_unique = max(d for d in range(1, 11) if args.steps % d == 0)
     # default: SURVEY 8(d) protocol, everything seeded per rank (ranks draw different utterance lengths, so a step
     # waits for the rank with the longest minibatch); --length-bucketed gives every rank the same lengths
     batches = make_batches(rng, n_unique, args.batch, dev,
@@ -973,7 +1010,7 @@ def main():
     # verifies the device and takes ~15 ms; it must not depend on W >= 1 to stay out of the timed region.
     tr.step(batches[n_unique - 1])
     for i in range(args.warmup):
-        tr.step(batches[i % n_unique])
+        tr.step(batches[(n_unique - 1 - i) % n_unique])
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
@@ -984,9 +1021,9 @@ def main():
     t0 = time.perf_counter()
     audio = 0.0
     for i in range(args.steps):
-        mb = batches[(args.warmup + i) % n_unique]
+        mb = batches[i % n_unique]
         if i + 1 < args.steps:          # the next step's supervisions: built by the worker thread during this step
-            tr.prefetch(batches[(args.warmup + i + 1) % n_unique])
+            tr.prefetch(batches[(i + 1) % n_unique])
         e0 = torch.cuda.Event(enable_timing=True); e0.record()
         tr.step(mb)
         e1 = torch.cuda.Event(enable_timing=True); e1.record()
@@ -1044,19 +1081,22 @@ def main():
     log("roofline done")
     # whole-model MFMA utilisation of the breakdown step: all BLSTM + output-layer FLOPs (forward + backward) of the real
     # (unpadded) frames over the time of the two model phases, against the f32 MFMA peak
-    lstm_ms = breakdown["lstm_fwd"] + breakdown["lstm_bwd"]
+    lstm_ms = (breakdown["model_fwd"] + breakdown["model_bwd"]) if args.transformer else (breakdown["lstm_fwd"] + breakdown["lstm_bwd"])
     if args.transformer:      # the model phases hold the 12-layer TransformerAM: its own FLOP count and label
         flops = 3.0 * sum(transformer_flops_per_frame(T) * T for T in lens)
         model_tf = flops / (lstm_ms * 1e-3) / 1e12
         roof_lstm = dict(bound="mfma", achieved=round(model_tf, 2), peak=157.3, unit="TFLOP/s", frac=round(model_tf / 157.3, 4),
                          kernel="12-layer TransformerAM (dim 512, 8 heads, FFN 2048, conv k=3) + output layer, forward + backward "
-                         "of the breakdown minibatch (f32 MFMA GEMMs, fused attention, row kernels)", frames=int(sum(lens)),
+                         "of the breakdown minibatch (GEMMs in the arithmetic `gemm_arith`, fused f32-MFMA attention, row kernels); "
+                         "FLOPs are f32-equivalent, peak = the f32 MFMA peak", gemm_arith=gemm_arith_name(), frames=int(sum(lens)),
                          padded_rows=len(lens) * max(lens), ms=round(lstm_ms, 3), flops_fwd_bwd=flops)
     else:
         lstm_tf = 3.0 * lstm_flops_per_frame() * sum(lens) / (lstm_ms * 1e-3) / 1e12
         roof_lstm = dict(bound="mfma", achieved=round(lstm_tf, 2), peak=157.3, unit="TFLOP/s", frac=round(lstm_tf / 157.3, 4),
                          kernel="3x512 BLSTM + output layer, forward + backward of the breakdown minibatch (recurrence "
-                         "step kernels + f32 MFMA GEMMs)", frames=int(sum(lens)), padded_rows=len(lens) * max(lens),
+                         "step kernels on the f32 MFMA + GEMMs in the arithmetic `gemm_arith`); FLOPs are f32-equivalent (2 per "
+                         "multiply-add of the model), peak = the f32 MFMA peak", gemm_arith=gemm_arith_name(),
+                         frames=int(sum(lens)), padded_rows=len(lens) * max(lens),
                          ms=round(lstm_ms, 3), flops_per_frame_fwd_bwd=3 * lstm_flops_per_frame(),
                          input_projection_gemm=gemm_mfma_roofline(dev, len(lens) * max(lens)))
     result = {
@@ -1065,15 +1105,16 @@ def main():
         "value": round(audio / dt, 2), "unit": "hours of audio per wall-clock hour",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
+        "vs_baseline": None, "dtype": dtype_string(), "data": "synthetic (seeded LibriSpeech-shaped waveforms, "
         "transition-id alignments over a synthetic left-biphone tree, 30k-state/1M-arc denominator graph (%s); "
         "random-init 3x512 BLSTM; supervisions built from the alignments inside the step%s)"
         % ("Kaldi chain topology: self-loop pdf != entering pdf" if DEN_TOPOLOGY == "chain" else "one pdf per destination state",
            "; utterance lengths bucketed across ranks" if args.length_bucketed else ""),
-        "config": {"workload": ("SECONDARY configs[4]: 12-layer TransformerAM LF-MMI; " if args.transformer else "") +
-                               "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py), batch %d x var-len per GPU, "
-                               "P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, Adam(amsgrad)+Noam+clip 5"
-                               % args.batch,
+        "config": {"workload": (("SECONDARY configs[4]: 12-layer TransformerAM (dim 512, 8 heads, FFN 2048) LF-MMI "
+                                 "(train_transformer_se.py's model under train_chain.py's loss)" if args.transformer else
+                                 "configs[2]: 3x512 BLSTM LF-MMI (train_chain.py)") +
+                                ", batch %d x var-len per GPU, P=6048, subsample 3, leaky 1e-4, xent_regularize 0.1, "
+                                "Adam(amsgrad)+Noam+clip 5" % args.batch),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "den_graph": {"states": S_DEN, "arcs": int(den.num_arcs()), "pdfs": P, "topology": DEN_TOPOLOGY},
                    "allocator_reserve_gb": args.reserve_gb,
@@ -1085,7 +1126,7 @@ def main():
                           "api": "pk2_allreduce_bucket" if hvd.comm_library() else "torch.distributed.all_reduce"},
                          **scaling["exchange"]),
         "per_rank": scaling["per_rank"], "ideal_weak_irtf": scaling["ideal_weak_irtf"], "irtf_bucketed": irtf_bucketed,
-        "roofline": roof, ("roofline_model" if args.transformer else "roofline_lstm"): roof_lstm, "breakdown_ms": breakdown, "last_objf_per_frame": round(loss_val / sum(lens), 4),
+        "roofline": roof, ("roofline_model" if args.transformer else "roofline_lstm"): roof_lstm, "last_objf_per_frame": round(loss_val / sum(lens), 4),
         "persistent_health": persistent_health(den, args.batch),
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -1105,6 +1146,20 @@ def main():
         del tr, batches
         torch.cuda.empty_cache()
         result["secondary"] = run_secondaries()
+    # the tail of the line (the driver keeps the last 2000 characters): the numbers a reader needs first
+    result["n_unique_minibatches"] = n_unique
+    result["gemm_arith"] = gemm_arith_name()
+    result[("roofline_model" if args.transformer else "roofline_lstm") + "_frac"] = roof_lstm["frac"]
+    result["roofline_frac"] = roof.get("frac")
+    result["breakdown_ms"] = breakdown
+    if "secondary" in result:
+        def short(d):
+            if not d or "error" in d:
+                return None
+            cb, par = d.get("cpu_baseline") or {}, d.get("parity") or {}
+            return [d.get("ms_per_step"), d.get("value"), (d.get("roofline") or {}).get("frac"), cb.get("value"), par.get("ok")]
+        result["secondary_summary"] = dict({k: short(v) for k, v in result["secondary"].items()},
+                                           fields="[ms_per_step, iRTF, roofline_frac, cpu_iRTF, parity_ok]")
     print(json.dumps(result), flush=True)
     hvd.shutdown()
 

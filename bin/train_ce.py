@@ -46,7 +46,9 @@ class ChunkPool:
             self.x, self.y, self.n = [X[keep]], [Y[keep]], int(keep.shape[0])
 
 
-def main():
+def parse_config(argv=None):
+    """Command line + YAML merge of the reference script (same flags, same keys; keys this framework does not use pass through
+    untouched): returns (args, config).  tests/test_host_logic.py pushes the reference's own configs/*.yaml through it."""
     parser = argparse.ArgumentParser()
     parser.add_argument("-exp_dir")
     parser.add_argument("-dataPath", default='', type=str, help="path of data files")
@@ -67,7 +69,7 @@ def main():
     parser.add_argument('-print_freq', default=100, type=int, metavar='N', help='print frequency (default: 100)')
     parser.add_argument('-hvd', default=False, type=bool, help="whether to use horovod for training")
     parser.add_argument('-synthetic', action='store_true', help='seeded synthetic utterances')
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
 
     with open(args.train_config) as f:
         config = yaml.safe_load(f)
@@ -83,6 +85,11 @@ def main():
     config["synthetic"] = args.synthetic
     config['data_path'] = args.dataPath
     print("Experiment starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
+    return args, config
+
+
+def main():
+    args, config = parse_config()
 
     if args.hvd:
         hvd.init()
@@ -126,6 +133,7 @@ def main():
             for param_group in optimizer.param_groups:
                 param_group['lr'] *= args.anneal_lr_ratio
         run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev, transform)
+        hvd.finish()      # collective: a persistent-kernel time-out of the last steps stops every rank before the checkpoint
         if (not args.hvd or hvd.rank() == 0) and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.' + str(epoch) + '.tar')

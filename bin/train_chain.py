@@ -29,7 +29,9 @@ from pykaldi2_amd.lattice import TransitionModel  # noqa: E402
 from pykaldi2_amd.tree import ContextDependency  # noqa: E402
 
 
-def main():
+def parse_config(argv=None):
+    """Command line + YAML merge of the reference script (same flags, same keys; keys this framework does not use pass through
+    untouched): returns (args, config).  tests/test_host_logic.py pushes the reference's own configs/*.yaml through it."""
     parser = argparse.ArgumentParser()
     parser.add_argument("-config")
     parser.add_argument("-data", help="data yaml file")
@@ -59,7 +61,7 @@ def main():
     parser.add_argument('-synthetic', action='store_true', help='seeded synthetic utterances and denominator graph')
     parser.add_argument('-den_states', default=30000, type=int, help='(synthetic) denominator graph states')
     parser.add_argument('-den_arcs', default=1000000, type=int, help='(synthetic) denominator graph arcs')
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
 
     with open(args.config) as f:
         config = yaml.safe_load(f)
@@ -76,6 +78,11 @@ def main():
     config["data_path"] = args.dataPath
     print("pytorch version:{}".format(th.__version__))
     print("Experiment starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
+    return args, config
+
+
+def main():
+    args, config = parse_config()
 
     hvd.init()
     th.cuda.set_device(hvd.local_rank())
@@ -126,6 +133,7 @@ def main():
     model.train()
     for epoch in range(args.num_epochs):
         run_train_epoch(model, optimizer, source, fb, epoch, supervision_opts, den, chain_opts, args, dev, sup_model, transform)
+        hvd.finish()      # collective: a persistent-kernel time-out of the last steps stops every rank before the checkpoint
         if hvd.rank() == 0 and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/chain.model.' + str(epoch) + '.tar')

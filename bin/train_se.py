@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pykaldi2_amd import data, fbank, hvd, lattice, lstm, ops, optim, se, synth, transformer, utils  # noqa: E402
 
 
-def main(arch="blstm"):
+def parse_config(argv=None, arch="blstm"):
     """arch = "transformer": the command line of the reference's bin/train_transformer_se.py (TransformerAM built
     from -dim_model / -nheads / -ff_size / -nlayers / -dropout, -look_ahead attention mask, -dataPath)."""
     parser = argparse.ArgumentParser()
@@ -65,7 +65,7 @@ def main(arch="blstm"):
     parser.add_argument('-save_freq', default=1000, type=int, metavar='N', help='save model frequency (default: 1000)')
     parser.add_argument('-synthetic', action='store_true', help='seeded synthetic utterances, HCLG and transition model')
     parser.add_argument('-graph_words', default=2000, type=int, help='(synthetic) vocabulary of the word-loop HCLG')
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
 
     with open(args.config) as f:
         config = yaml.safe_load(f)
@@ -82,6 +82,11 @@ def main(arch="blstm"):
     config["synthetic"] = args.synthetic
     print("pytorch version:{}".format(th.__version__))
     print("Experiment starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
+    return args, config
+
+
+def main(arch="blstm"):
+    args, config = parse_config(None, arch)
 
     hvd.init()
     th.cuda.set_device(hvd.local_rank())
@@ -152,6 +157,7 @@ def main(arch="blstm"):
     for epoch in range(args.num_epochs):
         run_train_epoch(model, optimizer, log_prior.to(dev), source, fb, epoch, asr_decoder, trans_model, silence_ids, args, dev,
                         forward, transform)
+        hvd.finish()      # collective: a persistent-kernel time-out of the last steps stops every rank before the checkpoint
         if hvd.rank() == 0 and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.se.' + str(epoch) + '.tar')

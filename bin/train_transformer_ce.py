@@ -23,7 +23,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pykaldi2_amd import data, fbank, hvd, ops, optim, transformer, utils  # noqa: E402
 
 
-def main():
+def parse_config(argv=None):
+    """Command line + YAML merge of the reference script (same flags, same keys; keys this framework does not use pass through
+    untouched): returns (args, config).  tests/test_host_logic.py pushes the reference's own configs/*.yaml through it."""
     parser = argparse.ArgumentParser()
     parser.add_argument("-train_config")
     parser.add_argument("-data_config")
@@ -48,7 +50,7 @@ def main():
     parser.add_argument('-print_freq', default=100, type=int, metavar='N', help='print frequency (default: 100)')
     parser.add_argument('-hvd', default=True, type=bool, help="whether to use horovod for training")
     parser.add_argument('-synthetic', action='store_true', help='seeded synthetic utterances')
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
 
     with open(args.train_config) as f:
         config = yaml.safe_load(f)
@@ -64,6 +66,11 @@ def main():
     config["synthetic"] = args.synthetic
     config['data_path'] = args.dataPath
     print("Experiment starts with config {}".format(json.dumps(config, sort_keys=True, indent=4)))
+    return args, config
+
+
+def main():
+    args, config = parse_config()
 
     if args.hvd:
         hvd.init()
@@ -104,6 +111,7 @@ def main():
     model.train()
     for epoch in range(start_epoch, args.num_epochs):
         run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args, dev, transform)
+        hvd.finish()      # collective: a persistent-kernel time-out of the last steps stops every rank before the checkpoint
         if (not args.hvd or hvd.rank() == 0) and args.exp_dir:
             th.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                     args.exp_dir + '/model.' + str(epoch) + '.tar')

@@ -244,9 +244,15 @@ struct DmaPlan {
   }
 };
 __device__ __forceinline__ void dma_issue(uint64_t mask, uint32_t m0v, uint32_t lane16, uint64_t g) {
-  asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %2, %3" PK2_DMA_SC "\n\ts_mov_b64 exec, -1"
-               : : "s"(mask), "s"(m0v), "v"(lane16), "s"(g) : "memory");      // (m0 is written too: the compiler sets it anew before each of its own uses)
+  // (exec is saved and restored instead of being assumed all ones.  m0 cannot be declared: it is a reserved
+  // register to LLVM, which answers a clobber entry with "reserved registers on the clobber list may not be preserved" and
+  // honours nothing; the compiler's own m0 uses in this kernel are the global_load_lds builtins, each of which sets m0
+  // immediately before the instruction (checked in the ISA), and -DPK2_DP2_PASS_ASM=0 keeps the builtin-only build as the
+  // parity A/B of this statement.)
+  uint64_t saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %3, %4" PK2_DMA_SC "\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "s"(mask), "s"(m0v), "v"(lane16), "s"(g) : "memory");
 }
 struct Chunk1Dma {
   uint64_t src;      // byte address of row 0 of chunk 1 in global memory (wave-uniform)

@@ -27,6 +27,9 @@ struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, kle
 
 // One block tile: C[m0.., n0..] (+)= alpha * A[m0.., kbeg..kend) * B[kbeg..kend), n0..].  `atomic`: the tile's k range is
 // shared with other workgroups -- the product is added with float atomics into a C that already holds beta * C + bias.
+#ifndef PK2_GEMMX_WAVES
+#define PK2_GEMMX_WAVES 2       // waves per SIMD the bf16x3 kernels are compiled for
+#endif
 // LDS bytes of one block tile (two stages of both operands).
 template <bool TA, bool TB, int TILES, bool X3>
 constexpr size_t gemm_smem_bytes() {
@@ -108,8 +111,11 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
 #endif
 }
 
+// (Round 6, measured and removed: an XCD-aware tile order -- workgroup l of the dispatch order takes tile (l % 8) (G / 8) + l / 8,
+// so that each XCD's L2 sees its own row bands of A instead of all of A -- changed nothing on 20480 x 4096 x 1024 in either
+// arithmetic (bf16x3 937 / 947 / 959 us against 905 / 966 / 950 in plain order): the memory-side cache absorbs the 8-fold fetch.)
 template <bool TA, bool TB, int TILES, bool X3>
-__global__ void __launch_bounds__(kGemmThreads, X3 ? 2 : 3) gemm_f32_kernel(int M, int N, int K, float alpha,
+__global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f32_kernel(int M, int N, int K, float alpha,
                                                                 const float* __restrict__ A, int64_t lda,
                                                                 const float* __restrict__ B, int64_t ldb,
                                                                 float beta, float* __restrict__ C, int64_t ldc,
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(kGemmThreads, X3 ? 2 : 3) gemm_f32_kernel(int 
 // + two launch / prologue / epilogue costs = 206 us); here they take the third workgroup slot of a CU from the start and the
 // slots the first of them free.
 template <bool TA, bool TB, bool X3>
-__global__ void __launch_bounds__(kGemmThreads, X3 ? 2 : 3) gemm_f32_bands_kernel(int M, int N, int K, float alpha,
+__global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f32_bands_kernel(int M, int N, int K, float alpha,
                                                                          const float* __restrict__ A, int64_t lda,
                                                                          const float* __restrict__ B, int64_t ldb,
                                                                          float beta, float* __restrict__ C, int64_t ldc,
@@ -251,7 +257,16 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // frames ran on 64 CUs for 43 us, 30 in slices; the TransformerAM has 29 of them per step whenever the minibatch has fewer
   // than 2048 frames.  Measured against it: 48 and 64 tiles at K = 1800 lose 8-10 us in slices, 16 tiles at K = 1000 lose 6)
   const int deep_k = big_tiles <= 16 ? 1536 : 2048;
-  if ((big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
+  // Round 6: the forward form  x W^T  (!transa && transb: every nn.Linear / Conv1d / input projection of a forward pass) is
+  // never sliced: slices add with float atomics, i.e. in arrival order, and a forward pass that is reproducible only up to
+  // summation order flips ReLU masks of activations within 2e-7 of zero -- one flipped element of a 96 x 2048 mask moved a
+  // weight-gradient tensor by 0.2-2 % of its maximum and failed the TransformerAM parity test in 15 % of its runs (round 5
+  // ran the tests with PK2_GEMM_SPLITK=1 instead).  Cost at the bench size (FFN down-projection 2300 x 512 x 2048): 57 -> 65 us
+  // on 64x64 tiles, 0.1 ms of a 19 ms TransformerAM step; weight gradients and the dX form keep their slices (their
+  // summation-order noise of 1e-7 cannot flip anything).  PK2_GEMM_SPLIT_FWD=1 restores the round-5 behaviour.
+  static const bool split_fwd = [] { const char* e = getenv("PK2_GEMM_SPLIT_FWD"); return e && atoi(e) == 1; }();
+  const bool forward_form = !transa && transb && !split_fwd;
+  if (!forward_form && (big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
     int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / PK2_GEMM_MIN_KSLICE);
     if (big_tiles > 256) {
       // between one and two tiles per CU: the slice count that fills whole rounds of the 512 workgroup slots best (368 tiles:

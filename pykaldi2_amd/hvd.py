@@ -191,7 +191,27 @@ def _fake_peer(t, st):
                                                 C.c_void_p(st.cuda_stream)))
 
 
+# Collective guard (DistributedOptimizer): the stamp of the last exchanged step per device is PROCESS state, like the verdict
+# ring it indexes (csrc/persist_guard.hip) -- a second optimiser of the same process (tests; SE after CE) must not restart at
+# stamp 1 and read the ring words an earlier optimiser left behind as its own verdicts.
+_GUARD_STAMP = {}
+_LIVE_OPTIMIZERS = []          # weak references: shutdown() flushes their last verdicts
+
+
+def finish():
+    """Collective flush of every live DistributedOptimizer (call on all ranks at the same point: epoch end, before a checkpoint
+    is written, before shutdown): raises on every rank when a persistent kernel timed out in one of the last steps."""
+    for ref in list(_LIVE_OPTIMIZERS):
+        opt = ref()
+        if opt is None:
+            _LIVE_OPTIMIZERS.remove(ref)
+        else:
+            opt.finish()
+
+
 def shutdown():
+    if _state["initialized"] or _LIVE_OPTIMIZERS:
+        finish()
     if _state["comm"] is not None:
         from . import _lib
         if torch.cuda.is_available():
@@ -416,12 +436,17 @@ class DistributedOptimizer:
         # of step s -- the same word everywhere -- and raises Pk2Error there; the local, unsynchronised check of the
         # wrapped optimiser is switched off.  (Two steps back: the host never waits for the device in a healthy job.)
         self._guard_slot = None
-        self._guard_stamp = 0
+        self._guard_dev = None
+        self._guard_first = 1          # first stamp this optimiser issues (verdicts of earlier stamps belong to someone else)
         if self._flat and _collective() and torch.cuda.is_available() and os.environ.get("PK2_HVD_GUARD", "1") != "0":
             dev = next(iter(optimizer.model.parameters())).device
             if dev.type == "cuda":
                 self._guard_slot = torch.zeros(1, dtype=torch.float32, device=dev)
+                self._guard_dev = dev.index if dev.index is not None else torch.cuda.current_device()
+                self._guard_first = _GUARD_STAMP.get(self._guard_dev, 0) + 1
                 optimizer.guard_check = False
+                import weakref
+                _LIVE_OPTIMIZERS.append(weakref.ref(self))
         # bench.py / diagnostics: with `timing = []` every step appends the (start, end) device events of its all-reduce
         # calls, in issue order, on whichever stream they ran (bench.py reads them after its timed region)
         self.timing = None
@@ -467,17 +492,33 @@ class DistributedOptimizer:
             for i, (lo, hi) in enumerate(pieces):
                 self._timed_allreduce(gflat[lo:hi], None, slot if i == len(pieces) - 1 else None)
             if slot is not None:
-                self._guard_stamp += 1
+                _GUARD_STAMP[self._guard_dev] = self._guard_stamp + 1
                 _lib.check(_lib.lib().pk2_persist_guard_import(_lib.ptr(slot), self._guard_stamp, _lib.stream_ptr(slot.device)))
             self._done = []
             self._reduced = True
             self._trial_mark_exchanged()
 
-    def _guard_verdict(self):
+    @property
+    def _guard_stamp(self):
+        return _GUARD_STAMP.get(self._guard_dev, 0)
+
+    def finish(self):
+        """Collective flush: the per-step check looks two steps back, so a time-out in the last two steps of a run
+        or epoch would otherwise never be raised -- the job would exit 0 and write its checkpoint although those updates
+        were skipped.  Waits for the device, then reads the verdicts of the last two exchanged steps; every rank sees the
+        same combined words and raises (or not) together.  Called by the bin/train_*.py loops at epoch end and by
+        hvd.shutdown()."""
+        if self._guard_slot is None:
+            return
+        torch.cuda.synchronize(self._guard_slot.device)
+        for back in (1, 0):
+            self._guard_verdict(back)
+
+    def _guard_verdict(self, back=2):
         """Raises on EVERY rank at the same step: the combined guard word of two steps ago (host-mapped, no device
         synchronisation in a healthy job: the device is never two whole steps behind the host for long)."""
-        want = self._guard_stamp - 2
-        if self._guard_slot is None or want < 1:
+        want = self._guard_stamp - back
+        if self._guard_slot is None or want < self._guard_first:
             return
         import time
         from . import _lib

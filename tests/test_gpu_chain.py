@@ -464,3 +464,41 @@ def test_graph_beyond_the_register_slots_streams_its_overflow():
         del os.environ["PK2_DEN_PERSIST"]
     assert np.abs(lp_f.cpu().numpy() - lp).max() <= 1e-5 * np.abs(lp).max()
     assert np.abs(gamma_f.cpu().numpy() - gamma).max() < 1e-5
+
+
+def test_bench_size_long_sequences_with_peaked_logits_match_c_oracle():
+    """VERDICT r5 weak #1c / next #6b: the regime the bench runs in -- T' ~ 570 subsampled frames per sequence (12 s
+    utterances), logits that look trained (per frame one pdf of a piecewise-constant path stands 10 above a N(0,1) floor, two
+    confusable pdfs 5 above it; 1/Sum-alpha rescaling and the +-30 clamp see a dynamic range Gaussian logits never produce) --
+    on the bench graph (S = 30 k, A = 1 M, P = 6048, chain topology), persistent kernel, against the float64 build of
+    oracle/chain_oracle.c: den log-prob 1e-3 rel (north star), occupancies 1e-4 abs, alpha-beta check sum within 1e-3 of 1."""
+    from oracle import chain_c
+    P = 6048
+    g = synth.den_graph_arcs(30000, 1000000, P, seed=0, loop_pdf_differs=True)
+    G = chain.DenominatorGraph(g, P)
+    lens = [569, 410, 377, 502]
+    assert G.kernel_path(len(lens)) == 2
+    pi = R.initial_probs_ref(g["num_states"], g["src"].astype(np.int64), g["dst"].astype(np.int64),
+                             g["prob"].astype(np.float64), 0)
+    rng = np.random.default_rng(21)
+    lg = rng.normal(0, 1, size=(4, max(lens), P)).astype(np.float32)
+    for n in range(4):
+        t = 0
+        while t < max(lens):
+            d, p = int(rng.integers(1, 7)), int(rng.integers(0, P))
+            lg[n, t:t + d, p] += 10.0
+            for q in rng.integers(0, P, size=2):
+                lg[n, t:t + d, q] += 5.0
+            t += d
+    x = torch.from_numpy(lg).cuda()
+    lp, gamma = chain.den_forward_backward(G, x, lens, 1e-4)
+    lp, gamma = lp.cpu().numpy(), gamma.cpu().numpy()
+    assert np.isfinite(lp).all() and np.isfinite(gamma).all()
+    for n, Tn in enumerate(lens):
+        want_lp, want_g, chk = chain_c.den_fb(g, pi, lg[n, :Tn], 1e-4, double=True)
+        assert abs(chk - 1.0) < 1e-3
+        assert abs(lp[n] - want_lp) <= 1e-3 * abs(want_lp), (n, lp[n], want_lp)
+        err = np.abs(gamma[n, :Tn] - want_g).max()
+        assert err < 1e-4, (n, err)
+        assert abs(gamma[n, :Tn].sum() - Tn) < 1e-3 * Tn          # occupancies of a frame sum to one
+        assert not gamma[n, Tn:].any()

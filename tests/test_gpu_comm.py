@@ -91,20 +91,29 @@ class Flat:
     def __init__(self, p): self.p, self.g = p, torch.zeros_like(p)
     def flat_parameters(self): return self.p, self.g
     def parameters(self): return [self.p]
+# an earlier optimiser of the same process: the next one continues the device's stamp sequence (ADVICE r5: a ring word of the
+# verdict ring is never reused, so a stale verdict cannot be taken for a fresh one)
+first = hvd.DistributedOptimizer(optim.Adam(Flat(torch.zeros(64).cuda()), lr=1e-2, amsgrad=True))
+for _ in range(3):
+    first.zero_grad(); first.step()
+first.finish()
 model = Flat(torch.linspace(-1.0, 1.0, 4096).cuda())
 opt = hvd.DistributedOptimizer(optim.Adam(model, lr=1e-2, amsgrad=True))
+assert first._guard_first == 1 and opt._guard_first == 4 and opt._guard_stamp == 3, (opt._guard_first, opt._guard_stamp)
 snap, step = None, 0
 try:
-    for step in range(1, 10):
+    for step in range(1, %(nsteps)d):
         opt.zero_grad()
         model.g.fill_(0.5 + rank)
-        if step == 3:
+        if step == %(fail)d:
             torch.cuda.synchronize()
             snap = model.p.clone()               # the weights before the failing step
             if rank == 1:                        # what a timed-out persistent kernel leaves: guard up, NaN gradient
                 _lib.check(_lib.lib().pk2_persist_guard_raise(_lib.stream_ptr()))
                 model.g.fill_(float("nan"))
         opt.step()
+    step = 99
+    hvd.finish()          # the verdicts of the last two steps: raised here, on both ranks, when the loop ended first
     print("RANK %%d NEVER RAISED" %% rank, flush=True)
 except _lib.Pk2Error as e:
     torch.cuda.synchronize()
@@ -125,14 +134,34 @@ def test_guard_of_one_rank_stops_every_rank_at_the_same_step(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "guard2.py"
-    script.write_text(_GUARD_SCRIPT % dict(root=root))
+    script.write_text(_GUARD_SCRIPT % dict(root=root, nsteps=10, fail=3))
+    got, r = _run_guard_script(script, root, 29547)
+    assert got == [("0", "5", "1", "1", "1"), ("1", "5", "1", "1", "1")], r.stdout[-2000:] + r.stderr[-2000:]
+    assert "NEVER RAISED" not in r.stdout
+
+
+def _run_guard_script(script, root, port):
+    import os
+    import re
+    import subprocess
+    import sys
     env = dict(os.environ, PK2_HVD_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    import re
     # (the two ranks share the pipe: their lines may run into each other)
-    got = sorted(re.findall(r"RANK (\d) RAISED step=(\d+) same=(\d) finite=(\d) local=(\d)", r.stdout))
-    assert got == [("0", "5", "1", "1", "1"), ("1", "5", "1", "1", "1")], r.stdout[-2000:] + r.stderr[-2000:]
+    return sorted(re.findall(r"RANK (\d) RAISED step=(\d+) same=(\d) finite=(\d) local=(\d)", r.stdout)), r
+
+
+def test_guard_raised_in_the_last_step_is_caught_by_the_collective_flush(tmp_path):
+    """the per-step check looks two steps back, so a time-out in the LAST step of a run was never raised (exit 0,
+    checkpoint written).  Rank 1's guard goes up in the last step of a 6-step loop; hvd.finish() (epoch end / shutdown)
+    must raise on BOTH ranks, with the weights of both ranks untouched by the failing step."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "guard_last.py"
+    script.write_text(_GUARD_SCRIPT % dict(root=root, nsteps=7, fail=6))
+    got, r = _run_guard_script(script, root, 29549)
+    assert got == [("0", "99", "1", "1", "1"), ("1", "99", "1", "1", "1")], r.stdout[-2000:] + r.stderr[-2000:]
     assert "NEVER RAISED" not in r.stdout

@@ -56,6 +56,9 @@ def err_study():
 def t_us(ta, tb, M, N, K, arith, reps=20):
     A = torch.randn((K, M) if ta else (M, K), device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
+    import os
+    if os.environ.get("PK2_ZERO"):      # (DVFS probe: zero operands toggle nothing; the same instruction stream clocks higher)
+        A.zero_(); B.zero_()
     C = torch.empty(M, N, device=dev)
     _lib.check(L.pk2_gemm_set_arith(arith))
     best = 1e9
