@@ -121,6 +121,18 @@ int pk2_chain_objf_and_deriv(const pk2_den_graph* g, const float* logits, int64_
                              float* grad, int64_t grad_seq_stride, int64_t grad_frame_stride,
                              float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same computation in the convention of the reference's autograd operator (ops/ops.py:243-280: forward returns the
+ * objective, backward returns MINUS its derivative whatever grad_out is): the gradient written is
+ * grad_scale * d objf / d logits (grad_scale = -1 for the operator) and *objf_sum (device f32, optional) receives
+ * sum_n objf[n] -- so that the operator needs no elementwise or reduction kernel of its own around the call. */
+int pk2_chain_objf_and_deriv_op(const pk2_den_graph* g, const float* logits, int64_t seq_stride,
+                                int64_t frame_stride, const int32_t* lengths, int32_t num_seqs,
+                                const pk2_num_batch* num, float leaky_hmm_coefficient,
+                                float xent_regularize, float l2_regularize, float weight,
+                                float* grad, int64_t grad_seq_stride, int64_t grad_frame_stride,
+                                float* out, void* workspace, size_t workspace_bytes, float grad_scale,
+                                float* objf_sum, void* stream);
+
 /* Denominator only (log p_den and its occupancies); used by tests/profiling.
  * den_logprob: device f32[N]; gamma: device, logits addressing, receives
  * d log p_den / d logits (posteriors, rows sum to 1). */

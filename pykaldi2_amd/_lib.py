@@ -55,6 +55,8 @@ SIGNATURES = {
     "pk2_chain_workspace_bytes": (_sz, [_vp, _i32, _i32, _i64]),
     "pk2_chain_objf_and_deriv": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(NumBatch), _f32,
                                            _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "pk2_chain_objf_and_deriv_op": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(NumBatch), _f32,
+                                              _f32, _f32, _f32, _vp, _i64, _i64, _vp, _vp, _sz, _f32, _vp, _vp]),
     "pk2_chain_den_fwd_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _f32, _vp, _vp, _i64, _i64,
                                         _vp, _sz, _vp]),
     "pk2_chain_debug_flags": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),

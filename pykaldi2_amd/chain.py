@@ -388,13 +388,16 @@ def _workspace(device, nbytes):
     return ws
 
 
-def compute_chain_objf_and_deriv(opts, den_graph, supervisions, nnet_output, lengths=None):
+def compute_chain_objf_and_deriv(opts, den_graph, supervisions, nnet_output, lengths=None, operator_form=False):
     """Batched kaldi.chain.compute_chain_objf_and_deriv (reference ops/ops.py:265-267).
 
     nnet_output: f32 CUDA tensor [N, T, P] (or [T, P] with a single Supervision); row t of
     sequence n is frame t.  Returns (out, grad): out is a device tensor [3, N] =
     (objf, log p_num, log p_den) per sequence, grad is d objf / d nnet_output with
     xent_regularize * numerator posterior already added (zeros on padding frames).
+    operator_form=True (ops.ChainObjtiveBatch): out is [3 N + 1] -- the same three rows followed by sum_n objf[n] -- and grad
+    holds MINUS the derivative, what the reference operator's backward returns (ops/ops.py:276-280); both come out of the
+    library call itself, no torch kernel runs around it.
     """
     _lib.require_gpu()
     if isinstance(supervisions, Supervision):
@@ -416,6 +419,16 @@ def compute_chain_objf_and_deriv(opts, den_graph, supervisions, nnet_output, len
     grad = torch.empty_like(x)
     if Tmax < T:
         grad[:, Tmax:].zero_()
+    if operator_form:
+        out = torch.empty(3 * N + 1, dtype=torch.float32, device=x.device)
+        _lib.check(L.pk2_chain_objf_and_deriv_op(den_graph._h, _lib.ptr(x), x.stride(0), x.stride(1),
+                                                 _lib.ptr(sb.lengths), N, C.byref(sb.struct),
+                                                 float(opts.leaky_hmm_coefficient), float(opts.xent_regularize),
+                                                 float(opts.l2_regularize), float(weight), _lib.ptr(grad),
+                                                 grad.stride(0), grad.stride(1), _lib.ptr(out), _lib.ptr(ws),
+                                                 ws.numel(), -1.0, _lib.ptr(out[3 * N:]), _lib.stream_ptr(x.device)))
+        out._pk2_keepalive = sb
+        return out, grad
     out = torch.empty(3, N, dtype=torch.float32, device=x.device)
     _lib.check(L.pk2_chain_objf_and_deriv(den_graph._h, _lib.ptr(x), x.stride(0), x.stride(1),
                                           _lib.ptr(sb.lengths), N, C.byref(sb.struct),

@@ -24,27 +24,38 @@ __global__ void __launch_bounds__(256) zero_rows(float* out, int64_t seq_stride,
 // (a product that is merely not ApproxEqual to it -- relative 1e-3 -- only draws a warning there and is trained on); here
 // the check is per sequence, so num_sequences = 1.  (Rounds 1-3 abandoned at 0.05: VERDICT r3, weak #1b.)
 constexpr float kAlphaBetaAbandon = 2.0f;
-__global__ void chain_flags(const float* num_lp, const float* den_lp, const float* check,
-                            const int32_t* lengths, int N, float weight, float* out, int32_t* flags) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const float nl = num_lp[n], dl = den_lp[n], ck = check[n];
-  const float objf = weight * (nl - dl);
-  const bool ok = isfinite(objf) && isfinite(ck) && fabsf(ck - 1.0f) <= kAlphaBetaAbandon;
-  flags[n] = ok ? 1 : 0;
-  out[n] = ok ? objf : -10.0f * weight * (float)lengths[n];
-  out[N + n] = nl;
-  out[2 * N + n] = dl;
+// One workgroup of 256; *objf_sum (optional) = sum_n out[n], added in a fixed order.
+__global__ void __launch_bounds__(256) chain_flags(const float* num_lp, const float* den_lp, const float* check,
+                                                   const int32_t* lengths, int N, float weight, float* out, int32_t* flags,
+                                                   float* objf_sum) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float nl = num_lp[n], dl = den_lp[n], ck = check[n];
+    const float objf = weight * (nl - dl);
+    const bool ok = isfinite(objf) && isfinite(ck) && fabsf(ck - 1.0f) <= kAlphaBetaAbandon;
+    flags[n] = ok ? 1 : 0;
+    const float o = ok ? objf : -10.0f * weight * (float)lengths[n];
+    out[n] = o;
+    out[N + n] = nl;
+    out[2 * N + n] = dl;
+    acc += o;
+  }
+  if (objf_sum == nullptr) return;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *objf_sum = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// grad[n][t][p] = ok ? grad - weight*gamma - weight*l2*logit : 0     (grad holds the numerator part)
+// grad[n][t][p] = ok ? gscale * (grad - weight*gamma - weight*l2*logit) : 0     (grad holds the numerator part)
 template <int NG>
 __global__ void __launch_bounds__(256) chain_combine(const float* __restrict__ gamma,
                                                      const int32_t* __restrict__ lengths,
                                                      const int32_t* __restrict__ flags, int N, int P,
                                                      int Tmax, float weight, float l2,
                                                      const float* __restrict__ logits, int64_t lss,
-                                                     int64_t lfs, float* grad, int64_t gss, int64_t gfs) {
+                                                     int64_t lfs, float* grad, int64_t gss, int64_t gfs, float gscale) {
   const int t = blockIdx.x, g = blockIdx.y;
   const float* src = gamma + ((size_t)g * Tmax + t) * (size_t)P * NG;
   for (int p = threadIdx.x; p < P; p += 256) {
@@ -66,6 +77,7 @@ __global__ void __launch_bounds__(256) chain_combine(const float* __restrict__ g
         if (live) {
           r = *o - weight * v[n];
           if (l2 != 0.f) r -= weight * l2 * logits[(int64_t)seq * lss + (int64_t)t * lfs + p];
+          r *= gscale;
         }
         *o = r;
       }
@@ -102,13 +114,13 @@ extern "C" size_t pk2_chain_workspace_bytes(const pk2_den_graph* g, int32_t num_
                      nullptr, nullptr);
 }
 
-extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* logits,
-                                        int64_t seq_stride, int64_t frame_stride,
-                                        const int32_t* lengths, int32_t N, const pk2_num_batch* num,
-                                        float leaky, float xent_regularize, float l2_regularize,
-                                        float weight, float* grad, int64_t gss, int64_t gfs,
-                                        float* out, void* workspace, size_t workspace_bytes,
-                                        void* stream_) {
+static int chain_objf_impl(const pk2_den_graph* gc, const float* logits,
+                           int64_t seq_stride, int64_t frame_stride,
+                           const int32_t* lengths, int32_t N, const pk2_num_batch* num,
+                           float leaky, float xent_regularize, float l2_regularize,
+                           float weight, float* grad, int64_t gss, int64_t gfs,
+                           float* out, void* workspace, size_t workspace_bytes, float gscale, float* objf_sum,
+                           void* stream_) {
   PK2_REQUIRE(gc && logits && lengths && N > 0 && num && grad && out && workspace,
               "chain_objf_and_deriv: bad args");
   pk2_den_graph* g = const_cast<pk2_den_graph*>(gc);
@@ -156,26 +168,43 @@ extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* lo
   if (rc) return rc;
   if (use_side) PK2_HIP(hipStreamWaitEvent(stream, side->join, 0));
   // 3. objective, guards, gradient = numerator - denominator occupancies
-  hipLaunchKernelGGL(chain_flags, dim3((N + 63) / 64), dim3(64), 0, stream, nbuf.num_lp, db.den_lp,
-                     db.check, db.lengths, N, weight, out, flags);
+  hipLaunchKernelGGL(chain_flags, dim3(1), dim3(256), 0, stream, nbuf.num_lp, db.den_lp,
+                     db.check, db.lengths, N, weight, out, flags, objf_sum);
   switch (ge.NG) {
     case 4:
       hipLaunchKernelGGL(chain_combine<4>, dim3(Tmax, ge.G), dim3(256), 0, stream, db.gamma, db.lengths,
                          flags, N, g->P, Tmax, weight, l2_regularize, logits, seq_stride, frame_stride,
-                         grad, gss, gfs);
+                         grad, gss, gfs, gscale);
       break;
     case 2:
       hipLaunchKernelGGL(chain_combine<2>, dim3(Tmax, ge.G), dim3(256), 0, stream, db.gamma, db.lengths,
                          flags, N, g->P, Tmax, weight, l2_regularize, logits, seq_stride, frame_stride,
-                         grad, gss, gfs);
+                         grad, gss, gfs, gscale);
       break;
     default:
       hipLaunchKernelGGL(chain_combine<1>, dim3(Tmax, ge.G), dim3(256), 0, stream, db.gamma, db.lengths,
                          flags, N, g->P, Tmax, weight, l2_regularize, logits, seq_stride, frame_stride,
-                         grad, gss, gfs);
+                         grad, gss, gfs, gscale);
   }
   PK2_LAUNCH_CHECK();
   return PK2_OK;
+}
+
+extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* logits, int64_t seq_stride, int64_t frame_stride,
+                                        const int32_t* lengths, int32_t N, const pk2_num_batch* num, float leaky,
+                                        float xent_regularize, float l2_regularize, float weight, float* grad, int64_t gss,
+                                        int64_t gfs, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  return chain_objf_impl(gc, logits, seq_stride, frame_stride, lengths, N, num, leaky, xent_regularize, l2_regularize, weight, grad,
+                         gss, gfs, out, workspace, workspace_bytes, 1.0f, nullptr, stream_);
+}
+
+extern "C" int pk2_chain_objf_and_deriv_op(const pk2_den_graph* gc, const float* logits, int64_t seq_stride, int64_t frame_stride,
+                                           const int32_t* lengths, int32_t N, const pk2_num_batch* num, float leaky,
+                                           float xent_regularize, float l2_regularize, float weight, float* grad, int64_t gss,
+                                           int64_t gfs, float* out, void* workspace, size_t workspace_bytes, float grad_scale,
+                                           float* objf_sum, void* stream_) {
+  return chain_objf_impl(gc, logits, seq_stride, frame_stride, lengths, N, num, leaky, xent_regularize, l2_regularize, weight, grad,
+                         gss, gfs, out, workspace, workspace_bytes, grad_scale, objf_sum, stream_);
 }
 
 // Test hook: the objective / guard rule of ComputeChainObjfAndDeriv on given per-sequence quantities (device arrays of N):
@@ -185,8 +214,8 @@ extern "C" int pk2_chain_objf_and_deriv(const pk2_den_graph* gc, const float* lo
 extern "C" int pk2_chain_debug_flags(const float* num_lp, const float* den_lp, const float* check, const int32_t* lengths,
                                      int32_t N, float weight, float* out, int32_t* flags, void* stream_) {
   PK2_REQUIRE(num_lp && den_lp && check && lengths && out && flags && N > 0, "chain_debug_flags: bad args");
-  hipLaunchKernelGGL(chain_flags, dim3((N + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), num_lp, den_lp, check,
-                     lengths, N, weight, out, flags);
+  hipLaunchKernelGGL(chain_flags, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), num_lp, den_lp, check,
+                     lengths, N, weight, out, flags, static_cast<float*>(nullptr));
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -297,4 +297,14 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
   }
 }
 
+
+// Round 6, measured and removed: a wide block tile (256 x 128, 512 threads = 8 waves 4 x 2, one workgroup per CU; a quarter
+// less operand traffic, split arithmetic and LDS stores per MFMA).  Parity-green in all four layouts and no faster on any
+// product of the CE configuration (20480 x 4096 x 1024: 954 us against 925).  The counters say why (tools/gpu_x3_pmc2.sh,
+// profiles/r06_gemm_bf16x3_pmc.txt): on random operands BOTH kernels run against the chip's power limit -- the 128 x 128 kernel
+// needs 1.59 M cycles per CU at 1.52 GHz (profiled run), the wide one 1.99 M cycles at 1.89 GHz, the same 1.05 ms; on ZERO
+// operands (nothing toggles, 2.06-2.12 GHz) 805 against 988 us.  What bounds the bf16x3 product is the energy of its six
+// MFMAs per k-step on random mantissas: 185 TFLOP/s of f32-equivalent work = 1.11 PFLOP/s of executed bf16 work, where
+// tuned plain-bf16 GEMMs on this part reach ~1.25 PFLOP/s on random data (MI355X_MICROARCH.md, DVFS give-back).
+
 }  // namespace pk2

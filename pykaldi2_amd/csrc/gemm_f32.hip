@@ -30,6 +30,42 @@ struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, kle
 #ifndef PK2_GEMMX_WAVES
 #define PK2_GEMMX_WAVES 2       // waves per SIMD the bf16x3 kernels are compiled for
 #endif
+// Epilogue of a block tile: the wave's TILES x TILES accumulators (C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) -> C rows m0 + wm.., columns n0 + wn..
+template <int TILES>
+__device__ __forceinline__ void gemm_store(const f32x16 (&acc)[TILES][TILES], int M, int N, float alpha, float beta, float* __restrict__ C,
+                                           int64_t ldc, const float* __restrict__ bias, int m0, int n0, int wm, int wn, bool atomic) {
+  const int lane = threadIdx.x & 63;
+  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
+#pragma unroll
+    for (int j = 0; j < TILES; ++j) {
+      const int gc = n0 + wn + j * 32 + col_l;
+      if (gc >= N) continue;
+      if (atomic) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gr = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (gr < M) atomicAdd(C + (int64_t)gr * ldc + gc, alpha * acc[i][j][r]);
+        }
+        continue;
+      }
+      const float bv = bias ? bias[gc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (gr < M) {
+          float* o = C + (int64_t)gr * ldc + gc;
+          float v = alpha * acc[i][j][r] + bv;
+          if (beta != 0.f) v += beta * (*o);
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
 // LDS bytes of one block tile (two stages of both operands).
 template <bool TA, bool TB, int TILES, bool X3>
 constexpr size_t gemm_smem_bytes() {
@@ -66,35 +102,7 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
 #ifdef PK2_GEMM_PROFILE
   const long long gp_t1 = wall_clock64();
 #endif
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col_l = lane & 31, row_h = 4 * (lane >> 5);
-#pragma unroll
-  for (int i = 0; i < TILES; ++i) {
-#pragma unroll
-    for (int j = 0; j < TILES; ++j) {
-      const int gc = n0 + wn + j * 32 + col_l;
-      if (gc >= N) continue;
-      if (atomic) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gr = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-          if (gr < M) atomicAdd(C + (int64_t)gr * ldc + gc, alpha * acc[i][j][r]);
-        }
-        continue;
-      }
-      const float bv = bias ? bias[gc] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gr = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-        if (gr < M) {
-          float* o = C + (int64_t)gr * ldc + gc;
-          float v = alpha * acc[i][j][r] + bv;
-          if (beta != 0.f) v += beta * (*o);
-          *o = v;
-        }
-      }
-    }
-  }
+  gemm_store<TILES>(acc, M, N, alpha, beta, C, ldc, bias, m0, n0, wm, wn, atomic);
 #ifdef PK2_GEMM_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef PK2_GEMM_PROFILE_N

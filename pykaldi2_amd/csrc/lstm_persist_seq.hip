@@ -44,7 +44,8 @@ struct SeqCtl {
   unsigned next_task;
   unsigned abort;
   unsigned done;
-  unsigned pad[5];
+  unsigned exited;        // workgroups that have left the kernel (round 6: the last one out runs the check)
+  unsigned pad[4];
   struct Team { unsigned task[kSeqMaxTasks + 1]; unsigned bar; unsigned pad[62]; } team[8][kSeqTeams];
 };
 
@@ -537,7 +538,7 @@ __device__ __forceinline__ float seq_writelane(float v, float old) {        // o
   return old;
 }
 
-__global__ void __launch_bounds__(256) lstm_fwd_seq2(SeqFwdParams p, SeqCtl* ctl) {
+__device__ __forceinline__ void lstm_fwd_seq2_body(const SeqFwdParams& p, SeqCtl* ctl) {
   constexpr int H = kSH;
   constexpr int kSlicePitch = 36;           // 32 + 4: the 16 slices a lane group reads side by side start on 16 different bank quads
   __shared__ __attribute__((aligned(16))) float hs[2][16 * kSlicePitch];
@@ -696,7 +697,7 @@ __global__ void __launch_bounds__(256) lstm_fwd_seq2(SeqFwdParams p, SeqCtl* ctl
   }
 }
 
-__global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl) {
+__device__ __forceinline__ void lstm_bwd_seq2_body(const SeqBwdParams& p, SeqCtl* ctl) {
   constexpr int H = kSH, G4 = 4 * kSH;
   __shared__ __attribute__((aligned(16))) float dgl[64];               // this workgroup's dgates [gate * 16 + unit]
   __shared__ __attribute__((aligned(16))) float cst[3][16][8];         // [step % 3][unit]{dy, A, F, Ci, Cf, Cg, Co, -}: written two steps ahead
@@ -920,6 +921,35 @@ __global__ void lstm_seq_check(SeqCtl* ctl, unsigned pairs, float* out, size_t n
   for (size_t i = threadIdx.x; i < mail_n; i += blockDim.x) mail[i] = __uint_as_float(kSeqSentinel);
 }
 
+// Round 6: the check rides in the recurrence launch.  Every workgroup counts itself out; the last one to leave sees the
+// control block in its final state (every other workgroup's atomics are in L2 before its exit count), does what
+// lstm_seq_check does -- verdict, control block zeroed for the next launch, on failure the sticky flag, the guard and the NaN
+// poison -- and the step has six launches less.  (first use on a device: `fold` = 0, the host reads the control block itself)
+struct SeqExit { unsigned pairs; int fold; float* out; size_t n; unsigned* sticky; unsigned* guard_dev; unsigned* guard_host; float* mail; size_t mail_n; };
+__device__ __forceinline__ void seq_exit_check(SeqCtl* ctl, const SeqExit& x) {
+  if (!x.fold) return;
+  __shared__ unsigned s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  const bool good = seq_load_u(&ctl->abort) == 0u && seq_load_u(&ctl->done) == x.pairs;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < sizeof(SeqCtl) / sizeof(unsigned); i += blockDim.x) reinterpret_cast<unsigned*>(ctl)[i] = 0u;
+  if (good) return;
+  if (threadIdx.x == 0) { *x.sticky = 1u; persist_guard_raise(x.guard_dev, x.guard_host); }
+  for (size_t i = threadIdx.x; i < x.n; i += blockDim.x) x.out[i] = __uint_as_float(0x7fc00000u);
+  for (size_t i = threadIdx.x; i < x.mail_n; i += blockDim.x) x.mail[i] = __uint_as_float(kSeqSentinel);
+}
+__global__ void __launch_bounds__(256) lstm_fwd_seq2(SeqFwdParams p, SeqCtl* ctl, SeqExit x) {
+  lstm_fwd_seq2_body(p, ctl);
+  seq_exit_check(ctl, x);
+}
+__global__ void __launch_bounds__(256) lstm_bwd_seq2(SeqBwdParams p, SeqCtl* ctl, SeqExit x) {
+  lstm_bwd_seq2_body(p, ctl);
+  seq_exit_check(ctl, x);
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------
 struct SeqScratch { SeqCtl* ctl = nullptr; float* mail = nullptr; unsigned* sticky = nullptr; PersistGuard guard;
                     int mail_clean_teams = 0;         // mailboxes of that many teams per XCD are known to hold only sentinels
@@ -991,8 +1021,11 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   static const int lps = getenv("PK2_SEQ_FWD_LOOPSLEEP") ? atoi(getenv("PK2_SEQ_FWD_LOOPSLEEP")) : 0;
   static const int smode = getenv("PK2_SEQ_STORE_MODE") ? atoi(getenv("PK2_SEQ_STORE_MODE")) : 1;
   SeqFwdParams p{gx, whh, bhh, y, gates, cells, B, T, D, pre, lps, smode};
+  static const bool fold_env = [] { const char* e = getenv("PK2_LSTM_SEQ_FOLD_CHECK"); return !(e && atoi(e) == 0); }();
+  const bool fold = fold_env && seq_form() != 1 && g_seq_state_pd.ref() == 1;
+  const SeqExit ex{(unsigned)(B * D), fold ? 1 : 0, y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev, nullptr, (size_t)0};
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
-  else hipLaunchKernelGGL(lstm_fwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
+  else hipLaunchKernelGGL(lstm_fwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl, ex);
   PK2_LAUNCH_CHECK();
   if (g_seq_state_pd.ref() < 0) {                 // first use on this device: every pair done, nobody timed out?
     SeqCtl* h = new SeqCtl;
@@ -1004,8 +1037,9 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
     g_seq_state_pd.ref() = ok ? 1 : 0;
     if (!ok) return PK2_OK;              // the caller falls back (and keeps doing so)
   }
-  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
-                     nullptr, (size_t)0);
+  if (!fold)
+    hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
+                       nullptr, (size_t)0);
   sc->ctl_clean = true;
   *ran = true;
   return PK2_OK;
@@ -1034,10 +1068,15 @@ int lstm_bwd_seq_launch(const float* dy, const float* whh, const float* gates, c
   const bool with_bias = seq_form() != 1 && dbias_ih != nullptr;
   SeqBwdParams p{dy, whh, gates, cells, dgx, sc->mail, B, T, D, pre, lps, smode, with_bias ? dbias_ih : nullptr, with_bias ? dbias_hh : nullptr};
   if (bias_done) *bias_done = with_bias;
+  static const bool fold_env = [] { const char* e = getenv("PK2_LSTM_SEQ_FOLD_CHECK"); return !(e && atoi(e) == 0); }();
+  const bool fold = fold_env && seq_form() != 1;
+  const SeqExit ex{(unsigned)(B * D), fold ? 1 : 0, dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev, sc->mail,
+                   (size_t)8 * kSeqTeams * kSeqMailFloats};
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_bwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
-  else hipLaunchKernelGGL(lstm_bwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
-  hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
-                     sc->mail, (size_t)8 * kSeqTeams * kSeqMailFloats);
+  else hipLaunchKernelGGL(lstm_bwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl, ex);
+  if (!fold)
+    hipLaunchKernelGGL(lstm_seq_check, dim3(1), dim3(1024), 0, stream, sc->ctl, (unsigned)(B * D), dgx, (size_t)T * B * D * 4 * H, sc->sticky, sc->guard.dev, sc->guard.host_dev,
+                       sc->mail, (size_t)8 * kSeqTeams * kSeqMailFloats);
   PK2_LAUNCH_CHECK();
   sc->ctl_clean = true;
   *ran = true;

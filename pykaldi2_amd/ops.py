@@ -45,16 +45,19 @@ class ChainObjtiveBatch(Function):
 
     @staticmethod
     def forward(ctx, prediction, den_graph, supervisions, chain_opts):
-        out, grad = chain.compute_chain_objf_and_deriv(chain_opts, den_graph, supervisions,
-                                                       prediction.detach())
-        ctx.save_for_backward(grad)
-        ctx.per_sequence = out
-        return out[0].sum()
+        # (round 6: the summed objective and the negated gradient come out of the library call -- out[0].sum() and
+        # -grad_input were a reduction, two fills and a [N, T, P] elementwise kernel of torch's in the middle of every step)
+        N = len(supervisions)
+        out, neg_grad = chain.compute_chain_objf_and_deriv(chain_opts, den_graph, supervisions,
+                                                           prediction.detach(), operator_form=True)
+        ctx.save_for_backward(neg_grad)
+        ctx.per_sequence = out[:3 * N].view(3, N)
+        return out[3 * N]
 
     @staticmethod
     def backward(ctx, grad_out):
-        grad_input, = ctx.saved_tensors
-        return -grad_input, None, None, None
+        neg_grad, = ctx.saved_tensors
+        return neg_grad, None, None, None
 
 
 class _CrossEntropyFunction(Function):

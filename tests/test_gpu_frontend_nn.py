@@ -94,7 +94,9 @@ def test_pad_roll_subsample_matches_reference_golden(golden):
                                          # tiles clamp their rows), row counts that are no multiple of four in the contiguous dimension
                                          # (those edge tiles keep the bounds-tested loader)
                                          (0, 1, 576, 1856, 144), (0, 0, 1024, 1028, 256), (0, 1, 2354, 512, 512), (1, 0, 2500, 4096, 250),
-                                         (0, 0, 1100, 642, 384), (1, 1, 901, 700, 200), (1, 0, 2502, 1030, 300)])
+                                         (0, 0, 1100, 642, 384), (1, 1, 901, 700, 200), (1, 0, 2502, 1030, 300),
+                                         # large grids (several rounds of tiles per CU), all four layouts, ragged edges
+                                         (0, 1, 4096, 4096, 100), (0, 0, 6200, 4220, 72), (1, 0, 6200, 4222, 40), (1, 1, 8190, 4096, 48)])
 @pytest.mark.parametrize("arith", ["f32", "bf16x3"])
 def test_gemm_f32_matches_float64(ta, tb, M, N, K, arith, gemm_arith):
     # both arithmetic paths of pk2_gemm_f32 (f32 MFMA; three-way bf16 split on the bf16 MFMA, csrc/gemm_bf16x3.h) at ONE bound
