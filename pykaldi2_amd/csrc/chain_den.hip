@@ -30,6 +30,7 @@
 #include "chain_num.h"
 #include "den_kernels.h"
 #include "den_persist.h"
+#include "persist_guard.h"
 #include "step_graph.h"
 
 namespace pk2 {
@@ -615,6 +616,155 @@ __global__ void __launch_bounds__(256) den_scales(DenParams p, const float* csum
     __syncthreads();
     if (tid == 255 || t == 0) { carry_s = lk; if (t == 0) check[g * NG + n] = (float)((1.0 + (double)p.leaky * p.pi_sum) * exp(lk) * (double)csum[(f0 * 2 + 1) * NG + n]); }
     __syncthreads();
+  }
+}
+
+// Round 6 (launches per step): den_csum + den_finalize + the persistent kernel's check + den_scales of the
+// NG = 1 state-x path in ONE launch, one workgroup per sequence.  Each phase is the kernel above it, instruction for
+// instruction in its arithmetic (same partial sums in the same order: the per-frame sums of den_csum take one wave, the other
+// three contributed zeros there), with the frame normalisers handed from phase to phase in LDS.  `ctl` (optional): the
+// control block of the persistent launch that has just run -- every workgroup reads its verdict first, the last one to have
+// done so zeroes the block for the next launch (what den_persist2_check / den_persist_check did in a launch of their own).
+__global__ void __launch_bounds__(256) den_tail1(DenParams p, float* csum, float* den_lp, float* Kf, float* check, DenTailCheck ck) {
+  extern __shared__ float cs[];            // [(Tmax + 1)][2]: cu, ratio
+  __shared__ double redd[4], reda[4], wsum[4];
+  __shared__ double carry_s;
+  __shared__ unsigned s_bad, s_last;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = p.lengths[g];
+  const int ncb = p.bwd.n_chunks, nc = p.fwd.n_chunks;
+  const size_t f0 = (size_t)g * (p.Tmax + 1);
+  if (tid == 0) {
+    s_bad = 0u; s_last = 0u;
+    if (ck.ctl) {
+      const unsigned ab = __hip_atomic_load(ck.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned dn = __hip_atomic_load(ck.done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_bad = (ab != 0u || dn != (unsigned)ck.ntasks) ? 1u : 0u;
+      s_last = __hip_atomic_fetch_add(ck.count_word, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    }
+  }
+  // ---- den_csum.  The persistent kernels leave 32 partial pairs per frame (256 contiguous bytes): a THREAD per frame, added
+  // in the order of the 64-lane butterfly the kernel of its own used (offsets 16, 8, 4, 2, 1 over 32 values; the upper 32
+  // lanes held zeros) -- the same bits, without a dependent round trip per frame (as a wave per frame this phase took 80 us)
+  if (ncb == 32) {
+    for (int t = tid; t <= p.Tmax; t += 256) {
+      const float4* src = reinterpret_cast<const float4*>(p.bpart + (f0 + t) * 64);
+      float c[32], u[32];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float4 v = src[i]; c[2 * i] = v.x; u[2 * i] = v.y; c[2 * i + 1] = v.z; u[2 * i + 1] = v.w; }
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < o; ++i) { c[i] += c[i + o]; u[i] += u[i + o]; }
+      const float cu = c[0] + p.wu * u[0], ratio = cu > 0.f ? c[0] / cu : 0.f;
+      cs[2 * t] = cu; cs[2 * t + 1] = ratio;
+      csum[(f0 + t) * 2] = cu; csum[(f0 + t) * 2 + 1] = ratio;
+    }
+  } else
+  for (int t = w; t <= p.Tmax; t += 4) {
+    float c = 0.f, u = 0.f;
+    for (int i = lane; i < ncb; i += 64) {
+      c += p.bpart[((f0 + t) * ncb + i) * 2];
+      u += p.bpart[((f0 + t) * ncb + i) * 2 + 1];
+    }
+    c = wave_sum(c); u = wave_sum(u);
+    if (lane == 0) {
+      const float cu = c + p.wu * u, ratio = cu > 0.f ? c / cu : 0.f;
+      cs[2 * t] = cu; cs[2 * t + 1] = ratio;
+      csum[(f0 + t) * 2] = cu; csum[(f0 + t) * 2 + 1] = ratio;
+    }
+  }
+  // ---- den_finalize
+  double acc = 0.0, at = 0.0;
+  for (int t = tid; t < T; t += 256) acc += log((double)p.asum[f0 + t]);
+  for (int c = tid; c < nc; c += 256) at += (double)p.apart[(f0 + T) * nc + c];
+  acc = wave_sum_d(acc); at = wave_sum_d(at);
+  if (lane == 0) { redd[w] = acc; reda[w] = at; }
+  __syncthreads();
+  const double s_log = redd[0] + redd[1] + redd[2] + redd[3];
+  const double a_tot = reda[0] + reda[1] + reda[2] + reda[3];
+  const double tot = a_tot * (1.0 + (double)p.leaky * (double)p.pi_sum);
+  const float inv_tot = (T > 0) ? (float)(1.0 / tot) : 0.f;
+  if (tid == 0) {
+    float lp = (T > 0) ? (float)(log(tot) + s_log) : 0.f;
+    if (s_bad) lp = __uint_as_float(0x7fc00000u);          // (den_persist2_check: a launch that gave up poisons its results)
+    den_lp[g] = lp;
+    p.inv_tot[g] = inv_tot;
+    if (s_bad) persist_guard_raise(ck.guard_dev, ck.guard_host);
+  }
+  if (s_last) {          // every workgroup has read the verdict: the control block starts the next launch at zero
+    for (int i = tid; i < ck.ctl_words; i += 256) ck.ctl[i] = 0u;
+  }
+  // ---- den_scales
+  for (int t = T + 1 + tid; t <= p.Tmax; t += 256) Kf[f0 + t] = 0.f;
+  if (T <= 0) { if (tid == 0) check[g] = 1.f; return; }
+  const double lkT = log((double)p.pi_sum) + log((double)inv_tot) + log((double)p.beta_seed);
+  if (tid == 0) { Kf[f0 + T] = (float)exp(lkT); carry_s = lkT; }
+  __syncthreads();
+  for (int hi = T - 1; hi >= 0; hi -= 256) {
+    const int t = hi - tid;
+    double v = 0.0;
+    if (t >= 0) v = log((double)cs[2 * t]) - log((double)p.asum[f0 + t]);
+    double x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    double off = carry_s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    const double lk = off + x;
+    if (t >= 0) Kf[f0 + t] = (float)exp(lk);
+    __syncthreads();
+    if (tid == 255 || t == 0) { carry_s = lk; if (t == 0) check[g] = (float)((1.0 + (double)p.leaky * p.pi_sum) * exp(lk) * (double)cs[1]); }
+    __syncthreads();
+  }
+}
+
+// Round 6: the passes in front of the recursions in ONE launch -- exp(logits) rows, the first alpha frame, the zeroed backward
+// partial sums and (when the caller wants its gradient rows zeroed: the numerator adds into them) the gradient rows -- as
+// independent jobs over ranges of blockIdx.x; each job is the kernel it replaces (den_exp_rows, den_init<1>, the memset of
+// bpart, zero_rows).
+struct DenPrepJobs { int exp_blocks, init_blocks, init_bx, bpart_blocks, zero_blocks; size_t bpart_floats;
+                     const float* logits; int64_t lss, lfs; float* xp; float* grad; int64_t gss, gfs; int N; };
+__global__ void __launch_bounds__(256) den_prep1(DenParams p, DenPrepJobs j) {
+  int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (b < j.exp_blocks) {
+    const int t = b % p.Tmax, g = b / p.Tmax;
+    const bool live = t < p.lengths[g];
+    const float* row = j.logits + (int64_t)g * j.lss + (int64_t)t * j.lfs;
+    float* out = j.xp + ((size_t)g * p.Tmax + t) * (size_t)p.P;
+    for (int q = tid; q < p.P; q += 256) {
+      float xx = live ? row[q] : 0.f;
+      xx = xx < -30.f ? -30.f : (xx > 30.f ? 30.f : xx);
+      out[q] = live ? expf(xx) : 1.0f;
+    }
+    return;
+  }
+  b -= j.exp_blocks;
+  if (b < j.init_blocks) {
+    const int bx = b % j.init_bx, g = b / j.init_bx;
+    float* a0 = p.alpha + (size_t)g * (p.Tmax + 1) * (size_t)p.S;
+    for (int s = bx * 256 + tid; s < p.S; s += j.init_bx * 256) a0[s] = p.pi[s];
+    if (bx == 0) {
+      float* ap = p.apart + (size_t)g * (p.Tmax + 1) * (size_t)p.fwd.n_chunks;
+      for (int c = tid; c < p.fwd.n_chunks; c += 256) ap[c] = (c == 0) ? p.pi_sum : 0.f;
+    }
+    return;
+  }
+  b -= j.init_blocks;
+  if (b < j.bpart_blocks) {
+    for (size_t i = (size_t)b * 256 + tid; i < j.bpart_floats; i += (size_t)j.bpart_blocks * 256) p.bpart[i] = 0.f;
+    return;
+  }
+  b -= j.bpart_blocks;
+  {
+    const int t = b % p.Tmax, n = b / p.Tmax;
+    float* row = j.grad + (int64_t)n * j.gss + (int64_t)t * j.gfs;
+    for (int q = tid; q < p.P; q += 256) row[q] = 0.f;
   }
 }
 
@@ -1386,9 +1536,14 @@ int get_side_stream(hipStream_t main, SideStream** out) {
 template <int NG>
 static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stride,
                          int64_t frame_stride, const int32_t* lengths_host, const DenGeom& ge,
-                         const DenBuffers& b, float leaky, hipStream_t stream, const NumDeferred* tail) {
+                         const DenBuffers& b, float leaky, hipStream_t stream, const NumDeferred* tail, const DenZeroRows* zr) {
   const int Tmax = ge.Tmax, G = ge.G;
   const size_t GN = (size_t)G * NG;
+  // Round 6: on the bench path (NG = 1, state-x kernels, second persistent form with the x gather) the passes in front of the
+  // recursions are ONE launch (den_prep1) and the ones behind them one more (den_tail1); PK2_DEN_MERGE=0 keeps the round-5
+  // launches.  The caller's gradient rows (zr) are zeroed by that launch, or by one of their own on every other path.
+  static const bool merge_env = [] { const char* e = getenv("PK2_DEN_MERGE"); return !(e && atoi(e) == 0); }();
+  bool zero_pending = zr != nullptr && zr->grad != nullptr;
   // lengths travel as kernel arguments (no dependence on the lifetime of the caller's host array);
   // padding sequences get 0 frames
   for (size_t base = 0; base < GN; base += IntPack::kN) {
@@ -1416,7 +1571,13 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     PK2_HIP(hipMemsetAsync(b.gamma, 0, GN * (size_t)Tmax * g->P * sizeof(float), stream));
   }
   const bool persist = ge.persist && NG == 1 && sx;
-  PK2_HIP(hipMemsetAsync(b.bpart, 0, GN * (Tmax + 1) * std::max<size_t>(hb.n_chunks, persist ? kPR : 0) * (sx ? 2 : 1) * sizeof(float), stream));
+  const size_t bpart_floats = GN * (Tmax + 1) * std::max<size_t>(hb.n_chunks, persist ? kPR : 0) * (sx ? 2 : 1);
+  bool use_prep = false;
+  if (merge_env && persist && NG == 1 && den_persist_version(g, ge.N) == 2 && !need_fill) {
+    const char* xg_e0 = getenv("PK2_DEN_XGATHER");
+    use_prep = !(xg_e0 && atoi(xg_e0) == 0) && g->P <= 32767 && g->V >= g->P && g->p2_rowarrays == kP2RowArrays;
+  }
+  if (!use_prep) PK2_HIP(hipMemsetAsync(b.bpart, 0, bpart_floats * sizeof(float), stream));
 
   DenParams p;
   p.fwd = sx ? g->fwdv : g->fwd; p.bwd = sx ? g->bwdv : g->bwd; p.gam = g->gam;
@@ -1447,14 +1608,34 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
   ParamSlot<DenParams>* slot;
   int rc = get_param_slot(g_den_slots, NG, stream, &slot);
   if (rc) return rc;
-  hipLaunchKernelGGL(param_block_store<DenParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
+  // (the frame kernels read their parameters from this block; the persistent kernels carry their own)
+  if (!(merge_env && persist)) hipLaunchKernelGGL(param_block_store<DenParams>, dim3(1), dim3(1), 0, stream, p, slot->params);
   const DenParams* pb = slot->params;
   const StepCounter* cnt = slot->counter;
 
   // Two kernel families: the "state-x" path (exp(logit) as a per-virtual-state factor; den_use_sx), else LDS-staged
   // exp(logits) + arc-based occupancies.
   char key[96];
-  hipLaunchKernelGGL(den_init<NG>, dim3(std::min(256, (g->S + 255) / 256), G), dim3(256), 0, stream, p);
+  const int init_bx = std::min(256, (g->S + 255) / 256);
+  if constexpr (NG == 1) {
+    if (use_prep) {
+      DenPrepJobs j{Tmax * G, init_bx * G, init_bx, 64, zero_pending ? Tmax * zr->N : 0, bpart_floats, logits, seq_stride, frame_stride,
+                    b.xv, zero_pending ? zr->grad : nullptr, zero_pending ? zr->gss : 0, zero_pending ? zr->gfs : 0, zero_pending ? zr->N : 0};
+      hipLaunchKernelGGL(den_prep1, dim3(j.exp_blocks + j.init_blocks + j.bpart_blocks + j.zero_blocks), dim3(256), 0, stream, p, j);
+      zero_pending = false;
+    } else if (zero_pending) {        // the gradient rows alone (same kernel, one job)
+      DenPrepJobs j{0, 0, 1, 0, Tmax * zr->N, 0, logits, seq_stride, frame_stride, nullptr, zr->grad, zr->gss, zr->gfs, zr->N};
+      hipLaunchKernelGGL(den_prep1, dim3(j.zero_blocks), dim3(256), 0, stream, p, j);
+      zero_pending = false;
+    }
+  }
+  if (zero_pending) {
+    DenParams pz = p;
+    DenPrepJobs j{0, 0, 1, 0, Tmax * zr->N, 0, logits, seq_stride, frame_stride, nullptr, zr->grad, zr->gss, zr->gfs, zr->N};
+    hipLaunchKernelGGL(den_prep1, dim3(j.zero_blocks), dim3(256), 0, stream, pz, j);
+    zero_pending = false;
+  }
+  if (!use_prep) hipLaunchKernelGGL(den_init<NG>, dim3(init_bx, G), dim3(256), 0, stream, p);
   if (sx) {
     // a frame's entries are cut into slices on grid.z so that short minibatches still fill the chip
     auto slices = [&](int n) { return std::max(1, std::min((n + 1023) / 1024, (4096 + Tmax * G - 1) / (Tmax * G))); };
@@ -1466,7 +1647,9 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
     const bool xg_env = !(xg_e && atoi(xg_e) == 0);
     const bool xgather = xg_env && form == 2 && NG == 1 && g->P <= 32767 && g->V >= g->P && g->p2_rowarrays == kP2RowArrays;
     if (form == 2 && NG == 1) p.brec = 1;       // (dense btilde' records: den_kernels.h; the frame kernels' copy of p keeps 2)
-    if (xgather) {
+    if (xgather && use_prep) {
+      // (den_prep1 has written the rows)
+    } else if (xgather) {
       hipLaunchKernelGGL(den_exp_rows, dim3(Tmax, G), dim3(256), 0, stream, logits, seq_stride, frame_stride, b.lengths, b.xv,
                          g->P, Tmax);
     } else if (persist || (exp_lds <= kGammaMaxLds && !getenv("PK2_DEN_EXP_GATHER"))) {
@@ -1496,7 +1679,8 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
       if (!ran) {       // the device failed the first-use verification: the frame kernels, with their own chunk counts
         DenGeom ge2 = ge;
         ge2.persist = false;
-        return den_compute_t<NG>(g, logits, seq_stride, frame_stride, lengths_host, ge2, b, leaky, stream, tail);
+        DenZeroRows none{};       // (the gradient rows have been zeroed above)
+        return den_compute_t<NG>(g, logits, seq_stride, frame_stride, lengths_host, ge2, b, leaky, stream, tail, zr ? &none : nullptr);
       }
     } else {
       // the backward chain needs only exp(logits): forward frame `step` and backward frame Tmax-1-step
@@ -1511,11 +1695,23 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
 #ifdef PK2_DEN_PROFILE
     hipLaunchKernelGGL(den_prof_print, dim3(1), dim3(1), 0, stream, Tmax);
 #endif
-    hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
-    hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
-    if (ran && persist_form == 2) den_persist2_check_launch(b.den_lp, ge.N, stream);
-    else if (ran) den_persist_check_launch(b.den_lp, ge.N, stream);
-    hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
+    bool tail_merged = false;
+    if constexpr (NG == 1) {
+      if (merge_env && (!ran || persist_form == 2) && (size_t)(Tmax + 1) * 2 * sizeof(float) <= 60 * 1024) {
+        DenTailCheck ck{};
+        if (ran && !den_persist2_tail_check(stream, &ck)) ck = DenTailCheck{};
+        hipLaunchKernelGGL(den_tail1, dim3(G), dim3(256), (size_t)(Tmax + 1) * 2 * sizeof(float), stream, p, b.csum, b.den_lp, b.kscale,
+                           b.check, ck);
+        tail_merged = true;
+      }
+    }
+    if (!tail_merged) {
+      hipLaunchKernelGGL(den_csum<NG>, dim3(Tmax + 1, G), dim3(256), 0, stream, p, b.csum);
+      hipLaunchKernelGGL(den_finalize<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.den_lp);
+      if (ran && persist_form == 2) den_persist2_check_launch(b.den_lp, ge.N, stream);
+      else if (ran) den_persist_check_launch(b.den_lp, ge.N, stream);
+      hipLaunchKernelGGL(den_scales<NG>, dim3(G, NG), dim3(256), 0, stream, p, b.csum, b.kscale, b.check);
+    }
     const size_t row_lds = (size_t)g->P * NG * sizeof(float);
     const bool lds_row = row_lds <= kGammaMaxLds && !getenv("PK2_DEN_GAMMA_GATHER");
     struct attr_n_t { bool f[8]; }; static PerDevice<attr_n_t> attr_n_pd(attr_n_t{}); bool (&attr_n)[8] = attr_n_pd.ref().f;
@@ -1568,7 +1764,7 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
 
 int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64_t frame_stride,
                 const int32_t* lengths_host, const DenGeom& ge, const DenBuffers& b, float leaky,
-                hipStream_t stream, const NumDeferred* tail) {
+                hipStream_t stream, const NumDeferred* tail, const DenZeroRows* zr) {
   int rc = den_upload(g);
   if (rc) return rc;
   if (den_choose_ng(g) == 0) {
@@ -1576,9 +1772,9 @@ int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64
     return PK2_ERR_LIMIT;
   }
   switch (ge.NG) {
-    case 4: return den_compute_t<4>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail);
-    case 2: return den_compute_t<2>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail);
-    default: return den_compute_t<1>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail);
+    case 4: return den_compute_t<4>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail, zr);
+    case 2: return den_compute_t<2>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail, zr);
+    default: return den_compute_t<1>(g, logits, seq_stride, frame_stride, lengths_host, ge, b, leaky, stream, tail, zr);
   }
 }
 

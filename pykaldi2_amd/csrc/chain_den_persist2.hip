@@ -1428,4 +1428,18 @@ void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream) {
   }
 }
 
+bool den_persist2_tail_check(hipStream_t stream, DenTailCheck* ck) {
+  DenPersist2Scratch& sc = g_den2_scratch[dev_stream(stream)];
+  PersistGuard guard;
+  (void)persist_guard(&guard);
+  if (!sc.ctl || sc.ntasks <= 0) return false;
+  ck->ctl = reinterpret_cast<unsigned*>(sc.ctl);
+  ck->ctl_words = (int)(sizeof(DenPersistCtl) / sizeof(unsigned));
+  ck->ntasks = sc.ntasks;
+  ck->abort_word = &sc.ctl->abort; ck->done_word = &sc.ctl->done; ck->count_word = &sc.ctl->pad[0];
+  ck->guard_dev = guard.dev; ck->guard_host = guard.host_dev;
+  sc.ctl_clean = true;
+  return true;
+}
+
 }  // namespace pk2

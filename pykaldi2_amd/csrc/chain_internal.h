@@ -252,9 +252,12 @@ struct NumDeferred;
 int den_upload(pk2_den_graph* g);
 // Runs exp-transpose, T forward steps, finalize, T backward steps.  Leaves
 // gamma / den_lp / check in `buf`.
+// `zero` (optional): gradient rows [N][Tmax][P] of the caller that must hold zeros before the numerator adds into them --
+// zeroed by the launch that prepares the recursions (round 6: one launch less per step) or by one of their own.
+struct DenZeroRows { float* grad = nullptr; int64_t gss = 0, gfs = 0; int N = 0; };
 int den_compute(pk2_den_graph* g, const float* logits, int64_t seq_stride, int64_t frame_stride,
                 const int32_t* lengths_host, const DenGeom& geom, const DenBuffers& buf,
-                float leaky, hipStream_t stream, const NumDeferred* tail = nullptr);
+                float leaky, hipStream_t stream, const NumDeferred* tail = nullptr, const DenZeroRows* zero = nullptr);
 
 // Internal side stream (+ fork/join events) paired with a caller stream: the numerator runs there while
 // the denominator occupies the caller's stream.

@@ -151,7 +151,8 @@ static int chain_objf_impl(const pk2_den_graph* gc, const float* logits,
   int rc = use_side ? get_side_stream(stream, &side) : 0;
   if (rc) return rc;
   hipStream_t num_stream = use_side ? side->stream : stream;
-  hipLaunchKernelGGL(zero_rows, dim3(Tmax, N), dim3(256), 0, stream, grad, gss, gfs, g->P, Tmax);
+  // (round 6: without a side stream the rows are zeroed by the denominator's preparing launch -- den_compute, `zero`)
+  if (use_side) hipLaunchKernelGGL(zero_rows, dim3(Tmax, N), dim3(256), 0, stream, grad, gss, gfs, g->P, Tmax);
   if (use_side) {
     PK2_HIP(hipEventRecord(side->fork, stream));
     PK2_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
@@ -164,7 +165,9 @@ static int chain_objf_impl(const pk2_den_graph* gc, const float* logits,
   if (rc) return rc;
   if (use_side) PK2_HIP(hipEventRecord(side->join, side->stream));
   // 2. denominator
-  rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream, use_side ? nullptr : &deferred);
+  DenZeroRows zr; zr.grad = grad; zr.gss = gss; zr.gfs = gfs; zr.N = N;
+  rc = den_compute(g, logits, seq_stride, frame_stride, lengths, ge, db, leaky, stream, use_side ? nullptr : &deferred,
+                   use_side ? nullptr : &zr);
   if (rc) return rc;
   if (use_side) PK2_HIP(hipStreamWaitEvent(stream, side->join, 0));
   // 3. objective, guards, gradient = numerator - denominator occupancies

@@ -45,6 +45,11 @@ int den_persist2_launch(pk2_den_graph* g, const DenParams& p, const float* xv, c
                         hipStream_t stream, bool* ran, const NumDeferred* tail = nullptr, bool* num_ran = nullptr,
                         bool xgather = false);      // xgather: `xv` is exp(logits) [G][Tmax][P], gathered by pdf
 void den_persist2_check_launch(float* den_lp, int N, hipStream_t stream);
+// Round 6: the check as a phase of den_tail1 (chain_den.hip) instead of a launch of its own.  Fills `ck` from the scratch of the
+// persistent launch that has just run on `stream` (false: there was none) and books the control block as zeroed.
+struct DenTailCheck { unsigned* ctl; int ctl_words; int ntasks; unsigned* abort_word; unsigned* done_word; unsigned* count_word;
+                      unsigned* guard_dev; unsigned* guard_host; };
+bool den_persist2_tail_check(hipStream_t stream, DenTailCheck* ck);
 // Which recursion kernel a call of N sequences takes: 0 = the launch-per-frame kernels, 1 = den_persist_kernel (everything
 // resident: graphs up to ~1.05 M arc slots and ~36 k states), 2 = den_persist2_kernel.  PK2_DEN_PERSIST = 0 | 1 | 2 forces one
 // (a forced form that does not fit the graph falls back to the frame kernels).
