@@ -313,6 +313,11 @@ int pk2_gemm_f32_batched(int32_t transa, int32_t transb, int32_t M, int32_t N, i
  *                 one bound), 2.67 x the matrix-core rate.  Same inputs, same outputs, same memory traffic. */
 int pk2_gemm_set_arith(int32_t arith);
 int pk2_gemm_get_arith(void);
+/* A Linear layer's weight AND bias gradient from one launch: C[M,N] = alpha * A^T B + beta * C with A stored [K,M] (= dY
+ * [frames, out_features]), B [K,N] (= the layer's input), and colsum[m] += sum_k A[k][m] (the bias gradient, ACCUMULATED:
+ * the buffer holds the gradient so far).  Replaces pk2_gemm_f32(1, 0, ...) followed by pk2_colsum_f32(A, ..., beta = 1). */
+int pk2_gemm_f32_tn_colsum(int32_t M, int32_t N, int32_t K, float alpha, const float* A, int64_t lda, const float* B,
+                           int64_t ldb, float beta, float* C, int64_t ldc, float* colsum, void* stream);
 /* out[n] (+)= sum_m A[m][n]  (bias gradients). */
 int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out,
                    void* stream);

@@ -110,6 +110,7 @@ SIGNATURES = {
                                _vp, _vp]),
     "pk2_gemm_f32_batched": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64,
                                        _f32, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "pk2_gemm_f32_tn_colsum": (C.c_int, [_i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _vp]),
     "pk2_gemm_set_arith": (C.c_int, [_i32]),
     "pk2_gemm_get_arith": (C.c_int, []),
     "pk2_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -133,8 +133,11 @@ __device__ __forceinline__ void xload_general(const PieceMap<KC, TILES>& pm, con
 }
 
 // Split a thread's two float4 and write the three planes of the stage `tile` (16-byte slots).
-template <bool KC, int TILES>
-__device__ __forceinline__ void xstore(const PieceMap<KC, TILES>& pm, u32x4_t* __restrict__ tile, const float4 (&reg)[2]) {
+// CS (row-contiguous A of a weight-gradient product only): cs[i] += the two values of row 4 q + i -- the thread's share of the
+// operand's sums over k, i.e. of the bias gradient that goes with the weight gradient (see tile_mainloop_bf16x3).
+template <bool KC, int TILES, bool CS = false>
+__device__ __forceinline__ void xstore(const PieceMap<KC, TILES>& pm, u32x4_t* __restrict__ tile, const float4 (&reg)[2],
+                                       float* cs = nullptr, float csw = 0.f) {
   typedef GeoX<TILES> G;
   constexpr int SP = G::template sp<KC>(), PL = G::NKG * SP;      // slots per k-group / per plane
   if (KC) {
@@ -160,6 +163,7 @@ __device__ __forceinline__ void xstore(const PieceMap<KC, TILES>& pm, u32x4_t* _
       p[4 * (G::SW * i)] = hh;
       p[4 * (G::SW * i + PL)] = mm;
       p[4 * (G::SW * i + 2 * PL)] = ll;
+      if (CS) cs[i] = fmaf(csw, a[i] + b[i], cs[i]);      // (csw = 0: the pipeline's clamped re-store of the last slab)
     }
   }
 }
@@ -171,7 +175,10 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
                                                      int m0, int n0, int kbeg, int K, int M, int N, bool vecA, bool vecB,
                                                      u32x4_t (*As)[GeoX<TILES>::template slots<KCA>()],
                                                      u32x4_t (*Bs)[GeoX<TILES>::template slots<KCB>()],
-                                                     f32x16 (&acc)[TILES][TILES]) {
+                                                     f32x16 (&acc)[TILES][TILES], float* __restrict__ colsum = nullptr) {
+  // colsum (row-contiguous A only, i.e. the weight-gradient form dW = dY^T X): colsum[m] += sum_k A[k][m] over this tile's k
+  // range, added with float atomics -- the bias gradient rides in the product that reads dY anyway (round 6: 62 colsum
+  // launches per TransformerAM step, one per LF-MMI step).  The caller passes it to the tiles of ONE column block only.
   typedef GeoX<TILES> G;
   constexpr int BM = G::BMN, BN = G::BMN, XBK = G::BK, NKG = G::NKG;
   constexpr int SPA = G::template sp<KCA>(), SPB = G::template sp<KCB>();
@@ -192,6 +199,12 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
   float4 ra[DEPTH][2], rb[DEPTH][2];
   const PieceMap<KCA, TILES> pma;
   const PieceMap<KCB, TILES> pmb;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = !KCA && colsum != nullptr;
+  auto store_a = [&](u32x4_t* tile, const float4 (&reg)[2], bool real = true) {
+    if constexpr (!KCA) { if (do_cs) { xstore<KCA, TILES, true>(pma, tile, reg, cs, real ? 1.f : 0.f); return; } }
+    xstore<KCA, TILES>(pma, tile, reg);
+  };
   const int nk = (K - kbeg + XBK - 1) / XBK;
   const bool interior = vecA && vecB && (m0 + BM <= M || KCA || ((M & 3) == 0 && M >= 4)) &&
                         (n0 + BN <= N || KCB || ((N & 3) == 0 && N >= 4));
@@ -234,7 +247,7 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
     if (n <= 0) return;
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) fetch(min(i, n - 1), ra[i], rb[i]);
-    xstore<KCA, TILES>(pma, As[0], ra[0]);
+    store_a(As[0], ra[0]);
     xstore<KCB, TILES>(pmb, Bs[0], rb[0]);
     lds_barrier();
     fetch(min(DEPTH, n - 1), ra[0], rb[0]);
@@ -248,7 +261,7 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
       constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
       multiply(std::integral_constant<int, cur>());
       if (kt + 1 < n) {
-        xstore<KCA, TILES>(pma, As[nxt], ra[sn]);
+        store_a(As[nxt], ra[sn]);
         xstore<KCB, TILES>(pmb, Bs[nxt], rb[sn]);
       }
       lds_barrier();
@@ -257,7 +270,7 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
     auto steady_step = [&](int kt, auto P) {
       constexpr int st = decltype(P)::value, cur = st & 1, nxt = 1 - cur, sn = (st + 1) % DEPTH;
       multiply(std::integral_constant<int, cur>());
-      xstore<KCA, TILES>(pma, As[nxt], ra[sn]);
+      store_a(As[nxt], ra[sn], kt + 1 < n);
       xstore<KCB, TILES>(pmb, Bs[nxt], rb[sn]);
       lds_barrier();
       fetch(min(kt + 1 + DEPTH, n - 1), ra[sn], rb[sn]);
@@ -283,7 +296,7 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
     if (nk > nk_fast) {
       xload_general<KCA, TILES>(pma, A, lda, m0, kbeg + nk_fast * XBK, M, K, vecA, ra[0]);
       xload_general<KCB, TILES>(pmb, B, ldb, n0, kbeg + nk_fast * XBK, N, K, vecB, rb[0]);
-      xstore<KCA, TILES>(pma, As[0], ra[0]);
+      store_a(As[0], ra[0]);
       xstore<KCB, TILES>(pmb, Bs[0], rb[0]);
       lds_barrier();
       multiply(std::integral_constant<int, 0>());
@@ -294,6 +307,19 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
       xload_general<KCA, TILES>(pma, A, lda, m0, kbeg + ks * XBK, M, K, vecA, xa);
       xload_general<KCB, TILES>(pmb, B, ldb, n0, kbeg + ks * XBK, N, K, vecB, xb);
     });
+  }
+  if constexpr (!KCA) {
+    if (do_cs) {      // the threads that share a row quad (k-groups x k-pairs) add up in LDS (the stages are free: the loop ends
+      float* red = reinterpret_cast<float*>(&As[0][0]);     // behind a barrier), then one atomic per row of the matrix
+      for (int r = threadIdx.x; r < BM; r += kGemmThreads) red[r] = 0.f;
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(&red[pma.row[0] + i], cs[i]);
+      lds_barrier();
+      for (int r = threadIdx.x; r < BM; r += kGemmThreads)
+        if (m0 + r < M) atomicAdd(colsum + m0 + r, red[r]);
+      lds_barrier();
+    }
   }
 }
 

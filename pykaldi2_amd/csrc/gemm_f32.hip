@@ -23,7 +23,7 @@ namespace pk2 {
 // Batched form: blockIdx.z = i0 * n1 + i1 selects a matrix triple at offsets i0*s?0 + i1*s?1 (floats).
 // Split-K form (ksplit > 1): blockIdx.z = batch * ksplit + slice; a slice covers klen k's and adds alpha * its
 // partial product into C with float atomics (C already holds beta * C + bias, see gemm_prescale_kernel).
-struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, klen; };
+struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, klen; float* colsum = nullptr; };      // colsum: pk2_gemm_f32_tn_colsum
 
 // One block tile: C[m0.., n0..] (+)= alpha * A[m0.., kbeg..kend) * B[kbeg..kend), n0..].  `atomic`: the tile's k range is
 // shared with other workgroups -- the product is added with float atomics into a C that already holds beta * C + bias.
@@ -77,7 +77,7 @@ template <bool TA, bool TB, int TILES, bool X3>
 __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int kbeg, float alpha, const float* __restrict__ A, int64_t lda,
                                            const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C,
                                            int64_t ldc, const float* __restrict__ bias, bool vecA, bool vecB, int m0, int n0,
-                                           bool atomic) {
+                                           bool atomic, float* colsum = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
 
@@ -90,7 +90,7 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
     typedef u32x4_t (*StB)[GeoX<TILES>::template slots<TB>()];
     StA Ax = reinterpret_cast<StA>(smem);
     StB Bx = reinterpret_cast<StB>(reinterpret_cast<u32x4_t*>(smem) + 2 * GeoX<TILES>::template slots<!TA>());
-    tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc);
+    tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, n0 == 0 ? colsum : nullptr);
   } else {
     constexpr int LDA = Geo<TILES>::template ld<!TA>(), LDB = Geo<TILES>::template ld<TB>();   // per-operand LDS row pitch
     typedef float (*StA)[BK * LDA];
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f
   }
   __shared__ __attribute__((aligned(16))) char smem[gemm_smem_bytes<TA, TB, TILES, X3>()];
   gemm_block<TA, TB, TILES, X3>(smem, M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
-                                blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1);
+                                blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1, bt.colsum);
 }
 
 // The row bands of a plain 2-D product in ONE launch (round 4): workgroups [0, nbig) take the 128x128 tiles of rows
@@ -216,6 +216,7 @@ using namespace pk2;
 #ifndef PK2_GEMM_ARITH_DEFAULT
 #define PK2_GEMM_ARITH_DEFAULT 1
 #endif
+extern "C" int pk2_colsum_f32(const float* A, int64_t lda, int32_t M, int32_t N, float beta, float* out, void* stream_);
 static int g_gemm_arith = -1;
 static int gemm_arith() {
   if (g_gemm_arith < 0) {
@@ -327,7 +328,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   const bool no_band = band_env && atoi(band_env) == 0;
   // (between one and two big tiles per CU -- 64x64 tiles throughout -- a band of one big tile per CU plus small ones was
   // slower: 6048 x 1024 x 2356: 351 against 334 us, tools/dbg/gemm_modes.py)
-  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && (transa ? (lda & 3) == 0 : true)) {
+  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && !bt.colsum && (transa ? (lda & 3) == 0 : true)) {
     const int Cn = (N + 127) / 128, R = (M + 127) / 128, Cs = (N + 63) / 64;
     auto rounds = [&](int64_t n) { return (double)((n + cus - 1) / cus); };
     int best_r = R; double best = rounds((int64_t)R * Cn);
@@ -373,6 +374,22 @@ extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N
   GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
   return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, true,
                      static_cast<hipStream_t>(stream_));
+}
+
+// Weight gradient + bias gradient in one launch: C = alpha A^T B + beta C as pk2_gemm_f32(transa = 1, transb = 0), and
+// colsum[m] += sum_k A[k][m] (A is stored [K, M]: the dY of a Linear layer, whose column sums are the bias gradient).  In
+// the bf16x3 arithmetic the sums ride in the product's operand loader (float atomics, like the product's K slices); in the
+// f32 arithmetic the colsum kernel runs behind the product.
+extern "C" int pk2_gemm_f32_tn_colsum(int32_t M, int32_t N, int32_t K, float alpha, const float* A, int64_t lda, const float* B,
+                                      int64_t ldb, float beta, float* C, int64_t ldc, float* colsum, void* stream_) {
+  PK2_REQUIRE(A && B && C && colsum && M > 0 && N > 0 && K > 0, "gemm_f32_tn_colsum: bad args");
+  GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
+  static const bool fuse_env = [] { const char* e = getenv("PK2_GEMM_FUSE_COLSUM"); return !(e && atoi(e) == 0); }();
+  const bool fuse = fuse_env && gemm_arith() == 1;
+  if (fuse) bt.colsum = colsum;
+  int rc = gemm_launch(1, 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 1, bt, true, static_cast<hipStream_t>(stream_));
+  if (rc || fuse) return rc;
+  return pk2_colsum_f32(A, lda, K, M, 1.0f, colsum, stream_);
 }
 
 extern "C" int pk2_gemm_f32_batched(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,

@@ -161,8 +161,9 @@ class _LstmAmFunction(torch.autograd.Function):
         _gemm(0, 0, rows, D * H, P, _p(dlogits), P, _p(m.output_layer.weight), D * H, _p(dy), D * H)
 
         def out_grads():
-            _gemm(1, 0, P, D * H, rows, _p(dlogits), P, _p(y_last), D * H, _p(gw), D * H, beta=1.0)
-            _lib.check(L.pk2_colsum_f32(_p(dlogits), P, rows, P, 1.0, _p(gb), _lib.stream_ptr()))
+            # weight and bias gradient in one launch (round 6: the column sums ride in the product's operand loader)
+            _lib.check(L.pk2_gemm_f32_tn_colsum(P, D * H, rows, 1.0, _p(dlogits), P, _p(y_last), D * H, 1.0, _p(gw), D * H, _p(gb),
+                                                _lib.stream_ptr()))
             m._bucket_ready("output_layer")
         on_side(out_grads, dlogits, y_last)
         scratch = torch.empty(L.pk2_lstm_bwd_scratch_floats(B, H, D), device=dev, dtype=torch.float32)
@@ -180,11 +181,14 @@ class _LstmAmFunction(torch.autograd.Function):
 
             def layer_grads(dgx=dgx, inp=inp, y=y, in_size=in_size, gw_ih=gw_ih, gw_hh=gw_hh, gb_ih=gb_ih,
                             gb_hh=gb_hh, l=l, bias_done=bool(bias_done.value)):
-                if not bias_done:          # bias gradients (b_ih and b_hh receive the same sum)
-                    _lib.check(L.pk2_colsum_f32(_p(dgx), G, rows, G, 1.0, _p(gb_ih), _lib.stream_ptr()))
+                # dW_ih (both directions at once) = dgx^T inp; the bias gradients (b_ih and b_hh receive the same sum) with it
+                # unless the one-launch recurrence has summed them already
+                if not bias_done:
+                    _lib.check(L.pk2_gemm_f32_tn_colsum(G, in_size, rows, 1.0, _p(dgx), G, _p(inp), in_size, 1.0, _p(gw_ih), in_size,
+                                                        _p(gb_ih), _lib.stream_ptr()))
                     gb_hh.copy_(gb_ih)
-                # dW_ih (both directions at once) = dgx^T inp
-                _gemm(1, 0, G, in_size, rows, _p(dgx), G, _p(inp), in_size, _p(gw_ih), in_size, beta=1.0)
+                else:
+                    _gemm(1, 0, G, in_size, rows, _p(dgx), G, _p(inp), in_size, _p(gw_ih), in_size, beta=1.0)
                 # dW_hh[d] = sum_t dg_d[t]^T h_d[t-1] (reverse direction: h_d[t+1]); time-major => row shift by B
                 if T > 1:
                     k = (T - 1) * B

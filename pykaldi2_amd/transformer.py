@@ -229,9 +229,9 @@ class _TransformerFunction(torch.autograd.Function):
         def lin_grads(dout, inp, in_dim, out_dim, wname, bname):
             def work():
                 st = _lib.stream_ptr()
-                _lib.check(L.pk2_gemm_f32(1, 0, out_dim, in_dim, R, 1.0, _p(dout), out_dim, _p(inp), in_dim, 1.0, _p(g[wname]), in_dim,
-                                          None, st))
-                _lib.check(L.pk2_colsum_f32(_p(dout), out_dim, R, out_dim, 1.0, _p(g[bname]), st))
+                # weight and bias gradient in one launch (the column sums ride in the product's operand loader)
+                _lib.check(L.pk2_gemm_f32_tn_colsum(out_dim, in_dim, R, 1.0, _p(dout), out_dim, _p(inp), in_dim, 1.0, _p(g[wname]), in_dim,
+                                                    _p(g[bname]), st))
             return on_side(work, dout, inp)
 
         lin_grads(dlogits, hn, C, P, "output_layer.weight", "output_layer.bias")
@@ -257,9 +257,10 @@ class _TransformerFunction(torch.autograd.Function):
 
                 def tn(Mo, No, Ko, A, Bm, Cm):
                     _lib.check(L.pk2_gemm_f32(1, 0, Mo, No, Ko, 1.0, A, C, Bm, C, 1.0, Cm, C, None, st))
-                _lib.check(L.pk2_colsum_f32(_p(dc), C, R, C, 1.0, _p(g[pre + "conv1d.bias"]), st))
                 dWp = torch.zeros(3, C, C, device=dev, dtype=torch.float32)
-                tn(C, C, R, _p(dc), _p(x2), _p(dWp, C * C))
+                # centre tap over all rows: its operand's column sums are the bias gradient (same launch)
+                _lib.check(L.pk2_gemm_f32_tn_colsum(C, C, R, 1.0, _p(dc), C, _p(x2), C, 1.0, _p(dWp, C * C), C,
+                                                    _p(g[pre + "conv1d.bias"]), st))
                 if T > 1:
                     tn(C, C, R - B, _p(dc, B * C), _p(x2), _p(dWp, 0))
                     tn(C, C, R - B, _p(dc), _p(x2, B * C), _p(dWp, 2 * C * C))

@@ -420,3 +420,26 @@ def test_dropout_is_an_unbiased_mask_and_backward_reuses_it():
     torch.manual_seed(7); f1 = (m(x + d) * w).sum().item()
     torch.manual_seed(7); f0 = (m(x - d) * w).sum().item()
     assert abs((f1 - f0) / 2e-2 - gx[1, 4, 3].item()) < 2e-2 * max(1.0, abs(gx[1, 4, 3].item()))
+
+
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+@pytest.mark.parametrize("M,N,K", [(6048, 1024, 2276), (512, 512, 2300), (2048, 512, 96), (130, 70, 1601), (4096, 80, 2276),
+                                   (1021, 260, 777)])
+def test_weight_and_bias_gradient_in_one_launch(M, N, K, arith, gemm_arith):
+    """pk2_gemm_f32_tn_colsum: C += A^T B and colsum += column sums of A (a Linear layer's weight and bias gradient; reference
+    models/lstm.py:59 / nn.Linear backward) against float64 -- plain tiles, K slices (deep K, few tiles), 64x64 tiles, ragged
+    edges (rows clamped in the loader must not be counted), an M that is no multiple of four (bounds-tested loader), both
+    arithmetic paths (f32: the colsum kernel behind the product)."""
+    gemm_arith(arith)
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    b0 = rng.standard_normal(M).astype(np.float32)
+    a, b, c, bs = (torch.from_numpy(v).cuda() for v in (A, B, C0.copy(), b0.copy()))
+    _lib.check(_lib.lib().pk2_gemm_f32_tn_colsum(M, N, K, 1.0, lstm._p(a), M, lstm._p(b), N, 1.0, lstm._p(c), N, lstm._p(bs),
+                                                 _lib.stream_ptr()))
+    want_c = A.T.astype(np.float64) @ B.astype(np.float64) + C0
+    want_b = A.astype(np.float64).sum(0) + b0
+    assert np.abs(c.cpu().numpy() - want_c).max() < 2e-4 * np.sqrt(K)
+    assert np.abs(bs.cpu().numpy() - want_b).max() < 2e-5 * np.sqrt(K), np.abs(bs.cpu().numpy() - want_b).max()
