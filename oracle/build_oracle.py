@@ -12,6 +12,18 @@ LIB = os.path.join(OUT, "libchain_oracle.so")
 LIB64 = os.path.join(OUT, "libchain_oracle_f64.so")      # the same recursion with double state (parity at bench size)
 
 
+LAT = os.path.join(OUT, "liblattice_oracle.so")
+
+
+def build_lattice():
+    """oracle/lattice_oracle.c: the C restatement of lattice_ref.py's decoder + lattice MMI (cpu_baseline of `bench.py --se`)."""
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(HERE, "lattice_oracle.c")
+    if not os.path.exists(LAT) or os.path.getmtime(LAT) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-march=x86-64-v2", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", LAT, "-lm"])
+    return LAT
+
+
 def build(double=False):
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(HERE, "chain_oracle.c")
@@ -23,3 +35,4 @@ def build(double=False):
 
 if __name__ == "__main__":
     print(build())
+    print(build_lattice())

@@ -181,3 +181,31 @@ def test_final_cutoff_rule_against_kaldis_serial_process_emitting(case, max_extr
         assert len(links - links0) <= max_extra * len(links0)
         like, post = lr.lattice_mmi(lat, ali, tm["tid2pdf"], P, 1.0, 0.2, False)
         assert np.abs(post - post0).max() <= max_dpost
+
+
+@pytest.mark.parametrize("kw", [dict(seed=0, T=9), dict(seed=1, T=14, beam=8.0, lattice_beam=3.0), dict(seed=2, T=11, ac=0.3),
+                                dict(seed=3, T=25, num_words=40, num_pdfs=60, max_phones=3, beam=11.0, lattice_beam=4.0, ac=0.1,
+                                     max_active=30, min_active=5),
+                                dict(seed=4, T=40, num_words=200, num_pdfs=90, max_phones=3, beam=13.0, lattice_beam=7.0, ac=0.1,
+                                     max_active=150, min_active=20)])
+def test_c_port_equals_numpy_oracle(kw):
+    """oracle/lattice_oracle.c (the cpu_baseline of `bench.py --se`) against oracle/lattice_ref.py on the same input: best
+    cost equal as float32, the same numbers of surviving tokens and kept links, MMI log-likelihood 1e-12 rel, posteriors
+    1e-12 abs -- with max_active / min_active binding, a small acoustic scale, and frames that drop_frames drops."""
+    from oracle import lattice_c
+    graph, tm, ll, opts, rng = _setup(**kw)
+    T = ll.shape[0]
+    P = ll.shape[1]
+    lat = lr.decode(graph, ll, tm["tid2pdf"], opts)
+    # a reference alignment: the transition-ids along one path of the lattice for some frames, an absent id for others
+    A = lat.arrays()
+    ref = np.zeros(T, np.int32)
+    for t in range(T):
+        em = [int(A["link_tid"][l]) for l in range(A["link_tid"].shape[0]) if A["link_tid"][l] != 0 and A["tok_frame"][A["link_src"][l]] == t]
+        ref[t] = em[int(rng.integers(len(em)))] if (em and t % 4 != 3) else 1 + int(rng.integers(len(tm["tid2pdf"]) - 1))
+    want_like, want_post = lr.lattice_mmi(lat, ref, tm["tid2pdf"], P, 1.0, 0.2, True)
+    got = lattice_c.decode_mmi(graph, ll, tm["tid2pdf"], opts, ref, P, 1.0, 0.2, True)
+    assert np.float32(got["best_cost"]) == np.float32(lat.best_cost)
+    assert got["toks"] == A["tok_state"].shape[0] and got["links"] == A["link_src"].shape[0]
+    assert abs(got["like"] - want_like) <= 1e-12 * max(1.0, abs(want_like))
+    assert np.abs(got["post"] - want_post).max() < 1e-12
