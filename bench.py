@@ -258,7 +258,7 @@ def den_roofline(den, dev, reps=5):
     # HBM bytes per call from the committed PMC passes (tools/gpu_profile.sh) of this same workload: counters cannot be
     # read live.  Only reported when the profile was taken on the same lengths and graph shape.
     traffic, traffic_note = None, "no PMC profile of this workload committed"
-    for name in ("r05_den_traffic.json", "r04_den_traffic.json"):         # the newest committed PMC passes of this workload
+    for name in ("r06_den_traffic.json", "r05_den_traffic.json", "r04_den_traffic.json"):         # the newest committed PMC passes of this workload
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 prof = json.load(f)
@@ -614,8 +614,11 @@ def ce_workload(args, dev, rank, world):
         flops = 3.0 * lstm_flops_per_frame(pdfs=PC) * BATCH * CH
         tf = flops / (ms_step * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=round(tf, 1), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), traffic=None,
-                    kernel="whole CE step (3x512 BLSTM + output layer forward + backward, f32 MFMA GEMMs pk2::gemm_f32_kernel + "
-                    "the persistent recurrences pk2::lstm_*_big_persist) over the step's wall time",
+                    gemm_arith=gemm_arith_name(), frac_of_bf16x3_peak=round(6.0 * tf / 2500.0, 4),
+                    kernel="whole CE step (3x512 BLSTM + output layer forward + backward: GEMMs pk2::gemm_f32_kernel in the arithmetic "
+                    "`gemm_arith` + the persistent recurrences pk2::lstm_*_big_persist on the f32 MFMA) over the step's wall time; "
+                    "FLOPs are f32-equivalent; peak / frac = the f32 MFMA peak (what the step is priced against since round 1), "
+                    "frac_of_bf16x3_peak = the same FLOPs against 2.5 PFLOP/s dense bf16 / 6 executed products",
                     flops_per_step=flops, ms=round(ms_step, 3),
                     input_projection_gemm=gemm_mfma_roofline(dev, BATCH * CH))
         if world == 1 and not args.no_cpu_baseline:

@@ -1,5 +1,5 @@
 """HBM traffic of one denominator call from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --den-only`:
-sums the counters over every kernel of the command and divides by the number of denominator calls (den_scales launches).
+sums the counters over every kernel of the command and divides by the number of denominator calls (launches of its tail kernel).
 Writes the JSON bench.py reads for `roofline.traffic`.  Usage: den_traffic.py fetch.db write.db den_only.json out.json"""
 import json
 import sqlite3
@@ -9,7 +9,13 @@ import sys
 def total(db, counter):
     cur = sqlite3.connect(db).cursor()
     s = cur.execute("select sum(counter_value) from pmc_events where counter_name = ?", (counter,)).fetchone()[0]
-    calls = cur.execute("select count(*) from pmc_events where counter_name = ? and name like '%den_scales%'", (counter,)).fetchone()[0]
+    # one launch of the call's tail kernel per denominator call (round 6: den_tail1; before: den_scales)
+    calls = 0
+    for pat in ("%den_tail1%", "%den_scales%"):
+        calls = cur.execute("select count(*) from pmc_events where counter_name = ? and name like ?", (counter, pat)).fetchone()[0]
+        if calls:
+            break
+    # (rocprofv3 reports one row per dispatch for the TCC-derived counters)
     return float(s), int(calls)
 
 
