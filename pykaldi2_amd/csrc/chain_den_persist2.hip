@@ -123,14 +123,21 @@ __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgk
 #define PK2_DP2_LATE_STREAM 1          // ... in the kernels with streamed pieces too
 #endif
 template <bool STREAM> constexpr bool kLateHistory = PK2_DP2_LATE_HISTORY && (!STREAM || PK2_DP2_LATE_STREAM);
+// (round 6, VERDICT r5 #2c: loads and stores switchable apart -- -DPK2_DP2_NT_LOAD=0 / -DPK2_DP2_NT_STORE=0)
+#ifndef PK2_DP2_NT_LOAD
+#define PK2_DP2_NT_LOAD PK2_DP2_NT
+#endif
+#ifndef PK2_DP2_NT_STORE
+#define PK2_DP2_NT_STORE PK2_DP2_NT
+#endif
 template <bool NT>
 __device__ __forceinline__ float once_load(cgfloat* p) {
-  if constexpr (NT && PK2_DP2_NT) return __builtin_nontemporal_load(p);
+  if constexpr (NT && PK2_DP2_NT_LOAD) return __builtin_nontemporal_load(p);
   else return *p;
 }
 template <bool NT>
 __device__ __forceinline__ void once_store(gfloat* p, float v) {
-  if constexpr (NT && PK2_DP2_NT) __builtin_nontemporal_store(v, p);
+  if constexpr (NT && PK2_DP2_NT_STORE) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
 
