@@ -63,6 +63,15 @@ def init(backend=None):
             ok = torch.tensor([1 if comm is not None else 0], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
+                # Round 6 (the grouped call of pk2_allreduce_guarded has never run on more than one rank): both
+                # entries are exercised ONCE here, on a small buffer, and checked against the closed form -- a node on which
+                # they fail or give a wrong sum falls back to torch.distributed on EVERY rank instead of failing in step 1.
+                err = _self_test_comm(comm)
+                ok = torch.tensor([1 if not err else 0], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) != 1 and not err:
+                    err = "a peer's self-test failed"
+            if int(ok.item()) == 1:
                 _state["comm"] = comm
             else:
                 if comm is not None:
@@ -100,6 +109,36 @@ def _ranks_share_a_device(local_world, devices):
     if changed and os.environ.get("RANK", "0") == "0":
         sys.stderr.write("[hvd] %d local ranks on %d device(s): ranks share a GPU, persistent kernels off (%s)\n"
                          % (local_world, devices, ", ".join(changed)))
+
+
+def _self_test_comm(comm):
+    """One pk2_allreduce_bucket and one pk2_allreduce_guarded on 4096 floats through the new communicator: '' if both
+    return rank sums / the guard maximum as they must, else what went wrong.  Never raises (every rank must reach the
+    vote that follows)."""
+    try:
+        from . import _lib
+        L = _lib.lib()
+        r, w = dist.get_rank(), dist.get_world_size()
+        st = torch.cuda.current_stream()
+        want = float(w * (w + 1) // 2)
+        for guarded in (False, True):
+            t = torch.full((4096,), float(r + 1), device="cuda")
+            slot = torch.tensor([1.0 if r == w - 1 else 0.0], device="cuda")
+            if guarded:
+                rc = L.pk2_allreduce_guarded(comm, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(slot.data_ptr()), C.c_void_p(st.cuda_stream))
+            else:
+                rc = L.pk2_allreduce_bucket(comm, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st.cuda_stream))
+            if rc != 0:
+                msg = L.pk2_last_error()
+                return "status %d: %s" % (rc, msg.decode() if msg else "")
+            torch.cuda.synchronize()
+            if not bool((t == want).all()):
+                return "%s all-reduce returned %r, expected %r" % ("guarded" if guarded else "bucket", float(t[0].item()), want)
+            if guarded and float(slot.item()) != 1.0:
+                return "guard slot maximum %r, expected 1.0" % float(slot.item())
+        return ""
+    except Exception as e:      # noqa: BLE001
+        return repr(e)[:200]
 
 
 def _create_comm():
