@@ -1107,6 +1107,27 @@ def main():
         dt, audio = float(tmax.item()), float(asum.item())
     loss_val = float(tr.last["loss"].item())
 
+    # The same timed window once more with the GEMMs on the f32 MFMA ("carries the pure-f32 number beside it"):
+    # same minibatches in the same order, same process; not part of `value`.
+    f32_window = None
+    if world == 1 and gemm_arith_name() == "bf16x3" and not args.den_states and not args.den_arcs:
+        from pykaldi2_amd import _lib
+        _lib.check(_lib.lib().pk2_gemm_set_arith(0))
+        try:
+            tr.step(batches[n_unique - 1])
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for i in range(args.steps):
+                if i + 1 < args.steps:
+                    tr.prefetch(batches[(i + 1) % n_unique])
+                tr.step(batches[i % n_unique])
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - tf0
+            f32_window = dict(arith="f32 (v_mfma_f32_32x32x2_f32)", ms_per_step=round(1e3 * dtf / args.steps, 3), value=round(audio / dtf, 2),
+                              note="the timed window repeated in the same process with PK2_GEMM_ARITH=f32 semantics (pk2_gemm_set_arith(0))")
+        finally:
+            _lib.check(_lib.lib().pk2_gemm_set_arith(1))
+
     # per-phase breakdown of one extra (untimed) step -- on EVERY rank: the step contains the gradient all-reduce
     events = []
     mb = batches[0]
@@ -1189,6 +1210,7 @@ def main():
     # the tail of the line (the driver keeps the last 2000 characters): the numbers a reader needs first
     result["n_unique_minibatches"] = n_unique
     result["gemm_arith"] = gemm_arith_name()
+    result["f32_gemm_window"] = f32_window
     result[("roofline_model" if args.transformer else "roofline_lstm") + "_frac"] = roof_lstm["frac"]
     result["roofline_frac"] = roof.get("frac")
     result["breakdown_ms"] = breakdown
