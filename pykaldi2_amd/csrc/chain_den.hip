@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(256) den_tail1(DenParams p, float* csum, float
     if (ck.ctl) {
       const unsigned ab = __hip_atomic_load(ck.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned dn = __hip_atomic_load(ck.done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_bad = (ab != 0u || dn != (unsigned)ck.ntasks) ? 1u : 0u;
+      s_bad = (ab != 0u || dn != (unsigned)ck.ntasks || ck.ntasks < 0) ? 1u : 0u;        // (ntasks < 0: test hook)
       s_last = __hip_atomic_fetch_add(ck.count_word, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
     }
   }
@@ -1700,6 +1700,8 @@ static int den_compute_t(pk2_den_graph* g, const float* logits, int64_t seq_stri
       if (merge_env && (!ran || persist_form == 2) && (size_t)(Tmax + 1) * 2 * sizeof(float) <= 60 * 1024) {
         DenTailCheck ck{};
         if (ran && !den_persist2_tail_check(stream, &ck)) ck = DenTailCheck{};
+        // (test hook, read per call: PK2_DEN_TEST_FAIL=1 makes the folded check behave as if the persistent launch had given up)
+        if (ck.ctl) { const char* tf_e = getenv("PK2_DEN_TEST_FAIL"); if (tf_e && atoi(tf_e) == 1) ck.ntasks = -1; }
         hipLaunchKernelGGL(den_tail1, dim3(G), dim3(256), (size_t)(Tmax + 1) * 2 * sizeof(float), stream, p, b.csum, b.den_lp, b.kscale,
                            b.check, ck);
         tail_merged = true;

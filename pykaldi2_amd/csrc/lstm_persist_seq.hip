@@ -933,11 +933,11 @@ __device__ __forceinline__ void seq_exit_check(SeqCtl* ctl, const SeqExit& x) {
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  const bool good = seq_load_u(&ctl->abort) == 0u && seq_load_u(&ctl->done) == x.pairs;
+  const bool good = seq_load_u(&ctl->abort) == 0u && seq_load_u(&ctl->done) == x.pairs && x.fold != 2;     // (fold = 2: test hook)
   __syncthreads();
   for (unsigned i = threadIdx.x; i < sizeof(SeqCtl) / sizeof(unsigned); i += blockDim.x) reinterpret_cast<unsigned*>(ctl)[i] = 0u;
   if (good) return;
-  if (threadIdx.x == 0) { *x.sticky = 1u; persist_guard_raise(x.guard_dev, x.guard_host); }
+  if (threadIdx.x == 0) { if (x.fold != 2) *x.sticky = 1u; persist_guard_raise(x.guard_dev, x.guard_host); }
   for (size_t i = threadIdx.x; i < x.n; i += blockDim.x) x.out[i] = __uint_as_float(0x7fc00000u);
   for (size_t i = threadIdx.x; i < x.mail_n; i += blockDim.x) x.mail[i] = __uint_as_float(kSeqSentinel);
 }
@@ -1023,7 +1023,10 @@ int lstm_fwd_seq_launch(const float* gx, const float* whh, const float* bhh, int
   SeqFwdParams p{gx, whh, bhh, y, gates, cells, B, T, D, pre, lps, smode};
   static const bool fold_env = [] { const char* e = getenv("PK2_LSTM_SEQ_FOLD_CHECK"); return !(e && atoi(e) == 0); }();
   const bool fold = fold_env && seq_form() != 1 && g_seq_state_pd.ref() == 1;
-  const SeqExit ex{(unsigned)(B * D), fold ? 1 : 0, y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev, nullptr, (size_t)0};
+  // (test hook, read per call: PK2_LSTM_SEQ_TEST_FAIL=1 makes the folded check of a forward launch behave as if a poll had timed out)
+  const char* tf_e = getenv("PK2_LSTM_SEQ_TEST_FAIL");
+  const int fold_mode = fold ? ((tf_e && atoi(tf_e) == 1) ? 2 : 1) : 0;
+  const SeqExit ex{(unsigned)(B * D), fold_mode, y, (size_t)T * B * D * H, sc->sticky, sc->guard.dev, sc->guard.host_dev, nullptr, (size_t)0};
   if (seq_form() == 1) hipLaunchKernelGGL(lstm_fwd_seq, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl);
   else hipLaunchKernelGGL(lstm_fwd_seq2, dim3(8 * kSWgs * seq_teams(B * D)), dim3(256), 0, stream, p, sc->ctl, ex);
   PK2_LAUNCH_CHECK();

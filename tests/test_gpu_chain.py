@@ -502,3 +502,31 @@ def test_bench_size_long_sequences_with_peaked_logits_match_c_oracle():
         assert err < 1e-4, (n, err)
         assert abs(gamma[n, :Tn].sum() - Tn) < 1e-3 * Tn          # occupancies of a frame sum to one
         assert not gamma[n, Tn:].any()
+
+
+def test_check_inside_the_denominator_tail_poisons_and_raises_the_guard(monkeypatch):
+    """Round 6: the persistent denominator's verdict is read by den_tail1 (no check kernel of its own).  PK2_DEN_TEST_FAIL=1
+    makes it "the launch gave up": every log-prob must come back NaN with the per-device guard up; lowered, the next call
+    runs clean from the control block the tail left zeroed."""
+    from pykaldi2_amd import _lib
+    P = 6048
+    g = synth.den_graph_arcs(30000, 1000000, P, seed=0, loop_pdf_differs=True)
+    G = chain.DenominatorGraph(g, P)
+    lens = [33, 21, 40, 17]
+    assert G.kernel_path(len(lens)) == 2
+    x = torch.from_numpy(np.random.default_rng(3).normal(0, 2, size=(4, 40, P)).astype(np.float32)).cuda()
+    lp0, gamma0 = chain.den_forward_backward(G, x, lens, 1e-4)
+    lp0, gamma0 = chain.den_forward_backward(G, x, lens, 1e-4)       # (the first call of a process verifies on the host)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lp0).all()) and not _lib.persist_guard_raised()
+    try:
+        monkeypatch.setenv("PK2_DEN_TEST_FAIL", "1")
+        lp1, _ = chain.den_forward_backward(G, x, lens, 1e-4)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("PK2_DEN_TEST_FAIL")
+        assert bool(torch.isnan(lp1).all()) and _lib.persist_guard_raised()
+    finally:
+        _lib.check(_lib.lib().pk2_persist_guard_clear())
+    lp2, gamma2 = chain.den_forward_backward(G, x, lens, 1e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(lp2, lp0) and torch.equal(gamma2, gamma0) and not _lib.persist_guard_raised()

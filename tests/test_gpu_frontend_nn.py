@@ -443,3 +443,34 @@ def test_weight_and_bias_gradient_in_one_launch(M, N, K, arith, gemm_arith):
     want_b = A.astype(np.float64).sum(0) + b0
     assert np.abs(c.cpu().numpy() - want_c).max() < 2e-4 * np.sqrt(K)
     assert np.abs(bs.cpu().numpy() - want_b).max() < 2e-5 * np.sqrt(K), np.abs(bs.cpu().numpy() - want_b).max()
+
+
+def test_check_inside_the_recurrence_launch_poisons_and_raises_the_guard(monkeypatch):
+    """Round 6: the verdict of a one-launch recurrence is taken by its LAST workgroup to leave (no check kernel behind it).
+    PK2_LSTM_SEQ_TEST_FAIL=1 makes that verdict "a poll timed out": the layer's output must come back as NaN, the per-device
+    guard must be up, and -- once it is lowered -- the next launch must run clean from the control block the failed one
+    left zeroed."""
+    L = _lib.lib()
+    T, B, H, D = 37, 4, 512, 2
+    torch.manual_seed(0)
+    gx = (torch.randn(T, B, D * 4 * H, device="cuda") * 0.1)
+    whh = torch.randn(D, 4 * H, H, device="cuda") * 0.04
+
+    def run():
+        y = torch.empty(T, B, D * H, device="cuda"); gates = torch.empty(D, T, B, 4 * H, device="cuda"); cells = torch.empty(D, T, B, H, device="cuda")
+        _lib.check(L.pk2_lstm_layer_fwd(_lib.ptr(gx), _lib.ptr(whh), None, B, T, H, D, _lib.ptr(y), _lib.ptr(gates), _lib.ptr(cells), None,
+                                        _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return y
+    good = run()                     # (the first launch of a process is verified on the host; the second one folds its check)
+    good = run()
+    assert bool(torch.isfinite(good).all()) and not _lib.persist_guard_raised()
+    try:
+        monkeypatch.setenv("PK2_LSTM_SEQ_TEST_FAIL", "1")
+        bad = run()
+        monkeypatch.delenv("PK2_LSTM_SEQ_TEST_FAIL")
+        assert bool(torch.isnan(bad).all()) and _lib.persist_guard_raised()
+    finally:
+        _lib.check(L.pk2_persist_guard_clear())
+    again = run()
+    assert torch.equal(again, good) and not _lib.persist_guard_raised()
