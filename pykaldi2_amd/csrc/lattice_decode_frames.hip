@@ -390,8 +390,30 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodePar
 }
 
 // ---- arc work list of the surviving tokens, arc costs, best new cost ----
-__device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_base) {
-  if (!c.live || c.t < 0) return;
+// Round 6 (persistent decoder): what the list phase does that does NOT depend on the frame's cutoff -- the log-likelihood row
+// into LDS, the sparse reset of the state table for the workgroup's slice of the old frame -- runs on ranks `first`.. while
+// rank 0 selects the cutoff (7 us during which the other 15 workgroups used to wait at the barrier); rank 0 then takes no
+// slice of the list phase.  `first` = 0, `pre` = false: the launch-per-frame kernels' behaviour.
+__device__ __forceinline__ void phase_list_pre(const DecodeParams& p, const TeamCtx& c, Shared& sh, int first) {
+  if (!c.live || c.t < 0 || c.wg < first) return;
+  const int tid = threadIdx.x;
+  const UttView& V = c.V;
+  LatFrame* F = c.F;
+  const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
+  for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
+  const int f0 = F->f0, f1 = F->f1, nr = c.G - first;
+  const int per = (f1 - f0 + nr - 1) / nr;
+  const int s0 = f0 + (c.wg - first) * per, s1 = min(s0 + per, f1);
+  for (int i = s0 + tid; i < s1; i += kLatThreads) {
+    const int st = V.ts[i];
+    V.stc[st] = kEmpty;
+    V.stt[st] = -1;
+  }
+}
+
+__device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_base, int first = 0,
+                                           bool pre = false) {
+  if (!c.live || c.t < 0 || c.wg < first) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
   LatFrame* F = c.F;
@@ -400,14 +422,17 @@ __device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx&
   const float cur_cutoff = F->cur_cutoff;
   // the frame's log-likelihood row staged in LDS (reading it per arc from L2 puts one more dependent round trip
   // into the cost pass: measured +6 us per launch)
-  const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
-  for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
+  if (!pre) {
+    const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
+    for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
+  }
   float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
   float nmin = INFINITY;
-  // the frame's tokens are cut into G equal slices (a frame has a few thousand tokens: dealing them in chunks of
+  // the frame's tokens are cut into equal slices (a frame has a few thousand tokens: dealing them in chunks of
   // 4096 would leave most of the team without work and put several dependent passes of the cost loop on the rest)
-  const int per = (f1 - f0 + c.G - 1) / c.G;
-  const int s0 = f0 + c.wg * per, s1 = min(s0 + per, f1);
+  const int nr = c.G - first;
+  const int per = (f1 - f0 + nr - 1) / nr;
+  const int s0 = f0 + (c.wg - first) * per, s1 = min(s0 + per, f1);
   for (int base = s0; base < s1; base += 4 * kLatThreads) {
     int2 ar[4];
     int mine = 0;
@@ -419,9 +444,11 @@ __device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx&
         if (tc[i] <= cur_cutoff) ar[q] = V.tarc[i];
         // sparse reset of the state table: every token of the old frame passes here once, and nothing reads the
         // table between the launch that closed the frame and the next expand
-        const int st = V.ts[i];
-        V.stc[st] = kEmpty;
-        V.stt[st] = -1;
+        if (!pre) {
+          const int st = V.ts[i];
+          V.stc[st] = kEmpty;
+          V.stt[st] = -1;
+        }
       }
       mine += ar[q].y;
     }
@@ -785,6 +812,10 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
   if (s_i[1] >= teams_per_xcd) return;                     // (whole teams only; the host sizes them for 32 CUs per XCD)
   LatTeamCtl::Team* tm = &ctl->team[s_i[2]][s_i[1]];
   unsigned nbar = 0;
+#ifndef PK2_LAT_LIST_PRE
+#define PK2_LAT_LIST_PRE 1
+#endif
+  const int list_first = (PK2_LAT_LIST_PRE && G > 2) ? 1 : 0;      // ranks that take slices of the list phase: list_first .. G - 1
 #ifdef PK2_LATP_PROFILE
   long long lp_acc[16], lp_last = 0; int lp_frames = 0;
   for (int k = 0; k < 16; ++k) lp_acc[k] = 0;
@@ -826,10 +857,11 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
         // (nobody writes the status between the barrier that closed the previous frame and the one behind the cutoff)
         if (ld_coherent(&F->status) != kLatOk) break;
         if (rank == 0) phase_cutoff(p, c, sh);
+        else if (list_first) phase_list_pre(p, c, sh, list_first);
         LP_T(0);
         if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
         LP_T(1);
-        phase_list(p, c, sh, s_base);
+        phase_list(p, c, sh, s_base, list_first, list_first != 0);
         LP_T(2);
         if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
         LP_T(3);
