@@ -494,8 +494,23 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_list(const DecodeParam
   phase_list(p, team_ctx(p, cnt, local), sh, s_base);
 }
 
+// The bookkeeping behind a phase, done by ONE thread once every workgroup of the team has finished the phase: in the
+// launch-per-frame kernels by the last workgroup to arrive (team_last: an atomic round trip at the end of the launch), in the
+// persistent kernel INSIDE the team barrier by its last arriver (round 6: lat_team_barrier_last -- one round trip instead of
+// two on every phase boundary).
+__device__ __forceinline__ unsigned expand_last(const TeamCtx& c) {
+  LatFrame* F = c.F;
+  if (!c.live || c.t < 0) return 0u;
+  const float nmin = dec_cost(F->nmin_key);
+  if (!(nmin < INFINITY)) return 0u;
+  F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
+  F->build_cutoff = nmin + F->adaptive;
+  return 0u;
+}
+
 // ---- tokens and emitting links of frame t+1 ----
-__device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCtx& c, int& s_flag) {
+__device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCtx& c, int& s_flag, bool defer = false) {
   if (!c.live || c.t < 0) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -582,19 +597,35 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
       ++li;
     }
   }
-  if (team_last(F, c.G, &s_flag) && tid == 0) {
-    F->ne_snap = min(ld_coherent(&F->n_elist), V.tok_cap);
-    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
-    F->build_cutoff = next_cutoff;
-  }
+  if (!defer && team_last(F, c.G, &s_flag) && tid == 0) expand_last(c);
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodeParams p, const StepCounter* cnt, int local) {
   __shared__ int s_flag;
   phase_expand(p, team_ctx(p, cnt, local), s_flag);
 }
 
+// (round0_last / round_last return the round's "a cost was lowered" flag, close_last "the utterance's status is not ok")
+__device__ __forceinline__ unsigned round0_last(const TeamCtx& c) {
+  LatFrame* F = c.F;
+  if (!c.live) return 0u;
+  const int l0 = F->link_end, nl = min(ld_coherent(&F->n_link), c.V.link_cap - l0);
+  F->link_end = l0 + nl;
+  c.V.seg[2 * c.t + 2] = l0 + nl;
+  st_coherent(&F->n_link, 0);
+  F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
+  return (unsigned)(ld_coherent(&F->changed[0]) != 0);
+}
+__device__ __forceinline__ unsigned round_last(const TeamCtx& c, int r) {
+  LatFrame* F = c.F;
+  if (!c.live) return 0u;
+  F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
+  return (unsigned)(ld_coherent(&F->changed[r]) != 0);
+}
+
 // ---- link destinations (state -> token index), epsilon relaxation round 0 ----
-__device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag) {
+__device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, bool defer = false) {
   if (!c.live) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -605,13 +636,7 @@ __device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCt
   __syncthreads();
   const int changed = eps_round(p, V, F, sh, fb, F->build_cutoff, F->ne_snap, F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[0], 1);
-  if (team_last(F, c.G, &s_flag) && tid == 0) {
-    F->link_end = l0 + nl;
-    V.seg[2 * c.t + 2] = l0 + nl;
-    st_coherent(&F->n_link, 0);
-    F->ne_snap = min(ld_coherent(&F->n_elist), V.tok_cap);
-    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
-  }
+  if (!defer && team_last(F, c.G, &s_flag) && tid == 0) round0_last(c);
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_round0(const DecodeParams p, const StepCounter* cnt, int local) {
   __shared__ Shared sh;
@@ -620,19 +645,16 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_round0(const DecodePar
 }
 
 // ---- epsilon relaxation round r >= 1 ----
-__device__ __forceinline__ void phase_round(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, int r) {
+__device__ __forceinline__ void phase_round(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, int r, bool defer = false) {
   if (!c.live) return;
   LatFrame* F = c.F;
-  if (!F->changed[r - 1]) return;
+  if (!defer && !F->changed[r - 1]) return;          // (the persistent kernel has the flag from the barrier's release word)
   const int tid = threadIdx.x;
   if (tid == 0) sh.n_heavy = 0;
   __syncthreads();
   const int changed = eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, F->ne_snap, F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[r], 1);
-  if (team_last(F, c.G, &s_flag) && tid == 0) {
-    F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
-    F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
-  }
+  if (!defer && team_last(F, c.G, &s_flag) && tid == 0) round_last(c, r);
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_round(const DecodeParams p, const StepCounter* cnt, int local, int r) {
   __shared__ Shared sh;
@@ -667,7 +689,24 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_tail(const DecodeParam
 }
 
 // ---- the frame is closed: epsilon links from the final costs, final token costs, arc ranges, best cost ----
-__device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag) {
+__device__ __forceinline__ unsigned close_last(const TeamCtx& c) {
+  LatFrame* F = c.F;
+  if (!c.live) return 1u;
+  const UttView& V = c.V;
+  const int fb = F->f1, cnt_new = min(ld_coherent(&F->n_new), V.tok_cap - fb);
+  const int tok_end = fb + cnt_new;
+  const int link_end = min(F->link_end + ld_coherent(&F->n_link), V.link_cap);
+  V.seg[2 * c.t + 3] = link_end;
+  V.ftok[c.t + 2] = tok_end;
+  F->f0 = fb; F->f1 = tok_end; F->link_end = link_end;
+  F->best_key = ld_coherent(&F->best_next);
+  st_coherent(&F->best_next, kEmpty);
+  st_coherent(&F->n_new, 0); st_coherent(&F->n_link, 0); st_coherent(&F->n_elist, 0); st_coherent(&F->n_hlist, 0);
+  F->ne_snap = 0; F->nh_snap = 0;
+  for (int r = 0; r <= kLatEpsRounds; ++r) st_coherent(&F->changed[r], 0);
+  return (unsigned)(ld_coherent(&F->status) != kLatOk);
+}
+__device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, bool defer = false) {
   if (!c.live) return;
   const int tid = threadIdx.x;
   const UttView& V = c.V;
@@ -717,18 +756,7 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
   if ((tid & 63) == 0 && kmin != kEmpty) atomicMin(&F->best_next, kmin);
-  if (team_last(F, c.G, &s_flag) && tid == 0) {
-    const int tok_end = fb + cnt_new;
-    const int link_end = min(F->link_end + ld_coherent(&F->n_link), V.link_cap);
-    V.seg[2 * c.t + 3] = link_end;
-    V.ftok[c.t + 2] = tok_end;
-    F->f0 = fb; F->f1 = tok_end; F->link_end = link_end;
-    F->best_key = ld_coherent(&F->best_next);
-    st_coherent(&F->best_next, kEmpty);
-    st_coherent(&F->n_new, 0); st_coherent(&F->n_link, 0); st_coherent(&F->n_elist, 0); st_coherent(&F->n_hlist, 0);
-    F->ne_snap = 0; F->nh_snap = 0;
-    for (int r = 0; r <= kLatEpsRounds; ++r) st_coherent(&F->changed[r], 0);
-  }
+  if (!defer && team_last(F, c.G, &s_flag) && tid == 0) close_last(c);
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodeParams p, const StepCounter* cnt, int local) {
   __shared__ Shared sh;
@@ -755,8 +783,11 @@ constexpr long long kLatSpinTicks = 1000LL * 1000 * 100;     // 1 s of the 100 M
 struct LatTeamCtl {
   unsigned arrive[8];
   unsigned next_utt, abort, done, pad[5];
-  struct Team { unsigned task[kLatMaxIter + 1]; unsigned bar; unsigned pad[62]; } team[8][kLatTeamsPerXcd];
+  // bar: arrivals (monotonic); rel: the release word of lat_team_barrier_last on a cache line of its own -- barrier number in
+  // the low half, the last arriver's payload (a flag the next phase branches on) in the high half
+  struct Team { unsigned task[kLatMaxIter + 1]; unsigned bar; unsigned pad[30]; unsigned long long rel; unsigned pad2[30]; } team[8][kLatTeamsPerXcd];
 };
+static_assert(sizeof(LatTeamCtl::Team) == 512 && offsetof(LatTeamCtl::Team, rel) == 384, "team record: 512 bytes, release word on its own line");
 
 struct LatSpin {
   LatTeamCtl* ctl; long long t0; unsigned n;
@@ -795,9 +826,47 @@ __device__ __forceinline__ bool lat_team_barrier(LatTeamCtl* ctl, LatTeamCtl::Te
   return *s_abort == 0;
 }
 
+// The team barrier whose LAST arriver runs `last_fn` (one thread) before it releases the others: arrival = a returning
+// atomic on the team's monotonic counter, release = a second monotonic word the others poll.  Every workgroup has waited for
+// its own stores and atomics (vmcnt) before it arrives, so the last arriver sees the phase's final counters in L2; its
+// bookkeeping stores are acknowledged before the release word goes out.  `last_fn` returns a payload that travels IN the
+// release word (the flag the next phase branches on: "did the round lower a cost", "is the utterance's status still ok"),
+// which saves every workgroup the dependent load of that flag behind the barrier; *payload holds it on return.
+template <class F_>
+__device__ __forceinline__ bool lat_team_barrier_last(LatTeamCtl* ctl, LatTeamCtl::Team* tm, int G, unsigned* nbar, int* s_abort,
+                                                      unsigned* s_pay, int inv_mode, unsigned* payload, F_ last_fn) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned gen = ++*nbar, target = (unsigned)G * gen;
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&tm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == target) {
+        const unsigned pay = last_fn();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        st_coherent(&tm->rel, ((unsigned long long)pay << 32) | gen);
+        *s_pay = pay;
+      } else {
+        LatSpin spin(ctl);
+        unsigned long long w;
+        while ((unsigned)(w = ld_coherent(&tm->rel)) < gen) {
+          if (spin.expired()) { *s_abort = 1; break; }
+        }
+        *s_pay = (unsigned)(w >> 32);
+      }
+    }
+    if (inv_mode == 1) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (inv_mode == 0) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  *payload = *s_pay;
+  return *s_abort == 0;
+}
+
 __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodeParams p, LatTeamCtl* ctl, int N, int G, int teams_per_xcd, int inv_mode) {
   __shared__ Shared sh;
   __shared__ int s_flag, s_base, s_abort, s_i[4];
+  __shared__ unsigned s_pay;
   const int tid = threadIdx.x;
   if (tid == 0) {
     unsigned xcd;
@@ -816,6 +885,10 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
 #define PK2_LAT_LIST_PRE 1
 #endif
   const int list_first = (PK2_LAT_LIST_PRE && G > 2) ? 1 : 0;      // ranks that take slices of the list phase: list_first .. G - 1
+#ifndef PK2_LAT_MERGE_LAST
+#define PK2_LAT_MERGE_LAST 1
+#endif
+  constexpr bool kMergeLast = PK2_LAT_MERGE_LAST != 0;
 #ifdef PK2_LATP_PROFILE
   long long lp_acc[16], lp_last = 0; int lp_frames = 0;
   for (int k = 0; k < 16; ++k) lp_acc[k] = 0;
@@ -848,6 +921,15 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
     TeamCtx c = team_ctx_of(p, n, rank, G, -1);            // (the utterance's record and views: once, not per frame)
     const int T = c.T;
     LatFrame* F = c.F;
+    // Barriers behind a phase with bookkeeping: merged form (the last arriver does the bookkeeping and hands the flag the
+    // next phase branches on to everybody inside the release word) or, -DPK2_LAT_MERGE_LAST=0, round 5's form (team_last
+    // inside the phase, plain barrier, every workgroup loads the flag).
+    unsigned pay = 0u, status_bad = 0u;
+#define LAT_BARRIER_LAST(FN)                                                                                           \
+    do {                                                                                                                \
+      if (kMergeLast) { if (!lat_team_barrier_last(ctl, tm, G, &nbar, &s_abort, &s_pay, inv_mode, &pay, [&] { return FN; })) return; } \
+      else if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;                                       \
+    } while (0)
     for (int t = -1; t < T; ++t) {
       c.t = t;
 #ifdef PK2_LATP_PROFILE
@@ -855,7 +937,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
 #endif
       if (t >= 0) {
         // (nobody writes the status between the barrier that closed the previous frame and the one behind the cutoff)
-        if (ld_coherent(&F->status) != kLatOk) break;
+        if (kMergeLast ? status_bad != 0u : ld_coherent(&F->status) != kLatOk) break;
         if (rank == 0) phase_cutoff(p, c, sh);
         else if (list_first) phase_list_pre(p, c, sh, list_first);
         LP_T(0);
@@ -865,40 +947,46 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
         LP_T(2);
         if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
         LP_T(3);
-        phase_expand(p, c, s_flag);
+        phase_expand(p, c, s_flag, kMergeLast);
         LP_T(4);
-        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LAT_BARRIER_LAST(expand_last(c));
         LP_T(5);
       }
-      phase_round0(p, c, sh, s_flag);
+      phase_round0(p, c, sh, s_flag, kMergeLast);
       LP_T(6);
-      if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+      LAT_BARRIER_LAST(round0_last(c));
       LP_T(7);
-      for (int r = 1; r <= kLatEpsRounds; ++r) {
-        if (!ld_coherent(&F->changed[r - 1])) break;       // (later rounds find their flag clear as well)
-        phase_round(p, c, sh, s_flag, r);
+      // a round that lowered nothing ends the fixed point (the flags of later rounds stay clear); after the last round the
+      // flag says whether the serial tail has to finish it
+      bool more = kMergeLast ? pay != 0u : ld_coherent(&F->changed[0]) != 0;
+      int r = 1;
+      for (; r <= kLatEpsRounds && more; ++r) {
+        phase_round(p, c, sh, s_flag, r, kMergeLast);
         LP_T(8);
-        if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+        LAT_BARRIER_LAST(round_last(c, r));
         LP_T(9);
+        more = kMergeLast ? pay != 0u : ld_coherent(&F->changed[r]) != 0;
       }
-      if (ld_coherent(&F->changed[kLatEpsRounds])) {
+      if (more) {                                           // (all rounds ran and the last one still lowered a cost)
         if (rank == 0) phase_tail(p, c, sh);
         LP_T(10);
         if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
         LP_T(11);
       }
-      phase_close(p, c, sh, s_flag);
+      phase_close(p, c, sh, s_flag, kMergeLast);
       LP_T(12);
-      if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
+      LAT_BARRIER_LAST(close_last(c));
+      status_bad = pay;
       LP_T(13);
     }
+#undef LAT_BARRIER_LAST
 #ifdef PK2_LATP_PROFILE
     if (tid == 0 && rank == 0 && n == 0)
       printf("kth_below, 10 ns ticks per frame: zero hist %lld | pass 1 %lld | scan %lld | pass 2 %lld | rank %lld\n", g_cut[0] / lp_frames,
              g_cut[1] / lp_frames, g_cut[2] / lp_frames, g_cut[3] / lp_frames, g_cut[4] / lp_frames);
-    if (tid == 0 && rank < 2 && n == 0)
-      printf("lat_frames_persist rank %d utt 0, %d frames, 10 ns ticks per frame: cutoff %lld bar %lld | list %lld bar %lld | expand %lld bar %lld | round0 %lld bar %lld | rounds %lld bar %lld | tail %lld bar %lld | close %lld bar %lld\n",
-             rank, lp_frames, lp_acc[0] / lp_frames, lp_acc[1] / lp_frames, lp_acc[2] / lp_frames, lp_acc[3] / lp_frames, lp_acc[4] / lp_frames,
+    if (tid == 0 && (rank < 2 && n == 0 || rank == 1))
+      printf("lat_frames_persist rank %d utt %d, %d frames, 10 ns ticks per frame: cutoff %lld bar %lld | list %lld bar %lld | expand %lld bar %lld | round0 %lld bar %lld | rounds %lld bar %lld | tail %lld bar %lld | close %lld bar %lld\n",
+             rank, n, lp_frames, lp_acc[0] / lp_frames, lp_acc[1] / lp_frames, lp_acc[2] / lp_frames, lp_acc[3] / lp_frames, lp_acc[4] / lp_frames,
              lp_acc[5] / lp_frames, lp_acc[6] / lp_frames, lp_acc[7] / lp_frames, lp_acc[8] / lp_frames, lp_acc[9] / lp_frames, lp_acc[10] / lp_frames,
              lp_acc[11] / lp_frames, lp_acc[12] / lp_frames, lp_acc[13] / lp_frames);
 #endif
