@@ -14,6 +14,18 @@ constexpr int kLatThreads = 1024;
 constexpr int kLatWaves = kLatThreads / 64;
 constexpr int kMaxPdfsLds = 8192;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+// The thread's index.  The team decoder's persistent kernel (PK2_LAT_OPAQUE_TID) takes it through an opaque asm at every use:
+// the compiler otherwise hoists every f(thread index) of every phase out of the frame loop -- shifts, masks, per-thread
+// addresses -- keeps them alive across all phases and spills them (1024 threads: 128 registers each); a reload from scratch
+// behind an L1 invalidation is a round trip to L2.
+__device__ __forceinline__ int lat_tid() {
+  int t = (int)threadIdx.x;
+#ifdef PK2_LAT_OPAQUE_TID
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
+
 constexpr int kMaxEpsRounds = 256;
 constexpr int kHeavyDegree = 48;   // states with more arcs than this (word-loop / silence states: 10^4 and more)
 constexpr int kMaxHeavy = 2048;    // are deferred and expanded by all 1024 threads, an arc per thread
@@ -40,7 +52,7 @@ struct DecodeParams {
 };
 
 #ifdef PK2_LAT_PROFILE
-#define LAT_T(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long now_ = wall_clock64(); sh.prof[k] += now_ - sh.prof_last; sh.prof_last = now_; } } while (0)
+#define LAT_T(k) do { __syncthreads(); if (lat_tid() == 0) { const long long now_ = wall_clock64(); sh.prof[k] += now_ - sh.prof_last; sh.prof_last = now_; } } while (0)
 #else
 #define LAT_T(k) do { } while (0)
 #endif
@@ -67,7 +79,7 @@ __device__ __forceinline__ float block_min(float v, Shared& sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
+  if ((lat_tid() & 63) == 0) sh.redf[lat_tid() >> 6] = v;
   __syncthreads();
   float r = sh.redf[0];
 #pragma unroll
@@ -78,7 +90,7 @@ __device__ __forceinline__ int block_sum_i(int v, Shared& sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh.redi[threadIdx.x >> 6] = v;
+  if ((lat_tid() & 63) == 0) sh.redi[lat_tid() >> 6] = v;
   __syncthreads();
   int r = 0;
 #pragma unroll
@@ -88,7 +100,7 @@ __device__ __forceinline__ int block_sum_i(int v, Shared& sh) {
 
 // k-th smallest (0-based) of cost[0..n): radix select on the order-preserving keys, 11 + 11 + 10 bits.
 __device__ float kth_smallest(const float* cost, int n, int k, Shared& sh) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   uint32_t prefix = 0, mask = 0;
   const int shifts[3] = {21, 10, 0};
   const int bits[3] = {11, 11, 10};
@@ -136,7 +148,7 @@ __device__ float kth_smallest(const float* cost, int n, int k, Shared& sh) {
 // [lo, hi) (the token costs of a frame share their exponent, so the radix select's first pass would pile every
 // key into a few LDS counters), then the exact radix select among the members of the selected bin.
 __device__ float kth_smallest_in_range(const float* cost, int n, int k, float lo, float hi, Shared& sh) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const float scale = 2047.0f / (hi - lo);
   auto bin_of = [&](float c) { return c >= hi ? 2047 : min(2046, (int)((c - lo) * scale)); };
   for (int i = tid; i < 2048; i += kLatThreads) sh.hist[i] = 0;
@@ -221,7 +233,7 @@ template <typename Active, typename Body>
 __device__ __forceinline__ void for_each_arc(Shared& sh, const int32_t* list, int n_list, const int32_t* ts,
                                              const int32_t* off, Active active, Body body, int first = -1,
                                              int stride = kLatThreads) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   for (int j = first < 0 ? tid : first; j < n_list; j += stride) {
     const int i = list[j];
     float c;
@@ -299,7 +311,7 @@ __device__ __forceinline__ void register_token(const DecodeParams& p, const UttV
 // reset of the state table.  On entry sh.n_new tokens exist with their costs in the table.
 __device__ void close_frame(const DecodeParams& p, const UttView& V, Shared& sh, int f0, float cutoff, int* link_end,
                             int* tok_end, int seg_index) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const uint32_t kcut = enc_cost(cutoff);
   int rounds = 0;
   while (true) {
@@ -386,7 +398,7 @@ __device__ void close_frame(const DecodeParams& p, const UttView& V, Shared& sh,
 
 // Exclusive prefix over the workgroup of one int per thread; *total receives the sum.
 __device__ __forceinline__ int block_exclusive_scan(int v, Shared& sh, int* total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = lat_tid() & 63, w = lat_tid() >> 6;
   int incl = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -412,7 +424,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, Shared& sh, int* tota
 template <typename Keep>
 __device__ int compact_links(const UttView& V, Shared& sh, int l0, int l1, float ac_mul, Keep keep) {
   constexpr int KPT = 4;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   int out = l0;
   for (int base = l0; base < l1; base += KPT * kLatThreads) {
     int4 r[KPT]; float a[KPT]; bool k[KPT];
@@ -447,7 +459,7 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((lat_tid() & 63) == 0) red[lat_tid() >> 6] = v;
   __syncthreads();
   float r = red[0];
 #pragma unroll
@@ -458,7 +470,7 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 // ---- final costs (ComputeFinalCosts): extra costs of the last frame's tokens; `red` = kLatWaves floats of LDS ----
 __device__ void final_costs(const DecodeParams& p, const UttView& V, float* red, int T, int s_tok_end, int* any_final,
                             float* best) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   int32_t* ts = V.ts; float* tc = V.tc; float* te = V.te; float* tf = V.tf;
   const int fT0 = V.ftok[T], fT1 = s_tok_end;
   int anyf = 0;
@@ -482,7 +494,7 @@ __device__ void final_costs(const DecodeParams& p, const UttView& V, float* red,
 
 // ---- lattice-beam pruning, last frame first (PruneForwardLinksFinal / PruneForwardLinks), everything in global memory ----
 __device__ void extra_costs_global(const DecodeParams& p, const UttView& V, int T) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   float* tc = V.tc;
   int32_t* seg = V.seg;
   int4* lrec = V.lrec;
@@ -536,7 +548,7 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
   int anyf; float best_final;
   final_costs(p, V, sh.redf, T, s_tok_end, &anyf, &best_final);
   extra_costs_global(p, V, T);
-  if (threadIdx.x == 0) {
+  if (lat_tid() == 0) {
     LatUtt* o = p.L.utt + n;
     o->status = kLatOk; o->n_tok = s_tok_end; o->n_link = s_link_end; o->any_final = anyf; o->best_cost = best_final;
   }
@@ -546,7 +558,7 @@ __device__ void finish_and_prune(const DecodeParams& p, const UttView& V, Shared
 // from the kept emitting links) and computes the depth of the epsilon DAG inside each frame, for the frames
 // first, first + stride, ...: independent per frame once finish_and_prune has fixed the extra costs.
 __device__ void prune_segments(const DecodeParams& p, const UttView& V, Shared& sh, int T, int first, int stride) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const float* tc = V.tc;
   const uint32_t* teu = reinterpret_cast<const uint32_t*>(V.te);
   const int32_t* seg = V.seg;

@@ -27,6 +27,9 @@
 // Final costs and lattice pruning: one workgroup per utterance (lat_frames_finish below, extra costs in LDS).
 #include <map>
 
+#ifndef PK2_LAT_PLAIN_TID
+#define PK2_LAT_OPAQUE_TID 1
+#endif
 #include "lattice_decode_common.h"
 #include "persist_guard.h"
 #include "step_graph.h"
@@ -37,11 +40,28 @@ template <typename T>
 __device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 
+// The hot fields of the frame record as every workgroup of a PERSISTENT team holds them in its LDS (round 6): they are
+// handed over inside the release words of the team barriers (lat_team_barrier_hand) or follow from values every workgroup
+// already has, so a phase starts with its first data loads instead of a dependent round trip to the record in L2, and the
+// barrier's last arriver releases the team without waiting for bookkeeping stores.  The launch-per-frame kernels (hot ==
+// nullptr) read and write the record as before.
+struct Hot {
+  int f0, f1, l0;              // tokens [f0, f1) of the frame being expanded; links of all closed segments at the frame's start
+  uint32_t best_key;
+  float cur_cutoff, adaptive, build_cutoff;
+  int n_arcs; uint32_t nmin_key;
+  int n_link;                  // emitting links of the frame (raw counter behind expand)
+  int ne, nh, n_new;           // raw counters behind the last relaxation round: epsilon list, heavy list, new tokens
+  int more, status_bad;        // the last round lowered a cost; the utterance's status is no longer ok
+  const float* ll_base; int64_t ll_stride;
+};
+
 struct TeamCtx {
   UttView V;
   LatFrame* F;
   int n, wg, G, t, T;
   bool live;
+  const Hot* hot = nullptr;
 };
 
 // Common prologue: frame index t = base + local - 1 (step 0 is InitDecoding's closure, "frame -1").
@@ -74,7 +94,7 @@ __device__ __forceinline__ TeamCtx team_ctx_of(const DecodeParams& p, int n, int
 // workgroup barrier.
 __device__ __forceinline__ bool team_last(LatFrame* F, int G, int* s_flag) {
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (lat_tid() == 0) {
     const int old = atomicAdd(&F->arrive, 1);
     *s_flag = old == G - 1;
     if (old == G - 1) st_coherent(&F->arrive, 0);
@@ -90,7 +110,7 @@ __device__ __forceinline__ bool team_last(LatFrame* F, int G, int* s_flag) {
 __device__ __forceinline__ int wave_alloc(int32_t* counter, bool want) {
   const unsigned long long mask = __ballot(want);
   if (!want) return -1;
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+  const int lane = lat_tid() & 63, leader = __ffsll((long long)mask) - 1;
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, __popcll(mask));
   base = __shfl(base, leader, 64);
@@ -99,7 +119,7 @@ __device__ __forceinline__ int wave_alloc(int32_t* counter, bool want) {
 
 // Same for a run of `count` slots per lane; every lane of the wave must be active.  Returns the lane's first slot.
 __device__ __forceinline__ int wave_alloc_n(int32_t* counter, int count) {
-  const int lane = threadIdx.x & 63;
+  const int lane = lat_tid() & 63;
   int incl = count;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -115,7 +135,7 @@ __device__ __forceinline__ int wave_alloc_n(int32_t* counter, int count) {
 // Index ownership of the epsilon list: the team's waves take turns (wave w of workgroup g owns entries (w G + g) 64 .. + 63
 // of every G * 1024) -- a frame has one or two thousand entries, which whole workgroups in a row would leave to two of them.
 __device__ __forceinline__ int team_entry(int wg, int G) {
-  return (((int)threadIdx.x >> 6) * G + wg) * 64 + ((int)threadIdx.x & 63);
+  return ((lat_tid() >> 6) * G + wg) * 64 + (lat_tid() & 63);
 }
 
 // A token whose state has more than kHeavyDegree epsilon arcs joins the team's heavy list (false: the list is full, the
@@ -131,7 +151,7 @@ __device__ __forceinline__ bool team_register_heavy(LatFrame* F, int G, int tok)
 // Two such reservations with both atomics in flight together (one round trip to L2 instead of two).
 __device__ __forceinline__ void wave_alloc_n2(int32_t* counter_a, int count_a, int32_t* counter_b, int count_b, int* first_a,
                                               int* first_b) {
-  const int lane = threadIdx.x & 63;
+  const int lane = lat_tid() & 63;
   int ia = count_a, ib = count_b;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -178,7 +198,7 @@ __device__ __forceinline__ void team_register_token(const DecodeParams& p, const
 template <typename Body>
 __device__ __forceinline__ void team_heavy_arcs(const DecodeParams& p, const UttView& V, LatFrame* F, Shared& sh, int nh,
                                                 int wg, int G, int Gteam, float cutoff, bool track, Body body) {
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   for (int h = 0; h < nh; ++h) {
     const int i = F->hlist[h];
     const int s = V.ts[i];
@@ -243,7 +263,7 @@ __device__ __forceinline__ int eps_round(const DecodeParams& p, const UttView& V
 
 // ---- step 0 only: the start token ----
 __device__ __forceinline__ void phase_init(const DecodeParams& p, int n, int G) {
-  if (threadIdx.x != 0) return;
+  if (lat_tid() != 0) return;
   const LatUtt U = p.L.utt[n];
   const UttView V = make_view(p, n, U);
   LatFrame* F = p.L.frame + n;
@@ -268,12 +288,12 @@ __global__ void lat_frames_init(const DecodeParams p, int G) { phase_init(p, blo
 // Returns false when at most k costs lie below hi.  Falls back to kth_smallest_in_range for a crowded bin.
 #ifdef PK2_LATP_PROFILE
 __device__ long long g_cut[8];
-#define CUT_T(k) do { if (threadIdx.x == 0) { const long long n_ = wall_clock64(); g_cut[k] += n_ - cut_last; cut_last = n_; } } while (0)
+#define CUT_T(k) do { if (lat_tid() == 0) { const long long n_ = wall_clock64(); g_cut[k] += n_ - cut_last; cut_last = n_; } } while (0)
 #else
 #define CUT_T(k) do { } while (0)
 #endif
 __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, Shared& sh, float* out) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = lat_tid(), lane = tid & 63, w = tid >> 6;
 #ifdef PK2_LATP_PROFILE
   long long cut_last = wall_clock64();
 #endif
@@ -281,7 +301,13 @@ __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, S
   auto bin_of = [&](float c) { return c >= hi ? 2047 : min(2046, (int)((c - lo) * scale)); };
   // The first kCutRegs * 1024 costs stay in registers for both passes: all their loads are in flight together (a
   // load -> LDS atomic loop waits for L2 once per iteration: 4.6 us for 8.5 k costs) and the second pass reads nothing.
-  constexpr int kCutRegs = 10;
+  #ifndef PK2_LAT_LAUNDER
+#define PK2_LAT_LAUNDER 1
+#endif
+#ifndef PK2_LAT_CUTREGS
+#define PK2_LAT_CUTREGS 10
+#endif
+  constexpr int kCutRegs = PK2_LAT_CUTREGS;
   float cr[kCutRegs];
 #pragma unroll
   for (int q = 0; q < kCutRegs; ++q) {
@@ -356,22 +382,24 @@ __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, S
   return true;
 }
 
-__device__ __forceinline__ void phase_cutoff(const DecodeParams& p, const TeamCtx& c, Shared& sh) {
+// (cutoff_out: {cur_cutoff, adaptive, adaptive follows from cur_cutoff} for all threads of the calling workgroup)
+__device__ __forceinline__ void phase_cutoff(const DecodeParams& p, const TeamCtx& c, Shared& sh, float* cutoff_out = nullptr) {
   if (!c.live || c.t < 0) return;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   if (tid == 0) sh.n_heavy = 0;
   LatFrame* F = c.F;
   const float* tc = c.V.tc;
-  const int f0 = F->f0, f1 = F->f1, nt = f1 - f0;
-  const float best = dec_cost(F->best_key);
+  const Hot* h = c.hot;
+  const int f0 = h ? h->f0 : F->f0, f1 = h ? h->f1 : F->f1, nt = f1 - f0;
+  const float best = dec_cost(h ? h->best_key : F->best_key);
   const float beam_cutoff = best + p.beam;
   float cur_cutoff = beam_cutoff, adaptive = p.beam;
   const bool chk_max = nt > p.max_active, chk_min = p.min_active > 0 && nt > p.min_active;
-  bool bound = false;
+  bool bound = false, adapted = false;     // adapted: adaptive = (cur_cutoff - best) + beam_delta, else the beam
   if (chk_max) {          // c_lt > max_active  <=>  the max_active-th cost (0-based) exists below the beam cutoff
     float kth;
     bound = kth_below(tc + f0, nt, p.max_active, best, beam_cutoff, sh, &kth);
-    if (bound) { cur_cutoff = kth; adaptive = (cur_cutoff - best) + p.beam_delta; }
+    if (bound) { cur_cutoff = kth; adaptive = (cur_cutoff - best) + p.beam_delta; adapted = true; }
   }
   if (!bound && chk_min) {
     int c_le = 0;
@@ -380,9 +408,11 @@ __device__ __forceinline__ void phase_cutoff(const DecodeParams& p, const TeamCt
     if (c_le <= p.min_active) {
       cur_cutoff = kth_smallest(tc + f0, nt, p.min_active, sh);
       adaptive = (cur_cutoff - best) + p.beam_delta;
+      adapted = true;
     }
   }
   if (tid == 0) { F->cur_cutoff = cur_cutoff; F->adaptive = adaptive; F->n_arcs = 0; F->nmin_key = kEmpty; }
+  if (cutoff_out) { cutoff_out[0] = cur_cutoff; cutoff_out[1] = adaptive; cutoff_out[2] = adapted ? 1.f : 0.f; }
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodeParams p, const StepCounter* cnt, int local) {
   __shared__ Shared sh;
@@ -396,12 +426,13 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_cutoff(const DecodePar
 // slice of the list phase.  `first` = 0, `pre` = false: the launch-per-frame kernels' behaviour.
 __device__ __forceinline__ void phase_list_pre(const DecodeParams& p, const TeamCtx& c, Shared& sh, int first) {
   if (!c.live || c.t < 0 || c.wg < first) return;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const UttView& V = c.V;
   LatFrame* F = c.F;
-  const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
+  const Hot* h = c.hot;
+  const float* row = (h ? h->ll_base : F->ll_base) + (int64_t)c.t * (h ? h->ll_stride : F->ll_stride);
   for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
-  const int f0 = F->f0, f1 = F->f1, nr = c.G - first;
+  const int f0 = h ? h->f0 : F->f0, f1 = h ? h->f1 : F->f1, nr = c.G - first;
   const int per = (f1 - f0 + nr - 1) / nr;
   const int s0 = f0 + (c.wg - first) * per, s1 = min(s0 + per, f1);
   for (int i = s0 + tid; i < s1; i += kLatThreads) {
@@ -414,16 +445,17 @@ __device__ __forceinline__ void phase_list_pre(const DecodeParams& p, const Team
 __device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_base, int first = 0,
                                            bool pre = false) {
   if (!c.live || c.t < 0 || c.wg < first) return;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const UttView& V = c.V;
   LatFrame* F = c.F;
   const float* tc = V.tc;
-  const int f0 = F->f0, f1 = F->f1;
-  const float cur_cutoff = F->cur_cutoff;
+  const Hot* h = c.hot;
+  const int f0 = h ? h->f0 : F->f0, f1 = h ? h->f1 : F->f1;
+  const float cur_cutoff = h ? h->cur_cutoff : F->cur_cutoff;
   // the frame's log-likelihood row staged in LDS (reading it per arc from L2 puts one more dependent round trip
   // into the cost pass: measured +6 us per launch)
   if (!pre) {
-    const float* row = F->ll_base + (int64_t)c.t * F->ll_stride;
+    const float* row = (h ? h->ll_base : F->ll_base) + (int64_t)c.t * (h ? h->ll_stride : F->ll_stride);
     for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
   }
   float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
@@ -512,16 +544,17 @@ __device__ __forceinline__ unsigned expand_last(const TeamCtx& c) {
 // ---- tokens and emitting links of frame t+1 ----
 __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCtx& c, int& s_flag, bool defer = false) {
   if (!c.live || c.t < 0) return;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const UttView& V = c.V;
   LatFrame* F = c.F;
-  const float nmin = dec_cost(F->nmin_key);
+  const Hot* h = c.hot;
+  const float nmin = dec_cost(h ? h->nmin_key : F->nmin_key);
   if (!(nmin < INFINITY)) {
-    if (c.wg == 0 && tid == 0) F->status = kLatNoSurvivor;     // seen by the next launch
+    if (c.wg == 0 && tid == 0) st_coherent(&F->status, (int32_t)kLatNoSurvivor);     // seen by the next launch / at the frame's last barrier
     return;
   }
-  const float next_cutoff = nmin + F->adaptive;
-  const int n_arcs = F->n_arcs, l0 = F->link_end, fb = F->f1;
+  const float next_cutoff = nmin + (h ? h->adaptive : F->adaptive);
+  const int n_arcs = h ? h->n_arcs : F->n_arcs, l0 = h ? h->l0 : F->link_end, fb = h ? h->f1 : F->f1;
   const float2* wcost = reinterpret_cast<const float2*>(V.work_tot);
   const int stride = c.G * kLatThreads;
   // Waves stay whole (the loop bound is the wave's first lane) so that slots can be reserved with one atomic per
@@ -627,14 +660,16 @@ __device__ __forceinline__ unsigned round_last(const TeamCtx& c, int r) {
 // ---- link destinations (state -> token index), epsilon relaxation round 0 ----
 __device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, bool defer = false) {
   if (!c.live) return;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const UttView& V = c.V;
   LatFrame* F = c.F;
   if (tid == 0) sh.n_heavy = 0;
-  const int fb = F->f1, l0 = F->link_end, nl = min(F->n_link, V.link_cap - l0);
+  const Hot* h = c.hot;
+  const int fb = h ? h->f1 : F->f1, l0 = h ? h->l0 : F->link_end, nl = min(h ? h->n_link : F->n_link, V.link_cap - l0);
   for (int l = l0 + c.wg * kLatThreads + tid; l < l0 + nl; l += c.G * kLatThreads) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
   __syncthreads();
-  const int changed = eps_round(p, V, F, sh, fb, F->build_cutoff, F->ne_snap, F->nh_snap, c.wg, c.G, c.G);
+  const int changed = eps_round(p, V, F, sh, fb, h ? h->build_cutoff : F->build_cutoff, h ? min(h->ne, V.tok_cap) : F->ne_snap,
+                                h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[0], 1);
   if (!defer && team_last(F, c.G, &s_flag) && tid == 0) round0_last(c);
 }
@@ -649,10 +684,12 @@ __device__ __forceinline__ void phase_round(const DecodeParams& p, const TeamCtx
   if (!c.live) return;
   LatFrame* F = c.F;
   if (!defer && !F->changed[r - 1]) return;          // (the persistent kernel has the flag from the barrier's release word)
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   if (tid == 0) sh.n_heavy = 0;
   __syncthreads();
-  const int changed = eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, F->ne_snap, F->nh_snap, c.wg, c.G, c.G);
+  const Hot* h = c.hot;
+  const int changed = eps_round(p, c.V, F, sh, h ? h->f1 : F->f1, h ? h->build_cutoff : F->build_cutoff,
+                                h ? min(h->ne, c.V.tok_cap) : F->ne_snap, h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[r], 1);
   if (!defer && team_last(F, c.G, &s_flag) && tid == 0) round_last(c, r);
 }
@@ -666,16 +703,17 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_round(const DecodePara
 __device__ __forceinline__ void phase_tail(const DecodeParams& p, const TeamCtx& c, Shared& sh) {
   if (!c.live) return;
   LatFrame* F = c.F;
-  if (!F->changed[kLatEpsRounds]) return;
-  const int tid = threadIdx.x;
+  const Hot* h = c.hot;
+  if (!h && !F->changed[kLatEpsRounds]) return;           // (the persistent kernel has the flag from the barrier's release word)
+  const int tid = lat_tid();
   if (tid == 0) sh.n_heavy = 0;
   __syncthreads();
   for (int rounds = 0; ; ++rounds) {
     const int ne = min(ld_coherent(&F->n_elist), c.V.tok_cap);   // single workgroup: its own appends, ordered by the barriers
     const int nh = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
-    if (!eps_round(p, c.V, F, sh, F->f1, F->build_cutoff, ne, nh, 0, 1, c.G)) break;
+    if (!eps_round(p, c.V, F, sh, h ? h->f1 : F->f1, h ? h->build_cutoff : F->build_cutoff, ne, nh, 0, 1, c.G)) break;
     if (ld_coherent(&F->status) != kLatOk) break;
-    if (rounds > kMaxEpsRounds) { if (tid == 0) F->status = kLatEpsilonLoop; break; }
+    if (rounds > kMaxEpsRounds) { if (tid == 0) st_coherent(&F->status, (int32_t)kLatEpsilonLoop); break; }
   }
   __syncthreads();
   if (tid == 0) {
@@ -708,13 +746,15 @@ __device__ __forceinline__ unsigned close_last(const TeamCtx& c) {
 }
 __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx& c, Shared& sh, int& s_flag, bool defer = false) {
   if (!c.live) return;
-  const int tid = threadIdx.x;
+  const int tid = lat_tid();
   const UttView& V = c.V;
   LatFrame* F = c.F;
   if (tid == 0) sh.n_heavy = 0;
   __syncthreads();
-  const int fb = F->f1, l0 = F->link_end;
-  const float cutoff = F->build_cutoff;
+  const Hot* h = c.hot;
+  // (persistent kernel: the link counter runs on from the frame's emitting links, so the base stays the frame's first link)
+  const int fb = h ? h->f1 : F->f1, l0 = h ? h->l0 : F->link_end;
+  const float cutoff = h ? h->build_cutoff : F->build_cutoff;
   auto eps_link = [&](int i, float cc, int a) {
     const float tot = cc + p.g.n_w[a];
     const int li = l0 + wave_alloc(&F->n_link, tot < cutoff);
@@ -727,12 +767,12 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
       }
     }
   };
-  for_each_arc(sh, V.elist, F->ne_snap, V.ts, p.g.n_off,
+  for_each_arc(sh, V.elist, h ? min(h->ne, V.tok_cap) : F->ne_snap, V.ts, p.g.n_off,
                [&](int i, float* cc) { *cc = dec_cost(V.stc[V.ts[i]]); return *cc < cutoff; },
                eps_link, team_entry(c.wg, c.G), c.G * kLatThreads);
-  team_heavy_arcs(p, V, F, sh, F->nh_snap, c.wg, c.G, c.G, cutoff, false, eps_link);
+  team_heavy_arcs(p, V, F, sh, h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G, cutoff, false, eps_link);
   // final costs and arc ranges of the new tokens (the state table is cleared by the next frame's list launch)
-  const int cnt_new = min(F->n_new, V.tok_cap - fb);
+  const int cnt_new = min(h ? h->n_new : F->n_new, V.tok_cap - fb);
   uint32_t kmin = kEmpty;
   const int stride = c.G * kLatThreads;
   for (int i0 = fb + c.wg * kLatThreads + tid; i0 < fb + cnt_new; i0 += 4 * stride) {
@@ -785,9 +825,16 @@ struct LatTeamCtl {
   unsigned next_utt, abort, done, pad[5];
   // bar: arrivals (monotonic); rel: the release word of lat_team_barrier_last on a cache line of its own -- barrier number in
   // the low half, the last arriver's payload (a flag the next phase branches on) in the high half
-  struct Team { unsigned task[kLatMaxIter + 1]; unsigned bar; unsigned pad[30]; unsigned long long rel; unsigned pad2[30]; } team[8][kLatTeamsPerXcd];
+  // (lat_team_barrier_hand: 7 bits of release number, 57 bits of payload.)  sig: the same for the cutoff, which rank 0 hands
+  // to the workgroups that list the frame's arcs without a barrier (they owe rank 0 nothing at that point).
+  struct Team {
+    unsigned task[kLatMaxIter + 1]; unsigned bar; unsigned pad[30];
+    unsigned long long rel; unsigned pad2[30];
+    unsigned long long sig; unsigned pad3[30];
+  } team[8][kLatTeamsPerXcd];
 };
-static_assert(sizeof(LatTeamCtl::Team) == 512 && offsetof(LatTeamCtl::Team, rel) == 384, "team record: 512 bytes, release word on its own line");
+static_assert(sizeof(LatTeamCtl::Team) == 640 && offsetof(LatTeamCtl::Team, rel) == 384 && offsetof(LatTeamCtl::Team, sig) == 512,
+              "team record: release words on cache lines of their own");
 
 struct LatSpin {
   LatTeamCtl* ctl; long long t0; unsigned n;
@@ -809,8 +856,8 @@ __device__ __forceinline__ bool lat_team_barrier(LatTeamCtl* ctl, LatTeamCtl::Te
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   const unsigned target = (unsigned)G * ++*nbar;
-  if (threadIdx.x < 64) {
-    if (threadIdx.x == 0) {
+  if (lat_tid() < 64) {
+    if (lat_tid() == 0) {
       __hip_atomic_fetch_add(&tm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       LatSpin spin(ctl);
       while (ld_coherent(&tm->bar) < target) {
@@ -838,8 +885,8 @@ __device__ __forceinline__ bool lat_team_barrier_last(LatTeamCtl* ctl, LatTeamCt
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   const unsigned gen = ++*nbar, target = (unsigned)G * gen;
-  if (threadIdx.x < 64) {
-    if (threadIdx.x == 0) {
+  if (lat_tid() < 64) {
+    if (lat_tid() == 0) {
       const unsigned old = __hip_atomic_fetch_add(&tm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old + 1u == target) {
         const unsigned pay = last_fn();
@@ -863,11 +910,219 @@ __device__ __forceinline__ bool lat_team_barrier_last(LatTeamCtl* ctl, LatTeamCt
   return *s_abort == 0;
 }
 
+// Round 6, second form: the barrier hands over VALUES.  `pre` (last arriver, one thread) reads the counters the phase's
+// atomics left in L2 and packs what the next phase needs into 57 bits; the release word carries them to every workgroup;
+// `post` (same thread, AFTER the release) writes what only later phases or later kernels read (segment bounds, counter
+// resets: they are acknowledged before that workgroup arrives at the next barrier).  A field that does not fit its bits is
+// sent as all-ones and the receivers read the counter themselves (kField*: 2^23 - 1 tokens or links in ONE frame).
+// Release numbers are compared for equality on 7 bits: a workgroup is never more than one release behind the word.
+constexpr unsigned kRelMask = 127u;
+constexpr unsigned long long kF23 = (1ull << 23) - 1ull, kF25 = (1ull << 25) - 1ull;
+// (sender: a value that needs more bits goes into the record's hand[slot] -- acknowledged before the release -- and all-ones
+// into the word; receiver: all-ones = read hand[slot], which the next sender touches only after every receiver has arrived at
+// the next barrier)
+__device__ __forceinline__ unsigned long long fld(int v, unsigned long long mx, int32_t* slot) {
+  if ((unsigned long long)(unsigned)v < mx) return (unsigned long long)(unsigned)v;
+  st_coherent(slot, v);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return mx;
+}
+__device__ __forceinline__ int unfld(unsigned long long f, unsigned long long mx, const int32_t* slot) {
+  return f == mx ? ld_coherent(slot) : (int)f;
+}
+template <class Pre, class Post, class Recv>
+__device__ __forceinline__ bool lat_team_barrier_hand(LatTeamCtl* ctl, LatTeamCtl::Team* tm, int G, unsigned* nbar, unsigned* nrel, int* s_abort,
+                                                      int inv_mode, Pre pre, Post post, Recv recv) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned target = (unsigned)G * ++*nbar, gen = ++*nrel & kRelMask;
+  if (lat_tid() < 64) {
+    if (lat_tid() == 0) {
+      const unsigned old = __hip_atomic_fetch_add(&tm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == target) {
+        const unsigned long long pay = pre();
+        st_coherent(&tm->rel, (pay << 7) | gen);
+        recv(pay);
+        post(pay);
+      } else {
+        LatSpin spin(ctl);
+        unsigned long long w;
+        while (((unsigned)(w = ld_coherent(&tm->rel)) & kRelMask) != gen) {
+          if (spin.expired()) { *s_abort = 1; break; }
+        }
+        recv(w >> 7);
+      }
+    }
+    if (inv_mode == 1) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (inv_mode == 0) asm volatile("buffer_inv sc1\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  return *s_abort == 0;
+}
+
+// The persistent kernel calls this at the top of every frame: the compiler otherwise hoists the per-thread addresses of all
+// phases (pointer + f(thread)) out of the frame loop, keeps them alive across every phase and spills them (the workgroup has
+// 128 registers per thread); scratch reloads behind an L1 invalidation are round trips to L2.  Behind an opaque asm the
+// addresses are computed where they are used (a few VALU instructions).
+__device__ __forceinline__ void launder_view(UttView& V, LatFrame*& F) {
+#if PK2_LAT_LAUNDER
+  asm volatile("" : "+s"(V.stc), "+s"(V.stt), "+s"(V.ts), "+s"(V.tc), "+s"(V.te), "+s"(V.tarc), "+s"(V.work), "+s"(V.work_tot));
+  asm volatile("" : "+s"(V.elist), "+s"(V.ftok), "+s"(V.seg), "+s"(V.lrec), "+s"(V.lac), "+s"(V.erec), "+s"(F));
+#endif
+}
+
+// One utterance's frames with the record's hot fields in the workgroup's LDS (see Hot; `h`: written by thread 0 inside the
+// barriers, read by everybody behind them).  Returns false after an abort.
+__device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTeamCtl* ctl, LatTeamCtl::Team* tm, TeamCtx& c, Shared& sh,
+                                                   Hot& h, int& s_flag, int& s_base, int& s_abort, unsigned& nbar, unsigned& nrel,
+                                                   unsigned& nsig, int list_first, int inv_mode, long long* lp_acc, int* lp_frames_p) {
+#ifdef PK2_LATP_PROFILE
+  long long lp_last = 0;
+#define LPH(k) do { const long long n_ = wall_clock64(); lp_acc[k] += n_ - lp_last; lp_last = n_; } while (0)
+#else
+#define LPH(k) do { } while (0)
+#endif
+  typedef unsigned long long u64;
+  const int tid = lat_tid(), rank = c.wg, G = c.G, T = c.T;
+  LatFrame*& F = c.F;
+  const UttView& V = c.V;
+  if (tid == 0) {
+    // (behind the barrier that follows phase_init: the record as InitDecoding left it)
+    h.f0 = F->f0; h.f1 = F->f1; h.l0 = F->link_end; h.best_key = F->best_key;
+    h.cur_cutoff = F->cur_cutoff; h.adaptive = F->adaptive; h.build_cutoff = F->build_cutoff;
+    h.n_arcs = 0; h.nmin_key = kEmpty; h.n_link = 0;
+    h.ne = F->ne_snap; h.nh = F->nh_snap; h.n_new = ld_coherent(&F->n_new);
+    h.ll_base = F->ll_base; h.ll_stride = F->ll_stride;
+    h.more = 0; h.status_bad = 0;
+  }
+  __syncthreads();
+  c.hot = &h;
+  auto hand = [&](auto pre, auto post, auto recv) {
+    return lat_team_barrier_hand(ctl, tm, G, &nbar, &nrel, &s_abort, inv_mode, pre, post, recv);
+  };
+  for (int t = -1; t < T; ++t) {
+    c.t = t;
+    launder_view(c.V, c.F);
+#ifdef PK2_LATP_PROFILE
+    lp_last = wall_clock64(); ++*lp_frames_p;
+#endif
+    if (t >= 0) {
+      if (h.status_bad) break;
+      // ---- cutoff: rank 0 selects it and hands it over in a word of its own; nobody waits for anybody else here ----
+      const unsigned sgen = ++nsig & kRelMask;
+      if (rank == 0) {
+        float co[3];
+        phase_cutoff(p, c, sh, co);
+        if (tid == 0) {
+          h.cur_cutoff = co[0]; h.adaptive = co[1];
+          // (the record's n_arcs / nmin_key were reset by this thread: acknowledged before the word goes out)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          st_coherent(&tm->sig, ((u64)__float_as_uint(co[0]) << 8) | ((co[2] != 0.f ? 1ull : 0ull) << 7) | sgen);
+        }
+        if (!list_first) __syncthreads();
+        LPH(0);
+      } else {
+        if (list_first) phase_list_pre(p, c, sh, list_first);
+        LPH(0);
+        if (tid == 0) {
+          LatSpin spin(ctl);
+          u64 w;
+          while (((unsigned)(w = ld_coherent(&tm->sig)) & kRelMask) != sgen) {
+            if (spin.expired()) { s_abort = 1; break; }
+          }
+          h.cur_cutoff = __uint_as_float((unsigned)(w >> 8));
+          h.adaptive = ((w >> 7) & 1ull) ? (h.cur_cutoff - dec_cost(h.best_key)) + p.beam_delta : p.beam;
+        }
+        __syncthreads();
+        if (s_abort) return false;
+        LPH(1);
+      }
+      // ---- list ----
+      phase_list(p, c, sh, s_base, list_first, list_first != 0);
+      LPH(2);
+      if (!hand([&]() -> u64 { return (fld(ld_coherent(&F->n_arcs), kF25, &F->hand[0]) << 32) | (u64)ld_coherent(&F->nmin_key); },
+                [](u64) { },
+                [&](u64 w) {
+                  h.nmin_key = (uint32_t)w;
+                  h.n_arcs = unfld(w >> 32, kF25, &F->hand[0]);
+                  const float nmin = dec_cost((uint32_t)w);
+                  if (nmin < INFINITY) h.build_cutoff = nmin + h.adaptive;
+                })) return false;
+      LPH(3);
+      // ---- expand ----
+      phase_expand(p, c, s_flag, true);
+      LPH(4);
+      if (!hand([&]() -> u64 { const int a = ld_coherent(&F->n_link), b = ld_coherent(&F->n_elist), d = ld_coherent(&F->n_hlist);
+                               return (fld(a, kF23, &F->hand[0]) << 28) | (fld(b, kF23, &F->hand[1]) << 5) | (u64)min(d, kLatTeamHeavy); },
+                [](u64) { },
+                [&](u64 w) {
+                  h.n_link = unfld(w >> 28, kF23, &F->hand[0]);
+                  h.ne = unfld((w >> 5) & kF23, kF23, &F->hand[1]);
+                  h.nh = (int)(w & 31ull);
+                })) return false;
+      LPH(5);
+    }
+    // ---- link destinations, relaxation rounds ----
+    phase_round0(p, c, sh, s_flag, true);
+    LPH(6);
+    for (int r = 0; ; ++r) {
+      if (r > 0) { phase_round(p, c, sh, s_flag, r, true); LPH(8); }
+      // {a cost was lowered, new tokens, epsilon list, heavy list}
+      if (!hand([&]() -> u64 { const int fl = ld_coherent(&F->changed[r]), b = ld_coherent(&F->n_elist), d = ld_coherent(&F->n_hlist),
+                                         e = ld_coherent(&F->n_new);
+                               return ((u64)(fl != 0) << 51) | (fld(e, kF23, &F->hand[0]) << 28) | (fld(b, kF23, &F->hand[1]) << 5) |
+                                      (u64)min(d, kLatTeamHeavy); },
+                [&](u64) { if (r == 0) V.seg[2 * t + 2] = h.l0 + min(h.n_link, V.link_cap - h.l0); },
+                [&](u64 w) {
+                  h.more = (int)((w >> 51) & 1ull);
+                  h.n_new = unfld((w >> 28) & kF23, kF23, &F->hand[0]);
+                  h.ne = unfld((w >> 5) & kF23, kF23, &F->hand[1]);
+                  h.nh = (int)(w & 31ull);
+                })) return false;
+      if (r == 0) LPH(7); else LPH(9);
+      if (!h.more || r == kLatEpsRounds) break;
+    }
+    if (h.more) {                                            // (all rounds ran and the last one still lowered a cost)
+      if (rank == 0) phase_tail(p, c, sh);
+      if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return false;
+      if (tid == 0) { h.ne = ld_coherent(&F->n_elist); h.nh = min(ld_coherent(&F->n_hlist), kLatTeamHeavy); h.n_new = ld_coherent(&F->n_new); }
+      __syncthreads();
+    }
+    // ---- close ----
+    phase_close(p, c, sh, s_flag, true);
+    LPH(12);
+    if (!hand([&]() -> u64 { const int a = ld_coherent(&F->n_link); const uint32_t bk = ld_coherent(&F->best_next);
+                             const int st = ld_coherent(&F->status);
+                             return ((u64)(st != kLatOk) << 55) | (fld(a, kF23, &F->hand[0]) << 32) | (u64)bk; },
+              [&](u64) {  // (behind recv: h is the NEXT frame's) what later kernels read, and the counters for the next frame
+                V.seg[2 * t + 3] = h.l0;
+                V.ftok[t + 2] = h.f1;
+                F->f0 = h.f0; F->f1 = h.f1; F->link_end = h.l0; F->best_key = h.best_key;
+                st_coherent(&F->best_next, kEmpty);
+                st_coherent(&F->n_new, 0); st_coherent(&F->n_link, 0); st_coherent(&F->n_elist, 0); st_coherent(&F->n_hlist, 0);
+                for (int r = 0; r <= kLatEpsRounds; ++r) st_coherent(&F->changed[r], 0);
+              },
+              [&](u64 w) {
+                const int fb = h.f1, a = unfld((w >> 32) & kF23, kF23, &F->hand[0]);
+                h.status_bad = (int)((w >> 55) & 1ull);
+                h.l0 = min(h.l0 + a, V.link_cap);
+                h.best_key = (uint32_t)w;
+                h.f0 = fb; h.f1 = fb + min(h.n_new, V.tok_cap - fb);
+                h.n_link = 0; h.ne = 0; h.nh = 0; h.n_new = 0;
+              })) return false;
+    LPH(13);
+  }
+#undef LPH
+  c.hot = nullptr;
+  return true;
+}
+
 __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodeParams p, LatTeamCtl* ctl, int N, int G, int teams_per_xcd, int inv_mode) {
   __shared__ Shared sh;
   __shared__ int s_flag, s_base, s_abort, s_i[4];
   __shared__ unsigned s_pay;
-  const int tid = threadIdx.x;
+  __shared__ Hot s_hot;
+  const int tid = lat_tid();
   if (tid == 0) {
     unsigned xcd;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
@@ -877,10 +1132,14 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
     s_abort = 0;
   }
   __syncthreads();
-  const int rank = s_i[0];
+  // (workgroup-uniform values read back from LDS: readfirstlane keeps them -- and every pointer derived from them -- in SGPRs)
+  const int rank = __builtin_amdgcn_readfirstlane(s_i[0]);
   if (s_i[1] >= teams_per_xcd) return;                     // (whole teams only; the host sizes them for 32 CUs per XCD)
-  LatTeamCtl::Team* tm = &ctl->team[s_i[2]][s_i[1]];
-  unsigned nbar = 0;
+  LatTeamCtl::Team* tm = &ctl->team[__builtin_amdgcn_readfirstlane(s_i[2])][__builtin_amdgcn_readfirstlane(s_i[1])];
+  unsigned nbar = 0, nrel = 0, nsig = 0;
+#ifndef PK2_LAT_HOT
+#define PK2_LAT_HOT 1
+#endif
 #ifndef PK2_LAT_LIST_PRE
 #define PK2_LAT_LIST_PRE 1
 #endif
@@ -914,13 +1173,20 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
       s_i[3] = (int)k;
     }
     __syncthreads();
-    const int n = s_i[3];
+    const int n = __builtin_amdgcn_readfirstlane(s_i[3]);
     if (s_abort || n >= N) return;
     if (rank == 0) phase_init(p, n, G);
     if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
     TeamCtx c = team_ctx_of(p, n, rank, G, -1);            // (the utterance's record and views: once, not per frame)
     const int T = c.T;
     LatFrame* F = c.F;
+#if PK2_LAT_HOT
+#ifdef PK2_LATP_PROFILE
+    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, lp_acc, &lp_frames)) return;
+#else
+    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, nullptr, nullptr)) return;
+#endif
+#else
     // Barriers behind a phase with bookkeeping: merged form (the last arriver does the bookkeeping and hands the flag the
     // next phase branches on to everybody inside the release word) or, -DPK2_LAT_MERGE_LAST=0, round 5's form (team_last
     // inside the phase, plain barrier, every workgroup loads the flag).
@@ -980,6 +1246,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
       LP_T(13);
     }
 #undef LAT_BARRIER_LAST
+#endif
 #ifdef PK2_LATP_PROFILE
     if (tid == 0 && rank == 0 && n == 0)
       printf("kth_below, 10 ns ticks per frame: zero hist %lld | pass 1 %lld | scan %lld | pass 2 %lld | rank %lld\n", g_cut[0] / lp_frames,
@@ -998,8 +1265,8 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
 __global__ void lat_persist_check(const DecodeParams p, const LatTeamCtl* ctl, int N, unsigned* sticky, unsigned* guard_dev, unsigned* guard_host) {
   if (ctl->abort == 0u && ctl->done == (unsigned)N) return;
   *sticky = 1u;
-  if (threadIdx.x == 0) persist_guard_raise(guard_dev, guard_host);
-  for (int n = threadIdx.x; n < N; n += blockDim.x) p.L.frame[n].status = kLatNotDecoded;
+  if (lat_tid() == 0) persist_guard_raise(guard_dev, guard_host);
+  for (int n = lat_tid(); n < N; n += blockDim.x) p.L.frame[n].status = kLatNotDecoded;
 }
 
 // ---- after the last frame: final costs + lattice-beam pruning, or the failure report ----
@@ -1016,7 +1283,7 @@ constexpr int kFinEmit = 12;       // emitting links per thread fetched ahead of
 extern __shared__ __attribute__((aligned(16))) uint32_t lat_fin_smem[];
 
 __global__ void __launch_bounds__(256) lat_link_delta(const DecodeParams p) {
-  const int n = blockIdx.y, tid = threadIdx.x;
+  const int n = blockIdx.y, tid = lat_tid();
   const LatUtt U = p.L.utt[n];
   if (p.L.frame[n].status != kLatOk) return;
   const UttView V = make_view(p, n, U);
@@ -1051,7 +1318,7 @@ __device__ __forceinline__ void fin_barrier(bool lds_only) {
 __global__ void __launch_bounds__(kLatThreads) lat_frames_finish(const DecodeParams p, int cap) {
   __shared__ float s_redf[kLatWaves];
   __shared__ int s_vote[3];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.x, tid = lat_tid();
   const LatUtt U = p.L.utt[n];
   const UttView V = make_view(p, n, U);
   const LatFrame* F = p.L.frame + n;

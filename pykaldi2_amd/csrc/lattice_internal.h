@@ -64,6 +64,7 @@ struct LatFrame {
   uint32_t nmin_key;           // best cost over the frame's arcs
   float cur_cutoff, adaptive, build_cutoff;
   int32_t status, arrive;
+  int32_t hand[2];             // persistent decoder: counts too large for their field of a barrier's release word
   int32_t changed[kLatEpsRounds + 1];
   // Tokens of the frame being built whose state has very many epsilon arcs (the word-loop state: one per word): their arcs
   // are dealt to ALL workgroups of the team (left to the token's owner, that workgroup walked 20 k arcs while the others
