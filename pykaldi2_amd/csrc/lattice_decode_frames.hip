@@ -168,9 +168,26 @@ __device__ __forceinline__ void wave_alloc_n2(int32_t* counter_a, int count_a, i
   *first_b = __shfl(base_b, 63, 64) + ib - count_b;
 }
 
-// Called by every lane that created the token of state d (old == kEmpty); others pass create = false.
+// The team's epsilon list holds RECORDS (round 6): {token, state} {first epsilon arc, epsilon degree} -- what a relaxation
+// round needs to start on the state's cost and its first arcs at once, where a list of token indices put three dependent
+// round trips in front of them (index -> state -> arc range).  16 bytes per entry in the lower half of the region whose upper
+// half holds the work list's graph costs: room for tok_cap / 4 entries of ONE frame (more: the utterance reports a token
+// overflow and is decoded again with larger pools).
+__device__ __forceinline__ int elist_cap(const UttView& V) { return V.tok_cap >> 2; }
+__device__ __forceinline__ void elist_put(const UttView& V, LatFrame* F, int e, int tok, int state, int a0, int deg) {
+  if (e < elist_cap(V)) {
+    int2* l2 = reinterpret_cast<int2*>(V.elist);
+    l2[2 * e] = make_int2(tok, state);
+    l2[2 * e + 1] = make_int2(a0, deg);
+  } else {
+    st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+  }
+}
+
+// Called by every lane that created the token of state d (old == kEmpty; its epsilon arcs are [a0, a0 + deg)); others pass
+// create = false.
 __device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int G, int fb, int d,
-                                                    bool create = true) {
+                                                    int a0, int deg, bool create = true) {
   const int idx = wave_alloc(&F->n_new, create);
   bool eps = false;
   if (create) {
@@ -178,7 +195,6 @@ __device__ __forceinline__ void team_register_token(const DecodeParams& p, const
       V.ts[fb + idx] = d;
       V.tc[fb + idx] = INFINITY;
       st_coherent(&V.stt[d], idx);
-      const int deg = p.g.n_off[d + 1] - p.g.n_off[d];
       eps = deg > 0;
       if (deg > kHeavyDegree && team_register_heavy(F, G, fb + idx)) eps = false;
     } else {
@@ -186,9 +202,44 @@ __device__ __forceinline__ void team_register_token(const DecodeParams& p, const
     }
   }
   const int e = wave_alloc(&F->n_elist, eps);
-  if (eps) {
-    if (e < V.tok_cap) V.elist[e] = fb + idx; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+  if (eps) elist_put(V, F, e, fb + idx, d, a0, deg);
+}
+
+// body(token, cost, arc, arc weight, arc destination) for the epsilon arcs of the list's records [first, first + stride, ..)
+// that `active(token, state, &cost)` accepts.  The first two arcs of a record are requested TOGETHER with what `active`
+// reads (every record has at least one arc); states with many arcs are queued in LDS and walked by the whole workgroup as in
+// for_each_arc.  Contains workgroup barriers.
+template <typename Active, typename Body>
+__device__ __forceinline__ void for_each_eps_record(Shared& sh, const DecodeParams& p, const UttView& V, int n_list, Active active,
+                                                    Body body, int first, int stride) {
+  const int tid = lat_tid();
+  const int2* l2 = reinterpret_cast<const int2*>(V.elist);
+  for (int j = first; j < n_list; j += stride) {
+    const int2 e0 = l2[2 * j], e1 = l2[2 * j + 1];
+    const int a0 = e1.x, a1 = e1.x + e1.y, a0b = min(a0 + 1, a1 - 1);
+    const float w0 = p.g.n_w[a0], w1 = p.g.n_w[a0b];
+    const int d0 = p.g.n_dst[a0], d1 = p.g.n_dst[a0b];
+    float c;
+    if (!active(e0.x, e0.y, &c)) continue;
+    if (e1.y > kHeavyDegree) {
+      const int h = atomicAdd(&sh.n_heavy, 1);
+      if (h < kMaxHeavy) { sh.heavy_tok[h] = e0.x; sh.heavy_cost[h] = c; continue; }
+    }
+    body(e0.x, c, a0, w0, d0);
+    if (e1.y > 1) body(e0.x, c, a0 + 1, w1, d1);
+    for (int a = a0 + 2; a < a1; ++a) body(e0.x, c, a, p.g.n_w[a], p.g.n_dst[a]);
   }
+  __syncthreads();
+  const int nh = min(sh.n_heavy, kMaxHeavy);
+  for (int h = 0; h < nh; ++h) {
+    const int i = sh.heavy_tok[h];
+    const float c = sh.heavy_cost[h];
+    const int s = V.ts[i];
+    for (int a = p.g.n_off[s] + tid; a < p.g.n_off[s + 1]; a += kLatThreads) body(i, c, a, p.g.n_w[a], p.g.n_dst[a]);
+  }
+  __syncthreads();
+  if (tid == 0) sh.n_heavy = 0;
+  __syncthreads();
 }
 
 // The arcs of the team's heavy tokens [0, nh): workgroup wg of G walks arcs wg * 1024 + thread, + G * 1024, ... of each.
@@ -225,7 +276,8 @@ __device__ __forceinline__ void team_heavy_arcs(const DecodeParams& p, const Utt
     const bool act = sh.heavy_tok[0] != 0;
     __syncthreads();
     if (act)
-      for (int a = p.g.n_off[s] + wg * kLatThreads + tid; a < p.g.n_off[s + 1]; a += G * kLatThreads) body(i, cc, a);
+      for (int a = p.g.n_off[s] + wg * kLatThreads + tid; a < p.g.n_off[s + 1]; a += G * kLatThreads)
+        body(i, cc, a, p.g.n_w[a], p.g.n_dst[a]);
   }
 }
 
@@ -235,28 +287,29 @@ __device__ __forceinline__ int eps_round(const DecodeParams& p, const UttView& V
                                          float cutoff, int ne, int nh, int wg, int G, int Gteam) {
   const uint32_t kcut = enc_cost(cutoff);
   int changed = 0;
-  auto relax = [&](int i, float c, int a) {
-    const float tot = c + p.g.n_w[a];
+  auto relax = [&](int i, float c, int a, float w, int d) {
+    const float tot = c + w;
     const uint32_t k = enc_cost(tot);
     if (k < kcut) {
-      const int d = p.g.n_dst[a];
+      // (the destination's epsilon arc range is requested with the atomic, not behind its answer)
+      const int o0 = p.g.n_off[d], o1 = p.g.n_off[d + 1];
       const uint32_t old = atomicMin(&V.stc[d], k);
       if (k < old) {
         // another round is needed only if the state that got cheaper has epsilon arcs of its own
-        if (p.g.n_off[d + 1] > p.g.n_off[d]) changed = 1;
-        if (old == kEmpty) team_register_token(p, V, F, Gteam, fb, d);
+        if (o1 > o0) changed = 1;
+        if (old == kEmpty) team_register_token(p, V, F, Gteam, fb, d, o0, o1 - o0);
       }
     }
   };
-  for_each_arc(sh, V.elist, ne, V.ts, p.g.n_off,
-               [&](int i, float* c) {
-                 const float cc = dec_cost(ld_coherent(&V.stc[V.ts[i]]));
-                 if (!(cc < V.tc[i])) return false;      // not improved since its last expansion
-                 V.tc[i] = cc;
-                 *c = cc;
-                 return cc < cutoff;
-               },
-               relax, team_entry(wg, G), G * kLatThreads);
+  for_each_eps_record(sh, p, V, ne,
+                      [&](int i, int s, float* c) {
+                        const float cc = dec_cost(ld_coherent(&V.stc[s]));
+                        if (!(cc < V.tc[i])) return false;      // not improved since its last expansion
+                        V.tc[i] = cc;
+                        *c = cc;
+                        return cc < cutoff;
+                      },
+                      relax, team_entry(wg, G), G * kLatThreads);
   team_heavy_arcs(p, V, F, sh, nh, wg, G, Gteam, cutoff, true, relax);
   return __syncthreads_or(changed);
 }
@@ -275,7 +328,7 @@ __device__ __forceinline__ void phase_init(const DecodeParams& p, int n, int G) 
   for (int r = 0; r <= kLatEpsRounds; ++r) F->changed[r] = 0;
   F->ll_base = p.loglikes + (int64_t)n * p.seq_stride; F->ll_stride = p.frame_stride;
   V.stc[p.g.start] = enc_cost(0.f);
-  team_register_token(p, V, F, G, 0, p.g.start);
+  team_register_token(p, V, F, G, 0, p.g.start, p.g.n_off[p.g.start], p.g.n_off[p.g.start + 1] - p.g.n_off[p.g.start]);
   F->ne_snap = F->n_elist; F->nh_snap = min(F->n_hlist, kLatTeamHeavy);
   V.ftok[0] = 0; V.seg[0] = 0;
 }
@@ -459,6 +512,11 @@ __device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx&
     for (int i = tid; i < p.P; i += kLatThreads) sh.ll[i] = row[i];
   }
   float2* wcost = reinterpret_cast<float2*>(V.work_tot);     // {total cost, acoustic cost} per listed arc
+  // {destination state, transition-id, graph cost} of every listed arc, by work-list index: the expand phase reads them
+  // together with the costs instead of going back to the arc records (one dependent round trip less in its chain).
+  // Arrays that are idle while frames are decoded: the final costs and epsilon levels of the tokens (written by the passes
+  // behind the last frame), the upper half of the epsilon list's region.
+  int32_t* wdst = reinterpret_cast<int32_t*>(V.tf); int32_t* wtid = V.tl; int32_t* wgc = V.elist + V.tok_cap;
   float nmin = INFINITY;
   // the frame's tokens are cut into equal slices (a frame has a few thousand tokens: dealing them in chunks of
   // 4096 would leave most of the team without work and put several dependent passes of the cost loop on the rest)
@@ -512,8 +570,13 @@ __device__ __forceinline__ void phase_list(const DecodeParams& p, const TeamCtx&
       const float tot0 = __fadd_rn(__fadd_rn(c0, ac0), __int_as_float(er0.z));
       const float tot1 = __fadd_rn(__fadd_rn(c1, ac1), __int_as_float(er1.z));
       wcost[j0] = make_float2(tot0, ac0);
+      wdst[j0] = er0.x; wtid[j0] = er0.y; wgc[j0] = er0.z;
       nmin = fminf(nmin, tot0);
-      if (two) { wcost[j1] = make_float2(tot1, ac1); nmin = fminf(nmin, tot1); }
+      if (two) {
+        wcost[j1] = make_float2(tot1, ac1);
+        wdst[j1] = er1.x; wtid[j1] = er1.y; wgc[j1] = er1.z;
+        nmin = fminf(nmin, tot1);
+      }
     }
     __syncthreads();
   }
@@ -535,7 +598,7 @@ __device__ __forceinline__ unsigned expand_last(const TeamCtx& c) {
   if (!c.live || c.t < 0) return 0u;
   const float nmin = dec_cost(F->nmin_key);
   if (!(nmin < INFINITY)) return 0u;
-  F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  F->ne_snap = min(ld_coherent(&F->n_elist), elist_cap(c.V));
   F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
   F->build_cutoff = nmin + F->adaptive;
   return 0u;
@@ -556,6 +619,7 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
   const float next_cutoff = nmin + (h ? h->adaptive : F->adaptive);
   const int n_arcs = h ? h->n_arcs : F->n_arcs, l0 = h ? h->l0 : F->link_end, fb = h ? h->f1 : F->f1;
   const float2* wcost = reinterpret_cast<const float2*>(V.work_tot);
+  const int32_t* wdst = reinterpret_cast<const int32_t*>(V.tf); const int32_t* wtid = V.tl; const int32_t* wgc = V.elist + V.tok_cap;
   const int stride = c.G * kLatThreads;
   // Waves stay whole (the loop bound is the wave's first lane) so that slots can be reserved with one atomic per
   // wave and counter, and the independent requests of a pass are all in flight together: costs + work items ->
@@ -567,23 +631,23 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
     for (int q = 0; q < 4; ++q) {
       const int j = j0 + q * stride;
       acc[q] = j < n_arcs;
-      if (acc[q]) { tc2[q] = wcost[j]; wk[q] = V.work[j]; }
+      if (acc[q]) { tc2[q] = wcost[j]; wk[q] = V.work[j]; er[q] = make_int4(wdst[j], wtid[j], wgc[j], 0); }
     }
     int n_acc = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       acc[q] = acc[q] && tc2[q].x < next_cutoff;
       n_acc += acc[q];
-      if (acc[q]) er[q] = V.erec[wk[q].y];
     }
     // one hop: atomicMin on the table, the link slots, the epsilon degree of the destinations
-    int deg[4];
+    int deg[4], ea0[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      deg[q] = 0;
+      deg[q] = 0; ea0[q] = 0;
       if (acc[q]) {
         old[q] = atomicMin(&V.stc[er[q].x], enc_cost(tc2[q].x));
-        deg[q] = p.g.n_off[er[q].x + 1] - p.g.n_off[er[q].x];
+        ea0[q] = p.g.n_off[er[q].x];
+        deg[q] = p.g.n_off[er[q].x + 1] - ea0[q];
       }
     }
     int li = l0 + wave_alloc_n(&F->n_link, n_acc);
@@ -609,12 +673,12 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
           V.tc[fb + ti] = INFINITY;
           st_coherent(&V.stt[er[q].x], ti);
           if (eps[q]) {
-            if (ei < V.tok_cap) V.elist[ei] = fb + ti; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+            elist_put(V, F, ei, fb + ti, er[q].x, ea0[q], deg[q]);
             ++ei;
           }
           if (heavy[q] && !team_register_heavy(F, c.G, fb + ti)) {      // (rare; the list is full: an ordinary entry)
             const int e = atomicAdd(&F->n_elist, 1);
-            if (e < V.tok_cap) V.elist[e] = fb + ti; else st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+            elist_put(V, F, e, fb + ti, er[q].x, ea0[q], deg[q]);
           }
         } else {
           st_coherent(&F->status, (int32_t)kLatTokenOverflow);
@@ -645,14 +709,14 @@ __device__ __forceinline__ unsigned round0_last(const TeamCtx& c) {
   F->link_end = l0 + nl;
   c.V.seg[2 * c.t + 2] = l0 + nl;
   st_coherent(&F->n_link, 0);
-  F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  F->ne_snap = min(ld_coherent(&F->n_elist), elist_cap(c.V));
   F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
   return (unsigned)(ld_coherent(&F->changed[0]) != 0);
 }
 __device__ __forceinline__ unsigned round_last(const TeamCtx& c, int r) {
   LatFrame* F = c.F;
   if (!c.live) return 0u;
-  F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+  F->ne_snap = min(ld_coherent(&F->n_elist), elist_cap(c.V));
   F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
   return (unsigned)(ld_coherent(&F->changed[r]) != 0);
 }
@@ -668,7 +732,7 @@ __device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCt
   const int fb = h ? h->f1 : F->f1, l0 = h ? h->l0 : F->link_end, nl = min(h ? h->n_link : F->n_link, V.link_cap - l0);
   for (int l = l0 + c.wg * kLatThreads + tid; l < l0 + nl; l += c.G * kLatThreads) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
   __syncthreads();
-  const int changed = eps_round(p, V, F, sh, fb, h ? h->build_cutoff : F->build_cutoff, h ? min(h->ne, V.tok_cap) : F->ne_snap,
+  const int changed = eps_round(p, V, F, sh, fb, h ? h->build_cutoff : F->build_cutoff, h ? min(h->ne, elist_cap(V)) : F->ne_snap,
                                 h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[0], 1);
   if (!defer && team_last(F, c.G, &s_flag) && tid == 0) round0_last(c);
@@ -689,7 +753,7 @@ __device__ __forceinline__ void phase_round(const DecodeParams& p, const TeamCtx
   __syncthreads();
   const Hot* h = c.hot;
   const int changed = eps_round(p, c.V, F, sh, h ? h->f1 : F->f1, h ? h->build_cutoff : F->build_cutoff,
-                                h ? min(h->ne, c.V.tok_cap) : F->ne_snap, h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
+                                h ? min(h->ne, elist_cap(c.V)) : F->ne_snap, h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[r], 1);
   if (!defer && team_last(F, c.G, &s_flag) && tid == 0) round_last(c, r);
 }
@@ -709,7 +773,7 @@ __device__ __forceinline__ void phase_tail(const DecodeParams& p, const TeamCtx&
   if (tid == 0) sh.n_heavy = 0;
   __syncthreads();
   for (int rounds = 0; ; ++rounds) {
-    const int ne = min(ld_coherent(&F->n_elist), c.V.tok_cap);   // single workgroup: its own appends, ordered by the barriers
+    const int ne = min(ld_coherent(&F->n_elist), elist_cap(c.V));   // single workgroup: its own appends, ordered by the barriers
     const int nh = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
     if (!eps_round(p, c.V, F, sh, h ? h->f1 : F->f1, h ? h->build_cutoff : F->build_cutoff, ne, nh, 0, 1, c.G)) break;
     if (ld_coherent(&F->status) != kLatOk) break;
@@ -717,7 +781,7 @@ __device__ __forceinline__ void phase_tail(const DecodeParams& p, const TeamCtx&
   }
   __syncthreads();
   if (tid == 0) {
-    F->ne_snap = min(ld_coherent(&F->n_elist), c.V.tok_cap);
+    F->ne_snap = min(ld_coherent(&F->n_elist), elist_cap(c.V));
     F->nh_snap = min(ld_coherent(&F->n_hlist), kLatTeamHeavy);
   }
 }
@@ -755,21 +819,21 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
   // (persistent kernel: the link counter runs on from the frame's emitting links, so the base stays the frame's first link)
   const int fb = h ? h->f1 : F->f1, l0 = h ? h->l0 : F->link_end;
   const float cutoff = h ? h->build_cutoff : F->build_cutoff;
-  auto eps_link = [&](int i, float cc, int a) {
-    const float tot = cc + p.g.n_w[a];
+  auto eps_link = [&](int i, float cc, int a, float w, int d) {
+    const float tot = cc + w;
     const int li = l0 + wave_alloc(&F->n_link, tot < cutoff);
     if (tot < cutoff) {
       if (li < V.link_cap) {
-        V.lrec[li] = make_int4(i, fb + V.stt[p.g.n_dst[a]], 0, __float_as_int(p.g.n_w[a]));
+        V.lrec[li] = make_int4(i, fb + V.stt[d], 0, __float_as_int(w));
         V.lac[li] = 0.f;
       } else {
         st_coherent(&F->status, (int32_t)kLatLinkOverflow);
       }
     }
   };
-  for_each_arc(sh, V.elist, h ? min(h->ne, V.tok_cap) : F->ne_snap, V.ts, p.g.n_off,
-               [&](int i, float* cc) { *cc = dec_cost(V.stc[V.ts[i]]); return *cc < cutoff; },
-               eps_link, team_entry(c.wg, c.G), c.G * kLatThreads);
+  for_each_eps_record(sh, p, V, h ? min(h->ne, elist_cap(V)) : F->ne_snap,
+                      [&](int i, int s, float* cc) { *cc = dec_cost(V.stc[s]); return *cc < cutoff; },
+                      eps_link, team_entry(c.wg, c.G), c.G * kLatThreads);
   team_heavy_arcs(p, V, F, sh, h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G, cutoff, false, eps_link);
   // final costs and arc ranges of the new tokens (the state table is cleared by the next frame's list launch)
   const int cnt_new = min(h ? h->n_new : F->n_new, V.tok_cap - fb);
