@@ -39,6 +39,11 @@ namespace pk2 {
 template <typename T>
 __device__ __forceinline__ void st_coherent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Workgroup barrier for data exchanged through LDS only: __syncthreads() is a full fence that begins with s_waitcnt vmcnt(0),
+// i.e. it waits for every global load, store and atomic the wave has in flight -- a round trip to L2 per barrier in a phase
+// whose next loads do not depend on them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 
 // The hot fields of the frame record as every workgroup of a PERSISTENT team holds them in its LDS (round 6): they are
 // handed over inside the release words of the team barriers (lat_team_barrier_hand) or follow from values every workgroup
@@ -140,10 +145,11 @@ __device__ __forceinline__ int team_entry(int wg, int G) {
 
 // A token whose state has more than kHeavyDegree epsilon arcs joins the team's heavy list (false: the list is full, the
 // token stays on the ordinary epsilon list and its owner walks the arcs).
-__device__ __forceinline__ bool team_register_heavy(LatFrame* F, int G, int tok) {
+__device__ __forceinline__ bool team_register_heavy(LatFrame* F, int G, int tok, int state, int a0, int deg) {
   const int h = atomicAdd(&F->n_hlist, 1);
   if (h >= kLatTeamHeavy) return false;
   F->hlist[h] = tok;
+  *reinterpret_cast<int4*>(&F->hrec[4 * h]) = make_int4(tok, state, a0, deg);
   for (int w = 0; w < G; ++w) F->hlast[h * kLatMaxTeam + w] = INFINITY;
   return true;
 }
@@ -166,6 +172,45 @@ __device__ __forceinline__ void wave_alloc_n2(int32_t* counter_a, int count_a, i
   }
   *first_a = __shfl(base_a, 63, 64) + ia - count_a;
   *first_b = __shfl(base_b, 63, 64) + ib - count_b;
+}
+
+// The same for a whole WORKGROUP: NC team-wide counters, one atomic per counter and workgroup.  (Round 6: the 224 waves of a
+// team reserving token, link and epsilon-list slots with one atomic per wave and counter -- all on the cache line of the frame
+// record -- queued behind each other in L2: 2.6 + 3.5 us of the expand phase's 7.)  scr: 64 ints of LDS; every thread of the
+// workgroup calls (LDS-only barriers inside: requests in flight stay in flight).
+template <int NC>
+__device__ __forceinline__ void block_alloc(int* scr, int32_t* c0, int32_t* c1, const int (&count)[NC], int (&first)[NC]) {
+  static_assert(NC == 1 || NC == 2, "one or two counters");
+  const int lane = lat_tid() & 63, w = lat_tid() >> 6;
+  int incl[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) incl[k] = count[k];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int y = __shfl_up(incl[k], o, 64);
+      if (lane >= o) incl[k] += y;
+    }
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) scr[k * kLatWaves + w] = incl[k];
+  }
+  lds_barrier();
+  if (w == 0 && lane < NC) {
+    int tot = 0;
+    for (int q = 0; q < kLatWaves; ++q) tot += scr[lane * kLatWaves + q];
+    scr[2 * kLatWaves + lane] = tot > 0 ? atomicAdd(lane == 0 ? c0 : c1, tot) : 0;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    int before = scr[2 * kLatWaves + k];
+    for (int q = 0; q < w; ++q) before += scr[k * kLatWaves + q];
+    first[k] = before + incl[k] - count[k];
+  }
+  lds_barrier();
 }
 
 // The team's epsilon list holds RECORDS (round 6): {token, state} {first epsilon arc, epsilon degree} -- what a relaxation
@@ -196,7 +241,7 @@ __device__ __forceinline__ void team_register_token(const DecodeParams& p, const
       V.tc[fb + idx] = INFINITY;
       st_coherent(&V.stt[d], idx);
       eps = deg > 0;
-      if (deg > kHeavyDegree && team_register_heavy(F, G, fb + idx)) eps = false;
+      if (deg > kHeavyDegree && team_register_heavy(F, G, fb + idx, d, a0, deg)) eps = false;
     } else {
       st_coherent(&F->status, (int32_t)kLatTokenOverflow);
     }
@@ -229,7 +274,7 @@ __device__ __forceinline__ void for_each_eps_record(Shared& sh, const DecodePara
     if (e1.y > 1) body(e0.x, c, a0 + 1, w1, d1);
     for (int a = a0 + 2; a < a1; ++a) body(e0.x, c, a, p.g.n_w[a], p.g.n_dst[a]);
   }
-  __syncthreads();
+  lds_barrier();
   const int nh = min(sh.n_heavy, kMaxHeavy);
   for (int h = 0; h < nh; ++h) {
     const int i = sh.heavy_tok[h];
@@ -237,48 +282,52 @@ __device__ __forceinline__ void for_each_eps_record(Shared& sh, const DecodePara
     const int s = V.ts[i];
     for (int a = p.g.n_off[s] + tid; a < p.g.n_off[s + 1]; a += kLatThreads) body(i, c, a, p.g.n_w[a], p.g.n_dst[a]);
   }
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) sh.n_heavy = 0;
-  __syncthreads();
+  lds_barrier();
 }
 
 // The arcs of the team's heavy tokens [0, nh): workgroup wg of G walks arcs wg * 1024 + thread, + G * 1024, ... of each.
 // track: a relaxation round -- the share is walked only if the token got cheaper since THIS workgroup last walked it
 // (slots of the team of Gteam workgroups; the single workgroup of the tail pass, G = 1, walks everything when any share is
 // behind and brings all slots up to date).  Contains workgroup barriers.
+// Round 6: the tokens' records, costs and verdicts are fetched by nh lanes side by side (record -> cost: two dependent round
+// trips for the whole list, where one thread took three per token with the workgroup waiting at a barrier), and handed to
+// the workgroup through LDS.
 template <typename Body>
 __device__ __forceinline__ void team_heavy_arcs(const DecodeParams& p, const UttView& V, LatFrame* F, Shared& sh, int nh,
                                                 int wg, int G, int Gteam, float cutoff, bool track, Body body) {
+  if (nh <= 0) return;
   const int tid = lat_tid();
-  for (int h = 0; h < nh; ++h) {
-    const int i = F->hlist[h];
-    const int s = V.ts[i];
-    if (tid == 0) {
-      const float cc = dec_cost(ld_coherent(&V.stc[s]));
-      bool act = cc < cutoff;
-      if (track && act) {
-        float* last = F->hlast + h * kLatMaxTeam;
-        if (G == Gteam) {
-          act = cc < last[wg];
-          if (act) last[wg] = cc;
-        } else {
-          float behind = last[0];
-          for (int w = 1; w < Gteam; ++w) behind = fmaxf(behind, last[w]);
-          act = cc < behind;
-          if (act) for (int w = 0; w < Gteam; ++w) last[w] = cc;
-        }
+  // sh.heavy_tok[0..4 nh): {token, first arc, last arc + 1, walk it}, sh.heavy_cost[h]: the token's cost
+  if (tid < nh) {
+    const int h = tid;
+    const int4 r = *reinterpret_cast<const int4*>(&F->hrec[4 * h]);
+    const float cc = dec_cost(ld_coherent(&V.stc[r.y]));
+    bool act = cc < cutoff;
+    if (track && act) {
+      float* last = F->hlast + h * kLatMaxTeam;
+      if (G == Gteam) {
+        act = cc < last[wg];
+        if (act) last[wg] = cc;
+      } else {
+        float behind = last[0];
+        for (int w = 1; w < Gteam; ++w) behind = fmaxf(behind, last[w]);
+        act = cc < behind;
+        if (act) for (int w = 0; w < Gteam; ++w) last[w] = cc;
       }
-      sh.heavy_cost[0] = cc;
-      sh.heavy_tok[0] = act ? 1 : 0;
     }
-    __syncthreads();
-    const float cc = sh.heavy_cost[0];
-    const bool act = sh.heavy_tok[0] != 0;
-    __syncthreads();
-    if (act)
-      for (int a = p.g.n_off[s] + wg * kLatThreads + tid; a < p.g.n_off[s + 1]; a += G * kLatThreads)
-        body(i, cc, a, p.g.n_w[a], p.g.n_dst[a]);
+    sh.heavy_cost[h] = cc;
+    sh.heavy_tok[4 * h] = r.x; sh.heavy_tok[4 * h + 1] = r.z; sh.heavy_tok[4 * h + 2] = r.z + r.w; sh.heavy_tok[4 * h + 3] = act ? 1 : 0;
   }
+  lds_barrier();
+  for (int h = 0; h < nh; ++h) {
+    if (!sh.heavy_tok[4 * h + 3]) continue;
+    const int i = sh.heavy_tok[4 * h], a1 = sh.heavy_tok[4 * h + 2];
+    const float cc = sh.heavy_cost[h];
+    for (int a = sh.heavy_tok[4 * h + 1] + wg * kLatThreads + tid; a < a1; a += G * kLatThreads) body(i, cc, a, p.g.n_w[a], p.g.n_dst[a]);
+  }
+  lds_barrier();
 }
 
 // One relaxation round over the epsilon-list entries [0, ne) owned by this workgroup and its share of the heavy tokens
@@ -340,10 +389,13 @@ __global__ void lat_frames_init(const DecodeParams p, int G) { phase_init(p, blo
 // a second pass collects that bin's members (a handful) in LDS, where each is ranked against the others.
 // Returns false when at most k costs lie below hi.  Falls back to kth_smallest_in_range for a crowded bin.
 #ifdef PK2_LATP_PROFILE
-__device__ long long g_cut[8];
+__device__ long long g_cut[8], g_exp[8];
+// (expand's stages on rank 1 of utterance 1, each behind a full wait: what a stage's requests take to come back)
+#define EXP_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lat_tid() == 0 && c.wg == 1 && c.n == 1) { const long long n_ = wall_clock64(); g_exp[k] += n_ - exp_last; exp_last = n_; } } while (0)
 #define CUT_T(k) do { if (lat_tid() == 0) { const long long n_ = wall_clock64(); g_cut[k] += n_ - cut_last; cut_last = n_; } } while (0)
 #else
 #define CUT_T(k) do { } while (0)
+#define EXP_T(k) do { } while (0)
 #endif
 __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, Shared& sh, float* out) {
   const int tid = lat_tid(), lane = tid & 63, w = tid >> 6;
@@ -605,7 +657,7 @@ __device__ __forceinline__ unsigned expand_last(const TeamCtx& c) {
 }
 
 // ---- tokens and emitting links of frame t+1 ----
-__device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCtx& c, int& s_flag, bool defer = false) {
+__device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCtx& c, int& s_flag, int* s_scr, bool defer = false) {
   if (!c.live || c.t < 0) return;
   const int tid = lat_tid();
   const UttView& V = c.V;
@@ -624,8 +676,12 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
   // Waves stay whole (the loop bound is the wave's first lane) so that slots can be reserved with one atomic per
   // wave and counter, and the independent requests of a pass are all in flight together: costs + work items ->
   // arc records -> atomicMin on the table and the link slots -> token slots and the epsilon test -> epsilon slots.
-  for (int jw = c.wg * kLatThreads + (tid & ~63); jw < n_arcs; jw += 4 * stride) {
-    const int j0 = jw + (tid & 63);
+#ifdef PK2_LATP_PROFILE
+  long long exp_last = wall_clock64();
+#endif
+  // (the workgroup's threads stay together: slots are reserved by the workgroup)
+  for (int jb = c.wg * kLatThreads; jb < n_arcs; jb += 4 * stride) {
+    const int j0 = jb + tid;
     float2 tc2[4]; int2 wk[4]; int4 er[4]; uint32_t old[4]; bool acc[4], made[4], eps[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -633,6 +689,7 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
       acc[q] = j < n_arcs;
       if (acc[q]) { tc2[q] = wcost[j]; wk[q] = V.work[j]; er[q] = make_int4(wdst[j], wtid[j], wgc[j], 0); }
     }
+    EXP_T(0);
     int n_acc = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -650,7 +707,14 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
         deg[q] = p.g.n_off[er[q].x + 1] - ea0[q];
       }
     }
-    int li = l0 + wave_alloc_n(&F->n_link, n_acc);
+    int li;
+    {
+      const int cnt[1] = {n_acc};
+      int fst[1];
+      block_alloc<1>(s_scr, &F->n_link, nullptr, cnt, fst);
+      li = l0 + fst[0];
+    }
+    EXP_T(1);
     int n_made = 0, n_eps = 0;
     bool heavy[4];
 #pragma unroll
@@ -663,7 +727,13 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
     }
     // one hop: token slots and epsilon-list slots together
     int ti, ei;
-    wave_alloc_n2(&F->n_new, n_made, &F->n_elist, n_eps, &ti, &ei);
+    {
+      const int cnt[2] = {n_made, n_eps};
+      int fst[2];
+      block_alloc<2>(s_scr, &F->n_new, &F->n_elist, cnt, fst);
+      ti = fst[0]; ei = fst[1];
+    }
+    EXP_T(2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!acc[q]) continue;
@@ -676,7 +746,7 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
             elist_put(V, F, ei, fb + ti, er[q].x, ea0[q], deg[q]);
             ++ei;
           }
-          if (heavy[q] && !team_register_heavy(F, c.G, fb + ti)) {      // (rare; the list is full: an ordinary entry)
+          if (heavy[q] && !team_register_heavy(F, c.G, fb + ti, er[q].x, ea0[q], deg[q])) {      // (rare; the list is full: an ordinary entry)
             const int e = atomicAdd(&F->n_elist, 1);
             elist_put(V, F, e, fb + ti, er[q].x, ea0[q], deg[q]);
           }
@@ -693,12 +763,13 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
       }
       ++li;
     }
+    EXP_T(3);
   }
   if (!defer && team_last(F, c.G, &s_flag) && tid == 0) expand_last(c);
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_expand(const DecodeParams p, const StepCounter* cnt, int local) {
-  __shared__ int s_flag;
-  phase_expand(p, team_ctx(p, cnt, local), s_flag);
+  __shared__ int s_flag, s_scr[64];
+  phase_expand(p, team_ctx(p, cnt, local), s_flag, s_scr);
 }
 
 // (round0_last / round_last return the round's "a cost was lowered" flag, close_last "the utterance's status is not ok")
@@ -729,9 +800,10 @@ __device__ __forceinline__ void phase_round0(const DecodeParams& p, const TeamCt
   LatFrame* F = c.F;
   if (tid == 0) sh.n_heavy = 0;
   const Hot* h = c.hot;
-  const int fb = h ? h->f1 : F->f1, l0 = h ? h->l0 : F->link_end, nl = min(h ? h->n_link : F->n_link, V.link_cap - l0);
-  for (int l = l0 + c.wg * kLatThreads + tid; l < l0 + nl; l += c.G * kLatThreads) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
-  __syncthreads();
+  // (the emitting links' destinations, state -> token index, are resolved in the close phase, inside a chain of loads that
+  // is there anyway; here they were two dependent round trips in front of the relaxation)
+  const int fb = h ? h->f1 : F->f1;
+  lds_barrier();
   const int changed = eps_round(p, V, F, sh, fb, h ? h->build_cutoff : F->build_cutoff, h ? min(h->ne, elist_cap(V)) : F->ne_snap,
                                 h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
   if (changed && tid == 0) st_coherent(&F->changed[0], 1);
@@ -750,7 +822,7 @@ __device__ __forceinline__ void phase_round(const DecodeParams& p, const TeamCtx
   if (!defer && !F->changed[r - 1]) return;          // (the persistent kernel has the flag from the barrier's release word)
   const int tid = lat_tid();
   if (tid == 0) sh.n_heavy = 0;
-  __syncthreads();
+  lds_barrier();
   const Hot* h = c.hot;
   const int changed = eps_round(p, c.V, F, sh, h ? h->f1 : F->f1, h ? h->build_cutoff : F->build_cutoff,
                                 h ? min(h->ne, elist_cap(c.V)) : F->ne_snap, h ? min(h->nh, kLatTeamHeavy) : F->nh_snap, c.wg, c.G, c.G);
@@ -814,7 +886,7 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
   const UttView& V = c.V;
   LatFrame* F = c.F;
   if (tid == 0) sh.n_heavy = 0;
-  __syncthreads();
+  lds_barrier();
   const Hot* h = c.hot;
   // (persistent kernel: the link counter runs on from the frame's emitting links, so the base stays the frame's first link)
   const int fb = h ? h->f1 : F->f1, l0 = h ? h->l0 : F->link_end;
@@ -839,6 +911,18 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
   const int cnt_new = min(h ? h->n_new : F->n_new, V.tok_cap - fb);
   uint32_t kmin = kEmpty;
   const int stride = c.G * kLatThreads;
+  // The frame's emitting links [le0, le1) still name their destination STATE: state -> token index here, the first two links
+  // of a thread inside the token loop's own chain of loads (state, then table entry, then stores).
+  int le0 = 0, le1 = 0;
+  if (c.t >= 0) {
+    if (h) { le0 = h->l0; le1 = le0 + min(h->n_link, V.link_cap - le0); }
+    else { le0 = V.seg[2 * c.t + 1]; le1 = V.seg[2 * c.t + 2]; }
+  }
+  const int la = le0 + c.wg * kLatThreads + tid, lb = la + stride;
+  int ls0 = 0, ls1 = 0;
+  if (la < le1) ls0 = V.lrec[la].y;
+  if (lb < le1) ls1 = V.lrec[lb].y;
+  bool links_pending = la < le1;
   for (int i0 = fb + c.wg * kLatThreads + tid; i0 < fb + cnt_new; i0 += 4 * stride) {
     int st[4]; uint32_t ck[4]; int a0[4], a1[4];
 #pragma unroll
@@ -846,6 +930,8 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (i0 + q * stride < fb + cnt_new) { ck[q] = V.stc[st[q]]; a0[q] = p.g.e_off[st[q]]; a1[q] = p.g.e_off[st[q] + 1]; }
+    int lt0 = 0, lt1 = 0;
+    if (links_pending) { lt0 = V.stt[ls0]; if (lb < le1) lt1 = V.stt[ls1]; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = i0 + q * stride;
@@ -856,7 +942,17 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
         kmin = min(kmin, ck[q]);
       }
     }
+    if (links_pending) {
+      V.lrec[la].y = fb + lt0;
+      if (lb < le1) V.lrec[lb].y = fb + lt1;
+      links_pending = false;
+    }
   }
+  if (links_pending) {                  // (no token of the loop above was this thread's)
+    V.lrec[la].y = fb + V.stt[ls0];
+    if (lb < le1) V.lrec[lb].y = fb + V.stt[ls1];
+  }
+  for (int l = la + 2 * stride; l < le1; l += stride) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
   if ((tid & 63) == 0 && kmin != kEmpty) atomicMin(&F->best_next, kmin);
@@ -1114,8 +1210,11 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
                 })) return false;
       LPH(3);
       // ---- expand ----
-      phase_expand(p, c, s_flag, true);
+      phase_expand(p, c, s_flag, reinterpret_cast<int*>(sh.hist), true);
       LPH(4);
+#ifdef PK2_LATP_PROFILE
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); LPH(10);     // (tail slot: the phase's drain)
+#endif
       if (!hand([&]() -> u64 { const int a = ld_coherent(&F->n_link), b = ld_coherent(&F->n_elist), d = ld_coherent(&F->n_hlist);
                                return (fld(a, kF23, &F->hand[0]) << 28) | (fld(b, kF23, &F->hand[1]) << 5) | (u64)min(d, kLatTeamHeavy); },
                 [](u64) { },
@@ -1277,7 +1376,7 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
         LP_T(2);
         if (!lat_team_barrier(ctl, tm, G, &nbar, &s_abort, inv_mode)) return;
         LP_T(3);
-        phase_expand(p, c, s_flag, kMergeLast);
+        phase_expand(p, c, s_flag, reinterpret_cast<int*>(sh.hist), kMergeLast);
         LP_T(4);
         LAT_BARRIER_LAST(expand_last(c));
         LP_T(5);
@@ -1313,9 +1412,12 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
 #endif
 #ifdef PK2_LATP_PROFILE
     if (tid == 0 && rank == 0 && n == 0)
+      printf("expand stages, rank 1 of utterance 1, 10 ns ticks per frame: loads %lld | table atomics + link slots %lld | token slots %lld | stores %lld\n",
+             g_exp[0] / 1613, g_exp[1] / 1613, g_exp[2] / 1613, g_exp[3] / 1613);
+    if (tid == 0 && rank == 0 && n == 0)
       printf("kth_below, 10 ns ticks per frame: zero hist %lld | pass 1 %lld | scan %lld | pass 2 %lld | rank %lld\n", g_cut[0] / lp_frames,
              g_cut[1] / lp_frames, g_cut[2] / lp_frames, g_cut[3] / lp_frames, g_cut[4] / lp_frames);
-    if (tid == 0 && (rank < 2 && n == 0 || rank == 1))
+    if (tid == 0 && n == 1)
       printf("lat_frames_persist rank %d utt %d, %d frames, 10 ns ticks per frame: cutoff %lld bar %lld | list %lld bar %lld | expand %lld bar %lld | round0 %lld bar %lld | rounds %lld bar %lld | tail %lld bar %lld | close %lld bar %lld\n",
              rank, n, lp_frames, lp_acc[0] / lp_frames, lp_acc[1] / lp_frames, lp_acc[2] / lp_frames, lp_acc[3] / lp_frames, lp_acc[4] / lp_frames,
              lp_acc[5] / lp_frames, lp_acc[6] / lp_frames, lp_acc[7] / lp_frames, lp_acc[8] / lp_frames, lp_acc[9] / lp_frames, lp_acc[10] / lp_frames,

@@ -71,6 +71,7 @@ struct LatFrame {
   // waited: 6 of the 9 us of every relaxation round).  hlast[h][w] = the token's cost when workgroup w last walked its share.
   int32_t n_hlist, nh_snap;
   int32_t hlist[kLatTeamHeavy];
+  int32_t hrec[kLatTeamHeavy * 4];   // {token, state, first epsilon arc, epsilon degree} of the list's tokens (team decoder)
   float hlast[kLatTeamHeavy * kLatMaxTeam];
   const float* ll_base;        // the utterance's log-likelihood rows (kept out of the graph-baked parameters)
   int64_t ll_stride;
