@@ -233,21 +233,27 @@ __device__ __forceinline__ void elist_put(const UttView& V, LatFrame* F, int e, 
 // create = false.
 __device__ __forceinline__ void team_register_token(const DecodeParams& p, const UttView& V, LatFrame* F, int G, int fb, int d,
                                                     int a0, int deg, bool create = true) {
+  // (both reservations are requested before either answer is used: one round trip; a state with very many arcs asks for the
+  // team's heavy list first and for an epsilon-list slot only when that list is full)
+  const bool light = create && deg > 0 && deg <= kHeavyDegree;
   const int idx = wave_alloc(&F->n_new, create);
-  bool eps = false;
+  int e = wave_alloc(&F->n_elist, light);
   if (create) {
     if (fb + idx < V.tok_cap) {
       V.ts[fb + idx] = d;
       V.tc[fb + idx] = INFINITY;
       st_coherent(&V.stt[d], idx);
-      eps = deg > 0;
-      if (deg > kHeavyDegree && team_register_heavy(F, G, fb + idx, d, a0, deg)) eps = false;
+      if (light) {
+        elist_put(V, F, e, fb + idx, d, a0, deg);
+      } else if (deg > kHeavyDegree && !team_register_heavy(F, G, fb + idx, d, a0, deg)) {
+        e = atomicAdd(&F->n_elist, 1);
+        elist_put(V, F, e, fb + idx, d, a0, deg);
+      }
     } else {
       st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+      if (light) elist_put(V, F, e, 0, d, a0, deg);      // (the reserved slot must hold valid indices; the utterance is decoded again)
     }
   }
-  const int e = wave_alloc(&F->n_elist, eps);
-  if (eps) elist_put(V, F, e, fb + idx, d, a0, deg);
 }
 
 // body(token, cost, arc, arc weight, arc destination) for the epsilon arcs of the list's records [first, first + stride, ..)
@@ -752,6 +758,7 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
           }
         } else {
           st_coherent(&F->status, (int32_t)kLatTokenOverflow);
+          if (eps[q]) { elist_put(V, F, ei, 0, er[q].x, ea0[q], deg[q]); ++ei; }   // (a reserved slot holds valid indices)
         }
         ++ti;
       }
@@ -955,7 +962,14 @@ __device__ __forceinline__ void phase_close(const DecodeParams& p, const TeamCtx
   for (int l = la + 2 * stride; l < le1; l += stride) V.lrec[l].y = fb + V.stt[V.lrec[l].y];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-  if ((tid & 63) == 0 && kmin != kEmpty) atomicMin(&F->best_next, kmin);
+  // (one atomic per workgroup: 256 of them on the frame record's cache line took microseconds to drain)
+  if ((tid & 63) == 0) sh.redi[tid >> 6] = (int)kmin;
+  lds_barrier();
+  if (tid == 0) {
+    uint32_t m = kEmpty;
+    for (int w = 0; w < kLatWaves; ++w) m = min(m, (uint32_t)sh.redi[w]);
+    if (m != kEmpty) atomicMin(&F->best_next, m);
+  }
   if (!defer && team_last(F, c.G, &s_flag) && tid == 0) close_last(c);
 }
 __global__ void __launch_bounds__(kLatThreads) lat_frames_close(const DecodeParams p, const StepCounter* cnt, int local) {
