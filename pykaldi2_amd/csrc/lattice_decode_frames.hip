@@ -396,11 +396,15 @@ __global__ void lat_frames_init(const DecodeParams p, int G) { phase_init(p, blo
 // Returns false when at most k costs lie below hi.  Falls back to kth_smallest_in_range for a crowded bin.
 #ifdef PK2_LATP_PROFILE
 __device__ long long g_cut[8], g_exp[8];
-// (expand's stages on rank 1 of utterance 1, each behind a full wait: what a stage's requests take to come back)
-#define EXP_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lat_tid() == 0 && c.wg == 1 && c.n == 1) { const long long n_ = wall_clock64(); g_exp[k] += n_ - exp_last; exp_last = n_; } } while (0)
 #define CUT_T(k) do { if (lat_tid() == 0) { const long long n_ = wall_clock64(); g_cut[k] += n_ - cut_last; cut_last = n_; } } while (0)
 #else
 #define CUT_T(k) do { } while (0)
+#endif
+#if defined(PK2_LATP_PROFILE) && defined(PK2_LATP_EXPAND)
+// (-DPK2_LATP_EXPAND: expand's stages on rank 1 of utterance 1, each behind a full wait: what a stage's requests take to come
+// back; the waits lengthen the phase, so the phase table is taken without this)
+#define EXP_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lat_tid() == 0 && c.wg == 1 && c.n == 1) { const long long n_ = wall_clock64(); g_exp[k] += n_ - exp_last; exp_last = n_; } } while (0)
+#else
 #define EXP_T(k) do { } while (0)
 #endif
 __device__ bool kth_below(const float* cost, int n, int k, float lo, float hi, Shared& sh, float* out) {
@@ -682,7 +686,7 @@ __device__ __forceinline__ void phase_expand(const DecodeParams& p, const TeamCt
   // Waves stay whole (the loop bound is the wave's first lane) so that slots can be reserved with one atomic per
   // wave and counter, and the independent requests of a pass are all in flight together: costs + work items ->
   // arc records -> atomicMin on the table and the link slots -> token slots and the epsilon test -> epsilon slots.
-#ifdef PK2_LATP_PROFILE
+#if defined(PK2_LATP_PROFILE) && defined(PK2_LATP_EXPAND)
   long long exp_last = wall_clock64();
 #endif
   // (the workgroup's threads stay together: slots are reserved by the workgroup)
@@ -1226,7 +1230,7 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
       // ---- expand ----
       phase_expand(p, c, s_flag, reinterpret_cast<int*>(sh.hist), true);
       LPH(4);
-#ifdef PK2_LATP_PROFILE
+#if defined(PK2_LATP_PROFILE) && defined(PK2_LATP_EXPAND)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); LPH(10);     // (tail slot: the phase's drain)
 #endif
       if (!hand([&]() -> u64 { const int a = ld_coherent(&F->n_link), b = ld_coherent(&F->n_elist), d = ld_coherent(&F->n_hlist);
