@@ -1095,7 +1095,7 @@ __device__ __forceinline__ bool lat_team_barrier_last(LatTeamCtl* ctl, LatTeamCt
 // sent as all-ones and the receivers read the counter themselves (kField*: 2^23 - 1 tokens or links in ONE frame).
 // Release numbers are compared for equality on 7 bits: a workgroup is never more than one release behind the word.
 constexpr unsigned kRelMask = 127u;
-constexpr unsigned long long kF23 = (1ull << 23) - 1ull, kF25 = (1ull << 25) - 1ull;
+constexpr unsigned long long kMask23 = (1ull << 23) - 1ull, kMask25 = (1ull << 25) - 1ull;
 // (sender: a value that needs more bits goes into the record's hand[slot] -- acknowledged before the release -- and all-ones
 // into the word; receiver: all-ones = read hand[slot], which the next sender touches only after every receiver has arrived at
 // the next barrier)
@@ -1153,7 +1153,10 @@ __device__ __forceinline__ void launder_view(UttView& V, LatFrame*& F) {
 // barriers, read by everybody behind them).  Returns false after an abort.
 __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTeamCtl* ctl, LatTeamCtl::Team* tm, TeamCtx& c, Shared& sh,
                                                    Hot& h, int& s_flag, int& s_base, int& s_abort, unsigned& nbar, unsigned& nrel,
-                                                   unsigned& nsig, int list_first, int inv_mode, long long* lp_acc, int* lp_frames_p) {
+                                                   unsigned& nsig, int list_first, int inv_mode, int field_bits, long long* lp_acc,
+                                                   int* lp_frames_p) {
+  // (the largest count a 23-bit / 25-bit field carries itself; PK2_LAT_FIELD_BITS narrows them so that tests drive the spill path)
+  const unsigned long long kF23 = (1ull << min(max(field_bits, 1), 23)) - 1ull, kF25 = (1ull << min(max(field_bits + 2, 1), 25)) - 1ull;
 #ifdef PK2_LATP_PROFILE
   long long lp_last = 0;
 #define LPH(k) do { const long long n_ = wall_clock64(); lp_acc[k] += n_ - lp_last; lp_last = n_; } while (0)
@@ -1238,7 +1241,7 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
                 [](u64) { },
                 [&](u64 w) {
                   h.n_link = unfld(w >> 28, kF23, &F->hand[0]);
-                  h.ne = unfld((w >> 5) & kF23, kF23, &F->hand[1]);
+                  h.ne = unfld((w >> 5) & kMask23, kF23, &F->hand[1]);
                   h.nh = (int)(w & 31ull);
                 })) return false;
       LPH(5);
@@ -1256,8 +1259,8 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
                 [&](u64) { if (r == 0) V.seg[2 * t + 2] = h.l0 + min(h.n_link, V.link_cap - h.l0); },
                 [&](u64 w) {
                   h.more = (int)((w >> 51) & 1ull);
-                  h.n_new = unfld((w >> 28) & kF23, kF23, &F->hand[0]);
-                  h.ne = unfld((w >> 5) & kF23, kF23, &F->hand[1]);
+                  h.n_new = unfld((w >> 28) & kMask23, kF23, &F->hand[0]);
+                  h.ne = unfld((w >> 5) & kMask23, kF23, &F->hand[1]);
                   h.nh = (int)(w & 31ull);
                 })) return false;
       if (r == 0) LPH(7); else LPH(9);
@@ -1284,7 +1287,7 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
                 for (int r = 0; r <= kLatEpsRounds; ++r) st_coherent(&F->changed[r], 0);
               },
               [&](u64 w) {
-                const int fb = h.f1, a = unfld((w >> 32) & kF23, kF23, &F->hand[0]);
+                const int fb = h.f1, a = unfld((w >> 32) & kMask23, kF23, &F->hand[0]);
                 h.status_bad = (int)((w >> 55) & 1ull);
                 h.l0 = min(h.l0 + a, V.link_cap);
                 h.best_key = (uint32_t)w;
@@ -1298,7 +1301,8 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
   return true;
 }
 
-__global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodeParams p, LatTeamCtl* ctl, int N, int G, int teams_per_xcd, int inv_mode) {
+__global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodeParams p, LatTeamCtl* ctl, int N, int G, int teams_per_xcd, int inv_mode,
+                                                                  int field_bits) {
   __shared__ Shared sh;
   __shared__ int s_flag, s_base, s_abort, s_i[4];
   __shared__ unsigned s_pay;
@@ -1363,9 +1367,9 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
     LatFrame* F = c.F;
 #if PK2_LAT_HOT
 #ifdef PK2_LATP_PROFILE
-    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, lp_acc, &lp_frames)) return;
+    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, field_bits, lp_acc, &lp_frames)) return;
 #else
-    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, nullptr, nullptr)) return;
+    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, field_bits, nullptr, nullptr)) return;
 #endif
 #else
     // Barriers behind a phase with bookkeeping: merged form (the last arriver does the bookkeeping and hands the flag the
@@ -1746,7 +1750,8 @@ static int lat_persist_launch(const DecodeParams& p, int N, int team, hipStream_
   // one team per XCD while the utterances fit (an utterance then has its XCD's L2 to itself), more when there are more
   const int tpx = std::max(1, std::min({32 / team, kLatTeamsPerXcd, (N + 7) / 8}));
   static const int inv_mode = [] { const char* e = getenv("PK2_LAT_INV"); return e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL(lat_frames_persist, dim3(256), dim3(kLatThreads), 0, stream, p, sc.ctl, N, team, tpx, inv_mode);
+  static const int field_bits = [] { const char* e = getenv("PK2_LAT_FIELD_BITS"); return e ? atoi(e) : 23; }();
+  hipLaunchKernelGGL(lat_frames_persist, dim3(256), dim3(kLatThreads), 0, stream, p, sc.ctl, N, team, tpx, inv_mode, field_bits);
   PK2_LAUNCH_CHECK();
   if (g_lat_persist_state_pd.ref() < 0) {          // first use on this device: every utterance done, nobody timed out?
     LatTeamCtl* h = new LatTeamCtl;

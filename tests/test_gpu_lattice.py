@@ -327,12 +327,15 @@ def test_one_workgroup_decoder_variant():
     assert " passed" in out.stdout and "failed" not in out.stdout
 
 
-@pytest.mark.parametrize("env", [dict(PK2_LAT_DECODER="frames"), dict(PK2_LAT_TEAM="8"), dict(PK2_LAT_TEAM="32")],
-                         ids=["launch_per_frame", "persistent_team8", "persistent_team32"])
+@pytest.mark.parametrize("env", [dict(PK2_LAT_DECODER="frames"), dict(PK2_LAT_TEAM="8"), dict(PK2_LAT_TEAM="32"),
+                                 dict(PK2_LAT_FIELD_BITS="3")],
+                         ids=["launch_per_frame", "persistent_team8", "persistent_team32", "persistent_spilled_counts"])
 def test_team_decoder_variants(env):
     """The default decoder runs all frames of an utterance inside one persistent launch (a team of 16 workgroups of one
     XCD); the launch-per-frame decoder (its fallback) and the other team sizes pass the same oracle comparisons in their own
-    processes (the choice is read once per process)."""
+    processes (the choice is read once per process).  PK2_LAT_FIELD_BITS=3: the counts that travel inside the team barriers'
+    release words (links, tokens, epsilon entries of a frame) get 3-bit fields, so nearly every one of them takes the spill
+    slot of the frame record instead -- the path a frame with more than 2^23 links would take."""
     import os
     import subprocess
     import sys
