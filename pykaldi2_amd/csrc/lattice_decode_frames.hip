@@ -1153,8 +1153,8 @@ __device__ __forceinline__ void launder_view(UttView& V, LatFrame*& F) {
 // barriers, read by everybody behind them).  Returns false after an abort.
 __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTeamCtl* ctl, LatTeamCtl::Team* tm, TeamCtx& c, Shared& sh,
                                                    Hot& h, int& s_flag, int& s_base, int& s_abort, unsigned& nbar, unsigned& nrel,
-                                                   unsigned& nsig, int list_first, int inv_mode, int field_bits, long long* lp_acc,
-                                                   int* lp_frames_p) {
+                                                   unsigned& nsig, int list_first, int inv_mode, int field_bits, int test_stall,
+                                                   long long* lp_acc, int* lp_frames_p) {
   // (the largest count a 23-bit / 25-bit field carries itself; PK2_LAT_FIELD_BITS narrows them so that tests drive the spill path)
   const unsigned long long kF23 = (1ull << min(max(field_bits, 1), 23)) - 1ull, kF25 = (1ull << min(max(field_bits + 2, 1), 25)) - 1ull;
 #ifdef PK2_LATP_PROFILE
@@ -1184,6 +1184,9 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
   for (int t = -1; t < T; ++t) {
     c.t = t;
     launder_view(c.V, c.F);
+    // (test hook, PK2_LAT_TEST_STALL=1: one workgroup of every team walks away in frame 2 -- its team mates must give up after
+    // the poll's time-out, the check kernel behind the launch must report every utterance "not decoded" and raise the guard)
+    if (test_stall && rank == G - 1 && t == 2) return false;
 #ifdef PK2_LATP_PROFILE
     lp_last = wall_clock64(); ++*lp_frames_p;
 #endif
@@ -1302,7 +1305,7 @@ __device__ __forceinline__ bool persist_frames_hot(const DecodeParams& p, LatTea
 }
 
 __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodeParams p, LatTeamCtl* ctl, int N, int G, int teams_per_xcd, int inv_mode,
-                                                                  int field_bits) {
+                                                                  int field_bits, int test_stall) {
   __shared__ Shared sh;
   __shared__ int s_flag, s_base, s_abort, s_i[4];
   __shared__ unsigned s_pay;
@@ -1367,9 +1370,9 @@ __global__ void __launch_bounds__(kLatThreads) lat_frames_persist(const DecodePa
     LatFrame* F = c.F;
 #if PK2_LAT_HOT
 #ifdef PK2_LATP_PROFILE
-    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, field_bits, lp_acc, &lp_frames)) return;
+    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, field_bits, test_stall, lp_acc, &lp_frames)) return;
 #else
-    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, field_bits, nullptr, nullptr)) return;
+    if (!persist_frames_hot(p, ctl, tm, c, sh, s_hot, s_flag, s_base, s_abort, nbar, nrel, nsig, list_first, inv_mode, field_bits, test_stall, nullptr, nullptr)) return;
 #endif
 #else
     // Barriers behind a phase with bookkeeping: merged form (the last arriver does the bookkeeping and hands the flag the
@@ -1751,7 +1754,10 @@ static int lat_persist_launch(const DecodeParams& p, int N, int team, hipStream_
   const int tpx = std::max(1, std::min({32 / team, kLatTeamsPerXcd, (N + 7) / 8}));
   static const int inv_mode = [] { const char* e = getenv("PK2_LAT_INV"); return e ? atoi(e) : 1; }();
   static const int field_bits = [] { const char* e = getenv("PK2_LAT_FIELD_BITS"); return e ? atoi(e) : 23; }();
-  hipLaunchKernelGGL(lat_frames_persist, dim3(256), dim3(kLatThreads), 0, stream, p, sc.ctl, N, team, tpx, inv_mode, field_bits);
+  const char* stall_env = getenv("PK2_LAT_TEST_STALL");         // (read per launch: a test switches it on for one call)
+  const int test_stall = stall_env && atoi(stall_env) != 0 ? 1 : 0;
+  hipLaunchKernelGGL(lat_frames_persist, dim3(256), dim3(kLatThreads), 0, stream, p, sc.ctl, N, team, tpx, inv_mode, field_bits,
+                     test_stall);
   PK2_LAUNCH_CHECK();
   if (g_lat_persist_state_pd.ref() < 0) {          // first use on this device: every utterance done, nobody timed out?
     LatTeamCtl* h = new LatTeamCtl;

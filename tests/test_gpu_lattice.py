@@ -386,6 +386,64 @@ def test_persistent_decoder_is_in_use():
         assert state == 1
 
 
+STALL_WORKER = r'''
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from pykaldi2_amd import _lib, lattice, synth
+g = synth.decoding_graph_arcs(30, 40, seed=3)
+tm = synth.transition_model_arrays(40)
+o = lattice.LatticeFasterDecoderOptions(beam=10.0, lattice_beam=5.0, max_active=2 ** 31 - 1, min_active=200)
+rec = lattice.MappedLatticeFasterRecognizer(lattice.TransitionModel.from_arrays(tm), g, 1.0, o)
+x = torch.from_numpy(np.random.default_rng(5).standard_normal((3, 25, 40)).astype(np.float32)).cuda()
+lens = [25, 11, 18]
+def canon(lat, n):
+    a = lat.export(n)
+    return sorted(zip(a["tok_frame"].tolist(), a["tok_state"].tolist(), a["tok_cost"].tolist())), len(a["link_src"])
+lat = rec.decode_batch(x, lens)            # (the first launch of a process is verified on the host)
+lat = rec.decode_batch(x, lens)
+assert (lat.status == 0).all()
+want = [canon(lat, n) for n in range(3)]
+state, abort = lattice.persistent_decoder_status()
+assert state == 1 and abort == 0 and not _lib.persist_guard_raised()
+os.environ["PK2_LAT_TEST_STALL"] = "1"
+t0 = time.time()
+try:
+    rec.decode_batch(x, lens)
+    raised = False
+except RuntimeError as e:
+    raised = True
+    msg = str(e)
+dt = time.time() - t0
+del os.environ["PK2_LAT_TEST_STALL"]
+state, abort = lattice.persistent_decoder_status()
+assert raised, "a decode whose team lost a workgroup must not return a lattice"
+assert abort != 0 and _lib.persist_guard_raised(), (state, abort)
+assert 0.9 < dt < 20.0, dt                 # the polls give up after 1 s; nobody hangs
+_lib.check(_lib.lib().pk2_persist_guard_clear())
+lat = rec.decode_batch(x, lens)
+assert (lat.status == 0).all() and [canon(lat, n) for n in range(3)] == want
+print("STALL_OK %%.2f s: %%s" %% (dt, msg[:120]))
+'''
+
+
+def test_persistent_decoder_gives_up_when_a_team_loses_a_workgroup(tmp_path):
+    """The persistent decoder's failure path, in a process of its own (the time-out flag is sticky): PK2_LAT_TEST_STALL=1 makes
+    one workgroup of every team leave in frame 2.  Its team mates must stop polling after the 1 s time-out (barrier release
+    words, the cutoff word), the check kernel behind the launch must mark every utterance "not decoded" and raise the
+    per-device guard, the call must raise instead of returning a lattice -- and the next call, guard cleared, must decode
+    the same lattices as before."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("PK2_LAT_DECODER") in ("frames", "wg"):
+        pytest.skip("the persistent decoder is switched off")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "stall.py"
+    script.write_text(STALL_WORKER % dict(root=root))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "STALL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 FULL_SIZE_WORKER = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %(root)r)
