@@ -288,6 +288,11 @@ int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_
 /* grad *= (*scale_num) / max(1, *count_den) on the device (mean reduction). */
 int pk2_scale_by_count(float* data, int64_t n, float numerator, const int32_t* count_den,
                        void* stream);
+/* out[i] = in[i] * (*mul_dev) / max(1, *count_den_dev) in one pass (either pointer may be NULL = factor 1; out may equal in):
+ * the gradient of nn.CrossEntropyLoss(reduction='mean') times the loss's incoming gradient, both factors on the device
+ * (reference bin/train_ce.py:189-195: loss = criterion(...); loss.backward()). */
+int pk2_scale_by_scalars(const float* in, float* out, int64_t n, const float* mul_dev, const int32_t* count_den_dev,
+                         void* stream);
 
 /* ------------------------------------------------------------------ *
  * f32 MFMA GEMM: C[M,N] (+)= alpha * op(A) * op(B) (+ bias[N]).

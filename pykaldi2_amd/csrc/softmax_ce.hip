@@ -102,9 +102,35 @@ __global__ void scale_by_count_kernel(float* data, int64_t n, float numerator, c
     data[i] *= f;
 }
 
+// out[i] = in[i] * (*mul) / max(1, *count): the two scalings of the CE gradient (1 / valid targets of reduction='mean', the
+// loss's incoming gradient) in ONE pass over the [rows, P] tensor, both factors read from device memory.
+__global__ void scale_by_scalars_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, const float* mul,
+                                        const int32_t* count) {
+  const float f = (mul ? *mul : 1.f) / (count ? (float)max(1, *count) : 1.f);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 ? n / 4 : 0;
+  for (int64_t i = i0; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(in)[i];
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+  for (int64_t i = 4 * n4 + i0; i < n; i += stride) out[i] = in[i] * f;
+}
+
 }  // namespace pk2
 
 using namespace pk2;
+
+extern "C" int pk2_scale_by_scalars(const float* in, float* out, int64_t n, const float* mul, const int32_t* count_den,
+                                    void* stream_) {
+  PK2_REQUIRE(in && out && n >= 0, "scale_by_scalars: bad args");
+  if (n == 0) return PK2_OK;
+  const int blocks = (int)std::min<int64_t>(4096, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(scale_by_scalars_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), in, out, n, mul,
+                     count_den);
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
 
 extern "C" int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_t* targets,
                                       int64_t ignore_index, int64_t rows, int32_t P, float* loss_sum,

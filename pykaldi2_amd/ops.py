@@ -84,20 +84,28 @@ class _CrossEntropyFunction(Function):
         _lib.check(L.pk2_softmax_ce_fwd_bwd(_lib.ptr(x2), P, _lib.ptr(tg), int(ignore_index), rows, P,
                                             _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(grad), P, None,
                                             _lib.stream_ptr(x.device)))
+        # the gradient stays UNSCALED here: 1 / (valid targets) and the loss's incoming gradient are applied together in
+        # backward, in one pass over the [rows, P] tensor (it was a scaling launch here and a torch multiply there: two
+        # read-modify-write passes over 470 MB at the CE configuration)
         if reduction == "mean":
-            _lib.check(L.pk2_scale_by_count(_lib.ptr(grad), grad.numel(), 1.0, _lib.ptr(cnt),
-                                            _lib.stream_ptr(x.device)))
             loss = acc[0] / cnt.to(torch.float32).clamp_min(1.0)[0]
         else:
             loss = acc[0].clone()
-        g = grad.view(x.shape[1], x.shape[0], P).transpose(0, 1) if layout == "tm" else grad.view(x.shape)
-        ctx.save_for_backward(g)
+        ctx.save_for_backward(grad, cnt)
+        ctx.mean = reduction == "mean"
+        ctx.view = (layout, tuple(x.shape), P)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        g, = ctx.saved_tensors
-        return g * grad_out, None, None, None
+        grad, cnt = ctx.saved_tensors
+        layout, shape, P = ctx.view
+        go = grad_out.detach().to(device=grad.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+        out = torch.empty_like(grad)
+        _lib.check(_lib.lib().pk2_scale_by_scalars(_lib.ptr(grad), _lib.ptr(out), grad.numel(), _lib.ptr(go),
+                                                   _lib.ptr(cnt) if ctx.mean else None, _lib.stream_ptr(grad.device)))
+        g = out.view(shape[1], shape[0], P).transpose(0, 1) if layout == "tm" else out.view(shape)
+        return g, None, None, None
 
 
 class CrossEntropyLoss(torch.nn.Module):
