@@ -318,7 +318,7 @@ static void build_persist(int64_t A, int num_rows, const int32_t* key, const int
 // ---- second persistent layout (chain_internal.h: HostPersist2; kernel: chain_den_persist2.hip) ----------------------------
 // Contiguous ranges of whole groups for the kPR ranks, balanced by arcs (+1 per row: every row costs a slot in every list).
 static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const int32_t* group_of_row, int num_groups,
-                            int max_rows_per_rank, HostPersist2* out) {
+                            int max_rows_per_rank, HostPersist2* out, bool by_rows = false) {
   std::vector<int64_t> rarcs(num_rows, 0);
   for (int64_t i = 0; i < A; ++i) rarcs[key[i]]++;
   std::vector<int32_t> grow(num_groups + 1, 0);
@@ -341,10 +341,14 @@ static bool persist2_assign(int64_t A, int num_rows, const int32_t* key, const i
   // weighting, 5.3 -> 6.1 us per frame, profiles/r05_den_sweep.txt mid-round)
   const int64_t spare = (int64_t)(0.92 * (double)kPR * (double)kPSlots) - A - 2 * (int64_t)num_rows;
   const int64_t row_w = num_rows <= 2 * kPT * kPR ? 2 : 2 + std::min<int64_t>(62, std::max<int64_t>(0, spare / std::max(1, num_rows)));
+  // by_rows (round 6): the ranks get equal ROW counts whatever their arcs -- the last resort of a graph whose mean is within a
+  // few rows of the most a workgroup's epilogues handle (S = 65 000: 2031 of 2048), where the greedy deal by cost leaves the
+  // last rank more rows than that; the ranks' uneven arc counts then go to the streamed pieces.
   std::vector<int64_t> gcost(num_groups, 0);
   int64_t total = 0;
   for (int g = 0; g < num_groups; ++g) {
-    for (int r = grow[g]; r < grow[g + 1]; ++r) gcost[g] += rarcs[r] + row_w;
+    if (by_rows) gcost[g] = grow[g + 1] - grow[g];
+    else for (int r = grow[g]; r < grow[g + 1]; ++r) gcost[g] += rarcs[r] + row_w;
     total += gcost[g];
   }
   out->row_begin.assign(kPR + 1, num_rows);
@@ -762,6 +766,12 @@ static void build_persist2(pk2_den_graph* g, int64_t A2, const int32_t* arc_v, c
     if (b.max_groups > lim) continue;
     assigned = true;
     break;
+  }
+  if (!assigned && persist2_assign(A2, V, arc_v, vstate, S, kPMaxRows, &f, true) && persist2_assign(A2, S, src2, nullptr, S, kPMaxRows, &b, true)) {
+    b.max_groups = 0;
+    for (int r = 0; r < kPR; ++r) b.max_groups = std::max(b.max_groups, g->voff[b.row_begin[r + 1]] - g->voff[b.row_begin[r]]);
+    assigned = b.max_groups <= kPMaxRows;
+    if (assigned && getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: ranks dealt by rows (%d / %d rows on the largest)\n", f.max_rows, b.max_rows);
   }
   if (!assigned) { if (getenv("PK2_DP2_DEBUG")) fprintf(stderr, "persist2: bail at line %d\n", __LINE__); return; }
   const int cap = (std::max({f.max_rows, f.max_groups, b.max_rows, b.max_groups, 1}) + 3) / 4 * 4;

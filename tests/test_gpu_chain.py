@@ -367,7 +367,9 @@ def test_large_state_graphs_match_c_oracle(S, A, want_form):
     Round 5: 55 k states -- the LDS layout WITHOUT the pdf arrays ("rows7": the eighth row array
     would cost a table chunk), two chunks taking turns in one buffer -- at 1.0 M arcs and at 0.5 M, which fell to the
     launch-per-frame kernels until the ranks were balanced by rows as well (csrc/chain_graph.hip: persist2_assign); and
-    65 k states, which no persistent layout takes (the launch-per-frame kernels)."""
+    65 k states: the launch-per-frame kernels by default (24.4 us per frame at 1.0 M arcs); since round 6 a persistent layout
+    exists for it as well (ranks dealt by ROWS, 2032 of the 2048 a workgroup handles; five table chunks, six streamed pieces per
+    rank: 28.2 us per frame, so the cost model does not pick it) and the forced run below checks it against the same oracle."""
     from oracle import chain_c
     P = 6048
     g = synth.den_graph_arcs(S, A, P, seed=1, loop_pdf_differs=True)
@@ -390,6 +392,7 @@ def test_large_state_graphs_match_c_oracle(S, A, want_form):
         finally:
             os.environ.pop("PK2_DEN_PERSIST", None)
     assert results["0"][0] == 1                                   # the launch-per-frame kernels
+    assert results["2"][1] == 2, results["2"][:2]                 # every size here has a persistent layout (65 k: since round 6)
     if want_form is not None:
         assert results["default"][1] == want_form, results["default"][:2]
         if want_form == 2:

@@ -5,7 +5,7 @@ out=gpurun_out/den_sweep.txt; : > $out
 for S in ${SWEEP_S:-10000 30000 50000}; do
   for A in ${SWEEP_A:-500000 1000000 1500000 2000000}; do
     for mode in ${SWEEP_MODES:-default frames}; do
-      env=""; [ "$mode" = frames ] && env="PK2_DEN_PERSIST=0"; [ "$mode" = v1 ] && env="PK2_DEN_PERSIST=1"
+      env=""; [ "$mode" = frames ] && env="PK2_DEN_PERSIST=0"; [ "$mode" = v1 ] && env="PK2_DEN_PERSIST=1"; [ "$mode" = v2 ] && env="PK2_DEN_PERSIST=2"
       line=$(env $env timeout 300 python bench.py --den-only --den-states $S --den-arcs $A 2>/dev/null | tail -1 | python -c "
 import json,sys
 try:
