@@ -238,6 +238,13 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
   };
   FbEmit cm, nm; FbEpsR ce, ne;
   FbSc s0, s1, s2;               // the frame at hand, the next one, the one after it (in the direction of the recursion)
+  // (-DPK2_FB_PROFILE: thread 0's time in the phases of a forward frame, printed for utterance 1 -- tools/gpu_fb.sh)
+#ifdef PK2_FB_PROFILE
+  long long ph[6] = {0, 0, 0, 0, 0, 0}, last = wall_clock64(); long long nlevs = 0, nlinks = 0, neps = 0, nglobal = 0, maxcnt = 0;
+#define FB_T(k) do { const long long now_ = wall_clock64(); ph[k] += now_ - last; last = now_; } while (0)
+#else
+#define FB_T(k) do { } while (0)
+#endif
   if (fwd) {
     load_sc(0, s0); load_sc(1, s1);
     load_emit(s0, cm);           // (frame 0 has no emitting links: empty)
@@ -255,6 +262,10 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
       load_emit(s1, nm);
       load_eps(s1, ne);
       fb_barrier(lds);
+      FB_T(0);
+#ifdef PK2_FB_PROFILE
+      nlevs += ce.nlev; nlinks += cm.m1 - cm.m0; neps += ce.e1 - ce.e0; nglobal += lds ? 0 : 1; maxcnt = cnt > maxcnt ? cnt : maxcnt;
+#endif
       if (t > 0) {
         auto push = [&](int s, int d, double like) {
           const double x = (plds ? P[s - pbase] : ldc(&val[s])) + like;
@@ -269,12 +280,16 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
         }
         fb_barrier(lds);
       }
+      FB_T(1);
       eps_levels(ce, base, lds);
+      FB_T(2);
       load_eps_levels(ne);         // (the records have arrived by now)
+      FB_T(3);
       if (lds)
         for (int i = tid; i < cnt; i += kFbThreads) val[base + i] = A[i];        // (for the posterior pass: nobody here waits for it)
       else
         __syncthreads();        // a frame on the global path: its values are in memory before the next frame gathers them
+      FB_T(4);
       double* tmp = A; A = P; P = tmp;
       pbase = base; plds = lds;
       cm = nm; ce = ne; s0 = s1; s1 = s2;
@@ -290,6 +305,10 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
       if (v.tf[i] < INFINITY) sm += exp(ldc(&v.alpha[i]) + final_like(p, v, i) - mx);
     sm = block_sum_d(sm, red);
     if (tid == 0) v.F->fb_tot = mx + log(sm);
+#ifdef PK2_FB_PROFILE
+    if (tid == 0 && n == 1) printf("lat_fb alpha utt %d, %d frames, 10 ns ticks per frame: init+prefetch+barrier %lld | emitting %lld | eps levels %lld | level loads %lld | write-back %lld ; per frame: %.1f levels, %.0f emitting links, %.0f epsilon links, %.0f tokens; %lld frames beyond the LDS arrays (cap %d, largest frame %lld)\n", n, T,
+                                ph[0] / (T + 1), ph[1] / (T + 1), ph[2] / (T + 1), ph[3] / (T + 1), ph[4] / (T + 1), (double)nlevs / (T + 1), (double)nlinks / (T + 1), (double)neps / (T + 1), (double)v.nt / (T + 1), nglobal, cap, maxcnt);
+#endif
   } else {
     int base = fT0, cnt = fT1 - fT0;
     bool lds = cnt <= cap;
