@@ -99,6 +99,7 @@ struct FbView {
   double* alpha; double* beta; double* af; double* ab;
   const int32_t* ref; double* ref_post;
   LatFrame* F;
+  double* lw; double* sca; double* scb;       // linear-domain recursion: link weights, per-frame log scales of alpha / beta
 };
 __device__ __forceinline__ FbView fb_view(const FbParams& p, int n, const LatUtt& U) {
   FbView v;
@@ -113,6 +114,7 @@ __device__ __forceinline__ FbView fb_view(const FbParams& p, int n, const LatUtt
   v.ref = p.ref_tids + (int64_t)n * p.ref_stride;
   v.ref_post = p.L.ref_post + U.frame_base;
   v.F = p.L.frame + n;
+  v.lw = p.L.link_w + U.link_base; v.sca = p.L.fb_scale + U.frame_base; v.scb = p.L.fb_scale + p.L.frame_total + U.frame_base;
   return v;
 }
 // fst::ScaleLattice stores the scaled weights as floats; the forward-backward then sums them in double
@@ -355,6 +357,387 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_alpha_beta(FbParams p, int 
   }
 }
 
+// Round 6, third session: the same two recursions in the LINEAR domain (the default; PK2_FB_LINEAR=0 keeps the kernel above).
+// The phase timers of the kernel above (profiles/r06_fb_phases.txt) put 3.1 us of a forward frame's 7.4 into the log-adds of its
+// ~1070 emitting links: every link is log1p(exp(.)) in double inside a 64-bit LDS compare-and-swap loop.  A frame's values span the
+// decoder's beams (tens of nats), a double spans 1400: here a frame's values are kept as  exp(value - r)  with ONE log scale r per
+// frame (every finished frame is normalised to maximum 1 for the next), a link multiplies by its weight w = exp(like) -- computed for
+// all kept links by a parallel pass in front of the recursions (lat_fb_weights) -- and adds with the LDS's own 64-bit float add
+// (ds_add_f64): no loop and no transcendental in the chain.  The finished frame is written back AS IT IS (linear) with its scale
+// in fb_scale; a parallel pass behind the recursions (lat_fb_logs) takes the logs for the posterior passes, which are unchanged.
+// (Taking the logs inside the chain was tried first: a frame has 8366 token slots of which ~1000 are in the pruned lattice, and
+// 8 logs per thread and frame made the kernel 24 ms against 17.)  Frames that do not fit the LDS arrays (frame 0: a token per
+// word) keep the log-domain path through global memory (scale = NaN: "logs already"); an LDS frame filled from one is converted
+// when it is finished.  Values differ from the log-add chain's in the last bits only (same sums); the tests bound MMI / sMBR /
+// MPFE against the oracle as before.
+// (512 threads: at 1024 the compiler has 128 registers per thread and this kernel spilled 70 of them -- the link records held
+// across a frame -- into scratch, whose reloads are round trips to L2; 256 registers hold four emitting and two epsilon links per
+// thread, a frame of the bench lattices has ~1100)
+constexpr int kLinThreads = 512, kLinWaves = kLinThreads / 64, kLinEmit = 4, kLinEps = 2;
+__device__ __forceinline__ double lin_block_max(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int q = 1; q < kLinWaves; ++q) r = fmax(r, red[q]);
+  return r;
+}
+__device__ __forceinline__ double lin_block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int q = 0; q < kLinWaves; ++q) r += red[q];
+  return r;
+}
+struct FbEmitW { int m0, m1; int src[kLinEmit], dst[kLinEmit]; double w[kLinEmit]; };      // (a log-domain frame reads its records again)
+struct FbEpsW { int e0, e1, nlev; int src[kLinEps], dst[kLinEps], lev[kLinEps]; double w[kLinEps]; };
+
+__device__ __forceinline__ double fb_block_max(double v, double* red) {     // red: kLinWaves doubles nobody else touches until the next barrier
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  fb_barrier(true);
+  double r = red[0];
+#pragma unroll
+  for (int k = 1; k < kLinWaves; ++k) r = fmax(r, red[k]);
+  return r;
+}
+
+// In front of the recursions, in parallel (64 workgroups per utterance): w[l] = exp(like(l)) for the kept links of every
+// segment, alpha = beta = -inf for every token slot ("nothing reaches it": a linear value is never negative, so -inf stays
+// recognisable), the accumulators of the posterior passes.  (The recursion kernel's own workgroup used to fill the utterance's
+// 13.5 M token slots by itself: ~2 ms at the head of the longest chain of the step.)
+__global__ void __launch_bounds__(256) lat_fb_prep(FbParams p, int with_acc) {
+  const int n = blockIdx.y;
+  const LatUtt U = p.L.utt[n];
+  if (U.status != kLatOk) return;
+  const FbView v = fb_view(p, n, U);
+  for (int sgm = blockIdx.x; sgm < 2 * (v.T + 1); sgm += gridDim.x) {
+    const int l0 = v.seg[sgm], l1 = l0 + v.kept[sgm];
+    for (int l = l0 + threadIdx.x; l < l1; l += 256) v.lw[l] = exp(link_like(p, v, v.lrec[l], l));
+  }
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+  for (int64_t i = i0; i < v.nt; i += step) {
+    v.alpha[i] = -INFINITY; v.beta[i] = -INFINITY;
+    if (with_acc) { v.af[i] = 0.0; v.ab[i] = 0.0; }
+  }
+  for (int64_t t = i0; t < v.T; t += step) v.ref_post[t] = 0.0;
+}
+
+// linear value x at log scale r -> its log (r is NaN when x is a log already; -inf marks a token nothing reaches)
+__device__ __forceinline__ double fb_log_of(double x, double r) { return (r == r && x != -INFINITY) ? r + log(x) : x; }
+
+// alpha / beta of the frames the recursions left linear -> logs (sMBR / MPFE: the accuracy recursions read them in chains)
+__global__ void __launch_bounds__(256) lat_fb_logs(FbParams p) {
+  const int n = blockIdx.y;
+  const LatUtt U = p.L.utt[n];
+  if (U.status != kLatOk) return;
+  const FbView v = fb_view(p, n, U);
+  for (int t = blockIdx.x; t <= v.T; t += gridDim.x) {
+    const int i0 = v.ftok[t], i1 = v.ftok[t + 1];
+    const double ra = v.sca[t], rb = v.scb[t];
+    if (ra == ra) for (int i = i0 + threadIdx.x; i < i1; i += 256) v.alpha[i] = fb_log_of(v.alpha[i], ra);
+    if (rb == rb) for (int i = i0 + threadIdx.x; i < i1; i += 256) v.beta[i] = fb_log_of(v.beta[i], rb);
+    __syncthreads();
+    if (threadIdx.x == 0) { v.sca[t] = __longlong_as_double(0x7ff8000000000000LL); v.scb[t] = v.sca[t]; }      // (logs now)
+  }
+}
+
+// The recursions.  A frame has ~8400 token slots of which ~1000 are in the pruned lattice; every loop over the slots (zeroes,
+// maximum, write-back: six per frame in the first version of this kernel) cost 0.5-1 us of the frame's 6.4-7.3.  The live tokens
+// of frame t are exactly the ends of its kept links -- destinations of the emitting links t-1 -> t, both ends of the epsilon
+// links inside t -- so those passes walk the LINK records the threads hold anyway (`touch`); duplicates are harmless (a zero,
+// a maximum, the same value stored twice), and the normalisation is a factor in the next frame's gathers instead of a pass.
+__global__ void __launch_bounds__(kLinThreads) lat_fb_alpha_beta_lin(FbParams p, int cap) {
+  __shared__ double red[kLinWaves];
+  __shared__ double redm[2][kLinWaves];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const LatUtt U = p.L.utt[n];
+  if (U.status != kLatOk) { if (tid == 0 && blockIdx.x == 0) p.out[n] = NAN; return; }
+  const FbView v = fb_view(p, n, U);
+  const int T = v.T;
+  const int fT0 = v.ftok[T], fT1 = v.ftok[T + 1];
+  const bool fwd = blockIdx.x == 0;
+  double* val = fwd ? v.alpha : v.beta;
+  double* sc = fwd ? v.sca : v.scb;
+  double* A = lat_fb_smem;
+  double* P = lat_fb_smem + cap;
+  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
+  int nmax = 0;
+  auto load_sc = [&](int t, FbSc& c) {
+    c.base = c.cnt = c.m0 = c.m1 = c.e0 = c.e1 = c.nlev = 0;
+    if (t < 0 || t > T) return;
+    c.base = v.ftok[t]; c.cnt = v.ftok[t + 1] - c.base;
+    if (t > 0) { c.m0 = v.seg[2 * t - 1]; c.m1 = c.m0 + v.kept[2 * t - 1]; }
+    c.e0 = v.seg[2 * t]; c.e1 = c.e0 + v.kept[2 * t]; c.nlev = v.maxlev[t];
+  };
+  auto load_emit = [&](const FbSc& c, FbEmitW& m) {
+    m.m0 = c.m0; m.m1 = c.m1;
+#pragma unroll
+    for (int q = 0; q < kLinEmit; ++q) {
+      const int l = m.m0 + tid + q * kLinThreads;
+      m.src[q] = -1; m.dst[q] = 0; m.w[q] = 0.0;
+      if (l < m.m1) { const int2 r = *reinterpret_cast<const int2*>(&v.lrec[l]); m.src[q] = r.x; m.dst[q] = r.y; m.w[q] = v.lw[l]; }
+    }
+  };
+  // (the epsilon records of a frame are kept whatever its depth says: their ends are live tokens)
+  auto load_eps = [&](const FbSc& c, FbEpsW& e) {
+    e.e0 = c.e0; e.e1 = c.e1; e.nlev = c.nlev;
+#pragma unroll
+    for (int q = 0; q < kLinEps; ++q) {
+      const int l = e.e0 + tid + q * kLinThreads;
+      e.src[q] = -1; e.dst[q] = 0; e.lev[q] = -1; e.w[q] = 0.0;
+      if (l < e.e1) { const int2 r = *reinterpret_cast<const int2*>(&v.lrec[l]); e.src[q] = r.x; e.dst[q] = r.y; e.w[q] = v.lw[l]; }
+    }
+  };
+  auto load_eps_levels = [&](FbEpsW& e) {
+#pragma unroll
+    for (int q = 0; q < kLinEps; ++q)
+      if (e.src[q] >= 0) e.lev[q] = v.tl[e.src[q]];
+  };
+  // f(token) for every live token of the frame whose emitting links (into it) are m and whose epsilon links are e
+  auto touch = [&](const FbEmitW& m, const FbEpsW& e, auto f) {
+#pragma unroll
+    for (int q = 0; q < kLinEmit; ++q) if (m.src[q] >= 0) f(m.dst[q]);
+    for (int l = m.m0 + tid + kLinEmit * kLinThreads; l < m.m1; l += kLinThreads) f(v.lrec[l].y);
+#pragma unroll
+    for (int q = 0; q < kLinEps; ++q) if (e.src[q] >= 0) { f(e.src[q]); f(e.dst[q]); }
+    for (int l = e.e0 + tid + kLinEps * kLinThreads; l < e.e1; l += kLinThreads) { const int2 r = *reinterpret_cast<const int2*>(&v.lrec[l]); f(r.x); f(r.y); }
+  };
+  // Epsilon links of the frame in A (linear or log values) or in global memory (log), level by level.
+  auto eps_levels = [&](const FbEpsW& e, int base, bool lds, bool lin) {
+    if (e.nlev <= 0 || e.e1 <= e.e0) return;
+    for (int k = 0; k < e.nlev; ++k) {
+      const int lev = fwd ? k : e.nlev - 1 - k;
+      if (lin) {
+#pragma unroll
+        for (int q = 0; q < kLinEps; ++q)
+          if (e.src[q] >= 0 && e.lev[q] == lev) {
+            const int from = fwd ? e.src[q] : e.dst[q], to = fwd ? e.dst[q] : e.src[q];
+            const double x = A[from - base] * e.w[q];
+            if (x != 0.0) atomicAdd(&A[to - base], x);
+          }
+        for (int l = e.e0 + tid + kLinEps * kLinThreads; l < e.e1; l += kLinThreads) {
+          const int2 r = *reinterpret_cast<const int2*>(&v.lrec[l]);
+          if (v.tl[r.x] == lev) {
+            const int from = fwd ? r.x : r.y, to = fwd ? r.y : r.x;
+            const double x = A[from - base] * v.lw[l];
+            if (x != 0.0) atomicAdd(&A[to - base], x);
+          }
+        }
+      } else {
+        for (int l = e.e0 + tid; l < e.e1; l += kLinThreads) {
+          const int4 r = v.lrec[l];
+          if (v.tl[r.x] == lev) {
+            const int from = fwd ? r.x : r.y, to = fwd ? r.y : r.x;
+            const double like = link_like(p, v, r, l);
+            if (lds) lds_log_add(&A[to - base], A[from - base] + like);
+            else atomic_log_add(&val[to], ldc(&val[from]) + like);
+          }
+        }
+      }
+      fb_barrier(lds);
+    }
+  };
+  // A (log values of a finished LDS frame, every slot) -> linear, maximum 1; returns the log scale
+  auto to_linear = [&](int cnt) -> double {
+    double mx = -INFINITY;
+    for (int i = tid; i < cnt; i += kLinThreads) mx = fmax(mx, A[i]);
+    mx = fb_block_max(mx, redm[nmax++ & 1]);
+    if (mx == -INFINITY) mx = 0.0;
+    for (int i = tid; i < cnt; i += kLinThreads) A[i] = exp(A[i] - mx);
+    return mx;
+  };
+  FbEmitW cm, nm; FbEpsW ce, ne;
+  FbSc s0, s1, s2;
+#ifdef PK2_FB_PROFILE
+  long long lph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, llast = wall_clock64();
+#define FBL_T(k) do { const long long now_ = wall_clock64(); lph[k] += now_ - llast; llast = now_; } while (0)
+#else
+#define FBL_T(k) do { } while (0)
+#endif
+  if (fwd) {
+    load_sc(0, s0); load_sc(1, s1);
+    load_emit(s0, cm);
+    load_eps(s0, ce);
+    load_eps_levels(ce);
+    int pbase = 0; bool plin = false;
+    double r = 0.0, inv = 1.0;        // a linear value x of the frame in P stands for  r + log(x inv)  (inv: 1 / the frame's maximum)
+    double rT = kNaN;                 // scale of the last frame as it lies in memory (for the total below)
+    for (int t = 0; t <= T; ++t) {
+      const int base = s0.base, cnt = s0.cnt;
+      const bool lds = cnt <= cap, lin = lds && (t == 0 || plin);
+      const bool whole = t == 0;      // (frame 0: the start token has no link into it -- every slot is walked, once)
+      if (lin) {
+        if (whole) { for (int i = tid; i < cnt; i += kLinThreads) A[i] = i == 0 ? 1.0 : 0.0; }
+        else touch(cm, ce, [&](int tok) { A[tok - base] = 0.0; });
+      } else if (lds) {
+        for (int i = tid; i < cnt; i += kLinThreads) A[i] = (t == 0 && i == 0) ? 0.0 : -INFINITY;
+      } else if (t == 0 && tid == 0) {
+        val[0] = 0.0;
+      }
+      load_sc(t + 2, s2);
+      load_emit(s1, nm);
+      load_eps(s1, ne);
+      if (lin) fb_barrier(true); else __syncthreads();      // (a log-domain frame gathers the frame before it from global memory)
+      FBL_T(0);
+      if (t > 0) {
+        if (lin) {
+#pragma unroll
+          for (int q = 0; q < kLinEmit; ++q)
+            if (cm.src[q] >= 0) { const double x = P[cm.src[q] - pbase] * inv * cm.w[q]; if (x != 0.0) atomicAdd(&A[cm.dst[q] - base], x); }
+          for (int l = cm.m0 + tid + kLinEmit * kLinThreads; l < cm.m1; l += kLinThreads) {
+            const int2 rr = *reinterpret_cast<const int2*>(&v.lrec[l]);
+            const double x = P[rr.x - pbase] * inv * v.lw[l];
+            if (x != 0.0) atomicAdd(&A[rr.y - base], x);
+          }
+        } else {
+          // (the frame before it as LOGS from global memory: written back linear when it was an LDS frame)
+          const double rp = sc[t - 1];
+          for (int l = cm.m0 + tid; l < cm.m1; l += kLinThreads) {
+            const int4 rr = v.lrec[l];
+            const double x = fb_log_of(ldc(&val[rr.x]), rp) + link_like(p, v, rr, l);
+            if (lds) lds_log_add(&A[rr.y - base], x); else atomic_log_add(&val[rr.y], x);
+          }
+        }
+        fb_barrier(lds);
+      }
+      FBL_T(1);
+      eps_levels(ce, base, lds, lin);
+      FBL_T(2);
+      load_eps_levels(ne);
+      FBL_T(3);
+      if (lin) {
+        // finished: written back as it is, with its scale; its maximum becomes a factor of the next frame's gathers
+        double mx = 0.0;
+        if (whole) { for (int i = tid; i < cnt; i += kLinThreads) mx = fmax(mx, A[i]); }
+        else touch(cm, ce, [&](int tok) { mx = fmax(mx, A[tok - base]); });
+        mx = fb_block_max(mx, redm[nmax++ & 1]);
+        FBL_T(4);
+        if (whole) { for (int i = tid; i < cnt; i += kLinThreads) val[base + i] = A[i]; }
+        else touch(cm, ce, [&](int tok) { val[tok] = A[tok - base]; });
+        if (tid == 0) sc[t] = r;
+        rT = r;
+        inv = mx > 0.0 ? 1.0 / mx : 1.0;
+        if (mx > 0.0) r += log(mx);
+        plin = true;
+      } else if (lds) {
+        for (int i = tid; i < cnt; i += kLinThreads) val[base + i] = A[i];
+        if (tid == 0) sc[t] = kNaN;
+        rT = kNaN;
+        r = to_linear(cnt); inv = 1.0;
+        plin = true;
+      } else {
+        if (tid == 0) sc[t] = kNaN;
+        rT = kNaN;
+        __syncthreads();
+        plin = false;
+      }
+      FBL_T(5);
+      double* tmp = A; A = P; P = tmp;
+      pbase = base;
+      cm = nm; ce = ne; s0 = s1; s1 = s2;
+    }
+#ifdef PK2_FB_PROFILE
+    if (tid == 0 && n == 1) printf("lat_fb_lin alpha utt %d, %d frames, 10 ns ticks per frame: zeroes+prefetch+barrier %lld | emitting %lld | eps levels %lld | level loads %lld | maximum %lld | write-back %lld\n", n, T,
+                                lph[0] / (T + 1), lph[1] / (T + 1), lph[2] / (T + 1), lph[3] / (T + 1), lph[4] / (T + 1), lph[5] / (T + 1));
+#endif
+    __syncthreads();
+    // total likelihood over the final tokens (stable log-sum-exp); the last frame may lie linear in memory
+    double mx = -INFINITY;
+    for (int i = fT0 + tid; i < fT1; i += kLinThreads)
+      if (v.tf[i] < INFINITY) mx = fmax(mx, fb_log_of(ldc(&v.alpha[i]), rT) + final_like(p, v, i));
+    mx = lin_block_max(mx, red);
+    double sm = 0.0;
+    for (int i = fT0 + tid; i < fT1; i += kLinThreads)
+      if (v.tf[i] < INFINITY) sm += exp(fb_log_of(ldc(&v.alpha[i]), rT) + final_like(p, v, i) - mx);
+    sm = lin_block_sum(sm, red);
+    if (tid == 0) v.F->fb_tot = mx + log(sm);
+  } else {
+    int base = fT0, cnt = fT1 - fT0;
+    bool lds = cnt <= cap, alin = false, whole = true;     // whole: every slot of A is meaningful (the last frame; a converted frame)
+    double r = 0.0;
+    for (int i = tid; i < cnt; i += kLinThreads) {
+      const double b0 = v.tf[base + i] < INFINITY ? final_like(p, v, base + i) : -INFINITY;
+      if (lds) A[i] = b0; else val[base + i] = b0;
+    }
+    load_sc(T, s0); load_sc(T - 1, s1);
+    load_eps(s0, ce);
+    load_eps_levels(ce);
+    load_emit(s0, cm);
+    __syncthreads();
+    for (int t = T; t >= 0; --t) {
+      if (lds && !alin) { r = to_linear(cnt); alin = true; whole = true; fb_barrier(true); }     // (filled in the log domain: the final costs, or from a frame in global memory)
+      const bool lin = lds && alin;
+      load_sc(t - 2, s2);
+      load_eps(s1, ne);
+      load_emit(s1, nm);
+      FBL_T(0);
+      eps_levels(ce, base, lds, lin);
+      FBL_T(1);
+      load_eps_levels(ne);
+      const bool all = whole || t == 0;
+      if (lin) {
+        if (all) { for (int i = tid; i < cnt; i += kLinThreads) { const double a = A[i]; val[base + i] = a == 0.0 ? -INFINITY : a; } }
+        else touch(cm, ce, [&](int tok) { val[tok] = A[tok - base]; });
+      } else if (lds) {
+        for (int i = tid; i < cnt; i += kLinThreads) val[base + i] = A[i];
+      }
+      if (tid == 0) sc[t] = lin ? r : kNaN;
+      FBL_T(2);
+      if (t > 0) {
+        const int pbase = s1.base, pcnt = s1.cnt;
+        const bool plds = pcnt <= cap, plin = lin && plds;
+        if (plin) {
+          // the live tokens of frame t-1: ends of ITS links, which are the records requested at the top of this iteration
+          if (t - 1 == 0) { for (int i = tid; i < pcnt; i += kLinThreads) P[i] = 0.0; }
+          else touch(nm, ne, [&](int tok) { P[tok - pbase] = 0.0; });
+          double mx = 0.0;
+          if (all) { for (int i = tid; i < cnt; i += kLinThreads) mx = fmax(mx, A[i]); }
+          else touch(cm, ce, [&](int tok) { mx = fmax(mx, A[tok - base]); });
+          mx = fb_block_max(mx, redm[nmax++ & 1]);              // (its barrier also orders P's zeroes)
+          FBL_T(3);
+          const double inv = mx > 0.0 ? 1.0 / mx : 1.0;
+          if (mx > 0.0) r += log(mx);
+#pragma unroll
+          for (int q = 0; q < kLinEmit; ++q)
+            if (cm.src[q] >= 0) { const double x = A[cm.dst[q] - base] * inv * cm.w[q]; if (x != 0.0) atomicAdd(&P[cm.src[q] - pbase], x); }
+          for (int l = cm.m0 + tid + kLinEmit * kLinThreads; l < cm.m1; l += kLinThreads) {
+            const int2 rr = *reinterpret_cast<const int2*>(&v.lrec[l]);
+            const double x = A[rr.y - base] * inv * v.lw[l];
+            if (x != 0.0) atomicAdd(&P[rr.x - pbase], x);
+          }
+        } else {
+          if (plds)
+            for (int i = tid; i < pcnt; i += kLinThreads) P[i] = -INFINITY;
+          __syncthreads();           // (a log-domain push gathers this frame from global memory)
+          for (int l = cm.m0 + tid; l < cm.m1; l += kLinThreads) {
+            const int4 rr = v.lrec[l];
+            const double x = fb_log_of(ldc(&val[rr.y]), lin ? r : kNaN) + link_like(p, v, rr, l);
+            if (plds) lds_log_add(&P[rr.x - pbase], x); else atomic_log_add(&val[rr.x], x);
+          }
+        }
+        fb_barrier(plds);
+        FBL_T(4);
+        double* tmp = A; A = P; P = tmp;
+        base = pbase; cnt = pcnt; lds = plds; alin = plin; whole = false;
+        cm = nm; ce = ne; s0 = s1; s1 = s2;
+      }
+    }
+#ifdef PK2_FB_PROFILE
+    if (tid == 0 && n == 1) printf("lat_fb_lin beta utt %d, %d frames, 10 ns ticks per frame: prefetch issue %lld | eps levels %lld | level loads + write-back %lld | zeroes + maximum %lld | emitting + barrier %lld\n", n, T,
+                                lph[0] / (T + 1), lph[1] / (T + 1), lph[2] / (T + 1), lph[3] / (T + 1), lph[4] / (T + 1));
+#endif
+  }
+}
+
 // sMBR / MPFE: the expected-accuracy recursions, forward (x = 0, needs alpha) and backward (x = 1, needs beta).
 __global__ void __launch_bounds__(kFbThreads) lat_fb_accuracy(FbParams p) {
   __shared__ double red[kFbWaves];
@@ -423,7 +806,8 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_accuracy(FbParams p) {
 // Posteriors, frame by frame in parallel (frames dealt round-robin to the workgroups of an utterance).
 // MODE 0: MMI (numerator - denominator with MergePosteriors' drop_frames test), MODE 1: sMBR / MPFE.
 template <int MODE>
-__global__ void __launch_bounds__(kFbThreads) lat_fb_posteriors(FbParams p) {
+__global__ void __launch_bounds__(kFbThreads) lat_fb_posteriors(FbParams p, int lin) {
+  const double kNaN = __longlong_as_double(0x7ff8000000000000LL);
   const int n = blockIdx.y, tid = threadIdx.x;
   const LatUtt U = p.L.utt[n];
   if (U.status != kLatOk) return;
@@ -436,17 +820,20 @@ __global__ void __launch_bounds__(kFbThreads) lat_fb_posteriors(FbParams p) {
     const int r = v.ref[t];
     float* row = post + (int64_t)t * p.post_frame_stride;
     if (MODE == 0) {
+      // (the linear-domain recursions leave alpha of frame t / beta of frame t + 1 linear with their log scales: fb_log_of;
+      // a scale of NaN = logs, which is also what the log-add kernel's fb_scale reads after lat_fb_logs or PK2_FB_LINEAR=0)
+      const double ra = lin ? v.sca[t] : kNaN, rb = lin ? v.scb[t + 1] : kNaN;
       // denominator posterior of the reference transition-id (MergePosteriors' drop_frames test)
       for (int l = m0 + tid; l < m1; l += kFbThreads) {
         const int4 q = v.lrec[l];
-        if (q.z == r) atomicAdd(&v.ref_post[t], exp(v.alpha[q.x] + link_like(p, v, q, l) + v.beta[q.y] - tot));
+        if (q.z == r) atomicAdd(&v.ref_post[t], exp(fb_log_of(v.alpha[q.x], ra) + link_like(p, v, q, l) + fb_log_of(v.beta[q.y], rb) - tot));
       }
       __syncthreads();
       const bool drop = p.drop_frames && ldc(&v.ref_post[t]) == 0.0;
       if (!drop) {
         for (int l = m0 + tid; l < m1; l += kFbThreads) {
           const int4 q = v.lrec[l];
-          atomicAdd(&row[p.tid2pdf[q.z]], -(float)exp(v.alpha[q.x] + link_like(p, v, q, l) + v.beta[q.y] - tot));
+          atomicAdd(&row[p.tid2pdf[q.z]], -(float)exp(fb_log_of(v.alpha[q.x], ra) + link_like(p, v, q, l) + fb_log_of(v.beta[q.y], rb) - tot));
         }
         if (tid == 0) atomicAdd(&row[p.tid2pdf[r]], 1.0f);
       }
@@ -477,16 +864,26 @@ static int fb_launch(int mode, const pk2_lattice_batch* b, void* workspace, FbPa
   if (!attr) {
     PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_fb_alpha_beta), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kFbCap * (int)sizeof(double)));
+    PK2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lat_fb_alpha_beta_lin), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kFbCap * (int)sizeof(double)));
     attr = true;
   }
   const char* cap_env = getenv("PK2_LAT_FIN_CAP");       // (test hook, shared with the pruning pass of the decoder)
   const int cap = cap_env ? std::max(0, std::min(kFbCap / 2, atoi(cap_env))) : kFbCap / 2;
-  hipLaunchKernelGGL(lat_fb_alpha_beta, two, thr, kFbCap * sizeof(double), stream, p, cap);
+  static const bool linear = [] { const char* e = getenv("PK2_FB_LINEAR"); return !(e && atoi(e) == 0); }();
+  const dim3 wide(256, b->N);
+  if (linear) {
+    hipLaunchKernelGGL(lat_fb_prep, wide, dim3(256), 0, stream, p, mode == 0 ? 0 : 1);
+    hipLaunchKernelGGL(lat_fb_alpha_beta_lin, two, dim3(kLinThreads), kFbCap * sizeof(double), stream, p, cap);
+    if (mode != 0) hipLaunchKernelGGL(lat_fb_logs, wide, dim3(256), 0, stream, p);     // (MMI's posterior pass takes the logs of what it reads)
+  } else {
+    hipLaunchKernelGGL(lat_fb_alpha_beta, two, thr, kFbCap * sizeof(double), stream, p, cap);
+  }
   if (mode == 0) {
-    hipLaunchKernelGGL(lat_fb_posteriors<0>, many, thr, 0, stream, p);
+    hipLaunchKernelGGL(lat_fb_posteriors<0>, many, thr, 0, stream, p, linear ? 1 : 0);
   } else {
     hipLaunchKernelGGL(lat_fb_accuracy, two, thr, 0, stream, p);
-    hipLaunchKernelGGL(lat_fb_posteriors<1>, many, thr, 0, stream, p);
+    hipLaunchKernelGGL(lat_fb_posteriors<1>, many, thr, 0, stream, p, 0);
   }
   PK2_LAUNCH_CHECK();
   return PK2_OK;

@@ -171,6 +171,9 @@ size_t lattice_carve(const pk2_lattice_batch* b, void* base, LatPtrs* out) {
   L.seg_kept = c.take<int32_t>(b->frame_total); L.frame_maxlev = c.take<int32_t>(b->frame_total);
   L.ref_post = c.take<double>(b->frame_total);
   L.frame = c.take<LatFrame>(N);
+  L.link_w = c.take<double>(b->link_total);
+  L.fb_scale = c.take<double>(2 * b->frame_total);
+  L.frame_total = b->frame_total;
   if (out) *out = L;
   return c.bytes();
 }

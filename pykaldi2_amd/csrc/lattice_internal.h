@@ -95,6 +95,12 @@ struct LatPtrs {
   int32_t* frame_maxlev; // per utterance [T+1]: depth of the epsilon DAG inside the frame
   double* ref_post;      // per utterance [T]
   LatFrame* frame;       // [N]
+  // forward-backward in the linear domain (round 6, lattice_fb.hip): exp(scaled log-likelihood) of every kept link, and per
+  // frame the log scale of the frame's alpha values ([0, frame_total)) and beta values ([frame_total, 2 frame_total)); NaN = the
+  // frame's values are logs already
+  double* link_w;
+  double* fb_scale;
+  int64_t frame_total;
 };
 
 }  // namespace pk2
