@@ -862,7 +862,7 @@ def run_secondaries():
     fields a reader needs.  Nothing of this runs inside the headline's timed region."""
     import subprocess
     out = {}
-    for name, flags in (("ce", ["--ce", "--steps", "8", "--warmup", "3"]), ("se", ["--se", "--steps", "3", "--warmup", "1"]),
+    for name, flags in (("ce", ["--ce", "--steps", "8", "--warmup", "3"]), ("se", ["--se", "--steps", "3", "--warmup", "3"]),
                         ("transformer", ["--transformer", "--steps", "8", "--warmup", "3"])):
         t0 = time.time()
         try:
