@@ -694,13 +694,23 @@ def se_workload(args, dev, rank, world):
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     audio = 0.0
+    step_ms = []
     for i in range(args.steps):
+        ts = time.perf_counter()
         loss, frames = step(batches[i % 3])
         audio += float(np.sum(frames)) * 0.01
+        step_ms.append(round(1e3 * (time.perf_counter() - ts), 1))      # (host time of the step's enqueueing; the decode's summary synchronises)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    mstat = torch.cuda.memory_stats(dev)
+    device_allocs = int(mstat.get("num_device_alloc", 0) - allocs0)     # hipMalloc calls inside the timed region
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    mem_gb = dict(device_total=round(total_b / 2 ** 30, 1), device_free=round(free_b / 2 ** 30, 1),
+                  reserved_peak=round(mstat.get("reserved_bytes.all.peak", 0) / 2 ** 30, 1),
+                  allocated_peak=round(mstat.get("allocated_bytes.all.peak", 0) / 2 ** 30, 1), alloc_retries=int(mstat.get("num_alloc_retries", 0)))
     # breakdown of the lattice part on the last minibatch (outside the timed region)
     mb = batches[(args.steps - 1) % 3]
     with torch.no_grad():
@@ -761,6 +771,7 @@ def se_workload(args, dev, rank, world):
                                      "CE regulariser 0.1, SGD+clip 5" % (crit_name.upper(), batch, words)},
                           "n_gpus": world, "steps": args.steps,
                           "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": "f32", "batch_per_gpu": batch,
+                          "step_host_ms": step_ms, "device_allocs_in_timed_region": device_allocs, "memory_gb": mem_gb,
                           "hclg": {"states": rec.graph.num_states, "arcs": rec.graph.num_arcs},
                           "lattice_ms": {"decode_and_prune": round(ev[0].elapsed_time(ev[1]), 2),
                                          "forward_backward": round(ev[1].elapsed_time(ev[2]), 2)},
@@ -882,6 +893,8 @@ def run_secondaries():
                 keep["breakdown_ms"] = d.get("breakdown_ms")
             if name == "se":
                 keep["lattice_ms"] = d.get("lattice_ms")
+                keep["step_host_ms"] = d.get("step_host_ms")
+                keep["device_allocs_in_timed_region"] = d.get("device_allocs_in_timed_region")
             out[name] = keep
         except subprocess.TimeoutExpired:
             out[name] = dict(error="exceeded 420 s")

@@ -12,6 +12,7 @@ prunes the lattice, the lattice forward-backward reads it in place.  Nothing fal
 """
 import ctypes as C
 
+import os
 import numpy as np
 import torch
 
@@ -446,6 +447,46 @@ class MappedLatticeFasterRecognizer:
         return _lib.DecoderOpts(float(o.beam), float(o.lattice_beam), float(o.beam_delta), self.acoustic_scale,
                                 max_active, int(o.min_active), int(min(tpf * grow, 2 ** 30)), int(min(lpf * grow, 2 ** 30)))
 
+    def _workspace(self, nbytes, dev):
+        """The device workspace of a minibatch's lattices (15-20 GB at the lattice-MMI configuration: the token and link pools of
+        every frame).  A fresh torch.empty per step sends blocks of that size through the caching allocator in ever different
+        sizes; it splits them and now and then goes back to hipMalloc INSIDE a step (measured: one call in three timed steps,
+        40 ms when it is lucky, 600 ms when cached blocks have to be released first: 305 instead of 147 ms per step on the bench
+        line, twice in four runs).  The recognizer therefore keeps TWO workspaces (the LatticeBatch of the step before is usually
+        still referenced -- by the loss tensor's graph -- when the next minibatch is decoded; the one before that is gone), each
+        1.25 x the largest request it has seen (2 x 24 GB at the bench configuration), and hands out one nobody else holds; sizes
+        settle within the first calls that see the largest minibatch.
+        PK2_LAT_WS_CACHE=0: a fresh tensor per call."""
+        import sys
+        if os.environ.get("PK2_LAT_WS_CACHE", "1") == "0":
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        slots = self.__dict__.setdefault("_ws_slots", [None, None])
+        self._ws_max = max(getattr(self, "_ws_max", 0), int(nbytes))
+        free = None
+        for k in range(2):
+            c = slots[k]
+            if c is None:
+                free = k if free is None else free
+                continue
+            idle = sys.getrefcount(c) <= 3          # (the list, `c`, the call's argument)
+            if idle and c.device == dev and c.numel() >= self._ws_max:
+                return c
+            if idle and free is None:
+                free = k
+            del c
+        if free is None:                            # (both handed out and alive: the caller keeps several LatticeBatches)
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        slots[free] = None                          # (too small, or empty: back to the allocator before the larger one is requested)
+        slots[free] = torch.empty(int(1.25 * self._ws_max), dtype=torch.uint8, device=dev)
+        # the other slot follows at once (when nobody holds it): a loop that keeps the step's loss alive needs it in its next
+        # step -- inside whatever is being timed -- while a loop that does not would never create it
+        o = slots[1 - free]
+        if o is None or (sys.getrefcount(o) <= 3 and o.numel() < self._ws_max):
+            del o
+            slots[1 - free] = None
+            slots[1 - free] = torch.empty(int(1.25 * self._ws_max), dtype=torch.uint8, device=dev)
+        return slots[free]
+
     def decode_batch(self, loglikes, lengths):
         """loglikes: CUDA f32 [N, Tmax, P] (unit pdf stride); lengths: frames per utterance.
         Returns a LatticeBatch.  Lattice pools that turn out too small are quadrupled and the decode repeated."""
@@ -462,7 +503,7 @@ class MappedLatticeFasterRecognizer:
             h = C.c_void_p()
             opts = self._opts(grow)
             _lib.check(L.pk2_lattice_batch_create(self.graph._h, lens.ctypes.data, N, C.byref(opts), C.byref(h)))
-            ws = torch.empty(L.pk2_lattice_batch_bytes(h), dtype=torch.uint8, device=dev)
+            ws = self._workspace(int(L.pk2_lattice_batch_bytes(h)), dev)
             batch = LatticeBatch(h, ws, lens.tolist(), dev, self.trans_model, P, self.graph)
             batch._acoustic_scale = self.acoustic_scale
             batch._lattice_beam = float(self.decoder_opts.lattice_beam)

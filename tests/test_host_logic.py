@@ -407,3 +407,31 @@ def test_reference_configs_go_through_every_cli_config_merge(cli, argv, arch, ca
         ours = lstm.LSTMAM(mc["feat_dim"], mc["label_size"], mc["hidden_size"], mc["num_layers"], mc["dropout"], True)
         ref = RefLSTMAM(mc["feat_dim"], mc["label_size"], mc["hidden_size"], mc["num_layers"], mc["dropout"], True)
         assert [(k, tuple(v.shape)) for k, v in ours.state_dict().items()] == [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+
+
+def test_lattice_workspace_slots_settle_and_never_alias_a_live_batch(monkeypatch):
+    """MappedLatticeFasterRecognizer._workspace (pykaldi2_amd/lattice.py): two grow-only workspaces, 1.25 x the largest request
+    seen; the buffer the previous minibatch's LatticeBatch still holds is never handed out again, and after the first three
+    calls no call allocates (the lattice-MMI bench line once read 305 instead of 147 ms per step because a 18 GB torch.empty per
+    step went back to hipMalloc inside the timed region)."""
+    import torch
+    from pykaldi2_amd import lattice
+    rec = type("R", (object,), {"_workspace": lattice.MappedLatticeFasterRecognizer._workspace})()
+    calls = []
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: (calls.append(a[0]), real_empty(*a, **k))[1])
+    dev = torch.device("cpu")
+    prev = None
+    sizes = [1000, 1800, 1500, 900, 1800, 1700]
+    for step in range(12):
+        ws = rec._workspace(sizes[step % len(sizes)], dev)          # `prev` is still alive here, as the step before's batch is
+        assert ws.numel() >= sizes[step % len(sizes)]
+        assert prev is None or ws.data_ptr() != prev.data_ptr()
+        if step >= 2:
+            assert len(calls) == 4, calls                # (two slots at 1.25 x 1000, both regrown when 1800 arrives: nothing after that)
+        prev = ws
+    # a caller that keeps every batch gets fresh, uncached tensors once both slots are out
+    kept = [rec._workspace(500, dev) for _ in range(4)]
+    assert len({k.data_ptr() for k in kept} | {prev.data_ptr()}) == 5
+    monkeypatch.setenv("PK2_LAT_WS_CACHE", "0")
+    assert rec._workspace(10, dev).numel() == 10
