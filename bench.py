@@ -1071,6 +1071,7 @@ def main():
     # call; read after the timed region): what the N > 1 line reports per rank
     tr.opt.timing = []
     step_events = []
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     audio = 0.0
     for i in range(args.steps):
@@ -1086,7 +1087,8 @@ def main():
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    log("timed region done: %.3f s" % dt)
+    device_allocs = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0)      # hipMalloc calls inside the timed region
+    log("timed region done: %.3f s (%d device allocations inside it)" % (dt, device_allocs))
     exchange_timing, tr.opt.timing = tr.opt.timing, None
     scaling = scaling_report(step_events, exchange_timing, audio, dev, rank, world)
     irtf_bucketed = None
@@ -1222,6 +1224,7 @@ def main():
         result["secondary"] = run_secondaries()
     # the tail of the line (the driver keeps the last 2000 characters): the numbers a reader needs first
     result["n_unique_minibatches"] = n_unique
+    result["device_allocs_in_timed_region"] = device_allocs
     result["gemm_arith"] = gemm_arith_name()
     result["f32_gemm_window"] = f32_window
     result[("roofline_model" if args.transformer else "roofline_lstm") + "_frac"] = roof_lstm["frac"]
