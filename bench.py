@@ -119,7 +119,7 @@ class Trainer:
             kpm = torch.ones(len(frames), Tp, dtype=torch.bool)
             for n_, f_ in enumerate(frames):
                 kpm[n_, :-(-f_ // 3)] = False
-            logits = self.model(x, None, kpm.to(x.device))
+            logits = self.model(x, None, kpm)       # (host mask: pinned, non-blocking inside forward)
         else:
             logits = self.model.forward_time_major(x)
         mark("model_fwd" if self.arch == "transformer" else "lstm_fwd")

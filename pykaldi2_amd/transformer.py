@@ -332,6 +332,16 @@ class _TransformerFunction(torch.autograd.Function):
         return (dx, None, None, None) + (None,) * len(m._param_names)
 
 
+def _mask_to_device(mask, device, dtype):
+    """A mask built on the host goes over pinned and non-blocking: a pageable copy is hipMemcpyAsync + a stream
+    synchronisation, i.e. the host would wait at the head of every forward until the device has finished the previous
+    step and then start enqueueing ~470 launches against an idle device (measured on the 12-layer LF-MMI step:
+    tools/host_time_tr.py)."""
+    if mask.is_cuda:
+        return mask.to(device=device, dtype=dtype).contiguous()
+    return mask.to(dtype).contiguous().pin_memory().to(device, non_blocking=True)
+
+
 class TransformerAM(nn.Module):
     def __init__(self, dim_feat, dim_model, nheads, dim_feedforward, nlayers, dropout, output_size, kernel_size=3,
                  stride=1):
@@ -348,14 +358,23 @@ class TransformerAM(nn.Module):
         encoder_layer = _LayerParams(dim_model, nheads, dim_feedforward, dropout, kernel_size, stride)
         self.transformer = _EncoderParams(encoder_layer, nlayers, encoder_norm)
         self._param_names = [n for n, _ in self.named_parameters()]
-        self._flat = self._gflat = self._layout = None
+        self._flat = self._gflat = self._layout = self._plist = None
 
     # ---- flat parameter / gradient buffers (fused optimiser, all-reduce) -------------------------------
     def _ensure_flat(self):
+        # steady state: the cached parameter objects are still the module's and still views of the flat buffer (a walk
+        # over named_parameters() costs 0.7 ms of host time, and a step asks three times)
+        cached = self._plist
+        if cached is not None and self._flat is not None and self.input_layer.weight is cached[0][0] \
+                and self._flat.device == cached[0][0].device:
+            base = self._flat.data_ptr()
+            if all(q.data_ptr() == base + 4 * o for q, o in cached):
+                return
         params = dict(self.named_parameters())
         first = params[self._param_names[0]]
         if self._flat is not None and self._flat.device == first.device and all(
                 params[n].data_ptr() == self._flat.data_ptr() + 4 * o for n, (o, _) in self._layout.items()):
+            self._plist = [(params[n], self._layout[n][0]) for n in self._param_names]
             return
         layout, off = {}, 0
         for n in self._param_names:
@@ -366,6 +385,7 @@ class TransformerAM(nn.Module):
             flat[o:o + c].copy_(params[n].data.reshape(-1))
             params[n].data = flat[o:o + c].view(params[n].shape)
         self._flat, self._layout, self._gflat = flat, layout, None
+        self._plist = [(params[n], layout[n][0]) for n in self._param_names]
 
     def _side_stream(self, dev):
         st = getattr(self, "_side", None)
@@ -392,11 +412,11 @@ class TransformerAM(nn.Module):
         self._ensure_flat()
         kp = None
         if src_key_padding_mask is not None:
-            kp = src_key_padding_mask.to(device=data.device, dtype=torch.uint8).contiguous()
+            kp = _mask_to_device(src_key_padding_mask, data.device, torch.uint8)
         sm = None
         if src_mask is not None:
-            sm = src_mask.to(device=data.device, dtype=torch.float32).contiguous()
-        params = [p for _, p in self.named_parameters()]
+            sm = _mask_to_device(src_mask, data.device, torch.float32)
+        params = [q for q, _ in self._plist]     # named_parameters() order (_ensure_flat)
         return _TransformerFunction.apply(data, self, sm, kp, *params)
 
 
@@ -412,5 +432,5 @@ def padded_forward(model, x, frames, look_ahead=-1):
     src_mask = None
     if look_ahead > -1:
         keep = torch.tril(torch.ones(T, T), diagonal=look_ahead)
-        src_mask = torch.zeros(T, T).masked_fill(keep == 0, float("-inf")).to(x.device)
-    return model(x, src_mask, kpm.to(x.device)).transpose(0, 1)
+        src_mask = torch.zeros(T, T).masked_fill(keep == 0, float("-inf"))
+    return model(x, src_mask, kpm).transpose(0, 1)
