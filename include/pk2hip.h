@@ -303,6 +303,14 @@ int pk2_scale_by_scalars(const float* in, float* out, int64_t n, const float* mu
 int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
                  const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                  int64_t ldc, const float* bias, void* stream);
+/* The product with the elementwise pass behind it in its epilogue: C = act(alpha op(A) op(B) + beta C + bias).
+ * act 0: none (= pk2_gemm_f32); 1: ReLU (reference models/transformer.py:60, the encoder layer's
+ * linear1 -> F.relu); 2: an element is kept where gate[m*ldg + n] > 0 and 0 elsewhere -- the ReLU's backward mask
+ * read from the forward activation (what autograd's threshold_backward does behind the dX product).  Never cut
+ * into atomically added K slices. */
+int pk2_gemm_f32_act(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                     const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                     int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg, void* stream);
 /* Batched form: matrix triple z = i0*n1 + i1 (i0 < n0, i1 < n1) lives at offsets i0*stride?0 + i1*stride?1
  * (in floats) from A / B / C; no bias.  Used for the per-(utterance, head) attention products of
  * TransformerAM (reference models/transformer.py:60, nn.MultiheadAttention). */

@@ -23,7 +23,8 @@ namespace pk2 {
 // Batched form: blockIdx.z = i0 * n1 + i1 selects a matrix triple at offsets i0*s?0 + i1*s?1 (floats).
 // Split-K form (ksplit > 1): blockIdx.z = batch * ksplit + slice; a slice covers klen k's and adds alpha * its
 // partial product into C with float atomics (C already holds beta * C + bias, see gemm_prescale_kernel).
-struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, klen; float* colsum = nullptr; };      // colsum: pk2_gemm_f32_tn_colsum
+struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, klen; float* colsum = nullptr;      // colsum: pk2_gemm_f32_tn_colsum
+                   int act = 0; const float* gate = nullptr; int64_t ldg = 0; };      // pk2_gemm_f32_act: 1 = ReLU, 2 = kept where gate > 0
 
 // One block tile: C[m0.., n0..] (+)= alpha * A[m0.., kbeg..kend) * B[kbeg..kend), n0..].  `atomic`: the tile's k range is
 // shared with other workgroups -- the product is added with float atomics into a C that already holds beta * C + bias.
@@ -34,7 +35,8 @@ struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, kle
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) -> C rows m0 + wm.., columns n0 + wn..
 template <int TILES>
 __device__ __forceinline__ void gemm_store(const f32x16 (&acc)[TILES][TILES], int M, int N, float alpha, float beta, float* __restrict__ C,
-                                           int64_t ldc, const float* __restrict__ bias, int m0, int n0, int wm, int wn, bool atomic) {
+                                           int64_t ldc, const float* __restrict__ bias, int m0, int n0, int wm, int wn, bool atomic,
+                                           int act = 0, const float* __restrict__ gate = nullptr, int64_t ldg = 0) {
   const int lane = threadIdx.x & 63;
   const int col_l = lane & 31, row_h = 4 * (lane >> 5);
 #pragma unroll
@@ -59,6 +61,9 @@ __device__ __forceinline__ void gemm_store(const f32x16 (&acc)[TILES][TILES], in
           float* o = C + (int64_t)gr * ldc + gc;
           float v = alpha * acc[i][j][r] + bv;
           if (beta != 0.f) v += beta * (*o);
+          // (pk2_gemm_f32_act: the ReLU behind a Linear, or the ReLU's backward mask from the forward activation)
+          if (act == 1) v = fmaxf(v, 0.f);
+          else if (act == 2) v = gate[(int64_t)gr * ldg + gc] > 0.f ? v : 0.f;
           *o = v;
         }
       }
@@ -77,7 +82,8 @@ template <bool TA, bool TB, int TILES, bool X3>
 __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int kbeg, float alpha, const float* __restrict__ A, int64_t lda,
                                            const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C,
                                            int64_t ldc, const float* __restrict__ bias, bool vecA, bool vecB, int m0, int n0,
-                                           bool atomic, float* colsum = nullptr) {
+                                           bool atomic, float* colsum = nullptr, int act = 0, const float* __restrict__ gate = nullptr,
+                                           int64_t ldg = 0) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
 
@@ -102,7 +108,7 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
 #ifdef PK2_GEMM_PROFILE
   const long long gp_t1 = wall_clock64();
 #endif
-  gemm_store<TILES>(acc, M, N, alpha, beta, C, ldc, bias, m0, n0, wm, wn, atomic);
+  gemm_store<TILES>(acc, M, N, alpha, beta, C, ldc, bias, m0, n0, wm, wn, atomic, act, gate, ldg);
 #ifdef PK2_GEMM_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef PK2_GEMM_PROFILE_N
@@ -144,7 +150,8 @@ __global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f
   }
   __shared__ __attribute__((aligned(16))) char smem[gemm_smem_bytes<TA, TB, TILES, X3>()];
   gemm_block<TA, TB, TILES, X3>(smem, M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
-                                blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1, bt.colsum);
+                                blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1, bt.colsum, bt.act, bt.gate,
+                                bt.ldg);
 }
 
 // The row bands of a plain 2-D product in ONE launch (round 4): workgroups [0, nbig) take the 128x128 tiles of rows
@@ -275,7 +282,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // summation-order noise of 1e-7 cannot flip anything).  PK2_GEMM_SPLIT_FWD=1 restores the round-5 behaviour.
   static const bool split_fwd = [] { const char* e = getenv("PK2_GEMM_SPLIT_FWD"); return e && atoi(e) == 1; }();
   const bool forward_form = !transa && transb && !split_fwd;
-  if (!forward_form && (big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
+  if (!forward_form && bt.act == 0 && (big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
     int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / PK2_GEMM_MIN_KSLICE);
     if (big_tiles > 256) {
       // between one and two tiles per CU: the slice count that fills whole rounds of the 512 workgroup slots best (368 tiles:
@@ -328,7 +335,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   const bool no_band = band_env && atoi(band_env) == 0;
   // (between one and two big tiles per CU -- 64x64 tiles throughout -- a band of one big tile per CU plus small ones was
   // slower: 6048 x 1024 x 2356: 351 against 334 us, tools/dbg/gemm_modes.py)
-  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && !bt.colsum && (transa ? (lda & 3) == 0 : true)) {
+  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && !bt.colsum && bt.act == 0 && (transa ? (lda & 3) == 0 : true)) {
     const int Cn = (N + 127) / 128, R = (M + 127) / 128, Cs = (N + 63) / 64;
     auto rounds = [&](int64_t n) { return (double)((n + cus - 1) / cus); };
     int best_r = R; double best = rounds((int64_t)R * Cn);
@@ -372,6 +379,21 @@ extern "C" int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N
                             int64_t ldc, const float* bias, void* stream_) {
   PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
   GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
+  return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, true,
+                     static_cast<hipStream_t>(stream_));
+}
+
+// C = act(alpha op(A) op(B) + beta C + bias): the product with the elementwise pass behind it in its epilogue.  act 1: ReLU (the
+// FFN's first Linear); act 2: v kept where gate[m][n] > 0, else 0 -- the ReLU's backward mask read from the forward
+// activation (gate may be C's own previous content only with beta = 0: an element is read before it is written by the same
+// lane).  Such a product is never cut into atomically added K slices (the activation needs the whole sum).
+extern "C" int pk2_gemm_f32_act(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
+                                const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                                int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg, void* stream_) {
+  PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm_f32_act: bad args");
+  PK2_REQUIRE(act == 0 || act == 1 || (act == 2 && gate && ldg >= N), "gemm_f32_act: act is 0, 1 (ReLU) or 2 (gate, ldg >= N)");
+  GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
+  bt.act = act; bt.gate = gate; bt.ldg = ldg;
   return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, true,
                      static_cast<hipStream_t>(stream_));
 }

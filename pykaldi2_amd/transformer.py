@@ -60,6 +60,17 @@ def _bgemm(ta, tb, M, N, K, alpha, A, lda, sA0, sA1, B, ldb, sB0, sB1, beta, C, 
                                                beta, C, ldc, sC0, sC1, n0, n1, _lib.stream_ptr()))
 
 
+def _gemm_act(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, beta=0.0, act=0, gate=None, ldg=0):
+    """pk2_gemm_f32_act: the product with the ReLU (act 1) or the ReLU's backward mask (act 2: kept where gate > 0) in its
+    epilogue instead of a row pass of its own behind it (PK2_TR_FUSE_RELU=0: the separate launches)."""
+    _lib.check(_lib.lib().pk2_gemm_f32_act(int(ta), int(tb), M, N, K, 1.0, A, lda, B, ldb, beta, C, ldc, bias, act, gate, ldg,
+                                           _lib.stream_ptr()))
+
+
+def _fuse_relu():
+    return os.environ.get("PK2_TR_FUSE_RELU", "1") != "0"
+
+
 def _colsum(A, lda, M, N, out, beta=0.0):
     _lib.check(_lib.lib().pk2_colsum_f32(A, lda, M, N, beta, out, _lib.stream_ptr()))
 
@@ -106,6 +117,7 @@ class _TransformerFunction(torch.autograd.Function):
         drop = m.dropout if m.training else 0.0
         fused = d == 64 and os.environ.get("PK2_ATTN_FUSED", "1") != "0"
         ctx.fused, ctx.masks = fused, (src_mask, key_pad)
+        fuse_relu = _fuse_relu()
         x = x.contiguous()
         h = new(R, C)
         _gemm(0, 1, R, C, Din, _p(x), Din, _p(m.input_layer.weight), Din, _p(h), C, bias=_p(m.input_layer.bias))
@@ -143,8 +155,11 @@ class _TransformerFunction(torch.autograd.Function):
             _lib.check(L.pk2_layernorm_fwd(_p(ao), _p(h), _p(e.norm1.weight), _p(e.norm1.bias), R, C, e.norm1.eps,
                                            _p(s1), _p(x1), _p(mu1), _p(rs1), sp))
             f1 = new(R, F)
-            _gemm(0, 1, R, F, C, _p(x1), C, _p(e.linear1.weight), C, _p(f1), F, bias=_p(e.linear1.bias))
-            _lib.check(L.pk2_relu_fwd(_p(f1), f1.numel(), sp))
+            if fuse_relu:
+                _gemm_act(0, 1, R, F, C, _p(x1), C, _p(e.linear1.weight), C, _p(f1), F, bias=_p(e.linear1.bias), act=1)
+            else:
+                _gemm(0, 1, R, F, C, _p(x1), C, _p(e.linear1.weight), C, _p(f1), F, bias=_p(e.linear1.bias))
+                _lib.check(L.pk2_relu_fwd(_p(f1), f1.numel(), sp))
             s["seedf"] = _seed() if drop > 0 else None
             f1d = _dropout(f1, drop, s["seedf"]) if drop > 0 else f1
             f2 = new(R, C)
@@ -241,6 +256,7 @@ class _TransformerFunction(torch.autograd.Function):
         dh = new(R, C)
         _lib.check(L.pk2_layernorm_bwd(_p(dhn), _p(hL), _p(muf), _p(rsf), _p(nf.weight), R, C, _p(dh),
                                        _p(g["transformer.norm.weight"]), _p(g["transformer.norm.bias"]), sp))
+        fuse_relu, dh_gated = _fuse_relu(), False
         for li in range(len(m.transformer.layers) - 1, -1, -1):
             lp = m.transformer.layers[li]
             e = lp.encoder_layer
@@ -248,7 +264,8 @@ class _TransformerFunction(torch.autograd.Function):
             s = ctx.saved[li]
             pre = "transformer.layers.%d." % li
             # ReLU + Conv1d
-            _lib.check(L.pk2_relu_bwd(_p(s["y"]), _p(dh), dh.numel(), sp))     # dh := dc
+            if not dh_gated:       # (else the product that finished dh applied this layer's ReLU mask in its epilogue)
+                _lib.check(L.pk2_relu_bwd(_p(s["y"]), _p(dh), dh.numel(), sp))     # dh := dc
             dc = dh
             x2 = s["x2"]
 
@@ -280,10 +297,15 @@ class _TransformerFunction(torch.autograd.Function):
             # FFN
             read_ds2 = lin_grads(df2, s["f1d"], F, C, pre + "encoder_layer.linear2.weight", pre + "encoder_layer.linear2.bias")
             df1 = new(R, F)
-            _gemm(0, 0, R, F, C, _p(df2), C, _p(e.linear2.weight), F, _p(df1), F)
-            if drop > 0:
-                _dropout(df1, drop, s["seedf"], df1)
-            _lib.check(L.pk2_relu_bwd(_p(s["f1"]), _p(df1), df1.numel(), sp))
+            if fuse_relu:         # (the ReLU mask and the dropout mask are both elementwise factors: their order is free)
+                _gemm_act(0, 0, R, F, C, _p(df2), C, _p(e.linear2.weight), F, _p(df1), F, act=2, gate=_p(s["f1"]), ldg=F)
+                if drop > 0:
+                    _dropout(df1, drop, s["seedf"], df1)
+            else:
+                _gemm(0, 0, R, F, C, _p(df2), C, _p(e.linear2.weight), F, _p(df1), F)
+                if drop > 0:
+                    _dropout(df1, drop, s["seedf"], df1)
+                _lib.check(L.pk2_relu_bwd(_p(s["f1"]), _p(df1), df1.numel(), sp))
             lin_grads(df1, s["x1"], C, F, pre + "encoder_layer.linear1.weight", pre + "encoder_layer.linear1.bias")
             dx1 = ds2 if drop == 0 else ds2    # residual branch: d x1 = d s2 (+ FFN path below)
             if df2 is ds2:
@@ -315,7 +337,13 @@ class _TransformerFunction(torch.autograd.Function):
             dh = ds1 if drop == 0 else ds1     # residual branch of the attention block
             if dao is ds1:
                 before_overwrite(read_ds1)
-            _gemm(0, 0, R, C, 3 * C, _p(dqkv), 3 * C, _p(a.in_proj_weight), C, _p(dh), C, beta=1.0)
+            if fuse_relu and li > 0:     # dh is complete with this product: the layer below starts with ReLU'(its y) on it
+                _gemm_act(0, 0, R, C, 3 * C, _p(dqkv), 3 * C, _p(a.in_proj_weight), C, _p(dh), C, beta=1.0, act=2,
+                          gate=_p(ctx.saved[li - 1]["y"]), ldg=C)
+                dh_gated = True
+            else:
+                _gemm(0, 0, R, C, 3 * C, _p(dqkv), 3 * C, _p(a.in_proj_weight), C, _p(dh), C, beta=1.0)
+                dh_gated = False
             ctx.saved[li] = None
         lin_grads(dh, ctx.x.view(R, Din), Din, C, "input_layer.weight", "input_layer.bias")
         dx = None

@@ -282,3 +282,91 @@ def test_side_stream_on_and_off_give_the_same_gradients(monkeypatch):
     for n in g0:
         e = (g1[n] - g0[n]).abs().max().item()
         assert e < 5e-6 * max(1e-6, g0[n].abs().max().item()), (n, e)
+
+
+@pytest.mark.parametrize("arith", [0, 1], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("M,N,K", [(2276, 2048, 512), (130, 96, 72), (2276, 512, 1536), (300, 2048, 512)])
+def test_gemm_act_epilogues_equal_the_product_followed_by_the_row_pass(M, N, K, arith):
+    """pk2_gemm_f32_act: act 1 = ReLU behind x W^T + b (models/transformer.py:60, linear1 -> F.relu), act 2 = the ReLU's
+    backward mask (kept where the forward activation > 0) behind the dX product, with and without beta = 1 -- the same
+    arithmetic as pk2_gemm_f32 followed by pk2_relu_fwd / pk2_relu_bwd, so bit-equal to that pair."""
+    import ctypes
+    from pykaldi2_amd import _lib
+    L = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())        # noqa: E731
+    sp = _lib.stream_ptr()
+    prev = L.pk2_gemm_get_arith()
+    _lib.check(L.pk2_gemm_set_arith(arith))
+    try:
+        g = torch.Generator(device="cuda").manual_seed(M + N + K)
+        A = torch.randn(M, K, device="cuda", generator=g)
+        W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        b = torch.randn(N, device="cuda", generator=g)
+        two, one = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        _lib.check(L.pk2_gemm_f32(0, 1, M, N, K, 1.0, p(A), K, p(W), K, 0.0, p(two), N, p(b), sp))
+        _lib.check(L.pk2_relu_fwd(p(two), two.numel(), sp))
+        _lib.check(L.pk2_gemm_f32_act(0, 1, M, N, K, 1.0, p(A), K, p(W), K, 0.0, p(one), N, p(b), 1, None, 0, sp))
+        assert torch.equal(one, two)
+        ref = torch.relu(A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
+        assert (one.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+        # backward mask, beta = 0 and beta = 1 (the residual sum the attention block's last dX product adds into)
+        Wd = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
+        gate = torch.randn(M, N, device="cuda", generator=g)
+        base = torch.randn(M, N, device="cuda", generator=g)
+        for beta in (0.0, 1.0):
+            two, one = base.clone(), base.clone()
+            _lib.check(L.pk2_gemm_f32(0, 0, M, N, K, 1.0, p(A), K, p(Wd), N, beta, p(two), N, None, sp))
+            _lib.check(L.pk2_relu_bwd(p(gate), p(two), two.numel(), sp))
+            _lib.check(L.pk2_gemm_f32_act(0, 0, M, N, K, 1.0, p(A), K, p(Wd), N, beta, p(one), N, None, 2, p(gate), N, sp))
+            assert torch.equal(one, two), beta
+        assert L.pk2_gemm_f32_act(0, 0, M, N, K, 1.0, p(A), K, p(Wd), N, 0.0, p(one), N, None, 2, None, N, sp) != 0     # act 2 needs a gate
+    finally:
+        _lib.check(L.pk2_gemm_set_arith(prev))
+
+
+def test_relu_in_the_product_epilogues_changes_no_bit(monkeypatch):
+    """PK2_TR_FUSE_RELU=1 (default: ReLU / ReLU' in the epilogues of linear1, of linear2's dX and of the attention block's last
+    dX product) against the separate row passes: same logits, same gradients."""
+    monkeypatch.setenv("PK2_TR_SIDE_STREAM", "0")
+    monkeypatch.setenv("PK2_TR_FUSE_RELU", "1")
+    y1, g1 = _tr_run(4, 90, 3, 300)
+    monkeypatch.setenv("PK2_TR_FUSE_RELU", "0")
+    y0, g0 = _tr_run(4, 90, 3, 300)
+    assert torch.equal(y1, y0)
+    for n in g0:
+        e = (g1[n] - g0[n]).abs().max().item()
+        assert e < 5e-6 * max(1e-6, g0[n].abs().max().item()), (n, e)
+
+
+@pytest.mark.parametrize("rows,C", [(2276, 512), (37, 512), (1000, 256), (513, 1024), (300, 80)])
+def test_layernorm_backward_matches_float64(rows, C):
+    """pk2_layernorm_bwd against autograd in float64; dgamma / dbeta are accumulated onto what the buffers hold.  (Round 6: a
+    one-launch form -- rows per wave, partial parameter gradients added by the last workgroup to arrive -- passed this test
+    and was dropped: 40 us per call against 8.7 for the two launches; the agent-scope release in front of the arrival
+    counter writes the XCD's dirty L2 lines back.)"""
+    import ctypes
+    from pykaldi2_amd import _lib
+    L = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())        # noqa: E731
+    sp = _lib.stream_ptr()
+    torch.manual_seed(rows + C)
+    s = torch.randn(rows, C, dtype=torch.float64) * 2 + 0.3
+    gamma = torch.randn(C, dtype=torch.float64)
+    dy = torch.randn(rows, C, dtype=torch.float64)
+    sr = s.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    F.layer_norm(sr, (C,), gr, br, 1e-5).backward(dy)
+    mean = s.mean(1)
+    rstd = 1.0 / torch.sqrt(s.var(1, unbiased=False) + 1e-5)
+    dev = lambda t: t.float().cuda().contiguous()      # noqa: E731
+    s_d, dy_d, mean_d, rstd_d, gamma_d = dev(s), dev(dy), dev(mean), dev(rstd), dev(gamma)
+    for rep in range(2):
+        ds = torch.empty(rows, C, device="cuda")
+        dg0, db0 = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        dg, db = dg0.clone(), db0.clone()
+        _lib.check(L.pk2_layernorm_bwd(p(dy_d), p(s_d), p(mean_d), p(rstd_d), p(gamma_d), rows, C, p(ds), p(dg), p(db), sp))
+        assert (ds.cpu().double() - sr.grad).abs().max().item() < 2e-5 * max(1.0, sr.grad.abs().max().item())
+        for got, was, want in ((dg, dg0, gr.grad), (db, db0, br.grad)):
+            e = ((got - was).cpu().double() - want).abs().max().item()
+            assert e < 2e-5 * max(1.0, want.abs().max().item()), (rep, e)
