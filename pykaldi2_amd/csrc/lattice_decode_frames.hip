@@ -1469,8 +1469,14 @@ __global__ void lat_persist_check(const DecodeParams p, const LatTeamCtl* ctl, i
 // before it live in LDS (order-preserving bit patterns, ds_min): a round is LDS traffic and a barrier.  The arithmetic and
 // its order are those of finish_and_prune (lattice_decode_common.h: the one-workgroup decoder's pass).  A frame with more
 // tokens than the LDS arrays hold (frame 0 has one per word of the vocabulary) is worked on in global memory.
-constexpr int kFinEps = 8;  // epsilon links per thread kept in registers over the rounds of a frame
-constexpr int kFinEmit = 12;       // emitting links per thread fetched ahead of the epsilon rounds
+#ifndef PK2_FIN_EPS
+#define PK2_FIN_EPS 6       // (8 / 12 before: 18.9 ms per call, 4 / 16: 18.65, 6 / 14: 18.4 -- tools/gpu_fin_ab.sh, twice in one job)
+#endif
+#ifndef PK2_FIN_EMIT
+#define PK2_FIN_EMIT 14
+#endif
+constexpr int kFinEps = PK2_FIN_EPS;  // epsilon links per thread kept in registers over the rounds of a frame
+constexpr int kFinEmit = PK2_FIN_EMIT;       // emitting links per thread fetched ahead of the epsilon rounds
 extern __shared__ __attribute__((aligned(16))) uint32_t lat_fin_smem[];
 
 __global__ void __launch_bounds__(256) lat_link_delta(const DecodeParams p) {
