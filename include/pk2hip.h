@@ -311,6 +311,15 @@ int pk2_gemm_f32(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K
 int pk2_gemm_f32_act(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, float alpha,
                      const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                      int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg, void* stream);
+/* Several products into one set of accumulators, one launch, fixed summation order:
+ *   C = act(alpha * sum_{j < nseg} op(A + j*segA) * op(B + j*segB) + beta*C + bias),   K = depth of ONE segment.
+ * TransformerAM's Conv1d(kernel 3, padding 1) over time (reference models/transformer.py:88-92: conv1d -> F.relu)
+ * is nseg = 3 over row-shifted views of a zero-padded [B + T*B + B, C] activation buffer (segA = +-B*C floats,
+ * segB = C*C: the taps' weight slices); segA / segB may be negative; act / gate as in pk2_gemm_f32_act. */
+int pk2_gemm_f32_seg(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, int32_t nseg, float alpha,
+                     const float* A, int64_t lda, int64_t segA, const float* B, int64_t ldb, int64_t segB, float beta,
+                     float* C, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
+                     void* stream);
 /* Batched form: matrix triple z = i0*n1 + i1 (i0 < n0, i1 < n1) lives at offsets i0*stride?0 + i1*stride?1
  * (in floats) from A / B / C; no bias.  Used for the per-(utterance, head) attention products of
  * TransformerAM (reference models/transformer.py:60, nn.MultiheadAttention). */

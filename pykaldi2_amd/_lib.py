@@ -111,6 +111,8 @@ SIGNATURES = {
                                _vp, _vp]),
     "pk2_gemm_f32_act": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _i32, _vp, _i64,
                                    _vp]),
+    "pk2_gemm_f32_seg": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp, _i64, _i64, _f32, _vp, _i64, _vp,
+                                   _i32, _vp, _i64, _vp]),
     "pk2_gemm_f32_batched": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64,
                                        _f32, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "pk2_gemm_f32_tn_colsum": (C.c_int, [_i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _vp]),

@@ -175,7 +175,8 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
                                                      int m0, int n0, int kbeg, int K, int M, int N, bool vecA, bool vecB,
                                                      u32x4_t (*As)[GeoX<TILES>::template slots<KCA>()],
                                                      u32x4_t (*Bs)[GeoX<TILES>::template slots<KCB>()],
-                                                     f32x16 (&acc)[TILES][TILES], float* __restrict__ colsum = nullptr) {
+                                                     f32x16 (&acc)[TILES][TILES], float* __restrict__ colsum = nullptr,
+                                                     bool zero_acc = true) {
   // colsum (row-contiguous A only, i.e. the weight-gradient form dW = dY^T X): colsum[m] += sum_k A[k][m] over this tile's k
   // range, added with float atomics -- the bias gradient rides in the product that reads dY anyway (round 6: 62 colsum
   // launches per TransformerAM step, one per LF-MMI step).  The caller passes it to the tiles of ONE column block only.
@@ -184,12 +185,14 @@ __device__ __forceinline__ void tile_mainloop_bf16x3(const float* __restrict__ A
   constexpr int SPA = G::template sp<KCA>(), SPB = G::template sp<KCB>();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
+  if (zero_acc) {
 #pragma unroll
-  for (int i = 0; i < TILES; ++i)
+    for (int i = 0; i < TILES; ++i)
 #pragma unroll
-    for (int j = 0; j < TILES; ++j)
+      for (int j = 0; j < TILES; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
   const int kq = lane >> 5, li = lane & 31;
 #ifndef PK2_GEMMX_DEPTH
 #define PK2_GEMMX_DEPTH 2

@@ -24,7 +24,8 @@ namespace pk2 {
 // Split-K form (ksplit > 1): blockIdx.z = batch * ksplit + slice; a slice covers klen k's and adds alpha * its
 // partial product into C with float atomics (C already holds beta * C + bias, see gemm_prescale_kernel).
 struct GemmBatch { int n1; int64_t sA0, sA1, sB0, sB1, sC0, sC1; int ksplit, klen; float* colsum = nullptr;      // colsum: pk2_gemm_f32_tn_colsum
-                   int act = 0; const float* gate = nullptr; int64_t ldg = 0; };      // pk2_gemm_f32_act: 1 = ReLU, 2 = kept where gate > 0
+                   int act = 0; const float* gate = nullptr; int64_t ldg = 0;        // pk2_gemm_f32_act: 1 = ReLU, 2 = kept where gate > 0
+                   int nseg = 1; int64_t segA = 0, segB = 0; };                       // pk2_gemm_f32_seg: sum over segments of A / B
 
 // One block tile: C[m0.., n0..] (+)= alpha * A[m0.., kbeg..kend) * B[kbeg..kend), n0..].  `atomic`: the tile's k range is
 // shared with other workgroups -- the product is added with float atomics into a C that already holds beta * C + bias.
@@ -83,7 +84,7 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
                                            const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C,
                                            int64_t ldc, const float* __restrict__ bias, bool vecA, bool vecB, int m0, int n0,
                                            bool atomic, float* colsum = nullptr, int act = 0, const float* __restrict__ gate = nullptr,
-                                           int64_t ldg = 0) {
+                                           int64_t ldg = 0, int nseg = 1, int64_t segA = 0, int64_t segB = 0) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
 
@@ -96,14 +97,20 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
     typedef u32x4_t (*StB)[GeoX<TILES>::template slots<TB>()];
     StA Ax = reinterpret_cast<StA>(smem);
     StB Bx = reinterpret_cast<StB>(reinterpret_cast<u32x4_t*>(smem) + 2 * GeoX<TILES>::template slots<!TA>());
-    tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, n0 == 0 ? colsum : nullptr);
+    if (nseg <= 1) tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, n0 == 0 ? colsum : nullptr);
+    else        // pk2_gemm_f32_seg: the segments' products one behind the other into the same accumulators (each ends behind a barrier)
+      for (int sg = 0; sg < nseg; ++sg)
+        tile_mainloop_bf16x3<!TA, TB, TILES>(A + sg * segA, lda, B + sg * segB, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, nullptr, sg == 0);
   } else {
     constexpr int LDA = Geo<TILES>::template ld<!TA>(), LDB = Geo<TILES>::template ld<TB>();   // per-operand LDS row pitch
     typedef float (*StA)[BK * LDA];
     typedef float (*StB)[BK * LDB];
     StA As = reinterpret_cast<StA>(smem);
     StB Bs = reinterpret_cast<StB>(reinterpret_cast<float*>(smem) + 2 * BK * LDA);
-    tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
+    if (nseg <= 1) tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
+    else
+      for (int sg = 0; sg < nseg; ++sg)
+        tile_mainloop<!TA, TB, TILES>(A + sg * segA, lda, B + sg * segB, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc, sg == 0);
   }
 #ifdef PK2_GEMM_PROFILE
   const long long gp_t1 = wall_clock64();
@@ -151,7 +158,7 @@ __global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f
   __shared__ __attribute__((aligned(16))) char smem[gemm_smem_bytes<TA, TB, TILES, X3>()];
   gemm_block<TA, TB, TILES, X3>(smem, M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
                                 blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1, bt.colsum, bt.act, bt.gate,
-                                bt.ldg);
+                                bt.ldg, bt.nseg, bt.segA, bt.segB);
 }
 
 // The row bands of a plain 2-D product in ONE launch (round 4): workgroups [0, nbig) take the 128x128 tiles of rows
@@ -282,7 +289,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   // summation-order noise of 1e-7 cannot flip anything).  PK2_GEMM_SPLIT_FWD=1 restores the round-5 behaviour.
   static const bool split_fwd = [] { const char* e = getenv("PK2_GEMM_SPLIT_FWD"); return e && atoi(e) == 1; }();
   const bool forward_form = !transa && transb && !split_fwd;
-  if (!forward_form && bt.act == 0 && (big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
+  if (!forward_form && bt.act == 0 && bt.nseg == 1 && (big_tiles <= 256 || (split_mid && transa && !transb && big_tiles < 512)) && K >= deep_k && (!fsplit || atoi(fsplit) != 1)) {
     int ks = (int)std::min<int64_t>((768 + big_tiles - 1) / big_tiles, K / PK2_GEMM_MIN_KSLICE);
     if (big_tiles > 256) {
       // between one and two tiles per CU: the slice count that fills whole rounds of the 512 workgroup slots best (368 tiles:
@@ -335,7 +342,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
   const bool no_band = band_env && atoi(band_env) == 0;
   // (between one and two big tiles per CU -- 64x64 tiles throughout -- a band of one big tile per CU plus small ones was
   // slower: 6048 x 1024 x 2356: 351 against 334 us, tools/dbg/gemm_modes.py)
-  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && !bt.colsum && bt.act == 0 && (transa ? (lda & 3) == 0 : true)) {
+  if (tiles == 2 && !no_band && bt.ksplit == 1 && n0 * bt.n1 == 1 && !force && !bt.colsum && bt.act == 0 && bt.nseg == 1 && (transa ? (lda & 3) == 0 : true)) {
     const int Cn = (N + 127) / 128, R = (M + 127) / 128, Cs = (N + 63) / 64;
     auto rounds = [&](int64_t n) { return (double)((n + cus - 1) / cus); };
     int best_r = R; double best = rounds((int64_t)R * Cn);
@@ -395,6 +402,26 @@ extern "C" int pk2_gemm_f32_act(int32_t transa, int32_t transb, int32_t M, int32
   GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
   bt.act = act; bt.gate = gate; bt.ldg = ldg;
   return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, true,
+                     static_cast<hipStream_t>(stream_));
+}
+
+// C = act(alpha sum_{j < nseg} op(A + j segA) op(B + j segB) + beta C + bias): several products into ONE set of accumulators, one
+// launch, no atomics (the sum's order is fixed: bit-reproducible).  TransformerAM's Conv1d(k = 3, pad = 1) over time
+// (reference models/transformer.py:88-92) is three taps = three products over row-shifted views of a zero-padded activation
+// buffer: segA = +- B*C floats walks the taps' row shifts, segB = C*C the taps' weight slices; K = the depth of ONE segment.
+// segA / segB may be negative.  Never cut into K slices.
+extern "C" int pk2_gemm_f32_seg(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, int32_t nseg, float alpha,
+                                const float* A, int64_t lda, int64_t segA, const float* B, int64_t ldb, int64_t segB, float beta,
+                                float* C, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
+                                void* stream_) {
+  PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nseg >= 1 && nseg <= 16, "gemm_f32_seg: bad args");
+  PK2_REQUIRE(act == 0 || act == 1 || (act == 2 && gate && ldg >= N), "gemm_f32_seg: act is 0, 1 (ReLU) or 2 (gate, ldg >= N)");
+  GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
+  bt.act = act; bt.gate = gate; bt.ldg = ldg;
+  bt.nseg = nseg; bt.segA = segA; bt.segB = segB;
+  // (the vector loads of the fast path need every segment's base 16-byte aligned)
+  const bool aligned = nseg == 1 || ((segA & 3) == 0 && (segB & 3) == 0);
+  return gemm_launch(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, 1, bt, aligned,
                      static_cast<hipStream_t>(stream_));
 }
 

@@ -146,17 +146,19 @@ __device__ __forceinline__ void tile_mainloop(const float* __restrict__ A, int64
                                               int m0, int n0, int kbeg, int K, int M, int N, bool vecA, bool vecB,
                                               float (*As)[BK * Geo<TILES>::template ld<KCA>()],
                                               float (*Bs)[BK * Geo<TILES>::template ld<KCB>()],
-                                              f32x16 (&acc)[TILES][TILES]) {
+                                              f32x16 (&acc)[TILES][TILES], bool zero_acc = true) {
   constexpr int BM = Geo<TILES>::BMN, BN = Geo<TILES>::BMN;
   constexpr int LDA = Geo<TILES>::template ld<KCA>(), LDB = Geo<TILES>::template ld<KCB>();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wm = (w >> 1) * 32 * TILES, wn = (w & 1) * 32 * TILES;
+  if (zero_acc) {        // (false: a further segment of pk2_gemm_f32_seg adds onto the accumulators of the one before)
 #pragma unroll
-  for (int i = 0; i < TILES; ++i)
+    for (int i = 0; i < TILES; ++i)
 #pragma unroll
-    for (int j = 0; j < TILES; ++j)
+      for (int j = 0; j < TILES; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
   const int kq = lane >> 5, li = lane & 31;
   // DEPTH k-slabs of BK = 16 in flight in registers, two LDS buffers, ONE barrier per slab: while slab kt is multiplied
   // out of LDS[kt & 1], slab kt+1 (loaded DEPTH iterations ago) is written into the other buffer and slabs kt+2 ..

@@ -67,6 +67,18 @@ def _gemm_act(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, beta=0.0, act=
                                            _lib.stream_ptr()))
 
 
+def _gemm_seg(ta, tb, M, N, K, nseg, A, lda, segA, B, ldb, segB, C, ldc, bias=None, beta=0.0, act=0, gate=None, ldg=0):
+    """pk2_gemm_f32_seg: sum over nseg products (A + j segA)(B + j segB) in one launch, one set of accumulators."""
+    _lib.check(_lib.lib().pk2_gemm_f32_seg(int(ta), int(tb), M, N, K, nseg, 1.0, A, lda, segA, B, ldb, segB, beta, C, ldc, bias,
+                                           act, gate, ldg, _lib.stream_ptr()))
+
+
+def _fuse_conv():
+    """Conv1d(k = 3) as ONE product over three row-shifted views of a zero-padded buffer (PK2_TR_FUSE_CONV=0: three products
+    accumulated with beta = 1 and a ReLU pass, the form of rounds 2-5)."""
+    return os.environ.get("PK2_TR_FUSE_CONV", "1") != "0"
+
+
 def _fuse_relu():
     return os.environ.get("PK2_TR_FUSE_RELU", "1") != "0"
 
@@ -117,7 +129,13 @@ class _TransformerFunction(torch.autograd.Function):
         drop = m.dropout if m.training else 0.0
         fused = d == 64 and os.environ.get("PK2_ATTN_FUSED", "1") != "0"
         ctx.fused, ctx.masks = fused, (src_mask, key_pad)
-        fuse_relu = _fuse_relu()
+        fuse_relu, fuse_conv = _fuse_relu(), _fuse_conv()
+
+        def new_padded(rows, cols):
+            """[B + rows + B, cols] with zero rows in front and behind (the convolution's padding in time: row r -+ B of
+            the time-major matrix is frame t -+ 1 of the same utterance); returns the buffer and its middle."""
+            buf = torch.zeros(rows + 2 * B, cols, device=dev, dtype=torch.float32)
+            return buf, buf[B:B + rows]
         x = x.contiguous()
         h = new(R, C)
         _gemm(0, 1, R, C, Din, _p(x), Din, _p(m.input_layer.weight), Din, _p(h), C, bias=_p(m.input_layer.bias))
@@ -167,17 +185,21 @@ class _TransformerFunction(torch.autograd.Function):
             s["seed2"] = _seed() if drop > 0 else None
             if drop > 0:
                 _dropout(f2, drop, s["seed2"], f2)
-            s2, x2, mu2, rs2 = new(R, C), new(R, C), new(R), new(R)
+            s2, mu2, rs2 = new(R, C), new(R), new(R)
+            x2p, x2 = new_padded(R, C) if fuse_conv else (None, new(R, C))
             _lib.check(L.pk2_layernorm_fwd(_p(f2), _p(x1), _p(e.norm2.weight), _p(e.norm2.bias), R, C, e.norm2.eps,
                                            _p(s2), _p(x2), _p(mu2), _p(rs2), sp))
-            # Conv1d(k=3, pad=1) over time = three GEMMs over row-shifted slices (time-major: t-1 <-> row - B)
+            # Conv1d(k=3, pad=1) over time = three products over row-shifted slices (time-major: t-1 <-> row - B)
             Wp = lp.conv1d.weight.detach().permute(2, 0, 1).contiguous()   # [3][Cout][Cin]
             y = new(R, C)
-            _gemm(0, 1, R, C, C, _p(x2), C, _p(Wp, C * C), C, _p(y), C, bias=_p(lp.conv1d.bias))
-            if T > 1:
-                _gemm(0, 1, R - B, C, C, _p(x2), C, _p(Wp, 0), C, _p(y, B * C), C, beta=1.0)
-                _gemm(0, 1, R - B, C, C, _p(x2, B * C), C, _p(Wp, 2 * C * C), C, _p(y), C, beta=1.0)
-            _lib.check(L.pk2_relu_fwd(_p(y), y.numel(), sp))
+            if fuse_conv:      # tap j reads rows r + (j - 1) B: views j B rows into the padded buffer; bias and ReLU in the epilogue
+                _gemm_seg(0, 1, R, C, C, 3, _p(x2p), C, B * C, _p(Wp), C, C * C, _p(y), C, bias=_p(lp.conv1d.bias), act=1)
+            else:
+                _gemm(0, 1, R, C, C, _p(x2), C, _p(Wp, C * C), C, _p(y), C, bias=_p(lp.conv1d.bias))
+                if T > 1:
+                    _gemm(0, 1, R - B, C, C, _p(x2), C, _p(Wp, 0), C, _p(y, B * C), C, beta=1.0)
+                    _gemm(0, 1, R - B, C, C, _p(x2, B * C), C, _p(Wp, 2 * C * C), C, _p(y), C, beta=1.0)
+                _lib.check(L.pk2_relu_fwd(_p(y), y.numel(), sp))
             s.update(qkv=qkv, P=Pm, Pd=Pd, lse=lse, cx=cx, s1=s1, x1=x1, mu1=mu1, rs1=rs1, f1=f1, f1d=f1d, s2=s2, x2=x2,
                      mu2=mu2, rs2=rs2, Wp=Wp, y=y)
             saved.append(s)
@@ -253,7 +275,14 @@ class _TransformerFunction(torch.autograd.Function):
         dhn = new(R, C)
         _gemm(0, 0, R, C, P, _p(dlogits), P, _p(m.output_layer.weight), C, _p(dhn), C)
         nf = m.transformer.norm
-        dh = new(R, C)
+        fuse_conv = _fuse_conv()
+
+        def new_dh():
+            """A gradient that becomes a convolution's output gradient: B zero rows in front and behind (see forward)."""
+            if not fuse_conv:
+                return new(R, C)
+            return torch.zeros(R + 2 * B, C, device=dev, dtype=torch.float32)[B:B + R]
+        dh = new_dh()
         _lib.check(L.pk2_layernorm_bwd(_p(dhn), _p(hL), _p(muf), _p(rsf), _p(nf.weight), R, C, _p(dh),
                                        _p(g["transformer.norm.weight"]), _p(g["transformer.norm.bias"]), sp))
         fuse_relu, dh_gated = _fuse_relu(), False
@@ -284,10 +313,13 @@ class _TransformerFunction(torch.autograd.Function):
                 g[pre + "conv1d.weight"].copy_(dWp.permute(1, 2, 0))
             on_side(conv_grads, dc, x2)
             dx2 = new(R, C)
-            _gemm(0, 0, R, C, C, _p(dc), C, _p(s["Wp"], C * C), C, _p(dx2), C)
-            if T > 1:
-                _gemm(0, 0, R - B, C, C, _p(dc, B * C), C, _p(s["Wp"], 0), C, _p(dx2), C, beta=1.0)
-                _gemm(0, 0, R - B, C, C, _p(dc), C, _p(s["Wp"], 2 * C * C), C, _p(dx2, B * C), C, beta=1.0)
+            if fuse_conv:      # tap j's transpose reads rows r + (1 - j) B of dc: one product over three views of its padded buffer
+                _gemm_seg(0, 0, R, C, C, 3, _p(dc, B * C), C, -B * C, _p(s["Wp"]), C, C * C, _p(dx2), C)
+            else:
+                _gemm(0, 0, R, C, C, _p(dc), C, _p(s["Wp"], C * C), C, _p(dx2), C)
+                if T > 1:
+                    _gemm(0, 0, R - B, C, C, _p(dc, B * C), C, _p(s["Wp"], 0), C, _p(dx2), C, beta=1.0)
+                    _gemm(0, 0, R - B, C, C, _p(dc), C, _p(s["Wp"], 2 * C * C), C, _p(dx2, B * C), C, beta=1.0)
             # LayerNorm 2 (+ residual)
             ds2 = new(R, C)
             _lib.check(L.pk2_layernorm_bwd(_p(dx2), _p(s["s2"]), _p(s["mu2"]), _p(s["rs2"]), _p(e.norm2.weight), R, C,
@@ -312,7 +344,7 @@ class _TransformerFunction(torch.autograd.Function):
                 before_overwrite(read_ds2)     # (the side stream reads d s2 as linear2's output gradient: the add below writes it)
             _gemm(0, 0, R, C, F, _p(df1), F, _p(e.linear1.weight), C, _p(dx1), C, beta=1.0)
             # LayerNorm 1 (+ residual)
-            ds1 = new(R, C)
+            ds1 = new_dh()         # (ends up as dh: the output gradient of the convolution of the layer below)
             _lib.check(L.pk2_layernorm_bwd(_p(dx1), _p(s["s1"]), _p(s["mu1"]), _p(s["rs1"]), _p(e.norm1.weight), R, C,
                                            _p(ds1), _p(g[pre + "encoder_layer.norm1.weight"]),
                                            _p(g[pre + "encoder_layer.norm1.bias"]), sp))

@@ -370,3 +370,59 @@ def test_layernorm_backward_matches_float64(rows, C):
         for got, was, want in ((dg, dg0, gr.grad), (db, db0, br.grad)):
             e = ((got - was).cpu().double() - want).abs().max().item()
             assert e < 2e-5 * max(1.0, want.abs().max().item()), (rep, e)
+
+
+@pytest.mark.parametrize("arith", [0, 1], ids=["f32", "bf16x3"])
+@pytest.mark.parametrize("R,B,C", [(2276, 4, 512), (90, 3, 64), (7, 7, 64), (301, 1, 128)])
+def test_segmented_product_is_the_three_tap_convolution(R, B, C, arith):
+    """pk2_gemm_f32_seg over three row-shifted views of a zero-padded [B + R + B, C] buffer against F.conv1d(k = 3,
+    padding = 1) in float64 (time-major rows: frame t of utterance b is row t B + b), forward (+ bias + ReLU) and the
+    transposed product of the input gradient (negative segment stride); R = B is a one-frame minibatch: only padding
+    either side."""
+    import ctypes
+    from pykaldi2_amd import _lib
+    L = _lib.lib()
+    p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)        # noqa: E731
+    sp = _lib.stream_ptr()
+    prev = L.pk2_gemm_get_arith()
+    _lib.check(L.pk2_gemm_set_arith(arith))
+    try:
+        torch.manual_seed(R + B + C)
+        T = R // B
+        conv = torch.nn.Conv1d(C, C, 3, padding=1).double()
+        x = torch.randn(T, B, C, dtype=torch.float64, requires_grad=True)
+        want = F.relu(conv(x.permute(1, 2, 0))).permute(2, 0, 1)              # [T, B, C]
+        dy = torch.randn(T, B, C, dtype=torch.float64)
+        pre = conv(x.permute(1, 2, 0)).permute(2, 0, 1)
+        pre.backward(dy)
+        Wp = conv.weight.detach().permute(2, 0, 1).contiguous().float().cuda()        # [3][Cout][Cin]
+        bias = conv.bias.detach().float().cuda()
+        xp = torch.zeros(R + 2 * B, C, device="cuda")
+        xp[B:B + R] = x.detach().reshape(R, C).float().cuda()
+        y = torch.empty(R, C, device="cuda")
+        _lib.check(L.pk2_gemm_f32_seg(0, 1, R, C, C, 3, 1.0, p(xp), C, B * C, p(Wp), C, C * C, 0.0, p(y), C, p(bias), 1, None, 0, sp))
+        scale = max(1.0, want.abs().max().item())
+        assert (y.cpu().double() - want.detach().reshape(R, C)).abs().max().item() < 2e-5 * scale
+        dcp = torch.zeros(R + 2 * B, C, device="cuda")
+        dcp[B:B + R] = dy.reshape(R, C).float().cuda()
+        dx = torch.empty(R, C, device="cuda")
+        _lib.check(L.pk2_gemm_f32_seg(0, 0, R, C, C, 3, 1.0, p(dcp, 2 * B * C), C, -B * C, p(Wp), C, C * C, 0.0, p(dx), C, None, 0,
+                                      None, 0, sp))
+        gx = x.grad.reshape(R, C)
+        assert (dx.cpu().double() - gx).abs().max().item() < 2e-5 * max(1.0, gx.abs().max().item())
+    finally:
+        _lib.check(L.pk2_gemm_set_arith(prev))
+
+
+def test_convolution_as_one_product_against_three(monkeypatch):
+    """PK2_TR_FUSE_CONV=1 (default) against the three accumulated products + ReLU pass: logits within the products' rounding
+    (one accumulator over K = 3 C instead of three sums added in f32), gradients likewise."""
+    monkeypatch.setenv("PK2_TR_SIDE_STREAM", "0")
+    monkeypatch.setenv("PK2_TR_FUSE_CONV", "1")
+    y1, g1 = _tr_run(4, 90, 3, 300)
+    monkeypatch.setenv("PK2_TR_FUSE_CONV", "0")
+    y0, g0 = _tr_run(4, 90, 3, 300)
+    assert (y1 - y0).abs().max().item() < 2e-5 * max(1.0, y0.abs().max().item())
+    for n in g0:       # (Frobenius norm: an activation within rounding of zero may flip its ReLU mask between the two forms)
+        e = (g1[n] - g0[n]).norm().item()
+        assert e < 5e-3 * max(1e-6, g0[n].norm().item()), (n, e)
