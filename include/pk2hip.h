@@ -315,7 +315,8 @@ int pk2_gemm_f32_act(int32_t transa, int32_t transb, int32_t M, int32_t N, int32
  *   C = act(alpha * sum_{j < nseg} op(A + j*segA) * op(B + j*segB) + beta*C + bias),   K = depth of ONE segment.
  * TransformerAM's Conv1d(kernel 3, padding 1) over time (reference models/transformer.py:88-92: conv1d -> F.relu)
  * is nseg = 3 over row-shifted views of a zero-padded [B + T*B + B, C] activation buffer (segA = +-B*C floats,
- * segB = C*C: the taps' weight slices); segA / segB may be negative; act / gate as in pk2_gemm_f32_act. */
+ * segB = C*C: the taps' weight slices); segA / segB may be negative; transa = 0 only; act / gate as in
+ * pk2_gemm_f32_act. */
 int pk2_gemm_f32_seg(int32_t transa, int32_t transb, int32_t M, int32_t N, int32_t K, int32_t nseg, float alpha,
                      const float* A, int64_t lda, int64_t segA, const float* B, int64_t ldb, int64_t segB, float beta,
                      float* C, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,

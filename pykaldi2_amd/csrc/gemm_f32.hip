@@ -79,7 +79,7 @@ constexpr size_t gemm_smem_bytes() {
   return 2 * sizeof(float) * BK * (size_t)(Geo<TILES>::template ld<!TA>() + Geo<TILES>::template ld<TB>());
 }
 
-template <bool TA, bool TB, int TILES, bool X3>
+template <bool TA, bool TB, int TILES, bool X3, bool SEG = false>
 __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int kbeg, float alpha, const float* __restrict__ A, int64_t lda,
                                            const float* __restrict__ B, int64_t ldb, float beta, float* __restrict__ C,
                                            int64_t ldc, const float* __restrict__ bias, bool vecA, bool vecB, int m0, int n0,
@@ -97,8 +97,11 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
     typedef u32x4_t (*StB)[GeoX<TILES>::template slots<TB>()];
     StA Ax = reinterpret_cast<StA>(smem);
     StB Bx = reinterpret_cast<StB>(reinterpret_cast<u32x4_t*>(smem) + 2 * GeoX<TILES>::template slots<!TA>());
-    if (nseg <= 1) tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, n0 == 0 ? colsum : nullptr);
-    else        // pk2_gemm_f32_seg: the segments' products one behind the other into the same accumulators (each ends behind a barrier)
+    // SEG (pk2_gemm_f32_seg): the segments' products one behind the other into the same accumulators (each main loop ends behind a
+    // barrier).  A template parameter, not a run-time branch: with both forms in ONE kernel every ordinary product ran slower (CE
+    // step 19.0 -> 19.8 ms, LF-MMI 11.59 -> 11.73, same job twice: the second copy of the main loop changes the register allocation).
+    if constexpr (!SEG) tile_mainloop_bf16x3<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, n0 == 0 ? colsum : nullptr);
+    else
       for (int sg = 0; sg < nseg; ++sg)
         tile_mainloop_bf16x3<!TA, TB, TILES>(A + sg * segA, lda, B + sg * segB, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, Ax, Bx, acc, nullptr, sg == 0);
   } else {
@@ -107,7 +110,7 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
     typedef float (*StB)[BK * LDB];
     StA As = reinterpret_cast<StA>(smem);
     StB Bs = reinterpret_cast<StB>(reinterpret_cast<float*>(smem) + 2 * BK * LDA);
-    if (nseg <= 1) tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
+    if constexpr (!SEG) tile_mainloop<!TA, TB, TILES>(A, lda, B, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc);
     else
       for (int sg = 0; sg < nseg; ++sg)
         tile_mainloop<!TA, TB, TILES>(A + sg * segA, lda, B + sg * segB, ldb, m0, n0, kbeg, K, M, N, vecA, vecB, As, Bs, acc, sg == 0);
@@ -135,7 +138,7 @@ __device__ __forceinline__ void gemm_block(void* smem, int M, int N, int K, int 
 // (Round 6, measured and removed: an XCD-aware tile order -- workgroup l of the dispatch order takes tile (l % 8) (G / 8) + l / 8,
 // so that each XCD's L2 sees its own row bands of A instead of all of A -- changed nothing on 20480 x 4096 x 1024 in either
 // arithmetic (bf16x3 937 / 947 / 959 us against 905 / 966 / 950 in plain order): the memory-side cache absorbs the 8-fold fetch.)
-template <bool TA, bool TB, int TILES, bool X3>
+template <bool TA, bool TB, int TILES, bool X3, bool SEG = false>
 __global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f32_kernel(int M, int N, int K, float alpha,
                                                                 const float* __restrict__ A, int64_t lda,
                                                                 const float* __restrict__ B, int64_t ldb,
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(kGemmThreads, X3 ? PK2_GEMMX_WAVES : 3) gemm_f
     C += i0 * bt.sC0 + i1 * bt.sC1;
   }
   __shared__ __attribute__((aligned(16))) char smem[gemm_smem_bytes<TA, TB, TILES, X3>()];
-  gemm_block<TA, TB, TILES, X3>(smem, M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
+  gemm_block<TA, TB, TILES, X3, SEG>(smem, M, N, K, kbeg, alpha, A, lda, B, ldb, beta, C, ldc, bias, vecA, vecB,
                                 blockIdx.y * Geo<TILES>::BMN, blockIdx.x * Geo<TILES>::BMN, bt.ksplit > 1, bt.colsum, bt.act, bt.gate,
                                 bt.ldg, bt.nseg, bt.segA, bt.segB);
 }
@@ -320,6 +323,16 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
 #define PK2_GEMM_T(TA, TB, T, X)                                                                                  \
   hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, T, X>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B, ldb, \
                      beta, Cp, ldc, bias, vecA, vecB, bt)
+#define PK2_GEMM_SEG_T(TB, T, X)                                                                                  \
+  hipLaunchKernelGGL((gemm_f32_kernel<false, TB, T, X, true>), grid, block, 0, stream, m_rows, N, K, alpha, Ap, lda, B, ldb, \
+                     beta, Cp, ldc, bias, vecA, vecB, bt)
+    if (bt.nseg > 1) {       // (A row-major only: pk2_gemm_f32_seg)
+      if (transb) { if (t == 2) { if (x3) PK2_GEMM_SEG_T(true, 2, true); else PK2_GEMM_SEG_T(true, 2, false); }
+                    else        { if (x3) PK2_GEMM_SEG_T(true, 1, true); else PK2_GEMM_SEG_T(true, 1, false); } }
+      else        { if (t == 2) { if (x3) PK2_GEMM_SEG_T(false, 2, true); else PK2_GEMM_SEG_T(false, 2, false); }
+                    else        { if (x3) PK2_GEMM_SEG_T(false, 1, true); else PK2_GEMM_SEG_T(false, 1, false); } }
+      return;
+    }
 #define PK2_GEMM(TA, TB)                                                                                          \
   do {                                                                                                            \
     if (t == 2) { if (x3) PK2_GEMM_T(TA, TB, 2, true); else PK2_GEMM_T(TA, TB, 2, false); }                       \
@@ -331,6 +344,7 @@ static int gemm_launch(int transa, int transb, int M, int N, int K, float alpha,
     else PK2_GEMM(true, true);
 #undef PK2_GEMM
 #undef PK2_GEMM_T
+#undef PK2_GEMM_SEG_T
   };
   // Tile quantisation: 128x128 tiles are dealt to 256 CUs, so e.g. the 18 x 32 = 576 tiles of the BLSTM input projection
   // (M = 2276 rows) take three tile-times on some CUs for 2.25 tile-times of work.  A plain 2-D product is therefore cut
@@ -415,6 +429,7 @@ extern "C" int pk2_gemm_f32_seg(int32_t transa, int32_t transb, int32_t M, int32
                                 float* C, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
                                 void* stream_) {
   PK2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nseg >= 1 && nseg <= 16, "gemm_f32_seg: bad args");
+  PK2_REQUIRE(!transa, "gemm_f32_seg: A is row-major [M, K] (transa = 0)");
   PK2_REQUIRE(act == 0 || act == 1 || (act == 2 && gate && ldg >= N), "gemm_f32_seg: act is 0, 1 (ReLU) or 2 (gate, ldg >= N)");
   GemmBatch bt{1, 0, 0, 0, 0, 0, 0, 1, 0};
   bt.act = act; bt.gate = gate; bt.ldg = ldg;
