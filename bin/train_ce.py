@@ -18,7 +18,7 @@ import torch as th
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pykaldi2_amd import data, fbank, hvd, lstm, ops, optim, utils  # noqa: E402
+from pykaldi2_amd import _lib, data, fbank, hvd, lstm, ops, optim, utils  # noqa: E402
 
 
 class ChunkPool:
@@ -184,7 +184,7 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
         off = np.concatenate([[0], np.cumsum(frames)])
         for n, y in enumerate(batch["y"]):
             f = feats[off[n]:off[n + 1]]
-            lab = th.from_numpy(np.asarray(y)[:frames[n]]).to(dev).unsqueeze(1)
+            lab = _lib.h2d(np.ascontiguousarray(np.asarray(y)[:frames[n]]), dev).unsqueeze(1)
             pool.add(fbank.utt2seg(f, seg_len, seg_shift), fbank.utt2seg(lab, seg_len, seg_shift))
         for x, y in pool.batches(args.batch_size):
             if i >= n_batches:

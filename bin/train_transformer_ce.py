@@ -20,7 +20,7 @@ import torch as th
 import yaml
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pykaldi2_amd import data, fbank, hvd, ops, optim, transformer, utils  # noqa: E402
+from pykaldi2_amd import _lib, data, fbank, hvd, ops, optim, transformer, utils  # noqa: E402
 
 
 def parse_config(argv=None):
@@ -136,7 +136,7 @@ def run_train_epoch(model, optimizer, criterion, source, fb, epoch, config, args
         y = np.full((N, Tmax), -100, np.int64)          # SeqDataloader pads the labels with -100 (data/dataloader.py:94-136)
         for n, lab in enumerate(batch["y"]):
             y[n, :frames[n]] = np.asarray(lab)[:frames[n]]
-        loss = criterion(prediction, th.from_numpy(y).to(dev))
+        loss = criterion(prediction, _lib.h2d(y, dev))
         optimizer.zero_grad()
         loss.backward()
         norm = optim.clip_grad_norm_(optimizer, args.max_grad_norm)

@@ -176,6 +176,18 @@ def lib():
     return _lib
 
 
+def h2d(host, device):
+    """Host array / tensor -> device without synchronising the stream: over pinned memory and non-blocking.  A pageable
+    copy is hipMemcpyAsync + a wait for everything the stream holds, i.e. a training loop that copies its labels or its
+    waveforms that way never has the next step's launches queued while the device works on this one (measured on the
+    TransformerAM step: DESIGN.md 4.3).  The pinned block goes back to torch's host allocator behind the copy's event."""
+    import numpy as np
+    t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
+    if torch.device(device).type != "cuda" or t.is_cuda or t.numel() == 0:
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def check(status):
     if status != 0:
         msg = lib().pk2_last_error()

@@ -24,7 +24,7 @@ import zipfile
 import numpy as np
 import torch
 
-from . import synth
+from . import _lib, synth
 
 
 def read_label_file(path):
@@ -270,7 +270,7 @@ class SimulationPool:
     def maybe_simulate(self, wav, device):
         """wav: host float32 -> device tensor, simulated with probability simulation_prob (the draws use numpy's
         global generator like the reference: data/sr_dataset.py:321-336)."""
-        x = torch.from_numpy(wav).to(device, non_blocking=True)
+        x = _lib.h2d(wav, device)
         if np.random.random() > self.prob:
             return x
         noise = noise_rir = src_rir = None
@@ -355,6 +355,6 @@ def sequence_batches(source, batch_size, hours, device, simulation=None, rank=No
         if simulation is not None:
             wav = torch.cat([simulation.maybe_simulate(u[0], device) for u in utts])
         else:
-            wav = torch.from_numpy(np.concatenate([u[0] for u in utts])).to(device, non_blocking=True)
+            wav = _lib.h2d(np.concatenate([u[0] for u in utts]), device)      # (pinned: the copy does not wait for the step in flight)
         yield dict(wav=wav, lens=lens, y=[u[1] for u in utts], aux=[u[2] for u in utts],
                    utt_ids=[u[3] for u in utts], seconds=sum(lens) / 16000.0)
