@@ -1144,8 +1144,14 @@ def main():
             _lib.check(_lib.lib().pk2_gemm_set_arith(1))
 
     # per-phase breakdown of one extra (untimed) step -- on EVERY rank: the step contains the gradient all-reduce
+    # The step whose phases are read follows two untimed ones WITHOUT a synchronisation in between, so that its launches are
+    # queued behind work the device still has, as in the timed loop: right behind a synchronisation the phases would
+    # hold the host's enqueue latency as well (400 launches of the TransformerAM step take the host 11.6 ms against the
+    # 12.7 ms the device needs for them; the `fbank` phase of either model read 0.4-3.9 ms for 0.1 ms of kernels).
     events = []
     mb = batches[0]
+    for _ in range(2):
+        tr.step(mb)
     tr.step(mb, events=events)
     torch.cuda.synchronize()
     if rank != 0:

@@ -140,7 +140,16 @@ class _TransformerFunction(torch.autograd.Function):
         h = new(R, C)
         _gemm(0, 1, R, C, Din, _p(x), Din, _p(m.input_layer.weight), Din, _p(h), C, bias=_p(m.input_layer.bias))
         saved = []
-        for lp in m.transformer.layers:
+        # The convolution taps of ALL layers in product layout [L][3][Cout][Cin] with one strided copy: the layers' weights
+        # sit at equal distances in the flat parameter buffer (same parameters in the same order per layer)
+        Wp_all = None
+        nl = len(m.transformer.layers)
+        if nl > 1 and m._flat is not None:
+            offs = [m._layout["transformer.layers.%d.conv1d.weight" % i][0] for i in range(nl)]
+            step = offs[1] - offs[0]
+            if step > 0 and all(offs[i] == offs[0] + i * step for i in range(nl)):
+                Wp_all = torch.as_strided(m._flat, (nl, C, C, 3), (step, 3 * C, 3, 1), offs[0]).permute(0, 3, 1, 2).contiguous()
+        for li_, lp in enumerate(m.transformer.layers):
             e = lp.encoder_layer
             a = e.self_attn
             s = dict(h_in=h)
@@ -190,7 +199,7 @@ class _TransformerFunction(torch.autograd.Function):
             _lib.check(L.pk2_layernorm_fwd(_p(f2), _p(x1), _p(e.norm2.weight), _p(e.norm2.bias), R, C, e.norm2.eps,
                                            _p(s2), _p(x2), _p(mu2), _p(rs2), sp))
             # Conv1d(k=3, pad=1) over time = three products over row-shifted slices (time-major: t-1 <-> row - B)
-            Wp = lp.conv1d.weight.detach().permute(2, 0, 1).contiguous()   # [3][Cout][Cin]
+            Wp = Wp_all[li_] if Wp_all is not None else lp.conv1d.weight.detach().permute(2, 0, 1).contiguous()   # [3][Cout][Cin]
             y = new(R, C)
             if fuse_conv:      # tap j reads rows r + (j - 1) B: views j B rows into the padded buffer; bias and ReLU in the epilogue
                 _gemm_seg(0, 1, R, C, C, 3, _p(x2p), C, B * C, _p(Wp), C, C * C, _p(y), C, bias=_p(lp.conv1d.bias), act=1)
