@@ -285,6 +285,15 @@ int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_
                            int64_t ignore_index, int64_t rows, int32_t num_classes,
                            float* loss_sum, int32_t* count, float* grad, int64_t grad_row_stride,
                            float* logprob_out /* optional [rows][P] or NULL */, void* stream);
+/* nn.CrossEntropyLoss(reduction='mean') in two launches with NO scaling pass over [rows, classes]: a one-workgroup launch
+ * counts the valid targets into *count first, then the kernel above writes grad = d(mean loss)/d logits directly
+ * (divided by max(1, count)); loss_sum stays the SUM of the row losses (reference bin/train_ce.py:134,189). */
+int pk2_softmax_ce_fwd_bwd_mean(const float* logits, int64_t row_stride, const int64_t* targets,
+                                int64_t ignore_index, int64_t rows, int32_t num_classes,
+                                float* loss_sum, int32_t* count, float* grad, int64_t grad_row_stride, void* stream);
+/* data[i] *= (*num_dev) / (*den_dev) IN PLACE (den_dev may be NULL = 1); when the factor is exactly 1 nothing is read or
+ * written beyond the two scalars: the incoming gradient of loss.backward() (1.0) costs no pass over the gradient. */
+int pk2_scale_inplace_ratio(float* data, int64_t n, const float* num_dev, const float* den_dev, void* stream);
 /* grad *= (*scale_num) / max(1, *count_den) on the device (mean reduction). */
 int pk2_scale_by_count(float* data, int64_t n, float numerator, const int32_t* count_den,
                        void* stream);

@@ -105,6 +105,8 @@ SIGNATURES = {
     "pk2_pad_roll_subsample": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "pk2_mvn_apply": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "pk2_softmax_ce_fwd_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "pk2_softmax_ce_fwd_bwd_mean": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "pk2_scale_inplace_ratio": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "pk2_scale_by_count": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "pk2_scale_by_scalars": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "pk2_gemm_f32": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64,

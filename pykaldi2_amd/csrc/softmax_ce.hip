@@ -34,9 +34,12 @@ template <bool IN_REGS>
 __global__ void __launch_bounds__(kCeThreads) softmax_ce_kernel(
     const float* __restrict__ logits, int64_t row_stride, const int64_t* __restrict__ targets,
     int64_t ignore_index, int64_t rows, int P, float* loss_sum, int32_t* count, float* __restrict__ grad,
-    int64_t grad_row_stride, float* __restrict__ logprob) {
+    int64_t grad_row_stride, float* __restrict__ logprob, const int32_t* __restrict__ count_in) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
+  // count_in (pk2_softmax_ce_fwd_bwd_mean): the number of valid targets is known before this launch (count_valid_kernel), so the
+  // gradient of the MEAN loss is written as it is -- no scaling pass over [rows, P] behind this kernel; the count is not added again
+  const float gs = count_in ? 1.f / (float)max(1, *count_in) : 1.f;
   // A workgroup takes rows blockIdx.x, + gridDim.x, ... and adds its loss and count to the totals ONCE at the end: an atomic
   // pair per row (20 480 rows x 2 on one cache line at the CE configuration) queued in L2 for longer than the rows took to
   // stream -- 518 us for 0.94 GB.
@@ -90,22 +93,59 @@ __global__ void __launch_bounds__(kCeThreads) softmax_ce_kernel(
       const int p = tid + k * kCeThreads;
       if (p < P) {
         const float sm = v[k] * inv;
-        if (g) g[p] = ignored ? 0.f : (sm - (p == tgt ? 1.f : 0.f));
+        if (g) g[p] = ignored ? 0.f : (sm - (p == tgt ? 1.f : 0.f)) * gs;
         if (logprob) logprob[row * (int64_t)P + p] = logf(fmaxf(sm, 1e-45f)) ;
       }
     }
   } else {
     for (int p = tid; p < P; p += kCeThreads) {
       const float lp = x[p] - lse;
-      if (g) g[p] = ignored ? 0.f : (expf(lp) - (p == tgt ? 1.f : 0.f));
+      if (g) g[p] = ignored ? 0.f : (expf(lp) - (p == tgt ? 1.f : 0.f)) * gs;
       if (logprob) logprob[row * (int64_t)P + p] = lp;
     }
   }
   }
   if (tid == 0) {
     if (loss_local != 0.f) atomicAdd(loss_sum, loss_local);       // (NaN != 0: the out-of-range marker goes through)
-    if (count_local) atomicAdd(count, count_local);
+    if (count_local && !count_in) atomicAdd(count, count_local);
   }
+}
+
+// Valid targets (neither ignore_index nor outside [0, P)) of the whole call, one workgroup: 20 480 labels at the CE configuration.
+__global__ void __launch_bounds__(1024) count_valid_kernel(const int64_t* __restrict__ targets, int64_t rows, int64_t ignore_index, int P,
+                                                           int32_t* count) {
+  __shared__ int red[16];
+  int c = 0;
+  for (int64_t r = threadIdx.x; r < rows; r += 1024) {
+    const int64_t t = targets[r];
+    c += (t != ignore_index && t >= 0 && t < P) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *count = t;
+  }
+}
+
+// data[i] *= (*num) / (*den)  (den may be null: 1), nothing touched when the factor is exactly 1: the loss's incoming gradient
+// applied IN PLACE to a gradient that is otherwise final -- loss.backward() hands in 1.0 and the pass over [rows, P] does not
+// happen (every workgroup reads the two scalars and leaves).  A repeated backward over a retained graph passes the factor
+// the buffer already carries as den.
+__global__ void scale_inplace_ratio_kernel(float* __restrict__ data, int64_t n, const float* num, const float* den) {
+  const float f = (*num) / (den ? *den : 1.f);
+  if (f == 1.f) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(data) & 15u) == 0 ? n / 4 : 0;
+  for (int64_t i = i0; i < n4; i += stride) {
+    float4 v = reinterpret_cast<float4*>(data)[i];
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    reinterpret_cast<float4*>(data)[i] = v;
+  }
+  for (int64_t i = 4 * n4 + i0; i < n; i += stride) data[i] *= f;
 }
 
 __global__ void scale_by_count_kernel(float* data, int64_t n, float numerator, const int32_t* count) {
@@ -144,14 +184,17 @@ extern "C" int pk2_scale_by_scalars(const float* in, float* out, int64_t n, cons
   return PK2_OK;
 }
 
-extern "C" int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_t* targets,
-                                      int64_t ignore_index, int64_t rows, int32_t P, float* loss_sum,
-                                      int32_t* count, float* grad, int64_t grad_row_stride,
-                                      float* logprob_out, void* stream_) {
-  PK2_REQUIRE(logits && targets && loss_sum && count && rows >= 0 && P > 0, "softmax_ce: bad args");
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int softmax_ce_launch(const float* logits, int64_t row_stride, const int64_t* targets, int64_t ignore_index, int64_t rows,
+                             int32_t P, float* loss_sum, int32_t* count, float* grad, int64_t grad_row_stride, float* logprob_out,
+                             bool mean_grad, hipStream_t stream) {
   PK2_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), stream));
-  PK2_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+  const int32_t* count_in = nullptr;
+  if (mean_grad && rows > 0) {
+    hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, stream, targets, rows, ignore_index, P, count);
+    count_in = count;
+  } else {
+    PK2_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+  }
   if (rows == 0) return PK2_OK;
   // (256 CUs x 8 resident workgroups; a workgroup walks rows blockIdx.x, + grid, ...)
   static const int ce_grid = [] { const char* e = getenv("PK2_CE_GRID"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : v; }();
@@ -159,12 +202,41 @@ extern "C" int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, c
   if (P <= kCeThreads * kCeVpt && !logprob_out) {
     hipLaunchKernelGGL(softmax_ce_kernel<true>, dim3(grid), dim3(kCeThreads), 0, stream, logits,
                        row_stride, targets, ignore_index, rows, P, loss_sum, count, grad, grad_row_stride,
-                       logprob_out);
+                       logprob_out, count_in);
   } else {
     hipLaunchKernelGGL(softmax_ce_kernel<false>, dim3(grid), dim3(kCeThreads), 0, stream, logits,
                        row_stride, targets, ignore_index, rows, P, loss_sum, count, grad, grad_row_stride,
-                       logprob_out);
+                       logprob_out, count_in);
   }
+  PK2_LAUNCH_CHECK();
+  return PK2_OK;
+}
+
+extern "C" int pk2_softmax_ce_fwd_bwd(const float* logits, int64_t row_stride, const int64_t* targets,
+                                      int64_t ignore_index, int64_t rows, int32_t P, float* loss_sum,
+                                      int32_t* count, float* grad, int64_t grad_row_stride,
+                                      float* logprob_out, void* stream_) {
+  PK2_REQUIRE(logits && targets && loss_sum && count && rows >= 0 && P > 0, "softmax_ce: bad args");
+  return softmax_ce_launch(logits, row_stride, targets, ignore_index, rows, P, loss_sum, count, grad, grad_row_stride, logprob_out,
+                           false, static_cast<hipStream_t>(stream_));
+}
+
+// As above with grad = d(MEAN loss) / d logits: the valid targets are counted by a one-workgroup launch in front, the
+// gradient leaves the kernel divided by max(1, count) (loss_sum stays the SUM: the caller divides one scalar).
+extern "C" int pk2_softmax_ce_fwd_bwd_mean(const float* logits, int64_t row_stride, const int64_t* targets,
+                                           int64_t ignore_index, int64_t rows, int32_t P, float* loss_sum,
+                                           int32_t* count, float* grad, int64_t grad_row_stride, void* stream_) {
+  PK2_REQUIRE(logits && targets && loss_sum && count && grad && rows >= 0 && P > 0, "softmax_ce (mean): bad args");
+  return softmax_ce_launch(logits, row_stride, targets, ignore_index, rows, P, loss_sum, count, grad, grad_row_stride, nullptr,
+                           true, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int pk2_scale_inplace_ratio(float* data, int64_t n, const float* num_dev, const float* den_dev, void* stream_) {
+  PK2_REQUIRE(data && num_dev && n >= 0, "scale_inplace_ratio: bad args");
+  if (n == 0) return PK2_OK;
+  const int blocks = (int)std::min<int64_t>(4096, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(scale_inplace_ratio_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), data, n, num_dev,
+                     den_dev);
   PK2_LAUNCH_CHECK();
   return PK2_OK;
 }

@@ -16,6 +16,8 @@ MMIFunction / sMBRFunction (lattice-based, ops/ops.py:41-75,119-156) decode on t
 is the whole-minibatch form.
 """
 import numpy as np
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -81,12 +83,18 @@ class _CrossEntropyFunction(Function):
         acc = torch.empty(2, dtype=torch.float32, device=x.device)
         cnt = acc[1:2].view(torch.int32)
         L = _lib.lib()
-        _lib.check(L.pk2_softmax_ce_fwd_bwd(_lib.ptr(x2), P, _lib.ptr(tg), int(ignore_index), rows, P,
-                                            _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(grad), P, None,
-                                            _lib.stream_ptr(x.device)))
-        # the gradient stays UNSCALED here: 1 / (valid targets) and the loss's incoming gradient are applied together in
-        # backward, in one pass over the [rows, P] tensor (it was a scaling launch here and a torch multiply there: two
-        # read-modify-write passes over 470 MB at the CE configuration)
+        # reduction='mean': the valid targets are counted by a one-workgroup launch in front, so the kernel writes the MEAN
+        # loss's gradient as it is; backward applies the loss's incoming gradient in place by a launch that returns at
+        # once when that gradient is exactly 1 (loss.backward()).  Rounds 1-6a scaled in a pass of its own over the
+        # [rows, P] tensor (185 us of the 18.5 ms CE step for 2 x 470 MB; PK2_CE_SCALE_PASS=1 keeps it).
+        ctx.prescaled = os.environ.get("PK2_CE_SCALE_PASS", "0") != "1"
+        if reduction == "mean" and ctx.prescaled:
+            _lib.check(L.pk2_softmax_ce_fwd_bwd_mean(_lib.ptr(x2), P, _lib.ptr(tg), int(ignore_index), rows, P,
+                                                     _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(grad), P, _lib.stream_ptr(x.device)))
+        else:
+            _lib.check(L.pk2_softmax_ce_fwd_bwd(_lib.ptr(x2), P, _lib.ptr(tg), int(ignore_index), rows, P,
+                                                _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(grad), P, None,
+                                                _lib.stream_ptr(x.device)))
         if reduction == "mean":
             loss = acc[0] / cnt.to(torch.float32).clamp_min(1.0)[0]
         else:
@@ -94,6 +102,7 @@ class _CrossEntropyFunction(Function):
         ctx.save_for_backward(grad, cnt)
         ctx.mean = reduction == "mean"
         ctx.view = (layout, tuple(x.shape), P)
+        ctx.applied = None          # the incoming gradient the saved buffer already carries (a second backward over a retained graph)
         return loss
 
     @staticmethod
@@ -101,9 +110,16 @@ class _CrossEntropyFunction(Function):
         grad, cnt = ctx.saved_tensors
         layout, shape, P = ctx.view
         go = grad_out.detach().to(device=grad.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
-        out = torch.empty_like(grad)
-        _lib.check(_lib.lib().pk2_scale_by_scalars(_lib.ptr(grad), _lib.ptr(out), grad.numel(), _lib.ptr(go),
-                                                   _lib.ptr(cnt) if ctx.mean else None, _lib.stream_ptr(grad.device)))
+        if ctx.prescaled:
+            _lib.check(_lib.lib().pk2_scale_inplace_ratio(_lib.ptr(grad), grad.numel(), _lib.ptr(go),
+                                                          _lib.ptr(ctx.applied) if ctx.applied is not None else None,
+                                                          _lib.stream_ptr(grad.device)))
+            ctx.applied = go
+            out = grad
+        else:
+            out = torch.empty_like(grad)
+            _lib.check(_lib.lib().pk2_scale_by_scalars(_lib.ptr(grad), _lib.ptr(out), grad.numel(), _lib.ptr(go),
+                                                       _lib.ptr(cnt) if ctx.mean else None, _lib.stream_ptr(grad.device)))
         g = out.view(shape[1], shape[0], P).transpose(0, 1) if layout == "tm" else out.view(shape)
         return g, None, None, None
 

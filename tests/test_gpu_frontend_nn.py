@@ -320,6 +320,35 @@ def test_cross_entropy_matches_reference_golden(golden):
     assert torch.isnan(loss).item() and not x.grad[0].any().item() and torch.isfinite(x.grad).all().item()
 
 
+@pytest.mark.parametrize("red", ["mean", "sum"])
+def test_cross_entropy_incoming_gradient_and_repeated_backward(red, monkeypatch):
+    """The gradient of the mean loss leaves the kernel final (valid targets counted in front); the loss's incoming gradient is
+    applied in place and skipped when it is 1: scaled losses, a second backward over a retained graph with another factor,
+    targets with ignored and out-of-count rows, and the old scaling pass (PK2_CE_SCALE_PASS=1) against torch on the host."""
+    torch.manual_seed(3)
+    rows, P = 300, 517
+    x0 = torch.randn(rows, P) * 3
+    tg = torch.randint(0, P, (rows,))
+    tg[::7] = -100
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PK2_CE_SCALE_PASS", mode)
+        ref = x0.clone().double().requires_grad_()
+        lref = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction=red)(ref, tg)
+        x = x0.clone().cuda().requires_grad_()
+        loss = ops.CrossEntropyLoss(ignore_index=-100, reduction=red)(x, tg.cuda())
+        assert abs(loss.item() - lref.item()) < 1e-5 * abs(lref.item())
+        scale = max(1e-12, torch.autograd.grad(lref, ref, retain_graph=True)[0].abs().max().item())
+        for factor in (1.0, 0.37, 1.0, -2.5):           # repeated backward passes over the retained graph
+            want = torch.autograd.grad(lref * factor, ref, retain_graph=True)[0]
+            got = torch.autograd.grad(loss * factor, x, retain_graph=True)[0]
+            assert (got.cpu().double() - want).abs().max().item() < 2e-6 * scale * max(1.0, abs(factor)), (mode, factor)
+    # every target ignored: count 0 -> the division is by max(1, 0)
+    x = x0.clone().cuda().requires_grad_()
+    loss = ops.CrossEntropyLoss(ignore_index=-100, reduction=red)(x, torch.full((rows,), -100).cuda())
+    loss.backward()
+    assert loss.item() == 0.0 and not x.grad.any().item()
+
+
 class _Flat:
     def __init__(self, p):
         self.p, self.g = p, torch.zeros_like(p)
