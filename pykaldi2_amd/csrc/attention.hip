@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pk2 {
@@ -36,7 +38,7 @@ constexpr int kATileFloats = kAT * kALd;
 struct AttnParams {
   const float* qkv; const float* ctx; const float* dctx; const float* lse_in;
   float* ctx_out; float* lse_out; float* dqkv; float* dsum;
-  const float* src_mask; const uint8_t* key_pad;
+  const float* src_mask; const uint8_t* key_pad; int skip_pad;
   int T, B, H;
   float scale;
   uint32_t keep_threshold; float keep_scale; uint64_t seed; int dropout;
@@ -131,6 +133,27 @@ __device__ __forceinline__ float mask_of(const AttnParams& p, int b, int q, int 
   return (p.src_mask && q < p.T) ? p.src_mask[(int64_t)q * p.T + k] : 0.f;
 }
 
+// Key tiles of utterance b that hold at least one key which is not padding (every wave computes it for itself: T bytes).  The
+// tiles behind the last valid key contribute exactly nothing -- every probability is 0 -- and a minibatch of utterances of
+// different lengths is mostly such tiles for its short ones (the bench minibatch, 146 / 539 / 569 / 159 frames: 45 of 72
+// (utterance, key tile) pairs are valid): the forward and dQ loops end there, a dK / dV workgroup of such a tile stores zeros.
+// PK2_ATTN_SKIP_PAD=0 (AttnParams::skip_pad) walks every tile as rounds 2-6a did.
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int valid_key_tiles(const AttnParams& p, int b) {
+  const int all = (p.T + kAT - 1) / kAT;
+  if (!p.key_pad || !p.skip_pad) return all;
+  const uint8_t* kp = p.key_pad + (int64_t)b * p.T;
+  int last = -1;
+  for (int k = threadIdx.x & 63; k < p.T; k += 64)
+    if (!kp[k]) last = k;
+  last = __builtin_amdgcn_readfirstlane(wave_max_i(last));
+  return min(all, (last + kAT) / kAT);
+}
+
 // The 32 floats of dims {4 hi + (r&3) + 8 (r>>2)} (+32) of query/key row `row` held by a lane in the transposed
 // accumulators acc0 / acc1 -> out[row][...] (8 float4 stores), scaled.
 __device__ __forceinline__ void store_t(float* out_row, int hi, const f32x16& acc0, const f32x16& acc1, float s) {
@@ -169,7 +192,7 @@ __global__ void __launch_bounds__(64 * kAWaves, 2) attn_fwd_kernel(AttnParams p)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   const int q = q0 + qi;
-  const int nkt = (T + kAT - 1) / kAT;
+  const int nkt = valid_key_tiles(p, b);
   TileRegs kr, vr;
   if (w < nkt) { fetch_tile(K, rs, w * kAT, T, kr); fetch_tile(V, rs, w * kAT, T, vr); }
   for (int kt = w; kt < nkt; kt += kAWaves) {
@@ -279,7 +302,7 @@ __global__ void __launch_bounds__(64 * kAWaves, 2) attn_bwd_dq_kernel(AttnParams
   f32x16 g0, g1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
-  const int nkt = (T + kAT - 1) / kAT;
+  const int nkt = valid_key_tiles(p, b);
   TileRegs kr, vr;
   if (w < nkt) { fetch_tile(K, rs, w * kAT, T, kr); fetch_tile(V, rs, w * kAT, T, vr); }
   for (int kt = w; kt < nkt; kt += kAWaves) {
@@ -344,7 +367,7 @@ __global__ void __launch_bounds__(64 * kAWaves) attn_bwd_dkv_kernel(AttnParams p
   f32x16 gk0, gk1, gv0, gv1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { gk0[r] = 0.f; gk1[r] = 0.f; gv0[r] = 0.f; gv1[r] = 0.f; }
-  const int nqt = (T + kAT - 1) / kAT;
+  const int nqt = blockIdx.x < valid_key_tiles(p, b) ? (T + kAT - 1) / kAT : 0;      // (a tile of padded keys: dK = dV = 0, stored below)
   // (the key side holds 64 registers here, the prefetched tiles 64 more: one workgroup per CU.  Measured: 135 us per layer
   // against 195 us without the prefetch at two workgroups per CU)
   TileRegs qr, dr;
@@ -409,6 +432,8 @@ static int attn_fill(AttnParams* p, int32_t T, int32_t B, int32_t H, int32_t hea
   PK2_REQUIRE(head_dim == kAD, "attention: the fused kernel serves head size %d (got %d)", kAD, head_dim);
   PK2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention: bad dropout");
   p->T = T; p->B = B; p->H = H; p->scale = scale; p->src_mask = src_mask; p->key_pad = key_pad;
+  static const int skip_pad = [] { const char* e = getenv("PK2_ATTN_SKIP_PAD"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  p->skip_pad = skip_pad;
   const double keep = 1.0 - (double)dropout_p;
   p->dropout = dropout_p > 0.f;
   p->keep_threshold = (uint32_t)std::min<double>(4294967295.0, keep * 4294967296.0);
