@@ -94,6 +94,16 @@ __device__ __forceinline__ void put_tile(const TileRegs& t, float* tile) {
     o[0] = t.v[it].x; o[1] = t.v[it].y; o[2] = t.v[it].z; o[3] = t.v[it].w;
   }
 }
+// Every element of the tile is (+-) zero: a tile of output gradients of frames no loss term reaches (padded frames more than a
+// few frames behind an utterance's end -- the convolutions carry gradient one frame further per layer) multiplies into exact
+// zeros in the backward kernels, so they leave it out (PK2_ATTN_SKIP_PAD=0 keeps it in).
+__device__ __forceinline__ bool tile_is_zero(const TileRegs& t) {
+  unsigned any = 0u;
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+    any |= (__float_as_uint(t.v[it].x) | __float_as_uint(t.v[it].y) | __float_as_uint(t.v[it].z) | __float_as_uint(t.v[it].w)) << 1;
+  return __ballot(any != 0u) == 0ull;
+}
 // "row operand" of a staged tile: lane (row = lane % 32, hi = lane / 32) -> tile[row][32 hi + i], i < 32
 __device__ __forceinline__ void load_rows(const float* tile, float (&r)[32]) {
   const int lane = threadIdx.x & 63;
@@ -145,7 +155,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 __device__ __forceinline__ int valid_key_tiles(const AttnParams& p, int b) {
   const int all = (p.T + kAT - 1) / kAT;
-  if (!p.key_pad || !p.skip_pad) return all;
+  if (!p.key_pad || !(p.skip_pad & 1)) return all;
   const uint8_t* kp = p.key_pad + (int64_t)b * p.T;
   int last = -1;
   for (int k = threadIdx.x & 63; k < p.T; k += 64)
@@ -283,6 +293,22 @@ __global__ void __launch_bounds__(64 * kAWaves, 2) attn_bwd_dq_kernel(AttnParams
   load_rows(Ks, qreg);
   load_rows(Vs, doreg);
   wave_lds_sync();
+  if (p.skip_pad & 2) {      // dO of this query tile is all zero (every wave holds the same tile): D = 0, dQ = 0
+    unsigned any = 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) any |= __float_as_uint(doreg[i]) << 1;
+    if (__ballot(any != 0u) == 0ull) {
+      const int q = q0 + qi;
+      if (w == 0 && q < T) {
+        if (hi == 0) p.dsum[(int64_t)z * T + q] = 0.f;
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        store_t(p.dqkv + ((int64_t)q * p.B + b) * 3 * C + h * kAD, hi, zero, zero, 1.0f);
+      }
+      return;
+    }
+  }
   stage_tile(O, rc, q0, T, Ks);
   wave_lds_sync();
   float dsum = 0.f;
@@ -374,9 +400,10 @@ __global__ void __launch_bounds__(64 * kAWaves) attn_bwd_dkv_kernel(AttnParams p
   if (w < nqt) { fetch_tile(Q, rs, w * kAT, T, qr); fetch_tile(dO, rc, w * kAT, T, dr); }
   for (int qt = w; qt < nqt; qt += kAWaves) {
     const int q0 = qt * kAT;
-    put_tile(qr, Qs);
-    put_tile(dr, Ds);
+    const bool dz = (p.skip_pad & 2) && tile_is_zero(dr);              // dO = 0 (and with it D = 0): dV += 0, dS = 0
+    if (!dz) { put_tile(qr, Qs); put_tile(dr, Ds); }
     if (qt + kAWaves < nqt) { fetch_tile(Q, rs, q0 + kAWaves * kAT, T, qr); fetch_tile(dO, rc, q0 + kAWaves * kAT, T, dr); }
+    if (dz) continue;
     if (lane < kAT) {
       const int q = q0 + lane;
       qstat[w][0][lane] = q < T ? p.lse_in[(int64_t)z * T + q] : -INFINITY;
@@ -432,7 +459,8 @@ static int attn_fill(AttnParams* p, int32_t T, int32_t B, int32_t H, int32_t hea
   PK2_REQUIRE(head_dim == kAD, "attention: the fused kernel serves head size %d (got %d)", kAD, head_dim);
   PK2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention: bad dropout");
   p->T = T; p->B = B; p->H = H; p->scale = scale; p->src_mask = src_mask; p->key_pad = key_pad;
-  static const int skip_pad = [] { const char* e = getenv("PK2_ATTN_SKIP_PAD"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  // bit 0: loops end at the last valid key tile; bit 1: the backward kernels leave all-zero dO tiles out (default: both)
+  static const int skip_pad = [] { const char* e = getenv("PK2_ATTN_SKIP_PAD"); return e ? (atoi(e) & 3) : 3; }();
   p->skip_pad = skip_pad;
   const double keep = 1.0 - (double)dropout_p;
   p->dropout = dropout_p > 0.f;

@@ -431,3 +431,52 @@ def test_convolution_as_one_product_against_three(monkeypatch):
     for n in g0:       # (Frobenius norm: an activation within rounding of zero may flip its ReLU mask between the two forms)
         e = (g1[n] - g0[n]).norm().item()
         assert e < 5e-3 * max(1e-6, g0[n].norm().item()), (n, e)
+
+
+_ATTN_SKIP_SNIPPET = r"""
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from pykaldi2_amd import _lib
+L = _lib.lib(); sp = _lib.stream_ptr()
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+T, B, H, d = 200, 4, 2, 64
+C = H * d
+g = torch.Generator(device="cuda").manual_seed(7)
+qkv = torch.randn(T, B, 3 * C, device="cuda", generator=g)
+lens = [200, 33, 1, 150]
+kpm = torch.zeros(B, T, dtype=torch.uint8, device="cuda")
+for b, n in enumerate(lens):
+    kpm[b, n:] = 1
+kpm[3, 40:100] = 1                                 # padding with a hole behind it
+dctx = torch.randn(T, B, C, device="cuda", generator=g)
+for b, n in enumerate(lens):
+    dctx[min(T, n + 5):, b] = 0.0                  # no loss term reaches frames far behind an utterance's end
+ctx = torch.empty(T, B, C, device="cuda"); lse = torch.empty(B * H, T, device="cuda")
+_lib.check(L.pk2_attention_fwd(p(qkv), T, B, H, d, 0.125, None, p(kpm), 0.1, 99, p(ctx), p(lse), sp))
+dqkv = torch.full((T, B, 3 * C), float("nan"), device="cuda"); dsum = torch.empty(B * H, T, device="cuda")
+_lib.check(L.pk2_attention_bwd(p(qkv), p(ctx), p(dctx), p(lse), T, B, H, d, 0.125, None, p(kpm), 0.1, 99, p(dqkv), p(dsum), sp))
+torch.cuda.synchronize()
+np.savez(sys.argv[1], ctx=ctx.cpu().numpy(), lse=lse.cpu().numpy(), dqkv=dqkv.cpu().numpy())
+"""
+
+
+def test_attention_padding_shortcuts_change_no_bit(tmp_path):
+    """PK2_ATTN_SKIP_PAD (read once per process, hence two child processes): loops that end at the last valid key tile and
+    backward kernels that leave all-zero output-gradient tiles out, against kernels that walk everything -- ctx, lse and
+    dqkv equal bit for bit (ragged lengths, a one-key utterance, padding with a hole, dropout on the probabilities)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("0", "3"):
+        out = str(tmp_path / ("attn_%s.npz" % mode))
+        env = dict(os.environ, PK2_ATTN_SKIP_PAD=mode)
+        r = subprocess.run([sys.executable, "-c", _ATTN_SKIP_SNIPPET % root, out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    for k in ("ctx", "lse", "dqkv"):
+        a, b = outs[0][k], outs[1][k]
+        assert np.isfinite(b[np.isfinite(a)]).all()
+        assert np.array_equal(a, b, equal_nan=True), k
+    assert np.isfinite(outs[1]["dqkv"]).all()       # every element written
